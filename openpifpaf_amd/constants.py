@@ -1,0 +1,36 @@
+"""COCO person keypoint constants (values only).
+
+The numbers are the dataset definition the reference ships in
+``src/openpifpaf/plugins/coco/constants.py:4-8,23-41,44-62``; they are data, not
+code, and have to be identical for a drop-in decoder.
+"""
+import numpy as np
+
+COCO_KEYPOINTS = [
+    'nose', 'left_eye', 'right_eye', 'left_ear', 'right_ear',
+    'left_shoulder', 'right_shoulder', 'left_elbow', 'right_elbow',
+    'left_wrist', 'right_wrist', 'left_hip', 'right_hip',
+    'left_knee', 'right_knee', 'left_ankle', 'right_ankle',
+]
+
+# 1-based joint pairs, in CAF field order
+COCO_PERSON_SKELETON = [
+    (16, 14), (14, 12), (17, 15), (15, 13), (12, 13), (6, 12), (7, 13),
+    (6, 7), (6, 8), (7, 9), (8, 10), (9, 11), (2, 3), (1, 2), (1, 3),
+    (2, 4), (3, 5), (4, 6), (5, 7),
+]
+
+COCO_PERSON_SIGMAS = [
+    0.026, 0.025, 0.025, 0.035, 0.035, 0.079, 0.079, 0.072, 0.072,
+    0.062, 0.062, 0.107, 0.107, 0.087, 0.087, 0.089, 0.089,
+]
+
+COCO_PERSON_SCORE_WEIGHTS = [3.0] * 3 + [1.0] * (len(COCO_KEYPOINTS) - 3)
+
+# x, y (y up) in "pose units"; a standing person is about 10 units tall
+COCO_UPRIGHT_POSE = np.array([
+    [0.0, 9.3], [-0.35, 9.7], [0.35, 9.7], [-0.7, 9.5], [0.7, 9.5],
+    [-1.4, 8.0], [1.4, 8.0], [-1.75, 6.0], [1.75, 6.2], [-1.75, 4.0],
+    [1.75, 4.2], [-1.26, 4.0], [1.26, 4.0], [-1.4, 2.0], [1.4, 2.1],
+    [-1.4, 0.0], [1.4, 0.1],
+], dtype=np.float64)

@@ -1,0 +1,158 @@
+"""Seeded "COCO-shaped" composite-field synthesiser.
+
+Random-initialised networks emit structureless fields (every cell active), and
+there are no checkpoints offline, so decode parity and throughput are measured
+on synthetic CIF/CAF tensors that have the statistics of a trained network's
+output: a few people per image, a confidence blob per keypoint and per bone,
+regressions that point at the true joints with a little noise.
+
+Layout follows CompositeField4 (reference ``network/heads.py:290,360-378``):
+CIF  ``[F, 5, H, W]``: 0 unused, 1 confidence, 2 x, 3 y (absolute, field units), 4 scale
+CAF  ``[A, 8, H, W]``: 0 unused, 1 confidence, 2..3 x1 y1, 4..5 x2 y2, 6 s1, 7 s2
+"""
+import numpy as np
+
+from . import constants
+
+
+def _blob(conf_plane, targets, cx, cy, radius, peak, sigma, rng):
+    """Paint one confidence blob; returns the (j, i) cells it touched."""
+    H, W = conf_plane.shape
+    i0, i1 = max(0, int(np.floor(cx - radius))), min(W - 1, int(np.ceil(cx + radius)))
+    j0, j1 = max(0, int(np.floor(cy - radius))), min(H - 1, int(np.ceil(cy + radius)))
+    if i1 < i0 or j1 < j0:
+        return np.zeros((0,), np.int64), np.zeros((0,), np.int64)
+    jj, ii = np.meshgrid(np.arange(j0, j1 + 1), np.arange(i0, i1 + 1), indexing='ij')
+    d2 = (ii - cx) ** 2 + (jj - cy) ** 2
+    inside = d2 <= radius * radius
+    jj, ii, d2 = jj[inside], ii[inside], d2[inside]
+    c = peak * np.exp(-d2 / (2.0 * sigma * sigma))
+    c = c * (1.0 - 0.02 * rng.random(c.shape))  # break exact ties
+    better = c > conf_plane[jj, ii]
+    jj, ii, c = jj[better], ii[better], c[better]
+    conf_plane[jj, ii] = c
+    return jj, ii
+
+
+def synth_fields(seed, n_people, *, height=81, width=81,
+                 pose=None, skeleton=None, noise=0.05):
+    """Generate one image's (cif, caf) float32 field tensors.
+
+    :param seed: numpy ``default_rng`` seed, fully determines the output
+    :param n_people: number of synthetic people
+    :param pose: ``[K, 2]`` pose template (x right, y up), default COCO upright
+    :param skeleton: 1-based bone list, default COCO person skeleton
+    """
+    rng = np.random.default_rng(seed)
+    if pose is None:
+        pose = constants.COCO_UPRIGHT_POSE
+    if skeleton is None:
+        skeleton = constants.COCO_PERSON_SKELETON
+    pose = np.asarray(pose, dtype=np.float64)[:, :2]
+    K, A = len(pose), len(skeleton)
+    H, W = height, width
+
+    jj, ii = np.meshgrid(np.arange(H, dtype=np.float64),
+                         np.arange(W, dtype=np.float64), indexing='ij')
+
+    cif = np.empty((K, 5, H, W), dtype=np.float64)
+    cif[:, 0] = rng.normal(0.0, 1.0, (K, H, W))
+    cif[:, 1] = rng.uniform(0.0, 0.05, (K, H, W))
+    cif[:, 2] = ii[None] + rng.normal(0.0, 1.0, (K, H, W))
+    cif[:, 3] = jj[None] + rng.normal(0.0, 1.0, (K, H, W))
+    cif[:, 4] = rng.uniform(0.1, 1.0, (K, H, W))
+
+    caf = np.empty((A, 8, H, W), dtype=np.float64)
+    caf[:, 0] = rng.normal(0.0, 1.0, (A, H, W))
+    caf[:, 1] = rng.uniform(0.0, 0.05, (A, H, W))
+    caf[:, 2] = ii[None] + rng.normal(0.0, 1.0, (A, H, W))
+    caf[:, 3] = jj[None] + rng.normal(0.0, 1.0, (A, H, W))
+    caf[:, 4] = ii[None] + rng.normal(0.0, 1.0, (A, H, W))
+    caf[:, 5] = jj[None] + rng.normal(0.0, 1.0, (A, H, W))
+    caf[:, 6] = rng.uniform(0.1, 1.0, (A, H, W))
+    caf[:, 7] = rng.uniform(0.1, 1.0, (A, H, W))
+
+    # normalise the pose template: origin at its centre, y pointing down
+    p = pose.copy()
+    p[:, 1] = -p[:, 1]
+    p -= 0.5 * (p.min(axis=0) + p.max(axis=0))
+    extent = (p.max(axis=0) - p.min(axis=0)).max()
+
+    for _ in range(n_people):
+        # person height between ~25% and ~75% of the field
+        size = rng.uniform(0.25, 0.75) * min(H, W)
+        unit = size / extent                      # field units per pose unit
+        half = 0.5 * unit * (p.max(axis=0) - p.min(axis=0))
+        cx = rng.uniform(half[0] + 1.0, max(half[0] + 1.5, W - 2.0 - half[0]))
+        cy = rng.uniform(half[1] + 1.0, max(half[1] + 1.5, H - 2.0 - half[1]))
+        joints = p * unit + np.array([cx, cy])
+        joints += rng.normal(0.0, 0.02 * unit, joints.shape)   # per-person shape jitter
+        s = max(0.5, 0.3 * unit)                  # joint scale in field units
+
+        for k in range(K):
+            x, y = joints[k]
+            bj, bi = _blob(cif[k, 1], None, x, y, 1.5 + 0.5 * s, 0.9, 0.6 + 0.5 * s, rng)
+            n = len(bj)
+            cif[k, 2, bj, bi] = x + rng.normal(0.0, noise, n)
+            cif[k, 3, bj, bi] = y + rng.normal(0.0, noise, n)
+            cif[k, 4, bj, bi] = s * (1.0 + rng.normal(0.0, 0.03, n))
+
+        for a, (j1, j2) in enumerate(skeleton):
+            x1, y1 = joints[j1 - 1]
+            x2, y2 = joints[j2 - 1]
+            for t in (0.0, 0.5, 1.0):
+                bx, by = x1 + t * (x2 - x1), y1 + t * (y2 - y1)
+                bj, bi = _blob(caf[a, 1], None, bx, by, 1.5 + 0.3 * s, 0.85, 0.8 + 0.4 * s, rng)
+                n = len(bj)
+                caf[a, 2, bj, bi] = x1 + rng.normal(0.0, noise, n)
+                caf[a, 3, bj, bi] = y1 + rng.normal(0.0, noise, n)
+                caf[a, 4, bj, bi] = x2 + rng.normal(0.0, noise, n)
+                caf[a, 5, bj, bi] = y2 + rng.normal(0.0, noise, n)
+                caf[a, 6, bj, bi] = s * (1.0 + rng.normal(0.0, 0.03, n))
+                caf[a, 7, bj, bi] = s * (1.0 + rng.normal(0.0, 0.03, n))
+
+    return cif.astype(np.float32), caf.astype(np.float32)
+
+
+PEOPLE_CYCLE = (1, 5, 10, 20, 3, 8, 15, 2)
+
+
+def synth_batch(batch, *, seed0=0, height=81, width=81, people=None,
+                pose=None, skeleton=None):
+    """A batch of images: image ``b`` uses seed ``seed0 + b`` and
+    ``people[b % len(people)]`` synthetic persons."""
+    if people is None:
+        people = PEOPLE_CYCLE
+    if isinstance(people, int):
+        people = (people,)
+    cifs, cafs = [], []
+    for b in range(batch):
+        cif, caf = synth_fields(seed0 + b, people[b % len(people)],
+                                height=height, width=width, pose=pose, skeleton=skeleton)
+        cifs.append(cif)
+        cafs.append(caf)
+    return np.stack(cifs), np.stack(cafs)
+
+
+def adversarial_fields(seed, *, n_keypoints=17, n_bones=19, height=81, width=81):
+    """The structureless all-active case a random-initialised head produces
+    (sigmoid ~ 0.5 everywhere): every cell passes every threshold."""
+    rng = np.random.default_rng(seed)
+    H, W = height, width
+    jj, ii = np.meshgrid(np.arange(H, dtype=np.float64),
+                         np.arange(W, dtype=np.float64), indexing='ij')
+    cif = np.empty((n_keypoints, 5, H, W))
+    cif[:, 0] = rng.normal(0, 1, (n_keypoints, H, W))
+    cif[:, 1] = 1.0 / (1.0 + np.exp(-rng.normal(0, 1, (n_keypoints, H, W))))
+    cif[:, 2] = ii[None] + rng.normal(0, 1, (n_keypoints, H, W))
+    cif[:, 3] = jj[None] + rng.normal(0, 1, (n_keypoints, H, W))
+    cif[:, 4] = np.log1p(np.exp(rng.normal(0, 1, (n_keypoints, H, W))))
+    caf = np.empty((n_bones, 8, H, W))
+    caf[:, 0] = rng.normal(0, 1, (n_bones, H, W))
+    caf[:, 1] = 1.0 / (1.0 + np.exp(-rng.normal(0, 1, (n_bones, H, W))))
+    for c in (2, 4):
+        caf[:, c] = ii[None] + rng.normal(0, 1, (n_bones, H, W))
+        caf[:, c + 1] = jj[None] + rng.normal(0, 1, (n_bones, H, W))
+    caf[:, 6] = np.log1p(np.exp(rng.normal(0, 1, (n_bones, H, W))))
+    caf[:, 7] = np.log1p(np.exp(rng.normal(0, 1, (n_bones, H, W))))
+    return cif.astype(np.float32), caf.astype(np.float32)
