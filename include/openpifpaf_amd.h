@@ -1,0 +1,184 @@
+/* openpifpaf_amd -- C ABI of the MI355X-native CifCaf decode path.
+ *
+ * This header is the drop-in boundary.  Every entry point replaces one piece
+ * of the reference's native decoder interface, the TorchScript registrations
+ * in /root/reference/src/openpifpaf/csrc/src/module.cpp:19-118 (cited per
+ * function below as "ref: module.cpp:<line>").  Signatures are plain C: raw
+ * pointers, sizes and a HIP stream passed as void*.  No torch types.
+ *
+ * Conventions
+ *  - "dev" pointers are HIP device pointers (MI355X HBM); "host" pointers are
+ *    ordinary host memory.  All tensors are dense, row-major, float32 unless
+ *    stated otherwise, and batched: the leading dimension is the image.
+ *  - Field layouts are the reference's CompositeField4 layouts
+ *    (ref: network/heads.py:290,360-378):
+ *      CIF [B, F, 5, H, W]  comps: 0 unused, 1 conf, 2 x, 3 y, 4 scale
+ *      CAF [B, A, 8, H, W]  comps: 0 unused, 1 conf, 2 x1, 3 y1, 4 x2, 5 y2, 6 s1, 7 s2
+ *  - Work is enqueued on `stream` and NOT synchronised; results are valid once
+ *    the stream reaches that point.  No entry point allocates device memory:
+ *    the caller owns the workspace (size from opa_cifcaf_workspace_bytes).
+ *  - Return value: OPA_OK or an error code; opa_last_error() gives the text.
+ *  - Semantics are those of a FRESH reference decoder instance per image
+ *    (CifHr revision 1.0): see DESIGN.md "revision".
+ */
+#ifndef OPENPIFPAF_AMD_H_
+#define OPENPIFPAF_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPA_OK 0
+#define OPA_ERR_INVALID_ARGUMENT 1   /* bad shape / null pointer / bad handle      */
+#define OPA_ERR_HIP 2                /* a HIP runtime call or kernel launch failed  */
+#define OPA_ERR_UNSUPPORTED 3        /* option the HIP path does not implement      */
+#define OPA_ERR_WORKSPACE 4          /* workspace too small                         */
+#define OPA_ERR_NO_DEVICE 5          /* no gfx950 device visible                    */
+
+/* The reference's process-global tunables (its C++ static members), one field
+ * per STATIC_GETSET line of module.cpp:26-32,76-116 plus the constructor
+ * constants of cifcaf.cpp:153 / cifcaf.hpp:103.  Defaults in comments. */
+typedef struct opa_params {
+    double cif_threshold;            /* CifHr::threshold               0.3     cif_hr.cpp:14        */
+    int64_t cifhr_neighbors;         /* CifHr::neighbors               16      cif_hr.cpp:13        */
+    double seed_threshold;           /* CifSeeds::threshold            0.2     cif_seeds.cpp:11     */
+    double caf_threshold;            /* CafScored::default_score_th    0.3     caf_scored.cpp:11    */
+    double cif_floor;                /* CafScored cif_floor            0.1     cifcaf.cpp:153       */
+    double keypoint_threshold;       /* CifCaf::keypoint_threshold     0.15    cifcaf.cpp:20        */
+    double keypoint_threshold_rel;   /* CifCaf::keypoint_threshold_rel 0.5     cifcaf.cpp:21        */
+    double nms_suppression;          /* NMSKeypoints::suppression      1e-5    nms_keypoints.cpp:12 */
+    double nms_instance_threshold;   /* NMSKeypoints::instance_threshold 0.15  nms_keypoints.cpp:13 */
+    double nms_keypoint_threshold;   /* NMSKeypoints::keypoint_threshold 0.15  nms_keypoints.cpp:14 */
+    double force_complete_caf_th;    /* CifCaf::force_complete_caf_th  0.001   cifcaf.cpp:24        */
+    double occupancy_reduction;      /* Occupancy(reduction, .)        2.0     cifcaf.hpp:103       */
+    double occupancy_min_scale;      /* Occupancy(., min_scale)        4.0     cifcaf.hpp:103       */
+    int32_t greedy;                  /* CifCaf::greedy                 0       cifcaf.cpp:19        */
+    int32_t reverse_match;           /* CifCaf::reverse_match          1       cifcaf.cpp:22        */
+    int32_t force_complete;          /* CifCaf::force_complete         0       cifcaf.cpp:23        */
+    int32_t block_joints;            /* CifCaf::block_joints           0       cifcaf.cpp:18 (no-op in the reference) */
+    int32_t ablation_cifseeds_nms;        /* CifSeeds::ablation_nms          0  cif_seeds.cpp:13  */
+    int32_t ablation_cifseeds_no_rescore; /* CifSeeds::ablation_no_rescore   0  cif_seeds.cpp:14  */
+    int32_t ablation_caf_no_rescore;      /* CafScored::ablation_no_rescore  0  caf_scored.cpp:12 */
+    int32_t ablation_cifhr_skip;          /* CifHr::ablation_skip            0  cif_hr.cpp:15     */
+} opa_params;
+
+/* Shapes of one batched decode call. */
+typedef struct opa_shape {
+    int32_t batch;            /* B images                                           */
+    int32_t n_cif;            /* F = number of CIF fields = number of keypoints K   */
+    int32_t n_caf;            /* A = number of CAF fields = number of bones         */
+    int32_t cif_h, cif_w;     /* CIF field height/width                             */
+    int32_t caf_h, caf_w;     /* CAF field height/width                             */
+    int32_t cif_stride;       /* pixels per CIF cell (meta.stride)                  */
+    int32_t caf_stride;       /* pixels per CAF cell                                */
+    int32_t max_annotations;  /* capacity of the per-image annotation output        */
+} opa_shape;
+
+/* ---- library ------------------------------------------------------------ */
+const char* opa_version(void);
+const char* opa_last_error(void);            /* thread-local, never NULL            */
+int opa_device_count(void);                  /* number of visible gfx950 devices    */
+
+/* ref: module.cpp:19-21  torch.ops.openpifpaf.set_quiet(bool) */
+void opa_set_quiet(int quiet);
+
+/* The reference keeps its tunables in process-global statics that are set
+ * before decoders are built (ref: decoder/factory.py:52-82, decoder/cifcaf.py:175-211).
+ * opa_get_params/opa_set_params are that global; every call also accepts an
+ * explicit opa_params* (NULL = use the global). */
+void opa_default_params(opa_params* out);
+void opa_get_params(opa_params* out);
+int opa_set_params(const opa_params* in);
+
+/* ---- CifCaf decoder object ---------------------------------------------- */
+/* ref: module.cpp:25,34  torch.classes.openpifpaf_decoder.CifCaf(n_keypoints, skeleton)
+ * skeleton_host: int64 [n_bones, 2], 0-based joint indices, CAF field order
+ * (ref: decoder/cifcaf.py:119-122).  The handle owns a small device copy of
+ * the skeleton and its adjacency; it holds no per-call state, so one handle
+ * may be used from several streams. */
+typedef struct opa_cifcaf opa_cifcaf;
+int opa_cifcaf_create(opa_cifcaf** out, int32_t n_keypoints,
+                      const int64_t* skeleton_host, int32_t n_bones);
+void opa_cifcaf_destroy(opa_cifcaf* dec);
+/* ref: module.cpp:41-53 (pickle state = (n_keypoints, skeleton)) */
+int opa_cifcaf_get_state(const opa_cifcaf* dec, int32_t* n_keypoints,
+                         int64_t* skeleton_host /* [n_bones,2] or NULL */, int32_t* n_bones);
+
+/* Bytes of device workspace opa_cifcaf_decode needs for `shape`
+ * (0 and an error text if the shape is invalid). */
+size_t opa_cifcaf_workspace_bytes(const opa_shape* shape);
+
+/* ref: module.cpp:35-36  CifCaf.call / CifCaf.call_with_initial_annotations,
+ * i.e. cifcaf.cpp:116-262, batched over B images and reading the field
+ * tensors where the network wrote them (device memory; the reference
+ * hard-requires CPU tensors, cifcaf.cpp:137-138).
+ *
+ *  cif_dev  [B,F,5,H,W], caf_dev [B,A,8,H,W]
+ *  initial_dev      optional [B, n_initial, K, 4] (v,x,y,s) or NULL
+ *  initial_ids_dev  optional int64 [B, n_initial] or NULL
+ *  out_dev          [B, max_annotations, K, 4] (v,x,y,s)   (ref: cifcaf.cpp:246-258)
+ *  out_ids_dev      int64 [B, max_annotations]             (ref: cifcaf.cpp:259)
+ *  out_count_dev    int32 [B]  number of annotations of each image; a value
+ *                   > max_annotations means the capacity overflowed and only the
+ *                   first max_annotations (by score) were written.
+ */
+int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_params* params,
+                      const float* cif_dev, const float* caf_dev,
+                      const float* initial_dev, const int64_t* initial_ids_dev, int32_t n_initial,
+                      void* workspace_dev, size_t workspace_bytes,
+                      float* out_dev, int64_t* out_ids_dev, int32_t* out_count_dev,
+                      void* stream);
+
+/* ref: module.cpp:37-39  CifCaf.get_cifhr() -> (Tensor[F,Hhr,Whr], revision).
+ * Describes where, inside the workspace of the LAST opa_cifcaf_decode call with
+ * this shape, the high-resolution map lives: image b, field f, row y, column x
+ * is at  ((float*)workspace)[offset_floats + ((b*F + f)*rows + y)*pitch + x].
+ * Cell content is the reference buffer's content at revision 1.0:
+ * 0.0 = never touched, otherwise 1.0 + accumulated confidence. */
+int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
+                          int32_t* rows, int32_t* cols, int32_t* pitch, double* revision);
+
+/* ---- stage-level entry points (openpifpaf_decoder_utils) ---------------- */
+/* ref: module.cpp:75-84  CifHr.reset + CifHr.accumulate (cif_hr.cpp:28-121).
+ *  cifhr_dev [B, F, rows, pitch] with rows=(H-1)*stride+1, pitch from opa_cifhr_pitch();
+ *  scratch_dev: opa_cifhr_scratch_bytes() bytes. */
+int32_t opa_cifhr_pitch(int32_t cif_w, int32_t stride);
+size_t opa_cifhr_scratch_bytes(int32_t batch, int32_t n_cif, int32_t cif_h, int32_t cif_w);
+int opa_cifhr_accumulate(const float* cif_dev, int32_t batch, int32_t n_cif, int32_t cif_h, int32_t cif_w,
+                         int32_t stride, double min_scale, double factor, const opa_params* params,
+                         float* cifhr_dev, void* scratch_dev, size_t scratch_bytes, void* stream);
+
+/* ref: module.cpp:86-94  CifSeeds(cifhr, revision).fill(cif, stride) + get()
+ * (cif_seeds.cpp:33-66,93-114).  Output sorted by v descending; ties by cell
+ * index ascending (the reference's std::sort leaves tie order unspecified).
+ *  seed_f_dev int32 [B, cap], seed_vxys_dev [B, cap, 4] (v,x,y,s), seed_count_dev int32 [B],
+ *  cap = F*H*W;  scratch_dev: opa_cifseeds_scratch_bytes() bytes. */
+size_t opa_cifseeds_scratch_bytes(int32_t batch, int32_t n_cif, int32_t cif_h, int32_t cif_w);
+int opa_cifseeds_fill(const float* cif_dev, int32_t batch, int32_t n_cif, int32_t cif_h, int32_t cif_w,
+                      int32_t stride, const float* cifhr_dev, const opa_params* params,
+                      int32_t* seed_f_dev, float* seed_vxys_dev, int32_t* seed_count_dev,
+                      void* scratch_dev, size_t scratch_bytes, void* stream);
+
+/* ref: module.cpp:104-111  CafScored(cifhr, revision, score_th, cif_floor).fill(caf, stride, skeleton) + get()
+ * (caf_scored.cpp:29-104).  Lists keep the reference's raster (j,i) order.
+ *  skeleton_dev int64 [A,2] 0-based (device);  score_th < 0 -> params->caf_threshold
+ *  lists_dev [B, A, 2(dir: 0 forward, 1 backward), 7, cap] planes (c,x1,y1,x2,y2,s1,s2), cap = caf_h*caf_w
+ *  counts_dev int32 [B, A, 2] */
+int opa_cafscored_fill(const float* caf_dev, int32_t batch, int32_t n_caf, int32_t caf_h, int32_t caf_w,
+                       int32_t stride, const float* cifhr_dev, int32_t n_cif, int32_t cif_h, int32_t cif_w,
+                       int32_t cif_stride, const int64_t* skeleton_dev, double score_th, double cif_floor,
+                       const opa_params* params, float* lists_dev, int32_t* counts_dev, void* stream);
+
+/* ref: module.cpp:55  torch.ops.openpifpaf_decoder.grow_connection_blend(caf[n,7], x, y, s, filter_sigmas, only_max)
+ * (cifcaf.cpp:32-113).  rows_dev: device [n,7] row list; out_host[4] = (x, y, s, v).
+ * Synchronous (copies the result back). */
+int opa_grow_connection_blend(const float* rows_dev, int32_t n, double x, double y, double s,
+                              double filter_sigmas, int32_t only_max, double* out_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* OPENPIFPAF_AMD_H_ */

@@ -1,0 +1,94 @@
+// CafScored: association-field thresholding, rescoring and list building on gfx950.
+//
+// Replaces reference CafScored::fill / get (csrc/src/caf_scored.cpp:29-104): every
+// CAF cell with confidence >= th yields a forward tuple (c,x1,y1,x2,y2,s1,s2)*stride
+// and the mirrored backward tuple; each is rescored with the CifHr value at its
+// TARGET joint, c * (floor + (1-floor) * hr), and kept when the result is > th.
+//
+// One 256-thread workgroup per (image, CAF field) walks the 7 used component
+// planes in raster order with coalesced loads (this is the bandwidth-bound stage
+// of the decode), gathers the two CifHr values from the L2-resident map, and
+// stream-compacts survivors IN RASTER ORDER (wave ballot + cross-wave prefix in
+// LDS) into structure-of-arrays lists:
+//     lists[b][a][dir][component 0..6][cap]      counts[b][a][dir]
+// Raster order is kept because grow_connection_blend's top-2 selection breaks score
+// ties by list position (cifcaf.cpp:65-73).  SoA planes make the association
+// kernel's list scans coalesced.
+#include "common.hpp"
+
+namespace opa {
+
+__global__ __launch_bounds__(256) void cafscored_kernel(
+        const float* __restrict__ caf, int A, int HW, int stride,
+        const float* __restrict__ cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
+        const int64_t* __restrict__ skeleton, double score_th, double cif_floor, int no_rescore,
+        float* __restrict__ lists, int32_t* __restrict__ counts) {
+    __shared__ int wave_tot[4];
+    const int plane = blockIdx.x;                  // b*A + a
+    const int b = plane / A, a = plane - b * A;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* P = caf + (size_t)plane * 8 * HW;
+    const float* hr = cifhr + (size_t)b * F * hr_rows * hr_pitch;
+    float* Lf = lists + ((size_t)plane * 2 + 0) * 7 * HW;
+    float* Lb = lists + ((size_t)plane * 2 + 1) * 7 * HW;
+    const long long j1 = skeleton[2 * a + 0], j2 = skeleton[2 * a + 1];
+    const float stride_f = (float)stride;
+    int base_f = 0, base_b = 0;
+
+    for (int c0 = 0; c0 < HW; c0 += 256) {
+        const int o = c0 + tid;
+        bool keep_f = false, keep_b = false;
+        float c = 0.f, cf = 0.f, cb = 0.f, x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, s1 = 0.f, s2 = 0.f;
+        if (o < HW) {
+            c = P[1 * HW + o];
+            if (!((double)c < score_th)) {                               // caf_scored.cpp:44
+                x1 = P[2 * HW + o] * stride_f; y1 = P[3 * HW + o] * stride_f;   // :46-54
+                x2 = P[4 * HW + o] * stride_f; y2 = P[5 * HW + o] * stride_f;
+                s1 = P[6 * HW + o] * stride_f; s2 = P[7 * HW + o] * stride_f;
+                cf = c; cb = c;
+                if (!no_rescore) {                                       // :66-71
+                    const float fhr = cifhr_value(hr, F, hr_rows, hr_cols, hr_pitch, j2, x2, y2, 0.0f);
+                    const float bhr = cifhr_value(hr, F, hr_rows, hr_cols, hr_pitch, j1, x1, y1, 0.0f);
+                    cf = (float)((double)c * (cif_floor + (1.0 - cif_floor) * (double)fhr));
+                    cb = (float)((double)c * (cif_floor + (1.0 - cif_floor) * (double)bhr));
+                }
+                keep_f = (double)cf > score_th;                          // :74
+                keep_b = (double)cb > score_th;                          // :77
+            }
+        }
+        const unsigned long long mf = __ballot(keep_f), mb = __ballot(keep_b);
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        if (lane == 0) wave_tot[w] = __popcll(mf) | (__popcll(mb) << 16);
+        __syncthreads();
+        int off_f = base_f + __popcll(mf & lt), off_b = base_b + __popcll(mb & lt);
+        int tot_f = 0, tot_b = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int t = wave_tot[k];
+            if (k < w) { off_f += t & 0xffff; off_b += t >> 16; }
+            tot_f += t & 0xffff; tot_b += t >> 16;
+        }
+        if (keep_f) {
+            Lf[0 * HW + off_f] = cf; Lf[1 * HW + off_f] = x1; Lf[2 * HW + off_f] = y1;
+            Lf[3 * HW + off_f] = x2; Lf[4 * HW + off_f] = y2; Lf[5 * HW + off_f] = s1; Lf[6 * HW + off_f] = s2;
+        }
+        if (keep_b) {                                                    // mirrored tuple, :55-63
+            Lb[0 * HW + off_b] = cb; Lb[1 * HW + off_b] = x2; Lb[2 * HW + off_b] = y2;
+            Lb[3 * HW + off_b] = x1; Lb[4 * HW + off_b] = y1; Lb[5 * HW + off_b] = s2; Lb[6 * HW + off_b] = s1;
+        }
+        base_f += tot_f; base_b += tot_b;
+        __syncthreads();
+    }
+    if (tid == 0) { counts[plane * 2 + 0] = base_f; counts[plane * 2 + 1] = base_b; }
+}
+
+hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
+                            const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
+                            const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
+                            float* lists, int32_t* counts, hipStream_t st) {
+    cafscored_kernel<<<B * A, 256, 0, st>>>(caf, A, cH * cW, cstride, cifhr, F, hr_rows, hr_cols, hr_pitch,
+                                            skeleton, score_th, cif_floor, no_rescore, lists, counts);
+    return hipGetLastError();
+}
+
+}  // namespace opa

@@ -1,0 +1,402 @@
+// C ABI of the library (include/openpifpaf_amd.h): argument checking, workspace
+// layout, decoder handle, and the kernel pipeline of one batched decode.
+#include "common.hpp"
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace opa {
+
+static thread_local std::string g_error;
+static std::mutex g_params_mutex;
+static int g_quiet = 0;
+
+static opa_params default_params() {
+    opa_params p;
+    p.cif_threshold = 0.3; p.cifhr_neighbors = 16; p.seed_threshold = 0.2; p.caf_threshold = 0.3;
+    p.cif_floor = 0.1; p.keypoint_threshold = 0.15; p.keypoint_threshold_rel = 0.5;
+    p.nms_suppression = 0.00001; p.nms_instance_threshold = 0.15; p.nms_keypoint_threshold = 0.15;
+    p.force_complete_caf_th = 0.001; p.occupancy_reduction = 2.0; p.occupancy_min_scale = 4.0;
+    p.greedy = 0; p.reverse_match = 1; p.force_complete = 0; p.block_joints = 0;
+    p.ablation_cifseeds_nms = 0; p.ablation_cifseeds_no_rescore = 0;
+    p.ablation_caf_no_rescore = 0; p.ablation_cifhr_skip = 0;
+    return p;
+}
+static opa_params g_params = default_params();
+
+static int fail(int code, const std::string& msg) { g_error = msg; return code; }
+static int fail_hip(hipError_t e, const char* where) {
+    g_error = std::string(where) + ": " + hipGetErrorString(e);
+    return OPA_ERR_HIP;
+}
+
+DevParams to_dev(const opa_params& p) {
+    DevParams d;
+    d.cif_threshold = p.cif_threshold; d.seed_threshold = p.seed_threshold;
+    d.caf_threshold = p.caf_threshold; d.cif_floor = p.cif_floor;
+    d.keypoint_threshold = p.keypoint_threshold; d.keypoint_threshold_rel = p.keypoint_threshold_rel;
+    d.nms_suppression = p.nms_suppression; d.nms_instance_threshold = p.nms_instance_threshold;
+    d.nms_keypoint_threshold = p.nms_keypoint_threshold; d.force_complete_caf_th = p.force_complete_caf_th;
+    d.occupancy_reduction = p.occupancy_reduction;
+    d.occupancy_min_scale_reduced = p.occupancy_min_scale / p.occupancy_reduction;   // occupancy.hpp:29
+    d.cifhr_neighbors = p.cifhr_neighbors;
+    d.reverse_match = p.reverse_match; d.force_complete = p.force_complete; d.greedy = p.greedy;
+    d.ablation_cifseeds_nms = p.ablation_cifseeds_nms;
+    d.ablation_cifseeds_no_rescore = p.ablation_cifseeds_no_rescore;
+    d.ablation_caf_no_rescore = p.ablation_caf_no_rescore;
+    d.ablation_cifhr_skip = p.ablation_cifhr_skip;
+    return d;
+}
+
+static bool check_params(const opa_params& p, const char** why) {
+    if (!(p.occupancy_reduction > 0.0)) { *why = "occupancy_reduction must be > 0"; return false; }
+    if (p.cifhr_neighbors <= 0) { *why = "cifhr_neighbors must be > 0"; return false; }
+    return true;
+}
+
+static size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+bool make_layout(const opa_shape& s, Layout* L, const char** why) {
+    if (s.batch <= 0 || s.n_cif <= 0 || s.n_caf <= 0 || s.cif_h <= 0 || s.cif_w <= 0 || s.caf_h <= 0 ||
+        s.caf_w <= 0 || s.cif_stride <= 0 || s.caf_stride <= 0 || s.max_annotations <= 0) {
+        *why = "opa_shape: every field must be positive"; return false;
+    }
+    if (s.n_cif > 32767 || s.n_caf > 16383) { *why = "opa_shape: too many fields"; return false; }
+    if ((long long)s.n_cif * s.cif_h * s.cif_w > (1ll << 30)) { *why = "opa_shape: CIF field too large"; return false; }
+    L->B = s.batch; L->F = s.n_cif; L->A = s.n_caf; L->H = s.cif_h; L->W = s.cif_w;
+    L->cH = s.caf_h; L->cW = s.caf_w; L->stride = s.cif_stride; L->cstride = s.caf_stride;
+    L->max_ann = s.max_annotations;
+    L->hr_rows = (s.cif_h - 1) * s.cif_stride + 1;                       // cif_hr.cpp:110-112
+    L->hr_cols = (s.cif_w - 1) * s.cif_stride + 1;
+    L->hr_pitch = (L->hr_cols + kHrTileW - 1) / kHrTileW * kHrTileW;
+    // capacity for occupancy_reduction >= 1 (the reference hard-codes 2.0, cifcaf.hpp:103);
+    // the per-call geometry (occupancy.cpp:47-48) is computed in opa_cifcaf_decode
+    L->occ_h = L->hr_rows + 1;
+    L->occ_w = L->hr_cols + 1;
+    L->cif_cells = s.n_cif * s.cif_h * s.cif_w;
+    L->caf_cells = s.caf_h * s.caf_w;
+    int sc = 2; while (sc < L->cif_cells) sc <<= 1;
+    if (sc < kSortLdsKeys) sc = kSortLdsKeys;
+    L->sort_cap = sc;
+    const size_t B = s.batch;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes); return o; };
+    L->off_cifhr = take(B * L->F * L->hr_rows * (size_t)L->hr_pitch * sizeof(float));
+    L->off_act = take(B * L->F * 4 * (size_t)(L->H * L->W) * sizeof(float));
+    L->off_act_count = take(B * L->F * sizeof(int32_t));
+    L->off_seed_keys = take(B * (size_t)L->sort_cap * sizeof(unsigned long long));
+    L->off_seed_count = take(B * sizeof(int32_t));
+    L->off_seed_f = take(B * (size_t)L->cif_cells * sizeof(int32_t));
+    L->off_seed_vxys = take(B * (size_t)L->cif_cells * 4 * sizeof(float));
+    const size_t list_bytes = B * L->A * 2 * 7 * (size_t)L->caf_cells * sizeof(float);
+    L->off_lists = take(list_bytes);
+    L->off_list_counts = take(B * L->A * 2 * sizeof(int32_t));
+    L->off_lists_fc = take(list_bytes);
+    L->off_list_counts_fc = take(B * L->A * 2 * sizeof(int32_t));
+    L->off_occ = take(B * L->F * (size_t)L->occ_h * L->occ_w);
+    L->off_anns = take(B * (size_t)L->max_ann * L->F * 4 * sizeof(double));
+    L->off_ann_meta = take(B * (size_t)L->max_ann * sizeof(int64_t));
+    L->off_status = take(B * sizeof(int32_t));
+    L->total = off;
+    return true;
+}
+
+}  // namespace opa
+
+using namespace opa;
+
+struct opa_cifcaf {
+    int32_t K, A;
+    std::vector<int64_t> skeleton;     // host copy [A,2]
+    void* dev_block;                   // one allocation holding everything below
+    DevSkeleton dev;
+    int device;
+};
+
+extern "C" {
+
+const char* opa_version(void) { return "openpifpaf_amd 0.1 (gfx950)"; }
+const char* opa_last_error(void) { return g_error.c_str(); }
+
+int opa_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void opa_set_quiet(int quiet) { g_quiet = quiet; }
+
+void opa_default_params(opa_params* out) { if (out) *out = default_params(); }
+void opa_get_params(opa_params* out) {
+    std::lock_guard<std::mutex> lock(g_params_mutex);
+    if (out) *out = g_params;
+}
+int opa_set_params(const opa_params* in) {
+    if (!in) return fail(OPA_ERR_INVALID_ARGUMENT, "opa_set_params: null");
+    const char* why = nullptr;
+    if (!check_params(*in, &why)) return fail(OPA_ERR_INVALID_ARGUMENT, why);
+    std::lock_guard<std::mutex> lock(g_params_mutex);
+    g_params = *in;
+    return OPA_OK;
+}
+
+int opa_cifcaf_create(opa_cifcaf** out, int32_t n_keypoints, const int64_t* skeleton_host, int32_t n_bones) {
+    if (!out || !skeleton_host || n_keypoints <= 0 || n_bones <= 0 || n_keypoints > 32767 || n_bones > 16383)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_create: bad arguments");
+    for (int a = 0; a < 2 * n_bones; a++)
+        if (skeleton_host[a] < 0 || skeleton_host[a] >= n_keypoints)
+            return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_create: skeleton index out of range (must be 0-based)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(OPA_ERR_NO_DEVICE, "opa_cifcaf_create: no HIP device visible (this library has no CPU path)");
+    const int K = n_keypoints, A = n_bones, E = 2 * A;
+    // adjacency in bone order, exactly the visiting order of cifcaf.cpp:323-345
+    std::vector<int32_t> off(K + 1, 0), other(E), bone(E), fwd(E), first(E);
+    std::vector<std::vector<int32_t>> slots(K);
+    std::vector<int32_t> s_other, s_bone, s_fwd;
+    for (int j = 0; j < K; j++) {
+        off[j] = (int32_t)s_other.size();
+        for (int a = 0; a < A; a++) {
+            const int64_t p0 = skeleton_host[2 * a], p1 = skeleton_host[2 * a + 1];
+            if (p0 == j) { s_other.push_back((int32_t)p1); s_bone.push_back(a); s_fwd.push_back(1); }
+            else if (p1 == j) { s_other.push_back((int32_t)p0); s_bone.push_back(a); s_fwd.push_back(0); }
+        }
+    }
+    off[K] = (int32_t)s_other.size();
+    s_other.resize(E, 0); s_bone.resize(E, 0); s_fwd.resize(E, 0);
+    for (int j = 0; j < K; j++)
+        for (int t = off[j]; t < off[j + 1]; t++) {
+            int f = t;
+            for (int u = off[j]; u < t; u++) if (s_other[u] == s_other[t]) { f = u; break; }
+            first[t] = f;
+        }
+    for (int t = off[K]; t < E; t++) first[t] = t;
+
+    const size_t skel_bytes = align_up(sizeof(int64_t) * 2 * A, 256);
+    const size_t off_bytes = align_up(sizeof(int32_t) * (K + 1), 256);
+    const size_t e_bytes = align_up(sizeof(int32_t) * E, 256);
+    const size_t total = skel_bytes + off_bytes + 4 * e_bytes;
+    void* block = nullptr;
+    hipError_t e = hipMalloc(&block, total);
+    if (e != hipSuccess) return fail_hip(e, "opa_cifcaf_create: hipMalloc");
+    unsigned char* base = (unsigned char*)block;
+    std::vector<unsigned char> host(total, 0);
+    std::memcpy(host.data(), skeleton_host, sizeof(int64_t) * 2 * A);
+    std::memcpy(host.data() + skel_bytes, off.data(), sizeof(int32_t) * (K + 1));
+    std::memcpy(host.data() + skel_bytes + off_bytes + 0 * e_bytes, s_other.data(), sizeof(int32_t) * E);
+    std::memcpy(host.data() + skel_bytes + off_bytes + 1 * e_bytes, s_bone.data(), sizeof(int32_t) * E);
+    std::memcpy(host.data() + skel_bytes + off_bytes + 2 * e_bytes, s_fwd.data(), sizeof(int32_t) * E);
+    std::memcpy(host.data() + skel_bytes + off_bytes + 3 * e_bytes, first.data(), sizeof(int32_t) * E);
+    e = hipMemcpy(block, host.data(), total, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hipFree(block); return fail_hip(e, "opa_cifcaf_create: hipMemcpy"); }
+
+    opa_cifcaf* d = new opa_cifcaf();
+    d->K = K; d->A = A;
+    d->skeleton.assign(skeleton_host, skeleton_host + 2 * A);
+    d->dev_block = block;
+    d->dev.K = K; d->dev.A = A;
+    d->dev.skeleton = (const int64_t*)base;
+    d->dev.adj_off = (const int32_t*)(base + skel_bytes);
+    d->dev.adj_other = (const int32_t*)(base + skel_bytes + off_bytes + 0 * e_bytes);
+    d->dev.adj_bone = (const int32_t*)(base + skel_bytes + off_bytes + 1 * e_bytes);
+    d->dev.adj_fwd = (const int32_t*)(base + skel_bytes + off_bytes + 2 * e_bytes);
+    d->dev.adj_first = (const int32_t*)(base + skel_bytes + off_bytes + 3 * e_bytes);
+    hipGetDevice(&d->device);
+    *out = d;
+    return OPA_OK;
+}
+
+void opa_cifcaf_destroy(opa_cifcaf* dec) {
+    if (!dec) return;
+    if (dec->dev_block) hipFree(dec->dev_block);
+    delete dec;
+}
+
+int opa_cifcaf_get_state(const opa_cifcaf* dec, int32_t* n_keypoints, int64_t* skeleton_host, int32_t* n_bones) {
+    if (!dec) return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_get_state: null handle");
+    if (n_keypoints) *n_keypoints = dec->K;
+    if (n_bones) *n_bones = dec->A;
+    if (skeleton_host) std::memcpy(skeleton_host, dec->skeleton.data(), sizeof(int64_t) * 2 * dec->A);
+    return OPA_OK;
+}
+
+size_t opa_cifcaf_workspace_bytes(const opa_shape* shape) {
+    Layout L; const char* why = nullptr;
+    if (!shape || !make_layout(*shape, &L, &why)) { g_error = why ? why : "null shape"; return 0; }
+    return L.total;
+}
+
+int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats, int32_t* rows, int32_t* cols,
+                          int32_t* pitch, double* revision) {
+    Layout L; const char* why = nullptr;
+    if (!shape || !make_layout(*shape, &L, &why)) return fail(OPA_ERR_INVALID_ARGUMENT, why ? why : "null shape");
+    if (offset_floats) *offset_floats = L.off_cifhr / sizeof(float);
+    if (rows) *rows = L.hr_rows;
+    if (cols) *cols = L.hr_cols;
+    if (pitch) *pitch = L.hr_pitch;
+    if (revision) *revision = 1.0;
+    return OPA_OK;
+}
+
+int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_params* params,
+                      const float* cif_dev, const float* caf_dev,
+                      const float* initial_dev, const int64_t* initial_ids_dev, int32_t n_initial,
+                      void* workspace_dev, size_t workspace_bytes,
+                      float* out_dev, int64_t* out_ids_dev, int32_t* out_count_dev, void* stream) {
+    if (!dec || !shape || !cif_dev || !caf_dev || !workspace_dev || !out_dev || !out_ids_dev || !out_count_dev)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_decode: null argument");
+    if (n_initial < 0 || (n_initial > 0 && !initial_dev))
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_decode: initial annotations without data");
+    opa_params hp;
+    if (params) hp = *params; else opa_get_params(&hp);
+    const char* why = nullptr;
+    if (!check_params(hp, &why)) return fail(OPA_ERR_INVALID_ARGUMENT, why);
+    Layout L;
+    if (!make_layout(*shape, &L, &why)) return fail(OPA_ERR_INVALID_ARGUMENT, why);
+    if (shape->n_cif != dec->K || shape->n_caf != dec->A)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_decode: shape does not match the decoder's keypoints/skeleton");
+    if (hp.occupancy_reduction < 1.0)
+        return fail(OPA_ERR_UNSUPPORTED, "opa_cifcaf_decode: occupancy_reduction < 1 is not supported");
+    L.occ_h = (int)((double)L.hr_rows / hp.occupancy_reduction) + 1;       // occupancy.cpp:47-48
+    L.occ_w = (int)((double)L.hr_cols / hp.occupancy_reduction) + 1;
+    if (workspace_bytes < L.total) return fail(OPA_ERR_WORKSPACE, "opa_cifcaf_decode: workspace too small");
+    if (((uintptr_t)workspace_dev & 255) != 0 || ((uintptr_t)out_dev & 15) != 0)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_decode: workspace must be 256-B and out 16-B aligned");
+
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)workspace_dev;
+    const DevParams p = to_dev(hp);
+    float* cifhr = (float*)(ws + L.off_cifhr);
+    hipError_t e;
+
+    e = launch_cifhr(cif_dev, L.B, L.F, L.H, L.W, L.stride, 0.0, 1.0, p, cifhr, L.hr_rows, L.hr_pitch,
+                     (float*)(ws + L.off_act), (int32_t*)(ws + L.off_act_count), st);       // cifcaf.cpp:140-141
+    if (e != hipSuccess) return fail_hip(e, "cifhr");
+    e = launch_cifseeds(cif_dev, L.B, L.F, L.H, L.W, L.stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
+                        (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap,
+                        (int32_t*)(ws + L.off_seed_count), (int32_t*)(ws + L.off_seed_f),
+                        (float*)(ws + L.off_seed_vxys), st);                                 // :144-146
+    if (e != hipSuccess) return fail_hip(e, "cifseeds");
+    e = launch_cafscored(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols, L.hr_pitch,
+                         dec->dev.skeleton, p.caf_threshold, p.cif_floor, p.ablation_caf_no_rescore,
+                         (float*)(ws + L.off_lists), (int32_t*)(ws + L.off_list_counts), st);   // :153-161
+    if (e != hipSuccess) return fail_hip(e, "cafscored");
+    if (p.force_complete) {                                                                   // :419-420
+        e = launch_cafscored(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols,
+                             L.hr_pitch, dec->dev.skeleton, p.force_complete_caf_th, 0.1,
+                             p.ablation_caf_no_rescore, (float*)(ws + L.off_lists_fc),
+                             (int32_t*)(ws + L.off_list_counts_fc), st);
+        if (e != hipSuccess) return fail_hip(e, "cafscored(force complete)");
+    }
+    e = hipMemsetAsync(ws + L.off_occ, 0, (size_t)L.B * L.F * L.occ_h * L.occ_w, st);        // :173
+    if (e != hipSuccess) return fail_hip(e, "occupancy memset");
+
+    AssocArgs a;
+    a.B = L.B; a.K = L.F; a.A = L.A; a.max_ann = L.max_ann; a.n_initial = n_initial;
+    a.hr_rows = L.hr_rows; a.hr_cols = L.hr_cols; a.occ_h = L.occ_h; a.occ_w = L.occ_w;
+    a.seed_cap = L.cif_cells; a.list_cap = L.caf_cells;
+    a.seed_f = (const int32_t*)(ws + L.off_seed_f); a.seed_vxys = (const float*)(ws + L.off_seed_vxys);
+    a.seed_count = (const int32_t*)(ws + L.off_seed_count);
+    a.lists = (const float*)(ws + L.off_lists); a.list_counts = (const int32_t*)(ws + L.off_list_counts);
+    a.lists_fc = (const float*)(ws + L.off_lists_fc); a.list_counts_fc = (const int32_t*)(ws + L.off_list_counts_fc);
+    a.occ = ws + L.off_occ;
+    a.anns = (double*)(ws + L.off_anns); a.ann_ids = (int64_t*)(ws + L.off_ann_meta);
+    a.initial = initial_dev; a.initial_ids = initial_ids_dev;
+    a.out = out_dev; a.out_ids = out_ids_dev; a.out_count = out_count_dev;
+    a.status = (int32_t*)(ws + L.off_status);
+    e = launch_assoc(a, dec->dev, p, st);                                                     // :176-261
+    if (e != hipSuccess) return fail_hip(e, "association");
+    return OPA_OK;
+}
+
+// ---- stage-level entry points ----------------------------------------------
+int32_t opa_cifhr_pitch(int32_t cif_w, int32_t stride) {
+    const int cols = (cif_w - 1) * stride + 1;
+    return (cols + kHrTileW - 1) / kHrTileW * kHrTileW;
+}
+
+size_t opa_cifhr_scratch_bytes(int32_t batch, int32_t n_cif, int32_t cif_h, int32_t cif_w) {
+    return align_up((size_t)batch * n_cif * 4 * cif_h * cif_w * sizeof(float)) +
+           align_up((size_t)batch * n_cif * sizeof(int32_t));
+}
+
+int opa_cifhr_accumulate(const float* cif_dev, int32_t batch, int32_t n_cif, int32_t cif_h, int32_t cif_w,
+                         int32_t stride, double min_scale, double factor, const opa_params* params,
+                         float* cifhr_dev, void* scratch_dev, size_t scratch_bytes, void* stream) {
+    if (!cif_dev || !cifhr_dev || !scratch_dev || batch <= 0 || n_cif <= 0 || cif_h <= 0 || cif_w <= 0 || stride <= 0)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifhr_accumulate: bad arguments");
+    if (scratch_bytes < opa_cifhr_scratch_bytes(batch, n_cif, cif_h, cif_w))
+        return fail(OPA_ERR_WORKSPACE, "opa_cifhr_accumulate: scratch too small");
+    opa_params hp; if (params) hp = *params; else opa_get_params(&hp);
+    const DevParams p = to_dev(hp);
+    unsigned char* sc = (unsigned char*)scratch_dev;
+    const size_t act_bytes = align_up((size_t)batch * n_cif * 4 * cif_h * cif_w * sizeof(float));
+    hipError_t e = launch_cifhr(cif_dev, batch, n_cif, cif_h, cif_w, stride, min_scale, factor, p, cifhr_dev,
+                                (cif_h - 1) * stride + 1, opa_cifhr_pitch(cif_w, stride),
+                                (float*)sc, (int32_t*)(sc + act_bytes), (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "cifhr");
+    return OPA_OK;
+}
+
+static int sort_cap_for(int cells) { int sc = 2; while (sc < cells) sc <<= 1; return sc < kSortLdsKeys ? kSortLdsKeys : sc; }
+
+size_t opa_cifseeds_scratch_bytes(int32_t batch, int32_t n_cif, int32_t cif_h, int32_t cif_w) {
+    return align_up((size_t)batch * sort_cap_for(n_cif * cif_h * cif_w) * sizeof(unsigned long long));
+}
+
+int opa_cifseeds_fill(const float* cif_dev, int32_t batch, int32_t n_cif, int32_t cif_h, int32_t cif_w,
+                      int32_t stride, const float* cifhr_dev, const opa_params* params,
+                      int32_t* seed_f_dev, float* seed_vxys_dev, int32_t* seed_count_dev,
+                      void* scratch_dev, size_t scratch_bytes, void* stream) {
+    if (!cif_dev || !cifhr_dev || !seed_f_dev || !seed_vxys_dev || !seed_count_dev || !scratch_dev ||
+        batch <= 0 || n_cif <= 0 || cif_h <= 0 || cif_w <= 0 || stride <= 0)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifseeds_fill: bad arguments");
+    if (scratch_bytes < opa_cifseeds_scratch_bytes(batch, n_cif, cif_h, cif_w))
+        return fail(OPA_ERR_WORKSPACE, "opa_cifseeds_fill: scratch too small");
+    opa_params hp; if (params) hp = *params; else opa_get_params(&hp);
+    const DevParams p = to_dev(hp);
+    hipError_t e = launch_cifseeds(cif_dev, batch, n_cif, cif_h, cif_w, stride, cifhr_dev,
+                                   (cif_h - 1) * stride + 1, (cif_w - 1) * stride + 1, opa_cifhr_pitch(cif_w, stride),
+                                   p, (unsigned long long*)scratch_dev, sort_cap_for(n_cif * cif_h * cif_w),
+                                   seed_count_dev, seed_f_dev, seed_vxys_dev, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "cifseeds");
+    return OPA_OK;
+}
+
+int opa_cafscored_fill(const float* caf_dev, int32_t batch, int32_t n_caf, int32_t caf_h, int32_t caf_w,
+                       int32_t stride, const float* cifhr_dev, int32_t n_cif, int32_t cif_h, int32_t cif_w,
+                       int32_t cif_stride, const int64_t* skeleton_dev, double score_th, double cif_floor,
+                       const opa_params* params, float* lists_dev, int32_t* counts_dev, void* stream) {
+    if (!caf_dev || !cifhr_dev || !skeleton_dev || !lists_dev || !counts_dev || batch <= 0 || n_caf <= 0 ||
+        caf_h <= 0 || caf_w <= 0 || stride <= 0 || n_cif <= 0 || cif_h <= 0 || cif_w <= 0 || cif_stride <= 0)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cafscored_fill: bad arguments");
+    opa_params hp; if (params) hp = *params; else opa_get_params(&hp);
+    if (score_th < 0.0) score_th = hp.caf_threshold;                       // caf_scored.hpp:52
+    hipError_t e = launch_cafscored(caf_dev, batch, n_caf, caf_h, caf_w, stride, cifhr_dev, n_cif,
+                                    (cif_h - 1) * cif_stride + 1, (cif_w - 1) * cif_stride + 1,
+                                    opa_cifhr_pitch(cif_w, cif_stride), skeleton_dev, score_th, cif_floor,
+                                    hp.ablation_caf_no_rescore, lists_dev, counts_dev, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "cafscored");
+    return OPA_OK;
+}
+
+int opa_grow_connection_blend(const float* rows_dev, int32_t n, double x, double y, double s,
+                              double filter_sigmas, int32_t only_max, double* out_host, void* stream) {
+    if (!out_host || n < 0 || (n > 0 && !rows_dev))
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_grow_connection_blend: bad arguments");
+    // a test/debug op: it is synchronous and owns a tiny temporary (the only allocating entry point)
+    void* tmp = nullptr;
+    hipError_t e = hipMalloc(&tmp, 4 * sizeof(double) + (size_t)(n > 0 ? n : 1) * 7 * sizeof(float));
+    if (e != hipSuccess) return fail_hip(e, "opa_grow_connection_blend: hipMalloc");
+    e = launch_blend(rows_dev, n, x, y, s, filter_sigmas, only_max, (double*)tmp, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out_host, tmp, 4 * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    hipFree(tmp);
+    if (e != hipSuccess) return fail_hip(e, "opa_grow_connection_blend");
+    return OPA_OK;
+}
+
+}  // extern "C"

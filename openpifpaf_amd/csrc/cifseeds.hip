@@ -1,0 +1,186 @@
+// CifSeeds: seed extraction and ordering on gfx950.
+//
+// Replaces reference CifSeeds::fill + CifSeeds::get (csrc/src/cif_seeds.cpp:33-66,
+// 93-114): threshold every CIF cell, rescore it with the high-resolution map
+// (0.9*hr + 0.1*c), threshold again, and return the survivors sorted by score.
+//
+//  cifseeds_fill_kernel  one thread per CIF cell (coalesced plane reads, one
+//      gather into the L2-resident CifHr map), survivors appended to the image's
+//      key array with ONE atomic per wavefront (ballot + popcount prefix).
+//      key = sortable(score) << 32 | ~cell_index, so that a descending key sort is
+//      "score descending, then cell index ascending" -- a total order, which makes
+//      the result independent of the append order and of the sort algorithm.
+//      (The reference's std::sort leaves the order of equal scores unspecified.)
+//  cifseeds_sort_kernel  one 1024-thread workgroup per image: bitonic sort of the
+//      u64 keys, entirely in LDS when n <= 8192 (64 KiB), otherwise LDS-blocked
+//      with the far strides done through L2.  The epilogue decodes the keys and
+//      writes the sorted (f, v, x, y, s) arrays the association kernel streams.
+#include "common.hpp"
+
+namespace opa {
+
+__device__ __forceinline__ unsigned sortable_bits(float v) {
+    const unsigned u = __float_as_uint(v);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_sortable(unsigned s) {
+    return __uint_as_float((s & 0x80000000u) ? (s & 0x7fffffffu) : ~s);
+}
+
+__global__ __launch_bounds__(256) void cifseeds_fill_kernel(
+        const float* __restrict__ cif, int F, int H, int W, int stride,
+        const float* __restrict__ cifhr, int hr_rows, int hr_cols, int hr_pitch,
+        double threshold, int ablation_nms, int no_rescore,
+        unsigned long long* __restrict__ keys, int sort_cap, int cap, int32_t* __restrict__ seed_count) {
+    const int HW = H * W;
+    const int plane = blockIdx.x;              // b*F + f
+    const int b = plane / F, f = plane - b * F;
+    const int o = blockIdx.y * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const float* P = cif + (size_t)plane * 5 * HW;
+    bool on = false;
+    float c = 0.f;
+    if (o < HW) {
+        c = P[HW + o];
+        if (!((double)c < threshold)) {                              // cif_seeds.cpp:47
+            on = true;
+            if (ablation_nms) {                                      // :35-40,49-51: 3x3 max-pool gate
+                const int j = o / W, i = o - j * W;
+                float m = c;
+                for (int dj = -1; dj <= 1; dj++) for (int di = -1; di <= 1; di++) {
+                    const int jj = j + dj, ii = i + di;
+                    if (jj < 0 || jj >= H || ii < 0 || ii >= W) continue;
+                    m = fmaxf(m, P[HW + jj * W + ii]);
+                }
+                if (c < m) on = false;
+            }
+            if (on) {
+                const float x = P[2 * HW + o] * (float)stride;       // :53-54
+                const float y = P[3 * HW + o] * (float)stride;
+                if (!no_rescore) {                                   // :56-58
+                    const float hv = cifhr_value(cifhr + (size_t)b * F * hr_rows * hr_pitch,
+                                                 F, hr_rows, hr_cols, hr_pitch, f, x, y, -1.0f);
+                    c = (float)(0.9 * (double)hv + 0.1 * (double)c);
+                }
+                if ((double)c < threshold) on = false;               // :59
+            }
+        }
+    }
+    const unsigned long long mask = __ballot(on);
+    if (mask == 0) return;
+    int base = 0;
+    const int leader = __builtin_ctzll(mask);
+    if (lane == leader) base = atomicAdd(&seed_count[b], __popcll(mask));
+    base = __shfl(base, leader);
+    if (on) {
+        const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
+        if (slot < cap) {
+            const unsigned idx = (unsigned)(f * HW + o);
+            keys[(size_t)b * sort_cap + slot] =
+                ((unsigned long long)sortable_bits(c) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+        }
+    }
+}
+
+__device__ __forceinline__ void compare_exchange_desc(unsigned long long& a, unsigned long long& b, bool desc) {
+    if ((a < b) == desc) { const unsigned long long t = a; a = b; b = t; }
+}
+
+__global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
+        unsigned long long* keys, int sort_cap, int cap, const int32_t* __restrict__ seed_count,
+        const float* __restrict__ cif, int F, int HW, int stride,
+        int32_t* __restrict__ seed_f, float* __restrict__ seed_vxys) {
+    __shared__ unsigned long long sk[kSortLdsKeys];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    unsigned long long* K = keys + (size_t)b * sort_cap;
+    int n = seed_count[b];
+    if (n > cap) n = cap;
+    int n_pad = 2;
+    while (n_pad < n) n_pad <<= 1;
+    const bool in_lds = n_pad <= kSortLdsKeys;
+
+    if (in_lds) {
+        for (int t = tid; t < n_pad; t += 1024) sk[t] = t < n ? K[t] : 0ull;
+        __syncthreads();
+        for (int k = 2; k <= n_pad; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = tid; t < (n_pad >> 1); t += 1024) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int p = i | j;
+                    unsigned long long a = sk[i], c = sk[p];
+                    compare_exchange_desc(a, c, (i & k) == 0);
+                    sk[i] = a; sk[p] = c;
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        for (int t = n + tid; t < n_pad; t += 1024) K[t] = 0ull;
+        __syncthreads();
+        for (int k = 2; k <= n_pad; k <<= 1) {
+            int j = k >> 1;
+            for (; j >= kSortLdsKeys; j >>= 1) {                    // far strides through L2
+                for (int t = tid; t < (n_pad >> 1); t += 1024) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const int p = i | j;
+                    unsigned long long a = K[i], c = K[p];
+                    compare_exchange_desc(a, c, (i & k) == 0);
+                    K[i] = a; K[p] = c;
+                }
+                __syncthreads();
+            }
+            for (int blk = 0; blk < n_pad; blk += kSortLdsKeys) {   // near strides inside LDS blocks
+                for (int t = tid; t < kSortLdsKeys; t += 1024) sk[t] = K[blk + t];
+                __syncthreads();
+                for (int jj = j; jj > 0; jj >>= 1) {
+                    for (int t = tid; t < (kSortLdsKeys >> 1); t += 1024) {
+                        const int i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+                        const int p = i | jj;
+                        unsigned long long a = sk[i], c = sk[p];
+                        compare_exchange_desc(a, c, ((blk + i) & k) == 0);
+                        sk[i] = a; sk[p] = c;
+                    }
+                    __syncthreads();
+                }
+                for (int t = tid; t < kSortLdsKeys; t += 1024) K[blk + t] = sk[t];
+                __syncthreads();
+            }
+        }
+    }
+
+    // epilogue: decode keys -> sorted seeds (cif_seeds.cpp:100-113)
+    int32_t* sf = seed_f + (size_t)b * cap;
+    float* sv = seed_vxys + (size_t)b * cap * 4;
+    const float* image = cif + (size_t)b * F * 5 * HW;
+    for (int t = tid; t < n; t += 1024) {
+        const unsigned long long key = in_lds ? sk[t] : K[t];
+        const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+        const int f = (int)(idx / (unsigned)HW), o = (int)(idx - (unsigned)f * (unsigned)HW);
+        const float* P = image + (size_t)f * 5 * HW;
+        sf[t] = f;
+        float4 r;
+        r.x = from_sortable((unsigned)(key >> 32));
+        r.y = P[2 * HW + o] * (float)stride;
+        r.z = P[3 * HW + o] * (float)stride;
+        r.w = P[4 * HW + o] * (float)stride;                        // cif_seeds.cpp:61
+        reinterpret_cast<float4*>(sv)[t] = r;
+    }
+}
+
+hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int stride,
+                           const float* cifhr, int hr_rows, int hr_cols, int hr_pitch, const DevParams& p,
+                           unsigned long long* keys, int sort_cap, int32_t* seed_count,
+                           int32_t* seed_f, float* seed_vxys, hipStream_t st) {
+    const int HW = H * W, cap = F * HW;
+    hipError_t e = hipMemsetAsync(seed_count, 0, sizeof(int32_t) * B, st);
+    if (e != hipSuccess) return e;
+    dim3 grid(B * F, (HW + 255) / 256);
+    cifseeds_fill_kernel<<<grid, 256, 0, st>>>(cif, F, H, W, stride, cifhr, hr_rows, hr_cols, hr_pitch,
+                                               p.seed_threshold, p.ablation_cifseeds_nms,
+                                               p.ablation_cifseeds_no_rescore, keys, sort_cap, cap, seed_count);
+    cifseeds_sort_kernel<<<B, 1024, 0, st>>>(keys, sort_cap, cap, seed_count, cif, F, HW, stride,
+                                             seed_f, seed_vxys);
+    return hipGetLastError();
+}
+
+}  // namespace opa

@@ -1,0 +1,130 @@
+// Shared declarations of the MI355X (gfx950) CifCaf decode library.
+// Internal header: the public boundary is include/openpifpaf_amd.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/openpifpaf_amd.h"
+
+namespace opa {
+
+constexpr int kWave = 64;                 // CDNA4 wavefront width
+constexpr int kHrTileW = 64;              // CifHr tile width  (one 256-B row segment)
+constexpr int kHrTileH = 32;              // CifHr tile height
+constexpr int kHrLdsPitch = kHrTileW + 16;// LDS row pitch: +16 banks so a 16x4 patch is conflict free
+constexpr int kSortLdsKeys = 8192;        // 64 KiB of u64 keys sorted inside LDS
+
+// Launch-time view of one batched decode (device pointers into the workspace).
+struct Layout {
+    // shapes
+    int B, F, A, H, W, cH, cW, stride, cstride, max_ann;
+    int hr_rows, hr_cols, hr_pitch;       // high-res map geometry
+    int occ_h, occ_w;                     // occupancy geometry
+    int cif_cells;                        // F*H*W  (seed capacity)
+    int caf_cells;                        // cH*cW  (list capacity per (field, direction))
+    int sort_cap;                         // next pow2 >= cif_cells
+    // byte offsets into the workspace (all 256-B aligned)
+    size_t off_cifhr, off_act, off_act_count, off_seed_keys, off_seed_count,
+           off_seed_f, off_seed_vxys, off_lists, off_list_counts,
+           off_lists_fc, off_list_counts_fc, off_occ, off_anns, off_ann_meta, off_status,
+           total;
+};
+
+bool make_layout(const opa_shape& s, Layout* L, const char** why);
+
+// Device-side copy of the tunables.
+struct DevParams {
+    double cif_threshold, seed_threshold, caf_threshold, cif_floor;
+    double keypoint_threshold, keypoint_threshold_rel;
+    double nms_suppression, nms_instance_threshold, nms_keypoint_threshold;
+    double force_complete_caf_th, occupancy_reduction, occupancy_min_scale_reduced;
+    int64_t cifhr_neighbors;
+    int reverse_match, force_complete, greedy;
+    int ablation_cifseeds_nms, ablation_cifseeds_no_rescore, ablation_caf_no_rescore, ablation_cifhr_skip;
+};
+DevParams to_dev(const opa_params& p);
+
+// Skeleton + adjacency on the device (owned by an opa_cifcaf handle).
+struct DevSkeleton {
+    int K, A;
+    const int64_t* skeleton;   // [A,2] 0-based
+    const int32_t* adj_off;    // [K+1]
+    const int32_t* adj_other;  // [2A]  other end of the bone
+    const int32_t* adj_bone;   // [2A]  CAF field index
+    const int32_t* adj_fwd;    // [2A]  1: joint is skeleton[a][0] (walk the forward list)
+    const int32_t* adj_first;  // [2A]  first slot of the same joint with the same other end
+                               //       (duplicate bones share one frontier slot, cifcaf.cpp:329,361-374)
+};
+
+// ---- kernel launchers (one per .hip file) ---------------------------------
+hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride,
+                        double min_scale, double factor, const DevParams& p,
+                        float* cifhr, int hr_rows, int hr_pitch,
+                        float* act, int32_t* act_count, hipStream_t st);
+
+hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int stride,
+                           const float* cifhr, int hr_rows, int hr_cols, int hr_pitch, const DevParams& p,
+                           unsigned long long* keys, int sort_cap, int32_t* seed_count,
+                           int32_t* seed_f, float* seed_vxys, hipStream_t st);
+
+hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
+                            const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
+                            const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
+                            float* lists, int32_t* counts, hipStream_t st);
+
+struct AssocArgs {
+    int B, K, A, max_ann, n_initial;
+    int hr_rows, hr_cols;
+    int occ_h, occ_w;
+    int seed_cap, list_cap;
+    const int32_t* seed_f; const float* seed_vxys; const int32_t* seed_count;
+    const float* lists; const int32_t* list_counts;          // caf_th lists
+    const float* lists_fc; const int32_t* list_counts_fc;    // force-complete lists (or null)
+    unsigned char* occ;
+    double* anns;            // [B, max_ann, K, 4] doubles (v,x,y,s) scratch
+    int64_t* ann_ids;        // [B, max_ann]
+    const float* initial; const int64_t* initial_ids;
+    float* out; int64_t* out_ids; int32_t* out_count;
+    int32_t* status;         // [B] debug/overflow flags
+};
+hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st);
+
+hipError_t launch_blend(const float* rows, int n, double x, double y, double s, double filter_sigmas,
+                        int only_max, double* out4_dev, hipStream_t st);
+
+}  // namespace opa
+
+// ---- device helpers ---------------------------------------------------------
+#ifdef __HIPCC__
+namespace opa {
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+__device__ __forceinline__ long long clampll(long long v, long long lo, long long hi) {
+    return v < lo ? lo : (v > hi ? hi : v);
+}
+
+// float -> int64 with x86 cvttss2si semantics for the values that can occur
+// (finite, |v| < 2^63): truncation toward zero.
+__device__ __forceinline__ long long trunc_ll(float v) { return (long long)v; }
+__device__ __forceinline__ long long trunc_ll(double v) { return (long long)v; }
+
+// Reference cifhr_value (cif_seeds.cpp:17-30 == caf_scored.cpp:15-26) on the raw
+// revision-1 buffer: 0 = untouched (-> default), else 1 + value.
+__device__ __forceinline__ float cifhr_value(const float* hr_image, int F, int rows, int cols, int pitch,
+                                             long long f, float x, float y, float default_value) {
+    const float max_x = (float)((double)(float)cols - 0.51);
+    const float max_y = (float)((double)(float)rows - 0.51);
+    if (f >= F || (double)x < -0.49 || (double)y < -0.49 || x > max_x || y > max_y) return default_value;
+    const long long yi = (long long)((double)y + 0.5);
+    const long long xi = (long long)((double)x + 0.5);
+    const float raw = hr_image[((size_t)f * rows + yi) * pitch + xi];
+    const float value = (float)((double)raw - 1.0);
+    if ((double)value < 0.0) return default_value;
+    return value;
+}
+
+}  // namespace opa
+#endif

@@ -1,0 +1,319 @@
+"""Torch-facing wrappers over the C ABI, mirroring the reference's TorchScript
+classes (reference ``csrc/src/module.cpp:19-118``):
+
+===============================================  =============================================
+reference                                        here
+===============================================  =============================================
+``torch.ops.openpifpaf.set_quiet``               :func:`set_quiet`
+``torch.classes.openpifpaf_decoder.CifCaf``      :class:`CifCaf` (+ ``call_batch``)
+``torch.ops.openpifpaf_decoder.grow_connection_blend``  :func:`grow_connection_blend`
+``torch.classes.openpifpaf_decoder_utils.CifHr``        :class:`CifHr`
+``torch.classes.openpifpaf_decoder_utils.CifSeeds``     :class:`CifSeeds`
+``torch.classes.openpifpaf_decoder_utils.CafScored``    :class:`CafScored`
+``...NMSKeypoints`` / static get_/set_ pairs     static get_/set_ pairs on the same classes
+===============================================  =============================================
+
+PyTorch is used for device memory and streams only; all compute is in the HIP
+library.  Tensors given on the CPU are uploaded to the current device first (the
+reference only accepts CPU tensors, ``cifcaf.cpp:137-138``); results come back
+on the device the inputs were on.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+DEFAULT_MAX_ANNOTATIONS = 128
+
+
+def set_quiet(quiet=True):
+    _lib.lib().opa_set_quiet(int(bool(quiet)))
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise _lib.NativeError('openpifpaf_amd: no MI355X/HIP device visible; the decode path has no CPU fallback')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def _prep(t, dtype=torch.float32):
+    """-> (contiguous device tensor, original device)"""
+    orig = t.device
+    if t.device.type != 'cuda':
+        t = t.to(_device(), non_blocking=True)
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous(), orig
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _static_getset(field, cast=float):
+    def getter():
+        return cast(getattr(_lib.get_params(), field))
+
+    def setter(v):
+        p = _lib.get_params()
+        setattr(p, field, cast(v) if cast is not bool else int(bool(v)))
+        _lib.set_params(p)
+    return staticmethod(getter), staticmethod(setter)
+
+
+class CifCaf:
+    """Drop-in for ``torch.classes.openpifpaf_decoder.CifCaf`` (module.cpp:25-54)."""
+
+    get_block_joints, set_block_joints = _static_getset('block_joints', bool)
+    get_greedy, set_greedy = _static_getset('greedy', bool)
+    get_keypoint_threshold, set_keypoint_threshold = _static_getset('keypoint_threshold')
+    get_keypoint_threshold_rel, set_keypoint_threshold_rel = _static_getset('keypoint_threshold_rel')
+    get_reverse_match, set_reverse_match = _static_getset('reverse_match', bool)
+    get_force_complete, set_force_complete = _static_getset('force_complete', bool)
+    get_force_complete_caf_th, set_force_complete_caf_th = _static_getset('force_complete_caf_th')
+
+    def __init__(self, n_keypoints, skeleton, *, max_annotations=DEFAULT_MAX_ANNOTATIONS):
+        skeleton = torch.as_tensor(skeleton)
+        if skeleton.dtype != torch.int64:
+            raise RuntimeError('skeleton must be of type LongTensor')      # cifcaf.hpp:106
+        self.n_keypoints = int(n_keypoints)
+        self.skeleton = skeleton.detach().cpu().contiguous().reshape(-1, 2)
+        self.max_annotations = int(max_annotations)
+        self._handle = ctypes.c_void_p()
+        self._workspaces = {}
+        self._last = None
+        _device()
+        _lib.check(_lib.lib().opa_cifcaf_create(
+            ctypes.byref(self._handle), self.n_keypoints,
+            ctypes.c_void_p(self.skeleton.data_ptr()), self.skeleton.shape[0]), 'opa_cifcaf_create')
+
+    def __del__(self):
+        try:
+            if getattr(self, '_handle', None):
+                _lib.lib().opa_cifcaf_destroy(self._handle)
+                self._handle = None
+        except Exception:   # interpreter shutdown
+            pass
+
+    # pickle state = (n_keypoints, skeleton), module.cpp:41-53
+    def __getstate__(self):
+        return (self.n_keypoints, self.skeleton, self.max_annotations)
+
+    def __setstate__(self, state):
+        self.__init__(state[0], state[1], max_annotations=state[2])
+
+    def _shape(self, cif, cif_stride, caf, caf_stride):
+        B, F, C, H, W = cif.shape
+        Bc, A, Cc, cH, cW = caf.shape
+        if C != 5 or Cc != 8 or B != Bc:
+            raise ValueError('expected cif [B,F,5,H,W] and caf [B,A,8,H,W], got %s and %s'
+                             % (tuple(cif.shape), tuple(caf.shape)))
+        return _lib.Shape(B, F, A, H, W, cH, cW, int(cif_stride), int(caf_stride), self.max_annotations)
+
+    def _workspace(self, shape, device):
+        key = tuple(getattr(shape, n) for n, _ in _lib.Shape._fields_) + (device.index,)
+        ws = self._workspaces.get(key)
+        if ws is None:
+            nbytes = _lib.lib().opa_cifcaf_workspace_bytes(ctypes.byref(shape))
+            if nbytes == 0:
+                raise _lib.NativeError(_lib.lib().opa_last_error().decode())
+            self._workspaces.clear()        # one live workspace per decoder
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._workspaces[key] = ws
+        return ws
+
+    def call_batch(self, cif, cif_stride, caf, caf_stride, initial_annotations=None, initial_ids=None,
+                   *, params=None):
+        """Batched, asynchronous decode on the current stream.
+
+        :param cif: ``[B,F,5,H,W]`` float32, :param caf: ``[B,A,8,H,W]`` float32 (device tensors)
+        :returns: ``(annotations [B,max,K,4] (v,x,y,s), ids [B,max] int64, counts [B] int32)``
+                  device tensors; rows >= counts[b] are undefined.
+        """
+        cif, orig = _prep(cif)
+        caf, _ = _prep(caf)
+        shape = self._shape(cif, cif_stride, caf, caf_stride)
+        ws = self._workspace(shape, cif.device)
+        B, K = shape.batch, shape.n_cif
+        out = torch.empty((B, self.max_annotations, K, 4), dtype=torch.float32, device=cif.device)
+        ids = torch.empty((B, self.max_annotations), dtype=torch.int64, device=cif.device)
+        counts = torch.empty((B,), dtype=torch.int32, device=cif.device)
+        n_initial = 0
+        init_t = ids_t = None
+        if initial_annotations is not None and initial_annotations.shape[-3] > 0:
+            init_t, _ = _prep(initial_annotations)
+            init_t = init_t.reshape(B, -1, K, 4)
+            n_initial = init_t.shape[1]
+            if initial_ids is None:
+                raise RuntimeError('require initial_ids when initial_annotations are given')   # cifcaf.cpp:178
+            ids_t, _ = _prep(initial_ids, torch.int64)
+            ids_t = ids_t.reshape(B, n_initial)
+        _lib.check(_lib.lib().opa_cifcaf_decode(
+            self._handle, ctypes.byref(shape), ctypes.byref(params) if params is not None else None,
+            _ptr(cif), _ptr(caf), _ptr(init_t), _ptr(ids_t), n_initial,
+            _ptr(ws), ws.numel(), _ptr(out), _ptr(ids), _ptr(counts), _stream()), 'opa_cifcaf_decode')
+        self._last = (shape, ws)
+        if orig.type != 'cuda':
+            out, ids, counts = out.to(orig), ids.to(orig), counts.to(orig)
+        return out, ids, counts
+
+    def call_with_initial_annotations(self, cif_field, cif_stride, caf_field, caf_stride,
+                                      initial_annotations=None, initial_ids=None):
+        """Single image, like module.cpp:36: ``-> (Tensor[n,K,4] (v,x,y,s), Tensor[n] int64)``."""
+        ia = initial_annotations.unsqueeze(0) if initial_annotations is not None else None
+        ii = initial_ids.unsqueeze(0) if initial_ids is not None else None
+        out, ids, counts = self.call_batch(cif_field.unsqueeze(0), cif_stride, caf_field.unsqueeze(0),
+                                           caf_stride, ia, ii)
+        n = int(counts[0])
+        if n > self.max_annotations:
+            raise _lib.NativeError('annotation capacity overflow: %d dropped; construct CifCaf with a larger '
+                                   'max_annotations' % (n - self.max_annotations))
+        return out[0, :n].clone(), ids[0, :n].clone()
+
+    def call(self, cif_field, cif_stride, caf_field, caf_stride):
+        """module.cpp:35."""
+        return self.call_with_initial_annotations(cif_field, cif_stride, caf_field, caf_stride)
+
+    def get_cifhr(self, image=0):
+        """module.cpp:37-39 -> (Tensor [F,Hhr,Whr] view of the internal buffer, revision)."""
+        if self._last is None:
+            return torch.zeros((1, 1, 1)), 0.0
+        shape, ws = self._last
+        off, rows, cols, pitch = ctypes.c_size_t(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        rev = ctypes.c_double()
+        _lib.check(_lib.lib().opa_cifcaf_cifhr_view(ctypes.byref(shape), ctypes.byref(off), ctypes.byref(rows),
+                                                    ctypes.byref(cols), ctypes.byref(pitch), ctypes.byref(rev)))
+        F = shape.n_cif
+        n = shape.batch * F * rows.value * pitch.value
+        flat = ws[off.value * 4:(off.value + n) * 4].view(torch.float32)
+        return flat.view(shape.batch, F, rows.value, pitch.value)[image, :, :, :cols.value], rev.value
+
+
+def grow_connection_blend(caf, x, y, s, filter_sigmas=1.0, only_max=False):
+    """``torch.ops.openpifpaf_decoder.grow_connection_blend`` (module.cpp:55) -> [x, y, s, v]."""
+    caf, _ = _prep(caf)
+    caf = caf.reshape(-1, 7)
+    out = (ctypes.c_double * 4)()
+    _lib.check(_lib.lib().opa_grow_connection_blend(_ptr(caf) if caf.numel() else None, caf.shape[0],
+                                                    float(x), float(y), float(s), float(filter_sigmas),
+                                                    int(bool(only_max)), out, _stream()),
+               'opa_grow_connection_blend')
+    return list(out)
+
+
+class CifHr:
+    """``torch.classes.openpifpaf_decoder_utils.CifHr`` (module.cpp:75-84), batched."""
+    get_neighbors, set_neighbors = _static_getset('cifhr_neighbors', int)
+    get_threshold, set_threshold = _static_getset('cif_threshold')
+    get_ablation_skip, set_ablation_skip = _static_getset('ablation_cifhr_skip', bool)
+
+    def __init__(self):
+        self.accumulated = None     # [B,F,rows,pitch]
+        self.cols = 0
+        self.revision = 0.0
+
+    def accumulate(self, cif_field, stride, min_scale=0.0, factor=1.0, *, params=None):
+        """reset() + accumulate() of a fresh instance.  ``cif_field``: [F,5,H,W] or [B,F,5,H,W]."""
+        cif, _ = _prep(cif_field)
+        if cif.dim() == 4:
+            cif = cif.unsqueeze(0)
+        B, F, _, H, W = cif.shape
+        L = _lib.lib()
+        pitch = L.opa_cifhr_pitch(W, int(stride))
+        rows, self.cols = (H - 1) * stride + 1, (W - 1) * stride + 1
+        self.accumulated = torch.empty((B, F, rows, pitch), dtype=torch.float32, device=cif.device)
+        nbytes = L.opa_cifhr_scratch_bytes(B, F, H, W)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=cif.device)
+        _lib.check(L.opa_cifhr_accumulate(_ptr(cif), B, F, H, W, int(stride), float(min_scale), float(factor),
+                                          ctypes.byref(params) if params is not None else None,
+                                          _ptr(self.accumulated), _ptr(scratch), nbytes, _stream()),
+                   'opa_cifhr_accumulate')
+        self.revision = 1.0
+        self._scratch = scratch     # keep alive until the stream has run
+
+    def get_accumulated(self, image=0):
+        return self.accumulated[image, :, :, :self.cols], self.revision
+
+
+class CifSeeds:
+    """``torch.classes.openpifpaf_decoder_utils.CifSeeds`` (module.cpp:86-94), batched."""
+    get_threshold, set_threshold = _static_getset('seed_threshold')
+    get_ablation_nms, set_ablation_nms = _static_getset('ablation_cifseeds_nms', bool)
+    get_ablation_no_rescore, set_ablation_no_rescore = _static_getset('ablation_cifseeds_no_rescore', bool)
+
+    def __init__(self, cifhr: CifHr):
+        self.cifhr = cifhr
+        self._out = None
+
+    def fill(self, cif_field, stride, *, params=None):
+        cif, _ = _prep(cif_field)
+        if cif.dim() == 4:
+            cif = cif.unsqueeze(0)
+        B, F, _, H, W = cif.shape
+        cap = F * H * W
+        L = _lib.lib()
+        f = torch.empty((B, cap), dtype=torch.int32, device=cif.device)
+        vxys = torch.empty((B, cap, 4), dtype=torch.float32, device=cif.device)
+        count = torch.empty((B,), dtype=torch.int32, device=cif.device)
+        nbytes = L.opa_cifseeds_scratch_bytes(B, F, H, W)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=cif.device)
+        _lib.check(L.opa_cifseeds_fill(_ptr(cif), B, F, H, W, int(stride), _ptr(self.cifhr.accumulated),
+                                       ctypes.byref(params) if params is not None else None,
+                                       _ptr(f), _ptr(vxys), _ptr(count), _ptr(scratch), nbytes, _stream()),
+                   'opa_cifseeds_fill')
+        self._out = (f, vxys, count, scratch)
+
+    def get(self, image=0):
+        """-> (fields int64 [n], vxys float32 [n,4]) sorted by v descending (cif_seeds.cpp:93-114)."""
+        f, vxys, count, _ = self._out
+        n = int(count[image])
+        return f[image, :n].to(torch.int64), vxys[image, :n]
+
+
+class CafScored:
+    """``torch.classes.openpifpaf_decoder_utils.CafScored`` (module.cpp:104-111), batched."""
+    get_default_score_th, set_default_score_th = _static_getset('caf_threshold')
+    get_ablation_no_rescore, set_ablation_no_rescore = _static_getset('ablation_caf_no_rescore', bool)
+
+    def __init__(self, cifhr: CifHr, cif_shape, cif_stride, score_th=-1.0, cif_floor=0.1):
+        self.cifhr = cifhr
+        self.cif_shape = tuple(cif_shape)[-4:]     # (F,5,H,W)
+        self.cif_stride = int(cif_stride)
+        self.score_th = float(score_th)
+        self.cif_floor = float(cif_floor)
+        self._out = None
+
+    def fill(self, caf_field, stride, skeleton, *, params=None):
+        caf, _ = _prep(caf_field)
+        if caf.dim() == 4:
+            caf = caf.unsqueeze(0)
+        B, A, _, H, W = caf.shape
+        F, _, cH, cW = self.cif_shape
+        skel, _ = _prep(torch.as_tensor(skeleton), torch.int64)
+        lists = torch.empty((B, A, 2, 7, H * W), dtype=torch.float32, device=caf.device)
+        counts = torch.empty((B, A, 2), dtype=torch.int32, device=caf.device)
+        _lib.check(_lib.lib().opa_cafscored_fill(
+            _ptr(caf), B, A, H, W, int(stride), _ptr(self.cifhr.accumulated), F, cH, cW, self.cif_stride,
+            _ptr(skel), self.score_th, self.cif_floor, ctypes.byref(params) if params is not None else None,
+            _ptr(lists), _ptr(counts), _stream()), 'opa_cafscored_fill')
+        self._out = (lists, counts, skel)
+
+    def get(self, image=0):
+        """-> (forward, backward): lists of [n,7] tensors (caf_scored.cpp:86-104)."""
+        lists, counts, _ = self._out
+        counts = counts[image].cpu()
+        fwd = [lists[image, a, 0, :, :int(counts[a, 0])].t().contiguous() for a in range(lists.shape[1])]
+        bwd = [lists[image, a, 1, :, :int(counts[a, 1])].t().contiguous() for a in range(lists.shape[1])]
+        return fwd, bwd
+
+
+class NMSKeypoints:
+    """Static tunables of ``openpifpaf_decoder_utils.NMSKeypoints`` (module.cpp:113-117)."""
+    get_instance_threshold, set_instance_threshold = _static_getset('nms_instance_threshold')
+    get_keypoint_threshold, set_keypoint_threshold = _static_getset('nms_keypoint_threshold')
+    get_suppression, set_suppression = _static_getset('nms_suppression')

@@ -1,0 +1,30 @@
+"""Shared helpers of the test-suite (parity comparator, case lists)."""
+import numpy as np
+
+TOL = 1e-4   # BASELINE.json north_star: keypoint coordinates/scores within 1e-4
+
+# (seed, people, H, W) -- the golden cases; small fields keep the CPU suite quick
+GOLDEN_CASES = [
+    (0, 1, 41, 41), (1, 3, 41, 41), (2, 5, 41, 41), (3, 8, 41, 41),
+    (4, 2, 33, 49), (5, 6, 49, 33),
+    (6, 5, 81, 81), (7, 10, 81, 81), (8, 20, 81, 81),
+]
+
+
+def compare_annotations(a, b, tol=TOL):
+    """a, b: [n,K,4] (v,x,y,s), both in the decoder's output order (score descending).
+    Returns (ok, message).  Discrete mismatches (count, joint presence) are reported as such."""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape:
+        return False, 'annotation count/shape differs: %s vs %s' % (a.shape, b.shape)
+    if a.size == 0:
+        return True, 'both empty'
+    present_a, present_b = a[..., 0] > 0, b[..., 0] > 0
+    if not np.array_equal(present_a, present_b):
+        return False, 'joint presence differs at %s' % (np.argwhere(present_a != present_b)[:5].tolist(),)
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    m = d.max()
+    if not m <= tol:
+        idx = np.unravel_index(d.argmax(), d.shape)
+        return False, 'max |delta| %.3g at %s: %s vs %s' % (m, idx, a[idx[0], idx[1]], b[idx[0], idx[1]])
+    return True, 'max |delta| %.3g' % m

@@ -1,0 +1,266 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle
+on identical, seeded field tensors.  Integer/index results bit-exact; the CifHr map
+and the CAF lists bit-exact (ordered accumulation, no FMA); keypoints within 1e-4."""
+import numpy as np
+import pytest
+
+from common import TOL, compare_annotations
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+
+@pytest.fixture(scope='module')
+def native():
+    from openpifpaf_amd import native as n
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    return n
+
+
+@pytest.fixture(scope='module')
+def port():
+    from oracle import port as p
+    return p
+
+
+def fields(seed, people, H=81, W=81):
+    from openpifpaf_amd import synth
+    return synth.synth_fields(seed, people, height=H, width=W)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+CASES = [(0, 1, 41, 41), (1, 5, 81, 81), (2, 10, 81, 81), (3, 20, 81, 81), (4, 3, 33, 49), (5, 6, 49, 33)]
+
+
+@pytest.mark.parametrize('seed,people,H,W', CASES)
+def test_cifhr_bit_exact(native, port, seed, people, H, W):
+    cif, _ = fields(seed, people, H, W)
+    ref = port.cifhr_accumulate(cif, 8)
+    hr = native.CifHr()
+    hr.accumulate(dev(cif), 8)
+    got, rev = hr.get_accumulated()
+    assert rev == 1.0
+    got = got.cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref), 'max |delta| %g, %d cells differ' % (
+        np.abs(got - ref).max(), (got != ref).sum())
+
+
+def test_cifhr_min_scale_and_factor(native, port):
+    cif, _ = fields(11, 5)
+    ref = port.cifhr_accumulate(cif, 8, min_scale=6.0, factor=0.5)
+    hr = native.CifHr()
+    hr.accumulate(dev(cif), 8, 6.0, 0.5)
+    assert np.array_equal(hr.get_accumulated()[0].cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize('seed,people,H,W', CASES)
+def test_cifseeds_exact(native, port, seed, people, H, W):
+    cif, _ = fields(seed, people, H, W)
+    ref_hr = port.cifhr_accumulate(cif, 8)
+    ref_f, ref_v = port.cifseeds(cif, 8, ref_hr)
+    hr = native.CifHr()
+    hr.accumulate(dev(cif), 8)
+    seeds = native.CifSeeds(hr)
+    seeds.fill(dev(cif), 8)
+    f, v = seeds.get()
+    f, v = f.cpu().numpy(), v.cpu().numpy()
+    assert len(f) == len(ref_f)
+    assert np.all(np.diff(v[:, 0]) <= 0), 'not sorted by score'
+    if len(np.unique(ref_v[:, 0])) == len(ref_v):      # no score ties: order is fully determined
+        assert np.array_equal(f, ref_f)
+        assert np.array_equal(v, ref_v)
+    else:                                             # compare as sets
+        a = sorted(map(tuple, np.column_stack([f, v]).tolist()))
+        b = sorted(map(tuple, np.column_stack([ref_f, ref_v]).tolist()))
+        assert a == b
+
+
+@pytest.mark.parametrize('seed,people,H,W', CASES)
+def test_cafscored_exact(native, port, coco_skeleton0, seed, people, H, W):
+    cif, caf = fields(seed, people, H, W)
+    ref_hr = port.cifhr_accumulate(cif, 8)
+    ref_f, ref_b = port.cafscored(caf, 8, ref_hr, cif.shape, 8, coco_skeleton0)
+    hr = native.CifHr()
+    hr.accumulate(dev(cif), 8)
+    cs = native.CafScored(hr, cif.shape, 8)
+    cs.fill(dev(caf), 8, torch.from_numpy(coco_skeleton0))
+    fwd, bwd = cs.get()
+    for a in range(len(ref_f)):
+        assert np.array_equal(fwd[a].cpu().numpy(), ref_f[a]), 'forward list %d' % a
+        assert np.array_equal(bwd[a].cpu().numpy(), ref_b[a]), 'backward list %d' % a
+
+
+def test_cafscored_force_complete_threshold(native, port, coco_skeleton0):
+    cif, caf = fields(7, 5)
+    ref_hr = port.cifhr_accumulate(cif, 8)
+    ref_f, ref_b = port.cafscored(caf, 8, ref_hr, cif.shape, 8, coco_skeleton0, score_th=0.001)
+    hr = native.CifHr()
+    hr.accumulate(dev(cif), 8)
+    cs = native.CafScored(hr, cif.shape, 8, 0.001, 0.1)
+    cs.fill(dev(caf), 8, torch.from_numpy(coco_skeleton0))
+    fwd, bwd = cs.get()
+    for a in range(len(ref_f)):
+        assert np.array_equal(fwd[a].cpu().numpy(), ref_f[a])
+        assert np.array_equal(bwd[a].cpu().numpy(), ref_b[a])
+
+
+def test_grow_connection_blend(native, port, coco_skeleton0):
+    cif, caf = fields(2, 10)
+    ref_hr = port.cifhr_accumulate(cif, 8)
+    ref_f, _ = port.cafscored(caf, 8, ref_hr, cif.shape, 8, coco_skeleton0)
+    rng = np.random.default_rng(0)
+    checked = 0
+    for rows in ref_f[:8]:
+        if len(rows) == 0:
+            continue
+        rows_d = dev(rows)
+        for _ in range(6):
+            r = rows[rng.integers(len(rows))]
+            x, y = float(r[1] + rng.normal(0, 1.0)), float(r[2] + rng.normal(0, 1.0))
+            s = float(rng.uniform(2.0, 30.0))
+            for only_max in (False, True):
+                for fs in (1.0, 4.0):
+                    want = port.grow_connection_blend(rows, x, y, s, fs, only_max)
+                    got = np.asarray(native.grow_connection_blend(rows_d, x, y, s, fs, only_max))
+                    assert np.allclose(got, want, rtol=1e-6, atol=1e-6), (got, want)
+                    checked += 1
+    assert checked > 50
+    # empty list and far-away query -> all-zero joint
+    assert native.grow_connection_blend(torch.zeros((0, 7)).cuda(), 1.0, 2.0, 3.0) == [0.0, 0.0, 0.0, 0.0]
+    assert native.grow_connection_blend(dev(ref_f[0]), -1e4, -1e4, 1.0) == [0.0, 0.0, 0.0, 0.0]
+
+
+def test_grow_connection_blend_ties(native, port):
+    """Exactly equal scores: the reference's '>=' / '>' rules pick by list position."""
+    base = np.array([[0.8, 10.0, 10.0, 50.0, 60.0, 4.0, 4.0]], dtype=np.float32)
+    for n in (2, 3, 5, 130):
+        rows = np.repeat(base, n, axis=0)
+        rows[:, 3] += np.arange(n, dtype=np.float32) * 0.25       # distinguishable targets
+        for x in (10.0, 10.5):
+            want = port.grow_connection_blend(rows, x, 10.0, 8.0)
+            got = np.asarray(native.grow_connection_blend(dev(rows), x, 10.0, 8.0))
+            assert np.allclose(got, want, rtol=1e-6, atol=1e-6), (n, got, want)
+
+
+@pytest.mark.parametrize('seed,people,H,W', CASES + [(6, 15, 81, 81), (7, 8, 81, 81), (8, 2, 81, 81)])
+def test_decode_parity(native, port, coco_skeleton0, seed, people, H, W):
+    cif, caf = fields(seed, people, H, W)
+    want, want_ids = port.decode(cif, 8, caf, 8, coco_skeleton0)
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    got, ids = dec.call(dev(cif), 8, dev(caf), 8)
+    ok, msg = compare_annotations(got.cpu().numpy(), want)
+    assert ok, msg
+    assert np.array_equal(ids.cpu().numpy(), want_ids)
+    hr, rev = dec.get_cifhr()
+    assert rev == 1.0 and tuple(hr.shape) == (17, (H - 1) * 8 + 1, (W - 1) * 8 + 1)
+
+
+def test_decode_batch_matches_single(native, port, coco_skeleton0):
+    from openpifpaf_amd import synth
+    cifs, cafs = synth.synth_batch(8, seed0=100)
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    out, ids, counts = dec.call_batch(dev(cifs), 8, dev(cafs), 8)
+    out, counts = out.cpu().numpy(), counts.cpu().numpy()
+    for b in range(8):
+        want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)
+        assert counts[b] == len(want)
+        ok, msg = compare_annotations(out[b, :counts[b]], want)
+        assert ok, 'image %d: %s' % (b, msg)
+
+
+def test_decode_force_complete(native, port, coco_skeleton0):
+    from openpifpaf_amd import _lib
+    for seed, people in [(20, 3), (21, 8), (22, 15)]:
+        cif, caf = fields(seed, people)
+        kw = dict(force_complete=1, keypoint_threshold=0.0, keypoint_threshold_rel=0.0,
+                  nms_instance_threshold=0.0, nms_keypoint_threshold=0.0)
+        want, _ = port.decode(cif, 8, caf, 8, coco_skeleton0, params=port.default_params(**kw))
+        dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0), max_annotations=512)
+        out, ids, counts = dec.call_batch(dev(cif)[None], 8, dev(caf)[None], 8, params=_lib.default_params(**kw))
+        n = int(counts[0])
+        assert n == len(want)
+        ok, msg = compare_annotations(out[0, :n].cpu().numpy(), want)
+        assert ok, 'seed %d: %s' % (seed, msg)
+        assert (want[:, :, 0] > 0).all(), 'force complete leaves no joint empty'
+
+
+def test_decode_initial_annotations(native, port, coco_skeleton0):
+    cif, caf = fields(30, 4)
+    first, _ = port.decode(cif, 8, caf, 8, coco_skeleton0)
+    assert len(first) >= 2
+    init = first[:2].copy()
+    init[:, 5:, :] = 0.0                      # keep only the head joints: the decoder must regrow the rest
+    init_ids = np.array([7, 9], dtype=np.int64)
+    want, want_ids = port.decode(cif, 8, caf, 8, coco_skeleton0, initial_annotations=init, initial_ids=init_ids)
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    got, ids = dec.call_with_initial_annotations(dev(cif), 8, dev(caf), 8, dev(init), dev(init_ids))
+    ok, msg = compare_annotations(got.cpu().numpy(), want)
+    assert ok, msg
+    assert np.array_equal(ids.cpu().numpy(), want_ids)
+    assert {7, 9} <= set(want_ids.tolist())
+
+
+def test_decode_greedy_and_no_reverse_match(native, port, coco_skeleton0):
+    from openpifpaf_amd import _lib
+    cif, caf = fields(40, 6)
+    for kw in (dict(greedy=1), dict(reverse_match=0), dict(keypoint_threshold=0.3, keypoint_threshold_rel=0.8)):
+        want, _ = port.decode(cif, 8, caf, 8, coco_skeleton0, params=port.default_params(**kw))
+        dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+        out, ids, counts = dec.call_batch(dev(cif)[None], 8, dev(caf)[None], 8, params=_lib.default_params(**kw))
+        n = int(counts[0])
+        assert n == len(want), kw
+        ok, msg = compare_annotations(out[0, :n].cpu().numpy(), want)
+        assert ok, '%s: %s' % (kw, msg)
+
+
+def test_decode_empty_fields(native, coco_skeleton0):
+    cif = np.zeros((17, 5, 41, 41), dtype=np.float32)
+    caf = np.zeros((19, 8, 41, 41), dtype=np.float32)
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    got, ids = dec.call(dev(cif), 8, dev(caf), 8)
+    assert got.shape == (0, 17, 4) and ids.shape == (0,)
+
+
+def test_decode_all_active_adversarial(native, port, coco_skeleton0):
+    """Random-initialised-network statistics: every cell passes every threshold.
+    31x31 cells x 17 fields = 16k seeds > 8192: exercises the LDS-blocked sort."""
+    from openpifpaf_amd import synth
+    cif, caf = synth.adversarial_fields(3, height=31, width=31)
+    ref_hr = port.cifhr_accumulate(cif, 8)
+    ref_f, ref_v = port.cifseeds(cif, 8, ref_hr)
+    assert len(ref_f) > 8192
+    hr = native.CifHr()
+    hr.accumulate(dev(cif), 8)
+    assert np.array_equal(hr.get_accumulated()[0].cpu().numpy(), ref_hr)
+    seeds = native.CifSeeds(hr)
+    seeds.fill(dev(cif), 8)
+    f, v = seeds.get()
+    assert len(f) == len(ref_f)
+    v = v.cpu().numpy()
+    assert np.all(np.diff(v[:, 0]) <= 0)
+    assert np.array_equal(np.sort(v[:, 0]), np.sort(ref_v[:, 0]))
+    want, _ = port.decode(cif, 8, caf, 8, coco_skeleton0)
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0), max_annotations=512)
+    got, _ = dec.call(dev(cif), 8, dev(caf), 8)
+    ok, msg = compare_annotations(got.cpu().numpy(), want)
+    assert ok, msg
+
+
+def test_static_getset_roundtrip(native):
+    C = native.CifCaf
+    old = C.get_keypoint_threshold()
+    try:
+        C.set_keypoint_threshold(0.25)
+        assert C.get_keypoint_threshold() == 0.25
+        C.set_force_complete(True)
+        assert C.get_force_complete() is True
+    finally:
+        C.set_keypoint_threshold(old)
+        C.set_force_complete(False)
+    assert native.CifHr.get_threshold() == 0.3 and native.CifSeeds.get_threshold() == 0.2
+    assert native.CafScored.get_default_score_th() == 0.3 and native.NMSKeypoints.get_suppression() == 1e-5
