@@ -1,0 +1,303 @@
+#!/usr/bin/env python
+"""bench.py -- images/s end-to-end (backbone + CifCaf decode) on N MI355X.
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (for N>1 launched by
+``torch.distributed.run`` with one rank per GPU) prints ONE JSON line on rank 0.
+
+A step = one pass of the inference path over one batch resident in HBM:
+  1. backbone + CIF/CAF heads (ResNet-50 @ 641x641, random init, PyTorch-ROCm)
+     on a synthetic image batch -- the real network work;
+  2. the HIP CifCaf decode (CifHr -> CifSeeds -> CafScored -> association -> NMS)
+     of COCO-shaped synthetic field tensors of exactly the heads' output shapes.
+     A randomly initialised head emits structureless fields, so decode inputs are
+     injected after the heads.  They are resident in HBM before
+     the timed region; nothing is skipped or cached;
+  3. final annotations: device -> pinned host copy; with N > 1 an RCCL all_gather
+     of the fixed-size annotation blocks over xGMI (images shard one batch per GPU,
+     no other collective).
+The decode runs on a second HIP stream so that batch i's decode overlaps batch
+i+1's backbone.
+
+Besides the contract fields the line carries
+  "roofline":     HBM roofline of the decode kernel that dominates the decode time,
+                  from per-kernel HIP-event timings on the launch stream;
+  "cpu_baseline": the reference CPU decoder (oracle/_ref, the reference's own C++)
+                  timed on this box's host cores on a bounded sample of the same fields.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
+
+
+def parse_args():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=20)
+    p.add_argument('--warmup', type=int, default=3)
+    p.add_argument('--batch', type=int, default=32, help='images per GPU per step')
+    p.add_argument('--backbone', default='resnet50')
+    p.add_argument('--backbone-dtype', default='bf16', choices=('bf16', 'fp16', 'fp32'))
+    p.add_argument('--long-edge', type=int, default=641)
+    p.add_argument('--no-overlap', action='store_true', help='decode on the backbone stream')
+    p.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline budget (rank 0, N=1)')
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--decode-only', action='store_true', help='skip the backbone (kernel work only)')
+    p.add_argument('--profile-steps', type=int, default=5)
+    return p.parse_args()
+
+
+def algorithmic_bytes(B, F, A, H, W, stride, max_ann):
+    """Per-launch algorithmic HBM bytes of each decode kernel."""
+    hw = H * W
+    rows, cols = (H - 1) * stride + 1, (W - 1) * stride + 1
+    return {
+        'cif_active_kernel': B * F * 4 * hw * 4,                 # reads conf,x,y,scale planes
+        'cifhr_tile_kernel': B * F * rows * cols * 4,            # writes the high-res map once
+        'cifseeds_fill_kernel': B * F * hw * 4,                  # reads the confidence plane
+        'cifseeds_sort_kernel': 0,
+        'cafscored_kernel': B * A * 7 * hw * 4,                  # reads the 7 used component planes
+        'memset_occupancy': B * F * (rows // 2 + 1) * (cols // 2 + 1),
+        'cifcaf_assoc_kernel': B * max_ann * F * 4 * 4,          # writes the annotations (lists are data dependent)
+        'decode_path': B * (F * 5 * hw * 4 + A * 8 * hw * 4 + max_ann * F * 4 * 4),   # 6.24 MB/img
+    }
+
+
+def cpu_baseline(cifs, cafs, skeleton0, seconds):
+    """The reference's own C++ decoder (oracle/_ref) on host cores: 1 thread and all cores."""
+    from oracle import reference
+    if not reference.available():
+        from oracle import port
+        kind, decode = 'port', lambda c, f: port.decode(c, 8, f, 8, skeleton0)
+        torch_ = None
+    else:
+        torch_ = reference.load()
+        torch_.set_num_threads(1)
+        reference.reset_statics()
+        kind = 'reference'
+        skel_t = torch_.as_tensor(skeleton0, dtype=torch_.int64)
+
+        def decode(c, f):
+            dec = torch_.classes.openpifpaf_decoder.CifCaf(int(c.shape[0]), skel_t)   # fresh instance per image
+            return dec.call(torch_.from_numpy(c), 8, torch_.from_numpy(f), 8)
+    n = len(cifs)
+    decode(cifs[0], cafs[0])                       # warm-up
+    t0 = time.perf_counter()
+    done = 0
+    while True:
+        decode(cifs[done % n], cafs[done % n])
+        done += 1
+        if done >= n and time.perf_counter() - t0 > seconds * 0.5:
+            break
+        if time.perf_counter() - t0 > seconds:
+            break
+    single = done / (time.perf_counter() - t0)
+
+    # all host cores: the reference's --decoder-workers mechanism is a fork pool
+    # (reference decoder/decoder.py:33-47,130-131); N = os.cpu_count()
+    cores = os.cpu_count() or 1
+    multi = None
+    try:
+        import multiprocessing as mp
+        ctx = mp.get_context('fork')
+        per_worker = max(4, int(single * seconds * 0.4))
+
+        def work(i, q):
+            if torch_ is not None:
+                torch_.set_num_threads(1)
+            t = time.perf_counter()
+            for k in range(per_worker):
+                decode(cifs[(i + k) % n], cafs[(i + k) % n])
+            q.put(time.perf_counter() - t)
+        q = ctx.Queue()
+        procs = [ctx.Process(target=work, args=(i, q)) for i in range(cores)]
+        t0 = time.perf_counter()
+        for pr in procs:
+            pr.start()
+        for pr in procs:
+            pr.join()
+        multi = cores * per_worker / (time.perf_counter() - t0)
+    except Exception as e:   # pragma: no cover
+        multi = None
+        print('cpu_baseline: multi-process leg failed: %r' % (e,), file=sys.stderr)
+    return {
+        'value': round(single, 2), 'unit': 'images/s (decode only, 1 thread)', 'cores': 1, 'kind': kind,
+        'all_cores_value': round(multi, 2) if multi else None, 'all_cores': cores,
+        'sample': '%d decodes of the rank-0 batch fields (fresh decoder per image), single thread; '
+                  'then %d forked workers' % (done, cores),
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)      # backend "nccl" is RCCL on ROCm
+    if args.gpus != world and rank == 0 and world > 1:
+        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+
+    from openpifpaf_amd import _lib, constants, headmeta, native, network, synth
+
+    B = args.batch
+    cif_meta, caf_meta = headmeta.cocokp_metas()
+    skeleton0 = np.asarray(constants.COCO_PERSON_SKELETON, dtype=np.int64) - 1
+    dtype = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}[args.backbone_dtype]
+
+    # ---- model + resident inputs
+    model = None
+    if not args.decode_only:
+        model = network.factory(args.backbone, [cif_meta, caf_meta]).to(device)
+        network.fuse_conv_bn_(model)
+        model = model.to(memory_format=torch.channels_last)
+        if dtype != torch.float32:
+            model = model.to(dtype)
+    g = torch.Generator(device='cpu').manual_seed(1000 + rank)
+    images = torch.randn((B, 3, args.long_edge, args.long_edge), generator=g).to(device)
+    images = images.contiguous(memory_format=torch.channels_last)
+    if dtype != torch.float32:
+        images = images.to(dtype)
+    fh = (args.long_edge - 1) // 16 * 2 + 1            # 641 -> 41 -> 82 -> 81
+    cifs_np, cafs_np = synth.synth_batch(B, seed0=rank * B, height=fh, width=fh)
+    cif_syn = torch.from_numpy(cifs_np).to(device)
+    caf_syn = torch.from_numpy(cafs_np).to(device)
+    stride = cif_meta.stride
+
+    dec = native.CifCaf(17, torch.from_numpy(skeleton0))
+    K = 17
+    host_out = torch.empty((B, dec.max_annotations, K, 4), dtype=torch.float32).pin_memory()
+    host_counts = torch.empty((B,), dtype=torch.int32).pin_memory()
+    main_stream = torch.cuda.current_stream()
+    dec_stream = main_stream if args.no_overlap else torch.cuda.Stream()
+    gathered = None
+    if world > 1:
+        gathered = [torch.empty((B, dec.max_annotations, K, 4), dtype=torch.float32, device=device)
+                    for _ in range(world)]
+        gathered_counts = [torch.empty((B,), dtype=torch.int32, device=device) for _ in range(world)]
+
+    shapes_checked = [False]
+
+    def step():
+        if model is not None:
+            with torch.no_grad():
+                heads = model(images)
+            if not shapes_checked[0]:
+                assert tuple(heads[0].shape) == tuple(cif_syn.shape), (heads[0].shape, cif_syn.shape)
+                assert tuple(heads[1].shape) == tuple(caf_syn.shape), (heads[1].shape, caf_syn.shape)
+                shapes_checked[0] = True
+        ev = torch.cuda.Event()
+        ev.record(main_stream)
+        with torch.cuda.stream(dec_stream):
+            dec_stream.wait_event(ev)                  # decode of batch i follows its backbone
+            out, ids, counts = dec.call_batch(cif_syn, stride, caf_syn, stride)
+            if world > 1:
+                import torch.distributed as dist
+                dist.all_gather(gathered, out)         # final annotations only, over xGMI
+                dist.all_gather(gathered_counts, counts)
+            host_out.copy_(out, non_blocking=True)
+            host_counts.copy_(counts, non_blocking=True)
+        return out
+
+    def sync_all():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_ann = int(host_counts.clamp(max=dec.max_annotations).sum())
+
+    # ---- rank 0: roofline leg (per-kernel HIP-event timings) and CPU baseline
+    result = None
+    if rank == 0:
+        per_kernel = {}
+        with torch.cuda.stream(dec_stream):
+            for _ in range(max(1, args.profile_steps)):
+                _lib.profile_begin(native._stream())
+                dec.call_batch(cif_syn, stride, caf_syn, stride)
+                for name, ms in _lib.profile_end():
+                    per_kernel.setdefault(name, []).append(ms)
+        avg_ms = {k: float(np.mean(v)) for k, v in per_kernel.items()}
+        alg = algorithmic_bytes(B, 17, 19, fh, fh, stride, dec.max_annotations)
+        decode_ms = sum(avg_ms.values())
+        dominant = max(avg_ms, key=avg_ms.get)
+        dom_bytes = alg.get(dominant, 0)
+        achieved = dom_bytes / (avg_ms[dominant] * 1e-3) / 1e9 if avg_ms[dominant] > 0 else 0.0
+        roofline = {
+            'bound': 'hbm', 'kernel': dominant, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBPS,
+            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5), 'traffic': None,
+            'avg_launch_ms': round(avg_ms[dominant], 4), 'algorithmic_bytes_per_launch': dom_bytes,
+            'kernels': {k: {'ms': round(v, 4),
+                            'GBps': round(alg.get(k, 0) / (v * 1e-3) / 1e9, 1) if v > 0 else None}
+                        for k, v in avg_ms.items()},
+            'decode_path': {'ms_per_batch': round(decode_ms, 4),
+                            'images_per_s': round(B / (decode_ms * 1e-3), 1),
+                            'GBps': round(alg['decode_path'] / (decode_ms * 1e-3) / 1e9, 2),
+                            'frac': round(alg['decode_path'] / (decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
+        }
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(cifs_np, cafs_np, skeleton0, args.cpu_seconds)
+        value = world * B * args.steps / elapsed
+        result = {
+            'metric': 'images/sec end-to-end (backbone+CifCaf decode), resnet50 641px',
+            'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {
+                'workload': 'configs[1] scaled to a batch: %s %dx%d, batch %d per GPU, COCO-17 CIF/CAF fields '
+                            '[%d,17,5,%d,%d]+[%d,19,8,%d,%d]' % (args.backbone, args.long_edge, args.long_edge,
+                                                                 B, B, fh, fh, B, fh, fh),
+                'backbone': 'none (decode only)' if model is None else args.backbone,
+                'backbone_dtype': args.backbone_dtype, 'decode_dtype': 'f32 (+f64 where the reference uses double)',
+                'global_batch': world * B, 'fields': 'COCO-shaped synthetic fields injected after the heads '
+                                                    '(people per image cycle %s)' % (list(synth.PEOPLE_CYCLE),),
+                'parallelism': 'images sharded one batch per GPU (dp%d); RCCL all_gather of annotations' % world
+                               if world > 1 else 'single GPU',
+                'decode_overlapped_on_second_stream': not args.no_overlap,
+                'annotations_per_batch': n_ann,
+            },
+            'roofline': roofline,
+            'cpu_baseline': cpu,
+        }
+        if cpu is not None:
+            result['decode_vs_cpu_1thread'] = round(roofline['decode_path']['images_per_s'] / cpu['value'], 1)
+        print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+if __name__ == '__main__':
+    main()

@@ -178,6 +178,16 @@ int opa_cafscored_fill(const float* caf_dev, int32_t batch, int32_t n_caf, int32
 int opa_grow_connection_blend(const float* rows_dev, int32_t n, double x, double y, double s,
                               double filter_sigmas, int32_t only_max, double* out_host, void* stream);
 
+/* ---- measurement -------------------------------------------------------- */
+/* Per-kernel timing with HIP events on the launch stream (no reference
+ * counterpart; bench.py's roofline leg uses it).  Between opa_profile_begin and
+ * opa_profile_end every kernel/memset the library enqueues from THIS host thread
+ * is followed by an event record; opa_profile_end synchronises the stream and
+ * returns, per enqueued operation in order, its name (static string) and the
+ * elapsed milliseconds since the previous event. */
+int opa_profile_begin(void* stream);
+int opa_profile_end(int32_t capacity, const char** names_out, float* ms_out, int32_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,1 +1,41 @@
-"""MI355X-native CifCaf decode path."""
+"""MI355X-native CifCaf decode path behind the OpenPifPaf decoder plugin API.
+
+See DESIGN.md (what is built and why) and INTEGRATION.md (how it binds to the
+reference).  The compute lives in ``lib/libopenpifpaf_amd.so`` (hand-written
+HIP for gfx950, C ABI in ``include/openpifpaf_amd.h``); this package is the
+host-side mirror of the reference's decoder interface.  There is no CPU
+fallback: using the decode path without the built library / without a GPU raises.
+"""
+from . import constants, headmeta, synth                      # noqa: F401  (light, no torch)
+
+__version__ = '0.1.0'
+
+_LAZY = {
+    'Annotation': ('annotation', 'Annotation'),
+    'Predictor': ('predictor', 'Predictor'),
+    'DECODERS': ('decoder', 'DECODERS'),
+    'Decoder': ('decoder', 'Decoder'),
+    'CifCaf': ('decoder', 'CifCaf'),
+}
+
+
+def __getattr__(name):
+    import importlib
+    if name in _LAZY:
+        mod, attr = _LAZY[name]
+        return getattr(importlib.import_module('.' + mod, __name__), attr)
+    if name in ('decoder', 'native', 'network', 'predictor', 'annotation', '_lib', 'build'):
+        return importlib.import_module('.' + name, __name__)
+    raise AttributeError(name)
+
+
+def register():
+    """Plugin entry point (reference ``plugin.py:17-40`` discovers importable modules whose
+    name starts with ``openpifpaf_`` and calls ``register()``): make the HIP-backed
+    ``CifCaf`` the decoder a host ``openpifpaf`` installation selects."""
+    from . import decoder
+    try:
+        import openpifpaf
+    except ImportError:
+        return
+    openpifpaf.DECODERS = {d for d in openpifpaf.DECODERS if d.__name__ != 'CifCaf'} | {decoder.CifCaf}

@@ -90,6 +90,8 @@ SYMBOLS = {
     'opa_cafscored_fill': (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32,
                                           _vp, _dbl, _dbl, _P(Params), _vp, _vp, _vp]),
     'opa_grow_connection_blend': (ctypes.c_int, [_vp, _i32, _dbl, _dbl, _dbl, _dbl, _i32, _P(_dbl), _vp]),
+    'opa_profile_begin': (ctypes.c_int, [_vp]),
+    'opa_profile_end': (ctypes.c_int, [_i32, _P(ctypes.c_char_p), _P(ctypes.c_float), _P(_i32)]),
 }
 
 _lib = None
@@ -140,3 +142,16 @@ def get_params():
 
 def set_params(p):
     check(lib().opa_set_params(ctypes.byref(p)), 'opa_set_params')
+
+
+def profile_begin(stream_ptr):
+    check(lib().opa_profile_begin(stream_ptr), 'opa_profile_begin')
+
+
+def profile_end(capacity=64):
+    """-> list of (kernel name, milliseconds) in launch order."""
+    names = (ctypes.c_char_p * capacity)()
+    ms = (ctypes.c_float * capacity)()
+    n = ctypes.c_int32()
+    check(lib().opa_profile_end(capacity, names, ms, ctypes.byref(n)), 'opa_profile_end')
+    return [(names[i].decode(), float(ms[i])) for i in range(min(n.value, capacity))]

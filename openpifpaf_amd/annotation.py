@@ -1,0 +1,95 @@
+"""Pose annotation object the decoder returns: the part of the reference's
+``openpifpaf.annotation.Annotation`` (reference ``annotation.py:16-143``) that
+``Predictor`` and JSON output use."""
+import numpy as np
+
+
+class Annotation:
+    def __init__(self, keypoints, skeleton, sigmas=None, *, categories=None, score_weights=None):
+        self.keypoints = keypoints
+        self.skeleton = skeleton
+        self.sigmas = sigmas
+        self.categories = categories
+        self.score_weights = score_weights
+        self.category_id = 1
+        self.data = np.zeros((len(keypoints), 3), dtype=np.float32)          # x, y, v
+        self.joint_scales = np.zeros((len(keypoints),), dtype=np.float32)
+        self.fixed_score = None
+        self.fixed_bbox = None
+        self.decoding_order = []
+        self.frontier_order = []
+        if score_weights is None:
+            self.score_weights = np.ones((len(keypoints),))
+        else:
+            assert len(score_weights) == len(keypoints), 'wrong number of scores'
+            self.score_weights = np.asarray(score_weights, dtype=np.float64)
+        self.score_weights = self.score_weights / np.sum(self.score_weights)
+
+    @property
+    def score(self):
+        """Weighted instance score over the confidence-sorted joints (reference
+        ``annotation.py:98-110``); NOT the plain mean the native NMS uses."""
+        if self.fixed_score is not None:
+            return self.fixed_score
+        v = self.data[:, 2]
+        return float(np.sum(self.score_weights * np.sort(v)[::-1]))
+
+    def bbox(self):
+        if self.fixed_bbox is not None:
+            return self.fixed_bbox
+        m = self.data[:, 2] > 0
+        if not np.any(m):
+            return [0, 0, 0, 0]
+        x = self.data[m, 0] - self.joint_scales[m]
+        y = self.data[m, 1] - self.joint_scales[m]
+        w = self.data[m, 0] + self.joint_scales[m]
+        h = self.data[m, 1] + self.joint_scales[m]
+        x0, y0 = float(x.min()), float(y.min())
+        return [x0, y0, float(w.max()) - x0, float(h.max()) - y0]
+
+    def json_data(self, coordinate_digits=2):
+        """Reference ``annotation.py:121-143``."""
+        v_mask = self.data[:, 2] > 0.0
+        keypoints = np.copy(self.data)
+        keypoints[v_mask, 2] = np.maximum(0.01, keypoints[v_mask, 2])
+        keypoints = np.around(keypoints.astype(np.float64), coordinate_digits)
+        data = {
+            'keypoints': keypoints.reshape(-1).tolist(),
+            'bbox': [round(float(c), coordinate_digits) for c in self.bbox()],
+            'score': max(0.001, round(self.score, 3)),
+            'category_id': self.category_id,
+        }
+        id_ = getattr(self, 'id_', None)
+        if id_:
+            data['id_'] = id_
+        return data
+
+    def inverse_transform(self, meta):
+        """Undo pad / rescale / hflip recorded in ``meta`` (reference ``annotation.py:162-200``)."""
+        import copy
+        import math
+        ann = copy.deepcopy(self)
+        if meta is None:
+            return ann
+        rot = meta.get('rotation')
+        if rot is not None and rot.get('angle', 0.0) != 0.0:
+            angle = -rot['angle']
+            rw, rh = rot['width'], rot['height']
+            ca, sa = math.cos(angle / 180.0 * math.pi), math.sin(angle / 180.0 * math.pi)
+            x_old = ann.data[:, 0].copy() - (rw - 1) / 2
+            y_old = ann.data[:, 1].copy() - (rh - 1) / 2
+            ann.data[:, 0] = (rw - 1) / 2 + ca * x_old + sa * y_old
+            ann.data[:, 1] = (rh - 1) / 2 - sa * x_old + ca * y_old
+        offset = np.asarray(meta.get('offset', (0.0, 0.0)), dtype=np.float32)
+        scale = np.asarray(meta.get('scale', (1.0, 1.0)), dtype=np.float32)
+        ann.data[:, 0] += offset[0]
+        ann.data[:, 1] += offset[1]
+        ann.data[:, 0] = ann.data[:, 0] / scale[0]
+        ann.data[:, 1] = ann.data[:, 1] / scale[1]
+        ann.joint_scales = ann.joint_scales / scale[0]
+        if meta.get('hflip'):
+            w = meta['width_height'][0]
+            ann.data[:, 0] = -ann.data[:, 0] + (w - 1)
+            if meta.get('horizontal_swap'):
+                ann.data[:] = meta['horizontal_swap'](ann.data)
+        return ann

@@ -88,6 +88,7 @@ hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int 
                             float* lists, int32_t* counts, hipStream_t st) {
     cafscored_kernel<<<B * A, 256, 0, st>>>(caf, A, cH * cW, cstride, cifhr, F, hr_rows, hr_cols, hr_pitch,
                                             skeleton, score_th, cif_floor, no_rescore, lists, counts);
+    prof_mark(st, "cafscored_kernel");
     return hipGetLastError();
 }
 

@@ -27,6 +27,23 @@ static opa_params default_params() {
 }
 static opa_params g_params = default_params();
 
+struct Profiler {
+    bool on = false;
+    hipStream_t st = nullptr;
+    std::vector<hipEvent_t> events;
+    std::vector<const char*> names;
+};
+static thread_local Profiler g_prof;
+
+void prof_mark(hipStream_t st, const char* name) {
+    if (!g_prof.on || st != g_prof.st) return;
+    hipEvent_t ev;
+    if (hipEventCreate(&ev) != hipSuccess) return;
+    if (hipEventRecord(ev, st) != hipSuccess) { (void)hipEventDestroy(ev); return; }
+    g_prof.events.push_back(ev);
+    g_prof.names.push_back(name);
+}
+
 static int fail(int code, const std::string& msg) { g_error = msg; return code; }
 static int fail_hip(hipError_t e, const char* where) {
     g_error = std::string(where) + ": " + hipGetErrorString(e);
@@ -191,7 +208,7 @@ int opa_cifcaf_create(opa_cifcaf** out, int32_t n_keypoints, const int64_t* skel
     std::memcpy(host.data() + skel_bytes + off_bytes + 2 * e_bytes, s_fwd.data(), sizeof(int32_t) * E);
     std::memcpy(host.data() + skel_bytes + off_bytes + 3 * e_bytes, first.data(), sizeof(int32_t) * E);
     e = hipMemcpy(block, host.data(), total, hipMemcpyHostToDevice);
-    if (e != hipSuccess) { hipFree(block); return fail_hip(e, "opa_cifcaf_create: hipMemcpy"); }
+    if (e != hipSuccess) { (void)hipFree(block); return fail_hip(e, "opa_cifcaf_create: hipMemcpy"); }
 
     opa_cifcaf* d = new opa_cifcaf();
     d->K = K; d->A = A;
@@ -204,14 +221,14 @@ int opa_cifcaf_create(opa_cifcaf** out, int32_t n_keypoints, const int64_t* skel
     d->dev.adj_bone = (const int32_t*)(base + skel_bytes + off_bytes + 1 * e_bytes);
     d->dev.adj_fwd = (const int32_t*)(base + skel_bytes + off_bytes + 2 * e_bytes);
     d->dev.adj_first = (const int32_t*)(base + skel_bytes + off_bytes + 3 * e_bytes);
-    hipGetDevice(&d->device);
+    (void)hipGetDevice(&d->device);
     *out = d;
     return OPA_OK;
 }
 
 void opa_cifcaf_destroy(opa_cifcaf* dec) {
     if (!dec) return;
-    if (dec->dev_block) hipFree(dec->dev_block);
+    if (dec->dev_block) (void)hipFree(dec->dev_block);
     delete dec;
 }
 
@@ -293,6 +310,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     }
     e = hipMemsetAsync(ws + L.off_occ, 0, (size_t)L.B * L.F * L.occ_h * L.occ_w, st);        // :173
     if (e != hipSuccess) return fail_hip(e, "occupancy memset");
+    prof_mark(st, "memset_occupancy");
 
     AssocArgs a;
     a.B = L.B; a.K = L.F; a.A = L.A; a.max_ann = L.max_ann; a.n_initial = n_initial;
@@ -394,8 +412,37 @@ int opa_grow_connection_blend(const float* rows_dev, int32_t n, double x, double
     e = launch_blend(rows_dev, n, x, y, s, filter_sigmas, only_max, (double*)tmp, (hipStream_t)stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out_host, tmp, 4 * sizeof(double), hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-    hipFree(tmp);
+    (void)hipFree(tmp);
     if (e != hipSuccess) return fail_hip(e, "opa_grow_connection_blend");
+    return OPA_OK;
+}
+
+int opa_profile_begin(void* stream) {
+    for (hipEvent_t ev : g_prof.events) (void)hipEventDestroy(ev);
+    g_prof.events.clear(); g_prof.names.clear();
+    g_prof.st = (hipStream_t)stream;
+    g_prof.on = true;
+    prof_mark(g_prof.st, "begin");
+    if (g_prof.events.empty()) { g_prof.on = false; return fail(OPA_ERR_HIP, "opa_profile_begin: cannot record an event"); }
+    return OPA_OK;
+}
+
+int opa_profile_end(int32_t capacity, const char** names_out, float* ms_out, int32_t* n_out) {
+    if (!g_prof.on) return fail(OPA_ERR_INVALID_ARGUMENT, "opa_profile_end: no profile in progress");
+    g_prof.on = false;
+    hipError_t e = hipStreamSynchronize(g_prof.st);
+    if (e != hipSuccess) return fail_hip(e, "opa_profile_end: sync");
+    int32_t n = 0;
+    for (size_t i = 1; i < g_prof.events.size(); i++) {
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, g_prof.events[i - 1], g_prof.events[i]);
+        if (e != hipSuccess) return fail_hip(e, "opa_profile_end: elapsed");
+        if (n < capacity) { if (names_out) names_out[n] = g_prof.names[i]; if (ms_out) ms_out[n] = ms; }
+        n++;
+    }
+    if (n_out) *n_out = n;
+    for (hipEvent_t ev : g_prof.events) (void)hipEventDestroy(ev);
+    g_prof.events.clear(); g_prof.names.clear();
     return OPA_OK;
 }
 

@@ -530,6 +530,7 @@ hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevPara
         if (e != hipSuccess) return e;
     }
     cifcaf_assoc_kernel<<<a.B, 64, lds, st>>>(a, sk, p);
+    prof_mark(st, "cifcaf_assoc_kernel");
     return hipGetLastError();
 }
 

@@ -166,10 +166,12 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
     if (p.ablation_cifhr_skip) {                      // cif_hr.cpp:29
         hipError_t e = hipMemsetAsync(act_count, 0, sizeof(int32_t) * planes, st);
         if (e != hipSuccess) return e;
+        prof_mark(st, "memset_act_count");
     } else {
         const float min_scale_f = (float)(min_scale / (double)stride);       // cif_hr.cpp:32
         cif_active_kernel<<<planes, 256, 0, st>>>(cif, HW, stride, min_scale_f, p.cif_threshold,
                                                    (float)p.cifhr_neighbors, factor, act, act_count);
+        prof_mark(st, "cif_active_kernel");
     }
     const int tiles_x = hr_pitch / kHrTileW;
     const int tiles_y = (hr_rows + kHrTileH - 1) / kHrTileH;
@@ -177,6 +179,7 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
     const unsigned grid = (unsigned)((total + 3) / 4);
     cifhr_tile_kernel<<<grid, 256, 0, st>>>(act, act_count, HW, cifhr, hr_rows, hr_cols, hr_pitch,
                                              tiles_x, tiles_y, total);
+    prof_mark(st, "cifhr_tile_kernel");
     return hipGetLastError();
 }
 

@@ -174,12 +174,15 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
     const int HW = H * W, cap = F * HW;
     hipError_t e = hipMemsetAsync(seed_count, 0, sizeof(int32_t) * B, st);
     if (e != hipSuccess) return e;
+    prof_mark(st, "memset_seed_count");
     dim3 grid(B * F, (HW + 255) / 256);
     cifseeds_fill_kernel<<<grid, 256, 0, st>>>(cif, F, H, W, stride, cifhr, hr_rows, hr_cols, hr_pitch,
                                                p.seed_threshold, p.ablation_cifseeds_nms,
                                                p.ablation_cifseeds_no_rescore, keys, sort_cap, cap, seed_count);
+    prof_mark(st, "cifseeds_fill_kernel");
     cifseeds_sort_kernel<<<B, 1024, 0, st>>>(keys, sort_cap, cap, seed_count, cif, F, HW, stride,
                                              seed_f, seed_vxys);
+    prof_mark(st, "cifseeds_sort_kernel");
     return hipGetLastError();
 }
 

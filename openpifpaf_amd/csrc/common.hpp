@@ -58,6 +58,9 @@ struct DevSkeleton {
                                //       (duplicate bones share one frontier slot, cifcaf.cpp:329,361-374)
 };
 
+// profiling hook: records an event after an enqueued operation when profiling is on
+void prof_mark(hipStream_t st, const char* name);
+
 // ---- kernel launchers (one per .hip file) ---------------------------------
 hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride,
                         double min_scale, double factor, const DevParams& p,

@@ -1,0 +1,362 @@
+"""Decoder plugin layer: the reference's ``openpifpaf.decoder`` interface for the
+CifCaf path, backed by the HIP library.
+
+Mirrors (same names, argument meaning and error behaviour):
+
+* ``Decoder`` base -- reference ``decoder/decoder.py:21-145`` (``cli``, ``configure``,
+  ``factory``, ``__call__``, ``fields_batch``, ``batch``, ``last_nn_time`` /
+  ``last_decoder_time``, pickling without the worker pool).
+* ``CifCaf`` -- reference ``decoder/cifcaf.py:81-277``.  ``__call__(fields)`` takes the
+  per-image list of head tensors; ``batch(model, image_batch)`` is overridden to keep
+  the head outputs ON THE DEVICE and decode the whole batch with one native call
+  (the reference copies every head to the host, ``decoder.py:96-100``, and decodes
+  image by image, optionally in a fork pool, ``decoder.py:130-131``).
+* ``DECODERS`` / ``factory`` / ``cli`` / ``configure`` / ``Multi`` -- reference
+  ``decoder/factory.py:17-172`` and ``decoder/multi.py:11-35``.
+* ``register()`` (package level) adds ``CifCaf`` to a host ``openpifpaf.DECODERS`` so
+  that the reference's ``--decoder=cifcaf:0`` selects it (plugin discovery,
+  reference ``plugin.py:17-40``: this package's name starts with ``openpifpaf_``).
+"""
+import argparse
+import logging
+import time
+from collections import defaultdict
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import headmeta, native
+from .annotation import Annotation
+
+LOG = logging.getLogger(__name__)
+
+
+class Decoder:
+    """Generate predictions from image or field inputs (reference ``decoder.py:21``)."""
+    default_worker_pool = None
+    torch_decoder = True
+
+    def __init__(self):
+        self.priority = 0.0
+        self.worker_pool = None      # the device decodes whole batches; no fork pool needed
+        self.last_decoder_time = 0.0
+        self.last_nn_time = 0.0
+
+    @classmethod
+    def cli(cls, parser: argparse.ArgumentParser):
+        """Command line interface (CLI) to extend argument parser."""
+
+    @classmethod
+    def configure(cls, args: argparse.Namespace):
+        """Take the parsed argument parser output and configure class variables."""
+
+    @classmethod
+    def factory(cls, head_metas) -> List['Decoder']:
+        raise NotImplementedError
+
+    def __call__(self, fields, *, initial_annotations=None) -> List[Annotation]:
+        raise NotImplementedError
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in ('worker_pool',)}
+
+    @classmethod
+    def fields_batch(cls, model, image_batch, *, device=None, to_cpu=False):
+        """From image batch to per-image field lists.  Unlike the reference
+        (``decoder.py:76-112``) the heads stay on the device unless ``to_cpu``."""
+        with torch.no_grad():
+            if device is not None:
+                image_batch = image_batch.to(device, non_blocking=True)
+            heads = model(image_batch)
+            if to_cpu:
+                heads = [h.cpu() for h in heads]
+        return [[h[b] for h in heads] for b in range(len(image_batch))]
+
+    def batch(self, model, image_batch, *, device=None, gt_anns_batch=None):
+        """From image batch straight to annotations batch (reference ``decoder.py:114-137``)."""
+        start_nn = time.perf_counter()
+        fields_batch = self.fields_batch(model, image_batch, device=device)
+        self.last_nn_time = time.perf_counter() - start_nn
+        start_decoder = time.perf_counter()
+        result = [self(fields) for fields in fields_batch]
+        self.last_decoder_time = time.perf_counter() - start_decoder
+        return result
+
+
+class CifCaf(Decoder):
+    """Generate CifCaf poses from fields on the MI355X."""
+    connection_method = 'blend'
+    nms_before_force_complete = False
+    reverse_match = True
+    max_annotations = native.DEFAULT_MAX_ANNOTATIONS
+
+    def __init__(self, cif_metas: List[headmeta.Cif], caf_metas: List[headmeta.Caf]):
+        super().__init__()
+        self.cif_metas = cif_metas
+        self.caf_metas = caf_metas
+        self.score_weights = cif_metas[0].score_weights
+        self.confidence_scales = caf_metas[0].decoder_confidence_scales
+        self.cpp_decoder = native.CifCaf(
+            len(cif_metas[0].keypoints),
+            torch.LongTensor(caf_metas[0].skeleton) - 1,          # reference cifcaf.py:119-122
+            max_annotations=self.max_annotations,
+        )
+        # prefer decoders with more keypoints and associations (reference cifcaf.py:123-125)
+        self.priority += sum(m.n_fields for m in cif_metas) / 1000.0
+        self.priority += sum(m.n_fields for m in caf_metas) / 1000.0
+
+    @classmethod
+    def cli(cls, parser: argparse.ArgumentParser):
+        """Reference ``cifcaf.py:127-172``."""
+        C = native.CifCaf
+        group = parser.add_argument_group('CifCaf decoder')
+        group.add_argument('--force-complete-pose', default=False, action='store_true')
+        group.add_argument('--force-complete-caf-th', type=float, default=C.get_force_complete_caf_th(),
+                           help='CAF threshold for force complete. Set to -1 to deactivate.')
+        group.add_argument('--nms-before-force-complete', default=False, action='store_true',
+                           help='run an additional NMS before completing poses')
+        group.add_argument('--keypoint-threshold', type=float, default=C.get_keypoint_threshold(),
+                           help='filter keypoints by score')
+        group.add_argument('--keypoint-threshold-rel', type=float, default=C.get_keypoint_threshold_rel(),
+                           help='filter keypoint connections by relative score')
+        group.add_argument('--greedy', default=False, action='store_true', help='greedy decoding')
+        group.add_argument('--connection-method', default=cls.connection_method, choices=('max', 'blend'),
+                           help='connection method to use, max is faster')
+        group.add_argument('--cifcaf-block-joints', default=False, action='store_true', help='block joints')
+        group.add_argument('--no-reverse-match', default=True, dest='reverse_match', action='store_false')
+        group.add_argument('--ablation-cifseeds-nms', default=False, action='store_true')
+        group.add_argument('--ablation-cifseeds-no-rescore', default=False, action='store_true')
+        group.add_argument('--ablation-caf-no-rescore', default=False, action='store_true')
+        group.add_argument('--ablation-independent-kp', default=False, action='store_true')
+        group.add_argument('--cifcaf-max-annotations', default=cls.max_annotations, type=int,
+                           help='per-image capacity of the device-side annotation buffer')
+
+    @classmethod
+    def configure(cls, args: argparse.Namespace):
+        """Reference ``cifcaf.py:174-211``: CLI -> the native library's global tunables."""
+        C = native.CifCaf
+        keypoint_threshold_nms = args.keypoint_threshold
+        if args.force_complete_pose:
+            if not args.ablation_independent_kp:
+                args.keypoint_threshold = 0.0
+            args.keypoint_threshold_rel = 0.0
+            keypoint_threshold_nms = 0.0
+        if args.seed_threshold < args.keypoint_threshold:
+            LOG.warning('consistency: decreasing keypoint threshold to seed threshold of %f',
+                        args.seed_threshold)
+            args.keypoint_threshold = args.seed_threshold
+
+        cls.nms_before_force_complete = args.nms_before_force_complete
+        native.NMSKeypoints.set_keypoint_threshold(keypoint_threshold_nms)
+        C.set_force_complete(args.force_complete_pose)
+        C.set_force_complete_caf_th(args.force_complete_caf_th)
+        C.set_keypoint_threshold(args.keypoint_threshold)
+        C.set_keypoint_threshold_rel(args.keypoint_threshold_rel)
+        C.set_greedy(args.greedy)
+        C.set_block_joints(args.cifcaf_block_joints)
+        cls.connection_method = args.connection_method
+        cls.reverse_match = args.reverse_match
+        C.set_reverse_match(args.reverse_match)
+        native.CifSeeds.set_ablation_nms(args.ablation_cifseeds_nms)
+        native.CifSeeds.set_ablation_no_rescore(args.ablation_cifseeds_no_rescore)
+        native.CafScored.set_ablation_no_rescore(args.ablation_caf_no_rescore)
+        if args.ablation_cifseeds_no_rescore and args.ablation_caf_no_rescore:
+            native.CifHr.set_ablation_skip(True)
+        cls.max_annotations = getattr(args, 'cifcaf_max_annotations', cls.max_annotations)
+
+    @classmethod
+    def factory(cls, head_metas):
+        """Reference ``cifcaf.py:213-222``."""
+        return [
+            cls([meta], [meta_next])
+            for meta, meta_next in zip(head_metas[:-1], head_metas[1:])
+            if isinstance(meta, headmeta.Cif) and isinstance(meta_next, headmeta.Caf)
+        ]
+
+    # ---- tensors <-> Annotation objects -------------------------------------------
+    def _annotations_py(self, ann_data: np.ndarray, ann_ids: np.ndarray) -> List[Annotation]:
+        """Reference ``cifcaf.py:262-272``: native (v,x,y,s) rows -> Annotation (x,y,v) + joint_scales."""
+        out = []
+        for data, ann_id in zip(ann_data, ann_ids):
+            ann = Annotation(self.cif_metas[0].keypoints, self.caf_metas[0].skeleton,
+                             score_weights=self.score_weights)
+            ann.data[:, :2] = data[:, 1:3]
+            ann.data[:, 2] = data[:, 0]
+            ann.joint_scales[:] = data[:, 3]
+            if ann_id != -1:
+                ann.id_ = int(ann_id)
+            out.append(ann)
+        return out
+
+    @staticmethod
+    def _initial_tensors(initial_annotations, n_fields):
+        """Reference ``cifcaf.py:225-239``."""
+        if not initial_annotations:
+            return None, None
+        t = torch.empty((len(initial_annotations), n_fields, 4))
+        ids = torch.empty((len(initial_annotations),), dtype=torch.int64)
+        for i, ann_py in enumerate(initial_annotations):
+            for f in range(len(ann_py.data)):
+                t[i, f, 0] = float(ann_py.data[f, 2])
+                t[i, f, 1] = float(ann_py.data[f, 0])
+                t[i, f, 2] = float(ann_py.data[f, 1])
+                t[i, f, 3] = float(ann_py.joint_scales[f])
+            ids[i] = getattr(ann_py, 'id_', -1)
+        return t, ids
+
+    def __call__(self, fields, initial_annotations=None):
+        """Single image: ``fields[meta.head_index]`` are ``[F,C,H,W]`` tensors (device or CPU)."""
+        init_t, ids_t = self._initial_tensors(initial_annotations, self.cif_metas[0].n_fields)
+        start = time.perf_counter()
+        annotations, annotation_ids = self.cpp_decoder.call_with_initial_annotations(
+            fields[self.cif_metas[0].head_index], self.cif_metas[0].stride,
+            fields[self.caf_metas[0].head_index], self.caf_metas[0].stride,
+            init_t, ids_t)
+        annotations = annotations.cpu().numpy()
+        annotation_ids = annotation_ids.cpu().numpy()
+        LOG.debug('native annotations = %d (%.1fms)', len(annotations), (time.perf_counter() - start) * 1000.0)
+        return self._annotations_py(annotations, annotation_ids)
+
+    def decode_heads(self, heads):
+        """Batched device decode of head outputs ``heads[head_index] = [B,F,C,H,W]``.
+        Returns device tensors ``(annotations [B,max,K,4], ids [B,max], counts [B])``; asynchronous."""
+        return self.cpp_decoder.call_batch(
+            heads[self.cif_metas[0].head_index], self.cif_metas[0].stride,
+            heads[self.caf_metas[0].head_index], self.caf_metas[0].stride)
+
+    def batch(self, model, image_batch, *, device=None, gt_anns_batch=None):
+        """Image batch -> annotations batch, fields never leave the device."""
+        start_nn = time.perf_counter()
+        with torch.no_grad():
+            if device is not None:
+                image_batch = image_batch.to(device, non_blocking=True)
+            heads = model(image_batch)
+        if image_batch.is_cuda:
+            torch.cuda.current_stream().synchronize()      # make last_nn_time mean what the reference's does
+        self.last_nn_time = time.perf_counter() - start_nn
+
+        start_decoder = time.perf_counter()
+        out, ids, counts = self.decode_heads(heads)
+        out, ids, counts = out.cpu().numpy(), ids.cpu().numpy(), counts.cpu().numpy()   # one small D2H
+        result = []
+        for b in range(len(counts)):
+            n = int(counts[b])
+            if n > self.cpp_decoder.max_annotations:
+                LOG.warning('image %d: %d annotations dropped (raise --cifcaf-max-annotations)',
+                            b, n - self.cpp_decoder.max_annotations)
+                n = self.cpp_decoder.max_annotations
+            result.append(self._annotations_py(out[b, :n], ids[b, :n]))
+        self.last_decoder_time = time.perf_counter() - start_decoder
+        LOG.debug('time: nn = %.1fms, dec = %.1fms', self.last_nn_time * 1e3, self.last_decoder_time * 1e3)
+        return result
+
+
+class Multi(Decoder):
+    """Reference ``decoder/multi.py:11-35``: run several decoders on the same fields."""
+
+    def __init__(self, decoders):
+        super().__init__()
+        self.decoders = decoders
+
+    def __call__(self, all_fields, *, initial_annotations=None):
+        out = []
+        for task_i, decoder in enumerate(self.decoders):
+            if decoder is None:
+                out.append(None)
+                continue
+            out += decoder(all_fields)
+        return out
+
+    def batch(self, model, image_batch, *, device=None, gt_anns_batch=None):
+        if len(self.decoders) == 1:
+            res = self.decoders[0].batch(model, image_batch, device=device, gt_anns_batch=gt_anns_batch)
+            self.last_nn_time = self.decoders[0].last_nn_time
+            self.last_decoder_time = self.decoders[0].last_decoder_time
+            return res
+        return super().batch(model, image_batch, device=device, gt_anns_batch=gt_anns_batch)
+
+
+DECODERS = {CifCaf}
+
+
+def cli(parser, *, workers=None):
+    """Reference ``decoder/factory.py:20-49``."""
+    group = parser.add_argument_group('decoder configuration')
+    available = [dec.__name__.lower() for dec in DECODERS]
+    group.add_argument('--decoder', default=None, nargs='+',
+                       help='Decoders to be considered: {}.'.format(available))
+    group.add_argument('--seed-threshold', default=native.CifSeeds.get_threshold(), type=float,
+                       help='minimum threshold for seeds')
+    group.add_argument('--instance-threshold', type=float, default=None,
+                       help='filter instances by score (default is 0.0 with --force-complete-pose '
+                            'and {} otherwise)'.format(native.NMSKeypoints.get_instance_threshold()))
+    group.add_argument('--decoder-workers', default=workers, type=int,
+                       help='accepted for compatibility; the device decodes whole batches')
+    group = parser.add_argument_group('CifCaf decoders')
+    group.add_argument('--cif-th', default=native.CifHr.get_threshold(), type=float, help='cif threshold')
+    group.add_argument('--caf-th', default=native.CafScored.get_default_score_th(), type=float,
+                       help='caf threshold')
+    for dec in DECODERS:
+        dec.cli(parser)
+
+
+def configure(args):
+    """Reference ``decoder/factory.py:52-82``."""
+    if args.instance_threshold is None:
+        args.instance_threshold = 0.0 if args.force_complete_pose else native.NMSKeypoints.get_instance_threshold()
+    Factory.decoder_request_from_args(args.decoder)
+    native.CifHr.set_threshold(args.cif_th)
+    native.CifSeeds.set_threshold(args.seed_threshold)
+    native.CafScored.set_default_score_th(args.caf_th)
+    native.NMSKeypoints.set_instance_threshold(args.instance_threshold)
+    for dec in DECODERS:
+        dec.configure(args)
+
+
+class Factory:
+    """Reference ``decoder/factory.py:85-160``."""
+    decoder_request: Optional[dict] = None
+
+    @classmethod
+    def decoder_request_from_args(cls, list_str):
+        if list_str is None:
+            cls.decoder_request = None
+            return
+        cls.decoder_request = defaultdict(list)
+        for dec_str in list_str:
+            if ':' not in dec_str:
+                if dec_str not in cls.decoder_request:
+                    cls.decoder_request[dec_str] = []
+                continue
+            dec_str, _, index = dec_str.partition(':')
+            cls.decoder_request[dec_str].append(int(index))
+
+    @classmethod
+    def decoders(cls, head_metas):
+        def per_class(request, dec_class):
+            class_name = dec_class.__name__.lower()
+            if request is not None and class_name not in request:
+                return []
+            decoders = sorted(dec_class.factory(head_metas), key=lambda d: d.priority, reverse=True)
+            for dec_i, dec in enumerate(decoders):
+                dec.request_index = dec_i
+            if request is not None:
+                indices = set(request[class_name])
+                decoders = (d for i, d in enumerate(decoders) if i in indices)
+            return decoders
+
+        decoders = [d for dec_class in DECODERS for d in per_class(cls.decoder_request, dec_class)]
+        decoders = list(sorted(decoders, key=lambda d: d.priority, reverse=True))
+        if not decoders:
+            LOG.warning('no decoders found for heads %s', [meta.name for meta in head_metas])
+        elif len(decoders) > 1 and cls.decoder_request is None:
+            decoders = [decoders[0]]
+        return decoders
+
+    @classmethod
+    def __call__(cls, head_metas):
+        return Multi(cls.decoders(head_metas))
+
+
+factory = Factory.__call__

@@ -1,0 +1,96 @@
+"""Head meta data: the subset of the reference's ``openpifpaf.headmeta`` the decode
+path reads (reference ``headmeta.py:12-31,36-104``): keypoints/skeleton, the
+field counts and ``stride = base_stride // upsample_stride``."""
+from dataclasses import dataclass, field
+from typing import Any, ClassVar, List, Optional, Tuple
+
+
+@dataclass
+class Base:
+    name: str
+    dataset: str
+
+    head_index: Optional[int] = field(default=None, init=False)
+    base_stride: Optional[int] = field(default=None, init=False)
+    upsample_stride: int = field(default=1, init=False)
+
+    n_confidences: ClassVar[int] = 1
+    n_vectors: ClassVar[int] = 1
+    n_scales: ClassVar[int] = 1
+    vector_offsets: ClassVar[List[bool]] = [True]
+
+    @property
+    def stride(self) -> Optional[int]:
+        if self.base_stride is None:
+            return None
+        return self.base_stride // self.upsample_stride
+
+    @property
+    def n_fields(self) -> int:
+        raise NotImplementedError
+
+
+@dataclass
+class Cif(Base):
+    """Composite Intensity Field: one field per keypoint, components
+    (width, confidence, x, y, scale)."""
+    keypoints: List[str] = None
+    sigmas: List[float] = None
+    pose: Any = None
+    draw_skeleton: Optional[List[Tuple[int, int]]] = None
+    score_weights: Optional[List[float]] = None
+
+    n_confidences: ClassVar[int] = 1
+    n_vectors: ClassVar[int] = 1
+    n_scales: ClassVar[int] = 1
+    vector_offsets: ClassVar[List[bool]] = [True]
+
+    decoder_min_scale = 0.0
+    decoder_seed_mask: Optional[List[int]] = None
+
+    @property
+    def n_fields(self) -> int:
+        return len(self.keypoints)
+
+
+@dataclass
+class Caf(Base):
+    """Composite Association Field: one field per bone, components
+    (width, confidence, x1, y1, x2, y2, scale1, scale2)."""
+    keypoints: List[str] = None
+    sigmas: List[float] = None
+    skeleton: List[Tuple[int, int]] = None      # 1-based joint pairs
+    pose: Any = None
+    sparse_skeleton: Optional[List[Tuple[int, int]]] = None
+    dense_to_sparse_radius: float = 2.0
+    only_in_field_of_view: bool = False
+
+    n_confidences: ClassVar[int] = 1
+    n_vectors: ClassVar[int] = 2
+    n_scales: ClassVar[int] = 2
+    vector_offsets: ClassVar[List[bool]] = [True, True]
+
+    decoder_min_distance = 0.0
+    decoder_max_distance = float('inf')
+    decoder_confidence_scales: Optional[List[float]] = None
+
+    @property
+    def n_fields(self) -> int:
+        return len(self.skeleton)
+
+
+def cocokp_metas(upsample_stride=2, base_stride=16):
+    """The (Cif, Caf) pair of the reference's ``cocokp`` datamodule
+    (reference ``plugins/coco/cocokp.py:68-85``) with the stride the pretrained
+    models use (``--cocokp-upsample=2``)."""
+    from . import constants
+    cif = Cif('cif', 'cocokp', keypoints=constants.COCO_KEYPOINTS, sigmas=constants.COCO_PERSON_SIGMAS,
+              pose=constants.COCO_UPRIGHT_POSE, draw_skeleton=constants.COCO_PERSON_SKELETON,
+              score_weights=constants.COCO_PERSON_SCORE_WEIGHTS)
+    caf = Caf('caf', 'cocokp', keypoints=constants.COCO_KEYPOINTS, sigmas=constants.COCO_PERSON_SIGMAS,
+              pose=constants.COCO_UPRIGHT_POSE, skeleton=constants.COCO_PERSON_SKELETON)
+    for i, m in enumerate((cif, caf)):
+        m.head_index = i
+        m.base_stride = base_stride
+        m.upsample_stride = upsample_stride
+    return cif, caf

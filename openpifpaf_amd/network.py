@@ -1,0 +1,286 @@
+"""Field producers on PyTorch-ROCm: backbones + CompositeField4 heads.
+
+This is the "plumbing" in front of the decode path: plain ``torch.nn`` modules
+(MIOpen / hipBLASLt convolutions, no custom kernels) restated without
+torchvision, with random initialisation (no checkpoints offline).  Architecture
+follows the reference so that the field tensors have the reference's shapes:
+
+* ``Resnet``: torchvision ResNet topology with the input max-pool removed, so
+  the overall stride is 16 (reference ``network/basenetworks.py:71-150``,
+  factories ``network/factory.py:51-57``).
+* ``ShuffleNetV2K``: reference ``network/basenetworks.py:186-355`` (k16: stages
+  [4,8,4], channels [24,348,696,1392,1392]; k30: [8,16,6], [32,512,1024,2048,2048]).
+* ``CompositeField4``: 1x1 conv -> PixelShuffle(2) -> crop last row/col -> view
+  ``[B, F, C, H, W]`` -> sigmoid / index-add / softplus (reference
+  ``network/heads.py:272-378``); 641 px -> 41 -> 82 -> 81.
+* ``Shell``: reference ``network/nets.py:11-48``.
+"""
+import math
+
+import torch
+from torch import nn
+
+from . import headmeta
+
+
+class _Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        return self.relu(out + identity)
+
+
+class _BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + identity)
+
+
+class BaseNetwork(nn.Module):
+    def __init__(self, name, *, stride, out_features):
+        super().__init__()
+        self.name = name
+        self.stride = stride
+        self.out_features = out_features
+
+
+class Resnet(BaseNetwork):
+    """ResNet-18/34/50/101 without the input max-pool: stride 16."""
+    CONFIGS = {
+        'resnet18': (_BasicBlock, [2, 2, 2, 2]),
+        'resnet34': (_BasicBlock, [3, 4, 6, 3]),
+        'resnet50': (_Bottleneck, [3, 4, 6, 3]),
+        'resnet101': (_Bottleneck, [3, 4, 23, 3]),
+    }
+
+    def __init__(self, name='resnet50'):
+        block, layers = self.CONFIGS[name]
+        super().__init__(name, stride=16, out_features=512 * block.expansion)
+        self.inplanes = 64
+        self.input_block = nn.Sequential(
+            nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64), nn.ReLU(inplace=True))
+        self.block2 = self._make_layer(block, 64, layers[0], 1)
+        self.block3 = self._make_layer(block, 128, layers[1], 2)
+        self.block4 = self._make_layer(block, 256, layers[2], 2)
+        self.block5 = self._make_layer(block, 512, layers[3], 2)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+
+    def _make_layer(self, block, planes, blocks, stride):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, 1, stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion))
+        layers = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    def forward(self, x):
+        return self.block5(self.block4(self.block3(self.block2(self.input_block(x)))))
+
+
+def _channel_shuffle(x, groups=2):
+    b, c, h, w = x.shape
+    return x.view(b, groups, c // groups, h, w).transpose(1, 2).reshape(b, c, h, w)
+
+
+class _InvertedResidualK(nn.Module):
+    """ShuffleNetV2 unit with a k x k depthwise conv (reference ``basenetworks.py:186-268``)."""
+
+    def __init__(self, inp, oup, first_in_stage, *, stride=1, kernel_size=5):
+        super().__init__()
+        assert stride in (1, 2) and (stride != 1 or inp == oup)
+        self.first_in_stage = first_in_stage
+        bf = oup // 2
+        pad = (kernel_size - 1) // 2
+        self.branch1 = None
+        if first_in_stage:
+            self.branch1 = nn.Sequential(
+                nn.Conv2d(inp, inp, kernel_size, stride, pad, groups=inp, bias=False), nn.BatchNorm2d(inp),
+                nn.Conv2d(inp, bf, 1, bias=False), nn.BatchNorm2d(bf), nn.ReLU(inplace=True))
+        self.branch2 = nn.Sequential(
+            nn.Conv2d(inp if first_in_stage else bf, bf, 1, bias=False), nn.BatchNorm2d(bf), nn.ReLU(inplace=True),
+            nn.Conv2d(bf, bf, kernel_size, stride, pad, groups=bf, bias=False), nn.BatchNorm2d(bf),
+            nn.Conv2d(bf, bf, 1, bias=False), nn.BatchNorm2d(bf), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        if self.branch1 is None:
+            x1, x2 = x.chunk(2, dim=1)
+            out = torch.cat((x1, self.branch2(x2)), dim=1)
+        else:
+            out = torch.cat((self.branch1(x), self.branch2(x)), dim=1)
+        return _channel_shuffle(out, 2)
+
+
+class ShuffleNetV2K(BaseNetwork):
+    """ShuffleNetV2 with 5x5 depthwise kernels, stride 16 (reference ``basenetworks.py:271-355``)."""
+    CONFIGS = {
+        'shufflenetv2k16': ([4, 8, 4], [24, 348, 696, 1392, 1392]),
+        'shufflenetv2k20': ([5, 10, 5], [32, 512, 1024, 2048, 2048]),
+        'shufflenetv2k30': ([8, 16, 6], [32, 512, 1024, 2048, 2048]),
+        'shufflenetv2k44': ([12, 24, 8], [32, 512, 1024, 2048, 2048]),
+    }
+
+    def __init__(self, name='shufflenetv2k16'):
+        repeats, ch = self.CONFIGS[name]
+        super().__init__(name, stride=16, out_features=ch[-1])
+        self.input_block = nn.Sequential(
+            nn.Conv2d(3, ch[0], 3, 2, 1, bias=False), nn.BatchNorm2d(ch[0]), nn.ReLU(inplace=True))
+        stages, inp = [], ch[0]
+        for rep, oup in zip(repeats, ch[1:4]):
+            # the first stage keeps resolution (the reference drops the max-pool and uses stride 16)
+            seq = [_InvertedResidualK(inp, oup, True, stride=2)]
+            seq += [_InvertedResidualK(oup, oup, False) for _ in range(rep - 1)]
+            stages.append(nn.Sequential(*seq))
+            inp = oup
+        self.stage2, self.stage3, self.stage4 = stages
+        self.conv5 = nn.Sequential(
+            nn.Conv2d(inp, ch[-1], 1, bias=False), nn.BatchNorm2d(ch[-1]), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self.conv5(self.stage4(self.stage3(self.stage2(self.input_block(x)))))
+
+
+BASE_FACTORIES = {
+    **{n: (lambda n=n: Resnet(n)) for n in Resnet.CONFIGS},
+    **{n: (lambda n=n: ShuffleNetV2K(n)) for n in ShuffleNetV2K.CONFIGS},
+}
+
+
+class CompositeField4(nn.Module):
+    """Head: features -> ``[B, n_fields, n_components, H, W]`` in the layout the decoder reads."""
+
+    def __init__(self, meta: headmeta.Base, in_features):
+        super().__init__()
+        self.meta = meta
+        self.n_components = 1 + meta.n_confidences + meta.n_vectors * 2 + meta.n_scales
+        self.conv = nn.Conv2d(in_features, meta.n_fields * self.n_components * (meta.upsample_stride ** 2), 1)
+        self.upsample_op = nn.PixelShuffle(meta.upsample_stride) if meta.upsample_stride > 1 else None
+
+    def forward(self, x):
+        x = self.conv(x)
+        if self.upsample_op is not None:
+            x = self.upsample_op(x)
+            us = self.meta.upsample_stride
+            low_cut = (us - 1) // 2
+            high_cut = math.ceil((us - 1) / 2.0)
+            x = x[:, :, low_cut:x.shape[2] - high_cut, low_cut:x.shape[3] - high_cut]
+        B, _, H, W = x.shape
+        m = self.meta
+        x = x.float().reshape(B, m.n_fields, self.n_components, H, W).contiguous()
+        if not self.training:
+            nc = m.n_confidences
+            x[:, :, 1:1 + nc].sigmoid_()
+            ii = torch.arange(W, device=x.device, dtype=x.dtype)
+            jj = torch.arange(H, device=x.device, dtype=x.dtype).unsqueeze(1)
+            for i, do_offset in enumerate(m.vector_offsets):
+                if do_offset:
+                    x[:, :, 1 + nc + 2 * i] += ii
+                    x[:, :, 1 + nc + 2 * i + 1] += jj
+            first_scale = 1 + nc + m.n_vectors * 2
+            x[:, :, first_scale:first_scale + m.n_scales] = nn.functional.softplus(
+                x[:, :, first_scale:first_scale + m.n_scales])
+        return x
+
+
+class Shell(nn.Module):
+    """base_net + head_nets (reference ``network/nets.py:11-48``)."""
+
+    def __init__(self, base_net, head_nets):
+        super().__init__()
+        self.base_net = base_net
+        self.head_nets = None
+        self.set_head_nets(head_nets)
+
+    @property
+    def head_metas(self):
+        return [hn.meta for hn in self.head_nets] if self.head_nets is not None else None
+
+    def set_head_nets(self, head_nets):
+        if not isinstance(head_nets, nn.ModuleList):
+            head_nets = nn.ModuleList(head_nets)
+        for i, hn in enumerate(head_nets):
+            hn.meta.head_index = i
+            hn.meta.base_stride = self.base_net.stride
+        self.head_nets = head_nets
+
+    def forward(self, image_batch):
+        x = self.base_net(image_batch)
+        return tuple(hn(x) for hn in self.head_nets)
+
+
+def factory(base_name='resnet50', head_metas=None, *, seed=0):
+    """Randomly initialised ``Shell`` for ``head_metas`` (default: cocokp CIF+CAF, upsample 2)."""
+    if head_metas is None:
+        head_metas = headmeta.cocokp_metas()
+    gen_state = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        base = BASE_FACTORIES[base_name]()
+        heads = [CompositeField4(m, base.out_features) for m in head_metas]
+        net = Shell(base, heads)
+    finally:
+        torch.random.set_rng_state(gen_state)
+    return net.eval()
+
+
+def _fold(conv, bn):
+    """conv <- conv followed by eval-mode batch norm."""
+    with torch.no_grad():
+        scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+        conv.weight.mul_(scale.reshape(-1, 1, 1, 1))
+        bias = bn.bias - bn.running_mean * scale
+        if conv.bias is not None:
+            bias = bias + conv.bias * scale
+        conv.bias = nn.Parameter(bias)
+
+
+def fuse_conv_bn_(model):
+    """Inference-time folding of every (Conv2d, BatchNorm2d) pair into the convolution
+    (removes one full activation read+write per layer, the dominant non-GEMM cost at 641 px)."""
+    assert not model.training
+    for module in model.modules():
+        if isinstance(module, nn.Sequential):
+            prev_name, prev = None, None
+            for name, child in list(module.named_children()):
+                if isinstance(child, nn.BatchNorm2d) and isinstance(prev, nn.Conv2d):
+                    _fold(prev, child)
+                    setattr(module, name, nn.Identity())
+                prev_name, prev = name, child
+        for i in (1, 2, 3):
+            conv, bn = getattr(module, 'conv%d' % i, None), getattr(module, 'bn%d' % i, None)
+            if isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d):
+                _fold(conv, bn)
+                setattr(module, 'bn%d' % i, nn.Identity())
+    return model

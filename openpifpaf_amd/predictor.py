@@ -1,0 +1,175 @@
+"""``Predictor``: the reference's convenience entry point (reference ``predictor.py:12-192``)
+over the device-resident decode path.
+
+Same constructor/attribute/method surface for the inputs that work offline
+(``numpy_image(s)``, ``pil_image(s)``, ``image(s)``, ``tensor_batch``); the model
+is a randomly initialised ``Shell`` unless one is passed (no checkpoints offline).
+Preprocessing restates the evaluation pipeline without torchvision:
+``RescaleAbsolute(long_edge)`` (reference ``transforms/scale.py:150-174``, Pillow
+bilinear = the reference's no-OpenCV "fast" path), ``CenterPad(long_edge)`` for
+batch > 1 / ``CenterPadTight(16)`` for batch 1 (reference ``transforms/pad.py:15-112``),
+ImageNet normalisation (reference ``transforms/__init__.py:26-33``).
+"""
+import argparse
+import logging
+import math
+
+import numpy as np
+import torch
+
+from . import decoder, network
+
+LOG = logging.getLogger(__name__)
+
+IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)
+IMAGENET_STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
+
+
+def _to_pil(image):
+    import PIL.Image
+    if isinstance(image, PIL.Image.Image):
+        return image.convert('RGB')
+    return PIL.Image.fromarray(np.asarray(image, dtype=np.uint8)).convert('RGB')
+
+
+def preprocess_image(image, *, long_edge=None, batch_mode=False):
+    """-> (float32 tensor [3,H,W], meta) with the meta fields ``inverse_transform`` needs."""
+    import PIL.Image
+    image = _to_pil(image)
+    w0, h0 = image.size
+    meta = {'offset': np.array((0.0, 0.0)), 'scale': np.array((1.0, 1.0)), 'hflip': False,
+            'rotation': {'angle': 0.0, 'width': None, 'height': None},
+            'valid_area': np.array((0.0, 0.0, w0 - 1, h0 - 1)), 'width_height': np.array((w0, h0))}
+    if long_edge:
+        s = long_edge / max(h0, w0)
+        tw, th = (int(w0 * s), int(long_edge)) if h0 > w0 else (int(long_edge), int(h0 * s))
+        resample = getattr(PIL.Image, 'Resampling', PIL.Image).BILINEAR
+        image = image.resize((tw, th), resample)
+        sx, sy = (tw - 1) / (w0 - 1), (th - 1) / (h0 - 1)
+        meta['offset'] *= (sx, sy)
+        meta['scale'] *= (sx, sy)
+        meta['valid_area'][:2] *= (sx, sy)
+        meta['valid_area'][2:] *= (sx, sy)
+    w, h = image.size
+    if batch_mode:
+        assert long_edge, '--long-edge must be provided for batch size > 1'
+        tw, th, fill = long_edge, long_edge, (124, 116, 104)
+    else:
+        tw = math.ceil((w - 1) / 16) * 16 + 1
+        th = math.ceil((h - 1) / 16) * 16 + 1
+        fill = (124, 116, 104)
+    left, top = max(0, int((tw - w) / 2.0)), max(0, int((th - h) / 2.0))
+    canvas = PIL.Image.new('RGB', (max(tw, w), max(th, h)), fill)
+    canvas.paste(image, (left, top))
+    meta['offset'] -= (left, top)
+    meta['valid_area'][:2] += (left, top)
+    x = np.asarray(canvas, dtype=np.float32) / 255.0
+    x = (x - IMAGENET_MEAN) / IMAGENET_STD
+    return torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1))), meta
+
+
+class Predictor:
+    """Predict from various inputs with a common configuration."""
+    batch_size = 1
+    device = torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
+    long_edge = None
+    base_name = 'resnet50'
+    channels_last = True
+    dtype = torch.float32          #: backbone compute dtype (heads always emit float32 fields)
+
+    def __init__(self, checkpoint=None, head_metas=None, *, model=None, json_data=False):
+        if checkpoint is not None and model is None:
+            self.base_name = str(checkpoint)
+        self.json_data = json_data
+        self.model_cpu = model if model is not None else network.factory(self.base_name, head_metas)
+        self.model = self.model_cpu.to(self.device)
+        if self.channels_last and self.device.type == 'cuda':
+            self.model = self.model.to(memory_format=torch.channels_last)
+        self.processor = decoder.factory(self.model_cpu.head_metas)
+        self.last_decoder_time = 0.0
+        self.last_nn_time = 0.0
+        self.total_nn_time = 0.0
+        self.total_decoder_time = 0.0
+        self.total_images = 0
+
+    @classmethod
+    def cli(cls, parser: argparse.ArgumentParser, *, skip_batch_size=False, skip_loader_workers=False):
+        group = parser.add_argument_group('Predictor')
+        if not skip_batch_size:
+            group.add_argument('--batch-size', default=cls.batch_size, type=int, help='processing batch size')
+        group.add_argument('--long-edge', default=cls.long_edge, type=int,
+                           help='rescale the long side of the image (aspect ratio maintained)')
+        group.add_argument('--basenet', default=cls.base_name, choices=sorted(network.BASE_FACTORIES))
+
+    @classmethod
+    def configure(cls, args: argparse.Namespace):
+        cls.batch_size = args.batch_size
+        cls.long_edge = args.long_edge
+        cls.base_name = getattr(args, 'basenet', cls.base_name)
+        if getattr(args, 'device', None) is not None:
+            cls.device = args.device
+
+    def _forward(self, image_batch):
+        image_batch = image_batch.to(self.device, non_blocking=True)
+        if self.channels_last and image_batch.is_cuda:
+            image_batch = image_batch.contiguous(memory_format=torch.channels_last)
+        if self.dtype != torch.float32 and image_batch.is_cuda:
+            with torch.autocast('cuda', dtype=self.dtype):
+                return self.model(image_batch)
+        return self.model(image_batch)
+
+    def tensor_batch(self, processed_image_batch, meta_batch=None):
+        """Predict from an already preprocessed ``[B,3,H,W]`` batch -> list (per image) of predictions."""
+        model = _CallModel(self._forward)
+        pred_batch = self.processor.batch(model, processed_image_batch, device=None)
+        self.last_decoder_time = self.processor.last_decoder_time
+        self.last_nn_time = self.processor.last_nn_time
+        self.total_decoder_time += self.last_decoder_time
+        self.total_nn_time += self.last_nn_time
+        self.total_images += len(processed_image_batch)
+        if meta_batch is None:
+            meta_batch = [None] * len(pred_batch)
+        out = []
+        for pred, meta in zip(pred_batch, meta_batch):
+            pred = [ann.inverse_transform(meta) for ann in pred]
+            if self.json_data:
+                pred = [ann.json_data() for ann in pred]
+            out.append(pred)
+        return out
+
+    def _images(self, images):
+        batch_mode = self.batch_size > 1
+        for i in range(0, len(images), self.batch_size):
+            items = [preprocess_image(im, long_edge=self.long_edge, batch_mode=batch_mode)
+                     for im in images[i:i + self.batch_size]]
+            batch = torch.stack([t for t, _ in items])
+            metas = [m for _, m in items]
+            for pred, meta in zip(self.tensor_batch(batch, metas), metas):
+                yield pred, [], meta
+
+    def numpy_images(self, numpy_images):
+        yield from self._images(list(numpy_images))
+
+    def numpy_image(self, image):
+        return next(iter(self.numpy_images([image])))
+
+    def pil_images(self, pil_images):
+        yield from self._images(list(pil_images))
+
+    def pil_image(self, image):
+        return next(iter(self.pil_images([image])))
+
+    def images(self, file_names):
+        import PIL.Image
+        yield from self._images([PIL.Image.open(f).convert('RGB') for f in file_names])
+
+    def image(self, file_name):
+        return next(iter(self.images([file_name])))
+
+
+class _CallModel:
+    def __init__(self, fn):
+        self.fn = fn
+
+    def __call__(self, x):
+        return self.fn(x)

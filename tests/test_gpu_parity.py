@@ -227,28 +227,36 @@ def test_decode_empty_fields(native, coco_skeleton0):
 
 
 def test_decode_all_active_adversarial(native, port, coco_skeleton0):
-    """Random-initialised-network statistics: every cell passes every threshold.
-    31x31 cells x 17 fields = 16k seeds > 8192: exercises the LDS-blocked sort."""
-    from openpifpaf_amd import synth
+    """Random-initialised-network statistics: every cell is active.  With the seed
+    rescoring ablated (raw confidences are the seed scores) 31x31 cells x 17 fields
+    give ~15k seeds > 8192: exercises the LDS-blocked bitonic sort and long lists."""
+    from openpifpaf_amd import _lib, synth
     cif, caf = synth.adversarial_fields(3, height=31, width=31)
+    kw = dict(ablation_cifseeds_no_rescore=1)
     ref_hr = port.cifhr_accumulate(cif, 8)
-    ref_f, ref_v = port.cifseeds(cif, 8, ref_hr)
+    ref_f, ref_v = port.cifseeds(cif, 8, ref_hr, params=port.default_params(**kw))
     assert len(ref_f) > 8192
     hr = native.CifHr()
     hr.accumulate(dev(cif), 8)
     assert np.array_equal(hr.get_accumulated()[0].cpu().numpy(), ref_hr)
     seeds = native.CifSeeds(hr)
-    seeds.fill(dev(cif), 8)
+    seeds.fill(dev(cif), 8, params=_lib.default_params(**kw))
     f, v = seeds.get()
+    f, v = f.cpu().numpy(), v.cpu().numpy()
     assert len(f) == len(ref_f)
-    v = v.cpu().numpy()
     assert np.all(np.diff(v[:, 0]) <= 0)
-    assert np.array_equal(np.sort(v[:, 0]), np.sort(ref_v[:, 0]))
-    want, _ = port.decode(cif, 8, caf, 8, coco_skeleton0)
-    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0), max_annotations=512)
-    got, _ = dec.call(dev(cif), 8, dev(caf), 8)
-    ok, msg = compare_annotations(got.cpu().numpy(), want)
-    assert ok, msg
+    if len(np.unique(ref_v[:, 0])) == len(ref_v):
+        assert np.array_equal(f, ref_f) and np.array_equal(v, ref_v)
+    else:
+        assert np.array_equal(np.sort(v[:, 0]), np.sort(ref_v[:, 0]))
+    for kw in (dict(), dict(ablation_cifseeds_no_rescore=1)):
+        want, _ = port.decode(cif, 8, caf, 8, coco_skeleton0, params=port.default_params(**kw))
+        dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0), max_annotations=512)
+        out, ids, counts = dec.call_batch(dev(cif)[None], 8, dev(caf)[None], 8, params=_lib.default_params(**kw))
+        n = int(counts[0])
+        assert n == len(want), kw
+        ok, msg = compare_annotations(out[0, :n].cpu().numpy(), want)
+        assert ok, '%s: %s' % (kw, msg)
 
 
 def test_static_getset_roundtrip(native):
