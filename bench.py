@@ -152,7 +152,7 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
 
-    from openpifpaf_amd import _lib, constants, headmeta, native, network, synth
+    from openpifpaf_amd import _lib, constants, distributed, headmeta, native, network, synth
 
     B = args.batch
     cif_meta, caf_meta = headmeta.cocokp_metas()
@@ -184,11 +184,6 @@ def main():
     host_counts = torch.empty((B,), dtype=torch.int32).pin_memory()
     main_stream = torch.cuda.current_stream()
     dec_stream = main_stream if args.no_overlap else torch.cuda.Stream()
-    gathered = None
-    if world > 1:
-        gathered = [torch.empty((B, dec.max_annotations, K, 4), dtype=torch.float32, device=device)
-                    for _ in range(world)]
-        gathered_counts = [torch.empty((B,), dtype=torch.int32, device=device) for _ in range(world)]
 
     shapes_checked = [False]
 
@@ -205,10 +200,8 @@ def main():
         with torch.cuda.stream(dec_stream):
             dec_stream.wait_event(ev)                  # decode of batch i follows its backbone
             out, ids, counts = dec.call_batch(cif_syn, stride, caf_syn, stride)
-            if world > 1:
-                import torch.distributed as dist
-                dist.all_gather(gathered, out)         # final annotations only, over xGMI
-                dist.all_gather(gathered_counts, counts)
+            if world > 1:                              # final annotations only, over xGMI (RCCL)
+                distributed.gather_annotations(out, ids, counts)
             host_out.copy_(out, non_blocking=True)
             host_counts.copy_(counts, non_blocking=True)
         return out

@@ -1,0 +1,8 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+timeout 1200 python tools/backbone_probe.py 32 2>&1 | grep -v amdgpu.ids | tee gpurun_out/backbone_probe.log
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_bench -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1
+ls -R $GRAFT_REPO_ROOT/gpurun_out/prof_bench | head -20

@@ -35,13 +35,14 @@ def _blob(conf_plane, targets, cx, cy, radius, peak, sigma, rng):
 
 
 def synth_fields(seed, n_people, *, height=81, width=81,
-                 pose=None, skeleton=None, noise=0.05):
+                 pose=None, skeleton=None, noise=0.05, size_range=(0.25, 0.75)):
     """Generate one image's (cif, caf) float32 field tensors.
 
     :param seed: numpy ``default_rng`` seed, fully determines the output
     :param n_people: number of synthetic people
     :param pose: ``[K, 2]`` pose template (x right, y up), default COCO upright
     :param skeleton: 1-based bone list, default COCO person skeleton
+    :param size_range: person height as a fraction of min(height, width)
     """
     rng = np.random.default_rng(seed)
     if pose is None:
@@ -80,7 +81,7 @@ def synth_fields(seed, n_people, *, height=81, width=81,
 
     for _ in range(n_people):
         # person height between ~25% and ~75% of the field
-        size = rng.uniform(0.25, 0.75) * min(H, W)
+        size = rng.uniform(*size_range) * min(H, W)
         unit = size / extent                      # field units per pose unit
         half = 0.5 * unit * (p.max(axis=0) - p.min(axis=0))
         cx = rng.uniform(half[0] + 1.0, max(half[0] + 1.5, W - 2.0 - half[0]))
@@ -91,7 +92,7 @@ def synth_fields(seed, n_people, *, height=81, width=81,
 
         for k in range(K):
             x, y = joints[k]
-            bj, bi = _blob(cif[k, 1], None, x, y, 1.5 + 0.5 * s, 0.9, 0.6 + 0.5 * s, rng)
+            bj, bi = _blob(cif[k, 1], None, x, y, max(2.3, 1.5 + 0.5 * s), 0.9, max(1.3, 0.6 + 0.5 * s), rng)
             n = len(bj)
             cif[k, 2, bj, bi] = x + rng.normal(0.0, noise, n)
             cif[k, 3, bj, bi] = y + rng.normal(0.0, noise, n)
@@ -102,7 +103,7 @@ def synth_fields(seed, n_people, *, height=81, width=81,
             x2, y2 = joints[j2 - 1]
             for t in (0.0, 0.5, 1.0):
                 bx, by = x1 + t * (x2 - x1), y1 + t * (y2 - y1)
-                bj, bi = _blob(caf[a, 1], None, bx, by, 1.5 + 0.3 * s, 0.85, 0.8 + 0.4 * s, rng)
+                bj, bi = _blob(caf[a, 1], None, bx, by, max(2.0, 1.5 + 0.3 * s), 0.85, max(1.2, 0.8 + 0.4 * s), rng)
                 n = len(bj)
                 caf[a, 2, bj, bi] = x1 + rng.normal(0.0, noise, n)
                 caf[a, 3, bj, bi] = y1 + rng.normal(0.0, noise, n)
@@ -118,7 +119,7 @@ PEOPLE_CYCLE = (1, 5, 10, 20, 3, 8, 15, 2)
 
 
 def synth_batch(batch, *, seed0=0, height=81, width=81, people=None,
-                pose=None, skeleton=None):
+                pose=None, skeleton=None, size_range=(0.25, 0.75)):
     """A batch of images: image ``b`` uses seed ``seed0 + b`` and
     ``people[b % len(people)]`` synthetic persons."""
     if people is None:
@@ -128,7 +129,8 @@ def synth_batch(batch, *, seed0=0, height=81, width=81, people=None,
     cifs, cafs = [], []
     for b in range(batch):
         cif, caf = synth_fields(seed0 + b, people[b % len(people)],
-                                height=height, width=width, pose=pose, skeleton=skeleton)
+                                height=height, width=width, pose=pose, skeleton=skeleton,
+                                size_range=size_range)
         cifs.append(cif)
         cafs.append(caf)
     return np.stack(cifs), np.stack(cafs)

@@ -1,0 +1,179 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol the header
+declares; the host-side mirror of the reference interface behaves like the reference
+(registry, factory, CLI -> global tunables, Annotation, preprocessing, field shapes).
+No compute call is made here (there is no GPU in this tier and no CPU fallback)."""
+import argparse
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, 'include', 'openpifpaf_amd.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(opa_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from openpifpaf_amd import _lib
+    assert _lib.available(), 'build the HIP library first: python -c "import __graft_entry__ as g; g.build()"'
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    declared = header_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(handle, name), 'library does not export %s' % name
+    assert sorted(_lib.SYMBOLS) == declared, 'ctypes table and header disagree'
+    assert _lib.lib().opa_version().decode().startswith('openpifpaf_amd')
+
+
+def test_params_struct_matches_reference_defaults():
+    from openpifpaf_amd import _lib
+    from oracle import port
+    p, q = _lib.default_params(), port.default_params()
+    assert ctypes.sizeof(_lib.Params) == ctypes.sizeof(port.Params) == 13 * 8 + 8 * 4
+    for name, _ in _lib.Params._fields_:
+        assert getattr(p, name) == getattr(q, name), name
+    assert (p.cif_threshold, p.seed_threshold, p.caf_threshold) == (0.3, 0.2, 0.3)
+    assert (p.keypoint_threshold, p.keypoint_threshold_rel, p.reverse_match, p.greedy) == (0.15, 0.5, 1, 0)
+
+
+def test_static_getset_is_process_global_like_the_reference():
+    from openpifpaf_amd import native
+    assert native.CifCaf.get_keypoint_threshold() == 0.15
+    try:
+        native.CifCaf.set_keypoint_threshold(0.4)
+        native.CifSeeds.set_threshold(0.25)
+        assert native.CifCaf.get_keypoint_threshold() == 0.4 and native.CifSeeds.get_threshold() == 0.25
+        assert native.CifCaf.get_reverse_match() is True
+    finally:
+        native.CifCaf.set_keypoint_threshold(0.15)
+        native.CifSeeds.set_threshold(0.2)
+
+
+def test_invalid_arguments_fail_loudly_without_gpu():
+    from openpifpaf_amd import _lib
+    L = _lib.lib()
+    shape = _lib.Shape(1, 17, 19, 0, 81, 81, 81, 8, 8, 64)            # zero height
+    assert L.opa_cifcaf_workspace_bytes(ctypes.byref(shape)) == 0
+    assert b'positive' in L.opa_last_error()
+    shape = _lib.Shape(32, 17, 19, 81, 81, 81, 81, 8, 8, 128)
+    nbytes = L.opa_cifcaf_workspace_bytes(ctypes.byref(shape))
+    assert 1.0e9 < nbytes < 3.0e9                                      # ~50 MB per image
+    h = ctypes.c_void_p()
+    skel = (ctypes.c_int64 * 4)(0, 1, 1, 99)
+    assert L.opa_cifcaf_create(ctypes.byref(h), 17, skel, 2) == 1      # index out of range
+
+
+def test_decoder_without_gpu_raises_instead_of_falling_back():
+    import torch
+    from openpifpaf_amd import _lib, native
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    with pytest.raises(_lib.NativeError):
+        native.CifCaf(17, torch.zeros((19, 2), dtype=torch.int64))
+
+
+def test_registry_factory_and_cli():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('constructing decoders on the GPU box is covered by the gpu tests')
+    from openpifpaf_amd import decoder, headmeta, native
+    assert decoder.CifCaf in decoder.DECODERS
+    parser = argparse.ArgumentParser()
+    decoder.cli(parser)
+    args = parser.parse_args(['--force-complete-pose', '--seed-threshold', '0.3', '--caf-th', '0.25',
+                              '--decoder', 'cifcaf:0'])
+    try:
+        decoder.configure(args)
+        assert native.CifCaf.get_force_complete() is True
+        assert native.CifCaf.get_keypoint_threshold() == 0.0          # reference cifcaf.py:181-185
+        assert native.CifCaf.get_keypoint_threshold_rel() == 0.0
+        assert native.NMSKeypoints.get_instance_threshold() == 0.0    # reference factory.py:53-57
+        assert native.CifSeeds.get_threshold() == 0.3
+        assert native.CafScored.get_default_score_th() == 0.25
+        assert decoder.Factory.decoder_request == {'cifcaf': [0]}
+    finally:
+        from openpifpaf_amd import _lib
+        _lib.set_params(_lib.default_params())
+        decoder.Factory.decoder_request = None
+    # the factory pairs consecutive (Cif, Caf) metas (reference cifcaf.py:213-222); building needs a GPU
+    cif, caf = headmeta.cocokp_metas()
+    assert cif.stride == 8 and caf.n_fields == 19 and cif.n_fields == 17
+
+
+def test_annotation_matches_reference_semantics():
+    from openpifpaf_amd import constants
+    from openpifpaf_amd.annotation import Annotation
+    ann = Annotation(constants.COCO_KEYPOINTS, constants.COCO_PERSON_SKELETON,
+                     score_weights=constants.COCO_PERSON_SCORE_WEIGHTS)
+    ann.data[:, 0] = np.arange(17) * 10.0
+    ann.data[:, 1] = 50.0
+    ann.data[:, 2] = np.linspace(0.2, 1.0, 17)
+    ann.joint_scales[:] = 4.0
+    w = np.asarray(constants.COCO_PERSON_SCORE_WEIGHTS) / np.sum(constants.COCO_PERSON_SCORE_WEIGHTS)
+    assert abs(ann.score - float(np.sum(w * np.sort(ann.data[:, 2])[::-1]))) < 1e-7   # reference annotation.py:98-110
+    j = ann.json_data()
+    assert len(j['keypoints']) == 51 and j['bbox'] == [-4.0, 46.0, 168.0, 8.0] and j['category_id'] == 1
+    meta = {'offset': np.array((-10.0, -20.0)), 'scale': np.array((2.0, 2.0)), 'hflip': False,
+            'rotation': {'angle': 0.0, 'width': None, 'height': None}, 'width_height': np.array((100, 100))}
+    inv = ann.inverse_transform(meta)
+    assert np.allclose(inv.data[1, :2], [(10.0 - 10.0) / 2.0, (50.0 - 20.0) / 2.0])
+    assert np.allclose(inv.joint_scales, 2.0) and ann.data[1, 0] == 10.0
+
+
+def test_preprocess_pads_like_the_reference():
+    from openpifpaf_amd.predictor import preprocess_image
+    img = (np.random.default_rng(0).random((300, 500, 3)) * 255).astype(np.uint8)
+    t, meta = preprocess_image(img, long_edge=641, batch_mode=True)
+    assert tuple(t.shape) == (3, 641, 641)                              # CenterPad(long_edge)
+    assert meta['offset'][0] == 0 and meta['offset'][1] < 0
+    t, meta = preprocess_image(img, long_edge=None, batch_mode=False)
+    assert tuple(t.shape) == (3, 305, 513)                              # CenterPadTight(16): ceil((w-1)/16)*16+1
+    t, meta = preprocess_image(img, long_edge=321, batch_mode=False)
+    assert t.shape[2] == 321 and (t.shape[1] - 1) % 16 == 0
+
+
+@pytest.mark.parametrize('name,features', [('resnet18', 512), ('shufflenetv2k16', 1392)])
+def test_forward_field_shapes(name, features):
+    """reference tests/test_forward.py:8-32: (1,17,5,H,W) / (1,19,8,H,W); 241x321 -> 31x41 at upsample 2."""
+    import torch
+    from openpifpaf_amd import network
+    net = network.factory(name)
+    assert net.base_net.out_features == features and net.base_net.stride == 16
+    with torch.no_grad():
+        cif, caf = net(torch.zeros((1, 3, 241, 321)))
+    assert tuple(cif.shape) == (1, 17, 5, 31, 41) and tuple(caf.shape) == (1, 19, 8, 31, 41)
+    assert float(cif[0, 0, 1].min()) >= 0.0 and float(cif[0, 0, 1].max()) <= 1.0   # sigmoid on confidences
+    assert float(cif[0, :, 4].min()) >= 0.0                                             # softplus on scales
+
+
+def test_conv_bn_folding_is_exact_enough():
+    import torch
+    from openpifpaf_amd import network
+    net = network.factory('resnet18')
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    x = torch.randn((1, 3, 97, 129))
+    with torch.no_grad():
+        a = net(x)
+        network.fuse_conv_bn_(net)
+        b = net(x)
+    assert not any(isinstance(m, torch.nn.BatchNorm2d) for m in net.modules())
+    assert max(float((u - v).abs().max()) for u, v in zip(a, b)) < 1e-3
+
+
+def test_synth_is_deterministic_and_shaped():
+    from openpifpaf_amd import synth
+    a = synth.synth_fields(5, 3, height=21, width=33)
+    b = synth.synth_fields(5, 3, height=21, width=33)
+    assert a[0].shape == (17, 5, 21, 33) and a[1].shape == (19, 8, 21, 33)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    cifs, cafs = synth.synth_batch(3, seed0=9, height=21, width=21)
+    assert cifs.shape == (3, 17, 5, 21, 21) and cafs.dtype == np.float32

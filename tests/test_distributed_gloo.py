@@ -1,0 +1,83 @@
+"""N>1 path on CPU: world_size=2 gloo processes shard a batch by image and gather
+fixed-size annotation blocks (the one collective of the path)."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np, torch, torch.distributed as dist
+    from openpifpaf_amd import distributed as D
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n_images, max_ann, K = 6, 4, 17
+    lo, hi = D.shard_bounds(n_images, rank, world)
+    assert hi - lo == 3
+    # stand-in for the device decode of the local shard: deterministic per global image index
+    ann = torch.zeros((hi - lo, max_ann, K, 4))
+    ids = torch.full((hi - lo, max_ann), -1, dtype=torch.int64)
+    counts = torch.zeros((hi - lo,), dtype=torch.int32)
+    for i, g in enumerate(range(lo, hi)):
+        counts[i] = g %% (max_ann + 1)
+        ann[i, :int(counts[i])] = float(g + 1)
+        ids[i, :int(counts[i])] = g
+    a, i_, c = D.gather_annotations(ann, ids, counts)
+    assert a.shape == (n_images, max_ann, K, 4) and c.tolist() == [g %% (max_ann + 1) for g in range(n_images)]
+    per_image = D.unpack(a, i_, c)
+    for g, (pa, pi) in enumerate(per_image):
+        assert len(pa) == g %% (max_ann + 1)
+        assert (pa == g + 1).all() and (pi == g).all()
+    dist.barrier()
+    dist.destroy_process_group()
+    print('rank', rank, 'ok')
+''') % ROOT
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_shard_bounds_cover_everything():
+    from openpifpaf_amd import distributed as D
+    for n in (0, 1, 7, 32, 255, 256):
+        for world in (1, 2, 3, 8):
+            spans = [D.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_gather_world_size_2_gloo(tmp_path):
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER)
+    port = free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE='2',
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert 'rank %d ok' % rank in out
+
+
+def test_gather_is_identity_without_process_group():
+    import torch
+    from openpifpaf_amd import distributed as D
+    a, i, c = torch.zeros((2, 3, 17, 4)), torch.zeros((2, 3), dtype=torch.int64), torch.zeros((2,), dtype=torch.int32)
+    out = D.gather_annotations(a, i, c)
+    assert out[0] is a and out[1] is i and out[2] is c

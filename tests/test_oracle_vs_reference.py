@@ -1,0 +1,73 @@
+"""The restatement against the REAL reference decoder (oracle/_ref, built from the
+reference's own sources).  Skipped where _ref is unavailable (it needs /root/reference
+to build); the committed golden vectors pin the oracle everywhere else."""
+import numpy as np
+import pytest
+
+from oracle import reference
+
+pytestmark = pytest.mark.skipif(not reference.available(), reason='oracle/_ref/openpifpaf_ref.so not built')
+
+
+@pytest.fixture(scope='module')
+def ref():
+    torch = reference.load()
+    torch.set_num_threads(1)
+    reference.reset_statics()
+    yield reference
+    reference.reset_statics()
+
+
+@pytest.mark.parametrize('seed,people', [(100, 1), (101, 4), (102, 9), (103, 16)])
+def test_decode_bit_equal(ref, coco_skeleton0, seed, people):
+    from openpifpaf_amd import synth
+    from oracle import port
+    cif, caf = synth.synth_fields(seed, people)
+    r_out, r_ids, r_hr = ref.decode(cif, 8, caf, 8, coco_skeleton0)
+    o_out, o_ids, o_hr = port.decode(cif, 8, caf, 8, coco_skeleton0, return_cifhr=True)
+    assert np.array_equal(r_hr, o_hr)
+    assert r_out.shape == o_out.shape and np.array_equal(r_out, o_out)
+    assert np.array_equal(r_ids, o_ids)
+
+
+@pytest.mark.parametrize('kw', [
+    dict(greedy=1), dict(reverse_match=0), dict(keypoint_threshold=0.3, keypoint_threshold_rel=0.7),
+    dict(cif_threshold=0.2, seed_threshold=0.3, caf_threshold=0.25),
+    dict(force_complete=1, keypoint_threshold=0.0, keypoint_threshold_rel=0.0,
+         nms_instance_threshold=0.0, nms_keypoint_threshold=0.0),
+    dict(ablation_cifseeds_nms=1), dict(ablation_cifseeds_no_rescore=1), dict(ablation_caf_no_rescore=1),
+])
+def test_decode_with_options(ref, coco_skeleton0, kw):
+    from openpifpaf_amd import synth
+    from oracle import port
+    cif, caf = synth.synth_fields(200, 6)
+    p = port.default_params(**kw)
+    ref.apply_params(p)
+    try:
+        r_out, _, _ = ref.decode(cif, 8, caf, 8, coco_skeleton0)
+    finally:
+        ref.reset_statics()
+    o_out, _ = port.decode(cif, 8, caf, 8, coco_skeleton0, params=p)
+    assert r_out.shape == o_out.shape and np.array_equal(r_out, o_out), kw
+
+
+def test_initial_annotations(ref, coco_skeleton0):
+    from openpifpaf_amd import synth
+    from oracle import port
+    cif, caf = synth.synth_fields(300, 4)
+    first, _ = port.decode(cif, 8, caf, 8, coco_skeleton0)
+    init = first[:2].copy()
+    init[:, 5:] = 0.0
+    ids = np.array([3, 11], dtype=np.int64)
+    r_out, r_ids, _ = ref.decode(cif, 8, caf, 8, coco_skeleton0, initial_annotations=init, initial_ids=ids)
+    o_out, o_ids = port.decode(cif, 8, caf, 8, coco_skeleton0, initial_annotations=init, initial_ids=ids)
+    assert np.array_equal(r_out, o_out) and np.array_equal(r_ids, o_ids)
+
+
+def test_all_active_adversarial(ref, coco_skeleton0):
+    from openpifpaf_amd import synth
+    from oracle import port
+    cif, caf = synth.adversarial_fields(1, height=21, width=21)
+    r_out, _, r_hr = ref.decode(cif, 8, caf, 8, coco_skeleton0)
+    o_out, _, o_hr = port.decode(cif, 8, caf, 8, coco_skeleton0, return_cifhr=True)
+    assert np.array_equal(r_hr, o_hr) and np.array_equal(r_out, o_out)
