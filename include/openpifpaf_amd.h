@@ -141,6 +141,14 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
 int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
                           int32_t* rows, int32_t* cols, int32_t* pitch, double* revision);
 
+/* Locates an intermediate buffer of the last opa_cifcaf_decode inside the workspace
+ * (debugging / tests; the reference exposes its intermediates through the utility
+ * classes of module.cpp:66-117).  what: "cifhr", "seed_count", "seed_f", "seed_vxys",
+ * "lists", "list_counts", "lists_fc", "list_counts_fc", "occupancy",
+ * "annotation_scratch", "status". */
+int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what,
+                              size_t* offset_bytes, size_t* size_bytes);
+
 /* ---- stage-level entry points (openpifpaf_decoder_utils) ---------------- */
 /* ref: module.cpp:75-84  CifHr.reset + CifHr.accumulate (cif_hr.cpp:28-121).
  *  cifhr_dev [B, F, rows, pitch] with rows=(H-1)*stride+1, pitch from opa_cifhr_pitch();

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'lib', 'libopenpifpaf_amd.so')
+LIB_PATH = os.environ.get('OPA_LIB_PATH') or os.path.join(HERE, 'lib', 'libopenpifpaf_amd.so')
 
 OPA_OK = 0
 ERROR_NAMES = {1: 'INVALID_ARGUMENT', 2: 'HIP', 3: 'UNSUPPORTED', 4: 'WORKSPACE', 5: 'NO_DEVICE'}
@@ -80,6 +80,7 @@ SYMBOLS = {
     'opa_cifcaf_decode': (ctypes.c_int, [_vp, _P(Shape), _P(Params), _vp, _vp, _vp, _vp, _i32,
                                          _vp, _sz, _vp, _vp, _vp, _vp]),
     'opa_cifcaf_cifhr_view': (ctypes.c_int, [_P(Shape), _P(_sz), _P(_i32), _P(_i32), _P(_i32), _P(_dbl)]),
+    'opa_cifcaf_workspace_view': (ctypes.c_int, [_P(Shape), ctypes.c_char_p, _P(_sz), _P(_sz)]),
     'opa_cifhr_pitch': (_i32, [_i32, _i32]),
     'opa_cifhr_scratch_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'opa_cifhr_accumulate': (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _dbl, _dbl, _P(Params),

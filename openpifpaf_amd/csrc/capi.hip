@@ -258,6 +258,27 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats, int32_t
     return OPA_OK;
 }
 
+int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what, size_t* offset_bytes, size_t* size_bytes) {
+    Layout L; const char* why = nullptr;
+    if (!shape || !what || !make_layout(*shape, &L, &why)) return fail(OPA_ERR_INVALID_ARGUMENT, why ? why : "null argument");
+    struct Entry { const char* name; size_t off, end; };
+    const Entry table[] = {
+        {"cifhr", L.off_cifhr, L.off_act}, {"seed_count", L.off_seed_count, L.off_seed_f},
+        {"seed_f", L.off_seed_f, L.off_seed_vxys}, {"seed_vxys", L.off_seed_vxys, L.off_lists},
+        {"lists", L.off_lists, L.off_list_counts}, {"list_counts", L.off_list_counts, L.off_lists_fc},
+        {"lists_fc", L.off_lists_fc, L.off_list_counts_fc}, {"list_counts_fc", L.off_list_counts_fc, L.off_occ},
+        {"occupancy", L.off_occ, L.off_anns}, {"annotation_scratch", L.off_anns, L.off_ann_meta},
+        {"status", L.off_status, L.total},
+    };
+    for (const Entry& e : table)
+        if (std::strcmp(e.name, what) == 0) {
+            if (offset_bytes) *offset_bytes = e.off;
+            if (size_bytes) *size_bytes = e.end - e.off;
+            return OPA_OK;
+        }
+    return fail(OPA_ERR_INVALID_ARGUMENT, std::string("opa_cifcaf_workspace_view: unknown buffer ") + what);
+}
+
 int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_params* params,
                       const float* cif_dev, const float* caf_dev,
                       const float* initial_dev, const int64_t* initial_ids_dev, int32_t n_initial,

@@ -5,31 +5,54 @@
 // _flood_fill (csrc/src/cifcaf.cpp:32-449), Occupancy (occupancy.cpp:13-79) and
 // NMSKeypoints::call (nms_keypoints.cpp:17-70).
 //
-// One wavefront per image (images are the data-parallel unit; a batch fills the
-// chip).  The reference's control flow is a serial dependency chain per image
-// (seed k is skipped iff an earlier pose occupies its cell; growth is a
-// best-first search), so the wave runs that control flow wave-uniformly and uses
-// its 64 lanes where the reference has inner loops:
-//   * 64 sorted seeds are tested against the occupancy map per step (ballot + ctz
-//     picks the next live seed);
-//   * grow_connection_blend scans a CAF candidate list 64 entries per step
-//     (coalesced SoA planes, L2 resident) and reduces top-1 / top-2 with
-//     cross-lane shuffles, reproducing the reference's ">=" / ">" tie rules by
-//     list position;
-//   * occupancy boxes are filled one row of lanes at a time; NMS tests all joints
-//     of a pose in one step.
-// The frontier is an exact re-implementation of the binary max-heap behind
-// std::priority_queue (sift-up on push, sift-down-to-leaf + sift-up on pop), so
-// that equal-priority entries -- the norm: all edges leaving one joint share the
-// bound sqrt(v) -- pop in the reference's order.  Joint confidences are kept in
-// double like the reference's Joint struct; every float/double promotion follows
-// the reference operation by operation and the library is built with
-// -ffp-contract=off.
+// One 4-wave workgroup per image (images are the data-parallel unit; a batch
+// fills the chip).  The reference's control flow is a serial dependency chain per
+// image (seed k is skipped iff an earlier pose occupies its cell; growth is a
+// best-first search) and every step of it is latency bound, so:
+//
+//  * All four waves run the SAME control flow on private, identical copies of the
+//    small state (current pose, frontier heap) in LDS -- replicated, deterministic,
+//    no synchronisation needed for it.
+//  * The expensive pure function, _connection_value (two grow_connection_blend list
+//    scans), is evaluated EAGERLY when a joint is assigned: the joint's outgoing
+//    edges are dealt to the four waves, each wave scans its CAF candidate lists
+//    (coalesced SoA planes from L2, 64 entries per lane-step, all loads of a scan in
+//    flight at once, top-1/top-2 by cross-lane shuffles with the reference's ">=" /
+//    ">" position tie rules) and publishes the result in a shared LDS connection
+//    cache; one workgroup barrier later every wave continues with the same cache.
+//    The frontier itself stays LAZY exactly like the reference's (an uncomputed
+//    entry carries the bound sqrt(v) and is re-pushed with its true score when
+//    popped): evaluation is a pure function of the start joint, so evaluating early
+//    changes nothing but the latency.
+//  * The frontier is an exact re-implementation of the binary max-heap behind
+//    std::priority_queue (sift-up on push, sift-to-leaf + sift-up on pop), so that
+//    equal-priority entries -- the norm: all edges leaving one joint share the
+//    bound -- pop in the reference's order.
+//  * 256 sorted seeds are tested against the occupancy map per step; occupancy
+//    boxes of a pose and NMS boxes are dealt to the waves.
+//
+// Joint confidences are double like the reference's Joint struct; every
+// float/double promotion follows the reference operation by operation and the
+// library is built with -ffp-contract=off.
 #include "common.hpp"
 
 namespace opa {
 
-// ------------------------------------------------------------------ helpers
+constexpr int kAssocWaves = 4;
+constexpr int kAssocThreads = kAssocWaves * kWave;
+constexpr int kBlendChunks = 8;        // list entries per lane held in registers by the single-pass scan
+
+// Optional phase timers (build with -DOPA_ASSOC_TIMING; tools/assoc_timing.py reads them).
+#ifdef OPA_ASSOC_TIMING
+#define OPA_T0(var) const long long var = wall_clock64()
+#define OPA_TACC(acc, var) (acc) += wall_clock64() - var
+#define OPA_TINC(acc, n) (acc) += (n)
+#else
+#define OPA_T0(var)
+#define OPA_TACC(acc, var)
+#define OPA_TINC(acc, n)
+#endif
+
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -39,44 +62,37 @@ struct ListView { const float* base; int cap; int n; };   // 7 SoA planes: c,x1,
 
 struct ImageCtx {
     int K, A, F;                         // F = occupancy fields = n_cif
+    int wave;
     const int32_t *adj_off, *adj_other, *adj_bone, *adj_fwd, *adj_first;
     const float* lists; const int32_t* list_counts; int list_cap;
     unsigned char* occ; int occ_h, occ_w;
-    // LDS
+    // private LDS (one copy per wave, kept identical)
     double* jv; float *jx, *jy, *js;     // current pose [K]
-    float* e_score; double* e_v; float *e_x, *e_y, *e_s; int* e_se;   // frontier entry pool [4A]
-    int* heap;                           // [4A] entry ids
+    unsigned long long* heap;            // [4A] nodes: float bits of max_score << 32 | entry id
+    double* e_v; float *e_x, *e_y, *e_s; int* e_se;   // frontier entry pool [4A]
     unsigned char* in_frontier;          // [2A]
+    int* pend;                           // [2A] edges pushed by the current frontier_add_from
     int heap_n, n_entries;
+    // shared LDS
+    double* cc_v; float *cc_x, *cc_y, *cc_s; unsigned char* cc_ok;   // connection cache [2A]
+    int* sh_counts;                      // [2A] list lengths of the active list set
+    long long t[8];                      // OPA_ASSOC_TIMING: 0 blend 1 #blend 2 #chunks 3 rest 4 grow 5 mark 6 nms 7 total
 };
 
 __device__ __forceinline__ ListView list_view(const ImageCtx& c, int bone, int dir) {
     ListView v;
     v.base = c.lists + ((size_t)bone * 2 + dir) * 7 * c.list_cap;
     v.cap = c.list_cap;
-    v.n = c.list_counts[bone * 2 + dir];
+    v.n = c.sh_counts[bone * 2 + dir];
     return v;
 }
 
 // -------------------------------------------------------- grow_connection_blend
 // cifcaf.cpp:32-103.  Returns false for the all-zero joint.
 struct BlendQuery { double x, y, xlo, xhi, ylo, yhi; float sigma2; };
+struct BlendResult { double v; float x, y, s; int ok; };
 
-__device__ __forceinline__ bool entry_score(const ListView& L, int i, const BlendQuery& q, float* score) {
-    const float x1 = L.base[1 * L.cap + i], y1 = L.base[2 * L.cap + i];
-    if ((double)x1 < q.xlo) return false;                      // cifcaf.cpp:54-57
-    if ((double)x1 > q.xhi) return false;
-    if ((double)y1 < q.ylo) return false;
-    if ((double)y1 > q.yhi) return false;
-    const double dx = (double)x1 - q.x, dy = (double)y1 - q.y;
-    const float d2 = (float)(dx * dx + dy * dy);               // :60
-    *score = (float)(exp(-0.5 * (double)d2 / (double)q.sigma2) * (double)L.base[i]);   // :63
-    return true;
-}
-
-__device__ bool blend(const ListView& L, double x, double y, double xy_scale, double filter_sigmas,
-                      bool only_max, double* ov, float* ox, float* oy, float* os) {
-    const int lane = lane_id();
+__device__ __forceinline__ BlendQuery make_query(double x, double y, double xy_scale, double filter_sigmas) {
     xy_scale = fmax(xy_scale, 0.5);                            // :44
     const float sigma_filter = (float)(filter_sigmas * xy_scale / 2.0);   // :47
     BlendQuery q;
@@ -84,87 +100,218 @@ __device__ bool blend(const ListView& L, double x, double y, double xy_scale, do
     q.sigma2 = (float)(0.25 * xy_scale * xy_scale);            // :48
     q.xlo = x - (double)sigma_filter; q.xhi = x + (double)sigma_filter;
     q.ylo = y - (double)sigma_filter; q.yhi = y + (double)sigma_filter;
+    return q;
+}
 
-    // pass 1: first place = max score, LAST list position among equals (">=", :65)
-    float s1 = 0.0f; int i1 = -1;
-    for (int i = lane; i < L.n; i += kWave) {
-        float sc;
-        if (entry_score(L, i, q, &sc) && sc >= s1) { s1 = sc; i1 = i; }
-    }
+__device__ __forceinline__ bool passes(const BlendQuery& q, float x1, float y1) {
+    if ((double)x1 < q.xlo) return false;                      // cifcaf.cpp:54-57
+    if ((double)x1 > q.xhi) return false;
+    if ((double)y1 < q.ylo) return false;
+    if ((double)y1 > q.yhi) return false;
+    return true;
+}
+
+__device__ __forceinline__ float score_of(const BlendQuery& q, float x1, float y1, float c) {
+    const double dx = (double)x1 - q.x, dy = (double)y1 - q.y;
+    const float d2 = (float)(dx * dx + dy * dy);               // :60
+    return (float)(exp(-0.5 * (double)d2 / (double)q.sigma2) * (double)c);   // :63
+}
+
+// first place = max score, LAST list position among equals (">=", :65)
+__device__ __forceinline__ void reduce_first(float& s1, int& i1) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float so = __shfl_xor(s1, off); const int io = __shfl_xor(i1, off);
         if (so > s1 || (so == s1 && io > i1)) { s1 = so; i1 = io; }
     }
-    if (s1 == 0.0f || i1 < 0) return false;                    // :76
-
-    const float e1x = L.base[3 * L.cap + i1], e1y = L.base[4 * L.cap + i1];
-    const float e1s = fmaxf(0.0f, L.base[6 * L.cap + i1]);    // :78-81
-    if (only_max) { *ov = (double)s1; *ox = e1x; *oy = e1y; *os = e1s; return true; }
-
-    // pass 2: second place.  Sequential rule (:65-73) == max score among the rest;
-    // among equals: the last position before i1 if any, else the first after i1.
-    float s2 = 0.0f; int r2 = -1;
-    for (int i = lane; i < L.n; i += kWave) {
-        float sc;
-        if (i == i1 || !entry_score(L, i, q, &sc) || !(sc > 0.0f)) continue;
-        const int rank = i < i1 ? L.n + i : L.n - i;
-        if (sc > s2 || (sc == s2 && rank > r2)) { s2 = sc; r2 = rank; }
-    }
+}
+// second place: max score among the rest; among equals the last position before
+// i1 if any, else the first after i1 (the outcome of the sequential rule :65-73).
+// rank(i) = i < i1 ? n + i : n - i, larger wins.
+__device__ __forceinline__ void reduce_second(float& s2, int& r2) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const float so = __shfl_xor(s2, off); const int ro = __shfl_xor(r2, off);
         if (so > s2 || (so == s2 && ro > r2)) { s2 = so; r2 = ro; }
     }
-    if (r2 < 0 || (double)s2 < 0.01 || (double)s2 < 0.5 * (double)s1) {     // :84-85
-        *ov = 0.5 * (double)s1; *ox = e1x; *oy = e1y; *os = e1s; return true;
+}
+
+__device__ __forceinline__ BlendResult blend_none() { BlendResult r; r.v = 0.0; r.x = r.y = r.s = 0.f; r.ok = 0; return r; }
+
+__device__ __forceinline__ BlendResult blend_finish(float s1, float s2, bool have2, bool only_max,
+                                                    float e1x, float e1y, float e1s, float e2x, float e2y, float e2s) {
+    BlendResult r; r.ok = 1;
+    e1s = fmaxf(0.0f, e1s);                                    // :78-81
+    if (only_max) { r.v = (double)s1; r.x = e1x; r.y = e1y; r.s = e1s; return r; }
+    if (!have2 || (double)s2 < 0.01 || (double)s2 < 0.5 * (double)s1) {     // :84-85
+        r.v = 0.5 * (double)s1; r.x = e1x; r.y = e1y; r.s = e1s; return r;
     }
-    const int i2 = r2 >= L.n ? r2 - L.n : L.n - r2;
-    const float e2x = L.base[3 * L.cap + i2], e2y = L.base[4 * L.cap + i2];
-    const float e2s = fmaxf(0.0f, L.base[6 * L.cap + i2]);    // :88-91
+    e2s = fmaxf(0.0f, e2s);                                    // :88-91
     const double ddx = (double)(e1x - e2x), ddy = (double)(e1y - e2y);
     const float blend_d2 = (float)(ddx * ddx + ddy * ddy);     // :93
     if ((double)blend_d2 > ((double)e1s * (double)e1s) / 4.0) {             // :94-95
-        *ov = 0.5 * (double)s1; *ox = e1x; *oy = e1y; *os = e1s; return true;
+        r.v = 0.5 * (double)s1; r.x = e1x; r.y = e1y; r.s = e1s; return r;
     }
     const float ssum = s1 + s2;                                // :97-102
-    *ov = 0.5 * (double)ssum;
-    *ox = (s1 * e1x + s2 * e2x) / ssum;
-    *oy = (s1 * e1y + s2 * e2y) / ssum;
-    *os = (s1 * e1s + s2 * e2s) / ssum;
-    return true;
+    r.v = 0.5 * (double)ssum;
+    r.x = (s1 * e1x + s2 * e2x) / ssum;
+    r.y = (s1 * e1y + s2 * e2y) / ssum;
+    r.s = (s1 * e1s + s2 * e2s) / ssum;
+    return r;
+}
+
+// Lists of up to 64*R entries: ONE memory round trip.  Every lane issues all its
+// loads (6 planes x R chunks, global address space) back to back, an empty asm
+// pins them there (hipcc otherwise sinks each load into the branch that uses it and
+// waits for them one by one), scores and targets stay in registers, and both
+// reductions and the target lookups are register/cross-lane only.
+typedef __attribute__((address_space(1))) const float gfloat;
+
+template <int R>
+__device__ __forceinline__ BlendResult blend_cached(const ListView& L, const BlendQuery& q, bool only_max) {
+    const int lane = lane_id();
+    const gfloat* g = (const gfloat*)L.base;
+    float sc[R], tx[R], ty[R], ts[R], x1[R], y1[R], cc[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = r * kWave + lane;
+        const int ii = i < L.n ? i : 0;
+        x1[r] = g[1 * L.cap + ii]; y1[r] = g[2 * L.cap + ii]; cc[r] = g[ii];
+        tx[r] = g[3 * L.cap + ii]; ty[r] = g[4 * L.cap + ii]; ts[r] = g[6 * L.cap + ii];
+    }
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]), "+v"(tx[r]), "+v"(ty[r]), "+v"(ts[r]) :: "memory");
+        sc[r] = -1.0f;
+    }
+    float s1 = 0.0f; int i1 = -1;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = r * kWave + lane;
+        if (i < L.n && passes(q, x1[r], y1[r])) {
+            sc[r] = score_of(q, x1[r], y1[r], cc[r]);
+            if (sc[r] >= s1) { s1 = sc[r]; i1 = i; }
+        }
+    }
+    reduce_first(s1, i1);
+    if (s1 == 0.0f || i1 < 0) return blend_none();             // :76
+    float s2 = 0.0f; int r2 = -1;
+    if (!only_max) {
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int i = r * kWave + lane;
+            if (i == i1 || !(sc[r] > 0.0f)) continue;
+            const int rank = i < i1 ? L.n + i : L.n - i;
+            if (sc[r] > s2 || (sc[r] == s2 && rank > r2)) { s2 = sc[r]; r2 = rank; }
+        }
+        reduce_second(s2, r2);
+    }
+    const bool have2 = r2 >= 0;
+    const int i2 = have2 ? (r2 >= L.n ? r2 - L.n : L.n - r2) : i1;
+    // fetch the two targets from the owning lanes' registers
+    const int c1 = i1 >> 6, c2 = i2 >> 6;
+    float p1x = 0.f, p1y = 0.f, p1s = 0.f, p2x = 0.f, p2y = 0.f, p2s = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        if (r == c1) { p1x = tx[r]; p1y = ty[r]; p1s = ts[r]; }
+        if (r == c2) { p2x = tx[r]; p2y = ty[r]; p2s = ts[r]; }
+    }
+    const float e1x = __shfl(p1x, i1 & 63), e1y = __shfl(p1y, i1 & 63), e1s = __shfl(p1s, i1 & 63);
+    const float e2x = __shfl(p2x, i2 & 63), e2y = __shfl(p2y, i2 & 63), e2s = __shfl(p2s, i2 & 63);
+    return blend_finish(s1, s2, have2, only_max, e1x, e1y, e1s, e2x, e2y, e2s);
+}
+
+// Any list length: two passes over the list (scores recomputed in pass 2).
+__device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const BlendQuery& q, bool only_max) {
+    const int lane = lane_id();
+    float s1 = 0.0f; int i1 = -1;
+    for (int i = lane; i < L.n; i += kWave) {
+        const float x1 = L.base[1 * L.cap + i], y1 = L.base[2 * L.cap + i];
+        if (!passes(q, x1, y1)) continue;
+        const float sc = score_of(q, x1, y1, L.base[i]);
+        if (sc >= s1) { s1 = sc; i1 = i; }
+    }
+    reduce_first(s1, i1);
+    if (s1 == 0.0f || i1 < 0) return blend_none();             // :76
+    float s2 = 0.0f; int r2 = -1;
+    if (!only_max) {
+        for (int i = lane; i < L.n; i += kWave) {
+            if (i == i1) continue;
+            const float x1 = L.base[1 * L.cap + i], y1 = L.base[2 * L.cap + i];
+            if (!passes(q, x1, y1)) continue;
+            const float sc = score_of(q, x1, y1, L.base[i]);
+            if (!(sc > 0.0f)) continue;
+            const int rank = i < i1 ? L.n + i : L.n - i;
+            if (sc > s2 || (sc == s2 && rank > r2)) { s2 = sc; r2 = rank; }
+        }
+        reduce_second(s2, r2);
+    }
+    const bool have2 = r2 >= 0;
+    const int i2 = have2 ? (r2 >= L.n ? r2 - L.n : L.n - r2) : i1;
+    const float e1x = L.base[3 * L.cap + i1], e1y = L.base[4 * L.cap + i1], e1s = L.base[6 * L.cap + i1];
+    const float e2x = L.base[3 * L.cap + i2], e2y = L.base[4 * L.cap + i2], e2s = L.base[6 * L.cap + i2];
+    return blend_finish(s1, s2, have2, only_max, e1x, e1y, e1s, e2x, e2y, e2s);
+}
+
+// The one real (non-inlined) device function of the kernel: everything is passed and
+// returned by value in registers.
+__device__ __noinline__ BlendResult blend_impl(const float* base, int cap, int n, double x, double y,
+                                               double xy_scale, double filter_sigmas, int only_max) {
+    if (n <= 0) return blend_none();
+    ListView L; L.base = base; L.cap = cap; L.n = n;
+    const BlendQuery q = make_query(x, y, xy_scale, filter_sigmas);
+    if (n <= kWave) return blend_cached<1>(L, q, only_max != 0);
+    if (n <= 2 * kWave) return blend_cached<2>(L, q, only_max != 0);
+    if (n <= 4 * kWave) return blend_cached<4>(L, q, only_max != 0);
+    if (n <= kBlendChunks * kWave) return blend_cached<kBlendChunks>(L, q, only_max != 0);
+    return blend_streamed(L, q, only_max != 0);
+}
+
+__device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, double x, double y, double xy_scale,
+                                             double filter_sigmas) {
+    OPA_T0(t0);
+    const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0);
+    OPA_TACC(c.t[0], t0); OPA_TINC(c.t[1], 1); OPA_TINC(c.t[2], (L.n + kWave - 1) / kWave);
+    return r;
 }
 
 // -------------------------------------------------------------- frontier heap
 // Exact behaviour of std::priority_queue<FrontierEntry, vector, FrontierCompare>
 // (cifcaf.hpp:93, cifcaf.cpp:27-29): comp(a,b) = a.max_score < b.max_score.
-__device__ __forceinline__ bool heap_less(const ImageCtx& c, int a, int b) { return c.e_score[a] < c.e_score[b]; }
+// max_score is a non-negative float, so its bit pattern orders like the value.
+__device__ __forceinline__ bool heap_less(unsigned long long a, unsigned long long b) {
+    return (unsigned)(a >> 32) < (unsigned)(b >> 32);
+}
 
-__device__ void heap_sift_up(ImageCtx& c, int hole, int top, int value) {
+__device__ __forceinline__ void heap_sift_up(ImageCtx& c, int hole, int top, unsigned long long value) {
     int parent = (hole - 1) / 2;
-    while (hole > top && heap_less(c, c.heap[parent], value)) {
-        c.heap[hole] = c.heap[parent];
+    while (hole > top) {
+        const unsigned long long pv = c.heap[parent];
+        if (!heap_less(pv, value)) break;
+        c.heap[hole] = pv;
         hole = parent;
         parent = (hole - 1) / 2;
     }
     c.heap[hole] = value;
 }
 
-__device__ void heap_push(ImageCtx& c, int entry) {
+__device__ __forceinline__ void heap_push(ImageCtx& c, float score, int entry) {
     c.heap_n++;
-    heap_sift_up(c, c.heap_n - 1, 0, entry);
+    heap_sift_up(c, c.heap_n - 1, 0, ((unsigned long long)__float_as_uint(score) << 32) | (unsigned)entry);
 }
 
-__device__ int heap_pop(ImageCtx& c) {          // returns the top entry id
-    const int top = c.heap[0];
+__device__ __forceinline__ int heap_pop(ImageCtx& c) {          // returns the top entry id
+    const int top = (int)(c.heap[0] & 0xffffffffull);
     const int len = c.heap_n - 1;               // heap length after removing the back
     if (len > 0) {
-        const int value = c.heap[len];
+        const unsigned long long value = c.heap[len];
         int hole = 0, child = 0;
         while (child < (len - 1) / 2) {
             child = 2 * (child + 1);
-            if (heap_less(c, c.heap[child], c.heap[child - 1])) child--;
-            c.heap[hole] = c.heap[child];
+            unsigned long long cv = c.heap[child];
+            const unsigned long long lv = c.heap[child - 1];
+            if (heap_less(cv, lv)) { child--; cv = lv; }
+            c.heap[hole] = cv;
             hole = child;
         }
         if ((len & 1) == 0 && child == (len - 2) / 2) {
@@ -178,91 +325,113 @@ __device__ int heap_pop(ImageCtx& c) {          // returns the top entry id
     return top;
 }
 
-__device__ int new_entry(ImageCtx& c, float score, double v, float x, float y, float s, int start, int end) {
+__device__ __forceinline__ int new_entry(ImageCtx& c, double v, float x, float y, float s, int start, int end) {
     const int e = c.n_entries++;
-    c.e_score[e] = score; c.e_v[e] = v; c.e_x[e] = x; c.e_y[e] = y; c.e_s[e] = s;
+    c.e_v[e] = v; c.e_x[e] = x; c.e_y[e] = y; c.e_s[e] = s;
     c.e_se[e] = (start << 16) | end;
     return e;
 }
 
-// cifcaf.cpp:316-346
-__device__ void frontier_add_from(ImageCtx& c, int start) {
-    const float max_score = (float)sqrt(c.jv[start]);
-    for (int t = c.adj_off[start]; t < c.adj_off[start + 1]; t++) {
-        const int other = c.adj_other[t];
-        if (c.jv[other] > 0.0) continue;
-        const int first = c.adj_first[t];
-        if (c.in_frontier[first]) continue;
-        heap_push(c, new_entry(c, max_score, 0.0, 0.f, 0.f, 0.f, start, other));
-        c.in_frontier[first] = 1;
-    }
-}
-
 // cifcaf.cpp:349-411 ; t = adjacency slot of (start -> end)
-__device__ bool connection_value(ImageCtx& c, const DevParams& p, int start, int t,
+__device__ __forceinline__ bool connection_value(ImageCtx& c, const DevParams& p, int start, int t,
                                  bool reverse_match_, double filter_sigmas,
                                  double* nv, float* nx, float* ny, float* ns) {
     const int bone = c.adj_bone[t], fwd = c.adj_fwd[t];
     const ListView caf_f = list_view(c, bone, fwd ? 0 : 1);
     const ListView caf_b = list_view(c, bone, fwd ? 1 : 0);
     const double sv = c.jv[start], sx = (double)c.jx[start], sy = (double)c.jy[start], ss = (double)c.js[start];
-    if (!blend(caf_f, sx, sy, ss, filter_sigmas, false, nv, nx, ny, ns)) return false;
-    *nv = sqrt(*nv * sv);                                                       // :386
+    const BlendResult nj = blend(c, caf_f, sx, sy, ss, filter_sigmas);
+    if (!nj.ok) return false;
+    *nx = nj.x; *ny = nj.y; *ns = nj.s;
+    *nv = sqrt(nj.v * sv);                                                      // :386
     if (*nv < p.keypoint_threshold || *nv < sv * p.keypoint_threshold_rel) return false;   // :387-390
     if (p.reverse_match && reverse_match_ && start < c.F) {                     // :397
-        double rv; float rx, ry, rs;
-        if (!blend(caf_b, (double)*nx, (double)*ny, (double)*ns, filter_sigmas, false, &rv, &rx, &ry, &rs))
-            return false;
-        if (fabs(sx - (double)rx) + fabs(sy - (double)ry) > ss) return false;   // :404
+        const BlendResult rj = blend(c, caf_b, (double)*nx, (double)*ny, (double)*ns, filter_sigmas);
+        if (!rj.ok) return false;
+        if (fabs(sx - (double)rj.x) + fabs(sy - (double)rj.y) > ss) return false;   // :404
     }
     return true;
 }
 
-__device__ void frontier_reset(ImageCtx& c) {
+// cifcaf.cpp:316-346, plus the eager evaluation of the edges it pushed.
+// `evaluate`: false for flood fill (no connection values needed).
+__device__ __forceinline__ void frontier_add_from(ImageCtx& c, const DevParams& p, int start, bool evaluate,
+                                  bool reverse_match_, double filter_sigmas) {
+    const float max_score = (float)sqrt(c.jv[start]);
+    int n_pend = 0;
+    for (int t = c.adj_off[start]; t < c.adj_off[start + 1]; t++) {
+        const int other = c.adj_other[t];
+        if (c.jv[other] > 0.0) continue;
+        const int first = c.adj_first[t];
+        if (c.in_frontier[first]) continue;
+        heap_push(c, max_score, new_entry(c, 0.0, 0.f, 0.f, 0.f, start, other));
+        c.in_frontier[first] = 1;
+        c.pend[n_pend++] = first;
+    }
+    if (!evaluate) return;
+    // deal the new edges to the waves; publish results in the shared connection cache
+    for (int r0 = 0; r0 < n_pend; r0 += kAssocWaves) {
+        const int k = r0 + c.wave;
+        if (k < n_pend) {
+            const int slot = c.pend[k];
+            double v; float x, y, s;
+            const bool ok = connection_value(c, p, start, slot, reverse_match_, filter_sigmas, &v, &x, &y, &s);
+            if (lane_id() == 0) {
+                c.cc_ok[slot] = ok ? 1 : 0;
+                if (ok) { c.cc_v[slot] = v; c.cc_x[slot] = x; c.cc_y[slot] = y; c.cc_s[slot] = s; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void frontier_reset(ImageCtx& c) {
     const int lane = lane_id();
     for (int t = lane; t < 2 * c.A; t += kWave) c.in_frontier[t] = 0;
     c.heap_n = 0; c.n_entries = 0;
     wave_sync();
 }
 
-__device__ int find_adj_slot(const ImageCtx& c, int start, int end) {
+__device__ __forceinline__ int find_adj_slot(const ImageCtx& c, int start, int end) {
     for (int t = c.adj_off[start]; t < c.adj_off[start + 1]; t++)
         if (c.adj_other[t] == end) return c.adj_first[t];
     return -1;
 }
 
 // cifcaf.cpp:265-313
-__device__ void grow(ImageCtx& c, const DevParams& p, int greedy, bool reverse_match_, double filter_sigmas) {
+__device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool reverse_match_, double filter_sigmas) {
     frontier_reset(c);
-    for (int j = 0; j < c.K; j++) if (c.jv[j] != 0.0) frontier_add_from(c, j);
+    for (int j = 0; j < c.K; j++)
+        if (c.jv[j] != 0.0) frontier_add_from(c, p, j, true, reverse_match_, filter_sigmas);
     while (c.heap_n > 0) {
         const int e = heap_pop(c);
         const int start = c.e_se[e] >> 16, end = c.e_se[e] & 0xffff;
         if (c.jv[end] > 0.0) continue;                                   // :284
         double v = c.e_v[e]; float x = c.e_x[e], y = c.e_y[e], s = c.e_s[e];
-        if (v == 0.0) {                                                  // :287
-            const int t = find_adj_slot(c, start, end);
-            if (!connection_value(c, p, start, t, reverse_match_, filter_sigmas, &v, &x, &y, &s)) continue;
-            if (!greedy) {                                               // :298-303
-                heap_push(c, new_entry(c, (float)v, v, x, y, s, start, end));
+        if (v == 0.0) {                                                  // :287: not computed yet
+            const int slot = find_adj_slot(c, start, end);
+            if (!c.cc_ok[slot]) continue;                                // :290-296 (block_joints is a no-op)
+            v = c.cc_v[slot]; x = c.cc_x[slot]; y = c.cc_y[slot]; s = c.cc_s[slot];
+            if (!p.greedy) {                                             // :298-303
+                heap_push(c, (float)v, new_entry(c, v, x, y, s, start, end));
                 continue;
             }
         }
         c.jv[end] = v; c.jx[end] = x; c.jy[end] = y; c.js[end] = s;     // :310
-        frontier_add_from(c, end);
+        frontier_add_from(c, p, end, true, reverse_match_, filter_sigmas);
     }
 }
 
 // cifcaf.cpp:429-449
-__device__ void flood_fill(ImageCtx& c) {
+__device__ __forceinline__ void flood_fill(ImageCtx& c, const DevParams& p) {
     frontier_reset(c);
-    for (int j = 0; j < c.K; j++) if (c.jv[j] != 0.0) frontier_add_from(c, j);
+    for (int j = 0; j < c.K; j++) if (c.jv[j] != 0.0) frontier_add_from(c, p, j, false, false, 0.0);
     while (c.heap_n > 0) {
         const int e = heap_pop(c);
         const int start = c.e_se[e] >> 16, end = c.e_se[e] & 0xffff;
         if (c.jv[end] > 0.0) continue;
         c.jv[end] = 0.00001; c.jx[end] = c.jx[start]; c.jy[end] = c.jy[start]; c.js[end] = c.js[start];
-        frontier_add_from(c, end);
+        frontier_add_from(c, p, end, false, false, 0.0);
     }
 }
 
@@ -275,8 +444,8 @@ __device__ __forceinline__ size_t occ_cell(const ImageCtx& c, const DevParams& p
     return ((size_t)f * c.occ_h + yi) * c.occ_w + xi;
 }
 
-// occupancy.cpp:13-29, all lanes cooperate on one box
-__device__ void occ_set(const ImageCtx& c, const DevParams& p, int f, double x, double y, double sigma,
+// occupancy.cpp:13-29, the 64 lanes of one wave cooperate on one box
+__device__ __forceinline__ void occ_set(const ImageCtx& c, const DevParams& p, int f, double x, double y, double sigma,
                         unsigned char level) {
     if (p.occupancy_reduction != 1.0) {
         x /= p.occupancy_reduction; y /= p.occupancy_reduction;
@@ -303,69 +472,96 @@ __device__ void occ_set(const ImageCtx& c, const DevParams& p, int f, double x, 
     }
 }
 
-// mark every filled joint of the current pose, cifcaf.cpp:225-229
-__device__ void mark_pose(const ImageCtx& c, const DevParams& p) {
+// mark every filled joint of the current pose (cifcaf.cpp:225-229), boxes dealt to the waves
+__device__ __forceinline__ void mark_pose(const ImageCtx& c, const DevParams& p) {
+    int n = 0;
     for (int f = 0; f < c.F; f++) {
         if (c.jv[f] == 0.0) continue;
-        occ_set(c, p, f, (double)c.jx[f], (double)c.jy[f], (double)c.js[f], 1);
+        if ((n++ % kAssocWaves) == c.wave) occ_set(c, p, f, (double)c.jx[f], (double)c.jy[f], (double)c.js[f], 1);
     }
-    __threadfence_block();
+    __syncthreads();                      // stores drained + visible to every wave of the workgroup
 }
 
 // nms_keypoints.hpp:25-32 on the LDS pose
-__device__ double pose_score_lds(const ImageCtx& c) {
+__device__ __forceinline__ double pose_score_lds(const ImageCtx& c) {
     double acc = 0.0;
     for (int k = 0; k < c.K; k++) { const float i = (float)acc; acc = (double)i + c.jv[k]; }
     return acc / (double)c.K;
 }
 
+__host__ __device__ inline size_t assoc_private_bytes(int K, int A) {
+    const int P4 = 4 * A, E = 2 * A;
+    const size_t b = sizeof(double) * (K + P4) + sizeof(unsigned long long) * P4 + sizeof(float) * (3 * K + 3 * P4)
+                   + sizeof(int) * (P4 + E) + E;
+    return (b + 15) / 16 * 16;
+}
+
 // ------------------------------------------------------------------- kernel
-__global__ __launch_bounds__(64) void cifcaf_assoc_kernel(AssocArgs a, DevSkeleton sk, DevParams p) {
+__global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArgs a, DevSkeleton sk, DevParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x, lane = lane_id();
+    const int b = blockIdx.x, tid = threadIdx.x, lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = a.K, A = a.A, E = 2 * A, P4 = 4 * A;
+    const int KC = (K + kWave - 1) / kWave;          // 64-joint chunks per pose
 
     ImageCtx c;
-    c.K = K; c.A = A; c.F = K;
+    c.K = K; c.A = A; c.F = K; c.wave = wave;
     c.adj_off = sk.adj_off; c.adj_other = sk.adj_other; c.adj_bone = sk.adj_bone; c.adj_fwd = sk.adj_fwd;
     c.adj_first = sk.adj_first;
-    const int greedy = p.greedy;
     c.lists = a.lists + (size_t)b * A * 2 * 7 * a.list_cap;
     c.list_counts = a.list_counts + (size_t)b * A * 2;
     c.list_cap = a.list_cap;
     c.occ = a.occ + (size_t)b * K * a.occ_h * a.occ_w; c.occ_h = a.occ_h; c.occ_w = a.occ_w;
-    // LDS carve (8-byte items first)
+
+    // ---- LDS carve: shared part, then one private part per wave
     unsigned char* sp = smem;
+    c.cc_v = (double*)sp; sp += sizeof(double) * E;
+    double* nms_score = (double*)sp; sp += sizeof(double) * a.max_ann;
+    unsigned long long* nms_supp = (unsigned long long*)sp; sp += sizeof(unsigned long long) * a.max_ann * KC;
+    unsigned long long* sh_mask = (unsigned long long*)sp; sp += sizeof(unsigned long long) * 2 * kAssocWaves;
+    c.cc_x = (float*)sp; sp += sizeof(float) * E;
+    c.cc_y = (float*)sp; sp += sizeof(float) * E;
+    c.cc_s = (float*)sp; sp += sizeof(float) * E;
+    c.sh_counts = (int*)sp; sp += sizeof(int) * E;
+    int* nms_order = (int*)sp; sp += sizeof(int) * a.max_ann;
+    int* nms_rank = (int*)sp; sp += sizeof(int) * a.max_ann;
+    c.cc_ok = sp; sp += (E + 15) / 16 * 16;
+    sp += (size_t)wave * assoc_private_bytes(K, A);
     c.jv = (double*)sp; sp += sizeof(double) * K;
     c.e_v = (double*)sp; sp += sizeof(double) * P4;
-    double* nms_score = (double*)sp; sp += sizeof(double) * a.max_ann;
+    c.heap = (unsigned long long*)sp; sp += sizeof(unsigned long long) * P4;
     c.jx = (float*)sp; sp += sizeof(float) * K;
     c.jy = (float*)sp; sp += sizeof(float) * K;
     c.js = (float*)sp; sp += sizeof(float) * K;
-    c.e_score = (float*)sp; sp += sizeof(float) * P4;
     c.e_x = (float*)sp; sp += sizeof(float) * P4;
     c.e_y = (float*)sp; sp += sizeof(float) * P4;
     c.e_s = (float*)sp; sp += sizeof(float) * P4;
     c.e_se = (int*)sp; sp += sizeof(int) * P4;
-    c.heap = (int*)sp; sp += sizeof(int) * P4;
-    int* nms_order = (int*)sp; sp += sizeof(int) * a.max_ann;
-    c.in_frontier = sp; sp += E;
+    c.pend = (int*)sp; sp += sizeof(int) * E;
+    c.in_frontier = sp;
     c.heap_n = 0; c.n_entries = 0;
+    for (int k = 0; k < 8; k++) c.t[k] = 0;
+    OPA_T0(t_total);
+
+    for (int k = tid; k < E; k += kAssocThreads) c.sh_counts[k] = c.list_counts[k];
+    __syncthreads();
 
     double* anns = a.anns + (size_t)b * a.max_ann * K * 4;
     int64_t* ann_ids = a.ann_ids + (size_t)b * a.max_ann;
     int n_kept = 0, n_dropped = 0;
     const bool prune = !p.force_complete;     // a pose scoring below the instance threshold before NMS cannot survive it
 
-    auto store_pose = [&](long long id) {
+    auto store_pose = [&](long long id) {     // wave 0 writes; every wave counts
         if (prune && pose_score_lds(c) < p.nms_instance_threshold) return;
         if (n_kept >= a.max_ann) { n_dropped++; return; }
-        double* dst = anns + (size_t)n_kept * K * 4;
-        for (int k = lane; k < K; k += kWave) {
-            dst[4 * k + 0] = c.jv[k]; dst[4 * k + 1] = (double)c.jx[k];
-            dst[4 * k + 2] = (double)c.jy[k]; dst[4 * k + 3] = (double)c.js[k];
+        if (wave == 0) {
+            double* dst = anns + (size_t)n_kept * K * 4;
+            for (int k = lane; k < K; k += kWave) {
+                dst[4 * k + 0] = c.jv[k]; dst[4 * k + 1] = (double)c.jx[k];
+                dst[4 * k + 2] = (double)c.jy[k]; dst[4 * k + 3] = (double)c.js[k];
+            }
+            if (lane == 0) ann_ids[n_kept] = id;
         }
-        if (lane == 0) ann_ids[n_kept] = id;
         n_kept++;
     };
 
@@ -377,44 +573,54 @@ __global__ __launch_bounds__(64) void cifcaf_assoc_kernel(AssocArgs a, DevSkelet
             c.jy[k] = src[4 * k + 2]; c.js[k] = src[4 * k + 3];
         }
         wave_sync();
-        grow(c, p, greedy, true, 1.0);
+        grow(c, p, true, 1.0);
         mark_pose(c, p);
         store_pose(a.initial_ids ? a.initial_ids[(size_t)b * a.n_initial + n] : -1);
     }
 
-    // ---- seeds in score order, cifcaf.cpp:206-231
+    // ---- seeds in score order, cifcaf.cpp:206-231; 256 seeds per occupancy test
     int n_seeds = a.seed_count[b];
     if (n_seeds > a.seed_cap) n_seeds = a.seed_cap;
     const int32_t* seed_f = a.seed_f + (size_t)b * a.seed_cap;
     const float4* seed_vxys = reinterpret_cast<const float4*>(a.seed_vxys) + (size_t)b * a.seed_cap;
-    int pos = 0;
+    int pos = 0, parity = 0;
     while (pos < n_seeds) {
-        const int i = pos + lane;
-        bool live = false; int f = 0; float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int i = pos + tid;
+        bool live = false;
         if (i < n_seeds) {
-            f = seed_f[i]; s = seed_vxys[i];
+            const int f = seed_f[i]; const float4 s = seed_vxys[i];
             live = c.occ[occ_cell(c, p, f, (double)s.y, (double)s.z)] == 0;     // :211
         }
         const unsigned long long mask = __ballot(live);
-        if (mask == 0) { pos += kWave; continue; }
-        const int l = __builtin_ctzll(mask);
-        const int sf = __shfl(f, l);
-        const float sv = __shfl(s.x, l), sx = __shfl(s.y, l), sy = __shfl(s.z, l), ss = __shfl(s.w, l);
+        if (lane == 0) sh_mask[parity * kAssocWaves + wave] = mask;
+        __syncthreads();
+        int first = -1;
+#pragma unroll
+        for (int w = kAssocWaves - 1; w >= 0; w--) {
+            const unsigned long long m = sh_mask[parity * kAssocWaves + w];
+            if (m) first = w * kWave + __builtin_ctzll(m);
+        }
+        parity ^= 1;
+        if (first < 0) { pos += kAssocThreads; continue; }
+        const int si = pos + first;
+        const int sf = seed_f[si]; const float4 sd = seed_vxys[si];
         for (int k = lane; k < K; k += kWave) { c.jv[k] = 0.0; c.jx[k] = 0.f; c.jy[k] = 0.f; c.js[k] = 0.f; }
         wave_sync();
-        c.jv[sf] = (double)sv; c.jx[sf] = sx; c.jy[sf] = sy; c.js[sf] = ss;   // :213-218
+        c.jv[sf] = (double)sd.x; c.jx[sf] = sd.y; c.jy[sf] = sd.z; c.js[sf] = sd.w;   // :213-218
         wave_sync();
-        grow(c, p, greedy, true, 1.0);
-        mark_pose(c, p);
+        { OPA_T0(tg); grow(c, p, true, 1.0); OPA_TACC(c.t[4], tg); }
+        { OPA_T0(tm); mark_pose(c, p); OPA_TACC(c.t[5], tm); }
         store_pose(-1);
-        pos += l + 1;
+        pos = si + 1;
     }
-    __threadfence_block();
+    __syncthreads();
 
     // ---- force complete, cifcaf.cpp:233-236,414-449
     if (p.force_complete) {
         c.lists = a.lists_fc + (size_t)b * A * 2 * 7 * a.list_cap;
         c.list_counts = a.list_counts_fc + (size_t)b * A * 2;
+        for (int k = tid; k < E; k += kAssocThreads) c.sh_counts[k] = c.list_counts[k];
+        __syncthreads();
         for (int pass = 0; pass < 2; pass++) {          // all grows first, then all flood fills
             for (int n = 0; n < n_kept; n++) {
                 double* src = anns + (size_t)n * K * 4;
@@ -423,113 +629,130 @@ __global__ __launch_bounds__(64) void cifcaf_assoc_kernel(AssocArgs a, DevSkelet
                     c.jy[k] = (float)src[4 * k + 2]; c.js[k] = (float)src[4 * k + 3];
                 }
                 wave_sync();
-                if (pass == 0) grow(c, p, greedy, false, 4.0); else flood_fill(c);
+                if (pass == 0) grow(c, p, false, 4.0); else flood_fill(c, p);
                 wave_sync();
-                for (int k = lane; k < K; k += kWave) {
-                    src[4 * k + 0] = c.jv[k]; src[4 * k + 1] = (double)c.jx[k];
-                    src[4 * k + 2] = (double)c.jy[k]; src[4 * k + 3] = (double)c.js[k];
-                }
-                __threadfence_block();
+                __syncthreads();                        // every wave has read the pose before wave 0 rewrites it
+                if (wave == 0)
+                    for (int k = lane; k < K; k += kWave) {
+                        src[4 * k + 0] = c.jv[k]; src[4 * k + 1] = (double)c.jx[k];
+                        src[4 * k + 2] = (double)c.jy[k]; src[4 * k + 3] = (double)c.js[k];
+                    }
             }
+            __syncthreads();
         }
     }
 
     // ---- keypoint NMS, nms_keypoints.cpp:17-70
-    auto global_score = [&](int n) {                    // UniformScore on a stored pose
+    OPA_T0(t_nms);
+    for (int n = tid; n < n_kept; n += kAssocThreads) {  // UniformScore of every stored pose
         const double* src = anns + (size_t)n * K * 4;
         double acc = 0.0;
         for (int k = 0; k < K; k++) { const float i = (float)acc; acc = (double)i + src[4 * k]; }
-        return acc / (double)K;
-    };
-    for (int n = lane; n < n_kept; n += kWave) nms_score[n] = global_score(n);
-    wave_sync();
-    for (int n = lane; n < n_kept; n += kWave) {        // rank by score desc (ties: creation order)
+        nms_score[n] = acc / (double)K;
+    }
+    __syncthreads();
+    for (int n = tid; n < n_kept; n += kAssocThreads) {  // rank by score desc (ties: creation order)
         const double sn = nms_score[n];
         int rank = 0;
         for (int m = 0; m < n_kept; m++) { const double sm = nms_score[m]; rank += (sm > sn || (sm == sn && m < n)) ? 1 : 0; }
         nms_order[rank] = n;
     }
-    wave_sync();
-    for (int r = 0; r < n_kept; r++) {
-        double* pose = anns + (size_t)nms_order[r] * K * 4;
-        for (int k0 = 0; k0 < K; k0 += kWave) {         // K is also the number of occupancy fields
-            const int k = k0 + lane;
-            bool need_set = false; double v = 0.0, x = 0.0, y = 0.0, s = 0.0;
+    __syncthreads();
+    for (int r = 0; r < n_kept; r++) {                   // serial over poses; joints in parallel
+        const double* pose = anns + (size_t)nms_order[r] * K * 4;
+        int n_set = 0;
+        for (int kc = 0; kc < KC; kc++) {                // K is also the number of occupancy fields
+            const int k = kc * kWave + lane;
+            bool need_set = false, suppressed = false; double x = 0.0, y = 0.0, s = 0.0;
             if (k < K) {
-                v = pose[4 * k]; x = pose[4 * k + 1]; y = pose[4 * k + 2]; s = pose[4 * k + 3];
+                const double v = pose[4 * k]; x = pose[4 * k + 1]; y = pose[4 * k + 2]; s = pose[4 * k + 3];
                 if (v != 0.0) {
-                    if (c.occ[occ_cell(c, p, k, x, y)] >= 2) pose[4 * k] = v * p.nms_suppression;   // :50-51
+                    if (c.occ[occ_cell(c, p, k, x, y)] >= 2) suppressed = true;         // :50-51
                     else need_set = true;
                 }
             }
+            const unsigned long long ms = __ballot(suppressed);
+            if (wave == 0 && lane == 0) nms_supp[r * KC + kc] = ms;
             unsigned long long m = __ballot(need_set);
+            __syncthreads();                             // every wave has tested before any wave marks
             while (m) {
                 const int l = __builtin_ctzll(m); m &= m - 1;
-                occ_set(c, p, k0 + l, __shfl(x, l), __shfl(y, l), __shfl(s, l), 2);               // :53
+                const double bx = __shfl(x, l), by = __shfl(y, l), bs = __shfl(s, l);
+                if ((n_set++ % kAssocWaves) == wave) occ_set(c, p, kc * kWave + l, bx, by, bs, 2);   // :53
             }
         }
-        __threadfence_block();
+        __syncthreads();
     }
-    // keypoint threshold, instance threshold, final order (:58-69)
-    for (int r = lane; r < n_kept; r += kWave) {
+    // suppression, keypoint threshold, instance threshold (:50,58-66); one thread per pose
+    for (int r = tid; r < n_kept; r += kAssocThreads) {
         double* pose = anns + (size_t)nms_order[r] * K * 4;
         double acc = 0.0;
         for (int k = 0; k < K; k++) {
             double v = pose[4 * k];
-            if (!(v > p.nms_keypoint_threshold)) { v = 0.0; pose[4 * k] = 0.0; }
+            if ((nms_supp[r * KC + (k >> 6)] >> (k & 63)) & 1ull) v *= p.nms_suppression;
+            if (!(v > p.nms_keypoint_threshold)) v = 0.0;
+            pose[4 * k] = v;
             const float i = (float)acc; acc = (double)i + v;
         }
-        nms_score[r] = acc / (double)K;                 // indexed by sorted position r now
+        nms_score[r] = acc / (double)K;                  // indexed by sorted position r now
     }
-    wave_sync();
-    __threadfence_block();
-    int n_out = 0;
-    float* out = a.out + (size_t)b * a.max_ann * K * 4;
-    int64_t* out_ids = a.out_ids + (size_t)b * a.max_ann;
-    for (int r0 = 0; r0 < n_kept; r0 += kWave) {
-        const int r = r0 + lane;
-        bool keep = false; int rank = 0;
-        if (r < n_kept) {
-            const double sr = nms_score[r];
-            keep = !(sr < p.nms_instance_threshold);
-            if (keep) for (int m = 0; m < n_kept; m++) {
+    __syncthreads();
+    for (int r = tid; r < n_kept; r += kAssocThreads) {  // final order (:69); ties keep the previous order
+        const double sr = nms_score[r];
+        int rank = -1;
+        if (!(sr < p.nms_instance_threshold)) {
+            rank = 0;
+            for (int m = 0; m < n_kept; m++) {
                 const double sm = nms_score[m];
                 if (sm < p.nms_instance_threshold) continue;
                 rank += (sm > sr || (sm == sr && m < r)) ? 1 : 0;
             }
         }
-        unsigned long long m = __ballot(keep);
-        n_out += __popcll(m);
-        while (m) {                                     // one pose per step, lanes over joints
-            const int l = __builtin_ctzll(m); m &= m - 1;
-            const int src_r = r0 + l, dst = __shfl(rank, l);
-            const int src_n = nms_order[src_r];
-            const double* pose = anns + (size_t)src_n * K * 4;
-            for (int k = lane; k < K; k += kWave) {     // cifcaf.cpp:250-258
-                float4 o;
-                o.x = (float)pose[4 * k]; o.y = (float)pose[4 * k + 1];
-                o.z = (float)pose[4 * k + 2]; o.w = (float)pose[4 * k + 3];
-                reinterpret_cast<float4*>(out)[(size_t)dst * K + k] = o;
-            }
-            if (lane == 0) out_ids[dst] = ann_ids[src_n];
-        }
+        nms_rank[r] = rank;
     }
-    if (lane == 0) {
+    __syncthreads();
+    float* out = a.out + (size_t)b * a.max_ann * K * 4;
+    int64_t* out_ids = a.out_ids + (size_t)b * a.max_ann;
+    int n_out = 0;
+    for (int r = 0; r < n_kept; r++) n_out += nms_rank[r] >= 0 ? 1 : 0;
+    for (int idx = tid; idx < n_kept * K; idx += kAssocThreads) {     // cifcaf.cpp:250-258
+        const int r = idx / K, k = idx - r * K;
+        const int dst = nms_rank[r];
+        if (dst < 0) continue;
+        const int src_n = nms_order[r];
+        const double* pose = anns + (size_t)src_n * K * 4;
+        float4 o;
+        o.x = (float)pose[4 * k]; o.y = (float)pose[4 * k + 1];
+        o.z = (float)pose[4 * k + 2]; o.w = (float)pose[4 * k + 3];
+        reinterpret_cast<float4*>(out)[(size_t)dst * K + k] = o;
+        if (k == 0) out_ids[dst] = ann_ids[src_n];
+    }
+    if (tid == 0) {
         a.out_count[b] = n_dropped > 0 ? a.max_ann + n_dropped : n_out;
         a.status[b] = n_dropped;
     }
+#ifdef OPA_ASSOC_TIMING
+    __syncthreads();
+    OPA_TACC(c.t[6], t_nms); OPA_TACC(c.t[7], t_total);
+    c.t[3] = c.t[7] - c.t[4] - c.t[5] - c.t[6];           // seed scanning + bookkeeping = the rest
+    if (tid == 0) for (int k = 0; k < 8; k++) reinterpret_cast<long long*>(anns)[k] = c.t[k];   // scratch is free now
+#endif
 }
 
 hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
-    const int K = a.K, A = a.A, P4 = 4 * A, E = 2 * A;
-    size_t lds = sizeof(double) * (K + P4 + a.max_ann) + sizeof(float) * (3 * K + 4 * P4)
-               + sizeof(int) * (2 * P4 + a.max_ann) + E + 16;
+    const int K = a.K, A = a.A, E = 2 * A;
+    const int KC = (K + kWave - 1) / kWave;
+    const size_t shared = sizeof(double) * (E + a.max_ann)
+                        + sizeof(unsigned long long) * ((size_t)a.max_ann * KC + 2 * kAssocWaves)
+                        + sizeof(float) * 3 * E + sizeof(int) * (E + 2 * a.max_ann) + (E + 15) / 16 * 16;
+    const size_t lds = shared + kAssocWaves * assoc_private_bytes(K, A) + 16;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)cifcaf_assoc_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    cifcaf_assoc_kernel<<<a.B, 64, lds, st>>>(a, sk, p);
+    cifcaf_assoc_kernel<<<a.B, kAssocThreads, lds, st>>>(a, sk, p);
     prof_mark(st, "cifcaf_assoc_kernel");
     return hipGetLastError();
 }
@@ -543,10 +766,9 @@ __global__ __launch_bounds__(64) void blend_rows_kernel(const float* rows, int n
         for (int k = 0; k < 7; k++) soa[(size_t)k * n + i] = rows[(size_t)i * 7 + k];
     __threadfence_block();
     ListView L; L.base = soa; L.cap = n; L.n = n;
-    double v = 0.0; float ox = 0.f, oy = 0.f, os = 0.f;
-    const bool ok = blend(L, x, y, s, filter_sigmas, only_max != 0, &v, &ox, &oy, &os);
+    const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, s, filter_sigmas, only_max);
     if (lane == 0) {
-        if (ok) { out4[0] = (double)ox; out4[1] = (double)oy; out4[2] = (double)os; out4[3] = v; }
+        if (r.ok) { out4[0] = (double)r.x; out4[1] = (double)r.y; out4[2] = (double)r.s; out4[3] = r.v; }
         else { out4[0] = 0.0; out4[1] = 0.0; out4[2] = 0.0; out4[3] = 0.0; }
     }
 }

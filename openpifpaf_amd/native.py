@@ -179,6 +179,14 @@ class CifCaf:
         """module.cpp:35."""
         return self.call_with_initial_annotations(cif_field, cif_stride, caf_field, caf_stride)
 
+    def workspace_view(self, what, dtype=torch.uint8):
+        """Flat tensor view of an intermediate buffer of the last ``call_batch`` (debug/tests)."""
+        shape, ws = self._last
+        off, size = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(_lib.lib().opa_cifcaf_workspace_view(ctypes.byref(shape), what.encode(), ctypes.byref(off),
+                                                        ctypes.byref(size)), 'opa_cifcaf_workspace_view')
+        return ws[off.value:off.value + size.value].view(dtype)
+
     def get_cifhr(self, image=0):
         """module.cpp:37-39 -> (Tensor [F,Hhr,Whr] view of the internal buffer, revision)."""
         if self._last is None:

@@ -138,7 +138,7 @@ def test_grow_connection_blend(native, port, coco_skeleton0):
 def test_grow_connection_blend_ties(native, port):
     """Exactly equal scores: the reference's '>=' / '>' rules pick by list position."""
     base = np.array([[0.8, 10.0, 10.0, 50.0, 60.0, 4.0, 4.0]], dtype=np.float32)
-    for n in (2, 3, 5, 130):
+    for n in (2, 3, 5, 130, 700):
         rows = np.repeat(base, n, axis=0)
         rows[:, 3] += np.arange(n, dtype=np.float32) * 0.25       # distinguishable targets
         for x in (10.0, 10.5):
