@@ -144,6 +144,9 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
+    # MIOpen "find" mode: benchmark the real solvers once per conv shape during warm-up.  The
+    # immediate-mode heuristic occasionally falls back to naive_conv (~300 ms per call).
+    torch.backends.cudnn.benchmark = True
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:

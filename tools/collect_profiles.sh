@@ -1,0 +1,23 @@
+#!/bin/bash
+# Collects the rocprofv3 evidence bench.py's roofline numbers are checked against.
+# Run on the GPU box:  bash tools/collect_profiles.sh   (outputs under gpurun_out/prof_r1)
+cd "${GRAFT_REPO_ROOT:-.}"
+OUT="$PWD/gpurun_out/prof_r1"
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+cd /tmp
+# 1. kernel trace + stats of the default bench command (N=1)
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o bench -- \
+    python "$OLDPWD/bench.py" --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_stdout.log" 2> "$OUT/bench_stderr.log"
+# 2. decode only (no backbone): the hot path's kernels in isolation
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/decode" -o decode -- \
+    python "$OLDPWD/bench.py" --decode-only --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/decode_stdout.log" 2> "$OUT/decode_stderr.log"
+# 3. HBM traffic counters, separate passes (FETCH_SIZE and WRITE_SIZE cannot share a pass)
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o pmc -- \
+      python "$OLDPWD/bench.py" --decode-only --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > "$OUT/pmc_${C}_stdout.log" 2> "$OUT/pmc_${C}_stderr.log"
+done
+cd "$OLDPWD"
+find "$OUT" -name "*.csv" | head -40
+python tools/summarize_profiles.py "$OUT" > "$OUT/summary.md" 2>&1
+cat "$OUT/summary.md" | head -80
