@@ -216,9 +216,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    t_setup = time.perf_counter()
     for _ in range(args.warmup):
         step()
     sync_all()
+    if rank == 0:
+        print('bench: warm-up (incl. MIOpen find) %.1f s' % (time.perf_counter() - t_setup), file=sys.stderr)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

@@ -34,3 +34,17 @@ COCO_UPRIGHT_POSE = np.array([
     [1.75, 4.2], [-1.26, 4.0], [1.26, 4.0], [-1.4, 2.0], [1.4, 2.1],
     [-1.4, 0.0], [1.4, 0.1],
 ], dtype=np.float64)
+
+
+def wholebody():
+    """The wholebody (133 keypoints, 160 bones) dataset definition, as data extracted from the
+    reference's ``plugins/wholebody/constants.py:38,71,210,358`` by
+    ``tools/extract_wholebody_constants.py``.  Returns a dict with ``keypoints``,
+    ``skeleton`` (1-based), ``standing_pose`` [133,2], ``sigmas``, ``score_weights``."""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'data', 'wholebody.json')
+    with open(path) as f:
+        d = json.load(f)
+    d['standing_pose'] = np.asarray(d['standing_pose'], dtype=np.float64)
+    return d

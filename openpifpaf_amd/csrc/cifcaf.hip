@@ -76,7 +76,7 @@ struct ImageCtx {
     // shared LDS
     double* cc_v; float *cc_x, *cc_y, *cc_s; unsigned char* cc_ok;   // connection cache [2A]
     int* sh_counts;                      // [2A] list lengths of the active list set
-    long long t[8];                      // OPA_ASSOC_TIMING: 0 blend 1 #blend 2 #chunks 3 rest 4 grow 5 mark 6 nms 7 total
+    long long t[10];                     // OPA_ASSOC_TIMING: 0 blend 1 #blend 2 #chunks 3 rest 4 grow 5 mark 6 nms 7 total
 };
 
 __device__ __forceinline__ ListView list_view(const ImageCtx& c, int bone, int dir) {
@@ -523,6 +523,12 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     c.cc_y = (float*)sp; sp += sizeof(float) * E;
     c.cc_s = (float*)sp; sp += sizeof(float) * E;
     c.sh_counts = (int*)sp; sp += sizeof(int) * E;
+    int* l_off = (int*)sp; sp += sizeof(int) * (K + 1);
+    int* l_other = (int*)sp; sp += sizeof(int) * E;
+    int* l_bone = (int*)sp; sp += sizeof(int) * E;
+    int* l_fwd = (int*)sp; sp += sizeof(int) * E;
+    int* l_first = (int*)sp; sp += sizeof(int) * E;
+    if ((K + 1) & 1) sp += sizeof(int);            // keep 8-byte alignment for what follows
     int* nms_order = (int*)sp; sp += sizeof(int) * a.max_ann;
     int* nms_rank = (int*)sp; sp += sizeof(int) * a.max_ann;
     c.cc_ok = sp; sp += (E + 15) / 16 * 16;
@@ -540,10 +546,19 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     c.pend = (int*)sp; sp += sizeof(int) * E;
     c.in_frontier = sp;
     c.heap_n = 0; c.n_entries = 0;
-    for (int k = 0; k < 8; k++) c.t[k] = 0;
+    for (int k = 0; k < 10; k++) c.t[k] = 0;
     OPA_T0(t_total);
+#ifdef OPA_ASSOC_TIMING
+    const long long cyc0 = clock64();
+#endif
 
-    for (int k = tid; k < E; k += kAssocThreads) c.sh_counts[k] = c.list_counts[k];
+    // the skeleton adjacency is consulted at every step of the search: keep it in LDS
+    for (int k = tid; k < E; k += kAssocThreads) {
+        c.sh_counts[k] = c.list_counts[k];
+        l_other[k] = sk.adj_other[k]; l_bone[k] = sk.adj_bone[k]; l_fwd[k] = sk.adj_fwd[k]; l_first[k] = sk.adj_first[k];
+    }
+    for (int k = tid; k <= K; k += kAssocThreads) l_off[k] = sk.adj_off[k];
+    c.adj_off = l_off; c.adj_other = l_other; c.adj_bone = l_bone; c.adj_fwd = l_fwd; c.adj_first = l_first;
     __syncthreads();
 
     double* anns = a.anns + (size_t)b * a.max_ann * K * 4;
@@ -735,7 +750,8 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     __syncthreads();
     OPA_TACC(c.t[6], t_nms); OPA_TACC(c.t[7], t_total);
     c.t[3] = c.t[7] - c.t[4] - c.t[5] - c.t[6];           // seed scanning + bookkeeping = the rest
-    if (tid == 0) for (int k = 0; k < 8; k++) reinterpret_cast<long long*>(anns)[k] = c.t[k];   // scratch is free now
+    c.t[8] = clock64() - cyc0;
+    if (tid == 0) for (int k = 0; k < 10; k++) reinterpret_cast<long long*>(anns)[k] = c.t[k];   // scratch is free now
 #endif
 }
 
@@ -744,7 +760,7 @@ hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevPara
     const int KC = (K + kWave - 1) / kWave;
     const size_t shared = sizeof(double) * (E + a.max_ann)
                         + sizeof(unsigned long long) * ((size_t)a.max_ann * KC + 2 * kAssocWaves)
-                        + sizeof(float) * 3 * E + sizeof(int) * (E + 2 * a.max_ann) + (E + 15) / 16 * 16;
+                        + sizeof(float) * 3 * E + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann) + (E + 15) / 16 * 16;
     const size_t lds = shared + kAssocWaves * assoc_private_bytes(K, A) + 16;
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (lds > 64 * 1024) {

@@ -259,6 +259,38 @@ def test_decode_all_active_adversarial(native, port, coco_skeleton0):
         assert ok, '%s: %s' % (kw, msg)
 
 
+@pytest.mark.parametrize('seed,people,H,W', [(0, 2, 41, 41), (1, 4, 81, 81)])
+def test_decode_wholebody_133_keypoints(native, port, seed, people, H, W):
+    """BASELINE config 4 shapes: 133 keypoints, 160 bones (max joint degree 6, K > one wave)."""
+    from openpifpaf_amd import constants, synth
+    wb = constants.wholebody()
+    skel0 = np.asarray(wb['skeleton'], dtype=np.int64) - 1
+    cif, caf = synth.synth_fields(seed, people, height=H, width=W, pose=wb['standing_pose'],
+                                  skeleton=wb['skeleton'], size_range=(0.6, 0.95))
+    assert cif.shape == (133, 5, H, W) and caf.shape == (160, 8, H, W)
+    want, _ = port.decode(cif, 8, caf, 8, skel0)
+    assert len(want) >= 1
+    dec = native.CifCaf(133, torch.from_numpy(skel0))
+    got, ids = dec.call(dev(cif), 8, dev(caf), 8)
+    ok, msg = compare_annotations(got.cpu().numpy(), want)
+    assert ok, msg
+    # stage parity at this shape too
+    hr = native.CifHr()
+    hr.accumulate(dev(cif), 8)
+    assert np.array_equal(hr.get_accumulated()[0].cpu().numpy(), port.cifhr_accumulate(cif, 8))
+    # force complete on the big skeleton (flood fill over 160 bones, frontier ties everywhere)
+    from openpifpaf_amd import _lib
+    kw = dict(force_complete=1, keypoint_threshold=0.0, keypoint_threshold_rel=0.0,
+              nms_instance_threshold=0.0, nms_keypoint_threshold=0.0)
+    want_fc, _ = port.decode(cif, 8, caf, 8, skel0, params=port.default_params(**kw))
+    dec = native.CifCaf(133, torch.from_numpy(skel0), max_annotations=256)
+    out, _, counts = dec.call_batch(dev(cif)[None], 8, dev(caf)[None], 8, params=_lib.default_params(**kw))
+    n = int(counts[0])
+    assert n == len(want_fc)
+    ok, msg = compare_annotations(out[0, :n].cpu().numpy(), want_fc)
+    assert ok, 'force complete: ' + msg
+
+
 def test_static_getset_roundtrip(native):
     C = native.CifCaf
     old = C.get_keypoint_threshold()
