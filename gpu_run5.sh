@@ -1,6 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -p no:cacheprovider 2>&1 | tail -25 | tee gpurun_out/pytest_gpu.log
+timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider 2>&1 | tail -25 | tee gpurun_out/pytest_gpu.log
 timeout 900 python bench.py --steps 10 --warmup 3 2>gpurun_out/bench.err | tee gpurun_out/bench.json
 tail -3 gpurun_out/bench.err

@@ -186,6 +186,16 @@ int opa_cafscored_fill(const float* caf_dev, int32_t batch, int32_t n_caf, int32
 int opa_grow_connection_blend(const float* rows_dev, int32_t n, double x, double y, double s,
                               double filter_sigmas, int32_t only_max, double* out_host, void* stream);
 
+/* ---- producer-side helper ------------------------------------------------ */
+/* Fused convolution epilogue of the field-producing network (no reference counterpart:
+ * the reference runs conv -> batch-norm -> ReLU (-> add -> ReLU) as separate PyTorch ops,
+ * network/basenetworks.py).  In place on an NHWC activation viewed as [rows, channels]:
+ *     x = act(x + bias[channel] (+ residual))
+ * dtype: 0 = float32, 1 = float16, 2 = bfloat16; channels must be a multiple of 16 bytes
+ * worth of elements; x/residual 16-B aligned; residual may be NULL; relu 0/1. */
+int opa_bias_act(void* x_dev, const void* bias_dev, const void* residual_dev,
+                 int64_t rows, int32_t channels, int32_t dtype, int32_t relu, void* stream);
+
 /* ---- measurement -------------------------------------------------------- */
 /* Per-kernel timing with HIP events on the launch stream (no reference
  * counterpart; bench.py's roofline leg uses it).  Between opa_profile_begin and

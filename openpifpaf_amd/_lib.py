@@ -91,6 +91,7 @@ SYMBOLS = {
     'opa_cafscored_fill': (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32,
                                           _vp, _dbl, _dbl, _P(Params), _vp, _vp, _vp]),
     'opa_grow_connection_blend': (ctypes.c_int, [_vp, _i32, _dbl, _dbl, _dbl, _dbl, _i32, _P(_dbl), _vp]),
+    'opa_bias_act': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     'opa_profile_begin': (ctypes.c_int, [_vp]),
     'opa_profile_end': (ctypes.c_int, [_i32, _P(ctypes.c_char_p), _P(ctypes.c_float), _P(_i32)]),
 }

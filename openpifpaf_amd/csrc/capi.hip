@@ -438,6 +438,20 @@ int opa_grow_connection_blend(const float* rows_dev, int32_t n, double x, double
     return OPA_OK;
 }
 
+int opa_bias_act(void* x_dev, const void* bias_dev, const void* residual_dev, int64_t rows, int32_t channels,
+                 int32_t dtype, int32_t relu, void* stream) {
+    if (!x_dev || !bias_dev || rows < 0 || channels <= 0 || dtype < 0 || dtype > 2)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_bias_act: bad arguments");
+    const int per_vec = dtype == 0 ? 4 : 8;
+    if (channels % per_vec != 0 || ((uintptr_t)x_dev & 15) || ((uintptr_t)bias_dev & 15) || ((uintptr_t)residual_dev & 15))
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_bias_act: channels must fill 16-byte vectors and pointers be 16-B aligned");
+    if (rows == 0) return OPA_OK;
+    hipError_t e = launch_bias_act(x_dev, bias_dev, residual_dev, rows, channels, dtype, relu, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "bias_act");
+    prof_mark((hipStream_t)stream, "bias_act_kernel");
+    return OPA_OK;
+}
+
 int opa_profile_begin(void* stream) {
     for (hipEvent_t ev : g_prof.events) (void)hipEventDestroy(ev);
     g_prof.events.clear(); g_prof.names.clear();

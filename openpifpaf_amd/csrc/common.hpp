@@ -94,6 +94,9 @@ struct AssocArgs {
 };
 hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st);
 
+hipError_t launch_bias_act(void* x, const void* bias, const void* res, long long rows, int channels, int dtype,
+                           int relu, hipStream_t st);
+
 hipError_t launch_blend(const float* rows, int n, double x, double y, double s, double filter_sigmas,
                         int only_max, double* out4_dev, hipStream_t st);
 

@@ -20,7 +20,23 @@ import math
 import torch
 from torch import nn
 
-from . import headmeta
+from . import fused, headmeta
+
+
+def _take_biases(block, conv_names):
+    """Move the (BN-folded) conv biases of a residual block into buffers ``fb1..`` applied by the
+    fused epilogue; the downsample conv's bias is merged into the last one (both are added
+    before the block's final ReLU)."""
+    for i, name in enumerate(conv_names, 1):
+        conv = getattr(block, name)
+        bias = conv.bias.detach().clone() if conv.bias is not None else torch.zeros(conv.out_channels)
+        if i == len(conv_names) and block.downsample is not None:
+            dconv = block.downsample[0]
+            if dconv.bias is not None:
+                bias = bias + dconv.bias.detach().to(bias.device)
+                dconv.bias = None
+        conv.bias = None
+        block.register_buffer('fb%d' % i, bias)
 
 
 class _Bottleneck(nn.Module):
@@ -36,8 +52,18 @@ class _Bottleneck(nn.Module):
         self.bn3 = nn.BatchNorm2d(planes * 4)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
+        self.fused = False
+
+    def enable_fused_(self):
+        _take_biases(self, ('conv1', 'conv2', 'conv3'))
+        self.fused = True
 
     def forward(self, x):
+        if self.fused:      # conv (no bias) -> ONE fused bias(+residual)+ReLU pass each
+            identity = x if self.downsample is None else self.downsample[0](x)
+            out = fused.bias_act_(self.conv1(x), self.fb1)
+            out = fused.bias_act_(self.conv2(out), self.fb2)
+            return fused.bias_act_(self.conv3(out), self.fb3, identity)
         identity = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
@@ -56,8 +82,17 @@ class _BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
+        self.fused = False
+
+    def enable_fused_(self):
+        _take_biases(self, ('conv1', 'conv2'))
+        self.fused = True
 
     def forward(self, x):
+        if self.fused:
+            identity = x if self.downsample is None else self.downsample[0](x)
+            out = fused.bias_act_(self.conv1(x), self.fb1)
+            return fused.bias_act_(self.conv2(out), self.fb2, identity)
         identity = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
@@ -106,8 +141,18 @@ class Resnet(BaseNetwork):
         layers += [block(self.inplanes, planes) for _ in range(1, blocks)]
         return nn.Sequential(*layers)
 
+    def enable_fused_(self):
+        conv = self.input_block[0]
+        self.register_buffer('fb0', conv.bias.detach().clone())
+        conv.bias = None
+        self.fused = True
+
     def forward(self, x):
-        return self.block5(self.block4(self.block3(self.block2(self.input_block(x)))))
+        if getattr(self, 'fused', False):
+            x = fused.bias_act_(self.input_block[0](x), self.fb0)
+        else:
+            x = self.input_block(x)
+        return self.block5(self.block4(self.block3(self.block2(x))))
 
 
 def _channel_shuffle(x, groups=2):
@@ -283,4 +328,15 @@ def fuse_conv_bn_(model):
             if isinstance(conv, nn.Conv2d) and isinstance(bn, nn.BatchNorm2d):
                 _fold(conv, bn)
                 setattr(module, 'bn%d' % i, nn.Identity())
+    return model
+
+
+def optimize_for_inference_(model):
+    """Fold every conv+BN pair, then switch the ResNet blocks to the fused-epilogue forward
+    (conv without bias followed by ONE ``fused.bias_act_`` pass).  Other backbones keep the
+    folded convs with their biases."""
+    fuse_conv_bn_(model)
+    for m in model.modules():
+        if isinstance(m, (_Bottleneck, _BasicBlock, Resnet)):
+            m.enable_fused_()
     return model
