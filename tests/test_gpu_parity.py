@@ -304,3 +304,54 @@ def test_static_getset_roundtrip(native):
         C.set_force_complete(False)
     assert native.CifHr.get_threshold() == 0.3 and native.CifSeeds.get_threshold() == 0.2
     assert native.CafScored.get_default_score_th() == 0.3 and native.NMSKeypoints.get_suppression() == 1e-5
+
+
+def test_full_size_batch_properties(native, port, coco_skeleton0):
+    """BASELINE config sizes (batch 32, 17x81x81 + 19x81x81): properties that do not need the
+    oracle on every image -- determinism, batch-order equivariance, sortedness, bounds --
+    plus an oracle comparison on a sample of the batch."""
+    from openpifpaf_amd import synth
+    B = 32
+    cifs, cafs = synth.synth_batch(B, seed0=500)
+    cif_d, caf_d = dev(cifs), dev(cafs)
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    out1, ids1, cnt1 = [t.clone() for t in dec.call_batch(cif_d, 8, caf_d, 8)]
+    # seeds of the same call: sorted by score, scores within [seed_th, 1], coordinates inside the map
+    n_seeds = dec.workspace_view('seed_count', torch.int32)[:B].cpu().numpy()
+    vxys = dec.workspace_view('seed_vxys', torch.float32).view(B, -1, 4)
+    for b in range(B):
+        v = vxys[b, :n_seeds[b]].cpu().numpy()
+        assert np.all(np.diff(v[:, 0]) <= 0) and v[:, 0].min() >= 0.2 and v[:, 0].max() <= 1.0
+    # the CifHr map holds 0 (untouched) or 1 + value with value in (0, 1]
+    hr, rev = dec.get_cifhr(image=3)
+    hr = hr.cpu().numpy()
+    assert rev == 1.0 and hr.shape == (17, 641, 641)
+    touched = hr[hr != 0]
+    assert touched.min() > 1.0 and touched.max() <= 2.0
+    # idempotence / determinism: same call, same bits
+    out2, ids2, cnt2 = dec.call_batch(cif_d, 8, caf_d, 8)
+    assert torch.equal(cnt1, cnt2)
+    for b in range(B):
+        assert torch.equal(out1[b, :int(cnt1[b])], out2[b, :int(cnt2[b])])
+    # batch-order equivariance: images are independent units
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(0)).cuda()
+    out3, ids3, cnt3 = dec.call_batch(cif_d[perm], 8, caf_d[perm], 8)
+    assert torch.equal(cnt3, cnt1[perm])
+    for b in range(B):
+        n = int(cnt3[b])
+        assert torch.equal(out3[b, :n], out1[perm[b], :n])
+    # outputs: scores sorted (mean of v), keypoints inside the padded image
+    o = out1.cpu().numpy()
+    c = cnt1.cpu().numpy()
+    assert c.sum() > 150 and c.max() <= dec.max_annotations
+    for b in range(B):
+        a = o[b, :c[b]]
+        if len(a):
+            assert np.all(np.diff(a[:, :, 0].mean(axis=1)) <= 1e-7)
+            present = a[:, :, 0] > 0
+            assert a[:, :, 1][present].min() > -64 and a[:, :, 1][present].max() < 704
+    # oracle on a sample
+    for b in (0, 3, 7, 19, 31):
+        want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)
+        ok, msg = compare_annotations(o[b, :c[b]], want)
+        assert ok, 'image %d: %s' % (b, msg)

@@ -35,6 +35,38 @@ def kernel_stats(sub, title, top=25):
     print()
 
 
+def steady_state_step(sub, title, top=16):
+    """MIOpen's find mode benchmarks many candidate solvers during warm-up, which pollutes the
+    whole-run statistics; this isolates ONE timed step: the kernels between two consecutive
+    association-kernel launches near the end of the trace."""
+    path = find(sub, '*kernel_trace.csv')
+    print('## %s\n' % title)
+    if not path:
+        print('(no kernel_trace.csv found)\n')
+        return
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r['Start_Timestamp']))
+    idx = [i for i, r in enumerate(rows) if 'cifcaf_assoc' in r['Kernel_Name']]
+    if len(idx) < 8:
+        print('(too few steps in the trace)\n')
+        return
+    a, b = idx[-7], idx[-6]
+    seg = rows[a + 1:b + 1]
+    agg = defaultdict(lambda: [0, 0.0])
+    for r in seg:
+        k = short(r['Kernel_Name'])
+        agg[k][0] += 1
+        agg[k][1] += (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    total = sum(v[1] for v in agg.values())
+    wall = (max(int(r['End_Timestamp']) for r in seg) - min(int(r['Start_Timestamp']) for r in seg)) / 1e6
+    print('%d kernels in the step, sum of kernel time %.2f ms, wall %.2f ms\n' % (len(seg), total / 1e3, wall))
+    print('| kernel | launches | total ms | avg us |')
+    print('|---|---|---|---|')
+    for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+        print('| `%s` | %d | %.3f | %.1f |' % (k, n, t / 1e3, t / n))
+    print()
+
+
 def pmc(sub, counter):
     path = find(sub, '*counter_collection.csv')
     if not path:
@@ -51,7 +83,8 @@ def pmc(sub, counter):
 
 print('# rocprofv3 summary (round 1)\n')
 print('Commands: see tools/collect_profiles.sh.  Batch 32 per launch, COCO-17 fields 81x81, stride 8.\n')
-kernel_stats('bench', 'bench.py --steps 5 --warmup 2 (backbone + decode), kernel trace')
+steady_state_step('bench', 'bench.py (backbone + decode): ONE steady-state step, batch 32')
+kernel_stats('bench', 'bench.py --steps 5 --warmup 2 whole run (includes MIOpen find candidates), kernel trace', top=12)
 kernel_stats('decode', 'bench.py --decode-only --steps 10 --warmup 2, kernel trace')
 fetch, write = pmc('pmc_FETCH_SIZE', 'FETCH_SIZE'), pmc('pmc_WRITE_SIZE', 'WRITE_SIZE')
 print('## HBM traffic counters per launch (decode only)\n')
