@@ -117,23 +117,48 @@ __device__ __forceinline__ float score_of(const BlendQuery& q, float x1, float y
     return (float)(exp(-0.5 * (double)d2 / (double)q.sigma2) * (double)c);   // :63
 }
 
-// first place = max score, LAST list position among equals (">=", :65)
+// Wave-wide max of a 64-bit key with DPP row operations instead of LDS-crossbar shuffles
+// (6 register-only steps: xor-1/xor-2 inside quads, half-row mirror, row mirror, then the
+// row-15 and row-31 broadcasts; the result lands in lane 63).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v) {
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROW_MASK, 0xF, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROW_MASK, 0xF, false);
+    const unsigned long long o = ((unsigned long long)ohi << 32) | olo;
+    return o > v ? o : v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    v = dpp_max_step<0xB1, 0xF>(v);      // quad_perm [1,0,3,2]
+    v = dpp_max_step<0x4E, 0xF>(v);      // quad_perm [2,3,0,1]
+    v = dpp_max_step<0x141, 0xF>(v);     // row_half_mirror
+    v = dpp_max_step<0x140, 0xF>(v);     // row_mirror
+    v = dpp_max_step<0x142, 0xA>(v);     // row_bcast:15 -> rows 1 and 3
+    v = dpp_max_step<0x143, 0xC>(v);     // row_bcast:31 -> rows 2 and 3
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, 63);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// first place = max score, LAST list position among equals (">=", :65).  Scores are
+// non-negative floats, so (score bits << 32 | position + 1) orders exactly like that;
+// a lane without a candidate contributes key 0.
 __device__ __forceinline__ void reduce_first(float& s1, int& i1) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float so = __shfl_xor(s1, off); const int io = __shfl_xor(i1, off);
-        if (so > s1 || (so == s1 && io > i1)) { s1 = so; i1 = io; }
-    }
+    const unsigned long long key = i1 < 0 ? 0ull
+        : ((unsigned long long)__float_as_uint(s1) << 32) | (unsigned)(i1 + 1);
+    const unsigned long long m = wave_max_u64(key);
+    s1 = __uint_as_float((unsigned)(m >> 32));
+    i1 = (int)(unsigned)(m & 0xffffffffull) - 1;
 }
 // second place: max score among the rest; among equals the last position before
 // i1 if any, else the first after i1 (the outcome of the sequential rule :65-73).
-// rank(i) = i < i1 ? n + i : n - i, larger wins.
+// rank(i) = i < i1 ? n + i : n - i (always >= 1), larger wins.
 __device__ __forceinline__ void reduce_second(float& s2, int& r2) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        const float so = __shfl_xor(s2, off); const int ro = __shfl_xor(r2, off);
-        if (so > s2 || (so == s2 && ro > r2)) { s2 = so; r2 = ro; }
-    }
+    const unsigned long long key = r2 < 0 ? 0ull
+        : ((unsigned long long)__float_as_uint(s2) << 32) | (unsigned)r2;
+    const unsigned long long m = wave_max_u64(key);
+    s2 = __uint_as_float((unsigned)(m >> 32));
+    r2 = m == 0ull ? -1 : (int)(unsigned)(m & 0xffffffffull);
 }
 
 __device__ __forceinline__ BlendResult blend_none() { BlendResult r; r.v = 0.0; r.x = r.y = r.s = 0.f; r.ok = 0; return r; }
