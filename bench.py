@@ -58,6 +58,9 @@ def parse_args():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--decode-only', action='store_true', help='skip the backbone (kernel work only)')
     p.add_argument('--profile-steps', type=int, default=5)
+    p.add_argument('--dist-backend', default='nccl', choices=('nccl', 'gloo'),
+                   help='nccl = RCCL over xGMI (default); gloo only to exercise the N>1 control flow on one GPU')
+    p.add_argument('--share-device', action='store_true', help='testing: every rank uses cuda:0')
     return p.parse_args()
 
 
@@ -151,11 +154,16 @@ def main():
     # MIOpen "find" mode: benchmark the real solvers once per conv shape during warm-up.  The
     # immediate-mode heuristic occasionally falls back to naive_conv (~300 ms per call).
     torch.backends.cudnn.benchmark = True
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)      # backend "nccl" is RCCL on ROCm
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)  # backend "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group('gloo')
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
 
@@ -209,7 +217,10 @@ def main():
             dec_stream.wait_event(ev)                  # decode of batch i follows its backbone
             out, ids, counts = dec.call_batch(cif_syn, stride, caf_syn, stride)
             if world > 1:                              # final annotations only, over xGMI (RCCL)
-                distributed.gather_annotations(out, ids, counts)
+                if args.dist_backend == 'nccl':
+                    distributed.gather_annotations(out, ids, counts)
+                else:
+                    distributed.gather_annotations(out.cpu(), ids.cpu(), counts.cpu())
             host_out.copy_(out, non_blocking=True)
             host_counts.copy_(counts, non_blocking=True)
         return out
@@ -234,7 +245,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.dist_backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_ann = int(host_counts.clamp(max=dec.max_annotations).sum())

@@ -186,6 +186,25 @@ int opa_cafscored_fill(const float* caf_dev, int32_t batch, int32_t n_caf, int32
 int opa_grow_connection_blend(const float* rows_dev, int32_t n, double x, double y, double s,
                               double filter_sigmas, int32_t only_max, double* out_host, void* stream);
 
+/* ---- CifDet decoder -------------------------------------------------------- */
+/* ref: module.cpp:57-62  torch.classes.openpifpaf_decoder.CifDet().call(cifdet_field, stride)
+ * (cifdet.cpp:24-80, CifDetHr cif_hr.cpp:124-150, CifDetSeeds cif_seeds.cpp:69-90,117-139), batched.
+ *  field_dev       [B, F, 6, H, W]  comps: 0 unused, 1 conf, 2 x, 3 y, 4 w, 5 h
+ *  categories_dev  int64 [B, max_detections]  (1-based field index, cifdet.cpp:61)
+ *  scores_dev      [B, max_detections]
+ *  boxes_dev       [B, max_detections, 4]  (x0, y0, x1, y1)
+ *  counts_dev      int32 [B]
+ * max_detections is the reference's static CifDet::max_detections_before_nms (120, cifdet.cpp:16).
+ * The IoU NMS that follows is host-side Python in the reference too (decoder/cifdet.py:62-72). */
+typedef struct opa_det_shape {
+    int32_t batch, n_fields, field_h, field_w, stride, max_detections;
+} opa_det_shape;
+size_t opa_cifdet_workspace_bytes(const opa_det_shape* shape);
+int opa_cifdet_decode(const opa_det_shape* shape, const opa_params* params, const float* field_dev,
+                      void* workspace_dev, size_t workspace_bytes,
+                      int64_t* categories_dev, float* scores_dev, float* boxes_dev, int32_t* counts_dev,
+                      void* stream);
+
 /* ---- producer-side helper ------------------------------------------------ */
 /* Fused convolution epilogue of the field-producing network (no reference counterpart:
  * the reference runs conv -> batch-norm -> ReLU (-> add -> ReLU) as separate PyTorch ops,

@@ -55,6 +55,11 @@ class Params(ctypes.Structure):
         return other
 
 
+class DetShape(ctypes.Structure):
+    """``opa_det_shape``."""
+    _fields_ = [(n, ctypes.c_int32) for n in ('batch', 'n_fields', 'field_h', 'field_w', 'stride', 'max_detections')]
+
+
 class Shape(ctypes.Structure):
     """``opa_shape``."""
     _fields_ = [(n, ctypes.c_int32) for n in (
@@ -91,6 +96,8 @@ SYMBOLS = {
     'opa_cafscored_fill': (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32,
                                           _vp, _dbl, _dbl, _P(Params), _vp, _vp, _vp]),
     'opa_grow_connection_blend': (ctypes.c_int, [_vp, _i32, _dbl, _dbl, _dbl, _dbl, _i32, _P(_dbl), _vp]),
+    'opa_cifdet_workspace_bytes': (_sz, [_P(DetShape)]),
+    'opa_cifdet_decode': (ctypes.c_int, [_P(DetShape), _P(Params), _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     'opa_bias_act': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     'opa_profile_begin': (ctypes.c_int, [_vp]),
     'opa_profile_end': (ctypes.c_int, [_i32, _P(ctypes.c_char_p), _P(ctypes.c_float), _P(_i32)]),

@@ -93,3 +93,45 @@ class Annotation:
             if meta.get('horizontal_swap'):
                 ann.data[:] = meta['horizontal_swap'](ann.data)
         return ann
+
+
+class AnnotationDet:
+    """Detection annotation (reference ``annotation.py:216-262``)."""
+
+    def __init__(self, categories):
+        self.categories = categories
+        self.category_id = None
+        self.score = None
+        self.bbox = None
+
+    def set(self, category_id, score, bbox):
+        self.category_id = category_id
+        self.score = score
+        self.bbox = np.asarray(bbox)
+        return self
+
+    @property
+    def category(self):
+        return self.categories[self.category_id - 1]
+
+    def json_data(self, coordinate_digits=2):
+        return {
+            'category_id': self.category_id,
+            'category': self.category,
+            'score': max(0.001, round(float(self.score), 3)),
+            'bbox': [round(float(c), coordinate_digits) for c in self.bbox],
+        }
+
+    def inverse_transform(self, meta):
+        import copy
+        ann = copy.deepcopy(self)
+        if meta is None:
+            return ann
+        ann.bbox = np.asarray(ann.bbox, dtype=np.float64).copy()
+        ann.bbox[:2] += np.asarray(meta.get('offset', (0.0, 0.0)))
+        ann.bbox[:2] /= np.asarray(meta.get('scale', (1.0, 1.0)))
+        ann.bbox[2:] /= np.asarray(meta.get('scale', (1.0, 1.0)))
+        if meta.get('hflip'):
+            w = meta['width_height'][0]
+            ann.bbox[0] = -(ann.bbox[0] + ann.bbox[2]) - 1.0 + w
+        return ann

@@ -438,6 +438,86 @@ int opa_grow_connection_blend(const float* rows_dev, int32_t n, double x, double
     return OPA_OK;
 }
 
+struct DetLayout {
+    int hr_rows, hr_cols, hr_pitch, occ_h, occ_w, cells, sort_cap;
+    size_t off_cifhr, off_act, off_act_count, off_keys, off_seed_count, off_seed_f, off_seed_v, off_occ, total;
+};
+
+static bool make_det_layout(const opa_det_shape& s, DetLayout* L, const char** why) {
+    if (s.batch <= 0 || s.n_fields <= 0 || s.field_h <= 0 || s.field_w <= 0 || s.stride <= 0 || s.max_detections <= 0) {
+        *why = "opa_det_shape: every field must be positive"; return false;
+    }
+    if ((long long)s.n_fields * s.field_h * s.field_w > (1ll << 30)) { *why = "opa_det_shape: field too large"; return false; }
+    L->hr_rows = (s.field_h - 1) * s.stride + 1;
+    L->hr_cols = (s.field_w - 1) * s.stride + 1;
+    L->hr_pitch = (L->hr_cols + kHrTileW - 1) / kHrTileW * kHrTileW;
+    L->occ_h = L->hr_rows + 1; L->occ_w = L->hr_cols + 1;
+    L->cells = s.n_fields * s.field_h * s.field_w;
+    int sc = 2; while (sc < L->cells) sc <<= 1;
+    L->sort_cap = sc < kSortLdsKeys ? kSortLdsKeys : sc;
+    const size_t B = s.batch;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes); return o; };
+    L->off_cifhr = take(B * s.n_fields * L->hr_rows * (size_t)L->hr_pitch * sizeof(float));
+    L->off_act = take(B * s.n_fields * 4 * (size_t)(s.field_h * s.field_w) * sizeof(float));
+    L->off_act_count = take(B * s.n_fields * sizeof(int32_t));
+    L->off_keys = take(B * (size_t)L->sort_cap * sizeof(unsigned long long));
+    L->off_seed_count = take(B * sizeof(int32_t));
+    L->off_seed_f = take(B * (size_t)L->cells * sizeof(int32_t));
+    L->off_seed_v = take(B * (size_t)L->cells * 5 * sizeof(float));
+    L->off_occ = take(B * s.n_fields * (size_t)L->occ_h * L->occ_w);
+    L->total = off;
+    return true;
+}
+
+size_t opa_cifdet_workspace_bytes(const opa_det_shape* shape) {
+    DetLayout L; const char* why = nullptr;
+    if (!shape || !make_det_layout(*shape, &L, &why)) { g_error = why ? why : "null shape"; return 0; }
+    return L.total;
+}
+
+int opa_cifdet_decode(const opa_det_shape* shape, const opa_params* params, const float* field_dev,
+                      void* workspace_dev, size_t workspace_bytes,
+                      int64_t* categories_dev, float* scores_dev, float* boxes_dev, int32_t* counts_dev,
+                      void* stream) {
+    if (!shape || !field_dev || !workspace_dev || !categories_dev || !scores_dev || !boxes_dev || !counts_dev)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifdet_decode: null argument");
+    opa_params hp;
+    if (params) hp = *params; else opa_get_params(&hp);
+    const char* why = nullptr;
+    if (!check_params(hp, &why)) return fail(OPA_ERR_INVALID_ARGUMENT, why);
+    if (hp.occupancy_reduction < 1.0) return fail(OPA_ERR_UNSUPPORTED, "opa_cifdet_decode: occupancy_reduction < 1");
+    DetLayout L;
+    if (!make_det_layout(*shape, &L, &why)) return fail(OPA_ERR_INVALID_ARGUMENT, why);
+    if (workspace_bytes < L.total) return fail(OPA_ERR_WORKSPACE, "opa_cifdet_decode: workspace too small");
+    if (((uintptr_t)workspace_dev & 255) != 0) return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifdet_decode: workspace must be 256-B aligned");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned char* ws = (unsigned char*)workspace_dev;
+    const DevParams p = to_dev(hp);
+    const int B = shape->batch, F = shape->n_fields, H = shape->field_h, W = shape->field_w;
+    float* cifhr = (float*)(ws + L.off_cifhr);
+    hipError_t e = launch_cifhr(field_dev, B, F, H, W, shape->stride, 0.0, 1.0, p, cifhr, L.hr_rows, L.hr_pitch,
+                                (float*)(ws + L.off_act), (int32_t*)(ws + L.off_act_count), st, true);   // cifdet.cpp:30-31
+    if (e != hipSuccess) return fail_hip(e, "cifdethr");
+    e = launch_cifseeds(field_dev, B, F, H, W, shape->stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
+                        (unsigned long long*)(ws + L.off_keys), L.sort_cap, (int32_t*)(ws + L.off_seed_count),
+                        (int32_t*)(ws + L.off_seed_f), (float*)(ws + L.off_seed_v), st, true);           // :34-36
+    if (e != hipSuccess) return fail_hip(e, "cifdetseeds");
+    const int occ_h = (int)((double)L.hr_rows / hp.occupancy_reduction) + 1;
+    const int occ_w = (int)((double)L.hr_cols / hp.occupancy_reduction) + 1;
+    e = hipMemsetAsync(ws + L.off_occ, 0, (size_t)B * F * occ_h * occ_w, st);                            // :44
+    if (e != hipSuccess) return fail_hip(e, "occupancy memset");
+    prof_mark(st, "memset_occupancy");
+    DetArgs a;
+    a.B = B; a.F = F; a.max_det = shape->max_detections; a.occ_h = occ_h; a.occ_w = occ_w; a.seed_cap = L.cells;
+    a.seed_f = (const int32_t*)(ws + L.off_seed_f); a.seed_vxywh = (const float*)(ws + L.off_seed_v);
+    a.seed_count = (const int32_t*)(ws + L.off_seed_count); a.occ = ws + L.off_occ;
+    a.categories = categories_dev; a.scores = scores_dev; a.boxes = boxes_dev; a.counts = counts_dev;
+    e = launch_cifdet_collect(a, p, st);                                                                // :50-67
+    if (e != hipSuccess) return fail_hip(e, "cifdet collect");
+    return OPA_OK;
+}
+
 int opa_bias_act(void* x_dev, const void* bias_dev, const void* residual_dev, int64_t rows, int32_t channels,
                  int32_t dtype, int32_t relu, void* stream) {
     if (!x_dev || !bias_dev || rows < 0 || channels <= 0 || dtype < 0 || dtype > 2)

@@ -25,12 +25,14 @@
 namespace opa {
 
 // ---------------------------------------------------------------- pass 1
+// DET: CifDet fields [F,6,H,W] (w,h instead of scale), CifDetHr::accumulate cif_hr.cpp:124-150
+template <bool DET>
 __global__ __launch_bounds__(256) void cif_active_kernel(
         const float* __restrict__ cif, int HW, int stride, float min_scale_f, double threshold,
         float neighbors_f, double factor, float* __restrict__ act, int32_t* __restrict__ act_count) {
     __shared__ int wave_tot[4];
     const int plane = blockIdx.x;
-    const float* P = cif + (size_t)plane * 5 * HW;
+    const float* P = cif + (size_t)plane * (DET ? 6 : 5) * HW;
     float* out = act + (size_t)plane * 4 * HW;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float stride_f = (float)stride;
@@ -43,11 +45,21 @@ __global__ __launch_bounds__(256) void cif_active_kernel(
             const float v = P[HW + o];
             if (!((double)v < threshold)) {                       // cif_hr.cpp:39
                 const float scale = P[4 * HW + o];
-                if (!(scale < min_scale_f)) {                     // cif_hr.cpp:42
+                bool big_enough;
+                double sigma_d;
+                if (DET) {                                        // cif_hr.cpp:135-141
+                    const float h = P[5 * HW + o];
+                    big_enough = !(scale < min_scale_f || h < min_scale_f);
+                    sigma_d = 0.1 * (double)fminf(scale, h) * (double)stride;
+                } else {                                          // cif_hr.cpp:42,46
+                    big_enough = !(scale < min_scale_f);
+                    sigma_d = 0.5 * (double)scale * (double)stride;
+                }
+                if (big_enough) {
                     on = true;
                     x = P[2 * HW + o] * stride_f;                 // cif_hr.cpp:44-45
                     y = P[3 * HW + o] * stride_f;
-                    sigma = fmaxf(1.0f, (float)(0.5 * (double)scale * (double)stride));   // :46
+                    sigma = fmaxf(1.0f, (float)sigma_d);
                     v16 = (float)((double)(v / neighbors_f) * factor);                    // :51
                 }
             }
@@ -160,17 +172,21 @@ __global__ __launch_bounds__(256) void cifhr_tile_kernel(
 hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride,
                         double min_scale, double factor, const DevParams& p,
                         float* cifhr, int hr_rows, int hr_pitch,
-                        float* act, int32_t* act_count, hipStream_t st) {
+                        float* act, int32_t* act_count, hipStream_t st, bool det) {
     const int planes = B * F, HW = H * W;
     const int hr_cols = (W - 1) * stride + 1;
-    if (p.ablation_cifhr_skip) {                      // cif_hr.cpp:29
+    if (p.ablation_cifhr_skip && !det) {              // cif_hr.cpp:29
         hipError_t e = hipMemsetAsync(act_count, 0, sizeof(int32_t) * planes, st);
         if (e != hipSuccess) return e;
         prof_mark(st, "memset_act_count");
     } else {
         const float min_scale_f = (float)(min_scale / (double)stride);       // cif_hr.cpp:32
-        cif_active_kernel<<<planes, 256, 0, st>>>(cif, HW, stride, min_scale_f, p.cif_threshold,
-                                                   (float)p.cifhr_neighbors, factor, act, act_count);
+        if (det)
+            cif_active_kernel<true><<<planes, 256, 0, st>>>(cif, HW, stride, min_scale_f, p.cif_threshold,
+                                                             (float)p.cifhr_neighbors, factor, act, act_count);
+        else
+            cif_active_kernel<false><<<planes, 256, 0, st>>>(cif, HW, stride, min_scale_f, p.cif_threshold,
+                                                              (float)p.cifhr_neighbors, factor, act, act_count);
         prof_mark(st, "cif_active_kernel");
     }
     const int tiles_x = hr_pitch / kHrTileW;

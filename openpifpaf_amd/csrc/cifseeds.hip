@@ -28,7 +28,7 @@ __device__ __forceinline__ float from_sortable(unsigned s) {
 }
 
 __global__ __launch_bounds__(256) void cifseeds_fill_kernel(
-        const float* __restrict__ cif, int F, int H, int W, int stride,
+        const float* __restrict__ cif, int F, int NC, int H, int W, int stride,
         const float* __restrict__ cifhr, int hr_rows, int hr_cols, int hr_pitch,
         double threshold, int ablation_nms, int no_rescore,
         unsigned long long* __restrict__ keys, int sort_cap, int cap, int32_t* __restrict__ seed_count) {
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void cifseeds_fill_kernel(
     const int b = plane / F, f = plane - b * F;
     const int o = blockIdx.y * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const float* P = cif + (size_t)plane * 5 * HW;
+    const float* P = cif + (size_t)plane * NC * HW;
     bool on = false;
     float c = 0.f;
     if (o < HW) {
@@ -88,7 +88,7 @@ __device__ __forceinline__ void compare_exchange_desc(unsigned long long& a, uns
 
 __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
         unsigned long long* keys, int sort_cap, int cap, const int32_t* __restrict__ seed_count,
-        const float* __restrict__ cif, int F, int HW, int stride,
+        const float* __restrict__ cif, int F, int NC, int HW, int stride,
         int32_t* __restrict__ seed_f, float* __restrict__ seed_vxys) {
     __shared__ unsigned long long sk[kSortLdsKeys];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -150,37 +150,43 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
 
     // epilogue: decode keys -> sorted seeds (cif_seeds.cpp:100-113)
     int32_t* sf = seed_f + (size_t)b * cap;
-    float* sv = seed_vxys + (size_t)b * cap * 4;
-    const float* image = cif + (size_t)b * F * 5 * HW;
+    const int ncol = NC - 1;                    // (v,x,y,s) for CIF; (v,x,y,w,h) for CifDet, cif_seeds.cpp:124-137
+    float* sv = seed_vxys + (size_t)b * cap * ncol;
+    const float* image = cif + (size_t)b * F * NC * HW;
     for (int t = tid; t < n; t += 1024) {
         const unsigned long long key = in_lds ? sk[t] : K[t];
         const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
         const int f = (int)(idx / (unsigned)HW), o = (int)(idx - (unsigned)f * (unsigned)HW);
-        const float* P = image + (size_t)f * 5 * HW;
+        const float* P = image + (size_t)f * NC * HW;
         sf[t] = f;
         float4 r;
         r.x = from_sortable((unsigned)(key >> 32));
         r.y = P[2 * HW + o] * (float)stride;
         r.z = P[3 * HW + o] * (float)stride;
         r.w = P[4 * HW + o] * (float)stride;                        // cif_seeds.cpp:61
-        reinterpret_cast<float4*>(sv)[t] = r;
+        if (NC == 5) {
+            reinterpret_cast<float4*>(sv)[t] = r;
+        } else {                                                    // cif_seeds.cpp:85-87
+            float* row = sv + (size_t)t * 5;
+            row[0] = r.x; row[1] = r.y; row[2] = r.z; row[3] = r.w; row[4] = P[5 * HW + o] * (float)stride;
+        }
     }
 }
 
 hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int stride,
                            const float* cifhr, int hr_rows, int hr_cols, int hr_pitch, const DevParams& p,
                            unsigned long long* keys, int sort_cap, int32_t* seed_count,
-                           int32_t* seed_f, float* seed_vxys, hipStream_t st) {
-    const int HW = H * W, cap = F * HW;
+                           int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det) {
+    const int HW = H * W, cap = F * HW, NC = det ? 6 : 5;
     hipError_t e = hipMemsetAsync(seed_count, 0, sizeof(int32_t) * B, st);
     if (e != hipSuccess) return e;
     prof_mark(st, "memset_seed_count");
     dim3 grid(B * F, (HW + 255) / 256);
-    cifseeds_fill_kernel<<<grid, 256, 0, st>>>(cif, F, H, W, stride, cifhr, hr_rows, hr_cols, hr_pitch,
-                                               p.seed_threshold, p.ablation_cifseeds_nms,
-                                               p.ablation_cifseeds_no_rescore, keys, sort_cap, cap, seed_count);
+    cifseeds_fill_kernel<<<grid, 256, 0, st>>>(cif, F, NC, H, W, stride, cifhr, hr_rows, hr_cols, hr_pitch,
+                                               p.seed_threshold, det ? 0 : p.ablation_cifseeds_nms,
+                                               det ? 0 : p.ablation_cifseeds_no_rescore, keys, sort_cap, cap, seed_count);
     prof_mark(st, "cifseeds_fill_kernel");
-    cifseeds_sort_kernel<<<B, 1024, 0, st>>>(keys, sort_cap, cap, seed_count, cif, F, HW, stride,
+    cifseeds_sort_kernel<<<B, 1024, 0, st>>>(keys, sort_cap, cap, seed_count, cif, F, NC, HW, stride,
                                              seed_f, seed_vxys);
     prof_mark(st, "cifseeds_sort_kernel");
     return hipGetLastError();

@@ -65,12 +65,12 @@ void prof_mark(hipStream_t st, const char* name);
 hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride,
                         double min_scale, double factor, const DevParams& p,
                         float* cifhr, int hr_rows, int hr_pitch,
-                        float* act, int32_t* act_count, hipStream_t st);
+                        float* act, int32_t* act_count, hipStream_t st, bool det = false);
 
 hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int stride,
                            const float* cifhr, int hr_rows, int hr_cols, int hr_pitch, const DevParams& p,
                            unsigned long long* keys, int sort_cap, int32_t* seed_count,
-                           int32_t* seed_f, float* seed_vxys, hipStream_t st);
+                           int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det = false);
 
 hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
@@ -93,6 +93,14 @@ struct AssocArgs {
     int32_t* status;         // [B] debug/overflow flags
 };
 hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st);
+
+struct DetArgs {
+    int B, F, max_det, occ_h, occ_w, seed_cap;
+    const int32_t* seed_f; const float* seed_vxywh; const int32_t* seed_count;
+    unsigned char* occ;
+    int64_t* categories; float* scores; float* boxes; int32_t* counts;
+};
+hipError_t launch_cifdet_collect(const DetArgs& a, const DevParams& p, hipStream_t st);
 
 hipError_t launch_bias_act(void* x, const void* bias, const void* res, long long rows, int channels, int dtype,
                            int relu, hipStream_t st);

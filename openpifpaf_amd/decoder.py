@@ -27,7 +27,7 @@ import numpy as np
 import torch
 
 from . import headmeta, native
-from .annotation import Annotation
+from .annotation import Annotation, AnnotationDet
 
 LOG = logging.getLogger(__name__)
 
@@ -252,6 +252,82 @@ class CifCaf(Decoder):
         return result
 
 
+def _nms_keep(boxes, scores, iou_threshold):
+    """Greedy IoU non-maximum suppression on (x0,y0,x1,y1) boxes -> kept indices (what
+    ``torchvision.ops.nms`` computes; torchvision is not a dependency here)."""
+    order = np.argsort(-scores, kind='stable')
+    area = np.maximum(0.0, boxes[:, 2] - boxes[:, 0]) * np.maximum(0.0, boxes[:, 3] - boxes[:, 1])
+    keep, alive = [], np.ones(len(boxes), dtype=bool)
+    for i in order:
+        if not alive[i]:
+            continue
+        keep.append(i)
+        xx0 = np.maximum(boxes[i, 0], boxes[:, 0]); yy0 = np.maximum(boxes[i, 1], boxes[:, 1])
+        xx1 = np.minimum(boxes[i, 2], boxes[:, 2]); yy1 = np.minimum(boxes[i, 3], boxes[:, 3])
+        inter = np.maximum(0.0, xx1 - xx0) * np.maximum(0.0, yy1 - yy0)
+        iou = inter / np.maximum(area[i] + area - inter, 1e-12)
+        alive &= ~(iou > iou_threshold)
+        alive[i] = False
+    return np.asarray(keep, dtype=np.int64)
+
+
+class CifDet(Decoder):
+    """Detection decoder on the MI355X (reference ``decoder/cifdet.py:16-91``)."""
+    iou_threshold = 0.5
+    instance_threshold = 0.15
+    nms_by_category = True
+    suppression = 0.1
+
+    def __init__(self, head_metas: List[headmeta.CifDet]):
+        super().__init__()
+        self.metas = head_metas
+        self.priority = -1.0                      # prefer keypoints over detections
+        self.priority += sum(m.n_fields for m in head_metas) / 1000.0
+        self.cpp_decoder = native.CifDet()
+
+    @classmethod
+    def factory(cls, head_metas):
+        return [cls([meta]) for meta in head_metas if isinstance(meta, headmeta.CifDet)]
+
+    def _post(self, categories, scores, boxes):
+        """Reference ``cifdet.py:61-91``: IoU NMS (suppressed scores x0.1), instance threshold, xywh."""
+        categories, scores, boxes = np.asarray(categories), np.asarray(scores).copy(), np.asarray(boxes).copy()
+        if len(scores):
+            if self.nms_by_category:              # batched_nms: boxes of different categories never overlap
+                offset = categories.astype(np.float64)[:, None] * (boxes.max() + 1.0)
+                keep = _nms_keep(boxes + offset, scores, self.iou_threshold)
+            else:
+                keep = _nms_keep(boxes, scores, self.iou_threshold)
+            pre = scores.copy()
+            scores *= self.suppression
+            scores[keep] = pre[keep]
+        mask = scores > self.instance_threshold
+        boxes = boxes[mask]
+        boxes[:, 2:] -= boxes[:, :2]
+        return [AnnotationDet(self.metas[0].categories).set(int(c), float(s), b)
+                for c, s, b in zip(categories[mask], scores[mask], boxes)]
+
+    def __call__(self, fields, initial_annotations=None):
+        cat, sc, bx = self.cpp_decoder.call(fields[self.metas[0].head_index], self.metas[0].stride)
+        return self._post(cat.cpu().numpy(), sc.cpu().numpy(), bx.cpu().numpy())
+
+    def batch(self, model, image_batch, *, device=None, gt_anns_batch=None):
+        start_nn = time.perf_counter()
+        with torch.no_grad():
+            if device is not None:
+                image_batch = image_batch.to(device, non_blocking=True)
+            heads = model(image_batch)
+        if image_batch.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        self.last_nn_time = time.perf_counter() - start_nn
+        start_decoder = time.perf_counter()
+        cat, sc, bx, cnt = self.cpp_decoder.call_batch(heads[self.metas[0].head_index], self.metas[0].stride)
+        cat, sc, bx, cnt = cat.cpu().numpy(), sc.cpu().numpy(), bx.cpu().numpy(), cnt.cpu().numpy()
+        result = [self._post(cat[b, :cnt[b]], sc[b, :cnt[b]], bx[b, :cnt[b]]) for b in range(len(cnt))]
+        self.last_decoder_time = time.perf_counter() - start_decoder
+        return result
+
+
 class Multi(Decoder):
     """Reference ``decoder/multi.py:11-35``: run several decoders on the same fields."""
 
@@ -277,7 +353,7 @@ class Multi(Decoder):
         return super().batch(model, image_batch, device=device, gt_anns_batch=gt_anns_batch)
 
 
-DECODERS = {CifCaf}
+DECODERS = {CifCaf, CifDet}
 
 
 def cli(parser, *, workers=None):
@@ -310,6 +386,7 @@ def configure(args):
     native.CifSeeds.set_threshold(args.seed_threshold)
     native.CafScored.set_default_score_th(args.caf_th)
     native.NMSKeypoints.set_instance_threshold(args.instance_threshold)
+    CifDet.instance_threshold = args.instance_threshold
     for dec in DECODERS:
         dec.configure(args)
 

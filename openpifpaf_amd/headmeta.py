@@ -79,6 +79,24 @@ class Caf(Base):
         return len(self.skeleton)
 
 
+@dataclass
+class CifDet(Base):
+    """Composite Intensity Field for detection: one field per category, components
+    (width, confidence, x, y, w, h) (reference ``headmeta.py:116-133``)."""
+    categories: List[str] = None
+
+    n_confidences: ClassVar[int] = 1
+    n_vectors: ClassVar[int] = 2
+    n_scales: ClassVar[int] = 0
+    vector_offsets: ClassVar[List[bool]] = [True, False]
+
+    decoder_min_scale = 0.0
+
+    @property
+    def n_fields(self) -> int:
+        return len(self.categories)
+
+
 def cocokp_metas(upsample_stride=2, base_stride=16):
     """The (Cif, Caf) pair of the reference's ``cocokp`` datamodule
     (reference ``plugins/coco/cocokp.py:68-85``) with the stride the pretrained

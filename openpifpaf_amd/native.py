@@ -325,3 +325,55 @@ class NMSKeypoints:
     get_instance_threshold, set_instance_threshold = _static_getset('nms_instance_threshold')
     get_keypoint_threshold, set_keypoint_threshold = _static_getset('nms_keypoint_threshold')
     get_suppression, set_suppression = _static_getset('nms_suppression')
+
+
+class CifDet:
+    """Drop-in for ``torch.classes.openpifpaf_decoder.CifDet`` (module.cpp:57-62), batched."""
+    _max_detections_before_nms = 120                   # cifdet.cpp:16
+
+    @classmethod
+    def get_max_detections_before_nms(cls):
+        return cls._max_detections_before_nms
+
+    @classmethod
+    def set_max_detections_before_nms(cls, v):
+        cls._max_detections_before_nms = int(v)
+
+    def __init__(self):
+        _device()
+        self._workspaces = {}
+
+    def call_batch(self, cifdet_field, cifdet_stride, *, params=None):
+        """``cifdet_field`` [B,F,6,H,W] -> device tensors (categories [B,max] int64, scores [B,max],
+        boxes [B,max,4] (x0,y0,x1,y1), counts [B] int32)."""
+        field, orig = _prep(cifdet_field)
+        B, F, C, H, W = field.shape
+        if C != 6:
+            raise ValueError('expected a CifDet field [B,F,6,H,W], got %s' % (tuple(field.shape),))
+        shape = _lib.DetShape(B, F, H, W, int(cifdet_stride), self._max_detections_before_nms)
+        key = (B, F, H, W, int(cifdet_stride), shape.max_detections, field.device.index)
+        ws = self._workspaces.get(key)
+        if ws is None:
+            nbytes = _lib.lib().opa_cifdet_workspace_bytes(ctypes.byref(shape))
+            if nbytes == 0:
+                raise _lib.NativeError(_lib.lib().opa_last_error().decode())
+            self._workspaces.clear()
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=field.device)
+            self._workspaces[key] = ws
+        M = shape.max_detections
+        cat = torch.empty((B, M), dtype=torch.int64, device=field.device)
+        sc = torch.empty((B, M), dtype=torch.float32, device=field.device)
+        bx = torch.empty((B, M, 4), dtype=torch.float32, device=field.device)
+        cnt = torch.empty((B,), dtype=torch.int32, device=field.device)
+        _lib.check(_lib.lib().opa_cifdet_decode(
+            ctypes.byref(shape), ctypes.byref(params) if params is not None else None, _ptr(field),
+            _ptr(ws), ws.numel(), _ptr(cat), _ptr(sc), _ptr(bx), _ptr(cnt), _stream()), 'opa_cifdet_decode')
+        if orig.type != 'cuda':
+            cat, sc, bx, cnt = cat.to(orig), sc.to(orig), bx.to(orig), cnt.to(orig)
+        return cat, sc, bx, cnt
+
+    def call(self, cifdet_field, cifdet_stride):
+        """Single image, like module.cpp:61: -> (categories [n], scores [n], boxes [n,4])."""
+        cat, sc, bx, cnt = self.call_batch(cifdet_field.unsqueeze(0), cifdet_stride)
+        n = int(cnt[0])
+        return cat[0, :n].clone(), sc[0, :n].clone(), bx[0, :n].clone()

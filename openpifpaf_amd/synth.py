@@ -158,3 +158,30 @@ def adversarial_fields(seed, *, n_keypoints=17, n_bones=19, height=81, width=81)
     caf[:, 6] = np.log1p(np.exp(rng.normal(0, 1, (n_bones, H, W))))
     caf[:, 7] = np.log1p(np.exp(rng.normal(0, 1, (n_bones, H, W))))
     return cif.astype(np.float32), caf.astype(np.float32)
+
+
+def synth_det_field(seed, n_objects, *, n_categories=8, height=81, width=81):
+    """One image's CifDet field ``[n_categories, 6, H, W]`` (0 unused, 1 conf, 2 x, 3 y, 4 w, 5 h):
+    a confidence blob at every object centre, regressions pointing at the centre, box size in
+    field units (reference ``headmeta.py:116-133``)."""
+    rng = np.random.default_rng(seed)
+    H, W = height, width
+    jj, ii = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing='ij')
+    f = np.empty((n_categories, 6, H, W), dtype=np.float64)
+    f[:, 0] = rng.normal(0.0, 1.0, (n_categories, H, W))
+    f[:, 1] = rng.uniform(0.0, 0.05, (n_categories, H, W))
+    f[:, 2] = ii[None] + rng.normal(0.0, 1.0, (n_categories, H, W))
+    f[:, 3] = jj[None] + rng.normal(0.0, 1.0, (n_categories, H, W))
+    f[:, 4] = rng.uniform(0.5, 3.0, (n_categories, H, W))
+    f[:, 5] = rng.uniform(0.5, 3.0, (n_categories, H, W))
+    for _ in range(n_objects):
+        c = int(rng.integers(n_categories))
+        w, h = rng.uniform(4.0, 0.5 * W), rng.uniform(4.0, 0.5 * H)
+        cx, cy = rng.uniform(0.5 * w, W - 1 - 0.5 * w), rng.uniform(0.5 * h, H - 1 - 0.5 * h)
+        bj, bi = _blob(f[c, 1], None, cx, cy, 2.5 + 0.05 * min(w, h), 0.9, 1.3 + 0.05 * min(w, h), rng)
+        n = len(bj)
+        f[c, 2, bj, bi] = cx + rng.normal(0.0, 0.05, n)
+        f[c, 3, bj, bi] = cy + rng.normal(0.0, 0.05, n)
+        f[c, 4, bj, bi] = w * (1.0 + rng.normal(0.0, 0.03, n))
+        f[c, 5, bj, bi] = h * (1.0 + rng.normal(0.0, 0.03, n))
+    return f.astype(np.float32)

@@ -165,6 +165,54 @@ std::vector<Seed> cif_seeds(const HiRes& hr, const float* cif, int64_t F, int64_
     return seeds;
 }
 
+// ---------------------------------------------------------------- CifDet pieces
+// cif_hr.cpp:124-150 ; field layout [F,6,H,W]: 0 unused, 1 conf, 2 x, 3 y, 4 w, 5 h
+void cifdethr_accumulate(HiRes& hr, const float* field, int64_t F, int64_t H, int64_t W, int64_t stride,
+                         double min_scale, double factor, const Params& p) {
+    const int64_t HW = H * W;
+    const float min_scale_f = min_scale / stride;
+    for (int64_t f = 0; f < F; f++) {
+        const float* plane = field + f * 6 * HW;
+        for (int64_t j = 0; j < H; j++) for (int64_t i = 0; i < W; i++) {
+            const int64_t o = j * W + i;
+            const float v = plane[1 * HW + o];
+            if (v < p.cif_threshold) continue;
+            const float w = plane[4 * HW + o], h = plane[5 * HW + o];
+            if (w < min_scale_f || h < min_scale_f) continue;
+            const float x = plane[2 * HW + o] * stride;
+            const float y = plane[3 * HW + o] * stride;
+            const float sigma = fmaxf(1.0, 0.1 * fmin(w, h) * stride);
+            add_gauss(hr, f, v / p.cifhr_neighbors * factor, x, y, sigma, 1.0);
+        }
+    }
+}
+
+struct DetSeed { int64_t c; float v, x, y, w, h; };   // cif_seeds.hpp:26-32
+
+// cif_seeds.cpp:69-90,117-123
+std::vector<DetSeed> cifdet_seeds(const HiRes& hr, const float* field, int64_t F, int64_t H, int64_t W,
+                                  int64_t stride, const Params& p) {
+    std::vector<DetSeed> seeds;
+    const int64_t HW = H * W;
+    for (int64_t f = 0; f < F; f++) {
+        const float* plane = field + f * 6 * HW;
+        for (int64_t j = 0; j < H; j++) for (int64_t i = 0; i < W; i++) {
+            const int64_t o = j * W + i;
+            const float c = plane[1 * HW + o];
+            if (c < p.seed_threshold) continue;
+            const float x = plane[2 * HW + o] * stride;
+            const float y = plane[3 * HW + o] * stride;
+            const float v = 0.9 * cifhr_value(hr, f, x, y, -1.0) + 0.1 * c;
+            if (v < p.seed_threshold) continue;
+            const float w = plane[4 * HW + o] * stride;
+            const float h = plane[5 * HW + o] * stride;
+            seeds.push_back(DetSeed{f, v, x, y, w, h});
+        }
+    }
+    std::sort(seeds.begin(), seeds.end(), [](const DetSeed& a, const DetSeed& b) { return a.v > b.v; });
+    return seeds;
+}
+
 // ---------------------------------------------------------------- CafScored
 struct Assoc { float c, x1, y1, x2, y2, s1, s2; };   // caf_scored.hpp:17-33
 typedef std::vector<std::vector<Assoc>> AssocLists;
@@ -512,6 +560,34 @@ int64_t oracle_cifcaf_decode(const float* cif, int64_t F, int64_t H, int64_t W, 
         out_ids[n] = anns[n].id;
     }
     return int64_t(anns.size());
+}
+
+// CifDet::call, cifdet.cpp:24-80.  Returns the number of detections (<= max_detections).
+// categories int64 [max], scores float [max], boxes float [max,4] (x0,y0,x1,y1); cifhr_out optional.
+int64_t oracle_cifdet_decode(const float* field, int64_t F, int64_t H, int64_t W, int64_t stride,
+                             const oracle_params* params, int64_t max_detections,
+                             int64_t* categories, float* scores, float* boxes, float* cifhr_out) {
+    const Params& p = *params;
+    const int64_t hh = (H - 1) * stride + 1, hw = (W - 1) * stride + 1;
+    std::vector<float> buffer(size_t(F) * hh * hw, 0.0f);
+    HiRes hr{buffer.data(), F, hh, hw};
+    cifdethr_accumulate(hr, field, F, H, W, stride, 0.0, 1.0, p);            // cifdet.cpp:30-32
+    if (cifhr_out) std::memcpy(cifhr_out, buffer.data(), buffer.size() * sizeof(float));
+    std::vector<DetSeed> seeds = cifdet_seeds(hr, field, F, H, W, stride, p);   // :34-38
+    Occupancy occ(p.occupancy_reduction, p.occupancy_min_scale);              // cifdet.hpp:37
+    occ.reset(F, hh, hw);                                                     // :44
+    int64_t n = 0;
+    for (const DetSeed& s : seeds) {                                          // :50-67
+        if (occ.get(s.c, s.x, s.y)) continue;
+        occ.set(s.c, s.x, s.y, 0.1 * fmin(s.w, s.h));
+        categories[n] = s.c + 1;
+        scores[n] = s.v;
+        boxes[4 * n + 0] = s.x - 0.5f * s.w; boxes[4 * n + 1] = s.y - 0.5f * s.h;
+        boxes[4 * n + 2] = s.x + 0.5f * s.w; boxes[4 * n + 3] = s.y + 0.5f * s.h;
+        n++;
+        if (n >= max_detections) break;
+    }
+    return n;
 }
 
 }  // extern "C"

@@ -54,6 +54,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.oracle_cifseeds.restype = ctypes.c_int64
         _lib.oracle_cifcaf_decode.restype = ctypes.c_int64
+        _lib.oracle_cifdet_decode.restype = ctypes.c_int64
     return _lib
 
 
@@ -169,3 +170,20 @@ def decode(cif, cif_stride, caf, caf_stride, skeleton0, *, params=None,
     if return_cifhr:
         res = res + (hr,)
     return res
+
+
+def cifdet_decode(field, stride, *, params=None, max_detections=120, return_cifhr=False):
+    """CifDet::call (cifdet.cpp:24-80) -> (categories int64[n], scores float32[n], boxes float32[n,4])."""
+    params = params or default_params()
+    field = _f32(field)
+    F, C, H, W = field.shape
+    assert C == 6
+    cat = np.zeros((max_detections,), dtype=np.int64)
+    sc = np.zeros((max_detections,), dtype=np.float32)
+    bx = np.zeros((max_detections, 4), dtype=np.float32)
+    hr = np.zeros((F, (H - 1) * stride + 1, (W - 1) * stride + 1), dtype=np.float32) if return_cifhr else None
+    n = lib().oracle_cifdet_decode(_ptr(field), _i64(F), _i64(H), _i64(W), _i64(stride), ctypes.byref(params),
+                                   _i64(max_detections), _ptr(cat), _ptr(sc), _ptr(bx),
+                                   _ptr(hr) if hr is not None else None)
+    res = (cat[:n].copy(), sc[:n].copy(), bx[:n].copy())
+    return res + (hr,) if return_cifhr else res

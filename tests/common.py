@@ -11,6 +11,10 @@ GOLDEN_CASES = [
 ]
 
 
+# (seed, objects, H, W) -- CifDet golden cases
+DET_CASES = [(0, 1, 41, 41), (1, 5, 41, 41), (2, 12, 33, 49), (3, 30, 81, 81), (4, 150, 81, 81)]
+
+
 def compare_annotations(a, b, tol=TOL):
     """a, b: [n,K,4] (v,x,y,s), both in the decoder's output order (score descending).
     Returns (ok, message).  Discrete mismatches (count, joint presence) are reported as such."""

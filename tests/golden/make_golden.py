@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(HERE))
 
-from common import GOLDEN_CASES          # noqa: E402
+from common import DET_CASES, GOLDEN_CASES          # noqa: E402
 from openpifpaf_amd import constants, synth   # noqa: E402
 from oracle import port, reference       # noqa: E402
 
@@ -79,6 +79,16 @@ def main():
         out['case%d_annotations_fc' % i] = ann_fc
         print('case %d seed=%d people=%d %dx%d: %d poses (%d force-complete), %d seeds'
               % (i, seed, people, H, W, len(ann), len(ann_fc), len(sf)))
+    # CifDet (reference torch.classes.openpifpaf_decoder.CifDet, fresh instance per case)
+    for i, (seed, n_obj, H, W) in enumerate(DET_CASES):
+        field = synth.synth_det_field(seed, n_obj, height=H, width=W)
+        det = torch.classes.openpifpaf_decoder.CifDet()
+        c, sc, bx = det.call(torch.from_numpy(field), 8)
+        out['det%d_input_sha256' % i] = as_u8(digest(field))
+        out['det%d_categories' % i] = c.numpy().copy()
+        out['det%d_scores' % i] = sc.numpy().copy()
+        out['det%d_boxes' % i] = bx.numpy().copy()
+        print('det case %d seed=%d objects=%d %dx%d: %d detections' % (i, seed, n_obj, H, W, len(c)))
     # grow_connection_blend known answers
     cif, caf = synth.synth_fields(7, 10)
     hr = port.cifhr_accumulate(cif, 8)
