@@ -5,31 +5,34 @@
 // _flood_fill (csrc/src/cifcaf.cpp:32-449), Occupancy (occupancy.cpp:13-79) and
 // NMSKeypoints::call (nms_keypoints.cpp:17-70).
 //
-// One 4-wave workgroup per image (images are the data-parallel unit; a batch
-// fills the chip).  The reference's control flow is a serial dependency chain per
-// image (seed k is skipped iff an earlier pose occupies its cell; growth is a
-// best-first search) and every step of it is latency bound, so:
+// One 16-wave workgroup per image (images are the data-parallel unit; a batch fills the
+// chip).  Per image the reference is one serial dependency chain -- seed k is skipped
+// iff an earlier pose occupies its cell -- but the GROWTH of a pose from a seed reads
+// only the CAF lists and the pose's own joints, never the occupancy map (cifcaf.cpp
+// :265-411).  So poses are grown SPECULATIVELY in parallel and only the accept/reject
+// decision is sequential:
 //
-//  * All four waves run the SAME control flow on private, identical copies of the
-//    small state (current pose, frontier heap) in LDS -- replicated, deterministic,
-//    no synchronisation needed for it.
-//  * The expensive pure function, _connection_value (two grow_connection_blend list
-//    scans), is evaluated EAGERLY when a joint is assigned: the joint's outgoing
-//    edges are dealt to the four waves, each wave scans its CAF candidate lists
-//    (coalesced SoA planes from L2, 64 entries per lane-step, all loads of a scan in
-//    flight at once, top-1/top-2 by cross-lane shuffles with the reference's ">=" /
-//    ">" position tie rules) and publishes the result in a shared LDS connection
-//    cache; one workgroup barrier later every wave continues with the same cache.
-//    The frontier itself stays LAZY exactly like the reference's (an uncomputed
-//    entry carries the bound sqrt(v) and is re-pushed with its true score when
-//    popped): evaluation is a pure function of the start joint, so evaluating early
-//    changes nothing but the latency.
-//  * The frontier is an exact re-implementation of the binary max-heap behind
-//    std::priority_queue (sift-up on push, sift-to-leaf + sift-up on pop), so that
-//    equal-priority entries -- the norm: all edges leaving one joint share the
-//    bound -- pop in the reference's order.
-//  * 256 sorted seeds are tested against the occupancy map per step; occupancy
-//    boxes of a pose and NMS boxes are dealt to the waves.
+//   round:  1024 sorted seeds are tested against the occupancy map at once (ballot);
+//           the first S live ones become candidates, one per wavefront;
+//           every wave grows its candidate's pose on its own (private LDS state, no
+//           barriers): best-first search with the reference's lazy frontier;
+//           resolve in seed order: candidate c is accepted iff its cell is still free
+//           after the poses accepted before it in this round were marked -- exactly the
+//           seeds the sequential loop would accept, with exactly the poses it would
+//           grow.  Seeds of the same person turn into discarded work, distinct persons
+//           into parallel speed-up (a 20-person image needs ~3 rounds instead of 20
+//           sequential growths).
+//
+// Inside a growth the wave uses its 64 lanes where the reference has inner loops:
+// grow_connection_blend scans a CAF candidate list 64 entries per lane-step (coalesced
+// SoA planes from L2, ALL loads of a scan in flight at once, scores kept in registers,
+// top-1/top-2 by DPP row-op reductions reproducing the reference's ">=" / ">" position
+// tie rules).  The frontier is an exact re-implementation of the binary max-heap behind
+// std::priority_queue (sift-up on push, sift-to-leaf + sift-up on pop), because equal
+// priorities are the norm (all edges leaving one joint share the bound sqrt(v); every
+// flood-filled joint carries 1e-5) and the pop order decides results.
+// Occupancy boxes of an accepted pose and NMS boxes are dealt to the 16 waves;
+// force-complete growth and flood fill run one pose per wave.
 //
 // Joint confidences are double like the reference's Joint struct; every
 // float/double promotion follows the reference operation by operation and the
@@ -38,9 +41,9 @@
 
 namespace opa {
 
-constexpr int kAssocWaves = 4;
+constexpr int kAssocWaves = 8;
 constexpr int kAssocThreads = kAssocWaves * kWave;
-constexpr int kBlendChunks = 8;        // list entries per lane held in registers by the single-pass scan
+constexpr int kBlendChunks = 4;        // list entries per lane held in registers by the single-pass scan
 
 // Optional phase timers (build with -DOPA_ASSOC_TIMING; tools/assoc_timing.py reads them).
 #ifdef OPA_ASSOC_TIMING
@@ -71,10 +74,8 @@ struct ImageCtx {
     unsigned long long* heap;            // [4A] nodes: float bits of max_score << 32 | entry id
     double* e_v; float *e_x, *e_y, *e_s; int* e_se;   // frontier entry pool [4A]
     unsigned char* in_frontier;          // [2A]
-    int* pend;                           // [2A] edges pushed by the current frontier_add_from
     int heap_n, n_entries;
     // shared LDS
-    double* cc_v; float *cc_x, *cc_y, *cc_s; unsigned char* cc_ok;   // connection cache [2A]
     int* sh_counts;                      // [2A] list lengths of the active list set
     long long t[10];                     // OPA_ASSOC_TIMING: 0 blend 1 #blend 2 #chunks 3 rest 4 grow 5 mark 6 nms 7 total
 };
@@ -280,14 +281,13 @@ __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const B
 
 // The one real (non-inlined) device function of the kernel: everything is passed and
 // returned by value in registers.
-__device__ __noinline__ BlendResult blend_impl(const float* base, int cap, int n, double x, double y,
+__device__ __forceinline__ BlendResult blend_impl(const float* base, int cap, int n, double x, double y,
                                                double xy_scale, double filter_sigmas, int only_max) {
     if (n <= 0) return blend_none();
     ListView L; L.base = base; L.cap = cap; L.n = n;
     const BlendQuery q = make_query(x, y, xy_scale, filter_sigmas);
     if (n <= kWave) return blend_cached<1>(L, q, only_max != 0);
     if (n <= 2 * kWave) return blend_cached<2>(L, q, only_max != 0);
-    if (n <= 4 * kWave) return blend_cached<4>(L, q, only_max != 0);
     if (n <= kBlendChunks * kWave) return blend_cached<kBlendChunks>(L, q, only_max != 0);
     return blend_streamed(L, q, only_max != 0);
 }
@@ -378,12 +378,9 @@ __device__ __forceinline__ bool connection_value(ImageCtx& c, const DevParams& p
     return true;
 }
 
-// cifcaf.cpp:316-346, plus the eager evaluation of the edges it pushed.
-// `evaluate`: false for flood fill (no connection values needed).
-__device__ __forceinline__ void frontier_add_from(ImageCtx& c, const DevParams& p, int start, bool evaluate,
-                                  bool reverse_match_, double filter_sigmas) {
+// cifcaf.cpp:316-346
+__device__ __forceinline__ void frontier_add_from(ImageCtx& c, int start) {
     const float max_score = (float)sqrt(c.jv[start]);
-    int n_pend = 0;
     for (int t = c.adj_off[start]; t < c.adj_off[start + 1]; t++) {
         const int other = c.adj_other[t];
         if (c.jv[other] > 0.0) continue;
@@ -391,22 +388,6 @@ __device__ __forceinline__ void frontier_add_from(ImageCtx& c, const DevParams& 
         if (c.in_frontier[first]) continue;
         heap_push(c, max_score, new_entry(c, 0.0, 0.f, 0.f, 0.f, start, other));
         c.in_frontier[first] = 1;
-        c.pend[n_pend++] = first;
-    }
-    if (!evaluate) return;
-    // deal the new edges to the waves; publish results in the shared connection cache
-    for (int r0 = 0; r0 < n_pend; r0 += kAssocWaves) {
-        const int k = r0 + c.wave;
-        if (k < n_pend) {
-            const int slot = c.pend[k];
-            double v; float x, y, s;
-            const bool ok = connection_value(c, p, start, slot, reverse_match_, filter_sigmas, &v, &x, &y, &s);
-            if (lane_id() == 0) {
-                c.cc_ok[slot] = ok ? 1 : 0;
-                if (ok) { c.cc_v[slot] = v; c.cc_x[slot] = x; c.cc_y[slot] = y; c.cc_s[slot] = s; }
-            }
-        }
-        __syncthreads();
     }
 }
 
@@ -423,11 +404,10 @@ __device__ __forceinline__ int find_adj_slot(const ImageCtx& c, int start, int e
     return -1;
 }
 
-// cifcaf.cpp:265-313
+// cifcaf.cpp:265-313 -- one wavefront, no workgroup barriers
 __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool reverse_match_, double filter_sigmas) {
     frontier_reset(c);
-    for (int j = 0; j < c.K; j++)
-        if (c.jv[j] != 0.0) frontier_add_from(c, p, j, true, reverse_match_, filter_sigmas);
+    for (int j = 0; j < c.K; j++) if (c.jv[j] != 0.0) frontier_add_from(c, j);
     while (c.heap_n > 0) {
         const int e = heap_pop(c);
         const int start = c.e_se[e] >> 16, end = c.e_se[e] & 0xffff;
@@ -435,28 +415,28 @@ __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool rever
         double v = c.e_v[e]; float x = c.e_x[e], y = c.e_y[e], s = c.e_s[e];
         if (v == 0.0) {                                                  // :287: not computed yet
             const int slot = find_adj_slot(c, start, end);
-            if (!c.cc_ok[slot]) continue;                                // :290-296 (block_joints is a no-op)
-            v = c.cc_v[slot]; x = c.cc_x[slot]; y = c.cc_y[slot]; s = c.cc_s[slot];
+            if (!connection_value(c, p, start, slot, reverse_match_, filter_sigmas, &v, &x, &y, &s))
+                continue;                                                // :290-296 (block_joints is a no-op)
             if (!p.greedy) {                                             // :298-303
                 heap_push(c, (float)v, new_entry(c, v, x, y, s, start, end));
                 continue;
             }
         }
         c.jv[end] = v; c.jx[end] = x; c.jy[end] = y; c.js[end] = s;     // :310
-        frontier_add_from(c, p, end, true, reverse_match_, filter_sigmas);
+        frontier_add_from(c, end);
     }
 }
 
 // cifcaf.cpp:429-449
-__device__ __forceinline__ void flood_fill(ImageCtx& c, const DevParams& p) {
+__device__ __forceinline__ void flood_fill(ImageCtx& c) {
     frontier_reset(c);
-    for (int j = 0; j < c.K; j++) if (c.jv[j] != 0.0) frontier_add_from(c, p, j, false, false, 0.0);
+    for (int j = 0; j < c.K; j++) if (c.jv[j] != 0.0) frontier_add_from(c, j);
     while (c.heap_n > 0) {
         const int e = heap_pop(c);
         const int start = c.e_se[e] >> 16, end = c.e_se[e] & 0xffff;
         if (c.jv[end] > 0.0) continue;
         c.jv[end] = 0.00001; c.jx[end] = c.jx[start]; c.jy[end] = c.jy[start]; c.js[end] = c.js[start];
-        frontier_add_from(c, p, end, false, false, 0.0);
+        frontier_add_from(c, end);
     }
 }
 
@@ -497,67 +477,75 @@ __device__ __forceinline__ void occ_set(const ImageCtx& c, const DevParams& p, i
     }
 }
 
-// mark every filled joint of the current pose (cifcaf.cpp:225-229), boxes dealt to the waves
-__device__ __forceinline__ void mark_pose(const ImageCtx& c, const DevParams& p) {
-    int n = 0;
-    for (int f = 0; f < c.F; f++) {
-        if (c.jv[f] == 0.0) continue;
-        if ((n++ % kAssocWaves) == c.wave) occ_set(c, p, f, (double)c.jx[f], (double)c.jy[f], (double)c.js[f], 1);
-    }
-    __syncthreads();                      // stores drained + visible to every wave of the workgroup
-}
-
-// nms_keypoints.hpp:25-32 on the LDS pose
-__device__ __forceinline__ double pose_score_lds(const ImageCtx& c) {
-    double acc = 0.0;
-    for (int k = 0; k < c.K; k++) { const float i = (float)acc; acc = (double)i + c.jv[k]; }
-    return acc / (double)c.K;
-}
-
+// Private LDS block of one wave (pose + frontier); kept 16-byte sized.
 __host__ __device__ inline size_t assoc_private_bytes(int K, int A) {
     const int P4 = 4 * A, E = 2 * A;
     const size_t b = sizeof(double) * (K + P4) + sizeof(unsigned long long) * P4 + sizeof(float) * (3 * K + 3 * P4)
-                   + sizeof(int) * (P4 + E) + E;
+                   + sizeof(int) * P4 + E;
     return (b + 15) / 16 * 16;
 }
 
+struct PoseView { const double* v; const float *x, *y, *s; };
+
+__device__ __forceinline__ PoseView pose_of_wave(unsigned char* private_base, int wave, int K, int A) {
+    unsigned char* sp = private_base + (size_t)wave * assoc_private_bytes(K, A);
+    const int P4 = 4 * A;
+    PoseView q;
+    q.v = (const double*)sp; sp += sizeof(double) * (K + P4) + sizeof(unsigned long long) * P4;
+    q.x = (const float*)sp; q.y = q.x + K; q.s = q.y + K;
+    return q;
+}
+
+// mark every filled joint of a pose (cifcaf.cpp:225-229), boxes dealt to the waves
+__device__ __forceinline__ void mark_pose(const ImageCtx& c, const DevParams& p, const PoseView& q) {
+    int n = 0;
+    for (int f = 0; f < c.F; f++) {
+        if (q.v[f] == 0.0) continue;
+        if ((n++ % kAssocWaves) == c.wave) occ_set(c, p, f, (double)q.x[f], (double)q.y[f], (double)q.s[f], 1);
+    }
+}
+
+// nms_keypoints.hpp:25-32 on an LDS pose
+__device__ __forceinline__ double pose_score(const PoseView& q, int K) {
+    double acc = 0.0;
+    for (int k = 0; k < K; k++) { const float i = (float)acc; acc = (double)i + q.v[k]; }
+    return acc / (double)K;
+}
+
 // ------------------------------------------------------------------- kernel
-__global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArgs a, DevSkeleton sk, DevParams p) {
+__global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArgs a, DevSkeleton sk, DevParams p,
+                                                                        int n_growers) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = a.K, A = a.A, E = 2 * A, P4 = 4 * A;
     const int KC = (K + kWave - 1) / kWave;          // 64-joint chunks per pose
+    const int S = n_growers;                         // speculative growers = waves with a private LDS block
 
     ImageCtx c;
     c.K = K; c.A = A; c.F = K; c.wave = wave;
-    c.adj_off = sk.adj_off; c.adj_other = sk.adj_other; c.adj_bone = sk.adj_bone; c.adj_fwd = sk.adj_fwd;
-    c.adj_first = sk.adj_first;
     c.lists = a.lists + (size_t)b * A * 2 * 7 * a.list_cap;
     c.list_counts = a.list_counts + (size_t)b * A * 2;
     c.list_cap = a.list_cap;
     c.occ = a.occ + (size_t)b * K * a.occ_h * a.occ_w; c.occ_h = a.occ_h; c.occ_w = a.occ_w;
 
-    // ---- LDS carve: shared part, then one private part per wave
+    // ---- LDS carve: shared part, then one private block per growing wave
     unsigned char* sp = smem;
-    c.cc_v = (double*)sp; sp += sizeof(double) * E;
     double* nms_score = (double*)sp; sp += sizeof(double) * a.max_ann;
     unsigned long long* nms_supp = (unsigned long long*)sp; sp += sizeof(unsigned long long) * a.max_ann * KC;
     unsigned long long* sh_mask = (unsigned long long*)sp; sp += sizeof(unsigned long long) * 2 * kAssocWaves;
-    c.cc_x = (float*)sp; sp += sizeof(float) * E;
-    c.cc_y = (float*)sp; sp += sizeof(float) * E;
-    c.cc_s = (float*)sp; sp += sizeof(float) * E;
     c.sh_counts = (int*)sp; sp += sizeof(int) * E;
     int* l_off = (int*)sp; sp += sizeof(int) * (K + 1);
     int* l_other = (int*)sp; sp += sizeof(int) * E;
     int* l_bone = (int*)sp; sp += sizeof(int) * E;
     int* l_fwd = (int*)sp; sp += sizeof(int) * E;
     int* l_first = (int*)sp; sp += sizeof(int) * E;
-    if ((K + 1) & 1) sp += sizeof(int);            // keep 8-byte alignment for what follows
+    if ((K + 1) & 1) sp += sizeof(int);             // keep 8-byte alignment for what follows
     int* nms_order = (int*)sp; sp += sizeof(int) * a.max_ann;
     int* nms_rank = (int*)sp; sp += sizeof(int) * a.max_ann;
-    c.cc_ok = sp; sp += (E + 15) / 16 * 16;
-    sp += (size_t)wave * assoc_private_bytes(K, A);
+    int* sh_cand = (int*)sp; sp += sizeof(int) * kAssocWaves;
+    unsigned char* private_base = sp;
+    sp += (size_t)(wave < S ? wave : 0) * assoc_private_bytes(K, A);   // waves >= S never touch theirs
     c.jv = (double*)sp; sp += sizeof(double) * K;
     c.e_v = (double*)sp; sp += sizeof(double) * P4;
     c.heap = (unsigned long long*)sp; sp += sizeof(unsigned long long) * P4;
@@ -568,7 +556,6 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     c.e_y = (float*)sp; sp += sizeof(float) * P4;
     c.e_s = (float*)sp; sp += sizeof(float) * P4;
     c.e_se = (int*)sp; sp += sizeof(int) * P4;
-    c.pend = (int*)sp; sp += sizeof(int) * E;
     c.in_frontier = sp;
     c.heap_n = 0; c.n_entries = 0;
     for (int k = 0; k < 10; k++) c.t[k] = 0;
@@ -577,7 +564,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     const long long cyc0 = clock64();
 #endif
 
-    // the skeleton adjacency is consulted at every step of the search: keep it in LDS
+    // list lengths and the skeleton adjacency are consulted at every step of the search: keep them in LDS
     for (int k = tid; k < E; k += kAssocThreads) {
         c.sh_counts[k] = c.list_counts[k];
         l_other[k] = sk.adj_other[k]; l_bone[k] = sk.adj_bone[k]; l_fwd[k] = sk.adj_fwd[k]; l_first[k] = sk.adj_first[k];
@@ -591,95 +578,127 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     int n_kept = 0, n_dropped = 0;
     const bool prune = !p.force_complete;     // a pose scoring below the instance threshold before NMS cannot survive it
 
-    auto store_pose = [&](long long id) {     // wave 0 writes; every wave counts
-        if (prune && pose_score_lds(c) < p.nms_instance_threshold) return;
+    // Accept the pose grown by wave `g` (every wave executes this with the same arguments):
+    // mark its joints (boxes dealt to the waves) and, unless it cannot survive NMS, store it.
+    auto accept_pose = [&](int g, long long id) {
+        const PoseView q = pose_of_wave(private_base, g, K, A);
+        mark_pose(c, p, q);
+        if (prune && pose_score(q, K) < p.nms_instance_threshold) return;
         if (n_kept >= a.max_ann) { n_dropped++; return; }
-        if (wave == 0) {
+        if (wave == g) {
             double* dst = anns + (size_t)n_kept * K * 4;
             for (int k = lane; k < K; k += kWave) {
-                dst[4 * k + 0] = c.jv[k]; dst[4 * k + 1] = (double)c.jx[k];
-                dst[4 * k + 2] = (double)c.jy[k]; dst[4 * k + 3] = (double)c.js[k];
+                dst[4 * k + 0] = q.v[k]; dst[4 * k + 1] = (double)q.x[k];
+                dst[4 * k + 2] = (double)q.y[k]; dst[4 * k + 3] = (double)q.s[k];
             }
             if (lane == 0) ann_ids[n_kept] = id;
         }
         n_kept++;
     };
 
-    // ---- initial annotations (tracking API), cifcaf.cpp:177-202
-    for (int n = 0; n < a.n_initial; n++) {
-        const float* src = a.initial + ((size_t)b * a.n_initial + n) * K * 4;
-        for (int k = lane; k < K; k += kWave) {
-            c.jv[k] = (double)src[4 * k + 0]; c.jx[k] = src[4 * k + 1];
-            c.jy[k] = src[4 * k + 2]; c.js[k] = src[4 * k + 3];
+    // ---- initial annotations (tracking API), cifcaf.cpp:177-202: S growths at a time
+    for (int n0 = 0; n0 < a.n_initial; n0 += S) {
+        const int n = n0 + wave;
+        if (wave < S && n < a.n_initial) {
+            const float* src = a.initial + ((size_t)b * a.n_initial + n) * K * 4;
+            for (int k = lane; k < K; k += kWave) {
+                c.jv[k] = (double)src[4 * k + 0]; c.jx[k] = src[4 * k + 1];
+                c.jy[k] = src[4 * k + 2]; c.js[k] = src[4 * k + 3];
+            }
+            wave_sync();
+            grow(c, p, true, 1.0);
         }
-        wave_sync();
-        grow(c, p, true, 1.0);
-        mark_pose(c, p);
-        store_pose(a.initial_ids ? a.initial_ids[(size_t)b * a.n_initial + n] : -1);
+        __syncthreads();
+        for (int g = 0; g < S && n0 + g < a.n_initial; g++)
+            accept_pose(g, a.initial_ids ? a.initial_ids[(size_t)b * a.n_initial + n0 + g] : -1);
+        __syncthreads();
     }
 
-    // ---- seeds in score order, cifcaf.cpp:206-231; 256 seeds per occupancy test
+    // ---- seeds in score order, cifcaf.cpp:206-231, in speculative rounds
     int n_seeds = a.seed_count[b];
     if (n_seeds > a.seed_cap) n_seeds = a.seed_cap;
     const int32_t* seed_f = a.seed_f + (size_t)b * a.seed_cap;
     const float4* seed_vxys = reinterpret_cast<const float4*>(a.seed_vxys) + (size_t)b * a.seed_cap;
     int pos = 0, parity = 0;
     while (pos < n_seeds) {
+        // 1. which of the next 1024 seeds are live right now?
         const int i = pos + tid;
         bool live = false;
         if (i < n_seeds) {
-            const int f = seed_f[i]; const float4 s = seed_vxys[i];
-            live = c.occ[occ_cell(c, p, f, (double)s.y, (double)s.z)] == 0;     // :211
+            const int f = seed_f[i]; const float4 sd = seed_vxys[i];
+            live = c.occ[occ_cell(c, p, f, (double)sd.y, (double)sd.z)] == 0;     // :211
         }
         const unsigned long long mask = __ballot(live);
         if (lane == 0) sh_mask[parity * kAssocWaves + wave] = mask;
         __syncthreads();
-        int first = -1;
+        // 2. the first S live ones are this round's candidates; wave g takes candidate g
+        int n_cand = 0, mine = -1;
 #pragma unroll
-        for (int w = kAssocWaves - 1; w >= 0; w--) {
-            const unsigned long long m = sh_mask[parity * kAssocWaves + w];
-            if (m) first = w * kWave + __builtin_ctzll(m);
+        for (int w = 0; w < kAssocWaves; w++) {
+            unsigned long long m = sh_mask[parity * kAssocWaves + w];
+            const int cnt = __popcll(m);
+            if (mine < 0 && wave >= n_cand && wave < n_cand + cnt && wave < S) {
+                int skip = wave - n_cand;
+                while (skip-- > 0) m &= m - 1;
+                mine = pos + w * kWave + __builtin_ctzll(m);
+            }
+            n_cand += cnt;
         }
         parity ^= 1;
-        if (first < 0) { pos += kAssocThreads; continue; }
-        const int si = pos + first;
-        const int sf = seed_f[si]; const float4 sd = seed_vxys[si];
-        for (int k = lane; k < K; k += kWave) { c.jv[k] = 0.0; c.jx[k] = 0.f; c.jy[k] = 0.f; c.js[k] = 0.f; }
-        wave_sync();
-        c.jv[sf] = (double)sd.x; c.jx[sf] = sd.y; c.jy[sf] = sd.z; c.js[sf] = sd.w;   // :213-218
-        wave_sync();
-        { OPA_T0(tg); grow(c, p, true, 1.0); OPA_TACC(c.t[4], tg); }
-        { OPA_T0(tm); mark_pose(c, p); OPA_TACC(c.t[5], tm); }
-        store_pose(-1);
-        pos = si + 1;
+        if (n_cand > S) n_cand = S;
+        if (n_cand == 0) { pos += kAssocThreads; continue; }
+        // 3. speculative growth, one pose per wave, no barriers inside
+        if (mine >= 0) {
+            if (lane == 0) sh_cand[wave] = mine;
+            const int sf = seed_f[mine]; const float4 sd = seed_vxys[mine];
+            for (int k = lane; k < K; k += kWave) { c.jv[k] = 0.0; c.jx[k] = 0.f; c.jy[k] = 0.f; c.js[k] = 0.f; }
+            wave_sync();
+            c.jv[sf] = (double)sd.x; c.jx[sf] = sd.y; c.jy[sf] = sd.z; c.js[sf] = sd.w;   // :213-218
+            wave_sync();
+            OPA_T0(tg); grow(c, p, true, 1.0); OPA_TACC(c.t[4], tg);
+        }
+        __syncthreads();
+        // 4. resolve in seed order: accept candidate g iff its cell is still free (:211 at its turn)
+        OPA_T0(tm);
+        int last = pos;
+        for (int g = 0; g < n_cand; g++) {
+            const int si = sh_cand[g];
+            last = si;
+            const int sf = seed_f[si]; const float4 sd = seed_vxys[si];
+            if (g > 0 && c.occ[occ_cell(c, p, sf, (double)sd.y, (double)sd.z)] != 0) continue;
+            accept_pose(g, -1);
+            __syncthreads();                  // marks drained and visible before the next test
+        }
+        OPA_TACC(c.t[5], tm);
+        // every seed up to the last candidate is decided; fewer than S candidates = all 1024 scanned
+        pos = (n_cand == S) ? last + 1 : pos + kAssocThreads;
     }
     __syncthreads();
 
-    // ---- force complete, cifcaf.cpp:233-236,414-449
+    // ---- force complete, cifcaf.cpp:233-236,414-449: poses are independent, one per wave
     if (p.force_complete) {
         c.lists = a.lists_fc + (size_t)b * A * 2 * 7 * a.list_cap;
         c.list_counts = a.list_counts_fc + (size_t)b * A * 2;
         for (int k = tid; k < E; k += kAssocThreads) c.sh_counts[k] = c.list_counts[k];
         __syncthreads();
-        for (int pass = 0; pass < 2; pass++) {          // all grows first, then all flood fills
-            for (int n = 0; n < n_kept; n++) {
+        if (wave < S) {
+            for (int n = wave; n < n_kept; n += S) {
                 double* src = anns + (size_t)n * K * 4;
                 for (int k = lane; k < K; k += kWave) {
                     c.jv[k] = src[4 * k + 0]; c.jx[k] = (float)src[4 * k + 1];
                     c.jy[k] = (float)src[4 * k + 2]; c.js[k] = (float)src[4 * k + 3];
                 }
                 wave_sync();
-                if (pass == 0) grow(c, p, false, 4.0); else flood_fill(c, p);
+                grow(c, p, false, 4.0);       // :419-425
+                flood_fill(c);                // :235
                 wave_sync();
-                __syncthreads();                        // every wave has read the pose before wave 0 rewrites it
-                if (wave == 0)
-                    for (int k = lane; k < K; k += kWave) {
-                        src[4 * k + 0] = c.jv[k]; src[4 * k + 1] = (double)c.jx[k];
-                        src[4 * k + 2] = (double)c.jy[k]; src[4 * k + 3] = (double)c.js[k];
-                    }
+                for (int k = lane; k < K; k += kWave) {
+                    src[4 * k + 0] = c.jv[k]; src[4 * k + 1] = (double)c.jx[k];
+                    src[4 * k + 2] = (double)c.jy[k]; src[4 * k + 3] = (double)c.js[k];
+                }
             }
-            __syncthreads();
         }
+        __syncthreads();
     }
 
     // ---- keypoint NMS, nms_keypoints.cpp:17-70
@@ -774,7 +793,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
 #ifdef OPA_ASSOC_TIMING
     __syncthreads();
     OPA_TACC(c.t[6], t_nms); OPA_TACC(c.t[7], t_total);
-    c.t[3] = c.t[7] - c.t[4] - c.t[5] - c.t[6];           // seed scanning + bookkeeping = the rest
+    c.t[3] = c.t[7] - c.t[4] - c.t[5] - c.t[6];           // seed scanning + waiting for the slowest grower
     c.t[8] = clock64() - cyc0;
     if (tid == 0) for (int k = 0; k < 10; k++) reinterpret_cast<long long*>(anns)[k] = c.t[k];   // scratch is free now
 #endif
@@ -783,17 +802,21 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
 hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
     const int K = a.K, A = a.A, E = 2 * A;
     const int KC = (K + kWave - 1) / kWave;
-    const size_t shared = sizeof(double) * (E + a.max_ann)
+    const size_t shared = sizeof(double) * a.max_ann
                         + sizeof(unsigned long long) * ((size_t)a.max_ann * KC + 2 * kAssocWaves)
-                        + sizeof(float) * 3 * E + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann) + (E + 15) / 16 * 16;
-    const size_t lds = shared + kAssocWaves * assoc_private_bytes(K, A) + 16;
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+                        + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann + kAssocWaves) + 16;
+    const size_t priv = assoc_private_bytes(K, A);
+    const size_t budget = 160 * 1024;
+    if (shared + priv > budget) return hipErrorInvalidValue;
+    int growers = (int)((budget - shared) / priv);
+    if (growers > kAssocWaves) growers = kAssocWaves;
+    const size_t lds = shared + (size_t)growers * priv;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)cifcaf_assoc_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    cifcaf_assoc_kernel<<<a.B, kAssocThreads, lds, st>>>(a, sk, p);
+    cifcaf_assoc_kernel<<<a.B, kAssocThreads, lds, st>>>(a, sk, p, growers);
     prof_mark(st, "cifcaf_assoc_kernel");
     return hipGetLastError();
 }
