@@ -43,7 +43,7 @@ namespace opa {
 
 constexpr int kAssocWaves = 8;
 constexpr int kAssocThreads = kAssocWaves * kWave;
-constexpr int kBlendChunks = 4;        // list entries per lane held in registers by the single-pass scan
+constexpr int kBlendChunks = 8;        // list entries per lane held in registers by the single-pass scan
 
 // Optional phase timers (build with -DOPA_ASSOC_TIMING; tools/assoc_timing.py reads them).
 #ifdef OPA_ASSOC_TIMING
@@ -288,6 +288,7 @@ __device__ __forceinline__ BlendResult blend_impl(const float* base, int cap, in
     const BlendQuery q = make_query(x, y, xy_scale, filter_sigmas);
     if (n <= kWave) return blend_cached<1>(L, q, only_max != 0);
     if (n <= 2 * kWave) return blend_cached<2>(L, q, only_max != 0);
+    if (n <= 4 * kWave) return blend_cached<4>(L, q, only_max != 0);
     if (n <= kBlendChunks * kWave) return blend_cached<kBlendChunks>(L, q, only_max != 0);
     return blend_streamed(L, q, only_max != 0);
 }
