@@ -111,29 +111,32 @@ def cpu_baseline(cifs, cafs, skeleton0, seconds):
     single = done / (time.perf_counter() - t0)
 
     # all host cores: the reference's --decoder-workers mechanism is a fork pool
-    # (reference decoder/decoder.py:33-47,130-131); N = os.cpu_count()
+    # (reference decoder/decoder.py:33-47,130-131); N = os.cpu_count().  Time-bounded.
     cores = os.cpu_count() or 1
     multi = None
     try:
         import multiprocessing as mp
         ctx = mp.get_context('fork')
-        per_worker = max(4, int(single * seconds * 0.4))
+        budget = max(3.0, 0.6 * seconds)
 
-        def work(i, q):
+        def work(i, q, t_end):
             if torch_ is not None:
                 torch_.set_num_threads(1)
-            t = time.perf_counter()
-            for k in range(per_worker):
+            k = 0
+            while time.perf_counter() < t_end or k == 0:
                 decode(cifs[(i + k) % n], cafs[(i + k) % n])
-            q.put(time.perf_counter() - t)
+                k += 1
+            q.put((k, time.perf_counter()))
         q = ctx.Queue()
-        procs = [ctx.Process(target=work, args=(i, q)) for i in range(cores)]
         t0 = time.perf_counter()
+        t_end = t0 + budget
+        procs = [ctx.Process(target=work, args=(i, q, t_end)) for i in range(cores)]
         for pr in procs:
             pr.start()
+        results = [q.get() for _ in procs]
         for pr in procs:
             pr.join()
-        multi = cores * per_worker / (time.perf_counter() - t0)
+        multi = sum(k for k, _ in results) / (max(t for _, t in results) - t0)
     except Exception as e:   # pragma: no cover
         multi = None
         print('cpu_baseline: multi-process leg failed: %r' % (e,), file=sys.stderr)
@@ -141,7 +144,7 @@ def cpu_baseline(cifs, cafs, skeleton0, seconds):
         'value': round(single, 2), 'unit': 'images/s (decode only, 1 thread)', 'cores': 1, 'kind': kind,
         'all_cores_value': round(multi, 2) if multi else None, 'all_cores': cores,
         'sample': '%d decodes of the rank-0 batch fields (fresh decoder per image), single thread; '
-                  'then %d forked workers' % (done, cores),
+                  'then %d forked single-thread workers for a fixed time budget' % (done, cores),
     }
 
 

@@ -16,6 +16,8 @@ def find(sub, pattern):
 
 def short(name):
     name = name.split('(')[0]
+    if name.startswith('void opa::'):
+        name = name[5:]
     return name if len(name) < 90 else name[:87] + '...'
 
 
@@ -98,3 +100,17 @@ for k in sorted(set(fetch) | set(write)):
         continue
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     print('| `%s` | %.1f | %.2f | %.1f | %.2f |' % (k, f, 2 * f * 1024 / 1e6, w, w * 1024 / 1e6))
+
+# machine-readable PMC traffic for bench.py's roofline.traffic
+import json
+out = {'batch': 32, 'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --decode-only, per launch; '
+       'units KiB of TCC_EA requests; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 x2 read correction '
+       'of MI355X_MICROARCH.md (calibrated for 16-B/lane streams only; 4-B/lane reads are uncalibrated)', 'kernels': {}}
+for k in sorted(set(fetch) | set(write)):
+    if not k.startswith('opa::'):
+        continue
+    name = k.split('::')[1].split('<')[0]
+    out['kernels'][name] = {'FETCH_SIZE': round(fetch.get(k, 0.0), 1), 'WRITE_SIZE': round(write.get(k, 0.0), 1),
+                            'hbm_bytes': int((2 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024)}
+if out['kernels']:
+    json.dump(out, open(os.path.join(root, 'pmc_traffic.json'), 'w'), indent=1)
