@@ -215,6 +215,13 @@ int opa_cifdet_decode(const opa_det_shape* shape, const opa_params* params, cons
 int opa_bias_act(void* x_dev, const void* bias_dev, const void* residual_dev,
                  int64_t rows, int32_t channels, int32_t dtype, int32_t relu, void* stream);
 
+/* 1x1 convolution as an MFMA GEMM with the epilogue fused (bfloat16 in/out, f32 accumulate):
+ *     out[M,N] = act(A[M,K] * W[N,K]^T + bias[N] (+ residual[M,N]))
+ * A = NHWC activation viewed as [B*H*W, C_in], W = conv weight [C_out, C_in].  K % 64 == 0,
+ * N % 64 == 0, all pointers 16-B aligned; residual may be NULL. */
+int opa_gemm_bias_act_bf16(const void* a_dev, const void* w_dev, const void* bias_dev, const void* residual_dev,
+                           void* out_dev, int64_t m, int32_t n, int32_t k, int32_t relu, void* stream);
+
 /* ---- measurement -------------------------------------------------------- */
 /* Per-kernel timing with HIP events on the launch stream (no reference
  * counterpart; bench.py's roofline leg uses it).  Between opa_profile_begin and

@@ -105,6 +105,9 @@ hipError_t launch_cifdet_collect(const DetArgs& a, const DevParams& p, hipStream
 hipError_t launch_bias_act(void* x, const void* bias, const void* res, long long rows, int channels, int dtype,
                            int relu, hipStream_t st);
 
+hipError_t launch_gemm_bias_act(const void* A, const void* W, const void* bias, const void* res, void* out,
+                                int M, int N, int K, int relu, hipStream_t st);
+
 hipError_t launch_blend(const float* rows, int n, double x, double y, double s, double filter_sigmas,
                         int only_max, double* out4_dev, hipStream_t st);
 

@@ -61,9 +61,9 @@ class _Bottleneck(nn.Module):
     def forward(self, x):
         if self.fused:      # conv (no bias) -> ONE fused bias(+residual)+ReLU pass each
             identity = x if self.downsample is None else self.downsample[0](x)
-            out = fused.bias_act_(self.conv1(x), self.fb1)
-            out = fused.bias_act_(self.conv2(out), self.fb2)
-            return fused.bias_act_(self.conv3(out), self.fb3, identity)
+            out = fused.conv_bias_act(self.conv1, x, self.fb1)            # 1x1: fused MFMA GEMM
+            out = fused.conv_bias_act(self.conv2, out, self.fb2)          # 3x3: MIOpen + fused epilogue
+            return fused.conv_bias_act(self.conv3, out, self.fb3, identity)
         identity = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))

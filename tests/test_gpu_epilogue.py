@@ -42,3 +42,45 @@ def test_resnet_fused_forward_equals_unfused_on_gpu():
         b = net(x)
     for u, v in zip(a, b):
         assert float((u - v).abs().max()) < 2e-3
+
+
+@pytest.mark.parametrize('cin,cout,hw,with_res', [(64, 256, 37, True), (256, 64, 41, False), (128, 512, 19, True),
+                                                  (2048, 512, 9, False), (64, 64, 23, False)])
+def test_fused_conv1x1_gemm_matches_fp32_reference(cin, cout, hw, with_res):
+    from openpifpaf_amd import fused
+    torch.manual_seed(1)
+    B = 3                                   # M = 3*hw*hw is not a multiple of the 128-row tile
+    x = (torch.randn(B, cin, hw, hw, device='cuda') * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w4 = (torch.randn(cout, cin, 1, 1, device='cuda') / cin ** 0.5).to(torch.bfloat16)
+    b = torch.randn(cout, device='cuda').to(torch.bfloat16)
+    r = torch.randn(B, cout, hw, hw, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last) \
+        if with_res else None
+    ref = torch.nn.functional.conv2d(x.float(), w4.float(), b.float())
+    if with_res:
+        ref = ref + r.float()
+    for relu in (True, False):
+        want = ref.clamp_min(0) if relu else ref
+        got = fused.conv1x1_bias_act(x, w4.reshape(cout, cin).contiguous(), b, r, relu)
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        err = (got.float() - want).abs()
+        tol = 2.0 ** -7 * want.abs().clamp_min(1.0)          # bf16 output rounding (8 bits of mantissa)
+        assert bool((err <= tol).all()), float(err.max())
+
+
+def test_resnet50_fused_gemm_forward_close_to_unfused():
+    from openpifpaf_amd import network
+    net = network.factory('resnet50').cuda()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    x = torch.randn((2, 3, 161, 193), device='cuda')
+    with torch.no_grad():
+        want = net(x)
+        network.optimize_for_inference_(net)
+        net = net.to(memory_format=torch.channels_last).to(torch.bfloat16)
+        got = net(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    for u, v in zip(got, want):
+        assert u.shape == v.shape and u.dtype == torch.float32
+        # bf16 network vs fp32 network: only a sanity bound (confidences are in [0,1])
+        assert float((u[:, :, 1] - v[:, :, 1]).abs().mean()) < 0.05
