@@ -34,7 +34,7 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {
 }
 
 template <int BN, bool RES, bool RELU>
-__global__ __launch_bounds__(256) void gemm_bias_act_kernel(
+__global__ __launch_bounds__(256, 3) void gemm_bias_act_kernel(
         const unsigned short* __restrict__ A, const unsigned short* __restrict__ W,
         const unsigned short* __restrict__ bias, const unsigned short* __restrict__ res,
         unsigned short* __restrict__ out, int M, int N, int K) {
@@ -50,8 +50,14 @@ __global__ __launch_bounds__(256) void gemm_bias_act_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int n_tiles = N / BN;
-    const int m0 = (int)(blockIdx.x / n_tiles) * kGemmBM;
-    const int n0 = (int)(blockIdx.x % n_tiles) * BN;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (each XCD has its own L2).  Give every XCD
+    // a contiguous range of logical tile ids so that the N-tiles sharing one A row-block are
+    // neighbours in time on ONE L2 instead of being fetched by eight (bijective for any grid size).
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3;
+    const unsigned q = nwg >> 3, r8 = nwg & 7u;
+    const unsigned logical = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + in_xcd;
+    const int m0 = (int)(logical / n_tiles) * kGemmBM;
+    const int n0 = (int)(logical % n_tiles) * BN;
 
     f32x16_t acc[2][NT];
 #pragma unroll
@@ -60,6 +66,24 @@ __global__ __launch_bounds__(256) void gemm_bias_act_kernel(
         for (int j = 0; j < NT; j++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    // The residual tile does not depend on the product: fetch this lane's share (the vectors it
+    // will combine in the epilogue) before anything else so that its HBM latency hides behind the
+    // operand loads and the MFMAs.
+    constexpr int VEC_PER_ROW = WN / 8;        // 16-B output vectors per patch row
+    constexpr int VPL = 32 * VEC_PER_ROW / 64; // epilogue vectors per lane and 32-row block
+    u32x4_t rpre[2][VPL];
+    auto fetch_residual = [&](int i) {
+#pragma unroll
+        for (int t = 0; t < VPL; t++) {
+            const int v = t * 64 + lane;
+            const int row = v / VEC_PER_ROW, c8 = (v % VEC_PER_ROW) * 8;
+            const int m = m0 + wm * 64 + i * 32 + row;
+            rpre[i][t] = (u32x4_t){0u, 0u, 0u, 0u};
+            if (m < M) rpre[i][t] = *reinterpret_cast<const u32x4_t*>(res + (size_t)m * N + n0 + wn * WN + c8);
+        }
+    };
+    if (RES) fetch_residual(0);                // the second half is fetched when the operand registers are free
 
     // staging map: a 64-wide bf16 row is 8 x 16 B; 256 threads cover 32 rows per pass
     const int s_row = tid >> 3, s_col = (tid & 7) * 8;
@@ -100,10 +124,10 @@ __global__ __launch_bounds__(256) void gemm_bias_act_kernel(
         }
     }
     __syncthreads();                           // staging LDS is free: reuse it for the epilogue
+    if (RES) fetch_residual(1);
 
     // epilogue, one 32-row block of the wave tile at a time through a wave-private f32 patch
     float* patch = reinterpret_cast<float*>(smem) + wave * (32 * WN);
-    constexpr int VEC_PER_ROW = WN / 8;        // 16-B output vectors per patch row
 #pragma unroll
     for (int i = 0; i < 2; i++) {
 #pragma unroll
@@ -118,7 +142,9 @@ __global__ __launch_bounds__(256) void gemm_bias_act_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int v = lane; v < 32 * VEC_PER_ROW; v += 64) {
+#pragma unroll
+        for (int t = 0; t < VPL; t++) {
+            const int v = t * 64 + lane;
             const int row = v / VEC_PER_ROW, c8 = (v % VEC_PER_ROW) * 8;
             const int m = m0 + wm * 64 + i * 32 + row;
             if (m < M) {
@@ -127,7 +153,7 @@ __global__ __launch_bounds__(256) void gemm_bias_act_kernel(
                 const float4 hi = *reinterpret_cast<const float4*>(patch + row * WN + c8 + 4);
                 float f[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
                 if (RES) {
-                    const u32x4_t rv = *reinterpret_cast<const u32x4_t*>(res + g);
+                    const u32x4_t rv = rpre[i][t];
 #pragma unroll
                     for (int q = 0; q < 4; q++) { f[2 * q] += bf16_lo(rv[q]); f[2 * q + 1] += bf16_hi(rv[q]); }
                 }
