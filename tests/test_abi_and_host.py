@@ -177,3 +177,22 @@ def test_synth_is_deterministic_and_shaped():
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     cifs, cafs = synth.synth_batch(3, seed0=9, height=21, width=21)
     assert cifs.shape == (3, 17, 5, 21, 21) and cafs.dtype == np.float32
+
+
+def test_register_replaces_cifcaf_in_a_host_openpifpaf(monkeypatch):
+    import sys
+    import types
+    import openpifpaf_amd
+    from openpifpaf_amd import decoder
+
+    class OldCifCaf:
+        pass
+    OldCifCaf.__name__ = 'CifCaf'
+
+    class CifDetHost:
+        pass
+    host = types.ModuleType('openpifpaf')
+    host.DECODERS = {OldCifCaf, CifDetHost}
+    monkeypatch.setitem(sys.modules, 'openpifpaf', host)
+    openpifpaf_amd.register()
+    assert decoder.CifCaf in host.DECODERS and OldCifCaf not in host.DECODERS and CifDetHost in host.DECODERS

@@ -1,0 +1,60 @@
+"""Host-side API on the GPU: Predictor / Decoder.batch keep the fields on the device and
+return the same annotations as decoding the same head outputs image by image with the oracle."""
+import sys
+import types
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+def test_decoder_batch_equals_oracle_on_model_fields(coco_skeleton0):
+    """decoder.CifCaf.batch(model, images): fields never leave the device; results must equal the
+    oracle's decode of the very same head outputs."""
+    from openpifpaf_amd import decoder, headmeta, synth
+    from oracle import port
+    cifs, cafs = synth.synth_batch(4, seed0=700, height=41, width=41, people=(2, 4), size_range=(0.6, 0.95))
+
+    class FieldModel:                       # stands in for a trained Shell: emits known fields
+        def __call__(self, images):
+            return (torch.from_numpy(cifs).cuda(), torch.from_numpy(cafs).cuda())
+
+    metas = headmeta.cocokp_metas()
+    dec = decoder.factory(list(metas))
+    assert isinstance(dec, decoder.Multi) and isinstance(dec.decoders[0], decoder.CifCaf)
+    images = torch.zeros((4, 3, 321, 321))
+    result = dec.batch(FieldModel(), images, device=torch.device('cuda'))
+    assert len(result) == 4 and dec.last_decoder_time > 0 and dec.last_nn_time >= 0
+    for b in range(4):
+        want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)
+        assert len(result[b]) == len(want) >= 1
+        for ann, w in zip(result[b], want):
+            assert np.allclose(ann.data[:, 0], w[:, 1], atol=1e-4) and np.allclose(ann.data[:, 1], w[:, 2], atol=1e-4)
+            assert np.allclose(ann.data[:, 2], w[:, 0], atol=1e-4) and np.allclose(ann.joint_scales, w[:, 3], atol=1e-4)
+    # single-image entry point, fields as a per-image list like the reference's Decoder.__call__
+    anns = dec([torch.from_numpy(cifs[1]).cuda(), torch.from_numpy(cafs[1]).cuda()])
+    assert len(anns) == len(result[1])
+
+
+def test_predictor_end_to_end_smoke():
+    """Random-init network: nothing to compare against, but the whole chain must run on the device
+    (preprocess -> backbone -> heads -> HIP decode -> Annotation objects / JSON)."""
+    from openpifpaf_amd import Predictor
+    Predictor.long_edge = 321
+    Predictor.batch_size = 2
+    try:
+        pred = Predictor('resnet18', json_data=True)
+        rng = np.random.default_rng(0)
+        images = [(rng.random((240, 320, 3)) * 255).astype(np.uint8) for _ in range(3)]
+        out = list(pred.numpy_images(images))
+        assert len(out) == 3
+        for anns, _, meta in out:
+            assert isinstance(anns, list) and 'offset' in meta
+            for a in anns:
+                assert set(a) >= {'keypoints', 'bbox', 'score', 'category_id'}
+        assert pred.total_images == 3 and pred.total_decoder_time > 0
+    finally:
+        Predictor.long_edge = None
+        Predictor.batch_size = 1
