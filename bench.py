@@ -58,6 +58,11 @@ def parse_args():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--decode-only', action='store_true', help='skip the backbone (kernel work only)')
     p.add_argument('--profile-steps', type=int, default=5)
+    p.add_argument('--force-complete', action='store_true',
+                   help='decode like the reference\'s benchmark CLI (--force-complete-pose, thresholds 0)')
+    p.add_argument('--fields', default='synthetic', choices=('synthetic', 'network'),
+                   help='decode COCO-shaped synthetic fields injected after the heads (default), or the '
+                        'random-init network\'s own all-active head outputs (adversarial case, reported separately)')
     p.add_argument('--dist-backend', default='nccl', choices=('nccl', 'gloo'),
                    help='nccl = RCCL over xGMI (default); gloo only to exercise the N>1 control flow on one GPU')
     p.add_argument('--share-device', action='store_true', help='testing: every rank uses cuda:0')
@@ -80,17 +85,21 @@ def algorithmic_bytes(B, F, A, H, W, stride, max_ann):
     }
 
 
-def cpu_baseline(cifs, cafs, skeleton0, seconds):
+def cpu_baseline(cifs, cafs, skeleton0, seconds, fc_kw=None):
     """The reference's own C++ decoder (oracle/_ref) on host cores: 1 thread and all cores."""
     from oracle import reference
     if not reference.available():
         from oracle import port
-        kind, decode = 'port', lambda c, f: port.decode(c, 8, f, 8, skeleton0)
+        port_params = port.default_params(**(fc_kw or {}))
+        kind, decode = 'port', lambda c, f: port.decode(c, 8, f, 8, skeleton0, params=port_params)
         torch_ = None
     else:
         torch_ = reference.load()
         torch_.set_num_threads(1)
         reference.reset_statics()
+        if fc_kw:
+            from oracle import port
+            reference.apply_params(port.default_params(**fc_kw))
         kind = 'reference'
         skel_t = torch_.as_tensor(skeleton0, dtype=torch_.int64)
 
@@ -196,6 +205,9 @@ def main():
     caf_syn = torch.from_numpy(cafs_np).to(device)
     stride = cif_meta.stride
 
+    fc_kw = dict(force_complete=1, keypoint_threshold=0.0, keypoint_threshold_rel=0.0,
+                 nms_instance_threshold=0.0, nms_keypoint_threshold=0.0)     # reference decoder/cifcaf.py:180-185
+    dec_params = _lib.default_params(**fc_kw) if args.force_complete else None
     dec = native.CifCaf(17, torch.from_numpy(skeleton0))
     K = 17
     host_out = torch.empty((B, dec.max_annotations, K, 4), dtype=torch.float32).pin_memory()
@@ -207,6 +219,7 @@ def main():
     shapes_checked = [False]
 
     def step():
+        heads = None
         if model is not None:
             with torch.no_grad():
                 heads = model(images)
@@ -218,7 +231,10 @@ def main():
         ev.record(main_stream)
         with torch.cuda.stream(dec_stream):
             dec_stream.wait_event(ev)                  # decode of batch i follows its backbone
-            out, ids, counts = dec.call_batch(cif_syn, stride, caf_syn, stride)
+            if args.fields == 'network' and model is not None:
+                out, ids, counts = dec.call_batch(heads[0], stride, heads[1], stride, params=dec_params)
+            else:
+                out, ids, counts = dec.call_batch(cif_syn, stride, caf_syn, stride, params=dec_params)
             if world > 1:                              # final annotations only, over xGMI (RCCL)
                 if args.dist_backend == 'nccl':
                     distributed.gather_annotations(out, ids, counts)
@@ -260,7 +276,7 @@ def main():
         with torch.cuda.stream(dec_stream):
             for _ in range(max(1, args.profile_steps)):
                 _lib.profile_begin(native._stream())
-                dec.call_batch(cif_syn, stride, caf_syn, stride)
+                dec.call_batch(cif_syn, stride, caf_syn, stride, params=dec_params)
                 for name, ms in _lib.profile_end():
                     per_kernel.setdefault(name, []).append(ms)
         avg_ms = {k: float(np.mean(v)) for k, v in per_kernel.items()}
@@ -293,7 +309,7 @@ def main():
         }
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(cifs_np, cafs_np, skeleton0, args.cpu_seconds)
+            cpu = cpu_baseline(cifs_np, cafs_np, skeleton0, args.cpu_seconds, fc_kw if args.force_complete else None)
         value = world * B * args.steps / elapsed
         result = {
             'metric': 'images/sec end-to-end (backbone+CifCaf decode), resnet50 641px',
@@ -307,11 +323,14 @@ def main():
                                                                  B, B, fh, fh, B, fh, fh),
                 'backbone': 'none (decode only)' if model is None else args.backbone,
                 'backbone_dtype': args.backbone_dtype, 'decode_dtype': 'f32 (+f64 where the reference uses double)',
-                'global_batch': world * B, 'fields': 'COCO-shaped synthetic fields injected after the heads '
-                                                    '(people per image cycle %s)' % (list(synth.PEOPLE_CYCLE),),
+                'global_batch': world * B,
+                'fields': ('COCO-shaped synthetic fields injected after the heads (people per image cycle %s)'
+                           % (list(synth.PEOPLE_CYCLE),)) if args.fields == 'synthetic' else
+                          'the random-init network\'s own head outputs (all-active adversarial case)',
                 'parallelism': 'images sharded one batch per GPU (dp%d); RCCL all_gather of annotations' % world
                                if world > 1 else 'single GPU',
                 'decode_overlapped_on_second_stream': not args.no_overlap,
+                'force_complete_pose': bool(args.force_complete),
                 'annotations_per_batch': n_ann,
             },
             'roofline': roofline,

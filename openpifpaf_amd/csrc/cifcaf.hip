@@ -247,35 +247,64 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
     return blend_finish(s1, s2, have2, only_max, e1x, e1y, e1s, e2x, e2y, e2s);
 }
 
-// Any list length: two passes over the list (scores recomputed in pass 2).
+// Any list length (force-complete lists at caf_th 0.001 and all-active fields hold thousands of
+// entries): two passes over the list, each in groups of 8 chunks whose loads are issued together
+// and pinned like in blend_cached, so a pass costs one memory round trip per 512 entries instead of
+// one per 64.  Scores are recomputed in pass 2.
 __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const BlendQuery& q, bool only_max) {
+    constexpr int G = 8;
     const int lane = lane_id();
+    const gfloat* g = (const gfloat*)L.base;
     float s1 = 0.0f; int i1 = -1;
-    for (int i = lane; i < L.n; i += kWave) {
-        const float x1 = L.base[1 * L.cap + i], y1 = L.base[2 * L.cap + i];
-        if (!passes(q, x1, y1)) continue;
-        const float sc = score_of(q, x1, y1, L.base[i]);
-        if (sc >= s1) { s1 = sc; i1 = i; }
+    for (int base = 0; base < L.n; base += G * kWave) {
+        float x1[G], y1[G], cc[G];
+#pragma unroll
+        for (int r = 0; r < G; r++) {
+            const int i = base + r * kWave + lane;
+            const int ii = i < L.n ? i : 0;
+            x1[r] = g[1 * L.cap + ii]; y1[r] = g[2 * L.cap + ii]; cc[r] = g[ii];
+        }
+#pragma unroll
+        for (int r = 0; r < G; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
+#pragma unroll
+        for (int r = 0; r < G; r++) {
+            const int i = base + r * kWave + lane;
+            if (i < L.n && passes(q, x1[r], y1[r])) {
+                const float sc = score_of(q, x1[r], y1[r], cc[r]);
+                if (sc >= s1) { s1 = sc; i1 = i; }
+            }
+        }
     }
     reduce_first(s1, i1);
     if (s1 == 0.0f || i1 < 0) return blend_none();             // :76
     float s2 = 0.0f; int r2 = -1;
     if (!only_max) {
-        for (int i = lane; i < L.n; i += kWave) {
-            if (i == i1) continue;
-            const float x1 = L.base[1 * L.cap + i], y1 = L.base[2 * L.cap + i];
-            if (!passes(q, x1, y1)) continue;
-            const float sc = score_of(q, x1, y1, L.base[i]);
-            if (!(sc > 0.0f)) continue;
-            const int rank = i < i1 ? L.n + i : L.n - i;
-            if (sc > s2 || (sc == s2 && rank > r2)) { s2 = sc; r2 = rank; }
+        for (int base = 0; base < L.n; base += G * kWave) {
+            float x1[G], y1[G], cc[G];
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+                const int i = base + r * kWave + lane;
+                const int ii = i < L.n ? i : 0;
+                x1[r] = g[1 * L.cap + ii]; y1[r] = g[2 * L.cap + ii]; cc[r] = g[ii];
+            }
+#pragma unroll
+            for (int r = 0; r < G; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+                const int i = base + r * kWave + lane;
+                if (i >= L.n || i == i1 || !passes(q, x1[r], y1[r])) continue;
+                const float sc = score_of(q, x1[r], y1[r], cc[r]);
+                if (!(sc > 0.0f)) continue;
+                const int rank = i < i1 ? L.n + i : L.n - i;
+                if (sc > s2 || (sc == s2 && rank > r2)) { s2 = sc; r2 = rank; }
+            }
         }
         reduce_second(s2, r2);
     }
     const bool have2 = r2 >= 0;
     const int i2 = have2 ? (r2 >= L.n ? r2 - L.n : L.n - r2) : i1;
-    const float e1x = L.base[3 * L.cap + i1], e1y = L.base[4 * L.cap + i1], e1s = L.base[6 * L.cap + i1];
-    const float e2x = L.base[3 * L.cap + i2], e2y = L.base[4 * L.cap + i2], e2s = L.base[6 * L.cap + i2];
+    const float e1x = g[3 * L.cap + i1], e1y = g[4 * L.cap + i1], e1s = g[6 * L.cap + i1];
+    const float e2x = g[3 * L.cap + i2], e2y = g[4 * L.cap + i2], e2s = g[6 * L.cap + i2];
     return blend_finish(s1, s2, have2, only_max, e1x, e1y, e1s, e2x, e2y, e2s);
 }
 

@@ -355,3 +355,30 @@ def test_full_size_batch_properties(native, port, coco_skeleton0):
         want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)
         ok, msg = compare_annotations(o[b, :c[b]], want)
         assert ok, 'image %d: %s' % (b, msg)
+
+
+def test_repeatability_and_wide_oracle_sweep(native, port, coco_skeleton0):
+    """Race screen for the speculative multi-wave association kernel: 48 different images, every
+    one against the oracle, and 10 repeated launches must return identical bits."""
+    from openpifpaf_amd import synth
+    B = 48
+    people = (1, 2, 4, 6, 9, 12, 16, 24)
+    cifs, cafs = synth.synth_batch(B, seed0=900, people=people)
+    cif_d, caf_d = dev(cifs), dev(cafs)
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    first = None
+    for rep in range(10):
+        out, ids, cnt = dec.call_batch(cif_d, 8, caf_d, 8)
+        cur = (out.clone(), cnt.clone())
+        if first is None:
+            first = cur
+        else:
+            assert torch.equal(cur[1], first[1]), 'repeat %d: counts differ' % rep
+            for b in range(B):
+                n = int(cur[1][b])
+                assert torch.equal(cur[0][b, :n], first[0][b, :n]), 'repeat %d image %d differs' % (rep, b)
+    o, c = first[0].cpu().numpy(), first[1].cpu().numpy()
+    for b in range(B):
+        want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)
+        ok, msg = compare_annotations(o[b, :c[b]], want)
+        assert ok, 'image %d (%d people): %s' % (b, people[b % len(people)], msg)
