@@ -382,3 +382,33 @@ def test_repeatability_and_wide_oracle_sweep(native, port, coco_skeleton0):
         want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)
         ok, msg = compare_annotations(o[b, :c[b]], want)
         assert ok, 'image %d (%d people): %s' % (b, people[b % len(people)], msg)
+
+
+@pytest.mark.parametrize('cif_stride,caf_stride', [(12, 12), (4, 4), (16, 16)])
+def test_decode_other_strides(native, port, coco_skeleton0, cif_stride, caf_stride):
+    """Non-power-of-two strides make every `value * stride` inexact: exercises the float/double
+    promotion order of every stage (the synthetic fields are in field units, so they decode at any stride)."""
+    cif, caf = fields(60 + cif_stride, 4, 41, 41)
+    ref_hr = port.cifhr_accumulate(cif, cif_stride)
+    hr = native.CifHr()
+    hr.accumulate(dev(cif), cif_stride)
+    assert np.array_equal(hr.get_accumulated()[0].cpu().numpy(), ref_hr)
+    want, _ = port.decode(cif, cif_stride, caf, caf_stride, coco_skeleton0)
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    got, _ = dec.call(dev(cif), cif_stride, dev(caf), caf_stride)
+    ok, msg = compare_annotations(got.cpu().numpy(), want)
+    assert ok, msg
+    assert len(want) >= 1
+
+
+def test_decode_different_cif_and_caf_geometry(native, port, coco_skeleton0):
+    """CAF head at half the CIF resolution (stride 16 vs 8): the reference allows it
+    (cifcaf.cpp:140-157 takes the two strides separately)."""
+    from openpifpaf_amd import synth
+    cif, _ = synth.synth_fields(77, 3, height=41, width=41, size_range=(0.6, 0.95))
+    _, caf16 = synth.synth_fields(77, 3, height=21, width=21, size_range=(0.6, 0.95))
+    want, _ = port.decode(cif, 8, caf16, 16, coco_skeleton0)
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    got, _ = dec.call(dev(cif), 8, dev(caf16), 16)
+    ok, msg = compare_annotations(got.cpu().numpy(), want)
+    assert ok, msg
