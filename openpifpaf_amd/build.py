@@ -38,5 +38,35 @@ def build_native(force=False, verbose=True):
     return OUT
 
 
+TORCH_SRC = os.path.join(CSRC, 'torch_binding.cpp')
+TORCH_OUT = os.path.join(HERE, 'lib', 'libopenpifpaf_amd_torch.so')
+
+
+def build_torch_binding(force=False, verbose=True):
+    """TorchScript custom-class binding (csrc/torch_binding.cpp): host C++ only, g++ against the
+    installed libtorch, linked to libopenpifpaf_amd.so next to it (rpath $ORIGIN)."""
+    build_native(force=False, verbose=verbose)
+    deps = [TORCH_SRC, OUT, os.path.join(HERE, '..', 'include', 'openpifpaf_amd.h')]
+    if not force and os.path.exists(TORCH_OUT) and \
+            all(os.path.getmtime(d) <= os.path.getmtime(TORCH_OUT) for d in deps):
+        return TORCH_OUT
+    import torch
+    from torch.utils import cpp_extension
+    inc = cpp_extension.include_paths() + ['/opt/rocm/include']
+    libdirs = cpp_extension.library_paths()
+    abi = int(torch._C._GLIBCXX_USE_CXX11_ABI)
+    cmd = (['g++', '-std=c++17', '-O2', '-fPIC', '-shared', '-w', '-D__HIP_PLATFORM_AMD__=1', '-DUSE_ROCM=1',
+            '-D_GLIBCXX_USE_CXX11_ABI=%d' % abi, '-DTORCH_API_INCLUDE_EXTENSION_H']
+           + ['-I' + i for i in inc] + [TORCH_SRC, '-o', TORCH_OUT]
+           + ['-L' + os.path.dirname(OUT), '-lopenpifpaf_amd', '-Wl,-rpath,$ORIGIN']
+           + ['-L' + d for d in libdirs] + ['-Wl,-rpath,' + d for d in libdirs]
+           + ['-lc10', '-lc10_hip', '-ltorch_cpu', '-ltorch'])
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.check_call(cmd)
+    return TORCH_OUT
+
+
 if __name__ == '__main__':
     build_native(force=True)
+    build_torch_binding(force=True)

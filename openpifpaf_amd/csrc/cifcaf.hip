@@ -641,7 +641,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
         __syncthreads();
         for (int g = 0; g < S && n0 + g < a.n_initial; g++)
             accept_pose(g, a.initial_ids ? a.initial_ids[(size_t)b * a.n_initial + n0 + g] : -1);
-        __syncthreads();
+        sync_global();
     }
 
     // ---- seeds in score order, cifcaf.cpp:206-231, in speculative rounds
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
             const int sf = seed_f[si]; const float4 sd = seed_vxys[si];
             if (g > 0 && c.occ[occ_cell(c, p, sf, (double)sd.y, (double)sd.z)] != 0) continue;
             accept_pose(g, -1);
-            __syncthreads();                  // marks drained and visible before the next test
+            sync_global();                    // marks drained and visible before the next test
         }
         OPA_TACC(c.t[5], tm);
         // every seed up to the last candidate is decided; fewer than S candidates = all 1024 scanned
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
                 }
             }
         }
-        __syncthreads();
+        sync_global();
     }
 
     // ---- keypoint NMS, nms_keypoints.cpp:17-70
@@ -770,7 +770,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
                 if ((n_set++ % kAssocWaves) == wave) occ_set(c, p, kc * kWave + l, bx, by, bs, 2);   // :53
             }
         }
-        __syncthreads();
+        sync_global();                                   // marks visible to the next pose's tests
     }
     // suppression, keypoint threshold, instance threshold (:50,58-66); one thread per pose
     for (int r = tid; r < n_kept; r += kAssocThreads) {
@@ -785,7 +785,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
         }
         nms_score[r] = acc / (double)K;                  // indexed by sorted position r now
     }
-    __syncthreads();
+    sync_global();                                       // the rewritten confidences are read by other threads below
     for (int r = tid; r < n_kept; r += kAssocThreads) {  // final order (:69); ties keep the previous order
         const double sr = nms_score[r];
         int rank = -1;

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
         }
     } else {
         for (int t = n + tid; t < n_pad; t += 1024) K[t] = 0ull;
-        __syncthreads();
+        sync_global();                                              // keys travel through HBM between threads here
         for (int k = 2; k <= n_pad; k <<= 1) {
             int j = k >> 1;
             for (; j >= kSortLdsKeys; j >>= 1) {                    // far strides through L2
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
                     compare_exchange_desc(a, c, (i & k) == 0);
                     K[i] = a; K[p] = c;
                 }
-                __syncthreads();
+                sync_global();
             }
             for (int blk = 0; blk < n_pad; blk += kSortLdsKeys) {   // near strides inside LDS blocks
                 for (int t = tid; t < kSortLdsKeys; t += 1024) sk[t] = K[blk + t];
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
                     __syncthreads();
                 }
                 for (int t = tid; t < kSortLdsKeys; t += 1024) K[blk + t] = sk[t];
-                __syncthreads();
+                sync_global();
             }
         }
     }

@@ -117,6 +117,17 @@ hipError_t launch_blend(const float* rows, int n, double x, double y, double s, 
 #ifdef __HIPCC__
 namespace opa {
 
+// Workgroup barrier that also orders GLOBAL memory between the waves: the occupancy map and the
+// annotation scratch live in HBM and are written by one wave and read by the others.  A plain
+// __syncthreads() compiles to "s_waitcnt lgkmcnt(0); s_barrier" -- stores may still be in flight
+// when the barrier releases (observed: waves disagreeing on an occupancy test, then running one
+// barrier apart).  Release = wait for this wave's stores, acquire = drop stale L1 lines.
+__device__ __forceinline__ void sync_global() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
 __device__ __forceinline__ long long clampll(long long v, long long lo, long long hi) {
