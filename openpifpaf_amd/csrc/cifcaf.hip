@@ -5,19 +5,19 @@
 // _flood_fill (csrc/src/cifcaf.cpp:32-449), Occupancy (occupancy.cpp:13-79) and
 // NMSKeypoints::call (nms_keypoints.cpp:17-70).
 //
-// One 16-wave workgroup per image (images are the data-parallel unit; a batch fills the
+// One 8-wave workgroup per image (images are the data-parallel unit; a batch fills the
 // chip).  Per image the reference is one serial dependency chain -- seed k is skipped
 // iff an earlier pose occupies its cell -- but the GROWTH of a pose from a seed reads
 // only the CAF lists and the pose's own joints, never the occupancy map (cifcaf.cpp
 // :265-411).  So poses are grown SPECULATIVELY in parallel and only the accept/reject
 // decision is sequential:
 //
-//   round:  1024 sorted seeds are tested against the occupancy map at once (ballot);
+//   round:  512 sorted seeds are tested against the occupancy map at once (ballot);
 //           the first S live ones become candidates, one per wavefront;
 //           every wave grows its candidate's pose on its own (private LDS state, no
 //           barriers): best-first search with the reference's lazy frontier;
-//           resolve in seed order: candidate c is accepted iff its cell is still free
-//           after the poses accepted before it in this round were marked -- exactly the
+//           resolve in seed order: candidate c is accepted iff its cell is not inside a joint
+//           box of a pose accepted before it in this round (tested analytically) -- exactly the
 //           seeds the sequential loop would accept, with exactly the poses it would
 //           grow.  Seeds of the same person turn into discarded work, distinct persons
 //           into parallel speed-up (a 20-person image needs ~3 rounds instead of 20
@@ -31,8 +31,10 @@
 // std::priority_queue (sift-up on push, sift-to-leaf + sift-up on pop), because equal
 // priorities are the norm (all edges leaving one joint share the bound sqrt(v); every
 // flood-filled joint carries 1e-5) and the pop order decides results.
-// Occupancy boxes of an accepted pose and NMS boxes are dealt to the 16 waves;
-// force-complete growth and flood fill run one pose per wave.
+// Occupancy boxes of an accepted pose are dealt to the 8 waves; force-complete growth and flood
+// fill run one pose per wave; keypoint NMS needs no map at all (box containment per field, one
+// field per wave).  The occupancy map and the pose scratch are the only state in HBM that one wave
+// writes and another reads: those hand-overs go through sync_global() (common.hpp).
 //
 // Joint confidences are double like the reference's Joint struct; every
 // float/double promotion follows the reference operation by operation and the
@@ -471,39 +473,56 @@ __device__ __forceinline__ void flood_fill(ImageCtx& c) {
 }
 
 // ---------------------------------------------------------------- occupancy
-// occupancy.cpp:32-43 (byte map; `level`: 1 = association phase, 2 = NMS phase)
-__device__ __forceinline__ size_t occ_cell(const ImageCtx& c, const DevParams& p, int f, double x, double y) {
+// occupancy.cpp:32-43: the cell a query (x, y) falls into
+__device__ __forceinline__ void occ_xy(const ImageCtx& c, const DevParams& p, double x, double y, int* xi, int* yi) {
     if (p.occupancy_reduction != 1.0) { x /= p.occupancy_reduction; y /= p.occupancy_reduction; }
-    const long long xi = clampll(trunc_ll(x), 0, c.occ_w - 1);
-    const long long yi = clampll(trunc_ll(y), 0, c.occ_h - 1);
+    *xi = (int)clampll(trunc_ll(x), 0, c.occ_w - 1);
+    *yi = (int)clampll(trunc_ll(y), 0, c.occ_h - 1);
+}
+__device__ __forceinline__ size_t occ_cell(const ImageCtx& c, const DevParams& p, int f, double x, double y) {
+    int xi, yi;
+    occ_xy(c, p, x, y, &xi, &yi);
     return ((size_t)f * c.occ_h + yi) * c.occ_w + xi;
 }
 
-// occupancy.cpp:13-29, the 64 lanes of one wave cooperate on one box
-__device__ __forceinline__ void occ_set(const ImageCtx& c, const DevParams& p, int f, double x, double y, double sigma,
-                        unsigned char level) {
+// occupancy.cpp:13-29: the half-open cell box [minx,maxx) x [miny,maxy) a joint occupies.  Used both to
+// fill the byte map and to test containment analytically (in-round resolve, keypoint NMS), so the two
+// can never disagree.
+struct __attribute__((aligned(16))) OccBox { int minx, miny, maxx, maxy; };
+__device__ __forceinline__ OccBox occ_box(const ImageCtx& c, const DevParams& p, double x, double y, double sigma) {
     if (p.occupancy_reduction != 1.0) {
         x /= p.occupancy_reduction; y /= p.occupancy_reduction;
         sigma = fmax(p.occupancy_min_scale_reduced, sigma / p.occupancy_reduction);
     }
-    const int minx = (int)clampll(trunc_ll(x - sigma), 0, c.occ_w - 1);
-    const int miny = (int)clampll(trunc_ll(y - sigma), 0, c.occ_h - 1);
-    const int maxx = (int)clampll(trunc_ll(x + sigma), minx + 1, c.occ_w);
-    const int maxy = (int)clampll(trunc_ll(y + sigma), miny + 1, c.occ_h);
+    OccBox b;
+    b.minx = (int)clampll(trunc_ll(x - sigma), 0, c.occ_w - 1);
+    b.miny = (int)clampll(trunc_ll(y - sigma), 0, c.occ_h - 1);
+    b.maxx = (int)clampll(trunc_ll(x + sigma), b.minx + 1, c.occ_w);
+    b.maxy = (int)clampll(trunc_ll(y + sigma), b.miny + 1, c.occ_h);
+    return b;
+}
+__device__ __forceinline__ bool box_contains(const OccBox& b, int xi, int yi) {
+    return xi >= b.minx && xi < b.maxx && yi >= b.miny && yi < b.maxy;
+}
+
+// the 64 lanes of one wave fill one box of the byte map
+__device__ __forceinline__ void occ_set(const ImageCtx& c, const DevParams& p, int f, double x, double y, double sigma) {
+    const OccBox b = occ_box(c, p, x, y, sigma);
+    const int minx = b.minx, miny = b.miny, maxx = b.maxx, maxy = b.maxy;
     const int bw = maxx - minx;
     const int lane = lane_id();
     unsigned char* plane = c.occ + (size_t)f * c.occ_h * c.occ_w;
     if (bw <= 16) {                       // 4 rows x 16 columns per step
         const int lx = lane & 15, ly = lane >> 4;
         for (int yy = miny + ly; yy < maxy; yy += 4)
-            if (lx < bw) plane[(size_t)yy * c.occ_w + minx + lx] = level;
+            if (lx < bw) plane[(size_t)yy * c.occ_w + minx + lx] = 1;
     } else if (bw <= 32) {                // 2 rows x 32 columns per step
         const int lx = lane & 31, ly = lane >> 5;
         for (int yy = miny + ly; yy < maxy; yy += 2)
-            if (lx < bw) plane[(size_t)yy * c.occ_w + minx + lx] = level;
+            if (lx < bw) plane[(size_t)yy * c.occ_w + minx + lx] = 1;
     } else {
         for (int yy = miny; yy < maxy; yy++)
-            for (int xx = minx + lane; xx < maxx; xx += kWave) plane[(size_t)yy * c.occ_w + xx] = level;
+            for (int xx = minx + lane; xx < maxx; xx += kWave) plane[(size_t)yy * c.occ_w + xx] = 1;
     }
 }
 
@@ -513,6 +532,11 @@ __host__ __device__ inline size_t assoc_private_bytes(int K, int A) {
     const size_t b = sizeof(double) * (K + P4) + sizeof(unsigned long long) * P4 + sizeof(float) * (3 * K + 3 * P4)
                    + sizeof(int) * P4 + E;
     return (b + 15) / 16 * 16;
+}
+
+// LDS scratch of one wave during keypoint NMS (aliases the growth state): a box and a cell per pose
+__host__ __device__ inline size_t nms_scratch_bytes(int max_ann) {
+    return (sizeof(int) * 4 + sizeof(int) * 2) * (size_t)max_ann;
 }
 
 struct PoseView { const double* v; const float *x, *y, *s; };
@@ -531,7 +555,7 @@ __device__ __forceinline__ void mark_pose(const ImageCtx& c, const DevParams& p,
     int n = 0;
     for (int f = 0; f < c.F; f++) {
         if (q.v[f] == 0.0) continue;
-        if ((n++ % kAssocWaves) == c.wave) occ_set(c, p, f, (double)q.x[f], (double)q.y[f], (double)q.s[f], 1);
+        if ((n++ % kAssocWaves) == c.wave) occ_set(c, p, f, (double)q.x[f], (double)q.y[f], (double)q.s[f]);
     }
 }
 
@@ -573,8 +597,12 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     if ((K + 1) & 1) sp += sizeof(int);             // keep 8-byte alignment for what follows
     int* nms_order = (int*)sp; sp += sizeof(int) * a.max_ann;
     int* nms_rank = (int*)sp; sp += sizeof(int) * a.max_ann;
-    int* sh_cand = (int*)sp; sp += sizeof(int) * kAssocWaves;
-    unsigned char* private_base = sp;
+    int* sh_cand = (int*)sp; sp += sizeof(int) * kAssocWaves;             // candidate seed index, field, x, y
+    int* sh_cand_f = (int*)sp; sp += sizeof(int) * kAssocWaves;
+    float* sh_cand_x = (float*)sp; sp += sizeof(float) * kAssocWaves;
+    float* sh_cand_y = (float*)sp; sp += sizeof(float) * kAssocWaves;
+    sp = smem + (((size_t)(sp - smem) + 15) & ~(size_t)15);
+    unsigned char* private_base = sp;                // growth state; reused as NMS scratch once growth is over
     sp += (size_t)(wave < S ? wave : 0) * assoc_private_bytes(K, A);   // waves >= S never touch theirs
     c.jv = (double*)sp; sp += sizeof(double) * K;
     c.e_v = (double*)sp; sp += sizeof(double) * P4;
@@ -610,20 +638,21 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
 
     // Accept the pose grown by wave `g` (every wave executes this with the same arguments):
     // mark its joints (boxes dealt to the waves) and, unless it cannot survive NMS, store it.
-    auto accept_pose = [&](int g, long long id) {
+    // Returns 0 = marked only (pruned), 1 = stored at slot n_kept, 2 = capacity overflow.
+    auto accept_pose = [&](int g, long long id, int slot) -> int {
         const PoseView q = pose_of_wave(private_base, g, K, A);
         mark_pose(c, p, q);
-        if (prune && pose_score(q, K) < p.nms_instance_threshold) return;
-        if (n_kept >= a.max_ann) { n_dropped++; return; }
+        if (prune && pose_score(q, K) < p.nms_instance_threshold) return 0;
+        if (slot >= a.max_ann) return 2;
         if (wave == g) {
-            double* dst = anns + (size_t)n_kept * K * 4;
+            double* dst = anns + (size_t)slot * K * 4;
             for (int k = lane; k < K; k += kWave) {
                 dst[4 * k + 0] = q.v[k]; dst[4 * k + 1] = (double)q.x[k];
                 dst[4 * k + 2] = (double)q.y[k]; dst[4 * k + 3] = (double)q.s[k];
             }
-            if (lane == 0) ann_ids[n_kept] = id;
+            if (lane == 0) ann_ids[slot] = id;
         }
-        n_kept++;
+        return 1;
     };
 
     // ---- initial annotations (tracking API), cifcaf.cpp:177-202: S growths at a time
@@ -639,8 +668,10 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
             grow(c, p, true, 1.0);
         }
         __syncthreads();
-        for (int g = 0; g < S && n0 + g < a.n_initial; g++)
-            accept_pose(g, a.initial_ids ? a.initial_ids[(size_t)b * a.n_initial + n0 + g] : -1);
+        for (int g = 0; g < S && n0 + g < a.n_initial; g++) {
+            const int rc = accept_pose(g, a.initial_ids ? a.initial_ids[(size_t)b * a.n_initial + n0 + g] : -1, n_kept);
+            n_kept += rc == 1; n_dropped += rc == 2;
+        }
         sync_global();
     }
 
@@ -679,8 +710,8 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
         if (n_cand == 0) { pos += kAssocThreads; continue; }
         // 3. speculative growth, one pose per wave, no barriers inside
         if (mine >= 0) {
-            if (lane == 0) sh_cand[wave] = mine;
             const int sf = seed_f[mine]; const float4 sd = seed_vxys[mine];
+            if (lane == 0) { sh_cand[wave] = mine; sh_cand_f[wave] = sf; sh_cand_x[wave] = sd.y; sh_cand_y[wave] = sd.z; }
             for (int k = lane; k < K; k += kWave) { c.jv[k] = 0.0; c.jx[k] = 0.f; c.jy[k] = 0.f; c.js[k] = 0.f; }
             wave_sync();
             c.jv[sf] = (double)sd.x; c.jx[sf] = sd.y; c.jy[sf] = sd.z; c.js[sf] = sd.w;   // :213-218
@@ -688,17 +719,31 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
             OPA_T0(tg); grow(c, p, true, 1.0); OPA_TACC(c.t[4], tg);
         }
         __syncthreads();
-        // 4. resolve in seed order: accept candidate g iff its cell is still free (:211 at its turn)
+        // 4. resolve in seed order: candidate g is accepted iff its cell is still free at its turn (:211).
+        //    It was free when the round started, so only the poses accepted before it IN THIS ROUND can
+        //    have taken it: test their joint boxes analytically (LDS only, every wave computes the same
+        //    mask), then write all marks of the round and synchronise global memory once.
         OPA_T0(tm);
-        int last = pos;
-        for (int g = 0; g < n_cand; g++) {
-            const int si = sh_cand[g];
-            last = si;
-            const int sf = seed_f[si]; const float4 sd = seed_vxys[si];
-            if (g > 0 && c.occ[occ_cell(c, p, sf, (double)sd.y, (double)sd.z)] != 0) continue;
-            accept_pose(g, -1);
-            sync_global();                    // marks drained and visible before the next test
+        unsigned acc_mask = 1u;
+        for (int g = 1; g < n_cand; g++) {
+            const int sf = sh_cand_f[g];
+            int xi, yi;
+            occ_xy(c, p, (double)sh_cand_x[g], (double)sh_cand_y[g], &xi, &yi);
+            bool cover = false;
+            if (lane < g && ((acc_mask >> lane) & 1u)) {
+                const PoseView q = pose_of_wave(private_base, lane, K, A);
+                if (q.v[sf] != 0.0)
+                    cover = box_contains(occ_box(c, p, (double)q.x[sf], (double)q.y[sf], (double)q.s[sf]), xi, yi);
+            }
+            if (__ballot(cover) == 0ull) acc_mask |= 1u << g;
         }
+        for (int g = 0; g < n_cand; g++)
+            if ((acc_mask >> g) & 1u) {
+                const int rc = accept_pose(g, -1, n_kept);
+                n_kept += rc == 1; n_dropped += rc == 2;
+            }
+        const int last = sh_cand[n_cand - 1];
+        sync_global();                        // marks and stored poses visible to every wave
         OPA_TACC(c.t[5], tm);
         // every seed up to the last candidate is decided; fewer than S candidates = all 1024 scanned
         pos = (n_cand == S) ? last + 1 : pos + kAssocThreads;
@@ -745,33 +790,47 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
         int rank = 0;
         for (int m = 0; m < n_kept; m++) { const double sm = nms_score[m]; rank += (sm > sn || (sm == sn && m < n)) ? 1 : 0; }
         nms_order[rank] = n;
+        for (int kc = 0; kc < KC; kc++) nms_supp[n * KC + kc] = 0ull;
     }
     __syncthreads();
-    for (int r = 0; r < n_kept; r++) {                   // serial over poses; joints in parallel
-        const double* pose = anns + (size_t)nms_order[r] * K * 4;
-        int n_set = 0;
-        for (int kc = 0; kc < KC; kc++) {                // K is also the number of occupancy fields
-            const int k = kc * kWave + lane;
-            bool need_set = false, suppressed = false; double x = 0.0, y = 0.0, s = 0.0;
-            if (k < K) {
-                const double v = pose[4 * k]; x = pose[4 * k + 1]; y = pose[4 * k + 2]; s = pose[4 * k + 3];
-                if (v != 0.0) {
-                    if (c.occ[occ_cell(c, p, k, x, y)] >= 2) suppressed = true;         // :50-51
-                    else need_set = true;
+    // Occupancy pass (:27-43) without a map: joints of different fields never interact, so wave w takes
+    // fields w, w+8, ...; per field the poses are visited in score order and pose r's joint is suppressed
+    // iff its cell lies in the box of an earlier, still unsuppressed joint (= Occupancy::get after the
+    // earlier Occupancy::set calls).  Boxes and cells of the field sit in this wave's LDS scratch.
+    {
+        unsigned char* nsp = private_base + (size_t)wave * nms_scratch_bytes(a.max_ann);
+        OccBox* my_box = (OccBox*)nsp;
+        int2* my_cell = (int2*)(nsp + sizeof(OccBox) * a.max_ann);
+        for (int k = wave; k < K; k += kAssocWaves) {
+            for (int r = lane; r < n_kept; r += kWave) {
+                const double* pose = anns + ((size_t)nms_order[r] * K + k) * 4;
+                OccBox bx; bx.minx = bx.miny = bx.maxx = bx.maxy = 0;
+                int2 cell; cell.x = -1; cell.y = -1;          // v == 0: neither tested nor set (:36)
+                if (pose[0] != 0.0) {
+                    occ_xy(c, p, pose[1], pose[2], &cell.x, &cell.y);
+                    bx = occ_box(c, p, pose[1], pose[2], pose[3]);
+                }
+                my_box[r] = bx; my_cell[r] = cell;
+            }
+            wave_sync();
+            for (int r = 1; r < n_kept; r++) {
+                const int2 cell = my_cell[r];
+                if (cell.x < 0) continue;
+                bool cover = false;
+                for (int q = lane; q < r; q += kWave) cover |= box_contains(my_box[q], cell.x, cell.y);
+                if (__ballot(cover) != 0ull) {                // :37-38 suppressed, sets no box
+                    if (lane == 0) {
+                        atomicOr(&nms_supp[r * KC + (k >> 6)], 1ull << (k & 63));
+                        OccBox e; e.minx = e.miny = e.maxx = e.maxy = 0;
+                        my_box[r] = e;
+                    }
+                    wave_sync();
                 }
             }
-            const unsigned long long ms = __ballot(suppressed);
-            if (wave == 0 && lane == 0) nms_supp[r * KC + kc] = ms;
-            unsigned long long m = __ballot(need_set);
-            __syncthreads();                             // every wave has tested before any wave marks
-            while (m) {
-                const int l = __builtin_ctzll(m); m &= m - 1;
-                const double bx = __shfl(x, l), by = __shfl(y, l), bs = __shfl(s, l);
-                if ((n_set++ % kAssocWaves) == wave) occ_set(c, p, kc * kWave + l, bx, by, bs, 2);   // :53
-            }
+            wave_sync();
         }
-        sync_global();                                   // marks visible to the next pose's tests
     }
+    __syncthreads();
     // suppression, keypoint threshold, instance threshold (:50,58-66); one thread per pose
     for (int r = tid; r < n_kept; r += kAssocThreads) {
         double* pose = anns + (size_t)nms_order[r] * K * 4;
@@ -834,13 +893,15 @@ hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevPara
     const int KC = (K + kWave - 1) / kWave;
     const size_t shared = sizeof(double) * a.max_ann
                         + sizeof(unsigned long long) * ((size_t)a.max_ann * KC + 2 * kAssocWaves)
-                        + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann + kAssocWaves) + 16;
+                        + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann + 4 * kAssocWaves) + 16;
     const size_t priv = assoc_private_bytes(K, A);
     const size_t budget = 160 * 1024;
     if (shared + priv > budget) return hipErrorInvalidValue;
     int growers = (int)((budget - shared) / priv);
     if (growers > kAssocWaves) growers = kAssocWaves;
-    const size_t lds = shared + (size_t)growers * priv;
+    const size_t nms = (size_t)kAssocWaves * nms_scratch_bytes(a.max_ann);
+    if (shared + nms > budget) return hipErrorInvalidValue;
+    const size_t lds = shared + ((size_t)growers * priv > nms ? (size_t)growers * priv : nms);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)cifcaf_assoc_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
