@@ -45,7 +45,8 @@ namespace opa {
 
 constexpr int kAssocWaves = 8;
 constexpr int kAssocThreads = kAssocWaves * kWave;
-constexpr int kBlendChunks = 8;        // list entries per lane held in registers by the single-pass scan
+constexpr int kBlendChunks = 8;
+       // list entries per lane held in registers by the single-pass scan
 
 // Optional phase timers (build with -DOPA_ASSOC_TIMING; tools/assoc_timing.py reads them).
 #ifdef OPA_ASSOC_TIMING
@@ -72,6 +73,7 @@ struct ImageCtx {
     const float* lists; const int32_t* list_counts; int list_cap;
     unsigned char* occ; int occ_h, occ_w;
     // private LDS (one copy per wave, kept identical)
+    struct OccBox* jbox;                 // occupancy boxes of the grown pose [K]
     double* jv; float *jx, *jy, *js;     // current pose [K]
     unsigned long long* heap;            // [4A] nodes: float bits of max_score << 32 | entry id
     double* e_v; float *e_x, *e_y, *e_s; int* e_se;   // frontier entry pool [4A]
@@ -79,7 +81,7 @@ struct ImageCtx {
     int heap_n, n_entries;
     // shared LDS
     int* sh_counts;                      // [2A] list lengths of the active list set
-    long long t[10];                     // OPA_ASSOC_TIMING: 0 blend 1 #blend 2 #chunks 3 rest 4 grow 5 mark 6 nms 7 total
+    long long t[10];                     // OPA_ASSOC_TIMING: 0 blend 1 #blend 2 #chunks 3 rest 4 grow 5 mark 6 nms 7 total 8 cycles 9 rounds
 };
 
 __device__ __forceinline__ ListView list_view(const ImageCtx& c, int bone, int dir) {
@@ -506,8 +508,7 @@ __device__ __forceinline__ bool box_contains(const OccBox& b, int xi, int yi) {
 }
 
 // the 64 lanes of one wave fill one box of the byte map
-__device__ __forceinline__ void occ_set(const ImageCtx& c, const DevParams& p, int f, double x, double y, double sigma) {
-    const OccBox b = occ_box(c, p, x, y, sigma);
+__device__ __forceinline__ void occ_fill(const ImageCtx& c, int f, const OccBox& b) {
     const int minx = b.minx, miny = b.miny, maxx = b.maxx, maxy = b.maxy;
     const int bw = maxx - minx;
     const int lane = lane_id();
@@ -526,11 +527,11 @@ __device__ __forceinline__ void occ_set(const ImageCtx& c, const DevParams& p, i
     }
 }
 
-// Private LDS block of one wave (pose + frontier); kept 16-byte sized.
+// Private LDS block of one wave (pose boxes + pose + frontier); kept 16-byte sized.
 __host__ __device__ inline size_t assoc_private_bytes(int K, int A) {
     const int P4 = 4 * A, E = 2 * A;
-    const size_t b = sizeof(double) * (K + P4) + sizeof(unsigned long long) * P4 + sizeof(float) * (3 * K + 3 * P4)
-                   + sizeof(int) * P4 + E;
+    const size_t b = 16 * (size_t)K + sizeof(double) * (K + P4) + sizeof(unsigned long long) * P4
+                   + sizeof(float) * (3 * K + 3 * P4) + sizeof(int) * P4 + E;
     return (b + 15) / 16 * 16;
 }
 
@@ -539,23 +540,34 @@ __host__ __device__ inline size_t nms_scratch_bytes(int max_ann) {
     return (sizeof(int) * 4 + sizeof(int) * 2) * (size_t)max_ann;
 }
 
-struct PoseView { const double* v; const float *x, *y, *s; };
+struct PoseView { const OccBox* box; const double* v; const float *x, *y, *s; };
 
 __device__ __forceinline__ PoseView pose_of_wave(unsigned char* private_base, int wave, int K, int A) {
     unsigned char* sp = private_base + (size_t)wave * assoc_private_bytes(K, A);
     const int P4 = 4 * A;
     PoseView q;
+    q.box = (const OccBox*)sp; sp += sizeof(OccBox) * K;
     q.v = (const double*)sp; sp += sizeof(double) * (K + P4) + sizeof(unsigned long long) * P4;
     q.x = (const float*)sp; q.y = q.x + K; q.s = q.y + K;
     return q;
 }
 
+// occupancy boxes of the pose this wave just grew (empty box for an unfilled joint): used by the
+// in-round resolve and by mark_pose
+__device__ __forceinline__ void pose_boxes(ImageCtx& c, const DevParams& p) {
+    for (int k = lane_id(); k < c.K; k += kWave) {
+        OccBox b; b.minx = b.miny = b.maxx = b.maxy = 0;
+        if (k < c.F && c.jv[k] != 0.0) b = occ_box(c, p, (double)c.jx[k], (double)c.jy[k], (double)c.js[k]);
+        c.jbox[k] = b;
+    }
+}
+
 // mark every filled joint of a pose (cifcaf.cpp:225-229), boxes dealt to the waves
-__device__ __forceinline__ void mark_pose(const ImageCtx& c, const DevParams& p, const PoseView& q) {
+__device__ __forceinline__ void mark_pose(const ImageCtx& c, const PoseView& q) {
     int n = 0;
     for (int f = 0; f < c.F; f++) {
         if (q.v[f] == 0.0) continue;
-        if ((n++ % kAssocWaves) == c.wave) occ_set(c, p, f, (double)q.x[f], (double)q.y[f], (double)q.s[f]);
+        if ((n++ % kAssocWaves) == c.wave) occ_fill(c, f, q.box[f]);
     }
 }
 
@@ -587,7 +599,6 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     unsigned char* sp = smem;
     double* nms_score = (double*)sp; sp += sizeof(double) * a.max_ann;
     unsigned long long* nms_supp = (unsigned long long*)sp; sp += sizeof(unsigned long long) * a.max_ann * KC;
-    unsigned long long* sh_mask = (unsigned long long*)sp; sp += sizeof(unsigned long long) * 2 * kAssocWaves;
     c.sh_counts = (int*)sp; sp += sizeof(int) * E;
     int* l_off = (int*)sp; sp += sizeof(int) * (K + 1);
     int* l_other = (int*)sp; sp += sizeof(int) * E;
@@ -597,13 +608,10 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     if ((K + 1) & 1) sp += sizeof(int);             // keep 8-byte alignment for what follows
     int* nms_order = (int*)sp; sp += sizeof(int) * a.max_ann;
     int* nms_rank = (int*)sp; sp += sizeof(int) * a.max_ann;
-    int* sh_cand = (int*)sp; sp += sizeof(int) * kAssocWaves;             // candidate seed index, field, x, y
-    int* sh_cand_f = (int*)sp; sp += sizeof(int) * kAssocWaves;
-    float* sh_cand_x = (float*)sp; sp += sizeof(float) * kAssocWaves;
-    float* sh_cand_y = (float*)sp; sp += sizeof(float) * kAssocWaves;
     sp = smem + (((size_t)(sp - smem) + 15) & ~(size_t)15);
     unsigned char* private_base = sp;                // growth state; reused as NMS scratch once growth is over
     sp += (size_t)(wave < S ? wave : 0) * assoc_private_bytes(K, A);   // waves >= S never touch theirs
+    c.jbox = (OccBox*)sp; sp += sizeof(OccBox) * K;
     c.jv = (double*)sp; sp += sizeof(double) * K;
     c.e_v = (double*)sp; sp += sizeof(double) * P4;
     c.heap = (unsigned long long*)sp; sp += sizeof(unsigned long long) * P4;
@@ -641,7 +649,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     // Returns 0 = marked only (pruned), 1 = stored at slot n_kept, 2 = capacity overflow.
     auto accept_pose = [&](int g, long long id, int slot) -> int {
         const PoseView q = pose_of_wave(private_base, g, K, A);
-        mark_pose(c, p, q);
+        mark_pose(c, q);
         if (prune && pose_score(q, K) < p.nms_instance_threshold) return 0;
         if (slot >= a.max_ann) return 2;
         if (wave == g) {
@@ -666,6 +674,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
             }
             wave_sync();
             grow(c, p, true, 1.0);
+            pose_boxes(c, p);
         }
         __syncthreads();
         for (int g = 0; g < S && n0 + g < a.n_initial; g++) {
@@ -676,77 +685,133 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     }
 
     // ---- seeds in score order, cifcaf.cpp:206-231, in speculative rounds
+    // Every wave runs candidate selection and the resolve walk redundantly on the same data (no
+    // barriers, no LDS exchange): lane l holds seeds pos + 64 r + l, r = 0..7, of the 512-seed window.
     int n_seeds = a.seed_count[b];
     if (n_seeds > a.seed_cap) n_seeds = a.seed_cap;
     const int32_t* seed_f = a.seed_f + (size_t)b * a.seed_cap;
     const float4* seed_vxys = reinterpret_cast<const float4*>(a.seed_vxys) + (size_t)b * a.seed_cap;
-    int pos = 0, parity = 0;
+    constexpr int WR = kAssocThreads / kWave;        // window chunks per lane
+    int pos = 0;
     while (pos < n_seeds) {
-        // 1. which of the next 1024 seeds are live right now?
-        const int i = pos + tid;
-        bool live = false;
-        if (i < n_seeds) {
-            const int f = seed_f[i]; const float4 sd = seed_vxys[i];
-            live = c.occ[occ_cell(c, p, f, (double)sd.y, (double)sd.z)] == 0;     // :211
-        }
-        const unsigned long long mask = __ballot(live);
-        if (lane == 0) sh_mask[parity * kAssocWaves + wave] = mask;
-        __syncthreads();
-        // 2. the first S live ones are this round's candidates; wave g takes candidate g
-        int n_cand = 0, mine = -1;
+        // 1. the window: field, cell and liveness (occupancy map = poses of earlier rounds, :211)
+        int wf[WR], wcx[WR], wcy[WR];
+        unsigned live = 0u;
+        int cand[kAssocWaves];
+        int n_cand = 0;
+        {
+            float wx[WR], wy[WR], ws[WR];
 #pragma unroll
-        for (int w = 0; w < kAssocWaves; w++) {
-            unsigned long long m = sh_mask[parity * kAssocWaves + w];
-            const int cnt = __popcll(m);
-            if (mine < 0 && wave >= n_cand && wave < n_cand + cnt && wave < S) {
-                int skip = wave - n_cand;
-                while (skip-- > 0) m &= m - 1;
-                mine = pos + w * kWave + __builtin_ctzll(m);
+            for (int r = 0; r < WR; r++) {
+                const int i = pos + r * kWave + lane;
+                wf[r] = 0; wcx[r] = 0; wcy[r] = 0; wx[r] = 0.f; wy[r] = 0.f; ws[r] = 0.f;
+                if (i < n_seeds) {
+                    const float4 sd = seed_vxys[i];
+                    wf[r] = seed_f[i]; wx[r] = sd.y; wy[r] = sd.z; ws[r] = sd.w;
+                    occ_xy(c, p, (double)sd.y, (double)sd.z, &wcx[r], &wcy[r]);
+                    if (c.occ[((size_t)wf[r] * c.occ_h + wcy[r]) * c.occ_w + wcx[r]] == 0) live |= 1u << r;
+                }
             }
-            n_cand += cnt;
+            // 2. candidates: the first live seed, then the next live seeds that do not fall into the
+            //    occupancy box an earlier candidate's own seed joint will mark (the other cells of the same
+            //    confidence blob).  Those are dead once that candidate is accepted; skipping them is still
+            //    only a PREDICTION (the candidate may be rejected) -- the walk below verifies it.
+            unsigned elig = live;
+#pragma unroll
+            for (int k = 0; k < kAssocWaves; k++) {
+                if (k >= S) break;
+                int first = -1;
+#pragma unroll
+                for (int r = WR - 1; r >= 0; r--) {
+                    const unsigned long long m = __ballot((elig >> r) & 1u);
+                    if (m) first = r * kWave + __builtin_ctzll(m);
+                }
+                if (first < 0) break;
+                const int fr = first >> 6;
+                float bx = 0.f, by = 0.f, bs = 0.f; int bf = 0;
+#pragma unroll
+                for (int r = 0; r < WR; r++) if (r == fr) { bx = wx[r]; by = wy[r]; bs = ws[r]; bf = wf[r]; }
+                bx = __shfl(bx, first & 63); by = __shfl(by, first & 63); bs = __shfl(bs, first & 63);
+                bf = __shfl(bf, first & 63);
+                cand[k] = first; n_cand = k + 1;
+                const OccBox sb = occ_box(c, p, (double)bx, (double)by, (double)bs);   // the box its seed joint will occupy
+#pragma unroll
+                for (int r = 0; r < WR; r++)
+                    if (r == fr ? lane == (first & 63) : false) elig &= ~(1u << r);
+#pragma unroll
+                for (int r = 0; r < WR; r++)
+                    if (wf[r] == bf && box_contains(sb, wcx[r], wcy[r])) elig &= ~(1u << r);
+            }
         }
-        parity ^= 1;
-        if (n_cand > S) n_cand = S;
         if (n_cand == 0) { pos += kAssocThreads; continue; }
+        OPA_TINC(c.t[9], 1);
         // 3. speculative growth, one pose per wave, no barriers inside
-        if (mine >= 0) {
+        if (wave < n_cand) {
+            int mine = pos;
+#pragma unroll
+            for (int k = 0; k < kAssocWaves; k++) if (k == wave) mine += cand[k];
             const int sf = seed_f[mine]; const float4 sd = seed_vxys[mine];
-            if (lane == 0) { sh_cand[wave] = mine; sh_cand_f[wave] = sf; sh_cand_x[wave] = sd.y; sh_cand_y[wave] = sd.z; }
             for (int k = lane; k < K; k += kWave) { c.jv[k] = 0.0; c.jx[k] = 0.f; c.jy[k] = 0.f; c.js[k] = 0.f; }
             wave_sync();
             c.jv[sf] = (double)sd.x; c.jx[sf] = sd.y; c.jy[sf] = sd.z; c.js[sf] = sd.w;   // :213-218
             wave_sync();
             OPA_T0(tg); grow(c, p, true, 1.0); OPA_TACC(c.t[4], tg);
+            pose_boxes(c, p);
         }
         __syncthreads();
-        // 4. resolve in seed order: candidate g is accepted iff its cell is still free at its turn (:211).
-        //    It was free when the round started, so only the poses accepted before it IN THIS ROUND can
-        //    have taken it: test their joint boxes analytically (LDS only, every wave computes the same
-        //    mask), then write all marks of the round and synchronise global memory once.
+        // 4. resolve walk in seed order.  `unc` = live and not inside a box of a pose accepted in this
+        //    round, i.e. what the sequential loop would find free at that seed's turn (:211).  A candidate
+        //    that is still free is accepted; a free seed that is NOT a candidate (a wrong prediction)
+        //    ends the round there -- it becomes the first candidate of the next round.
         OPA_T0(tm);
-        unsigned acc_mask = 1u;
-        for (int g = 1; g < n_cand; g++) {
-            const int sf = sh_cand_f[g];
-            int xi, yi;
-            occ_xy(c, p, (double)sh_cand_x[g], (double)sh_cand_y[g], &xi, &yi);
-            bool cover = false;
-            if (lane < g && ((acc_mask >> lane) & 1u)) {
-                const PoseView q = pose_of_wave(private_base, lane, K, A);
-                if (q.v[sf] != 0.0)
-                    cover = box_contains(occ_box(c, p, (double)q.x[sf], (double)q.y[sf], (double)q.s[sf]), xi, yi);
+        unsigned unc = live, acc_mask = 0u;
+        int prev = -1, stop = -1;
+        auto first_free_between = [&](int lo, int hi) -> int {     // window offsets in (lo, hi)
+            int first = -1;
+#pragma unroll
+            for (int r = WR - 1; r >= 0; r--) {
+                const int off = r * kWave + lane;
+                const unsigned long long m = __ballot(((unc >> r) & 1u) && off > lo && off < hi);
+                if (m) first = r * kWave + __builtin_ctzll(m);
             }
-            if (__ballot(cover) == 0ull) acc_mask |= 1u << g;
+            return first;
+        };
+#pragma unroll
+        for (int k = 0; k < kAssocWaves; k++) {
+            if (k >= n_cand) break;
+            const int ck = cand[k];
+            stop = first_free_between(prev, ck);
+            if (stop >= 0) break;
+            unsigned long long mk = 0ull;
+#pragma unroll
+            for (int r = 0; r < WR; r++) {
+                const unsigned long long m = __ballot((unc >> r) & 1u);
+                if (r == (ck >> 6)) mk = m;
+            }
+            if ((mk >> (ck & 63)) & 1ull) {
+                acc_mask |= 1u << k;
+                const PoseView q = pose_of_wave(private_base, k, K, A);
+#pragma unroll
+                for (int r = 0; r < WR; r++)
+                    if (((unc >> r) & 1u) && box_contains(q.box[wf[r]], wcx[r], wcy[r])) unc &= ~(1u << r);
+            }
+            prev = ck;
+        }
+        int next_pos;
+        if (stop >= 0) next_pos = pos + stop;
+        else if (n_cand == S) next_pos = pos + prev + 1;             // seeds behind the last candidate are undecided
+        else {                                                       // every live seed of the window was considered
+            stop = first_free_between(prev, kAssocThreads);
+            next_pos = stop >= 0 ? pos + stop : pos + kAssocThreads;
         }
         for (int g = 0; g < n_cand; g++)
             if ((acc_mask >> g) & 1u) {
                 const int rc = accept_pose(g, -1, n_kept);
                 n_kept += rc == 1; n_dropped += rc == 2;
             }
-        const int last = sh_cand[n_cand - 1];
         sync_global();                        // marks and stored poses visible to every wave
         OPA_TACC(c.t[5], tm);
-        // every seed up to the last candidate is decided; fewer than S candidates = all 1024 scanned
-        pos = (n_cand == S) ? last + 1 : pos + kAssocThreads;
+        pos = next_pos;
     }
     __syncthreads();
 
@@ -891,9 +956,10 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
 hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
     const int K = a.K, A = a.A, E = 2 * A;
     const int KC = (K + kWave - 1) / kWave;
+    if (a.occ_w > 32767 || a.occ_h > 32767) return hipErrorInvalidValue;
     const size_t shared = sizeof(double) * a.max_ann
-                        + sizeof(unsigned long long) * ((size_t)a.max_ann * KC + 2 * kAssocWaves)
-                        + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann + 4 * kAssocWaves) + 16;
+                        + sizeof(unsigned long long) * ((size_t)a.max_ann * KC)
+                        + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann) + 32;
     const size_t priv = assoc_private_bytes(K, A);
     const size_t budget = 160 * 1024;
     if (shared + priv > budget) return hipErrorInvalidValue;
