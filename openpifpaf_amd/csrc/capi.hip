@@ -108,6 +108,7 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     L->off_seed_count = take(B * sizeof(int32_t));
     L->off_seed_f = take(B * (size_t)L->cif_cells * sizeof(int32_t));
     L->off_seed_vxys = take(B * (size_t)L->cif_cells * 4 * sizeof(float));
+    L->off_seed_cell = take(B * (size_t)L->cif_cells * sizeof(int32_t));
     const size_t list_bytes = B * L->A * 2 * 7 * (size_t)L->caf_cells * sizeof(float);
     L->off_lists = take(list_bytes);
     L->off_list_counts = take(B * L->A * 2 * sizeof(int32_t));
@@ -264,7 +265,7 @@ int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what, size_t* 
     struct Entry { const char* name; size_t off, end; };
     const Entry table[] = {
         {"cifhr", L.off_cifhr, L.off_act}, {"seed_count", L.off_seed_count, L.off_seed_f},
-        {"seed_f", L.off_seed_f, L.off_seed_vxys}, {"seed_vxys", L.off_seed_vxys, L.off_lists},
+        {"seed_f", L.off_seed_f, L.off_seed_vxys}, {"seed_vxys", L.off_seed_vxys, L.off_seed_cell}, {"seed_cell", L.off_seed_cell, L.off_lists},
         {"lists", L.off_lists, L.off_list_counts}, {"list_counts", L.off_list_counts, L.off_lists_fc},
         {"lists_fc", L.off_lists_fc, L.off_list_counts_fc}, {"list_counts_fc", L.off_list_counts_fc, L.off_occ},
         {"occupancy", L.off_occ, L.off_anns}, {"annotation_scratch", L.off_anns, L.off_ann_meta},
@@ -316,7 +317,8 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     e = launch_cifseeds(cif_dev, L.B, L.F, L.H, L.W, L.stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
                         (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap,
                         (int32_t*)(ws + L.off_seed_count), (int32_t*)(ws + L.off_seed_f),
-                        (float*)(ws + L.off_seed_vxys), st);                                 // :144-146
+                        (float*)(ws + L.off_seed_vxys), st, false, (int32_t*)(ws + L.off_seed_cell),
+                        L.occ_h, L.occ_w);                                                   // :144-146
     if (e != hipSuccess) return fail_hip(e, "cifseeds");
     e = launch_cafscored(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols, L.hr_pitch,
                          dec->dev.skeleton, p.caf_threshold, p.cif_floor, p.ablation_caf_no_rescore,
@@ -339,6 +341,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     a.seed_cap = L.cif_cells; a.list_cap = L.caf_cells;
     a.seed_f = (const int32_t*)(ws + L.off_seed_f); a.seed_vxys = (const float*)(ws + L.off_seed_vxys);
     a.seed_count = (const int32_t*)(ws + L.off_seed_count);
+    a.seed_cell = (const int32_t*)(ws + L.off_seed_cell);
     a.lists = (const float*)(ws + L.off_lists); a.list_counts = (const int32_t*)(ws + L.off_list_counts);
     a.lists_fc = (const float*)(ws + L.off_lists_fc); a.list_counts_fc = (const int32_t*)(ws + L.off_list_counts_fc);
     a.occ = ws + L.off_occ;

@@ -73,6 +73,7 @@ struct ImageCtx {
     const float* lists; const int32_t* list_counts; int list_cap;
     unsigned char* occ; int occ_h, occ_w;
     // private LDS (one copy per wave, kept identical)
+    float* tgt;                          // [3][kBlendChunks][64] target columns of the list being scanned
     struct OccBox* jbox;                 // occupancy boxes of the grown pose [K]
     double* jv; float *jx, *jy, *js;     // current pose [K]
     unsigned long long* heap;            // [4A] nodes: float bits of max_score << 32 | entry id
@@ -81,7 +82,7 @@ struct ImageCtx {
     int heap_n, n_entries;
     // shared LDS
     int* sh_counts;                      // [2A] list lengths of the active list set
-    long long t[10];                     // OPA_ASSOC_TIMING: 0 blend 1 #blend 2 #chunks 3 rest 4 grow 5 mark 6 nms 7 total 8 cycles 9 rounds
+    long long t[12];                     // OPA_ASSOC_TIMING: 0 blend 1 #blend 2 #chunks 3 rest 4 grow 5 mark 6 nms 7 total 8 cycles 9 rounds
 };
 
 __device__ __forceinline__ ListView list_view(const ImageCtx& c, int bone, int dir) {
@@ -145,6 +146,17 @@ __device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
     return ((unsigned long long)hi << 32) | lo;
 }
 
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    auto step = [](unsigned x, unsigned o) { return o > x ? o : x; };
+    v = step(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));
+    v = step(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));
+    v = step(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));
+    v = step(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));
+    v = step(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x142, 0xA, 0xF, false));
+    v = step(v, (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x143, 0xC, 0xF, false));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // first place = max score, LAST list position among equals (">=", :65).  Scores are
 // non-negative floats, so (score bits << 32 | position + 1) orders exactly like that;
 // a lane without a candidate contributes key 0.
@@ -197,21 +209,34 @@ __device__ __forceinline__ BlendResult blend_finish(float s1, float s2, bool hav
 // reductions and the target lookups are register/cross-lane only.
 typedef __attribute__((address_space(1))) const float gfloat;
 
+typedef __attribute__((address_space(3))) float lfloat;
+
 template <int R>
-__device__ __forceinline__ BlendResult blend_cached(const ListView& L, const BlendQuery& q, bool only_max) {
+__device__ __forceinline__ BlendResult blend_cached(const ListView& L, const BlendQuery& q, bool only_max, float* tgt) {
     const int lane = lane_id();
     const gfloat* g = (const gfloat*)L.base;
-    float sc[R], tx[R], ty[R], ts[R], x1[R], y1[R], cc[R];
+    // The target columns (x2, y2, s2) are needed for two entries only: they travel HBM/L2 -> LDS
+    // directly (global_load_lds, no VGPRs), in flight together with the register loads below; chunk r of
+    // column k lands at tgt[(k * R + r) * 64 + lane].
+    lfloat* t3 = (lfloat*)tgt;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int i = r * kWave + lane;
+        const int ii = i < L.n ? i : 0;
+        __builtin_amdgcn_global_load_lds(g + 3 * L.cap + ii, t3 + (0 * R + r) * kWave, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(g + 4 * L.cap + ii, t3 + (1 * R + r) * kWave, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(g + 6 * L.cap + ii, t3 + (2 * R + r) * kWave, 4, 0, 0);
+    }
+    float sc[R], x1[R], y1[R], cc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int i = r * kWave + lane;
         const int ii = i < L.n ? i : 0;
         x1[r] = g[1 * L.cap + ii]; y1[r] = g[2 * L.cap + ii]; cc[r] = g[ii];
-        tx[r] = g[3 * L.cap + ii]; ty[r] = g[4 * L.cap + ii]; ts[r] = g[6 * L.cap + ii];
     }
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]), "+v"(tx[r]), "+v"(ty[r]), "+v"(ts[r]) :: "memory");
+        asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
         sc[r] = -1.0f;
     }
     float s1 = 0.0f; int i1 = -1;
@@ -224,7 +249,10 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
         }
     }
     reduce_first(s1, i1);
-    if (s1 == 0.0f || i1 < 0) return blend_none();             // :76
+    if (s1 == 0.0f || i1 < 0) {                                // :76
+        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): the LDS loads must land before the area is reused
+        return blend_none();
+    }
     float s2 = 0.0f; int r2 = -1;
     if (!only_max) {
 #pragma unroll
@@ -238,16 +266,10 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
     }
     const bool have2 = r2 >= 0;
     const int i2 = have2 ? (r2 >= L.n ? r2 - L.n : L.n - r2) : i1;
-    // fetch the two targets from the owning lanes' registers
-    const int c1 = i1 >> 6, c2 = i2 >> 6;
-    float p1x = 0.f, p1y = 0.f, p1s = 0.f, p2x = 0.f, p2y = 0.f, p2s = 0.f;
-#pragma unroll
-    for (int r = 0; r < R; r++) {
-        if (r == c1) { p1x = tx[r]; p1y = ty[r]; p1s = ts[r]; }
-        if (r == c2) { p2x = tx[r]; p2y = ty[r]; p2s = ts[r]; }
-    }
-    const float e1x = __shfl(p1x, i1 & 63), e1y = __shfl(p1y, i1 & 63), e1s = __shfl(p1s, i1 & 63);
-    const float e2x = __shfl(p2x, i2 & 63), e2y = __shfl(p2y, i2 & 63), e2s = __shfl(p2s, i2 & 63);
+    __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): target columns are in LDS
+    wave_sync();
+    const float e1x = tgt[0 * R * kWave + i1], e1y = tgt[1 * R * kWave + i1], e1s = tgt[2 * R * kWave + i1];
+    const float e2x = tgt[0 * R * kWave + i2], e2y = tgt[1 * R * kWave + i2], e2s = tgt[2 * R * kWave + i2];
     return blend_finish(s1, s2, have2, only_max, e1x, e1y, e1s, e2x, e2y, e2s);
 }
 
@@ -315,21 +337,21 @@ __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const B
 // The one real (non-inlined) device function of the kernel: everything is passed and
 // returned by value in registers.
 __device__ __forceinline__ BlendResult blend_impl(const float* base, int cap, int n, double x, double y,
-                                               double xy_scale, double filter_sigmas, int only_max) {
+                                               double xy_scale, double filter_sigmas, int only_max, float* tgt) {
     if (n <= 0) return blend_none();
     ListView L; L.base = base; L.cap = cap; L.n = n;
     const BlendQuery q = make_query(x, y, xy_scale, filter_sigmas);
-    if (n <= kWave) return blend_cached<1>(L, q, only_max != 0);
-    if (n <= 2 * kWave) return blend_cached<2>(L, q, only_max != 0);
-    if (n <= 4 * kWave) return blend_cached<4>(L, q, only_max != 0);
-    if (n <= kBlendChunks * kWave) return blend_cached<kBlendChunks>(L, q, only_max != 0);
+    if (n <= kWave) return blend_cached<1>(L, q, only_max != 0, tgt);
+    if (n <= 2 * kWave) return blend_cached<2>(L, q, only_max != 0, tgt);
+    if (n <= 4 * kWave) return blend_cached<4>(L, q, only_max != 0, tgt);
+    if (n <= kBlendChunks * kWave) return blend_cached<kBlendChunks>(L, q, only_max != 0, tgt);
     return blend_streamed(L, q, only_max != 0);
 }
 
 __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, double x, double y, double xy_scale,
                                              double filter_sigmas) {
     OPA_T0(t0);
-    const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0);
+    const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt);
     OPA_TACC(c.t[0], t0); OPA_TINC(c.t[1], 1); OPA_TINC(c.t[2], (L.n + kWave - 1) / kWave);
     return r;
 }
@@ -474,6 +496,214 @@ __device__ __forceinline__ void flood_fill(ImageCtx& c) {
     }
 }
 
+// ------------------------------------------------ register-resident growth state
+// For skeletons with K <= 64 joints and 2A <= 64 directed bones (COCO: 17 / 38) the pose, the
+// frontier entries (one per directed bone: an entry is popped before it is pushed again, and
+// in_frontier admits a bone once) and the binary heap live in VGPR lanes instead of LDS:
+//     lane k: joint k      lane t: entry + static data of directed bone t      lane i: heap node i
+// Everything the search does with them is wave-uniform, so it is v_readlane / v_writelane and scalar
+// control flow -- a few cycles per access where a dependent LDS round trip costs ~100.  The
+// algorithm (cifcaf.cpp:265-346, 429-449 and the std::priority_queue heap) is the same as in the
+// LDS variant below, statement by statement.
+struct RegSkeleton { int slot_info, slot_first, off, off1; };   // built once per kernel
+struct RegState {
+    int jv_lo, jv_hi; float jx, jy, js;          // lane k: joint k (v is a double)
+    int ev_lo, ev_hi; float ex, ey, es;          // lane t: entry of directed bone t (v == 0: not computed yet)
+    int list_n;                                  // lane 2*bone+dir: length of that CAF list
+    int h_score, h_slot;                         // lane i: heap node i (float bits of max_score, bone slot)
+    int heap_n;                                  // uniform
+    unsigned long long in_frontier;              // uniform, one bit per directed bone
+};
+
+__device__ __forceinline__ int rlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float rlanef(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+// (this clang has no writelane builtin: one v_cmp against the lane id + a v_cndmask per register)
+__device__ __forceinline__ void wlane(int& v, int val, int l) { v = lane_id() == l ? val : v; }
+__device__ __forceinline__ void wlanef(float& v, float val, int l) { v = lane_id() == l ? val : v; }
+__device__ __forceinline__ double uniform_f64(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ float uniform_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+__device__ __forceinline__ double reg_jv(const RegState& R, int j) {
+    return __hiloint2double(rlane(R.jv_hi, j), rlane(R.jv_lo, j));
+}
+__device__ __forceinline__ void reg_set_joint(RegState& R, int j, double v, float x, float y, float s) {
+    wlane(R.jv_lo, __double2loint(v), j); wlane(R.jv_hi, __double2hiint(v), j);
+    wlanef(R.jx, x, j); wlanef(R.jy, y, j); wlanef(R.js, s, j);
+}
+
+__device__ __forceinline__ void reg_heap_sift_up(RegState& R, int hole, unsigned score, int slot) {
+    int parent = (hole - 1) / 2;
+    while (hole > 0) {
+        const unsigned ps = (unsigned)rlane(R.h_score, parent);
+        if (!(ps < score)) break;
+        const int pslot = rlane(R.h_slot, parent);
+        wlane(R.h_score, (int)ps, hole); wlane(R.h_slot, pslot, hole);
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    wlane(R.h_score, (int)score, hole); wlane(R.h_slot, slot, hole);
+}
+__device__ __forceinline__ void reg_heap_push(RegState& R, float score, int slot) {
+    R.heap_n++;
+    reg_heap_sift_up(R, R.heap_n - 1, (unsigned)__builtin_amdgcn_readfirstlane(__float_as_int(score)), slot);
+}
+__device__ __forceinline__ int reg_heap_pop(RegState& R) {      // returns the top node's bone slot
+    const int top = rlane(R.h_slot, 0);
+    const int len = R.heap_n - 1;
+    if (len > 0) {
+        const unsigned vscore = (unsigned)rlane(R.h_score, len);
+        const int vslot = rlane(R.h_slot, len);
+        int hole = 0, child = 0;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            unsigned cs = (unsigned)rlane(R.h_score, child);
+            const unsigned ls = (unsigned)rlane(R.h_score, child - 1);
+            if (cs < ls) { child--; cs = ls; }
+            const int cslot = rlane(R.h_slot, child);
+            wlane(R.h_score, (int)cs, hole); wlane(R.h_slot, cslot, hole);
+            hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) {
+            child = 2 * (child + 1);
+            const int cs = rlane(R.h_score, child - 1), cslot = rlane(R.h_slot, child - 1);
+            wlane(R.h_score, cs, hole); wlane(R.h_slot, cslot, hole);
+            hole = child - 1;
+        }
+        reg_heap_sift_up(R, hole, vscore, vslot);
+    }
+    R.heap_n = len;
+    return top;
+}
+
+// cifcaf.cpp:316-346
+__device__ __forceinline__ void reg_frontier_add_from(RegState& R, const RegSkeleton& sk, int start) {
+    const float max_score = (float)sqrt(reg_jv(R, start));
+    const int t1 = rlane(sk.off1, start);
+    for (int t = rlane(sk.off, start); t < t1; t++) {
+        const int other = (rlane(sk.slot_info, t) >> 8) & 0xff;
+        if (reg_jv(R, other) > 0.0) continue;
+        const int first = rlane(sk.slot_first, t);
+        if ((R.in_frontier >> first) & 1ull) continue;
+        wlane(R.ev_lo, 0, first); wlane(R.ev_hi, 0, first);
+        reg_heap_push(R, max_score, first);
+        R.in_frontier |= 1ull << first;
+    }
+}
+
+__device__ __forceinline__ void reg_frontier_start(RegState& R, const RegSkeleton& sk, int K) {
+    R.heap_n = 0; R.in_frontier = 0ull;
+    unsigned long long filled = __ballot(lane_id() < K && __hiloint2double(R.jv_hi, R.jv_lo) != 0.0);
+    while (filled) {
+        const int j = __builtin_ctzll(filled);
+        filled &= filled - 1;
+        reg_frontier_add_from(R, sk, j);
+    }
+}
+
+// cifcaf.cpp:349-411 for the directed bone `slot` leaving joint `start`
+__device__ __forceinline__ bool reg_connection_value(ImageCtx& c, const DevParams& p, const RegState& R, int start,
+                                                     int info, bool reverse_match_, double filter_sigmas,
+                                                     double* nv, float* nx, float* ny, float* ns) {
+    const int bone = (info >> 16) & 0xff, fwd = (info >> 24) & 1;
+    ListView caf_f, caf_b;
+    caf_f.cap = caf_b.cap = c.list_cap;
+    caf_f.base = c.lists + ((size_t)bone * 2 + (fwd ? 0 : 1)) * 7 * c.list_cap;
+    caf_b.base = c.lists + ((size_t)bone * 2 + (fwd ? 1 : 0)) * 7 * c.list_cap;
+    caf_f.n = rlane(R.list_n, bone * 2 + (fwd ? 0 : 1));
+    caf_b.n = rlane(R.list_n, bone * 2 + (fwd ? 1 : 0));
+    const double sv = reg_jv(R, start);
+    const double sx = (double)rlanef(R.jx, start), sy = (double)rlanef(R.jy, start), ss = (double)rlanef(R.js, start);
+    const BlendResult nj = blend(c, caf_f, sx, sy, ss, filter_sigmas);
+    if (!nj.ok) return false;
+    *nx = uniform_f32(nj.x); *ny = uniform_f32(nj.y); *ns = uniform_f32(nj.s);
+    *nv = uniform_f64(sqrt(nj.v * sv));                                         // :386
+    if (*nv < p.keypoint_threshold || *nv < sv * p.keypoint_threshold_rel) return false;   // :387-390
+    if (p.reverse_match && reverse_match_ && start < c.F) {                     // :397
+        const BlendResult rj = blend(c, caf_b, (double)*nx, (double)*ny, (double)*ns, filter_sigmas);
+        if (!rj.ok) return false;
+        if (fabs(sx - (double)rj.x) + fabs(sy - (double)rj.y) > ss) return false;   // :404
+    }
+    return true;
+}
+
+// pose: LDS -> lanes, and back
+__device__ __forceinline__ void reg_load_pose(const ImageCtx& c, RegState& R) {
+    const int lane = lane_id();
+    double v = 0.0; R.jx = 0.f; R.jy = 0.f; R.js = 0.f;
+    if (lane < c.K) { v = c.jv[lane]; R.jx = c.jx[lane]; R.jy = c.jy[lane]; R.js = c.js[lane]; }
+    R.jv_lo = __double2loint(v); R.jv_hi = __double2hiint(v);
+    R.list_n = lane < 2 * c.A ? c.sh_counts[lane] : 0;
+    R.ev_lo = R.ev_hi = 0; R.ex = R.ey = R.es = 0.f; R.h_score = 0; R.h_slot = 0;
+}
+__device__ __forceinline__ void reg_store_pose(ImageCtx& c, const RegState& R) {
+    const int lane = lane_id();
+    if (lane < c.K) {
+        c.jv[lane] = __hiloint2double(R.jv_hi, R.jv_lo); c.jx[lane] = R.jx; c.jy[lane] = R.jy; c.js[lane] = R.js;
+    }
+    wave_sync();
+}
+
+// cifcaf.cpp:265-313 on the pose in this wave's LDS block
+__device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const RegSkeleton& sk, bool reverse_match_,
+                                         double filter_sigmas, bool then_flood_fill) {
+    RegState R;
+    reg_load_pose(c, R);
+    reg_frontier_start(R, sk, c.K);
+    while (R.heap_n > 0) {
+        const int slot = reg_heap_pop(R);
+        const int info = rlane(sk.slot_info, slot);
+        const int start = info & 0xff, end = (info >> 8) & 0xff;
+        if (reg_jv(R, end) > 0.0) continue;                                  // :284
+        double v = __hiloint2double(rlane(R.ev_hi, slot), rlane(R.ev_lo, slot));
+        float x, y, s;
+        if (v == 0.0) {                                                      // :287: not computed yet
+            if (!reg_connection_value(c, p, R, start, info, reverse_match_, filter_sigmas, &v, &x, &y, &s))
+                continue;                                                    // :290-296 (block_joints is a no-op)
+            if (!p.greedy) {                                                 // :298-303
+                wlane(R.ev_lo, __double2loint(v), slot); wlane(R.ev_hi, __double2hiint(v), slot);
+                wlanef(R.ex, x, slot); wlanef(R.ey, y, slot); wlanef(R.es, s, slot);
+                reg_heap_push(R, (float)v, slot);
+                continue;
+            }
+        } else {
+            x = rlanef(R.ex, slot); y = rlanef(R.ey, slot); s = rlanef(R.es, slot);
+        }
+        reg_set_joint(R, end, v, x, y, s);                                   // :310
+        reg_frontier_add_from(R, sk, end);
+    }
+    if (then_flood_fill) {                                                   // cifcaf.cpp:429-449
+        reg_frontier_start(R, sk, c.K);
+        while (R.heap_n > 0) {
+            const int slot = reg_heap_pop(R);
+            const int info = rlane(sk.slot_info, slot);
+            const int start = info & 0xff, end = (info >> 8) & 0xff;
+            if (reg_jv(R, end) > 0.0) continue;
+            reg_set_joint(R, end, 0.00001, rlanef(R.jx, start), rlanef(R.jy, start), rlanef(R.js, start));
+            reg_frontier_add_from(R, sk, end);
+        }
+    }
+    reg_store_pose(c, R);
+}
+
+template <bool REG>
+__device__ __forceinline__ void grow_pose(ImageCtx& c, const DevParams& p, const RegSkeleton& sk, bool reverse_match_,
+                                          double filter_sigmas, bool then_flood_fill) {
+    if constexpr (REG) {
+        grow_reg(c, p, sk, reverse_match_, filter_sigmas, then_flood_fill);
+    } else {
+        grow(c, p, reverse_match_, filter_sigmas);
+        if (then_flood_fill) flood_fill(c);
+        wave_sync();
+    }
+}
+
+
 // ---------------------------------------------------------------- occupancy
 // occupancy.cpp:32-43: the cell a query (x, y) falls into
 __device__ __forceinline__ void occ_xy(const ImageCtx& c, const DevParams& p, double x, double y, int* xi, int* yi) {
@@ -579,6 +809,7 @@ __device__ __forceinline__ double pose_score(const PoseView& q, int K) {
 }
 
 // ------------------------------------------------------------------- kernel
+template <bool REG>
 __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArgs a, DevSkeleton sk, DevParams p,
                                                                         int n_growers) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -609,7 +840,12 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     int* nms_order = (int*)sp; sp += sizeof(int) * a.max_ann;
     int* nms_rank = (int*)sp; sp += sizeof(int) * a.max_ann;
     sp = smem + (((size_t)(sp - smem) + 15) & ~(size_t)15);
-    unsigned char* private_base = sp;                // growth state; reused as NMS scratch once growth is over
+    unsigned char* work_base = sp;                   // growth phase: targets | pool | private blocks; NMS phase: scratch
+    c.tgt = (float*)sp + (size_t)wave * (3 * kBlendChunks * kWave);
+    sp += sizeof(float) * 3 * kBlendChunks * kWave * kAssocWaves;
+    int* pool_save = (int*)sp + (size_t)wave * (2 * 8 * kWave) + lane;   // this wave's seed pool while a pose grows
+    sp += sizeof(int) * 2 * 8 * kWave * kAssocWaves;
+    unsigned char* private_base = sp;
     sp += (size_t)(wave < S ? wave : 0) * assoc_private_bytes(K, A);   // waves >= S never touch theirs
     c.jbox = (OccBox*)sp; sp += sizeof(OccBox) * K;
     c.jv = (double*)sp; sp += sizeof(double) * K;
@@ -624,7 +860,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     c.e_se = (int*)sp; sp += sizeof(int) * P4;
     c.in_frontier = sp;
     c.heap_n = 0; c.n_entries = 0;
-    for (int k = 0; k < 10; k++) c.t[k] = 0;
+    for (int k = 0; k < 12; k++) c.t[k] = 0;
     OPA_T0(t_total);
 #ifdef OPA_ASSOC_TIMING
     const long long cyc0 = clock64();
@@ -638,6 +874,16 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     for (int k = tid; k <= K; k += kAssocThreads) l_off[k] = sk.adj_off[k];
     c.adj_off = l_off; c.adj_other = l_other; c.adj_bone = l_bone; c.adj_fwd = l_fwd; c.adj_first = l_first;
     __syncthreads();
+    RegSkeleton rs; rs.slot_info = 0; rs.slot_first = 0; rs.off = 0; rs.off1 = 0;
+    if constexpr (REG) {                             // lane t: directed bone t; lane j: adjacency range of joint j
+        if (lane < E) {
+            int start = 0;
+            while (l_off[start + 1] <= lane) start++;
+            rs.slot_info = start | (l_other[lane] << 8) | (l_bone[lane] << 16) | (l_fwd[lane] << 24);
+            rs.slot_first = l_first[lane];
+        }
+        if (lane < K) { rs.off = l_off[lane]; rs.off1 = l_off[lane + 1]; }
+    }
 
     double* anns = a.anns + (size_t)b * a.max_ann * K * 4;
     int64_t* ann_ids = a.ann_ids + (size_t)b * a.max_ann;
@@ -673,7 +919,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
                 c.jy[k] = src[4 * k + 2]; c.js[k] = src[4 * k + 3];
             }
             wave_sync();
-            grow(c, p, true, 1.0);
+            grow_pose<REG>(c, p, rs, true, 1.0, false);
             pose_boxes(c, p);
         }
         __syncthreads();
@@ -685,125 +931,166 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     }
 
     // ---- seeds in score order, cifcaf.cpp:206-231, in speculative rounds
-    // Every wave runs candidate selection and the resolve walk redundantly on the same data (no
-    // barriers, no LDS exchange): lane l holds seeds pos + 64 r + l, r = 0..7, of the 512-seed window.
+    // Every wave keeps the same pool of up to 512 LIVE, undecided seeds (8 slots per lane, any order) and
+    // runs candidate selection and the resolve walk redundantly on it: no barriers, no LDS exchange.
+    // Invariant: every seed below scan_pos is either in a slot or dead for good (inside a box of an
+    // accepted pose), so each seed is fetched and tested against the occupancy map exactly once.
     int n_seeds = a.seed_count[b];
     if (n_seeds > a.seed_cap) n_seeds = a.seed_cap;
     const int32_t* seed_f = a.seed_f + (size_t)b * a.seed_cap;
     const float4* seed_vxys = reinterpret_cast<const float4*>(a.seed_vxys) + (size_t)b * a.seed_cap;
-    constexpr int WR = kAssocThreads / kWave;        // window chunks per lane
-    int pos = 0;
-    while (pos < n_seeds) {
-        // 1. the window: field, cell and liveness (occupancy map = poses of earlier rounds, :211)
-        int wf[WR], wcx[WR], wcy[WR];
-        unsigned live = 0u;
-        int cand[kAssocWaves];
-        int n_cand = 0;
-        {
-            float wx[WR], wy[WR], ws[WR];
+    const int32_t* seed_cell = a.seed_cell + (size_t)b * a.seed_cap;
+    constexpr int WR = 8;                            // slots per lane
+    constexpr int kIdxMask = 0xFFFFFF;
+    int s_pack[WR], s_if[WR];                        // cell x | cell y << 12 | box half-width << 24 ;  seed index | field << 24
+    unsigned occupied = 0u;                          // bit r: slot r holds a live undecided seed
+    int scan_pos = 0;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < WR; r++) { s_pack[r] = 0; s_if[r] = kIdxMask; }
+    for (;;) {
+        OPA_T0(tsel);
+        // 1. refill free slots with the next seeds that are still free in the occupancy map (:211 for
+        //    the poses of earlier rounds); slot (r, lane) takes the seed of its rank among the free slots.
+        //    Passes repeat only while the pool is less than half full.
+        while (scan_pos < n_seeds) {
+            int nidx[WR], base = 0;
 #pragma unroll
             for (int r = 0; r < WR; r++) {
-                const int i = pos + r * kWave + lane;
-                wf[r] = 0; wcx[r] = 0; wcy[r] = 0; wx[r] = 0.f; wy[r] = 0.f; ws[r] = 0.f;
-                if (i < n_seeds) {
-                    const float4 sd = seed_vxys[i];
-                    wf[r] = seed_f[i]; wx[r] = sd.y; wy[r] = sd.z; ws[r] = sd.w;
-                    occ_xy(c, p, (double)sd.y, (double)sd.z, &wcx[r], &wcy[r]);
-                    if (c.occ[((size_t)wf[r] * c.occ_h + wcy[r]) * c.occ_w + wcx[r]] == 0) live |= 1u << r;
-                }
+                const bool fr = !((occupied >> r) & 1u);
+                const unsigned long long m = __ballot(fr);
+                nidx[r] = fr ? scan_pos + base + __popcll(m & lanes_below) : n_seeds;
+                base += __popcll(m);
             }
-            // 2. candidates: the first live seed, then the next live seeds that do not fall into the
-            //    occupancy box an earlier candidate's own seed joint will mark (the other cells of the same
-            //    confidence blob).  Those are dead once that candidate is accepted; skipping them is still
-            //    only a PREDICTION (the candidate may be rejected) -- the walk below verifies it.
-            unsigned elig = live;
+            if (base == 0) break;
+            int ff[WR], pk[WR]; unsigned char ob[WR];
 #pragma unroll
-            for (int k = 0; k < kAssocWaves; k++) {
-                if (k >= S) break;
-                int first = -1;
+            for (int r = 0; r < WR; r++) {
+                ff[r] = 0; pk[r] = 0;
+                if (nidx[r] < n_seeds) { ff[r] = seed_f[nidx[r]]; pk[r] = seed_cell[nidx[r]]; }
+            }
 #pragma unroll
-                for (int r = WR - 1; r >= 0; r--) {
-                    const unsigned long long m = __ballot((elig >> r) & 1u);
-                    if (m) first = r * kWave + __builtin_ctzll(m);
+            for (int r = 0; r < WR; r++) {
+                ob[r] = 1;
+                if (nidx[r] < n_seeds)
+                    ob[r] = c.occ[((size_t)ff[r] * c.occ_h + ((pk[r] >> 12) & 0xfff)) * c.occ_w + (pk[r] & 0xfff)];
+            }
+#pragma unroll
+            for (int r = 0; r < WR; r++)
+                if (nidx[r] < n_seeds && ob[r] == 0) {
+                    s_pack[r] = pk[r]; s_if[r] = nidx[r] | (ff[r] << 24); occupied |= 1u << r;
                 }
-                if (first < 0) break;
-                const int fr = first >> 6;
-                float bx = 0.f, by = 0.f, bs = 0.f; int bf = 0;
+            scan_pos = scan_pos + base < n_seeds ? scan_pos + base : n_seeds;
+            int n_occ = 0;
 #pragma unroll
-                for (int r = 0; r < WR; r++) if (r == fr) { bx = wx[r]; by = wy[r]; bs = ws[r]; bf = wf[r]; }
-                bx = __shfl(bx, first & 63); by = __shfl(by, first & 63); bs = __shfl(bs, first & 63);
-                bf = __shfl(bf, first & 63);
-                cand[k] = first; n_cand = k + 1;
-                const OccBox sb = occ_box(c, p, (double)bx, (double)by, (double)bs);   // the box its seed joint will occupy
+            for (int r = 0; r < WR; r++) n_occ += __popcll(__ballot((occupied >> r) & 1u));
+            if (2 * n_occ >= WR * kWave) break;
+        }
+        // 2. candidates in seed order: the first pooled seed, then the next ones that do not fall into the
+        //    box an earlier candidate's own seed joint will occupy (the other cells of the same confidence
+        //    blob: dead as soon as that candidate is accepted).  Skipping them is a PREDICTION that costs
+        //    nothing when right and is verified by the walk below.
+        unsigned elig = occupied;
+        int cand[kAssocWaves], n_cand = 0;
 #pragma unroll
-                for (int r = 0; r < WR; r++)
-                    if (r == fr ? lane == (first & 63) : false) elig &= ~(1u << r);
+        for (int k = 0; k < kAssocWaves; k++) {
+            cand[k] = -1;
+            if (k >= S || n_cand < k) continue;
+            unsigned mn = 0xFFFFFFFFu;
 #pragma unroll
-                for (int r = 0; r < WR; r++)
-                    if (wf[r] == bf && box_contains(sb, wcx[r], wcy[r])) elig &= ~(1u << r);
+            for (int r = 0; r < WR; r++)
+                if ((elig >> r) & 1u) mn = min(mn, (unsigned)(s_if[r] & kIdxMask));
+            mn = ~wave_max_u32(~mn);
+            if (mn == 0xFFFFFFFFu) continue;
+            int pk = 0, fo = 0; bool own = false;
+#pragma unroll
+            for (int r = 0; r < WR; r++)
+                if (((elig >> r) & 1u) && (unsigned)(s_if[r] & kIdxMask) == mn) {
+                    pk = s_pack[r]; fo = (int)((unsigned)s_if[r] >> 24); own = true; elig &= ~(1u << r);
+                }
+            const int owner = __builtin_ctzll(__ballot(own));
+            pk = rlane(pk, owner); fo = rlane(fo, owner);
+            cand[k] = (int)mn; n_cand = k + 1;
+            const int ccx = pk & 0xfff, ccy = (pk >> 12) & 0xfff, half = (pk >> 24) & 0xff;
+#pragma unroll
+            for (int r = 0; r < WR; r++) {
+                const int dx = (s_pack[r] & 0xfff) - ccx, dy = ((s_pack[r] >> 12) & 0xfff) - ccy;
+                if ((int)((unsigned)s_if[r] >> 24) == fo && dx > -half && dx < half && dy > -half && dy < half)
+                    elig &= ~(1u << r);
             }
         }
-        if (n_cand == 0) { pos += kAssocThreads; continue; }
+        if (n_cand == 0) break;                      // pool empty and no seeds left
         OPA_TINC(c.t[9], 1);
-        // 3. speculative growth, one pose per wave, no barriers inside
-        if (wave < n_cand) {
-            int mine = pos;
+        OPA_TACC(c.t[10], tsel);
+        // 3. speculative growth, one pose per wave, no barriers inside (the pool waits in LDS meanwhile)
 #pragma unroll
-            for (int k = 0; k < kAssocWaves; k++) if (k == wave) mine += cand[k];
+        for (int r = 0; r < WR; r++) { pool_save[r * kWave] = s_pack[r]; pool_save[(WR + r) * kWave] = s_if[r]; }
+        if (wave < n_cand) {
+            int mine = 0;
+#pragma unroll
+            for (int k = 0; k < kAssocWaves; k++) if (k == wave) mine = cand[k];
             const int sf = seed_f[mine]; const float4 sd = seed_vxys[mine];
             for (int k = lane; k < K; k += kWave) { c.jv[k] = 0.0; c.jx[k] = 0.f; c.jy[k] = 0.f; c.js[k] = 0.f; }
             wave_sync();
             c.jv[sf] = (double)sd.x; c.jx[sf] = sd.y; c.jy[sf] = sd.z; c.js[sf] = sd.w;   // :213-218
             wave_sync();
-            OPA_T0(tg); grow(c, p, true, 1.0); OPA_TACC(c.t[4], tg);
+            OPA_T0(tg); grow_pose<REG>(c, p, rs, true, 1.0, false); OPA_TACC(c.t[4], tg);
             pose_boxes(c, p);
         }
+        OPA_T0(twait);
         __syncthreads();
-        // 4. resolve walk in seed order.  `unc` = live and not inside a box of a pose accepted in this
-        //    round, i.e. what the sequential loop would find free at that seed's turn (:211).  A candidate
-        //    that is still free is accepted; a free seed that is NOT a candidate (a wrong prediction)
-        //    ends the round there -- it becomes the first candidate of the next round.
-        OPA_T0(tm);
-        unsigned unc = live, acc_mask = 0u;
-        int prev = -1, stop = -1;
-        auto first_free_between = [&](int lo, int hi) -> int {     // window offsets in (lo, hi)
-            int first = -1;
+        OPA_TACC(c.t[11], twait);
 #pragma unroll
-            for (int r = WR - 1; r >= 0; r--) {
-                const int off = r * kWave + lane;
-                const unsigned long long m = __ballot(((unc >> r) & 1u) && off > lo && off < hi);
-                if (m) first = r * kWave + __builtin_ctzll(m);
+        for (int r = 0; r < WR; r++) { s_pack[r] = pool_save[r * kWave]; s_if[r] = pool_save[(WR + r) * kWave]; }
+        // 4. resolve walk in seed order.  `unc` = pooled and not inside a box of a pose accepted in this
+        //    round, i.e. what the sequential loop would find free at that seed's turn (:211).  A candidate
+        //    that is still free is accepted; a free seed that is NOT a candidate (a wrong prediction) ends
+        //    the round there and stays pooled -- it is the first candidate of the next round.
+        OPA_T0(tm);
+        unsigned unc = occupied, acc_mask = 0u;
+        int prev = -1, boundary = -1;
+        auto first_free_between = [&](int lo, int hi) -> int {     // smallest pooled free seed index in (lo, hi), or -1
+            unsigned mn = 0xFFFFFFFFu;
+#pragma unroll
+            for (int r = 0; r < WR; r++) {
+                const int idx = s_if[r] & kIdxMask;
+                if (((unc >> r) & 1u) && idx > lo && idx < hi) mn = min(mn, (unsigned)idx);
             }
-            return first;
+            if (__ballot(mn != 0xFFFFFFFFu) == 0ull) return -1;
+            return (int)~wave_max_u32(~mn);
         };
 #pragma unroll
         for (int k = 0; k < kAssocWaves; k++) {
-            if (k >= n_cand) break;
+            if (k >= n_cand || boundary >= 0) continue;
             const int ck = cand[k];
-            stop = first_free_between(prev, ck);
-            if (stop >= 0) break;
-            unsigned long long mk = 0ull;
+            boundary = first_free_between(prev, ck);
+            if (boundary >= 0) continue;
+            bool mine_free = false;
 #pragma unroll
-            for (int r = 0; r < WR; r++) {
-                const unsigned long long m = __ballot((unc >> r) & 1u);
-                if (r == (ck >> 6)) mk = m;
-            }
-            if ((mk >> (ck & 63)) & 1ull) {
+            for (int r = 0; r < WR; r++) mine_free |= ((unc >> r) & 1u) && (s_if[r] & kIdxMask) == ck;
+            if (__ballot(mine_free) != 0ull) {
                 acc_mask |= 1u << k;
                 const PoseView q = pose_of_wave(private_base, k, K, A);
 #pragma unroll
                 for (int r = 0; r < WR; r++)
-                    if (((unc >> r) & 1u) && box_contains(q.box[wf[r]], wcx[r], wcy[r])) unc &= ~(1u << r);
+                    if (((unc >> r) & 1u) &&
+                        box_contains(q.box[(unsigned)s_if[r] >> 24], s_pack[r] & 0xfff, (s_pack[r] >> 12) & 0xfff))
+                        unc &= ~(1u << r);
             }
             prev = ck;
         }
-        int next_pos;
-        if (stop >= 0) next_pos = pos + stop;
-        else if (n_cand == S) next_pos = pos + prev + 1;             // seeds behind the last candidate are undecided
-        else {                                                       // every live seed of the window was considered
-            stop = first_free_between(prev, kAssocThreads);
-            next_pos = stop >= 0 ? pos + stop : pos + kAssocThreads;
+        OPA_TINC(c.t[9], ((long long)n_cand << 32) + ((long long)__popc(acc_mask) << 48) + (boundary >= 0 ? (1 << 16) : 0));
+        if (boundary < 0) {
+            if (n_cand == S) boundary = prev + 1;                    // pooled seeds behind the last candidate are undecided
+            else {                                                   // every pooled seed was a candidate or predicted dead
+                boundary = first_free_between(prev, kIdxMask);
+                if (boundary < 0) boundary = kIdxMask;
+            }
         }
+        // decided seeds (before the boundary) and seeds that are dead now leave the pool
+#pragma unroll
+        for (int r = 0; r < WR; r++)
+            if ((s_if[r] & kIdxMask) < boundary || !((unc >> r) & 1u)) { occupied &= ~(1u << r); s_if[r] |= kIdxMask; }
         for (int g = 0; g < n_cand; g++)
             if ((acc_mask >> g) & 1u) {
                 const int rc = accept_pose(g, -1, n_kept);
@@ -811,7 +1098,6 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
             }
         sync_global();                        // marks and stored poses visible to every wave
         OPA_TACC(c.t[5], tm);
-        pos = next_pos;
     }
     __syncthreads();
 
@@ -829,9 +1115,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
                     c.jy[k] = (float)src[4 * k + 2]; c.js[k] = (float)src[4 * k + 3];
                 }
                 wave_sync();
-                grow(c, p, false, 4.0);       // :419-425
-                flood_fill(c);                // :235
-                wave_sync();
+                grow_pose<REG>(c, p, rs, false, 4.0, true);   // :419-425, :235
                 for (int k = lane; k < K; k += kWave) {
                     src[4 * k + 0] = c.jv[k]; src[4 * k + 1] = (double)c.jx[k];
                     src[4 * k + 2] = (double)c.jy[k]; src[4 * k + 3] = (double)c.js[k];
@@ -863,7 +1147,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     // iff its cell lies in the box of an earlier, still unsuppressed joint (= Occupancy::get after the
     // earlier Occupancy::set calls).  Boxes and cells of the field sit in this wave's LDS scratch.
     {
-        unsigned char* nsp = private_base + (size_t)wave * nms_scratch_bytes(a.max_ann);
+        unsigned char* nsp = work_base + (size_t)wave * nms_scratch_bytes(a.max_ann);
         OccBox* my_box = (OccBox*)nsp;
         int2* my_cell = (int2*)(nsp + sizeof(OccBox) * a.max_ann);
         for (int k = wave; k < K; k += kAssocWaves) {
@@ -949,31 +1233,38 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     OPA_TACC(c.t[6], t_nms); OPA_TACC(c.t[7], t_total);
     c.t[3] = c.t[7] - c.t[4] - c.t[5] - c.t[6];           // seed scanning + waiting for the slowest grower
     c.t[8] = clock64() - cyc0;
-    if (tid == 0) for (int k = 0; k < 10; k++) reinterpret_cast<long long*>(anns)[k] = c.t[k];   // scratch is free now
+    if (tid == 0) for (int k = 0; k < 12; k++) reinterpret_cast<long long*>(anns)[k] = c.t[k];   // scratch is free now
 #endif
 }
 
 hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
     const int K = a.K, A = a.A, E = 2 * A;
     const int KC = (K + kWave - 1) / kWave;
-    if (a.occ_w > 32767 || a.occ_h > 32767) return hipErrorInvalidValue;
+    // the seed pool packs cell coordinates into 12 bits, the field into 8 and the seed index into 24
+    if (a.occ_w > 4096 || a.occ_h > 4096 || K > 256 || a.seed_cap > 0xFFFFFF) return hipErrorInvalidValue;
     const size_t shared = sizeof(double) * a.max_ann
                         + sizeof(unsigned long long) * ((size_t)a.max_ann * KC)
                         + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann) + 32;
+    // work area behind it: blend targets + seed pool of every wave + one private block per grower while
+    // poses grow, the keypoint-NMS scratch afterwards
+    const size_t fixed = sizeof(int) * 2 * 8 * kWave * kAssocWaves + sizeof(float) * 3 * kBlendChunks * kWave * kAssocWaves;
     const size_t priv = assoc_private_bytes(K, A);
     const size_t budget = 160 * 1024;
-    if (shared + priv > budget) return hipErrorInvalidValue;
-    int growers = (int)((budget - shared) / priv);
+    if (shared + fixed + priv > budget) return hipErrorInvalidValue;
+    int growers = (int)((budget - shared - fixed) / priv);
     if (growers > kAssocWaves) growers = kAssocWaves;
     const size_t nms = (size_t)kAssocWaves * nms_scratch_bytes(a.max_ann);
     if (shared + nms > budget) return hipErrorInvalidValue;
-    const size_t lds = shared + ((size_t)growers * priv > nms ? (size_t)growers * priv : nms);
+    const size_t grow_bytes = fixed + (size_t)growers * priv;
+    const size_t lds = shared + (grow_bytes > nms ? grow_bytes : nms);
+    const bool reg = K <= kWave && E <= kWave;       // pose, frontier and heap fit the lanes of a wave
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)cifcaf_assoc_kernel,
+        hipError_t e = hipFuncSetAttribute(reg ? (const void*)cifcaf_assoc_kernel<true> : (const void*)cifcaf_assoc_kernel<false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    cifcaf_assoc_kernel<<<a.B, kAssocThreads, lds, st>>>(a, sk, p, growers);
+    if (reg) cifcaf_assoc_kernel<true><<<a.B, kAssocThreads, lds, st>>>(a, sk, p, growers);
+    else cifcaf_assoc_kernel<false><<<a.B, kAssocThreads, lds, st>>>(a, sk, p, growers);
     prof_mark(st, "cifcaf_assoc_kernel");
     return hipGetLastError();
 }
@@ -986,8 +1277,9 @@ __global__ __launch_bounds__(64) void blend_rows_kernel(const float* rows, int n
     for (int i = lane; i < n; i += kWave)
         for (int k = 0; k < 7; k++) soa[(size_t)k * n + i] = rows[(size_t)i * 7 + k];
     __threadfence_block();
+    __shared__ float tgt[3 * kBlendChunks * kWave];
     ListView L; L.base = soa; L.cap = n; L.n = n;
-    const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, s, filter_sigmas, only_max);
+    const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, s, filter_sigmas, only_max, tgt);
     if (lane == 0) {
         if (r.ok) { out4[0] = (double)r.x; out4[1] = (double)r.y; out4[2] = (double)r.s; out4[3] = r.v; }
         else { out4[0] = 0.0; out4[1] = 0.0; out4[2] = 0.0; out4[3] = 0.0; }

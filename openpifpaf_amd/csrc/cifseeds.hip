@@ -89,7 +89,8 @@ __device__ __forceinline__ void compare_exchange_desc(unsigned long long& a, uns
 __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
         unsigned long long* keys, int sort_cap, int cap, const int32_t* __restrict__ seed_count,
         const float* __restrict__ cif, int F, int NC, int HW, int stride,
-        int32_t* __restrict__ seed_f, float* __restrict__ seed_vxys) {
+        int32_t* __restrict__ seed_f, float* __restrict__ seed_vxys,
+        int32_t* __restrict__ seed_cell, int occ_h, int occ_w, DevParams p) {
     __shared__ unsigned long long sk[kSortLdsKeys];
     const int b = blockIdx.x, tid = threadIdx.x;
     unsigned long long* K = keys + (size_t)b * sort_cap;
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
         r.y = P[2 * HW + o] * (float)stride;
         r.z = P[3 * HW + o] * (float)stride;
         r.w = P[4 * HW + o] * (float)stride;                        // cif_seeds.cpp:61
+        if (seed_cell) seed_cell[(size_t)b * cap + t] = seed_cell_pack(p, occ_h, occ_w, (double)r.y, (double)r.z, (double)r.w);
         if (NC == 5) {
             reinterpret_cast<float4*>(sv)[t] = r;
         } else {                                                    // cif_seeds.cpp:85-87
@@ -176,7 +178,8 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
 hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int stride,
                            const float* cifhr, int hr_rows, int hr_cols, int hr_pitch, const DevParams& p,
                            unsigned long long* keys, int sort_cap, int32_t* seed_count,
-                           int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det) {
+                           int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det,
+                           int32_t* seed_cell, int occ_h, int occ_w) {
     const int HW = H * W, cap = F * HW, NC = det ? 6 : 5;
     hipError_t e = hipMemsetAsync(seed_count, 0, sizeof(int32_t) * B, st);
     if (e != hipSuccess) return e;
@@ -187,7 +190,7 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
                                                det ? 0 : p.ablation_cifseeds_no_rescore, keys, sort_cap, cap, seed_count);
     prof_mark(st, "cifseeds_fill_kernel");
     cifseeds_sort_kernel<<<B, 1024, 0, st>>>(keys, sort_cap, cap, seed_count, cif, F, NC, HW, stride,
-                                             seed_f, seed_vxys);
+                                             seed_f, seed_vxys, seed_cell, occ_h, occ_w, p);
     prof_mark(st, "cifseeds_sort_kernel");
     return hipGetLastError();
 }

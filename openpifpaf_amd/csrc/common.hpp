@@ -27,7 +27,7 @@ struct Layout {
     int sort_cap;                         // next pow2 >= cif_cells
     // byte offsets into the workspace (all 256-B aligned)
     size_t off_cifhr, off_act, off_act_count, off_seed_keys, off_seed_count,
-           off_seed_f, off_seed_vxys, off_lists, off_list_counts,
+           off_seed_f, off_seed_vxys, off_seed_cell, off_lists, off_list_counts,
            off_lists_fc, off_list_counts_fc, off_occ, off_anns, off_ann_meta, off_status,
            total;
 };
@@ -70,7 +70,8 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
 hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int stride,
                            const float* cifhr, int hr_rows, int hr_cols, int hr_pitch, const DevParams& p,
                            unsigned long long* keys, int sort_cap, int32_t* seed_count,
-                           int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det = false);
+                           int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det = false,
+                           int32_t* seed_cell = nullptr, int occ_h = 0, int occ_w = 0);
 
 hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
@@ -83,6 +84,7 @@ struct AssocArgs {
     int occ_h, occ_w;
     int seed_cap, list_cap;
     const int32_t* seed_f; const float* seed_vxys; const int32_t* seed_count;
+    const int32_t* seed_cell;  // occupancy cell of the seed: x | y << 12 | box half-width << 24 (seed_cell_pack)
     const float* lists; const int32_t* list_counts;          // caf_th lists
     const float* lists_fc; const int32_t* list_counts_fc;    // force-complete lists (or null)
     unsigned char* occ;
@@ -128,6 +130,10 @@ __device__ __forceinline__ void sync_global() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
+// Occupancy cell of a seed and the half-width of the box its joint occupies (occupancy.cpp:13-43),
+// packed for the association kernel's seed pool: x | y << 12 | half << 24.
+__device__ __forceinline__ int seed_cell_pack(const DevParams& p, int occ_h, int occ_w, double x, double y, double sigma);
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
 
 __device__ __forceinline__ long long clampll(long long v, long long lo, long long hi) {
@@ -141,6 +147,16 @@ __device__ __forceinline__ long long trunc_ll(double v) { return (long long)v; }
 
 // Reference cifhr_value (cif_seeds.cpp:17-30 == caf_scored.cpp:15-26) on the raw
 // revision-1 buffer: 0 = untouched (-> default), else 1 + value.
+__device__ __forceinline__ int seed_cell_pack(const DevParams& p, int occ_h, int occ_w, double x, double y, double sigma) {
+    if (p.occupancy_reduction != 1.0) {
+        x /= p.occupancy_reduction; y /= p.occupancy_reduction;
+        sigma = fmax(p.occupancy_min_scale_reduced, sigma / p.occupancy_reduction);
+    }
+    const int xi = (int)clampll(trunc_ll(x), 0, occ_w - 1), yi = (int)clampll(trunc_ll(y), 0, occ_h - 1);
+    const int half = (int)fmin(fmax(sigma, 1.0), 255.0);
+    return xi | (yi << 12) | (half << 24);
+}
+
 __device__ __forceinline__ float cifhr_value(const float* hr_image, int F, int rows, int cols, int pitch,
                                              long long f, float x, float y, float default_value) {
     const float max_x = (float)((double)(float)cols - 0.51);

@@ -21,9 +21,9 @@ per_image = dec.max_annotations * 17 * 4
 names = ['blend', '#blend', '#blend_iters', 'seeds+rest', 'grow', 'mark', 'nms', 'total']
 print('wall_clock64 ticks are 100 MHz (10 ns)')
 for b in range(B):
-    t = scratch[b * per_image:b * per_image + 10]
+    t = scratch[b * per_image:b * per_image + 12]
     n_seeds = int(dec.workspace_view('seed_count', torch.int32)[b])
     print('image %d people %2d poses %2d seeds %5d | ' % (b, synth.PEOPLE_CYCLE[b % 8], int(counts[b]), n_seeds)
           + '  '.join('%s=%d' % (n, v) for n, v in zip(names, t)) + '  shader clock %.0f MHz' % (t[8] / max(1, t[7]) * 100)
-          + '  | us: total %.0f grow %.0f blend %.0f (%.2f us/blend, %.1f iters/blend) seeds %.0f mark %.0f nms %.0f rounds %d' % (
-              t[7] / 100, t[4] / 100, t[0] / 100, t[0] / 100 / max(1, t[1]), t[2] / max(1, t[1]), t[3] / 100, t[5] / 100, t[6] / 100, t[9]))
+          + '  | us: total %.0f grow %.0f blend %.0f (%.2f us/blend, %.1f iters/blend) seeds %.0f mark %.0f nms %.0f rounds %d (stopped early %d) grown %d accepted %d select %.0f wait %.0f' % (
+              t[7] / 100, t[4] / 100, t[0] / 100, t[0] / 100 / max(1, t[1]), t[2] / max(1, t[1]), t[3] / 100, t[5] / 100, t[6] / 100, t[9] & 0xffff, (t[9] >> 16) & 0xffff, (t[9] >> 32) & 0xffff, (t[9] >> 48) & 0xffff, t[10] / 100, t[11] / 100))
