@@ -761,8 +761,8 @@ __device__ __forceinline__ void occ_fill(const ImageCtx& c, int f, const OccBox&
 __host__ __device__ inline size_t assoc_private_bytes(int K, int A) {
     const int P4 = 4 * A, E = 2 * A;
     const size_t b = 16 * (size_t)K + sizeof(double) * (K + P4) + sizeof(unsigned long long) * P4
-                   + sizeof(float) * (3 * K + 3 * P4) + sizeof(int) * P4 + E;
-    return (b + 15) / 16 * 16;
+                   + sizeof(float) * (3 * K + 3 * P4) + sizeof(int) * P4 + (E + 15) / 16 * 16;
+    return (b + 15) / 16 * 16 + sizeof(float) * 3 * kBlendChunks * kWave;      // + blend target columns
 }
 
 // LDS scratch of one wave during keypoint NMS (aliases the growth state): a box and a cell per pose
@@ -840,11 +840,9 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     int* nms_order = (int*)sp; sp += sizeof(int) * a.max_ann;
     int* nms_rank = (int*)sp; sp += sizeof(int) * a.max_ann;
     sp = smem + (((size_t)(sp - smem) + 15) & ~(size_t)15);
-    unsigned char* work_base = sp;                   // growth phase: targets | pool | private blocks; NMS phase: scratch
-    c.tgt = (float*)sp + (size_t)wave * (3 * kBlendChunks * kWave);
-    sp += sizeof(float) * 3 * kBlendChunks * kWave * kAssocWaves;
-    int* pool_save = (int*)sp + (size_t)wave * (2 * 8 * kWave) + lane;   // this wave's seed pool while a pose grows
-    sp += sizeof(int) * 2 * 8 * kWave * kAssocWaves;
+    unsigned char* work_base = sp;                   // growth phase: pool | private blocks; NMS phase: scratch
+    int* pool_save = (int*)sp + lane;                // the seed pool while poses grow (every wave holds and writes the same values)
+    sp += sizeof(int) * 2 * 8 * kWave;
     unsigned char* private_base = sp;
     sp += (size_t)(wave < S ? wave : 0) * assoc_private_bytes(K, A);   // waves >= S never touch theirs
     c.jbox = (OccBox*)sp; sp += sizeof(OccBox) * K;
@@ -858,7 +856,8 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     c.e_y = (float*)sp; sp += sizeof(float) * P4;
     c.e_s = (float*)sp; sp += sizeof(float) * P4;
     c.e_se = (int*)sp; sp += sizeof(int) * P4;
-    c.in_frontier = sp;
+    c.in_frontier = sp; sp += (E + 15) / 16 * 16;
+    c.tgt = (float*)sp;
     c.heap_n = 0; c.n_entries = 0;
     for (int k = 0; k < 12; k++) c.t[k] = 0;
     OPA_T0(t_total);
@@ -1245,9 +1244,9 @@ hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevPara
     const size_t shared = sizeof(double) * a.max_ann
                         + sizeof(unsigned long long) * ((size_t)a.max_ann * KC)
                         + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann) + 32;
-    // work area behind it: blend targets + seed pool of every wave + one private block per grower while
-    // poses grow, the keypoint-NMS scratch afterwards
-    const size_t fixed = sizeof(int) * 2 * 8 * kWave * kAssocWaves + sizeof(float) * 3 * kBlendChunks * kWave * kAssocWaves;
+    // work area behind it: the seed pool + one private block per grower while poses grow, the
+    // keypoint-NMS scratch afterwards
+    const size_t fixed = sizeof(int) * 2 * 8 * kWave;
     const size_t priv = assoc_private_bytes(K, A);
     const size_t budget = 160 * 1024;
     if (shared + fixed + priv > budget) return hipErrorInvalidValue;
