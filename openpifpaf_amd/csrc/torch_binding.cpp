@@ -6,9 +6,12 @@
 // (export_torchscript.py:15-43) and loaded from C++ (cpp/cli_video.cpp:48-64).  This file is the
 // same surface for the HIP path, under the namespaces
 //     torch.ops.openpifpaf_amd.set_quiet
-//     torch.classes.openpifpaf_amd_decoder.CifCaf          (+ call_batch)
+//     torch.classes.openpifpaf_amd_decoder.{CifCaf,CifDet} (+ call_batch)
 //     torch.ops.openpifpaf_amd_decoder.grow_connection_blend
-//     torch.classes.openpifpaf_amd_decoder_utils.{CifHr,CifSeeds,CafScored,NMSKeypoints}  (static tunables)
+//     torch.classes.openpifpaf_amd_decoder_utils.{CifHr,CifSeeds,CafScored} (stage objects + static tunables),
+//                                               NMSKeypoints (static tunables)
+// Not exported: Occupancy / CifDetSeeds (module.cpp:66-73,96-102) -- the HIP path has no standalone
+// occupancy object (poses are tested inside the association kernel).
 // It contains no compute: every method marshals tensors into the C ABI of libopenpifpaf_amd.so.
 // Host C++ only (g++); built by openpifpaf_amd/build.py into lib/libopenpifpaf_amd_torch.so.
 #include <torch/script.h>
@@ -143,10 +146,164 @@ struct CifCaf : torch::CustomClassHolder {
     }
 };
 
-// static-only holders for the utility classes' tunables (module.cpp:75-117)
-struct CifHrStatics : torch::CustomClassHolder {};
-struct CifSeedsStatics : torch::CustomClassHolder {};
-struct CafScoredStatics : torch::CustomClassHolder {};
+// module.cpp:57-62
+struct CifDet : torch::CustomClassHolder {
+    static int64_t max_detections_before_nms;        // cifdet.cpp:16
+    torch::Tensor workspace;
+
+    std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> call_batch(const torch::Tensor& field_in,
+                                                                                       int64_t stride) {
+        torch::Tensor field = to_device_f32(field_in);
+        TORCH_CHECK(field.dim() == 5 && field.size(2) == 6, "expected a CifDet field [B,F,6,H,W]");
+        opa_det_shape s;
+        s.batch = (int32_t)field.size(0); s.n_fields = (int32_t)field.size(1);
+        s.field_h = (int32_t)field.size(3); s.field_w = (int32_t)field.size(4);
+        s.stride = (int32_t)stride; s.max_detections = (int32_t)max_detections_before_nms;
+        const size_t need = opa_cifdet_workspace_bytes(&s);
+        TORCH_CHECK(need > 0, "opa_cifdet_workspace_bytes: ", opa_last_error());
+        if (!workspace.defined() || (size_t)workspace.numel() < need || workspace.device() != field.device())
+            workspace = torch::empty({(int64_t)need}, torch::dtype(torch::kUInt8).device(field.device()));
+        auto opts = torch::TensorOptions().device(field.device());
+        const int64_t M = s.max_detections;
+        torch::Tensor cat = torch::empty({s.batch, M}, opts.dtype(torch::kInt64));
+        torch::Tensor sc = torch::empty({s.batch, M}, opts.dtype(torch::kFloat32));
+        torch::Tensor bx = torch::empty({s.batch, M, 4}, opts.dtype(torch::kFloat32));
+        torch::Tensor cnt = torch::empty({s.batch}, opts.dtype(torch::kInt32));
+        check(opa_cifdet_decode(&s, nullptr, field.data_ptr<float>(), workspace.data_ptr(), (size_t)workspace.numel(),
+                                cat.data_ptr<int64_t>(), sc.data_ptr<float>(), bx.data_ptr<float>(),
+                                cnt.data_ptr<int32_t>(), current_stream(field)),
+              "opa_cifdet_decode");
+        return std::make_tuple(cat, sc, bx, cnt);
+    }
+
+    std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> call(const torch::Tensor& field, int64_t stride) {
+        auto [cat, sc, bx, cnt] = call_batch(field.unsqueeze(0), stride);
+        const int64_t n = cnt.cpu().item<int32_t>();
+        torch::Tensor c = cat[0].narrow(0, 0, n).clone(), v = sc[0].narrow(0, 0, n).clone(),
+                      b = bx[0].narrow(0, 0, n).clone();
+        if (!field.is_cuda()) { c = c.cpu(); v = v.cpu(); b = b.cpu(); }
+        return std::make_tuple(c, v, b);
+    }
+};
+int64_t CifDet::max_detections_before_nms = 120;
+
+// The pitched layout the stage entry points share: [F, rows, pitch] with pitch = opa_cifhr_pitch.
+// `hr` may be the view get_accumulated() returned (used in place) or any [F, rows, cols] tensor (copied).
+torch::Tensor pitched_cifhr(const torch::Tensor& hr_in) {
+    TORCH_CHECK(hr_in.dim() == 3, "cifhr must be [F, rows, cols]");
+    torch::Tensor hr = hr_in;
+    if (!hr.is_cuda()) hr = hr.to(torch::Device(torch::kCUDA, c10::hip::current_device()));
+    if (hr.scalar_type() != torch::kFloat32) hr = hr.to(torch::kFloat32);
+    const int64_t F = hr.size(0), rows = hr.size(1), cols = hr.size(2);
+    const int64_t pitch = opa_cifhr_pitch((int32_t)cols, 1);
+    if (hr.stride(2) == 1 && hr.stride(1) == pitch && hr.stride(0) == rows * pitch) return hr;
+    torch::Tensor buf = torch::zeros({F, rows, pitch}, hr.options());
+    buf.narrow(2, 0, cols).copy_(hr);
+    return buf.narrow(2, 0, cols);
+}
+
+// module.cpp:75-84
+struct CifHr : torch::CustomClassHolder {
+    torch::Tensor accumulated;       // [F, rows, pitch]
+    torch::Tensor scratch;
+    int64_t cols = 0;
+    double revision = 0.0;
+
+    void reset(std::vector<int64_t> shape, int64_t stride) {      // sizes are taken from the field in accumulate()
+        accumulated = torch::Tensor(); cols = 0; revision = 0.0;
+    }
+    void accumulate(const torch::Tensor& cif_in, int64_t stride, double min_scale, double factor) {
+        torch::Tensor cif = to_device_f32(cif_in);
+        TORCH_CHECK(cif.dim() == 4 && cif.size(1) == 5, "expected a CIF field [F,5,H,W]");
+        const int32_t F = (int32_t)cif.size(0), H = (int32_t)cif.size(2), W = (int32_t)cif.size(3);
+        const int64_t rows = (int64_t)(H - 1) * stride + 1, pitch = opa_cifhr_pitch(W, (int32_t)stride);
+        cols = (int64_t)(W - 1) * stride + 1;
+        accumulated = torch::empty({F, rows, pitch}, cif.options());
+        const size_t nbytes = opa_cifhr_scratch_bytes(1, F, H, W);
+        scratch = torch::empty({(int64_t)nbytes}, torch::dtype(torch::kUInt8).device(cif.device()));
+        check(opa_cifhr_accumulate(cif.data_ptr<float>(), 1, F, H, W, (int32_t)stride, min_scale, factor, nullptr,
+                                   accumulated.data_ptr<float>(), scratch.data_ptr(), nbytes, current_stream(cif)),
+              "opa_cifhr_accumulate");
+        revision = 1.0;
+    }
+    std::tuple<torch::Tensor, double> get_accumulated() {
+        TORCH_CHECK(accumulated.defined(), "CifHr.accumulate() has not been called");
+        return std::make_tuple(accumulated.narrow(2, 0, cols), revision);
+    }
+};
+
+// module.cpp:86-94
+struct CifSeeds : torch::CustomClassHolder {
+    torch::Tensor hr;                // view [F, rows, cols] on a pitched buffer
+    torch::Tensor f, vxys, count, scratch;
+
+    CifSeeds(const torch::Tensor& cifhr, double revision) : hr(pitched_cifhr(cifhr)) {
+        TORCH_CHECK(revision == 1.0, "the HIP path stores the map at revision 1.0 (a fresh reference instance)");
+    }
+    void fill(const torch::Tensor& cif_in, int64_t stride) {
+        torch::Tensor cif = to_device_f32(cif_in);
+        TORCH_CHECK(cif.dim() == 4 && cif.size(1) == 5, "expected a CIF field [F,5,H,W]");
+        const int32_t F = (int32_t)cif.size(0), H = (int32_t)cif.size(2), W = (int32_t)cif.size(3);
+        TORCH_CHECK(hr.size(0) == F && hr.size(1) == (int64_t)(H - 1) * stride + 1 && hr.size(2) == (int64_t)(W - 1) * stride + 1,
+                    "cifhr does not match the field shape and stride");
+        const int64_t cap = (int64_t)F * H * W;
+        auto opts = torch::TensorOptions().device(cif.device());
+        f = torch::empty({cap}, opts.dtype(torch::kInt32));
+        vxys = torch::empty({cap, 4}, opts.dtype(torch::kFloat32));
+        count = torch::empty({1}, opts.dtype(torch::kInt32));
+        const size_t nbytes = opa_cifseeds_scratch_bytes(1, F, H, W);
+        scratch = torch::empty({(int64_t)nbytes}, opts.dtype(torch::kUInt8));
+        check(opa_cifseeds_fill(cif.data_ptr<float>(), 1, F, H, W, (int32_t)stride, hr.data_ptr<float>(), nullptr,
+                                f.data_ptr<int32_t>(), vxys.data_ptr<float>(), count.data_ptr<int32_t>(),
+                                scratch.data_ptr(), nbytes, current_stream(cif)),
+              "opa_cifseeds_fill");
+    }
+    std::tuple<torch::Tensor, torch::Tensor> get() {              // cif_seeds.cpp:93-114
+        TORCH_CHECK(count.defined(), "CifSeeds.fill() has not been called");
+        const int64_t n = count.cpu().item<int32_t>();
+        return std::make_tuple(f.narrow(0, 0, n).to(torch::kInt64), vxys.narrow(0, 0, n).clone());
+    }
+};
+
+// module.cpp:104-111
+struct CafScored : torch::CustomClassHolder {
+    torch::Tensor hr, lists, counts;
+    double score_th, cif_floor;
+
+    CafScored(const torch::Tensor& cifhr, double revision, double score_th_, double cif_floor_)
+        : hr(pitched_cifhr(cifhr)), score_th(score_th_), cif_floor(cif_floor_) {
+        TORCH_CHECK(revision == 1.0, "the HIP path stores the map at revision 1.0 (a fresh reference instance)");
+    }
+    void fill(const torch::Tensor& caf_in, int64_t stride, const torch::Tensor& skeleton) {
+        torch::Tensor caf = to_device_f32(caf_in);
+        TORCH_CHECK(caf.dim() == 4 && caf.size(1) == 8, "expected a CAF field [A,8,H,W]");
+        TORCH_CHECK(skeleton.dtype() == torch::kInt64, "skeleton must be of type LongTensor");
+        const int32_t A = (int32_t)caf.size(0), H = (int32_t)caf.size(2), W = (int32_t)caf.size(3);
+        torch::Tensor skel = skeleton.to(caf.device()).contiguous();
+        auto opts = torch::TensorOptions().device(caf.device());
+        lists = torch::empty({A, 2, 7, (int64_t)H * W}, opts.dtype(torch::kFloat32));
+        counts = torch::empty({A, 2}, opts.dtype(torch::kInt32));
+        // the map's own size is all the stage needs: describe it as a stride-1 field of that size
+        check(opa_cafscored_fill(caf.data_ptr<float>(), 1, A, H, W, (int32_t)stride, hr.data_ptr<float>(),
+                                 (int32_t)hr.size(0), (int32_t)hr.size(1), (int32_t)hr.size(2), 1,
+                                 skel.data_ptr<int64_t>(), score_th, cif_floor, nullptr,
+                                 lists.data_ptr<float>(), counts.data_ptr<int32_t>(), current_stream(caf)),
+              "opa_cafscored_fill");
+    }
+    std::tuple<std::vector<torch::Tensor>, std::vector<torch::Tensor>> get() {   // caf_scored.cpp:86-104
+        TORCH_CHECK(counts.defined(), "CafScored.fill() has not been called");
+        torch::Tensor cnt = counts.cpu();
+        auto acc = cnt.accessor<int32_t, 2>();
+        std::vector<torch::Tensor> fwd, bwd;
+        for (int64_t a = 0; a < lists.size(0); a++) {
+            fwd.push_back(lists[a][0].narrow(1, 0, acc[a][0]).t().contiguous());
+            bwd.push_back(lists[a][1].narrow(1, 0, acc[a][1]).t().contiguous());
+        }
+        return std::make_tuple(fwd, bwd);
+    }
+};
+
+// static-only holder (module.cpp:113-117)
 struct NMSKeypointsStatics : torch::CustomClassHolder {};
 
 std::vector<double> grow_connection_blend(const torch::Tensor& caf, double x, double y, double s,
@@ -188,20 +345,36 @@ TORCH_LIBRARY(openpifpaf_amd_decoder, m) {
                 return c10::make_intrusive<CifCaf>(std::get<0>(state), std::get<1>(state));
             });
     m.def("grow_connection_blend", grow_connection_blend);                               // :55
+    m.class_<CifDet>("CifDet")                                                           // :57-62
+        .def_static("set_max_detections_before_nms", [](int64_t v) { CifDet::max_detections_before_nms = v; })
+        .def_static("get_max_detections_before_nms", []() { return CifDet::max_detections_before_nms; })
+        .def(torch::init<>())
+        .def("call", &CifDet::call)
+        .def("call_batch", &CifDet::call_batch);
 }
 
 TORCH_LIBRARY(openpifpaf_amd_decoder_utils, m) {
-    m.class_<CifHrStatics>("CifHr")                                                      // :75-79
+    m.class_<CifHr>("CifHr")                                                             // :75-84
         OPA_STATIC_GETSET_AS(neighbors, cifhr_neighbors, int64_t)
         OPA_STATIC_GETSET_AS(threshold, cif_threshold, double)
-        OPA_STATIC_GETSET_AS(ablation_skip, ablation_cifhr_skip, bool);
-    m.class_<CifSeedsStatics>("CifSeeds")                                                // :86-90
+        OPA_STATIC_GETSET_AS(ablation_skip, ablation_cifhr_skip, bool)
+        .def(torch::init<>())
+        .def("accumulate", &CifHr::accumulate)
+        .def("get_accumulated", &CifHr::get_accumulated)
+        .def("reset", &CifHr::reset);
+    m.class_<CifSeeds>("CifSeeds")                                                       // :86-94
         OPA_STATIC_GETSET_AS(threshold, seed_threshold, double)
         OPA_STATIC_GETSET_AS(ablation_nms, ablation_cifseeds_nms, bool)
-        OPA_STATIC_GETSET_AS(ablation_no_rescore, ablation_cifseeds_no_rescore, bool);
-    m.class_<CafScoredStatics>("CafScored")                                              // :104-107
+        OPA_STATIC_GETSET_AS(ablation_no_rescore, ablation_cifseeds_no_rescore, bool)
+        .def(torch::init<const torch::Tensor&, double>())
+        .def("fill", &CifSeeds::fill)
+        .def("get", &CifSeeds::get);
+    m.class_<CafScored>("CafScored")                                                     // :104-111
         OPA_STATIC_GETSET_AS(default_score_th, caf_threshold, double)
-        OPA_STATIC_GETSET_AS(ablation_no_rescore, ablation_caf_no_rescore, bool);
+        OPA_STATIC_GETSET_AS(ablation_no_rescore, ablation_caf_no_rescore, bool)
+        .def(torch::init<const torch::Tensor&, double, double, double>())
+        .def("fill", &CafScored::fill)
+        .def("get", &CafScored::get);
     m.class_<NMSKeypointsStatics>("NMSKeypoints")                                        // :113-117
         OPA_STATIC_GETSET_AS(instance_threshold, nms_instance_threshold, double)
         OPA_STATIC_GETSET_AS(keypoint_threshold, nms_keypoint_threshold, double)

@@ -114,3 +114,53 @@ def test_binding_batch_cifhr_initial_annotations_and_blend(coco_skeleton0):
     got = torch.ops.openpifpaf_amd_decoder.grow_connection_blend(rows, 10.0, 10.0, 4.0, 1.0, False)
     want = native.grow_connection_blend(rows, 10.0, 10.0, 4.0, 1.0, False)
     assert list(got) == list(want)
+
+
+@pytest.mark.gpu
+def test_binding_stage_objects_and_cifdet_equal_the_ctypes_mirror(coco_skeleton0):
+    """openpifpaf_amd_decoder_utils.{CifHr,CifSeeds,CafScored} and openpifpaf_amd_decoder.CifDet used the way
+    the reference's tests/tools use theirs (module.cpp:57-111)."""
+    from openpifpaf_amd import native, synth, torchscript
+    torchscript.load()
+    U = torch.classes.openpifpaf_amd_decoder_utils
+    cif, caf = synth.synth_fields(50, 4, height=41, width=41)
+    cif_t, caf_t = torch.from_numpy(cif).cuda(), torch.from_numpy(caf).cuda()
+    skel = torch.from_numpy(coco_skeleton0)
+    # reference call sequence: reset, accumulate, get_accumulated -> seeds / caf lists built from the map
+    hr = U.CifHr()
+    hr.reset(list(cif.shape), 8)
+    hr.accumulate(cif_t, 8, 0.0, 1.0)
+    acc, rev = hr.get_accumulated()
+    want_hr = native.CifHr()
+    want_hr.accumulate(cif_t, 8)
+    assert rev == 1.0 and torch.equal(acc, want_hr.get_accumulated()[0])
+    seeds = U.CifSeeds(acc, rev)
+    seeds.fill(cif_t, 8)
+    f, vxys = seeds.get()
+    want_seeds = native.CifSeeds(want_hr)
+    want_seeds.fill(cif_t, 8)
+    wf, wv = want_seeds.get()
+    assert len(f) > 0 and torch.equal(f, wf) and torch.equal(vxys, wv)
+    # a plain contiguous copy of the map (not the pitched view) must work too
+    seeds2 = U.CifSeeds(acc.contiguous().cpu(), rev)
+    seeds2.fill(cif_t, 8)
+    assert torch.equal(seeds2.get()[1], wv)
+    scored = U.CafScored(acc, rev, -1.0, 0.1)
+    scored.fill(caf_t, 8, skel)
+    fwd, bwd = scored.get()
+    want_scored = native.CafScored(want_hr, cif.shape, 8)
+    want_scored.fill(caf_t, 8, skel)
+    wfwd, wbwd = want_scored.get()
+    assert len(fwd) == 19 and sum(len(x) for x in fwd) > 0
+    assert all(torch.equal(a, b) for a, b in zip(fwd, wfwd)) and all(torch.equal(a, b) for a, b in zip(bwd, wbwd))
+    with pytest.raises(RuntimeError, match='revision'):
+        U.CifSeeds(acc, 2.0)
+    # CifDet
+    D = torch.classes.openpifpaf_amd_decoder.CifDet
+    assert D.get_max_detections_before_nms() == 120
+    field = torch.from_numpy(synth.synth_det_field(3, 5, height=33, width=41))
+    cat, sc, bx = D().call(field.cuda(), 8)
+    wcat, wsc, wbx = native.CifDet().call(field.cuda(), 8)
+    assert len(cat) > 0 and torch.equal(cat, wcat) and torch.equal(sc, wsc) and torch.equal(bx, wbx)
+    cat_c, _, _ = D().call(field, 8)
+    assert not cat_c.is_cuda and torch.equal(cat_c, cat.cpu())
