@@ -12,16 +12,19 @@
 // :265-411).  So poses are grown SPECULATIVELY in parallel and only the accept/reject
 // decision is sequential:
 //
-//   round:  512 sorted seeds are tested against the occupancy map at once (ballot);
-//           the first S live ones become candidates, one per wavefront;
-//           every wave grows its candidate's pose on its own (private LDS state, no
-//           barriers): best-first search with the reference's lazy frontier;
-//           resolve in seed order: candidate c is accepted iff its cell is not inside a joint
-//           box of a pose accepted before it in this round (tested analytically) -- exactly the
-//           seeds the sequential loop would accept, with exactly the poses it would
-//           grow.  Seeds of the same person turn into discarded work, distinct persons
-//           into parallel speed-up (a 20-person image needs ~3 rounds instead of 20
-//           sequential growths).
+//   pool:   every wave keeps the same pool of up to 512 live, undecided seeds (8 slots per lane);
+//           a seed is fetched and tested against the occupancy map once, when it enters the pool;
+//           selection and the walk below run redundantly in every wave -- no barriers, no exchange;
+//   round:  candidates = the first pooled seed in score order, then the next ones outside the box an
+//           earlier candidate's own seed joint will occupy (the rest of its confidence blob), up to
+//           one per wavefront; every wave grows its candidate's pose on its own (no barriers):
+//           best-first search with the reference's lazy frontier;
+//           resolve walk in seed order: a seed is free iff it is not inside a joint box of a pose
+//           accepted earlier in this round (box containment on the LDS poses = what the map would
+//           say); a free candidate is accepted, a free non-candidate (wrong prediction) ends the
+//           round there -- exactly the seeds the sequential loop would accept, with exactly the
+//           poses it would grow.  Seeds of the same person turn into discarded work, distinct
+//           persons into parallel speed-up.
 //
 // Inside a growth the wave uses its 64 lanes where the reference has inner loops:
 // grow_connection_blend scans a CAF candidate list 64 entries per lane-step (coalesced
@@ -30,7 +33,8 @@
 // tie rules).  The frontier is an exact re-implementation of the binary max-heap behind
 // std::priority_queue (sift-up on push, sift-to-leaf + sift-up on pop), because equal
 // priorities are the norm (all edges leaving one joint share the bound sqrt(v); every
-// flood-filled joint carries 1e-5) and the pop order decides results.
+// flood-filled joint carries 1e-5) and the pop order decides results; for skeletons that fit a
+// wave (K <= 64, 2A <= 64) pose, frontier and heap live in VGPR lanes (readlane), else in LDS.
 // Occupancy boxes of an accepted pose are dealt to the 8 waves; force-complete growth and flood
 // fill run one pose per wave; keypoint NMS needs no map at all (box containment per field, one
 // field per wave).  The occupancy map and the pose scratch are the only state in HBM that one wave
