@@ -75,7 +75,7 @@ def algorithmic_bytes(B, F, A, H, W, stride, max_ann):
     rows, cols = (H - 1) * stride + 1, (W - 1) * stride + 1
     return {
         'cif_active_kernel': B * F * 4 * hw * 4,                 # reads conf,x,y,scale planes
-        'cifhr_tile_kernel': B * F * rows * cols * 4,            # writes the high-res map once
+        'cifhr_tile_kernel': B * F * rows * cols * 4,            # whole map; bench.py replaces it by the tiles actually written
         'cifseeds_fill_kernel': B * F * hw * 4,                  # reads the confidence plane
         'cifseeds_sort_kernel': 0,
         'cafscored_kernel': B * A * 7 * hw * 4,                  # reads the 7 used component planes
@@ -281,6 +281,12 @@ def main():
                     per_kernel.setdefault(name, []).append(ms)
         avg_ms = {k: float(np.mean(v)) for k, v in per_kernel.items()}
         alg = algorithmic_bytes(B, 17, 19, fh, fh, stride, dec.max_annotations)
+        # the tile kernel writes only the 32x64 tiles this call's or the previous call's cells reach
+        # (lazy clear): its algorithmic bytes are those tiles, counted from the bitmaps in the workspace
+        bitmaps = dec.workspace_view('tile_bitmaps', torch.int32).cpu().numpy().view(np.uint32)
+        words = ((((fh - 1) * stride + 1 + 63) // 64) * (((fh - 1) * stride + 1 + 31) // 32) + 31) // 32
+        tiles_written = int(np.unpackbits(bitmaps[:B * 17 * words].view(np.uint8)).sum())
+        alg['cifhr_tile_kernel'] = tiles_written * 32 * 64 * 4
         decode_ms = sum(avg_ms.values())
         dominant = max(avg_ms, key=avg_ms.get)
         dom_bytes = alg.get(dominant, 0)

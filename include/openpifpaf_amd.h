@@ -108,7 +108,15 @@ int opa_cifcaf_get_state(const opa_cifcaf* dec, int32_t* n_keypoints,
                          int64_t* skeleton_host /* [n_bones,2] or NULL */, int32_t* n_bones);
 
 /* Bytes of device workspace opa_cifcaf_decode needs for `shape`
- * (0 and an error text if the shape is invalid). */
+ * (0 and an error text if the shape is invalid).
+ *
+ * The workspace may hold anything when it is first used.  Between calls it carries one piece of
+ * state: a 256-byte header plus a bitmap of the 32x64 tiles of the high-resolution map the previous
+ * call wrote to, so that tiles no CIF cell touches and that are already zero are not written again
+ * (the per-tile form of the reference's lazy clear, cif_hr.cpp:97-121).  The bitmap is trusted only
+ * while the header matches the layout of the call.  So: do not write into a workspace between the calls that use
+ * it; after lending the memory to anything else, overwrite its first 256 bytes (hipMemset 0) --
+ * that alone makes the next call treat every tile as dirty. */
 size_t opa_cifcaf_workspace_bytes(const opa_shape* shape);
 
 /* ref: module.cpp:35-36  CifCaf.call / CifCaf.call_with_initial_annotations,
@@ -143,7 +151,8 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
 
 /* Locates an intermediate buffer of the last opa_cifcaf_decode inside the workspace
  * (debugging / tests; the reference exposes its intermediates through the utility
- * classes of module.cpp:66-117).  what: "cifhr", "seed_count", "seed_f", "seed_vxys",
+ * classes of module.cpp:66-117).  what: "tile_bitmaps" (u32 [2][B*F][words]: tiles of the map written by
+ * the previous / by this call), "cifhr", "seed_count", "seed_f", "seed_vxys", "seed_cell",
  * "lists", "list_counts", "lists_fc", "list_counts_fc", "occupancy",
  * "annotation_scratch", "status". */
 int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what,

@@ -101,6 +101,11 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     const size_t B = s.batch;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes); return o; };
+    L->off_hdr = take(256);                                           // see kWsMagic (common.hpp)
+    {   // two tile bitmaps per (image, field) plane: the previous call's and this call's touched tiles
+        const size_t tpp = (size_t)(L->hr_pitch / kHrTileW) * ((L->hr_rows + kHrTileH - 1) / kHrTileH);
+        L->off_tile_clean = take(2 * B * L->F * ((tpp + 31) / 32) * sizeof(unsigned));
+    }
     L->off_cifhr = take(B * L->F * L->hr_rows * (size_t)L->hr_pitch * sizeof(float));
     L->off_act = take(B * L->F * 4 * (size_t)(L->H * L->W) * sizeof(float));
     L->off_act_count = take(B * L->F * sizeof(int32_t));
@@ -264,7 +269,7 @@ int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what, size_t* 
     if (!shape || !what || !make_layout(*shape, &L, &why)) return fail(OPA_ERR_INVALID_ARGUMENT, why ? why : "null argument");
     struct Entry { const char* name; size_t off, end; };
     const Entry table[] = {
-        {"cifhr", L.off_cifhr, L.off_act}, {"seed_count", L.off_seed_count, L.off_seed_f},
+        {"tile_bitmaps", L.off_tile_clean, L.off_cifhr}, {"cifhr", L.off_cifhr, L.off_act}, {"seed_count", L.off_seed_count, L.off_seed_f},
         {"seed_f", L.off_seed_f, L.off_seed_vxys}, {"seed_vxys", L.off_seed_vxys, L.off_seed_cell}, {"seed_cell", L.off_seed_cell, L.off_lists},
         {"lists", L.off_lists, L.off_list_counts}, {"list_counts", L.off_list_counts, L.off_lists_fc},
         {"lists_fc", L.off_lists_fc, L.off_list_counts_fc}, {"list_counts_fc", L.off_list_counts_fc, L.off_occ},
@@ -311,8 +316,14 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     float* cifhr = (float*)(ws + L.off_cifhr);
     hipError_t e;
 
+    // the clean-tile flags are valid for exactly this carving of the workspace
+    unsigned long long layout_hash = 1469598103934665603ull;
+    for (long long v : {(long long)L.B, (long long)L.F, (long long)L.H, (long long)L.W, (long long)L.stride,
+                        (long long)L.A, (long long)L.cH, (long long)L.cW, (long long)L.max_ann, (long long)L.total})
+        layout_hash = (layout_hash ^ (unsigned long long)v) * 1099511628211ull;
     e = launch_cifhr(cif_dev, L.B, L.F, L.H, L.W, L.stride, 0.0, 1.0, p, cifhr, L.hr_rows, L.hr_pitch,
-                     (float*)(ws + L.off_act), (int32_t*)(ws + L.off_act_count), st);       // cifcaf.cpp:140-141
+                     (float*)(ws + L.off_act), (int32_t*)(ws + L.off_act_count), st, false,
+                     (unsigned long long*)(ws + L.off_hdr), layout_hash, ws + L.off_tile_clean);   // cifcaf.cpp:140-141
     if (e != hipSuccess) return fail_hip(e, "cifhr");
     e = launch_cifseeds(cif_dev, L.B, L.F, L.H, L.W, L.stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
                         (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap,

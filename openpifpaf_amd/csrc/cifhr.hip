@@ -24,14 +24,35 @@
 
 namespace opa {
 
+// cif_hr.cpp:61-64 (truncate = 1.0): the pixel box add_gauss walks for a cell
+__device__ __forceinline__ void gauss_box(float cx, float cy, float sigma, int rows, int cols,
+                                          int* minx, int* miny, int* maxx, int* maxy) {
+    *minx = (int)clampll(trunc_ll(cx - sigma), 0, cols - 1);
+    *miny = (int)clampll(trunc_ll(cy - sigma), 0, rows - 1);
+    *maxx = (int)clampll(trunc_ll(cx + sigma + 1.0f), *minx + 1, cols);
+    *maxy = (int)clampll(trunc_ll(cy + sigma + 1.0f), *miny + 1, rows);
+}
+
 // ---------------------------------------------------------------- pass 1
 // DET: CifDet fields [F,6,H,W] (w,h instead of scale), CifDetHr::accumulate cif_hr.cpp:124-150
 template <bool DET>
 __global__ __launch_bounds__(256) void cif_active_kernel(
         const float* __restrict__ cif, int HW, int stride, float min_scale_f, double threshold,
-        float neighbors_f, double factor, float* __restrict__ act, int32_t* __restrict__ act_count) {
+        float neighbors_f, double factor, float* __restrict__ act, int32_t* __restrict__ act_count,
+        unsigned long long* ws_header, unsigned long long layout_hash,
+        unsigned* __restrict__ tile_touch, int touch_words, int rows, int cols, int tiles_x) {
     __shared__ int wave_tot[4];
     const int plane = blockIdx.x;
+    unsigned* touch = tile_touch ? tile_touch + (size_t)plane * touch_words : nullptr;   // one bit per tile of this plane
+    if (touch) {
+        for (int k = threadIdx.x; k < touch_words; k += 256) touch[k] = 0u;
+        __syncthreads();
+    }
+    if (ws_header && blockIdx.x == 0 && threadIdx.x == 0) {       // do the clean-tile flags describe this layout?
+        const bool valid = ws_header[0] == kWsMagic && ws_header[1] == layout_hash;
+        ws_header[2] = valid ? 0ull : 1ull;
+        ws_header[0] = kWsMagic; ws_header[1] = layout_hash;
+    }
     const float* P = cif + (size_t)plane * (DET ? 6 : 5) * HW;
     float* out = act + (size_t)plane * 4 * HW;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -61,6 +82,15 @@ __global__ __launch_bounds__(256) void cif_active_kernel(
                     y = P[3 * HW + o] * stride_f;
                     sigma = fmaxf(1.0f, (float)sigma_d);
                     v16 = (float)((double)(v / neighbors_f) * factor);                    // :51
+                    if (touch) {                                  // tiles this cell's box overlaps
+                        int minx, miny, maxx, maxy;
+                        gauss_box(x, y, sigma, rows, cols, &minx, &miny, &maxx, &maxy);
+                        for (int ty = miny / kHrTileH; ty <= (maxy - 1) / kHrTileH; ty++)
+                            for (int tx = minx / kHrTileW; tx <= (maxx - 1) / kHrTileW; tx++) {
+                                const int t = ty * tiles_x + tx;
+                                atomicOr(&touch[t >> 5], 1u << (t & 31));
+                            }
+                    }
                 }
             }
         }
@@ -81,59 +111,61 @@ __global__ __launch_bounds__(256) void cif_active_kernel(
     if (tid == 0) act_count[plane] = base;
 }
 
-// cif_hr.cpp:18-25
+// cif_hr.cpp:18-25.  The reference evaluates `1.0 + x / 8.0` and the caller's `-0.5 * d2 / sigma2` in double
+// and rounds to float; for one +, / of float operands that double rounding is innocuous (53 >= 2*24+2
+// bits), so the correctly rounded float operation gives the same bits at a third of the instructions.
 __device__ __forceinline__ float approx_exp(float x) {
-    if ((double)x > 2.0 || (double)x < -2.0) return 0.0f;
-    x = (float)(1.0 + (double)x / 8.0);
+    if (x > 2.0f || x < -2.0f) return 0.0f;
+    x = 1.0f + x * 0.125f;
     x *= x; x *= x; x *= x;
     return x;
 }
 
 // ---------------------------------------------------------------- pass 2
-__global__ __launch_bounds__(256) void cifhr_tile_kernel(
-        const float* __restrict__ act, const int32_t* __restrict__ act_count, int HW,
-        float* __restrict__ hr, int rows, int cols, int pitch,
-        int tiles_x, int tiles_y, long long total_tiles) {
-    __shared__ __attribute__((aligned(16))) float lds[4 * kHrTileH * kHrLdsPitch];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const long long tile = (long long)blockIdx.x * 4 + w;
-    if (tile >= total_tiles) return;                 // no workgroup barriers below
-    const int tpp = tiles_x * tiles_y;
-    const int plane = (int)(tile / tpp);
-    const int rem = (int)(tile - (long long)plane * tpp);
-    const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
-    const int x0 = tx * kHrTileW, y0 = ty * kHrTileH;
-    const int x1 = min(x0 + kHrTileW, cols), y1 = min(y0 + kHrTileH, rows);
-    float* T = lds + w * (kHrTileH * kHrLdsPitch);
-
-    for (int k = lane; k < kHrTileH * kHrLdsPitch / 4; k += 64)
+// The four waves of a workgroup build one 32x64 tile in LDS, each its own band of 8 rows (pixels are
+// independent of each other; only the order of the cells applied to ONE pixel matters), and write it out.
+constexpr int kBandH = kHrTileH / 4;
+__device__ __forceinline__ void build_tile(const float* __restrict__ A, int n, int HW, float* __restrict__ T,
+                                           float* __restrict__ hr_plane, int rows, int cols, int pitch,
+                                           int tx, int ty, int band, bool touched) {
+    const int lane = threadIdx.x & 63;
+    const int lx = lane & 15, ly = lane >> 4;
+    const int x0 = tx * kHrTileW, ytile = ty * kHrTileH, y0 = ytile + band * kBandH;
+    if (!touched) {                                   // no cell reaches this tile: it only has to be zero
+        for (int r = ly; r < kBandH; r += 4)
+            if (y0 + r < rows)
+                *reinterpret_cast<float4*>(hr_plane + (size_t)(y0 + r) * pitch + x0 + lx * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const int x1 = min(x0 + kHrTileW, cols), y1 = min(y0 + kBandH, rows);
+    T += band * kBandH * kHrLdsPitch;                 // this wave's rows of the tile
+    for (int k = lane; k < kBandH * kHrLdsPitch / 4; k += 64)
         reinterpret_cast<float4*>(T)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    const int n = act_count[plane];
-    const float* A = act + (size_t)plane * 4 * HW;
-    const int lx = lane & 15, ly = lane >> 4;
-
+    // the list chunk after the current one is already in flight while the current one is applied
+    float nv = 0.f, nx = 0.f, ny = 0.f, ns = 1.f;
+    if (lane < n) { nv = A[0 * HW + lane]; nx = A[1 * HW + lane]; ny = A[2 * HW + lane]; ns = A[3 * HW + lane]; }
     for (int c0 = 0; c0 < n; c0 += 64) {
         const int i = c0 + lane;
-        float v16 = 0.f, cx = 0.f, cy = 0.f, sigma = 1.f;
+        const float v16 = nv, cx = nx, cy = ny, sigma = ns;
+        if (i + 64 < n) {
+            nv = A[0 * HW + i + 64]; nx = A[1 * HW + i + 64]; ny = A[2 * HW + i + 64]; ns = A[3 * HW + i + 64];
+        }
         int minx = 0, maxx = 0, miny = 0, maxy = 0;
         bool hit = false;
         if (i < n) {
-            v16 = A[0 * HW + i]; cx = A[1 * HW + i]; cy = A[2 * HW + i]; sigma = A[3 * HW + i];
-            // cif_hr.cpp:61-64 (truncate = 1.0)
-            minx = (int)clampll(trunc_ll(cx - sigma), 0, cols - 1);
-            miny = (int)clampll(trunc_ll(cy - sigma), 0, rows - 1);
-            maxx = (int)clampll(trunc_ll(cx + sigma + 1.0f), minx + 1, cols);
-            maxy = (int)clampll(trunc_ll(cy + sigma + 1.0f), miny + 1, rows);
+            gauss_box(cx, cy, sigma, rows, cols, &minx, &miny, &maxx, &maxy);
             hit = minx < x1 && maxx > x0 && miny < y1 && maxy > y0;
         }
         unsigned long long mask = __ballot(hit);
         while (mask) {
             const int l = __builtin_ctzll(mask);
             mask &= mask - 1;
-            const float bv = __shfl(v16, l), bx = __shfl(cx, l), by = __shfl(cy, l), bs = __shfl(sigma, l);
-            const int bx0 = max(__shfl(minx, l), x0), bx1 = min(__shfl(maxx, l), x1);
-            const int by0 = max(__shfl(miny, l), y0), by1 = min(__shfl(maxy, l), y1);
+            // l is wave-uniform: v_readlane (a few cycles) instead of a ds_bpermute round trip per value
+            auto rl = [l](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+            const float bv = rl(v16), bx = rl(cx), by = rl(cy), bs = rl(sigma);
+            const int bx0 = max(__builtin_amdgcn_readlane(minx, l), x0), bx1 = min(__builtin_amdgcn_readlane(maxx, l), x1);
+            const int by0 = max(__builtin_amdgcn_readlane(miny, l), y0), by1 = min(__builtin_amdgcn_readlane(maxy, l), y1);
             const float sigma2 = bs * bs;                         // cif_hr.cpp:66-67
             for (int py = by0; py < by1; py += 4) {
                 const int yy = py + ly;
@@ -147,8 +179,8 @@ __global__ __launch_bounds__(256) void cifhr_tile_kernel(
                         const float d2 = dx2 + dy2;
                         if (!(d2 > sigma2)) {                     // cif_hr.cpp:75
                             float vv;
-                            if ((double)dx2 < 0.25 && (double)dy2 < 0.25) vv = bv;   // :77-79
-                            else vv = bv * approx_exp((float)(-0.5 * (double)d2 / (double)sigma2));
+                            if (dx2 < 0.25f && dy2 < 0.25f) vv = bv;     // :77-79
+                            else vv = bv * approx_exp(__fdiv_rn(-0.5f * d2, sigma2));   // :81
                             float* e = T + (yy - y0) * kHrLdsPitch + (xx - x0);
                             float a = fmaxf(*e, 1.0f) + vv;       // :84-86 at revision 1.0
                             *e = fminf(a, 2.0f);
@@ -158,13 +190,64 @@ __global__ __launch_bounds__(256) void cifhr_tile_kernel(
             }
         }
     }
-
     // coalesced write-out: 16 lanes x float4 = one 256-B tile row, 4 rows per instruction
-    for (int r = ly; r < kHrTileH; r += 4) {
+    for (int r = ly; r < kBandH; r += 4) {
         const int yy = y0 + r;
         if (yy < rows) {
             const float4 val = *reinterpret_cast<const float4*>(T + r * kHrLdsPitch + lx * 4);
-            *reinterpret_cast<float4*>(hr + ((size_t)plane * rows + yy) * pitch + x0 + lx * 4) = val;
+            *reinterpret_cast<float4*>(hr_plane + (size_t)yy * pitch + x0 + lx * 4) = val;
+        }
+    }
+}
+
+// kTileGroups 4-wave workgroups per (image, field) plane share the plane's tiles, one tile at a time per
+// workgroup.  Lazy clear, the reference's revision trick
+// (cif_hr.cpp:97-121) per tile: pass 1 left a bitmap of the tiles this call's cells reach (`cur`), the
+// workspace remembers the bitmap of the previous call (`prev`); only tiles in cur | prev are visited --
+// built if in cur, zeroed if only in prev -- and every other tile is already all-zero in HBM.  Most of the
+// map is such tiles.  Without workspace state (stage-level entry point, invalid header) every tile is built.
+constexpr int kTileGroups = 8;
+
+__global__ __launch_bounds__(256) void cifhr_tile_kernel(
+        const float* __restrict__ act, const int32_t* __restrict__ act_count, int HW,
+        float* __restrict__ hr, int rows, int cols, int pitch, int tiles_x, int tiles_y,
+        const unsigned long long* __restrict__ ws_header, const unsigned* __restrict__ tile_prev,
+        const unsigned* __restrict__ tile_cur, int touch_words) {
+    __shared__ __attribute__((aligned(16))) float T[kHrTileH * kHrLdsPitch];
+    const int band = threadIdx.x >> 6;
+    const int g = blockIdx.x % kTileGroups;          // this workgroup's number within the plane
+    const int plane = blockIdx.x / kTileGroups;
+    const int tpp = tiles_x * tiles_y;
+    const int n = act_count[plane];
+    const float* A = act + (size_t)plane * 4 * HW;
+    float* hr_plane = hr + (size_t)plane * rows * pitch;
+    const bool stateful = tile_cur != nullptr;
+    const bool valid = stateful && ws_header[2] == 0ull;
+    int k = 0;                                       // running index of the tiles that need work, dealt round-robin
+    const int lane = threadIdx.x & 63;
+    for (int w0 = 0; w0 < touch_words; w0 += 64) {   // 64 bitmap words per step: one load per lane, then readlane
+        const int wl = w0 + lane;
+        unsigned my_need = 0u, my_cur = 0u;
+        if (wl < touch_words) {
+            const unsigned in_range = tpp - wl * 32 >= 32 ? 0xFFFFFFFFu : (1u << (tpp - wl * 32)) - 1u;
+            my_cur = stateful ? tile_cur[(size_t)plane * touch_words + wl] : in_range;
+            const unsigned prev = valid ? tile_prev[(size_t)plane * touch_words + wl] : in_range;
+            my_need = (my_cur | prev) & in_range;
+        }
+        unsigned long long words = __ballot(my_need != 0u);
+        while (words) {
+            const int wi = __builtin_ctzll(words);
+            words &= words - 1;
+            unsigned need = (unsigned)__builtin_amdgcn_readlane((int)my_need, wi);
+            const unsigned cur = (unsigned)__builtin_amdgcn_readlane((int)my_cur, wi);
+            while (need) {
+                const int bit = __builtin_ctz(need);
+                need &= need - 1;
+                if ((k++ % kTileGroups) != g) continue;
+                const int t = (w0 + wi) * 32 + bit;
+                const int ty = t / tiles_x, tx = t - ty * tiles_x;
+                build_tile(A, n, HW, T, hr_plane, rows, cols, pitch, tx, ty, band, (cur >> bit) & 1u);
+            }
         }
     }
 }
@@ -172,29 +255,45 @@ __global__ __launch_bounds__(256) void cifhr_tile_kernel(
 hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride,
                         double min_scale, double factor, const DevParams& p,
                         float* cifhr, int hr_rows, int hr_pitch,
-                        float* act, int32_t* act_count, hipStream_t st, bool det) {
+                        float* act, int32_t* act_count, hipStream_t st, bool det,
+                        unsigned long long* ws_header, unsigned long long layout_hash, unsigned char* tile_state) {
     const int planes = B * F, HW = H * W;
     const int hr_cols = (W - 1) * stride + 1;
+    const int tiles_x = hr_pitch / kHrTileW;
+    const int tiles_y = (hr_rows + kHrTileH - 1) / kHrTileH;
+    // two per-plane tile bitmaps in the workspace region `tile_state`: previous call, this call
+    const int touch_words = (tiles_x * tiles_y + 31) / 32;
+    unsigned* tile_prev = ws_header ? reinterpret_cast<unsigned*>(tile_state) : nullptr;
+    unsigned* tile_touch = ws_header ? tile_prev + (size_t)planes * touch_words : nullptr;
     if (p.ablation_cifhr_skip && !det) {              // cif_hr.cpp:29
         hipError_t e = hipMemsetAsync(act_count, 0, sizeof(int32_t) * planes, st);
         if (e != hipSuccess) return e;
         prof_mark(st, "memset_act_count");
+        if (ws_header) {                              // no kernel validates the flags on this path: invalidate them
+            e = hipMemsetAsync(ws_header, 0xFF, 32, st);
+            if (e != hipSuccess) return e;
+            e = hipMemsetAsync(tile_touch, 0, sizeof(unsigned) * touch_words * planes, st);
+            if (e != hipSuccess) return e;
+        }
     } else {
         const float min_scale_f = (float)(min_scale / (double)stride);       // cif_hr.cpp:32
         if (det)
             cif_active_kernel<true><<<planes, 256, 0, st>>>(cif, HW, stride, min_scale_f, p.cif_threshold,
-                                                             (float)p.cifhr_neighbors, factor, act, act_count);
+                                                             (float)p.cifhr_neighbors, factor, act, act_count, ws_header, layout_hash,
+                                                             tile_touch, touch_words, hr_rows, hr_cols, tiles_x);
         else
             cif_active_kernel<false><<<planes, 256, 0, st>>>(cif, HW, stride, min_scale_f, p.cif_threshold,
-                                                              (float)p.cifhr_neighbors, factor, act, act_count);
+                                                              (float)p.cifhr_neighbors, factor, act, act_count, ws_header, layout_hash,
+                                                              tile_touch, touch_words, hr_rows, hr_cols, tiles_x);
         prof_mark(st, "cif_active_kernel");
     }
-    const int tiles_x = hr_pitch / kHrTileW;
-    const int tiles_y = (hr_rows + kHrTileH - 1) / kHrTileH;
-    const long long total = (long long)planes * tiles_x * tiles_y;
-    const unsigned grid = (unsigned)((total + 3) / 4);
-    cifhr_tile_kernel<<<grid, 256, 0, st>>>(act, act_count, HW, cifhr, hr_rows, hr_cols, hr_pitch,
-                                             tiles_x, tiles_y, total);
+    cifhr_tile_kernel<<<planes * kTileGroups, 256, 0, st>>>(act, act_count, HW, cifhr, hr_rows, hr_cols, hr_pitch,
+                                                             tiles_x, tiles_y, ws_header, tile_prev, tile_touch, touch_words);
+    if (ws_header) {                                  // this call's bitmap is the next call's "previous"
+        hipError_t e = hipMemcpyAsync(tile_prev, tile_touch, sizeof(unsigned) * touch_words * planes,
+                                      hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return e;
+    }
     prof_mark(st, "cifhr_tile_kernel");
     return hipGetLastError();
 }

@@ -26,7 +26,7 @@ struct Layout {
     int caf_cells;                        // cH*cW  (list capacity per (field, direction))
     int sort_cap;                         // next pow2 >= cif_cells
     // byte offsets into the workspace (all 256-B aligned)
-    size_t off_cifhr, off_act, off_act_count, off_seed_keys, off_seed_count,
+    size_t off_hdr, off_tile_clean, off_cifhr, off_act, off_act_count, off_seed_keys, off_seed_count,
            off_seed_f, off_seed_vxys, off_seed_cell, off_lists, off_list_counts,
            off_lists_fc, off_list_counts_fc, off_occ, off_anns, off_ann_meta, off_status,
            total;
@@ -65,7 +65,13 @@ void prof_mark(hipStream_t st, const char* name);
 hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride,
                         double min_scale, double factor, const DevParams& p,
                         float* cifhr, int hr_rows, int hr_pitch,
-                        float* act, int32_t* act_count, hipStream_t st, bool det = false);
+                        float* act, int32_t* act_count, hipStream_t st, bool det = false,
+                        unsigned long long* ws_header = nullptr, unsigned long long layout_hash = 0,
+                        unsigned char* tile_state = nullptr);
+
+// Workspace header (first 256 bytes): [0] magic, [1] hash of the layout the stored tile bitmap describes,
+// [2] 1 = stored bitmap invalid for this call (written by the first kernel of a call).
+constexpr unsigned long long kWsMagic = 0x6f70615f63696668ull;   // "opa_cifh"
 
 hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int stride,
                            const float* cifhr, int hr_rows, int hr_cols, int hr_pitch, const DevParams& p,

@@ -434,3 +434,33 @@ def test_decode_different_cif_and_caf_geometry(native, port, coco_skeleton0):
     got, _ = dec.call(dev(cif), 8, dev(caf16), 16)
     ok, msg = compare_annotations(got.cpu().numpy(), want)
     assert ok, msg
+
+
+def test_workspace_state_across_different_images(native, port, coco_skeleton0):
+    """The CifHr map is cleared lazily per tile (clean-tile flags live in the workspace): a sequence of
+    DIFFERENT images through one decoder -- crowded, sparse, empty, crowded again -- must give the oracle's
+    map and poses every time; a workspace that was scribbled over recovers once its header is wiped."""
+    from openpifpaf_amd import synth
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    seq = [(61, 14), (62, 1), (63, 0), (64, 9), (62, 1), (61, 14)]
+    for step, (seed, people) in enumerate(seq + seq[:2]):
+        cif, caf = synth.synth_fields(seed, people, height=49, width=57)
+        if people == 0:
+            cif[:, 1] = 0.0
+            caf[:, 1] = 0.0
+        if step == len(seq):                        # someone else used the memory: garbage everywhere, header wiped
+            shape, ws = dec._last
+            ws.view(torch.float32)[64:].uniform_(0.5, 3.0)
+            ws[:256] = 0
+        out, ids, cnt = dec.call_batch(dev(cif[None]), 8, dev(caf[None]), 8)
+        want, _ = port.decode(cif, 8, caf, 8, coco_skeleton0)
+        want_hr = port.cifhr_accumulate(cif, 8)
+        n = int(cnt[0])
+        assert n == len(want), 'step %d: %d poses, oracle %d' % (step, n, len(want))
+        ok, msg = compare_annotations(out[0, :n].cpu().numpy(), want)
+        assert ok, 'step %d: %s' % (step, msg)
+        hr, rev = dec.get_cifhr()
+        got_hr = hr.cpu().numpy()
+        assert got_hr.shape == want_hr.shape
+        assert np.array_equal(got_hr, want_hr), 'step %d: stale or missing tiles (%d cells differ)' % (
+            step, (got_hr != want_hr).sum())
