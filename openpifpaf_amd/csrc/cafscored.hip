@@ -5,7 +5,7 @@
 // and the mirrored backward tuple; each is rescored with the CifHr value at its
 // TARGET joint, c * (floor + (1-floor) * hr), and kept when the result is > th.
 //
-// One 256-thread workgroup per (image, CAF field) walks the 7 used component
+// One 1024-thread workgroup per (image, CAF field) walks the 7 used component
 // planes in raster order with coalesced loads (this is the bandwidth-bound stage
 // of the decode), gathers the two CifHr values from the L2-resident map, and
 // stream-compacts survivors IN RASTER ORDER (wave ballot + cross-wave prefix in
@@ -18,12 +18,14 @@
 
 namespace opa {
 
-__global__ __launch_bounds__(256) void cafscored_kernel(
+constexpr int kScoredThreads = 1024;     // one workgroup walks a field: fewer, wider steps (each ends in a barrier)
+
+__global__ __launch_bounds__(kScoredThreads) void cafscored_kernel(
         const float* __restrict__ caf, int A, int HW, int stride,
         const float* __restrict__ cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
         const int64_t* __restrict__ skeleton, double score_th, double cif_floor, int no_rescore,
         float* __restrict__ lists, int32_t* __restrict__ counts) {
-    __shared__ int wave_tot[4];
+    __shared__ int wave_tot[2][kScoredThreads / 64];
     const int plane = blockIdx.x;                  // b*A + a
     const int b = plane / A, a = plane - b * A;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -33,9 +35,9 @@ __global__ __launch_bounds__(256) void cafscored_kernel(
     float* Lb = lists + ((size_t)plane * 2 + 1) * 7 * HW;
     const long long j1 = skeleton[2 * a + 0], j2 = skeleton[2 * a + 1];
     const float stride_f = (float)stride;
-    int base_f = 0, base_b = 0;
+    int base_f = 0, base_b = 0, parity = 0;
 
-    for (int c0 = 0; c0 < HW; c0 += 256) {
+    for (int c0 = 0; c0 < HW; c0 += kScoredThreads, parity ^= 1) {
         const int o = c0 + tid;
         bool keep_f = false, keep_b = false;
         float c = 0.f, cf = 0.f, cb = 0.f, x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, s1 = 0.f, s2 = 0.f;
@@ -58,13 +60,13 @@ __global__ __launch_bounds__(256) void cafscored_kernel(
         }
         const unsigned long long mf = __ballot(keep_f), mb = __ballot(keep_b);
         const unsigned long long lt = (1ull << lane) - 1ull;
-        if (lane == 0) wave_tot[w] = __popcll(mf) | (__popcll(mb) << 16);
-        __syncthreads();
+        if (lane == 0) wave_tot[parity][w] = __popcll(mf) | (__popcll(mb) << 16);
+        __syncthreads();                              // double-buffered totals: one barrier per step
         int off_f = base_f + __popcll(mf & lt), off_b = base_b + __popcll(mb & lt);
         int tot_f = 0, tot_b = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int t = wave_tot[k];
+        for (int k = 0; k < kScoredThreads / 64; k++) {
+            const int t = wave_tot[parity][k];
             if (k < w) { off_f += t & 0xffff; off_b += t >> 16; }
             tot_f += t & 0xffff; tot_b += t >> 16;
         }
@@ -77,7 +79,6 @@ __global__ __launch_bounds__(256) void cafscored_kernel(
             Lb[3 * HW + off_b] = x1; Lb[4 * HW + off_b] = y1; Lb[5 * HW + off_b] = s2; Lb[6 * HW + off_b] = s1;
         }
         base_f += tot_f; base_b += tot_b;
-        __syncthreads();
     }
     if (tid == 0) { counts[plane * 2 + 0] = base_f; counts[plane * 2 + 1] = base_b; }
 }
@@ -86,7 +87,7 @@ hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int 
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
                             float* lists, int32_t* counts, hipStream_t st) {
-    cafscored_kernel<<<B * A, 256, 0, st>>>(caf, A, cH * cW, cstride, cifhr, F, hr_rows, hr_cols, hr_pitch,
+    cafscored_kernel<<<B * A, kScoredThreads, 0, st>>>(caf, A, cH * cW, cstride, cifhr, F, hr_rows, hr_cols, hr_pitch,
                                             skeleton, score_th, cif_floor, no_rescore, lists, counts);
     prof_mark(st, "cafscored_kernel");
     return hipGetLastError();

@@ -35,17 +35,19 @@ __device__ __forceinline__ void gauss_box(float cx, float cy, float sigma, int r
 
 // ---------------------------------------------------------------- pass 1
 // DET: CifDet fields [F,6,H,W] (w,h instead of scale), CifDetHr::accumulate cif_hr.cpp:124-150
+constexpr int kActiveThreads = 256;      // one workgroup walks a plane: fewer, wider steps (each ends in a barrier)
+
 template <bool DET>
-__global__ __launch_bounds__(256) void cif_active_kernel(
+__global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
         const float* __restrict__ cif, int HW, int stride, float min_scale_f, double threshold,
         float neighbors_f, double factor, float* __restrict__ act, int32_t* __restrict__ act_count,
         unsigned long long* ws_header, unsigned long long layout_hash,
         unsigned* __restrict__ tile_touch, int touch_words, int rows, int cols, int tiles_x) {
-    __shared__ int wave_tot[4];
+    __shared__ int wave_tot[2][kActiveThreads / 64];
     const int plane = blockIdx.x;
     unsigned* touch = tile_touch ? tile_touch + (size_t)plane * touch_words : nullptr;   // one bit per tile of this plane
     if (touch) {
-        for (int k = threadIdx.x; k < touch_words; k += 256) touch[k] = 0u;
+        for (int k = threadIdx.x; k < touch_words; k += kActiveThreads) touch[k] = 0u;
         __syncthreads();
     }
     if (ws_header && blockIdx.x == 0 && threadIdx.x == 0) {       // do the clean-tile flags describe this layout?
@@ -58,7 +60,8 @@ __global__ __launch_bounds__(256) void cif_active_kernel(
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float stride_f = (float)stride;
     int base = 0;
-    for (int c0 = 0; c0 < HW; c0 += 256) {
+    int parity = 0;
+    for (int c0 = 0; c0 < HW; c0 += kActiveThreads, parity ^= 1) {
         const int o = c0 + tid;
         bool on = false;
         float v16 = 0.f, x = 0.f, y = 0.f, sigma = 0.f;
@@ -96,17 +99,16 @@ __global__ __launch_bounds__(256) void cif_active_kernel(
         }
         const unsigned long long mask = __ballot(on);
         const int pre = __popcll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[w] = __popcll(mask);
-        __syncthreads();
+        if (lane == 0) wave_tot[parity][w] = __popcll(mask);
+        __syncthreads();                              // double-buffered totals: one barrier per step
         int off = base + pre, tot = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { const int t = wave_tot[k]; if (k < w) off += t; tot += t; }
+        for (int k = 0; k < kActiveThreads / 64; k++) { const int t = wave_tot[parity][k]; if (k < w) off += t; tot += t; }
         if (on) {
             out[0 * HW + off] = v16; out[1 * HW + off] = x;
             out[2 * HW + off] = y;   out[3 * HW + off] = sigma;
         }
         base += tot;
-        __syncthreads();
     }
     if (tid == 0) act_count[plane] = base;
 }
@@ -278,11 +280,11 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
     } else {
         const float min_scale_f = (float)(min_scale / (double)stride);       // cif_hr.cpp:32
         if (det)
-            cif_active_kernel<true><<<planes, 256, 0, st>>>(cif, HW, stride, min_scale_f, p.cif_threshold,
+            cif_active_kernel<true><<<planes, kActiveThreads, 0, st>>>(cif, HW, stride, min_scale_f, p.cif_threshold,
                                                              (float)p.cifhr_neighbors, factor, act, act_count, ws_header, layout_hash,
                                                              tile_touch, touch_words, hr_rows, hr_cols, tiles_x);
         else
-            cif_active_kernel<false><<<planes, 256, 0, st>>>(cif, HW, stride, min_scale_f, p.cif_threshold,
+            cif_active_kernel<false><<<planes, kActiveThreads, 0, st>>>(cif, HW, stride, min_scale_f, p.cif_threshold,
                                                               (float)p.cifhr_neighbors, factor, act, act_count, ws_header, layout_hash,
                                                               tile_touch, touch_words, hr_rows, hr_cols, tiles_x);
         prof_mark(st, "cif_active_kernel");
