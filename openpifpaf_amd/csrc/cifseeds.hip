@@ -4,7 +4,7 @@
 // 93-114): threshold every CIF cell, rescore it with the high-resolution map
 // (0.9*hr + 0.1*c), threshold again, and return the survivors sorted by score.
 //
-//  cifseeds_fill_kernel  one thread per CIF cell (coalesced plane reads, one
+//  cifseeds_fill_kernel  four CIF cells per thread (coalesced plane reads, one
 //      gather into the L2-resident CifHr map), survivors appended to the image's
 //      key array with ONE atomic per wavefront (ballot + popcount prefix).
 //      key = sortable(score) << 32 | ~cell_index, so that a descending key sort is
@@ -27,6 +27,8 @@ __device__ __forceinline__ float from_sortable(unsigned s) {
     return __uint_as_float((s & 0x80000000u) ? (s & 0x7fffffffu) : ~s);
 }
 
+constexpr int kFillCells = 4;            // CIF cells per thread: their confidence loads are in flight together
+
 __global__ __launch_bounds__(256) void cifseeds_fill_kernel(
         const float* __restrict__ cif, int F, int NC, int H, int W, int stride,
         const float* __restrict__ cifhr, int hr_rows, int hr_cols, int hr_pitch,
@@ -35,50 +37,60 @@ __global__ __launch_bounds__(256) void cifseeds_fill_kernel(
     const int HW = H * W;
     const int plane = blockIdx.x;              // b*F + f
     const int b = plane / F, f = plane - b * F;
-    const int o = blockIdx.y * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const float* P = cif + (size_t)plane * NC * HW;
-    bool on = false;
-    float c = 0.f;
-    if (o < HW) {
-        c = P[HW + o];
-        if (!((double)c < threshold)) {                              // cif_seeds.cpp:47
-            on = true;
+    int o[kFillCells]; float c[kFillCells]; bool on[kFillCells];
+#pragma unroll
+    for (int r = 0; r < kFillCells; r++) {
+        o[r] = (blockIdx.y * kFillCells + r) * 256 + threadIdx.x;
+        c[r] = o[r] < HW ? P[HW + o[r]] : -1.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < kFillCells; r++) {
+        on[r] = false;
+        if (o[r] < HW && !((double)c[r] < threshold)) {              // cif_seeds.cpp:47
+            on[r] = true;
             if (ablation_nms) {                                      // :35-40,49-51: 3x3 max-pool gate
-                const int j = o / W, i = o - j * W;
-                float m = c;
+                const int j = o[r] / W, i = o[r] - j * W;
+                float m = c[r];
                 for (int dj = -1; dj <= 1; dj++) for (int di = -1; di <= 1; di++) {
                     const int jj = j + dj, ii = i + di;
                     if (jj < 0 || jj >= H || ii < 0 || ii >= W) continue;
                     m = fmaxf(m, P[HW + jj * W + ii]);
                 }
-                if (c < m) on = false;
+                if (c[r] < m) on[r] = false;
             }
-            if (on) {
-                const float x = P[2 * HW + o] * (float)stride;       // :53-54
-                const float y = P[3 * HW + o] * (float)stride;
+            if (on[r]) {
+                const float x = P[2 * HW + o[r]] * (float)stride;    // :53-54
+                const float y = P[3 * HW + o[r]] * (float)stride;
                 if (!no_rescore) {                                   // :56-58
                     const float hv = cifhr_value(cifhr + (size_t)b * F * hr_rows * hr_pitch,
                                                  F, hr_rows, hr_cols, hr_pitch, f, x, y, -1.0f);
-                    c = (float)(0.9 * (double)hv + 0.1 * (double)c);
+                    c[r] = (float)(0.9 * (double)hv + 0.1 * (double)c[r]);
                 }
-                if ((double)c < threshold) on = false;               // :59
+                if ((double)c[r] < threshold) on[r] = false;         // :59
             }
         }
     }
-    const unsigned long long mask = __ballot(on);
-    if (mask == 0) return;
+    unsigned long long mask[kFillCells];
+    int total = 0;
+#pragma unroll
+    for (int r = 0; r < kFillCells; r++) { mask[r] = __ballot(on[r]); total += __popcll(mask[r]); }
+    if (total == 0) return;
     int base = 0;
-    const int leader = __builtin_ctzll(mask);
-    if (lane == leader) base = atomicAdd(&seed_count[b], __popcll(mask));
-    base = __shfl(base, leader);
-    if (on) {
-        const int slot = base + __popcll(mask & ((1ull << lane) - 1ull));
-        if (slot < cap) {
-            const unsigned idx = (unsigned)(f * HW + o);
-            keys[(size_t)b * sort_cap + slot] =
-                ((unsigned long long)sortable_bits(c) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+    if (lane == 0) base = atomicAdd(&seed_count[b], total);          // one atomic per wave
+    base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+    for (int r = 0; r < kFillCells; r++) {
+        if (on[r]) {
+            const int slot = base + __popcll(mask[r] & ((1ull << lane) - 1ull));
+            if (slot < cap) {
+                const unsigned idx = (unsigned)(f * HW + o[r]);
+                keys[(size_t)b * sort_cap + slot] =
+                    ((unsigned long long)sortable_bits(c[r]) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+            }
         }
+        base += __popcll(mask[r]);
     }
 }
 
@@ -184,7 +196,7 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
     hipError_t e = hipMemsetAsync(seed_count, 0, sizeof(int32_t) * B, st);
     if (e != hipSuccess) return e;
     prof_mark(st, "memset_seed_count");
-    dim3 grid(B * F, (HW + 255) / 256);
+    dim3 grid(B * F, (HW + 256 * kFillCells - 1) / (256 * kFillCells));
     cifseeds_fill_kernel<<<grid, 256, 0, st>>>(cif, F, NC, H, W, stride, cifhr, hr_rows, hr_cols, hr_pitch,
                                                p.seed_threshold, det ? 0 : p.ablation_cifseeds_nms,
                                                det ? 0 : p.ablation_cifseeds_no_rescore, keys, sort_cap, cap, seed_count);
