@@ -35,7 +35,8 @@ __device__ __forceinline__ void gauss_box(float cx, float cy, float sigma, int r
 
 // ---------------------------------------------------------------- pass 1
 // DET: CifDet fields [F,6,H,W] (w,h instead of scale), CifDetHr::accumulate cif_hr.cpp:124-150
-constexpr int kActiveThreads = 256;      // one workgroup walks a plane: fewer, wider steps (each ends in a barrier)
+constexpr int kActiveThreads = 256;
+constexpr int kActiveCells = 4;
 
 template <bool DET>
 __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
         float neighbors_f, double factor, float* __restrict__ act, int32_t* __restrict__ act_count,
         unsigned long long* ws_header, unsigned long long layout_hash,
         unsigned* __restrict__ tile_touch, int touch_words, int rows, int cols, int tiles_x) {
-    __shared__ int wave_tot[2][kActiveThreads / 64];
+    __shared__ int wave_tot[2][kActiveCells][kActiveThreads / 64];
     const int plane = blockIdx.x;
     unsigned* touch = tile_touch ? tile_touch + (size_t)plane * touch_words : nullptr;   // one bit per tile of this plane
     if (touch) {
@@ -61,13 +62,23 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
     const float stride_f = (float)stride;
     int base = 0;
     int parity = 0;
-    for (int c0 = 0; c0 < HW; c0 += kActiveThreads, parity ^= 1) {
-        const int o = c0 + tid;
-        bool on = false;
-        float v16 = 0.f, x = 0.f, y = 0.f, sigma = 0.f;
-        if (o < HW) {
-            const float v = P[HW + o];
-            if (!((double)v < threshold)) {                       // cif_hr.cpp:39
+    // kActiveCells cells per thread and step: their confidence loads are in flight together; cell order
+    // (r, wave, lane) is raster order, and the list keeps it
+    for (int c0 = 0; c0 < HW; c0 += kActiveThreads * kActiveCells, parity ^= 1) {
+        float vin[kActiveCells];
+#pragma unroll
+        for (int r = 0; r < kActiveCells; r++) {
+            const int o = c0 + r * kActiveThreads + tid;
+            vin[r] = o < HW ? P[HW + o] : -1.0f;
+        }
+        bool on[kActiveCells];
+        float v16[kActiveCells], x[kActiveCells], y[kActiveCells], sigma[kActiveCells];
+#pragma unroll
+        for (int r = 0; r < kActiveCells; r++) {
+            const int o = c0 + r * kActiveThreads + tid;
+            on[r] = false; v16[r] = 0.f; x[r] = 0.f; y[r] = 0.f; sigma[r] = 0.f;
+            const float v = vin[r];
+            if (o < HW && !((double)v < threshold)) {             // cif_hr.cpp:39
                 const float scale = P[4 * HW + o];
                 bool big_enough;
                 double sigma_d;
@@ -80,14 +91,14 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
                     sigma_d = 0.5 * (double)scale * (double)stride;
                 }
                 if (big_enough) {
-                    on = true;
-                    x = P[2 * HW + o] * stride_f;                 // cif_hr.cpp:44-45
-                    y = P[3 * HW + o] * stride_f;
-                    sigma = fmaxf(1.0f, (float)sigma_d);
-                    v16 = (float)((double)(v / neighbors_f) * factor);                    // :51
+                    on[r] = true;
+                    x[r] = P[2 * HW + o] * stride_f;              // cif_hr.cpp:44-45
+                    y[r] = P[3 * HW + o] * stride_f;
+                    sigma[r] = fmaxf(1.0f, (float)sigma_d);
+                    v16[r] = (float)((double)(v / neighbors_f) * factor);                 // :51
                     if (touch) {                                  // tiles this cell's box overlaps
                         int minx, miny, maxx, maxy;
-                        gauss_box(x, y, sigma, rows, cols, &minx, &miny, &maxx, &maxy);
+                        gauss_box(x[r], y[r], sigma[r], rows, cols, &minx, &miny, &maxx, &maxy);
                         for (int ty = miny / kHrTileH; ty <= (maxy - 1) / kHrTileH; ty++)
                             for (int tx = minx / kHrTileW; tx <= (maxx - 1) / kHrTileW; tx++) {
                                 const int t = ty * tiles_x + tx;
@@ -97,18 +108,24 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
                 }
             }
         }
-        const unsigned long long mask = __ballot(on);
-        const int pre = __popcll(mask & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[parity][w] = __popcll(mask);
-        __syncthreads();                              // double-buffered totals: one barrier per step
-        int off = base + pre, tot = 0;
+        unsigned long long mask[kActiveCells];
 #pragma unroll
-        for (int k = 0; k < kActiveThreads / 64; k++) { const int t = wave_tot[parity][k]; if (k < w) off += t; tot += t; }
-        if (on) {
-            out[0 * HW + off] = v16; out[1 * HW + off] = x;
-            out[2 * HW + off] = y;   out[3 * HW + off] = sigma;
+        for (int r = 0; r < kActiveCells; r++) {
+            mask[r] = __ballot(on[r]);
+            if (lane == 0) wave_tot[parity][r][w] = __popcll(mask[r]);
         }
-        base += tot;
+        __syncthreads();                              // double-buffered totals: one barrier per step
+#pragma unroll
+        for (int r = 0; r < kActiveCells; r++) {
+            int off = base + __popcll(mask[r] & ((1ull << lane) - 1ull)), tot = 0;
+#pragma unroll
+            for (int k = 0; k < kActiveThreads / 64; k++) { const int t = wave_tot[parity][r][k]; if (k < w) off += t; tot += t; }
+            if (on[r]) {
+                out[0 * HW + off] = v16[r]; out[1 * HW + off] = x[r];
+                out[2 * HW + off] = y[r];   out[3 * HW + off] = sigma[r];
+            }
+            base += tot;
+        }
     }
     if (tid == 0) act_count[plane] = base;
 }
