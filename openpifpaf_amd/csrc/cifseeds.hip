@@ -115,18 +115,43 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
     if (in_lds) {
         for (int t = tid; t < n_pad; t += 1024) sk[t] = t < n ? K[t] : 0ull;
         __syncthreads();
+        // Wave w owns the contiguous block of E = n_pad / 16 keys: every pass whose stride stays inside a
+        // block (j < E) touches only keys this wave wrote, so it needs no workgroup barrier -- for 8192 keys
+        // that is 81 of the 91 passes.  Only the far strides (j >= E) synchronise the workgroup.
+        const int E = n_pad >= 32 ? n_pad / 16 : n_pad;      // tiny inputs: wave 0 does everything
+        const int wave = tid >> 6, lane = tid & 63;
+        const bool owner = n_pad >= 32 || wave == 0;
+        bool synced = true;                                  // a workgroup barrier separates us from the last local pass
         for (int k = 2; k <= n_pad; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int t = tid; t < (n_pad >> 1); t += 1024) {
-                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    const int p = i | j;
-                    unsigned long long a = sk[i], c = sk[p];
-                    compare_exchange_desc(a, c, (i & k) == 0);
-                    sk[i] = a; sk[p] = c;
+                if (j >= E) {                                // far stride: any thread, any pair
+                    if (!synced) __syncthreads();
+                    for (int t = tid; t < (n_pad >> 1); t += 1024) {
+                        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                        const int p = i | j;
+                        unsigned long long a = sk[i], c = sk[p];
+                        compare_exchange_desc(a, c, (i & k) == 0);
+                        sk[i] = a; sk[p] = c;
+                    }
+                    __syncthreads();
+                    synced = true;
+                } else {                                     // stride inside this wave's block
+                    if (owner) {
+                        for (int q = lane; q < (E >> 1); q += 64) {
+                            const int i = wave * E + (((q & ~(j - 1)) << 1) | (q & (j - 1)));
+                            const int p = i | j;
+                            unsigned long long a = sk[i], c = sk[p];
+                            compare_exchange_desc(a, c, (i & k) == 0);
+                            sk[i] = a; sk[p] = c;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    synced = false;
                 }
-                __syncthreads();
             }
         }
+        __syncthreads();
     } else {
         for (int t = n + tid; t < n_pad; t += 1024) K[t] = 0ull;
         sync_global();                                              // keys travel through HBM between threads here
