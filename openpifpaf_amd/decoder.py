@@ -252,6 +252,62 @@ class CifCaf(Decoder):
         return result
 
 
+class CifCafDense(Decoder):
+    """Reference ``decoder/cifcaf.py:17-78``: a third head with dense (extra) bones is decoded together
+    with the sparse CAF head -- the two CAF field stacks are concatenated along the bone axis and go
+    through the same association kernel with the concatenated skeleton (53+ bones for COCO: the LDS
+    variant of the growth state).  Like the reference's C++ (``cifcaf.cpp:299-301``, commented out),
+    ``dense_coupling`` only selects the decoder; the confidence scales are recorded, not applied."""
+    dense_coupling = 0.0
+
+    def __init__(self, cif_meta: headmeta.Cif, caf_meta: headmeta.Caf, dense_caf_meta: headmeta.Caf):
+        super().__init__()
+        self.cif_meta = cif_meta
+        self.caf_meta = caf_meta
+        self.dense_caf_meta = dense_caf_meta
+        self.priority += cif_meta.n_fields / 1000.0
+        self.priority += caf_meta.n_fields / 1000.0
+        self.priority += dense_caf_meta.n_fields / 1000.0
+        self.dense_caf_meta.decoder_confidence_scales = [self.dense_coupling for _ in self.dense_caf_meta.skeleton]
+        concatenated_caf_meta = headmeta.Caf.concatenate([caf_meta, dense_caf_meta])
+        self.cifcaf = CifCaf([cif_meta], [concatenated_caf_meta])
+
+    @classmethod
+    def cli(cls, parser: argparse.ArgumentParser):
+        group = parser.add_argument_group('CifCafDense decoder')
+        group.add_argument('--dense-connections', nargs='?', type=float, default=0.0, const=1.0)
+
+    @classmethod
+    def configure(cls, args: argparse.Namespace):
+        cls.dense_coupling = args.dense_connections
+
+    @classmethod
+    def factory(cls, head_metas):
+        if len(head_metas) < 3 or not cls.dense_coupling:
+            return []
+        return [
+            CifCafDense(cif_meta, caf_meta, dense_meta)
+            for cif_meta, caf_meta, dense_meta in zip(head_metas, head_metas[1:], head_metas[2:])
+            if (isinstance(cif_meta, headmeta.Cif) and isinstance(caf_meta, headmeta.Caf)
+                and isinstance(dense_meta, headmeta.Caf))
+        ]
+
+    def _fields(self, fields, dim):
+        return [fields[self.cif_meta.head_index],
+                torch.cat([fields[self.caf_meta.head_index], fields[self.dense_caf_meta.head_index]], dim=dim)]
+
+    def __call__(self, fields, initial_annotations=None):
+        return self.cifcaf(self._fields(fields, 0))
+
+    def batch(self, model, image_batch, *, device=None, gt_anns_batch=None):
+        """Batched: heads ``[B,A,8,H,W]`` are concatenated along the bone axis on the device."""
+        inner = self.cifcaf
+        wrapped = lambda images: self._fields(model(images), 1)    # noqa: E731
+        result = inner.batch(wrapped, image_batch, device=device, gt_anns_batch=gt_anns_batch)
+        self.last_nn_time, self.last_decoder_time = inner.last_nn_time, inner.last_decoder_time
+        return result
+
+
 def _nms_keep(boxes, scores, iou_threshold):
     """Greedy IoU non-maximum suppression on (x0,y0,x1,y1) boxes -> kept indices (what
     ``torchvision.ops.nms`` computes; torchvision is not a dependency here)."""
@@ -353,7 +409,7 @@ class Multi(Decoder):
         return super().batch(model, image_batch, device=device, gt_anns_batch=gt_anns_batch)
 
 
-DECODERS = {CifCaf, CifDet}
+DECODERS = {CifCaf, CifCafDense, CifDet}
 
 
 def cli(parser, *, workers=None):

@@ -78,6 +78,29 @@ class Caf(Base):
     def n_fields(self) -> int:
         return len(self.skeleton)
 
+    @staticmethod
+    def concatenate(metas):
+        """Reference ``headmeta.py:89-113``: one meta whose skeleton is the metas' skeletons in a row
+        (used by ``CifCafDense``: sparse + dense CAF heads decoded as one CAF head)."""
+        concatenated = Caf(
+            name='_'.join(m.name for m in metas),
+            dataset=metas[0].dataset,
+            keypoints=metas[0].keypoints,
+            sigmas=metas[0].sigmas,
+            pose=metas[0].pose,
+            skeleton=[s for meta in metas for s in meta.skeleton],
+            sparse_skeleton=metas[0].sparse_skeleton,
+            only_in_field_of_view=metas[0].only_in_field_of_view,
+        )
+        concatenated.decoder_confidence_scales = [
+            s for meta in metas
+            for s in (meta.decoder_confidence_scales if meta.decoder_confidence_scales
+                      else [1.0 for _ in meta.skeleton])]
+        concatenated.head_index = metas[0].head_index
+        concatenated.base_stride = metas[0].base_stride
+        concatenated.upsample_stride = metas[0].upsample_stride
+        return concatenated
+
 
 @dataclass
 class CifDet(Base):
@@ -112,3 +135,17 @@ def cocokp_metas(upsample_stride=2, base_stride=16):
         m.base_stride = base_stride
         m.upsample_stride = upsample_stride
     return cif, caf
+
+
+def cocokp_dense_metas(upsample_stride=2, base_stride=16):
+    """(Cif, Caf, dense Caf): the ``cocokp`` heads plus the CAF head over ``DENSER_COCO_PERSON_CONNECTIONS``
+    (reference ``plugins/coco/cocokp.py:68-85`` with ``--cocokp-with-dense``)."""
+    from . import constants
+    cif, caf = cocokp_metas(upsample_stride, base_stride)
+    dcaf = Caf('caf25', 'cocokp', keypoints=constants.COCO_KEYPOINTS, sigmas=constants.COCO_PERSON_SIGMAS,
+               pose=constants.COCO_UPRIGHT_POSE, skeleton=constants.DENSER_COCO_PERSON_CONNECTIONS,
+               sparse_skeleton=constants.COCO_PERSON_SKELETON, only_in_field_of_view=True)
+    dcaf.head_index = 2
+    dcaf.base_stride = base_stride
+    dcaf.upsample_stride = upsample_stride
+    return cif, caf, dcaf

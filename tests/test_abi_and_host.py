@@ -104,6 +104,12 @@ def test_registry_factory_and_cli():
     # the factory pairs consecutive (Cif, Caf) metas (reference cifcaf.py:213-222); building needs a GPU
     cif, caf = headmeta.cocokp_metas()
     assert cif.stride == 8 and caf.n_fields == 19 and cif.n_fields == 17
+    # CifCafDense (reference cifcaf.py:17-78) is offered only with --dense-connections and three heads
+    cif, caf, dcaf = headmeta.cocokp_dense_metas()
+    both = headmeta.Caf.concatenate([caf, dcaf])
+    assert both.n_fields == 19 + 25 and both.skeleton[:19] == list(caf.skeleton) and both.head_index == 1
+    assert both.decoder_confidence_scales == [1.0] * 44
+    assert decoder.CifCafDense in decoder.DECODERS and decoder.CifCafDense.factory([cif, caf, dcaf]) == []
 
 
 def test_annotation_matches_reference_semantics():

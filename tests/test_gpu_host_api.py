@@ -58,3 +58,40 @@ def test_predictor_end_to_end_smoke():
     finally:
         Predictor.long_edge = None
         Predictor.batch_size = 1
+
+
+def test_cifcafdense_decodes_concatenated_heads_like_the_oracle():
+    """CifCafDense (reference decoder/cifcaf.py:17-78): sparse + dense CAF heads go through the association
+    kernel as ONE 44-bone head (2A = 88 directed bones: the LDS variant of the growth state)."""
+    from openpifpaf_amd import constants, decoder, headmeta, synth
+    from oracle import port
+    skeleton = list(constants.COCO_PERSON_SKELETON) + list(constants.DENSER_COCO_PERSON_CONNECTIONS)
+    skeleton0 = np.asarray(skeleton, dtype=np.int64) - 1
+    metas = headmeta.cocokp_dense_metas()
+    decoder.CifCafDense.dense_coupling = 1.0
+    try:
+        decs = decoder.CifCafDense.factory(list(metas))
+        assert len(decs) == 1 and decs[0].priority > decoder.CifCaf.factory(list(metas))[0].priority
+        dec = decs[0]
+        cifs, cafs = [], []
+        for seed, people in ((81, 3), (82, 7)):
+            cif, caf = synth.synth_fields(seed, people, height=49, width=49, skeleton=skeleton)
+            assert caf.shape[0] == 44
+            cifs.append(cif); cafs.append(caf)
+            fields = [torch.from_numpy(cif).cuda(), torch.from_numpy(caf[:19]).cuda(), torch.from_numpy(caf[19:]).cuda()]
+            anns = dec(fields)
+            want, _ = port.decode(cif, 8, caf, 8, skeleton0)
+            assert len(anns) == len(want) >= 1
+            for ann, w in zip(anns, want):
+                assert np.allclose(ann.data[:, 2], w[:, 0], atol=1e-4) and np.allclose(ann.data[:, :2], w[:, 1:3], atol=1e-4)
+                assert len(ann.skeleton) == 44
+
+        class Heads:                          # a model that emits the three heads for a batch
+            def __call__(self, images):
+                c, a = torch.from_numpy(np.stack(cifs)).cuda(), torch.from_numpy(np.stack(cafs)).cuda()
+                return (c, a[:, :19].contiguous(), a[:, 19:].contiguous())
+
+        result = dec.batch(Heads(), torch.zeros((2, 3, 385, 385)), device=torch.device('cuda'))
+        assert [len(r) for r in result] == [len(port.decode(c, 8, a, 8, skeleton0)[0]) for c, a in zip(cifs, cafs)]
+    finally:
+        decoder.CifCafDense.dense_coupling = 0.0
