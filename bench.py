@@ -57,6 +57,11 @@ def parse_args():
     p.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline budget (rank 0, N=1)')
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--decode-only', action='store_true', help='skip the backbone (kernel work only)')
+    p.add_argument('--graph', action='store_true',
+                   help='decode-only: replay each decoder\'s call as a captured HIP graph')
+    p.add_argument('--decode-streams', type=int, default=1,
+                   help='decode-only: round-robin the batches over this many decoders, each with its own '
+                        'stream and workspace (a batch-32 association occupies 32 of the 256 CUs)')
     p.add_argument('--profile-steps', type=int, default=5)
     p.add_argument('--force-complete', action='store_true',
                    help='decode like the reference\'s benchmark CLI (--force-complete-pose, thresholds 0)')
@@ -209,6 +214,17 @@ def main():
                  nms_instance_threshold=0.0, nms_keypoint_threshold=0.0)     # reference decoder/cifcaf.py:180-185
     dec_params = _lib.default_params(**fc_kw) if args.force_complete else None
     dec = native.CifCaf(17, torch.from_numpy(skeleton0))
+    n_streams = max(1, args.decode_streams) if args.decode_only else 1
+    extra = [(native.CifCaf(17, torch.from_numpy(skeleton0)), torch.cuda.Stream(priority=-1))
+             for _ in range(n_streams - 1)]
+    step_no = [0]
+    graphs = None
+    if args.decode_only and args.graph:              # one captured decode per (decoder, stream)
+        lanes = [(dec, torch.cuda.Stream(priority=-1))] + extra
+        graphs = []
+        for d, st in lanes:
+            g, outs = d.capture(cif_syn, stride, caf_syn, stride, params=dec_params, stream=st)
+            graphs.append((g, st, outs))
     K = 17
     host_out = torch.empty((B, dec.max_annotations, K, 4), dtype=torch.float32).pin_memory()
     host_counts = torch.empty((B,), dtype=torch.int32).pin_memory()
@@ -227,6 +243,21 @@ def main():
                 assert tuple(heads[0].shape) == tuple(cif_syn.shape), (heads[0].shape, cif_syn.shape)
                 assert tuple(heads[1].shape) == tuple(caf_syn.shape), (heads[1].shape, caf_syn.shape)
                 shapes_checked[0] = True
+        step_no[0] += 1
+        if graphs is not None:
+            g, st, (out, ids, counts) = graphs[step_no[0] % n_streams]
+            with torch.cuda.stream(st):
+                g.replay()
+                host_out.copy_(out, non_blocking=True)
+                host_counts.copy_(counts, non_blocking=True)
+            return out
+        if n_streams > 1 and step_no[0] % n_streams:   # decode-only: this batch goes to one of the extra decoders
+            d, st = extra[step_no[0] % n_streams - 1]
+            with torch.cuda.stream(st):
+                out, ids, counts = d.call_batch(cif_syn, stride, caf_syn, stride, params=dec_params)
+                host_out.copy_(out, non_blocking=True)
+                host_counts.copy_(counts, non_blocking=True)
+            return out
         ev = torch.cuda.Event()
         ev.record(main_stream)
         with torch.cuda.stream(dec_stream):
@@ -336,6 +367,7 @@ def main():
                 'parallelism': 'images sharded one batch per GPU (dp%d); RCCL all_gather of annotations' % world
                                if world > 1 else 'single GPU',
                 'decode_overlapped_on_second_stream': not args.no_overlap,
+                'decode_streams': n_streams, 'hip_graph': graphs is not None,
                 'force_complete_pose': bool(args.force_complete),
                 'annotations_per_batch': n_ann,
             },

@@ -342,7 +342,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
                              (int32_t*)(ws + L.off_list_counts_fc), st);
         if (e != hipSuccess) return fail_hip(e, "cafscored(force complete)");
     }
-    e = hipMemsetAsync(ws + L.off_occ, 0, (size_t)L.B * L.F * L.occ_h * L.occ_w, st);        // :173
+    e = launch_zero(ws + L.off_occ, ((size_t)L.B * L.F * L.occ_h * L.occ_w + 3) & ~(size_t)3, st);   // :173
     if (e != hipSuccess) return fail_hip(e, "occupancy memset");
     prof_mark(st, "memset_occupancy");
 
@@ -519,7 +519,7 @@ int opa_cifdet_decode(const opa_det_shape* shape, const opa_params* params, cons
     if (e != hipSuccess) return fail_hip(e, "cifdetseeds");
     const int occ_h = (int)((double)L.hr_rows / hp.occupancy_reduction) + 1;
     const int occ_w = (int)((double)L.hr_cols / hp.occupancy_reduction) + 1;
-    e = hipMemsetAsync(ws + L.off_occ, 0, (size_t)B * F * occ_h * occ_w, st);                            // :44
+    e = launch_zero(ws + L.off_occ, ((size_t)B * F * occ_h * occ_w + 3) & ~(size_t)3, st);                // :44
     if (e != hipSuccess) return fail_hip(e, "occupancy memset");
     prof_mark(st, "memset_occupancy");
     DetArgs a;

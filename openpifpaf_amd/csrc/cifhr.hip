@@ -271,6 +271,13 @@ __global__ __launch_bounds__(256) void cifhr_tile_kernel(
     }
 }
 
+// this call's touched-tile bitmap becomes the next call's "previous" (a kernel rather than a D2D
+// hipMemcpyAsync: small copy nodes inside a captured HIP graph fault on replay with ROCm 7.2)
+__global__ __launch_bounds__(256) void tile_state_roll_kernel(unsigned* __restrict__ prev, const unsigned* __restrict__ cur, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) prev[i] = cur[i];
+}
+
 hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride,
                         double min_scale, double factor, const DevParams& p,
                         float* cifhr, int hr_rows, int hr_pitch,
@@ -309,9 +316,8 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
     cifhr_tile_kernel<<<planes * kTileGroups, 256, 0, st>>>(act, act_count, HW, cifhr, hr_rows, hr_cols, hr_pitch,
                                                              tiles_x, tiles_y, ws_header, tile_prev, tile_touch, touch_words);
     if (ws_header) {                                  // this call's bitmap is the next call's "previous"
-        hipError_t e = hipMemcpyAsync(tile_prev, tile_touch, sizeof(unsigned) * touch_words * planes,
-                                      hipMemcpyDeviceToDevice, st);
-        if (e != hipSuccess) return e;
+        const int n = touch_words * planes;
+        tile_state_roll_kernel<<<(n + 255) / 256, 256, 0, st>>>(tile_prev, tile_touch, n);
     }
     prof_mark(st, "cifhr_tile_kernel");
     return hipGetLastError();

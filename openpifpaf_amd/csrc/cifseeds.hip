@@ -218,7 +218,7 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
                            int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det,
                            int32_t* seed_cell, int occ_h, int occ_w) {
     const int HW = H * W, cap = F * HW, NC = det ? 6 : 5;
-    hipError_t e = hipMemsetAsync(seed_count, 0, sizeof(int32_t) * B, st);
+    hipError_t e = launch_zero(seed_count, sizeof(int32_t) * B, st);
     if (e != hipSuccess) return e;
     prof_mark(st, "memset_seed_count");
     dim3 grid(B * F, (HW + 256 * kFillCells - 1) / (256 * kFillCells));

@@ -84,6 +84,10 @@ hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int 
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
                             float* lists, int32_t* counts, hipStream_t st);
 
+// zero-fill on the stream with a kernel of this library (the runtime's memset / small-copy nodes are the
+// one thing that faulted when the decode was replayed as a captured HIP graph); bytes % 4 == 0
+hipError_t launch_zero(void* dst, size_t bytes, hipStream_t st);
+
 struct AssocArgs {
     int B, K, A, max_ann, n_initial;
     int hr_rows, hr_cols;

@@ -116,4 +116,24 @@ hipError_t launch_bias_act(void* x, const void* bias, const void* res, long long
     }
 }
 
+// ---- zero fill (see common.hpp) ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void zero_kernel(unsigned* __restrict__ dst, size_t n_words) {
+    const size_t n16 = n_words / 4;
+    uint4* d16 = reinterpret_cast<uint4*>(dst);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        d16[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0 && threadIdx.x < (n_words & 3)) dst[n16 * 4 + threadIdx.x] = 0u;
+}
+
+hipError_t launch_zero(void* dst, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return hipSuccess;
+    if ((bytes & 3) || ((uintptr_t)dst & 15)) return hipMemsetAsync(dst, 0, bytes, st);
+    const size_t n_words = bytes / 4;
+    size_t blocks = (n_words / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks == 0) blocks = 1;
+    zero_kernel<<<(unsigned)blocks, 256, 0, st>>>((unsigned*)dst, n_words);
+    return hipGetLastError();
+}
+
 }  // namespace opa

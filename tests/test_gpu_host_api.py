@@ -95,3 +95,26 @@ def test_cifcafdense_decodes_concatenated_heads_like_the_oracle():
         assert [len(r) for r in result] == [len(port.decode(c, 8, a, 8, skeleton0)[0]) for c, a in zip(cifs, cafs)]
     finally:
         decoder.CifCafDense.dense_coupling = 0.0
+
+
+def test_captured_decode_graph_replays_equal_eager_results(coco_skeleton0):
+    """native.CifCaf.capture: the decode as one HIP graph; refilling the static input tensors and replaying
+    must give what an eager call gives (workspace state -- the lazily cleared CifHr map -- included)."""
+    from openpifpaf_amd import native, synth
+    eager = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    a = synth.synth_batch(4, seed0=300, height=49, width=49, people=(6, 1, 3, 9))
+    b = synth.synth_batch(4, seed0=400, height=49, width=49, people=(1, 8, 2, 0))
+    cif_t, caf_t = torch.from_numpy(a[0]).cuda(), torch.from_numpy(a[1]).cuda()
+    graph, (out, ids, counts) = dec.capture(cif_t, 8, caf_t, 8)
+    for fields in (b, a, b):
+        cif_t.copy_(torch.from_numpy(fields[0]))
+        caf_t.copy_(torch.from_numpy(fields[1]))
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        want = eager.call_batch(torch.from_numpy(fields[0]).cuda(), 8, torch.from_numpy(fields[1]).cuda(), 8)
+        assert torch.equal(counts, want[2])
+        for i in range(4):
+            n = int(counts[i])
+            assert torch.equal(out[i, :n], want[0][i, :n])
