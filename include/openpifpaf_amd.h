@@ -231,6 +231,14 @@ int opa_bias_act(void* x_dev, const void* bias_dev, const void* residual_dev,
 int opa_gemm_bias_act_bf16(const void* a_dev, const void* w_dev, const void* bias_dev, const void* residual_dev,
                            void* out_dev, int64_t m, int32_t n, int32_t k, int32_t relu, void* stream);
 
+/* The same GEMM with a fused PROLOGUE on its A operand: A is the raw output of the preceding (3x3)
+ * convolution and  A'[m,k] = relu(A[m,k] + a_bias[k])  -- that convolution's bias + ReLU -- is applied while
+ * the tile is staged, so its separate epilogue pass (opa_bias_act) disappears:
+ *     out[M,N] = act(relu(A + a_bias) * W^T + bias (+ residual)) */
+int opa_gemm_pro_bias_act_bf16(const void* a_dev, const void* a_bias_dev, const void* w_dev, const void* bias_dev,
+                               const void* residual_dev, void* out_dev, int64_t m, int32_t n, int32_t k,
+                               int32_t relu, void* stream);
+
 /* ---- measurement -------------------------------------------------------- */
 /* Per-kernel timing with HIP events on the launch stream (no reference
  * counterpart; bench.py's roofline leg uses it).  Between opa_profile_begin and

@@ -100,6 +100,7 @@ SYMBOLS = {
     'opa_cifdet_decode': (ctypes.c_int, [_P(DetShape), _P(Params), _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     'opa_bias_act': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     'opa_gemm_bias_act_bf16': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    'opa_gemm_pro_bias_act_bf16': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     'opa_profile_begin': (ctypes.c_int, [_vp]),
     'opa_profile_end': (ctypes.c_int, [_i32, _P(ctypes.c_char_p), _P(ctypes.c_float), _P(_i32)]),
 }

@@ -562,6 +562,23 @@ int opa_gemm_bias_act_bf16(const void* a_dev, const void* w_dev, const void* bia
     return OPA_OK;
 }
 
+int opa_gemm_pro_bias_act_bf16(const void* a_dev, const void* a_bias_dev, const void* w_dev, const void* bias_dev,
+                               const void* residual_dev, void* out_dev, int64_t m, int32_t n, int32_t k,
+                               int32_t relu, void* stream) {
+    if (!a_dev || !a_bias_dev || !w_dev || !bias_dev || !out_dev || m < 0 || n <= 0 || k <= 0 || m > 0x7fffffffll)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_gemm_pro_bias_act_bf16: bad arguments");
+    if (k % 64 != 0 || n % 64 != 0)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_gemm_pro_bias_act_bf16: K and N must be multiples of 64");
+    if (((uintptr_t)a_dev | (uintptr_t)a_bias_dev | (uintptr_t)w_dev | (uintptr_t)out_dev | (uintptr_t)residual_dev) & 15)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_gemm_pro_bias_act_bf16: pointers must be 16-B aligned");
+    if (m == 0) return OPA_OK;
+    hipError_t e = launch_gemm_bias_act(a_dev, w_dev, bias_dev, residual_dev, out_dev, (int)m, n, k, relu,
+                                        (hipStream_t)stream, a_bias_dev);
+    if (e != hipSuccess) return fail_hip(e, "gemm_pro_bias_act");
+    prof_mark((hipStream_t)stream, "gemm_pro_bias_act_kernel");
+    return OPA_OK;
+}
+
 int opa_profile_begin(void* stream) {
     for (hipEvent_t ev : g_prof.events) (void)hipEventDestroy(ev);
     g_prof.events.clear(); g_prof.names.clear();

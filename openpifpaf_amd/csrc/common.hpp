@@ -118,7 +118,7 @@ hipError_t launch_bias_act(void* x, const void* bias, const void* res, long long
                            int relu, hipStream_t st);
 
 hipError_t launch_gemm_bias_act(const void* A, const void* W, const void* bias, const void* res, void* out,
-                                int M, int N, int K, int relu, hipStream_t st);
+                                int M, int N, int K, int relu, hipStream_t st, const void* a_bias = nullptr);
 
 hipError_t launch_blend(const float* rows, int n, double x, double y, double s, double filter_sigmas,
                         int only_max, double* out4_dev, hipStream_t st);

@@ -33,11 +33,15 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {
     return u >> 16;
 }
 
-template <int BN, bool RES, bool RELU>
+// PRO: the A operand is the RAW output of the preceding convolution; its bias + ReLU epilogue
+// (a_bias[k], per input channel) is applied while the tile is staged into LDS -- same f32 add, max and
+// round-to-nearest-even as the separate bias_act pass, which is thereby saved (one read and one write
+// of the 3x3 convolution's output per bottleneck).
+template <int BN, bool RES, bool RELU, bool PRO>
 __global__ __launch_bounds__(256, 3) void gemm_bias_act_kernel(
         const unsigned short* __restrict__ A, const unsigned short* __restrict__ W,
         const unsigned short* __restrict__ bias, const unsigned short* __restrict__ res,
-        unsigned short* __restrict__ out, int M, int N, int K) {
+        unsigned short* __restrict__ out, int M, int N, int K, const unsigned short* __restrict__ a_bias) {
     constexpr int WN = BN / 2;                 // wave tile width
     constexpr int NT = WN / 32;                // 32-wide MFMA blocks per wave in N (2 or 1)
     constexpr int LDS_A = kGemmBM * kGemmPitch, LDS_B = BN * kGemmPitch;
@@ -94,6 +98,17 @@ __global__ __launch_bounds__(256, 3) void gemm_bias_act_kernel(
             const int m = m0 + p * 32 + s_row;
             ra[p] = (u32x4_t){0u, 0u, 0u, 0u};
             if (m < M) ra[p] = *reinterpret_cast<const u32x4_t*>(A + (size_t)m * K + k0 + s_col);
+        }
+        if (PRO) {
+            const u32x4_t ab = *reinterpret_cast<const u32x4_t*>(a_bias + k0 + s_col);
+#pragma unroll
+            for (int p = 0; p < kGemmBM / 32; p++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const float lo = fmaxf(bf16_lo(ra[p][q]) + bf16_lo(ab[q]), 0.0f);
+                    const float hi = fmaxf(bf16_hi(ra[p][q]) + bf16_hi(ab[q]), 0.0f);
+                    ra[p][q] = bf16_rne(lo) | (bf16_rne(hi) << 16);
+                }
         }
 #pragma unroll
         for (int p = 0; p < BN / 32; p++)
@@ -172,27 +187,32 @@ __global__ __launch_bounds__(256, 3) void gemm_bias_act_kernel(
     }
 }
 
-template <int BN>
+template <int BN, bool PRO>
 static hipError_t launch_bn(const void* A, const void* W, const void* bias, const void* res, void* out,
-                            int M, int N, int K, int relu, hipStream_t st) {
+                            int M, int N, int K, int relu, const void* a_bias, hipStream_t st) {
     const long long blocks = (long long)((M + kGemmBM - 1) / kGemmBM) * (N / BN);
     const unsigned short *a = (const unsigned short*)A, *w = (const unsigned short*)W,
-                         *b = (const unsigned short*)bias, *r = (const unsigned short*)res;
+                         *b = (const unsigned short*)bias, *r = (const unsigned short*)res,
+                         *ab = (const unsigned short*)a_bias;
     unsigned short* o = (unsigned short*)out;
     if (res) {
-        if (relu) gemm_bias_act_kernel<BN, true, true><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K);
-        else gemm_bias_act_kernel<BN, true, false><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K);
+        if (relu) gemm_bias_act_kernel<BN, true, true, PRO><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab);
+        else gemm_bias_act_kernel<BN, true, false, PRO><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab);
     } else {
-        if (relu) gemm_bias_act_kernel<BN, false, true><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K);
-        else gemm_bias_act_kernel<BN, false, false><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K);
+        if (relu) gemm_bias_act_kernel<BN, false, true, PRO><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab);
+        else gemm_bias_act_kernel<BN, false, false, PRO><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_gemm_bias_act(const void* A, const void* W, const void* bias, const void* res, void* out,
-                                int M, int N, int K, int relu, hipStream_t st) {
-    if (N % 128 == 0) return launch_bn<128>(A, W, bias, res, out, M, N, K, relu, st);
-    return launch_bn<64>(A, W, bias, res, out, M, N, K, relu, st);
+                                int M, int N, int K, int relu, hipStream_t st, const void* a_bias) {
+    if (a_bias) {
+        if (N % 128 == 0) return launch_bn<128, true>(A, W, bias, res, out, M, N, K, relu, a_bias, st);
+        return launch_bn<64, true>(A, W, bias, res, out, M, N, K, relu, a_bias, st);
+    }
+    if (N % 128 == 0) return launch_bn<128, false>(A, W, bias, res, out, M, N, K, relu, nullptr, st);
+    return launch_bn<64, false>(A, W, bias, res, out, M, N, K, relu, nullptr, st);
 }
 
 }  // namespace opa

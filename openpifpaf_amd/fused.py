@@ -47,16 +47,25 @@ def conv1x1_supported(x, weight):
             and weight.shape[1] % 64 == 0 and weight.shape[0] % 64 == 0)
 
 
-def conv1x1_bias_act(x, weight2d, bias, residual=None, relu=True):
+def conv1x1_bias_act(x, weight2d, bias, residual=None, relu=True, a_bias=None):
     """``act(conv1x1(x, weight) + bias (+ residual))`` as ONE MFMA GEMM kernel with fused epilogue.
 
     :param x: ``[B, C_in, H, W]`` bfloat16, channels_last
     :param weight2d: ``[C_out, C_in]`` bfloat16 contiguous
+    :param a_bias: ``[C_in]``: ``x`` is the RAW output of the preceding convolution and
+        ``relu(x + a_bias)`` -- that convolution's epilogue -- is applied while the operand is staged
     :returns: ``[B, C_out, H, W]`` bfloat16, channels_last
     """
     B, K, H, W = x.shape
     N = weight2d.shape[0]
     out = torch.empty((B, N, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if a_bias is not None:
+        _lib.check(_lib.lib().opa_gemm_pro_bias_act_bf16(
+            ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(a_bias.data_ptr()), ctypes.c_void_p(weight2d.data_ptr()),
+            ctypes.c_void_p(bias.data_ptr()), ctypes.c_void_p(residual.data_ptr()) if residual is not None else None,
+            ctypes.c_void_p(out.data_ptr()), B * H * W, N, K, int(bool(relu)),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'opa_gemm_pro_bias_act_bf16')
+        return out
     _lib.check(_lib.lib().opa_gemm_bias_act_bf16(
         ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(weight2d.data_ptr()), ctypes.c_void_p(bias.data_ptr()),
         ctypes.c_void_p(residual.data_ptr()) if residual is not None else None,
@@ -80,23 +89,33 @@ def _time_ms(fn, reps=3):
     return start.elapsed_time(end) / reps
 
 
-def conv_bias_act(conv, x, bias, residual=None, relu=True):
+def conv_bias_act(conv, x, bias, residual=None, relu=True, a_bias=None):
     """``act(conv(x) + bias (+ residual))`` for a bias-free ``conv`` module: 1x1 stride-1 convolutions go
     to the fused MFMA GEMM when it is faster than MIOpen's convolution + the fused epilogue pass
-    (decided once per shape by timing both on the first call); everything else is conv + ``bias_act_``."""
+    (decided once per shape by timing both on the first call); everything else is conv + ``bias_act_``.
+
+    With ``a_bias``, ``x`` is the raw output of the preceding convolution whose epilogue
+    ``relu(x + a_bias[c])`` has not been applied yet: the GEMM applies it to its operand on the fly, the
+    fallback applies it in place first."""
     w = conv.weight
     if (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and conv.padding == (0, 0)
             and conv1x1_supported(x, w)):
         M = x.shape[0] * x.shape[2] * x.shape[3]
-        key = (M, w.shape[1], w.shape[0], residual is not None)
+        key = (M, w.shape[1], w.shape[0], residual is not None, a_bias is not None)
         w2d = w.reshape(w.shape[0], w.shape[1])
         if not w2d.is_contiguous():
             w2d = w2d.contiguous()
         choice = _CHOICE.get(key)
         if choice is None:
-            t_gemm = _time_ms(lambda: conv1x1_bias_act(x, w2d, bias, residual, relu))
-            t_conv = _time_ms(lambda: bias_act_(conv(x), bias, residual, relu))
+            t_gemm = _time_ms(lambda: conv1x1_bias_act(x, w2d, bias, residual, relu, a_bias))
+            if a_bias is None:
+                t_conv = _time_ms(lambda: bias_act_(conv(x), bias, residual, relu))
+            else:       # timing only: the extra epilogue pass runs on a scratch copy
+                scratch = x.clone()
+                t_conv = _time_ms(lambda: bias_act_(conv(bias_act_(scratch, a_bias)), bias, residual, relu))
             choice = _CHOICE[key] = 'gemm' if t_gemm < t_conv else 'conv'
         if choice == 'gemm':
-            return conv1x1_bias_act(x, w2d, bias, residual, relu)
+            return conv1x1_bias_act(x, w2d, bias, residual, relu, a_bias)
+    if a_bias is not None:
+        x = bias_act_(x, a_bias)
     return bias_act_(conv(x), bias, residual, relu)

@@ -62,8 +62,9 @@ class _Bottleneck(nn.Module):
         if self.fused:      # conv (no bias) -> ONE fused bias(+residual)+ReLU pass each
             identity = x if self.downsample is None else self.downsample[0](x)
             out = fused.conv_bias_act(self.conv1, x, self.fb1)            # 1x1: fused MFMA GEMM
-            out = fused.conv_bias_act(self.conv2, out, self.fb2)          # 3x3: MIOpen + fused epilogue
-            return fused.conv_bias_act(self.conv3, out, self.fb3, identity)
+            out = self.conv2(out)                                         # 3x3: MIOpen, raw output ...
+            # ... whose bias + ReLU is applied by the 1x1 GEMM below while it stages its operand
+            return fused.conv_bias_act(self.conv3, out, self.fb3, identity, a_bias=self.fb2)
         identity = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))

@@ -67,6 +67,24 @@ def test_fused_conv1x1_gemm_matches_fp32_reference(cin, cout, hw, with_res):
         assert bool((err <= tol).all()), float(err.max())
 
 
+@pytest.mark.parametrize('cin,cout,hw,with_res', [(64, 256, 37, True), (128, 512, 19, True), (512, 2048, 9, False)])
+def test_gemm_with_fused_operand_prologue_equals_two_passes(cin, cout, hw, with_res):
+    """opa_gemm_pro_bias_act_bf16: relu(x + a_bias) applied while the A tile is staged must give the very
+    same bits as the separate bias_act pass followed by the plain fused GEMM."""
+    from openpifpaf_amd import fused
+    torch.manual_seed(2)
+    B = 3
+    x = (torch.randn(B, cin, hw, hw, device='cuda') * 0.7).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ab = (torch.randn(cin, device='cuda') * 0.3).to(torch.bfloat16)
+    w = (torch.randn(cout, cin, device='cuda') / cin ** 0.5).to(torch.bfloat16)
+    b = torch.randn(cout, device='cuda').to(torch.bfloat16)
+    r = torch.randn(B, cout, hw, hw, device='cuda').to(torch.bfloat16).contiguous(memory_format=torch.channels_last) \
+        if with_res else None
+    want = fused.conv1x1_bias_act(fused.bias_act_(x.clone(), ab), w, b, r, True)
+    got = fused.conv1x1_bias_act(x, w, b, r, True, a_bias=ab)
+    assert torch.equal(got, want)
+
+
 def test_resnet50_fused_gemm_forward_close_to_unfused():
     from openpifpaf_amd import network
     net = network.factory('resnet50').cuda()
