@@ -91,14 +91,17 @@ __global__ __launch_bounds__(256, 3) void gemm_bias_act_kernel(
 
     // staging map: a 64-wide bf16 row is 8 x 16 B; 256 threads cover 32 rows per pass
     const int s_row = tid >> 3, s_col = (tid & 7) * 8;
-    for (int k0 = 0; k0 < K; k0 += kGemmBK) {
-        u32x4_t ra[kGemmBM / 32], rb[BN / 32];
+    u32x4_t ra[kGemmBM / 32], rb[BN / 32];
+    auto fetch = [&](int k0) {                 // global -> registers for K-step k0 (with the operand prologue)
 #pragma unroll
         for (int p = 0; p < kGemmBM / 32; p++) {
             const int m = m0 + p * 32 + s_row;
             ra[p] = (u32x4_t){0u, 0u, 0u, 0u};
             if (m < M) ra[p] = *reinterpret_cast<const u32x4_t*>(A + (size_t)m * K + k0 + s_col);
         }
+#pragma unroll
+        for (int p = 0; p < BN / 32; p++)
+            rb[p] = *reinterpret_cast<const u32x4_t*>(W + (size_t)(n0 + p * 32 + s_row) * K + k0 + s_col);
         if (PRO) {
             const u32x4_t ab = *reinterpret_cast<const u32x4_t*>(a_bias + k0 + s_col);
 #pragma unroll
@@ -110,9 +113,9 @@ __global__ __launch_bounds__(256, 3) void gemm_bias_act_kernel(
                     ra[p][q] = bf16_rne(lo) | (bf16_rne(hi) << 16);
                 }
         }
-#pragma unroll
-        for (int p = 0; p < BN / 32; p++)
-            rb[p] = *reinterpret_cast<const u32x4_t*>(W + (size_t)(n0 + p * 32 + s_row) * K + k0 + s_col);
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += kGemmBK) {
         __syncthreads();                       // previous step's fragment reads are done
 #pragma unroll
         for (int p = 0; p < kGemmBM / 32; p++)
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(256, 3) void gemm_bias_act_kernel(
         for (int p = 0; p < BN / 32; p++)
             *reinterpret_cast<u32x4_t*>(sB + (p * 32 + s_row) * kGemmPitch + s_col) = rb[p];
         __syncthreads();
+        if (k0 + kGemmBK < K) fetch(k0 + kGemmBK);   // the next K-step's operands travel while this one multiplies
 #pragma unroll
         for (int kk = 0; kk < kGemmBK; kk += 16) {
             bf16x8_t fa[2], fb[NT];
