@@ -107,15 +107,19 @@ def conv_bias_act(conv, x, bias, residual=None, relu=True, a_bias=None):
             w2d = w2d.contiguous()
         choice = _CHOICE.get(key)
         if choice is None:
-            t_gemm = _time_ms(lambda: conv1x1_bias_act(x, w2d, bias, residual, relu, a_bias))
+            times = {'gemm': _time_ms(lambda: conv1x1_bias_act(x, w2d, bias, residual, relu, a_bias))}
             if a_bias is None:
-                t_conv = _time_ms(lambda: bias_act_(conv(x), bias, residual, relu))
-            else:       # timing only: the extra epilogue pass runs on a scratch copy
+                times['conv'] = _time_ms(lambda: bias_act_(conv(x), bias, residual, relu))
+            else:       # timing only: the separate epilogue pass runs on a scratch copy
                 scratch = x.clone()
-                t_conv = _time_ms(lambda: bias_act_(conv(bias_act_(scratch, a_bias)), bias, residual, relu))
-            choice = _CHOICE[key] = 'gemm' if t_gemm < t_conv else 'conv'
+                times['pass+gemm'] = _time_ms(
+                    lambda: conv1x1_bias_act(bias_act_(scratch, a_bias), w2d, bias, residual, relu))
+                times['conv'] = _time_ms(lambda: bias_act_(conv(bias_act_(scratch, a_bias)), bias, residual, relu))
+            choice = _CHOICE[key] = min(times, key=times.get)
         if choice == 'gemm':
             return conv1x1_bias_act(x, w2d, bias, residual, relu, a_bias)
+        if choice == 'pass+gemm':     # the prologue's VALU work is repeated per N-tile: cheaper as its own pass here
+            return conv1x1_bias_act(bias_act_(x, a_bias), w2d, bias, residual, relu)
     if a_bias is not None:
         x = bias_act_(x, a_bias)
     return bias_act_(conv(x), bias, residual, relu)

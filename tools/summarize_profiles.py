@@ -73,14 +73,15 @@ def pmc(sub, counter):
     path = find(sub, '*counter_collection.csv')
     if not path:
         return {}
-    acc = defaultdict(lambda: [0.0, 0])
+    acc = defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r.get('Counter_Name') != counter:
             continue
         k = short(r['Kernel_Name'])
-        acc[k][0] += float(r['Counter_Value'])
-        acc[k][1] += 1
-    return {k: v[0] / v[1] for k, v in acc.items() if v[1]}
+        acc[k].append(float(r['Counter_Value']))
+    # median over the launches: the first call on a workspace writes the whole CifHr map (lazy clear not
+    # primed yet) and would dominate a mean
+    return {k: sorted(v)[len(v) // 2] for k, v in acc.items() if v}
 
 
 print('# rocprofv3 summary (round 1)\n')
