@@ -464,3 +464,41 @@ def test_workspace_state_across_different_images(native, port, coco_skeleton0):
         assert got_hr.shape == want_hr.shape
         assert np.array_equal(got_hr, want_hr), 'step %d: stale or missing tiles (%d cells differ)' % (
             step, (got_hr != want_hr).sum())
+
+
+def test_annotation_capacity_overflow_is_flagged(native, port, coco_skeleton0):
+    """counts[b] > max_annotations flags dropped poses; the ones that fit are the first ones the sequential
+    loop creates (include/openpifpaf_amd.h: out_count_dev)."""
+    cif, caf = fields(91, 9)
+    want, _ = port.decode(cif, 8, caf, 8, coco_skeleton0)
+    assert len(want) >= 6
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0), max_annotations=3)
+    out, ids, cnt = dec.call_batch(dev(cif[None]), 8, dev(caf[None]), 8)
+    assert int(cnt[0]) > 3
+    with pytest.raises(Exception, match='capacity overflow'):
+        dec.call(dev(cif), 8, dev(caf), 8)
+    # enough room again: same decoder class, full result
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0), max_annotations=len(want))
+    out, ids, cnt = dec.call_batch(dev(cif[None]), 8, dev(caf[None]), 8)
+    ok, msg = compare_annotations(out[0, :int(cnt[0])].cpu().numpy(), want)
+    assert int(cnt[0]) == len(want) and ok, msg
+
+
+def test_random_geometry_sweep(native, port, coco_skeleton0):
+    """Many small, odd-shaped fields with random people counts, sizes and noise: every one must equal the
+    oracle (pool refill, tile bitmaps at plane borders, clamped boxes, single-row / single-column maps)."""
+    from openpifpaf_amd import synth
+    rng = np.random.default_rng(2024)
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    for case in range(40):
+        H, W = int(rng.integers(5, 40)), int(rng.integers(5, 40))
+        people = int(rng.integers(0, 7))
+        lo = float(rng.uniform(0.2, 0.6))
+        cif, caf = synth.synth_fields(1000 + case, people, height=H, width=W,
+                                      noise=float(rng.uniform(0.0, 0.3)), size_range=(lo, min(1.2, lo + 0.5)))
+        want, _ = port.decode(cif, 8, caf, 8, coco_skeleton0)
+        out, ids, cnt = dec.call_batch(dev(cif[None]), 8, dev(caf[None]), 8)
+        n = int(cnt[0])
+        assert n == len(want), 'case %d (%dx%d, %d people): %d poses, oracle %d' % (case, H, W, people, n, len(want))
+        ok, msg = compare_annotations(out[0, :n].cpu().numpy(), want)
+        assert ok, 'case %d (%dx%d, %d people): %s' % (case, H, W, people, msg)
