@@ -17,6 +17,12 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/pmc_$C" -o pmc -- \
       python "$OLDPWD/bench.py" --decode-only --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > "$OUT/pmc_${C}_stdout.log" 2> "$OUT/pmc_${C}_stderr.log"
 done
+# 4. cache / LDS / instruction-mix counters of the decode kernels (one small group per pass)
+for G in "TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
+  D="$OUT/pmc_$(echo $G | cut -d' ' -f1)"
+  rocprofv3 --pmc $G --kernel-trace --output-format csv -d "$D" -o pmc -- \
+      python "$OLDPWD/bench.py" --decode-only --steps 3 --warmup 1 --profile-steps 1 --no-cpu-baseline > "$D.stdout.log" 2> "$D.stderr.log"
+done
 cd "$OLDPWD"
 find "$OUT" -name "*.csv" | head -40
 python tools/summarize_profiles.py "$OUT" > "$OUT/summary.md" 2>&1

@@ -102,6 +102,25 @@ for k in sorted(set(fetch) | set(write)):
     f, w = fetch.get(k, 0.0), write.get(k, 0.0)
     print('| `%s` | %.1f | %.2f | %.1f | %.2f |' % (k, f, 2 * f * 1024 / 1e6, w, w * 1024 / 1e6))
 
+# cache / LDS / instruction mix of the decode kernels
+hit, miss = pmc('pmc_TCC_HIT_sum', 'TCC_HIT_sum'), pmc('pmc_TCC_HIT_sum', 'TCC_MISS_sum')
+conf, lds_act, lds_inst = (pmc('pmc_SQ_LDS_BANK_CONFLICT', c) for c in ('SQ_LDS_BANK_CONFLICT', 'SQ_ACTIVE_INST_LDS', 'SQ_INSTS_LDS'))
+valu, salu, wcyc = (pmc('pmc_SQ_INSTS_VALU', c) for c in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES'))
+if hit or conf or valu:
+    print('\n## L2 hit rate, LDS bank conflicts, instruction mix (decode only, per launch, median)\n')
+    print('L2 hit rate = TCC_HIT / (TCC_HIT + TCC_MISS); LDS conflict share = SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS '
+          '(cycles); instructions are per launch, summed over all waves.\n')
+    print('| kernel | L2 hit rate | LDS bank-conflict cycles / LDS active cycles | LDS instr | VALU instr | SALU instr | wave cycles |')
+    print('|---|---|---|---|---|---|---|')
+    for k in sorted(set(hit) | set(conf) | set(valu)):
+        if not k.startswith('opa::'):
+            continue
+        h, m = hit.get(k, 0.0), miss.get(k, 0.0)
+        print('| `%s` | %s | %s | %.3g | %.3g | %.3g | %.3g |' % (
+            k, '%.1f %%' % (100 * h / (h + m)) if h + m else '-',
+            '%.1f %%' % (100 * conf.get(k, 0.0) / lds_act[k]) if lds_act.get(k) else '-',
+            lds_inst.get(k, 0.0), valu.get(k, 0.0), salu.get(k, 0.0), wcyc.get(k, 0.0)))
+
 # machine-readable PMC traffic for bench.py's roofline.traffic
 import json
 out = {'batch': 32, 'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --decode-only, per launch; '
