@@ -68,13 +68,18 @@ typedef struct opa_params {
 /* Shapes of one batched decode call. */
 typedef struct opa_shape {
     int32_t batch;            /* B images                                           */
-    int32_t n_cif;            /* F = number of CIF fields = number of keypoints K   */
+    int32_t n_cif;            /* F = number of CIF fields (= number of keypoints K unless n_keypoints says otherwise) */
     int32_t n_caf;            /* A = number of CAF fields = number of bones         */
     int32_t cif_h, cif_w;     /* CIF field height/width                             */
     int32_t caf_h, caf_w;     /* CAF field height/width                             */
     int32_t cif_stride;       /* pixels per CIF cell (meta.stride)                  */
     int32_t caf_stride;       /* pixels per CAF cell                                */
     int32_t max_annotations;  /* capacity of the per-image annotation output        */
+    int32_t n_keypoints;      /* K joints per annotation; 0 = n_cif.  K > n_cif is the reference's tracking
+                               * setup (decoder/tracking_pose.py:47-80): joints F..K-1 belong to earlier
+                               * frames, have no CIF field -- no seeds, no rescoring, no occupancy, no reverse
+                               * match from them (cifcaf.cpp:173,225-229,397; caf_scored.cpp:15-18) -- and are
+                               * reached only through initial annotations and bones                    */
 } opa_shape;
 
 /* ---- library ------------------------------------------------------------ */
@@ -127,7 +132,7 @@ size_t opa_cifcaf_workspace_bytes(const opa_shape* shape);
  *  cif_dev  [B,F,5,H,W], caf_dev [B,A,8,H,W]
  *  initial_dev      optional [B, n_initial, K, 4] (v,x,y,s) or NULL
  *  initial_ids_dev  optional int64 [B, n_initial] or NULL
- *  out_dev          [B, max_annotations, K, 4] (v,x,y,s)   (ref: cifcaf.cpp:246-258)
+ *  out_dev          [B, max_annotations, K, 4] (v,x,y,s)   (ref: cifcaf.cpp:246-258), K = the decoder's n_keypoints
  *  out_ids_dev      int64 [B, max_annotations]             (ref: cifcaf.cpp:259)
  *  out_count_dev    int32 [B]  number of annotations of each image; a value
  *                   > max_annotations means the capacity overflowed and only the

@@ -64,7 +64,7 @@ class Shape(ctypes.Structure):
     """``opa_shape``."""
     _fields_ = [(n, ctypes.c_int32) for n in (
         'batch', 'n_cif', 'n_caf', 'cif_h', 'cif_w', 'caf_h', 'caf_w',
-        'cif_stride', 'caf_stride', 'max_annotations')]
+        'cif_stride', 'caf_stride', 'max_annotations', 'n_keypoints')]
 
 
 # every symbol include/openpifpaf_amd.h declares: name -> (restype, argtypes)

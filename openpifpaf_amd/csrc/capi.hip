@@ -84,6 +84,8 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     if (s.n_cif > 32767 || s.n_caf > 16383) { *why = "opa_shape: too many fields"; return false; }
     if ((long long)s.n_cif * s.cif_h * s.cif_w > (1ll << 30)) { *why = "opa_shape: CIF field too large"; return false; }
     L->B = s.batch; L->F = s.n_cif; L->A = s.n_caf; L->H = s.cif_h; L->W = s.cif_w;
+    L->K = s.n_keypoints > 0 ? s.n_keypoints : s.n_cif;
+    if (L->K < L->F || L->K > 32767) { *why = "opa_shape: n_keypoints must be 0 or in [n_cif, 32767]"; return false; }
     L->cH = s.caf_h; L->cW = s.caf_w; L->stride = s.cif_stride; L->cstride = s.caf_stride;
     L->max_ann = s.max_annotations;
     L->hr_rows = (s.cif_h - 1) * s.cif_stride + 1;                       // cif_hr.cpp:110-112
@@ -120,7 +122,7 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     L->off_lists_fc = take(list_bytes);
     L->off_list_counts_fc = take(B * L->A * 2 * sizeof(int32_t));
     L->off_occ = take(B * L->F * (size_t)L->occ_h * L->occ_w);
-    L->off_anns = take(B * (size_t)L->max_ann * L->F * 4 * sizeof(double));
+    L->off_anns = take(B * (size_t)L->max_ann * L->K * 4 * sizeof(double));
     L->off_ann_meta = take(B * (size_t)L->max_ann * sizeof(int64_t));
     L->off_status = take(B * sizeof(int32_t));
     L->total = off;
@@ -300,7 +302,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     if (!check_params(hp, &why)) return fail(OPA_ERR_INVALID_ARGUMENT, why);
     Layout L;
     if (!make_layout(*shape, &L, &why)) return fail(OPA_ERR_INVALID_ARGUMENT, why);
-    if (shape->n_cif != dec->K || shape->n_caf != dec->A)
+    if (L.K != dec->K || shape->n_caf != dec->A)
         return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_decode: shape does not match the decoder's keypoints/skeleton");
     if (hp.occupancy_reduction < 1.0)
         return fail(OPA_ERR_UNSUPPORTED, "opa_cifcaf_decode: occupancy_reduction < 1 is not supported");
@@ -319,7 +321,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     // the clean-tile flags are valid for exactly this carving of the workspace
     unsigned long long layout_hash = 1469598103934665603ull;
     for (long long v : {(long long)L.B, (long long)L.F, (long long)L.H, (long long)L.W, (long long)L.stride,
-                        (long long)L.A, (long long)L.cH, (long long)L.cW, (long long)L.max_ann, (long long)L.total})
+                        (long long)L.A, (long long)L.cH, (long long)L.cW, (long long)L.max_ann, (long long)L.K, (long long)L.total})
         layout_hash = (layout_hash ^ (unsigned long long)v) * 1099511628211ull;
     e = launch_cifhr(cif_dev, L.B, L.F, L.H, L.W, L.stride, 0.0, 1.0, p, cifhr, L.hr_rows, L.hr_pitch,
                      (float*)(ws + L.off_act), (int32_t*)(ws + L.off_act_count), st, false,
@@ -347,7 +349,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     prof_mark(st, "memset_occupancy");
 
     AssocArgs a;
-    a.B = L.B; a.K = L.F; a.A = L.A; a.max_ann = L.max_ann; a.n_initial = n_initial;
+    a.B = L.B; a.K = L.K; a.F = L.F; a.A = L.A; a.max_ann = L.max_ann; a.n_initial = n_initial;
     a.hr_rows = L.hr_rows; a.hr_cols = L.hr_cols; a.occ_h = L.occ_h; a.occ_w = L.occ_w;
     a.seed_cap = L.cif_cells; a.list_cap = L.caf_cells;
     a.seed_f = (const int32_t*)(ws + L.off_seed_f); a.seed_vxys = (const float*)(ws + L.off_seed_vxys);

@@ -824,11 +824,11 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     const int S = n_growers;                         // speculative growers = waves with a private LDS block
 
     ImageCtx c;
-    c.K = K; c.A = A; c.F = K; c.wave = wave;
+    c.K = K; c.A = A; c.F = a.F; c.wave = wave;
     c.lists = a.lists + (size_t)b * A * 2 * 7 * a.list_cap;
     c.list_counts = a.list_counts + (size_t)b * A * 2;
     c.list_cap = a.list_cap;
-    c.occ = a.occ + (size_t)b * K * a.occ_h * a.occ_w; c.occ_h = a.occ_h; c.occ_w = a.occ_w;
+    c.occ = a.occ + (size_t)b * a.F * a.occ_h * a.occ_w; c.occ_h = a.occ_h; c.occ_w = a.occ_w;
 
     // ---- LDS carve: shared part, then one private block per growing wave
     unsigned char* sp = smem;
@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
         unsigned char* nsp = work_base + (size_t)wave * nms_scratch_bytes(a.max_ann);
         OccBox* my_box = (OccBox*)nsp;
         int2* my_cell = (int2*)(nsp + sizeof(OccBox) * a.max_ann);
-        for (int k = wave; k < K; k += kAssocWaves) {
+        for (int k = wave; k < a.F; k += kAssocWaves) {       // :27-30: only joints with an occupancy field take part
             for (int r = lane; r < n_kept; r += kWave) {
                 const double* pose = anns + ((size_t)nms_order[r] * K + k) * 4;
                 OccBox bx; bx.minx = bx.miny = bx.maxx = bx.maxy = 0;
@@ -1244,7 +1244,7 @@ hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevPara
     const int K = a.K, A = a.A, E = 2 * A;
     const int KC = (K + kWave - 1) / kWave;
     // the seed pool packs cell coordinates into 12 bits, the field into 8 and the seed index into 24
-    if (a.occ_w > 4096 || a.occ_h > 4096 || K > 256 || a.seed_cap > 0xFFFFFF) return hipErrorInvalidValue;
+    if (a.occ_w > 4096 || a.occ_h > 4096 || a.F > 256 || a.seed_cap > 0xFFFFFF) return hipErrorInvalidValue;
     const size_t shared = sizeof(double) * a.max_ann
                         + sizeof(unsigned long long) * ((size_t)a.max_ann * KC)
                         + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann) + 32;

@@ -19,7 +19,7 @@ constexpr int kSortLdsKeys = 8192;        // 64 KiB of u64 keys sorted inside LD
 // Launch-time view of one batched decode (device pointers into the workspace).
 struct Layout {
     // shapes
-    int B, F, A, H, W, cH, cW, stride, cstride, max_ann;
+    int B, F, K, A, H, W, cH, cW, stride, cstride, max_ann;     // F CIF fields, K >= F joints per annotation
     int hr_rows, hr_cols, hr_pitch;       // high-res map geometry
     int occ_h, occ_w;                     // occupancy geometry
     int cif_cells;                        // F*H*W  (seed capacity)
@@ -89,7 +89,7 @@ hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int 
 hipError_t launch_zero(void* dst, size_t bytes, hipStream_t st);
 
 struct AssocArgs {
-    int B, K, A, max_ann, n_initial;
+    int B, K, F, A, max_ann, n_initial;      // K joints per annotation, F <= K of them with a CIF field
     int hr_rows, hr_cols;
     int occ_h, occ_w;
     int seed_cap, list_cap;
@@ -155,8 +155,6 @@ __device__ __forceinline__ long long clampll(long long v, long long lo, long lon
 __device__ __forceinline__ long long trunc_ll(float v) { return (long long)v; }
 __device__ __forceinline__ long long trunc_ll(double v) { return (long long)v; }
 
-// Reference cifhr_value (cif_seeds.cpp:17-30 == caf_scored.cpp:15-26) on the raw
-// revision-1 buffer: 0 = untouched (-> default), else 1 + value.
 __device__ __forceinline__ int seed_cell_pack(const DevParams& p, int occ_h, int occ_w, double x, double y, double sigma) {
     if (p.occupancy_reduction != 1.0) {
         x /= p.occupancy_reduction; y /= p.occupancy_reduction;
@@ -167,6 +165,8 @@ __device__ __forceinline__ int seed_cell_pack(const DevParams& p, int occ_h, int
     return xi | (yi << 12) | (half << 24);
 }
 
+// Reference cifhr_value (cif_seeds.cpp:17-30 == caf_scored.cpp:15-26) on the raw
+// revision-1 buffer: 0 = untouched (-> default), else 1 + value.
 __device__ __forceinline__ float cifhr_value(const float* hr_image, int F, int rows, int cols, int pitch,
                                              long long f, float x, float y, float default_value) {
     const float max_x = (float)((double)(float)cols - 0.51);

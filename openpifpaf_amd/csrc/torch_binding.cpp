@@ -81,6 +81,7 @@ struct CifCaf : torch::CustomClassHolder {
         s.caf_h = (int32_t)caf.size(3); s.caf_w = (int32_t)caf.size(4);
         s.cif_stride = (int32_t)cif_stride; s.caf_stride = (int32_t)caf_stride;
         s.max_annotations = (int32_t)max_annotations;
+        s.n_keypoints = (int32_t)n_keypoints;        // > n_cif in the tracking setup
         const size_t need = opa_cifcaf_workspace_bytes(&s);
         TORCH_CHECK(need > 0, "opa_cifcaf_workspace_bytes: ", opa_last_error());
         if (!workspace.defined() || (size_t)workspace.numel() < need || workspace.device() != cif.device())

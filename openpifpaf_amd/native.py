@@ -113,7 +113,11 @@ class CifCaf:
         if C != 5 or Cc != 8 or B != Bc:
             raise ValueError('expected cif [B,F,5,H,W] and caf [B,A,8,H,W], got %s and %s'
                              % (tuple(cif.shape), tuple(caf.shape)))
-        return _lib.Shape(B, F, A, H, W, cH, cW, int(cif_stride), int(caf_stride), self.max_annotations)
+        if F > self.n_keypoints:
+            raise ValueError('the CIF field has %d fields, more than the decoder\'s %d keypoints' % (F, self.n_keypoints))
+        # F < n_keypoints: tracking setup, joints F.. have no CIF field (reference tracking_pose.py:47-80)
+        return _lib.Shape(B, F, A, H, W, cH, cW, int(cif_stride), int(caf_stride), self.max_annotations,
+                          self.n_keypoints)
 
     def _workspace(self, shape, device):
         key = tuple(getattr(shape, n) for n, _ in _lib.Shape._fields_) + (device.index,)
@@ -139,7 +143,7 @@ class CifCaf:
         caf, _ = _prep(caf)
         shape = self._shape(cif, cif_stride, caf, caf_stride)
         ws = self._workspace(shape, cif.device)
-        B, K = shape.batch, shape.n_cif
+        B, K = shape.batch, self.n_keypoints
         out = torch.empty((B, self.max_annotations, K, 4), dtype=torch.float32, device=cif.device)
         ids = torch.empty((B, self.max_annotations), dtype=torch.int64, device=cif.device)
         counts = torch.empty((B,), dtype=torch.int32, device=cif.device)

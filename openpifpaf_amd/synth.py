@@ -115,6 +115,27 @@ def synth_fields(seed, n_people, *, height=81, width=81,
     return cif.astype(np.float32), caf.astype(np.float32)
 
 
+def tracking_skeleton(skeleton=None, n_keypoints=17):
+    """1-based bones of the reference's tracking pose (``decoder/tracking_pose.py:50-57``): the single-frame
+    skeleton plus one temporal bone per joint, (k, k + n_keypoints) -- current frame to previous frame."""
+    skeleton = list(skeleton if skeleton is not None else constants.COCO_PERSON_SKELETON)
+    return skeleton + [(k + 1, k + 1 + n_keypoints) for k in range(n_keypoints)]
+
+
+def synth_tracking_fields(seed, n_people, *, height=49, width=49, motion=(0.35, -0.2), size_range=(0.3, 0.7)):
+    """Fields of a two-frame tracking problem the way ``TrackingPose.__call__`` hands them to the decoder
+    (``decoder/tracking_pose.py:209-217``): -> ``(cif [17,5,H,W], caf [19+17,8,H,W], full_cif [34,5,H,W])``.
+    ``cif`` holds the CURRENT frame's joints only; ``caf`` = single-frame CAF head + temporal CAF head; joints
+    17..33 (the previous frame, displaced by ``motion`` pose units) exist only through the temporal bones.
+    ``full_cif`` (with fields for the previous frame too) lets a test derive previous-frame poses."""
+    pose = np.asarray(constants.COCO_UPRIGHT_POSE, dtype=np.float64)[:, :2]
+    K = len(pose)
+    double_pose = np.concatenate([pose, pose + np.asarray(motion, dtype=np.float64)[None]], axis=0)
+    full_cif, caf = synth_fields(seed, n_people, height=height, width=width, pose=double_pose,
+                                 skeleton=tracking_skeleton(n_keypoints=K), size_range=size_range)
+    return full_cif[:K].copy(), caf, full_cif
+
+
 PEOPLE_CYCLE = (1, 5, 10, 20, 3, 8, 15, 2)
 
 

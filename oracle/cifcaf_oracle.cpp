@@ -489,13 +489,15 @@ void oracle_grow_connection_blend(const float* rows, int64_t n, double x, double
 // out: [cap, K, 4] (v,x,y,s) float32 ; out_ids: [cap]
 // initial: optional [n_initial, K, 4] (v,x,y,s) + ids (may be NULL / 0)
 // cifhr_out: optional [F,Hhr,Whr] raw buffer copy (may be NULL)
-int64_t oracle_cifcaf_decode(const float* cif, int64_t F, int64_t H, int64_t W, int64_t cif_stride,
-                             const float* caf, int64_t A, int64_t caf_H, int64_t caf_W, int64_t caf_stride,
-                             const int64_t* skeleton, const oracle_params* params,
-                             const float* initial, const int64_t* initial_ids, int64_t n_initial,
-                             int64_t cap, float* out, int64_t* out_ids, float* cifhr_out) {
+// K = n_keypoints of the decoder object (cifcaf.hpp:99-107), F = fields of the CIF tensor.  K > F is the
+// reference's tracking setup (decoder/tracking_pose.py:47-80): occupancy, seeds and the high-res map cover
+// the F current-frame joints only (cifcaf.cpp:173), annotations carry K joints.
+int64_t oracle_cifcaf_decode_k(const float* cif, int64_t F, int64_t H, int64_t W, int64_t cif_stride,
+                               const float* caf, int64_t A, int64_t caf_H, int64_t caf_W, int64_t caf_stride,
+                               const int64_t* skeleton, const oracle_params* params,
+                               const float* initial, const int64_t* initial_ids, int64_t n_initial,
+                               int64_t cap, float* out, int64_t* out_ids, float* cifhr_out, int64_t K) {
     const Params& p = *params;
-    const int64_t K = F;
     const int64_t hh = (H - 1) * cif_stride + 1, hw = (W - 1) * cif_stride + 1;
     std::vector<float> buffer(size_t(F) * hh * hw, 0.0f);
     HiRes hr{buffer.data(), F, hh, hw};
@@ -560,6 +562,15 @@ int64_t oracle_cifcaf_decode(const float* cif, int64_t F, int64_t H, int64_t W, 
         out_ids[n] = anns[n].id;
     }
     return int64_t(anns.size());
+}
+
+int64_t oracle_cifcaf_decode(const float* cif, int64_t F, int64_t H, int64_t W, int64_t cif_stride,
+                             const float* caf, int64_t A, int64_t caf_H, int64_t caf_W, int64_t caf_stride,
+                             const int64_t* skeleton, const oracle_params* params,
+                             const float* initial, const int64_t* initial_ids, int64_t n_initial,
+                             int64_t cap, float* out, int64_t* out_ids, float* cifhr_out) {
+    return oracle_cifcaf_decode_k(cif, F, H, W, cif_stride, caf, A, caf_H, caf_W, caf_stride, skeleton, params,
+                                  initial, initial_ids, n_initial, cap, out, out_ids, cifhr_out, F);
 }
 
 // CifDet::call, cifdet.cpp:24-80.  Returns the number of detections (<= max_detections).

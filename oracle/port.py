@@ -54,6 +54,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.oracle_cifseeds.restype = ctypes.c_int64
         _lib.oracle_cifcaf_decode.restype = ctypes.c_int64
+        _lib.oracle_cifcaf_decode_k.restype = ctypes.c_int64
         _lib.oracle_cifdet_decode.restype = ctypes.c_int64
     return _lib
 
@@ -139,15 +140,18 @@ def grow_connection_blend(rows, x, y, s, filter_sigmas=1.0, only_max=False):
 
 
 def decode(cif, cif_stride, caf, caf_stride, skeleton0, *, params=None,
-           initial_annotations=None, initial_ids=None, return_cifhr=False, cap=4096):
-    """The whole CifCaf decode -> (annotations float32 [n,K,4] (v,x,y,s), ids int64[n])."""
+           initial_annotations=None, initial_ids=None, return_cifhr=False, cap=4096, n_keypoints=None):
+    """The whole CifCaf decode -> (annotations float32 [n,K,4] (v,x,y,s), ids int64[n]).
+    ``n_keypoints`` > number of CIF fields: the reference's tracking setup (tracking_pose.py:47-80)."""
     params = params or default_params()
     cif, caf = _f32(cif), _f32(caf)
     F, _, H, W = cif.shape
     A, _, cH, cW = caf.shape
     skel = np.ascontiguousarray(skeleton0, dtype=np.int64)
     assert skel.shape == (A, 2)
-    out = np.zeros((cap, F, 4), dtype=np.float32)
+    K = int(n_keypoints) if n_keypoints else F
+    assert K >= F
+    out = np.zeros((cap, K, 4), dtype=np.float32)
     ids = np.full((cap,), -1, dtype=np.int64)
     hr = None
     if return_cifhr:
@@ -159,11 +163,11 @@ def decode(cif, cif_stride, caf, caf_stride, skeleton0, *, params=None,
         init_p, ids_p = _ptr(init), _ptr(init_ids)
     else:
         n_init, init_p, ids_p = 0, None, None
-    n = lib().oracle_cifcaf_decode(
+    n = lib().oracle_cifcaf_decode_k(
         _ptr(cif), _i64(F), _i64(H), _i64(W), _i64(cif_stride),
         _ptr(caf), _i64(A), _i64(cH), _i64(cW), _i64(caf_stride),
         _ptr(skel), ctypes.byref(params), init_p, ids_p, _i64(n_init),
-        _i64(cap), _ptr(out), _ptr(ids), _ptr(hr) if hr is not None else None)
+        _i64(cap), _ptr(out), _ptr(ids), _ptr(hr) if hr is not None else None, _i64(K))
     if n > cap:
         raise RuntimeError('oracle produced %d annotations > cap %d' % (n, cap))
     res = (out[:n].copy(), ids[:n].copy())

@@ -78,11 +78,12 @@ def new_decoder(n_keypoints, skeleton0):
     return torch.classes.openpifpaf_decoder.CifCaf(int(n_keypoints), torch.as_tensor(skeleton0, dtype=torch.int64))
 
 
-def decode(cif, cif_stride, caf, caf_stride, skeleton0, *, initial_annotations=None, initial_ids=None):
+def decode(cif, cif_stride, caf, caf_stride, skeleton0, *, initial_annotations=None, initial_ids=None,
+           n_keypoints=None):
     """Fresh decoder instance -> (annotations [n,K,4] np.float32, ids np.int64, cifhr np.float32 raw)."""
     torch = load()
     import numpy as np
-    dec = new_decoder(cif.shape[0], skeleton0)
+    dec = new_decoder(n_keypoints or cif.shape[0], skeleton0)
     cif_t = torch.from_numpy(np.ascontiguousarray(cif, dtype=np.float32))
     caf_t = torch.from_numpy(np.ascontiguousarray(caf, dtype=np.float32))
     if initial_annotations is not None and len(initial_annotations):

@@ -32,3 +32,29 @@ def compare_annotations(a, b, tol=TOL):
         idx = np.unravel_index(d.argmax(), d.shape)
         return False, 'max |delta| %.3g at %s: %s vs %s' % (m, idx, a[idx[0], idx[1]], b[idx[0], idx[1]])
     return True, 'max |delta| %.3g' % m
+
+
+# (seed, people, height, width) of the tracking goldens (tests/golden/make_golden_tracking.py)
+TRACKING_CASES = [(7, 3, 49, 49), (8, 6, 57, 41), (9, 1, 33, 33)]
+
+
+def tracking_problem(seed, people, height, width):
+    """The decode problem of the reference's TrackingPose for two synthetic frames: -> (cif [17,...] of the
+    current frame, caf [36,...], 0-based 36-bone skeleton, initial annotations [n,34,4] carrying the previous
+    frame's poses in joints 17..33, their track ids).  The previous-frame poses are what the restatement
+    decodes from the full 34-field problem, with the weakest pose dropped and one joint removed so that the
+    initial annotations are not trivially complete."""
+    import numpy as np
+    from openpifpaf_amd import synth
+    from oracle import port
+    cif, caf, full = synth.synth_tracking_fields(seed, people, height=height, width=width)
+    skel0 = np.asarray(synth.tracking_skeleton(), dtype=np.int64) - 1
+    full_anns, _ = port.decode(full, 8, caf, 8, skel0)
+    if len(full_anns) > 1:
+        full_anns = full_anns[:-1]
+    init = np.zeros((len(full_anns), 34, 4), dtype=np.float32)
+    init[:, 17:] = full_anns[:, 17:]
+    if len(init):
+        init[0, 20] = 0.0
+    ids = np.arange(100, 100 + len(init), dtype=np.int64)
+    return cif, caf, skel0, init, ids
