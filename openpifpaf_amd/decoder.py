@@ -409,13 +409,19 @@ class Multi(Decoder):
         return super().batch(model, image_batch, device=device, gt_anns_batch=gt_anns_batch)
 
 
-DECODERS = {CifCaf, CifCafDense, CifDet}
+DECODERS = {CifCaf, CifCafDense, CifDet}        # + tracking.TrackingPose, which registers itself on import
+
+
+def _with_tracking():
+    """``DECODERS`` including the tracking decoders (their module imports this one, hence the late import)."""
+    from . import tracking      # noqa: F401
+    return DECODERS
 
 
 def cli(parser, *, workers=None):
     """Reference ``decoder/factory.py:20-49``."""
     group = parser.add_argument_group('decoder configuration')
-    available = [dec.__name__.lower() for dec in DECODERS]
+    available = [dec.__name__.lower() for dec in _with_tracking()]
     group.add_argument('--decoder', default=None, nargs='+',
                        help='Decoders to be considered: {}.'.format(available))
     group.add_argument('--seed-threshold', default=native.CifSeeds.get_threshold(), type=float,
@@ -429,8 +435,10 @@ def cli(parser, *, workers=None):
     group.add_argument('--cif-th', default=native.CifHr.get_threshold(), type=float, help='cif threshold')
     group.add_argument('--caf-th', default=native.CafScored.get_default_score_th(), type=float,
                        help='caf threshold')
-    for dec in DECODERS:
+    for dec in _with_tracking():
         dec.cli(parser)
+    from . import tracking
+    tracking.TrackBase.cli(parser)              # reference decoder/factory.py:47
 
 
 def configure(args):
@@ -443,8 +451,10 @@ def configure(args):
     native.CafScored.set_default_score_th(args.caf_th)
     native.NMSKeypoints.set_instance_threshold(args.instance_threshold)
     CifDet.instance_threshold = args.instance_threshold
-    for dec in DECODERS:
+    for dec in _with_tracking():
         dec.configure(args)
+    from . import tracking
+    tracking.TrackBase.configure(args)          # reference decoder/factory.py:80
 
 
 class Factory:
@@ -479,7 +489,7 @@ class Factory:
                 decoders = (d for i, d in enumerate(decoders) if i in indices)
             return decoders
 
-        decoders = [d for dec_class in DECODERS for d in per_class(cls.decoder_request, dec_class)]
+        decoders = [d for dec_class in _with_tracking() for d in per_class(cls.decoder_request, dec_class)]
         decoders = list(sorted(decoders, key=lambda d: d.priority, reverse=True))
         if not decoders:
             LOG.warning('no decoders found for heads %s', [meta.name for meta in head_metas])
@@ -493,3 +503,4 @@ class Factory:
 
 
 factory = Factory.__call__
+

@@ -103,6 +103,51 @@ class Caf(Base):
 
 
 @dataclass
+class TSingleImageCif(Cif):
+    """Single-image CIF head of a tracking model (reference ``headmeta.py:136-138``)."""
+
+
+@dataclass
+class TSingleImageCaf(Caf):
+    """Single-image CAF head of a tracking model (reference ``headmeta.py:141-143``)."""
+
+
+@dataclass
+class Tcaf(Base):
+    """Tracking Composite Association Field: one field per joint, from its position in this frame to its
+    position in the previous frame (reference ``headmeta.py:146-186``)."""
+    keypoints_single_frame: List[str] = None
+    sigmas_single_frame: List[float] = None
+    pose_single_frame: Any = None
+    draw_skeleton_single_frame: Optional[List[Tuple[int, int]]] = None
+    keypoints: Optional[List[str]] = None
+    sigmas: Optional[List[float]] = None
+    pose: Any = None
+    draw_skeleton: Optional[List[Tuple[int, int]]] = None
+    only_in_field_of_view: bool = False
+
+    n_confidences: ClassVar[int] = 1
+    n_vectors: ClassVar[int] = 2
+    n_scales: ClassVar[int] = 2
+    vector_offsets: ClassVar[List[bool]] = [True, True]
+
+    def __post_init__(self):
+        if self.keypoints is None:
+            self.keypoints = list(self.keypoints_single_frame) * 2
+        if self.sigmas is None:
+            self.sigmas = list(self.sigmas_single_frame) * 2
+
+    @property
+    def skeleton(self):
+        n = len(self.keypoints_single_frame)
+        return [(i + 1, i + 1 + n) for i in range(n)]
+
+    @property
+    def n_fields(self) -> int:
+        return len(self.keypoints_single_frame)
+
+
+@dataclass
 class CifDet(Base):
     """Composite Intensity Field for detection: one field per category, components
     (width, confidence, x, y, w, h) (reference ``headmeta.py:116-133``)."""

@@ -136,6 +136,76 @@ def synth_tracking_fields(seed, n_people, *, height=49, width=49, motion=(0.35, 
     return full_cif[:K].copy(), caf, full_cif
 
 
+def synth_tracking_sequence(seed, n_people, n_frames, *, height=49, width=65, appear=None):
+    """A short synthetic video for the tracking decoder: people with the COCO upright pose walk with constant
+    velocity; per frame -> ``(cif [17,5,H,W], caf [19,8,H,W], tcaf [17,8,H,W])``, the three heads a tracking
+    network emits (reference ``headmeta.py:136-186``): ``tcaf`` field k points from joint k in this frame to
+    where that joint was in the previous frame.  ``appear[p]`` = first frame person p is visible in."""
+    rng = np.random.default_rng(seed)
+    pose = np.asarray(constants.COCO_UPRIGHT_POSE, dtype=np.float64)[:, :2].copy()
+    pose[:, 1] = -pose[:, 1]
+    pose -= 0.5 * (pose.min(axis=0) + pose.max(axis=0))
+    extent = (pose.max(axis=0) - pose.min(axis=0)).max()
+    K, skeleton = len(pose), constants.COCO_PERSON_SKELETON
+    H, W = height, width
+    appear = list(appear) if appear is not None else [0] * n_people
+    people = []
+    for _ in range(n_people):
+        unit = rng.uniform(0.35, 0.6) * min(H, W) / extent
+        half = 0.5 * unit * (pose.max(axis=0) - pose.min(axis=0))
+        start = np.array([rng.uniform(half[0] + 3.0, W - 4.0 - half[0]), rng.uniform(half[1] + 2.0, H - 3.0 - half[1])])
+        velocity = rng.uniform(-0.6, 0.6, 2)
+        people.append((unit, start, velocity))
+    jj, ii = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing='ij')
+
+    def background(n, comps):
+        """Structureless field: low confidences, regressions pointing at the own cell, random scales."""
+        n_vec = 1 if comps == 5 else 2                   # CIF: (x, y); CAF: (x1, y1, x2, y2)
+        f = np.empty((n, comps, H, W), dtype=np.float64)
+        f[:, 0] = rng.normal(0.0, 1.0, (n, H, W))
+        f[:, 1] = rng.uniform(0.0, 0.05, (n, H, W))
+        for v in range(n_vec):
+            f[:, 2 + 2 * v] = ii[None] + rng.normal(0.0, 1.0, (n, H, W))
+            f[:, 3 + 2 * v] = jj[None] + rng.normal(0.0, 1.0, (n, H, W))
+        f[:, 2 + 2 * n_vec:] = rng.uniform(0.1, 1.0, (n, comps - 2 - 2 * n_vec, H, W))
+        return f
+
+    def bone_blobs(field, a, p1, p2, s):
+        for t in (0.0, 0.5, 1.0):
+            bx, by = p1[0] + t * (p2[0] - p1[0]), p1[1] + t * (p2[1] - p1[1])
+            bj, bi = _blob(field[a, 1], None, bx, by, max(2.0, 1.5 + 0.3 * s), 0.85, max(1.2, 0.8 + 0.4 * s), rng)
+            n = len(bj)
+            field[a, 2, bj, bi] = p1[0] + rng.normal(0.0, 0.05, n)
+            field[a, 3, bj, bi] = p1[1] + rng.normal(0.0, 0.05, n)
+            field[a, 4, bj, bi] = p2[0] + rng.normal(0.0, 0.05, n)
+            field[a, 5, bj, bi] = p2[1] + rng.normal(0.0, 0.05, n)
+            field[a, 6, bj, bi] = s * (1.0 + rng.normal(0.0, 0.03, n))
+            field[a, 7, bj, bi] = s * (1.0 + rng.normal(0.0, 0.03, n))
+
+    frames = []
+    for t in range(n_frames):
+        cif, caf, tcaf = background(K, 5), background(len(skeleton), 8), background(K, 8)
+        for p, (unit, start, velocity) in enumerate(people):
+            if t < appear[p]:
+                continue
+            now = pose * unit + start + t * velocity
+            before = pose * unit + start + (t - 1) * velocity
+            s = max(0.5, 0.3 * unit)
+            for k in range(K):
+                x, y = now[k]
+                bj, bi = _blob(cif[k, 1], None, x, y, max(2.3, 1.5 + 0.5 * s), 0.9, max(1.3, 0.6 + 0.5 * s), rng)
+                n = len(bj)
+                cif[k, 2, bj, bi] = x + rng.normal(0.0, 0.05, n)
+                cif[k, 3, bj, bi] = y + rng.normal(0.0, 0.05, n)
+                cif[k, 4, bj, bi] = s * (1.0 + rng.normal(0.0, 0.03, n))
+                if t > appear[p]:
+                    bone_blobs(tcaf, k, now[k], before[k], s)
+            for a, (j1, j2) in enumerate(skeleton):
+                bone_blobs(caf, a, now[j1 - 1], now[j2 - 1], s)
+        frames.append((cif.astype(np.float32), caf.astype(np.float32), tcaf.astype(np.float32)))
+    return frames
+
+
 PEOPLE_CYCLE = (1, 5, 10, 20, 3, 8, 15, 2)
 
 

@@ -58,3 +58,6 @@ def tracking_problem(seed, people, height, width):
         init[0, 20] = 0.0
     ids = np.arange(100, 100 + len(init), dtype=np.int64)
     return cif, caf, skel0, init, ids
+
+# (seed, people, frames, first frame each person is visible in) of tests/golden/make_golden_tracking_pose.py
+TRACKING_VIDEOS = [(3, 3, 5, (0, 0, 2)), (4, 5, 4, (0, 1, 0, 0, 2))]

@@ -1,0 +1,66 @@
+"""Generates tests/golden/tracking_pose_golden.npz: the reference's own ``TrackingPose`` decoder -- its Python
+(`decoder/tracking_pose.py`, `track_base.py`, `track_annotation.py`) imported by oracle/reference_python.py, its
+native decoder being oracle/_ref -- run frame by frame over a seeded synthetic video.
+
+    python tests/golden/make_golden_tracking_pose.py      (build container only: needs /root/reference)
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(HERE))
+
+from common import TRACKING_VIDEOS                        # noqa: E402
+from openpifpaf_amd import constants, synth                # noqa: E402
+from oracle import reference, reference_python            # noqa: E402
+
+
+def reference_metas(opp):
+    hm = opp.headmeta
+    cif = hm.TSingleImageCif('cif', 'synthetic', keypoints=constants.COCO_KEYPOINTS,
+                             sigmas=constants.COCO_PERSON_SIGMAS, pose=np.asarray(constants.COCO_UPRIGHT_POSE),
+                             draw_skeleton=constants.COCO_PERSON_SKELETON)
+    caf = hm.TSingleImageCaf('caf', 'synthetic', keypoints=constants.COCO_KEYPOINTS,
+                             sigmas=constants.COCO_PERSON_SIGMAS, pose=np.asarray(constants.COCO_UPRIGHT_POSE),
+                             skeleton=constants.COCO_PERSON_SKELETON)
+    tcaf = hm.Tcaf('tcaf', 'synthetic', keypoints_single_frame=constants.COCO_KEYPOINTS,
+                   sigmas_single_frame=constants.COCO_PERSON_SIGMAS,
+                   pose_single_frame=np.asarray(constants.COCO_UPRIGHT_POSE),
+                   draw_skeleton_single_frame=constants.COCO_PERSON_SKELETON)
+    for i, m in enumerate((cif, caf, tcaf)):
+        m.head_index = i
+        m.base_stride = 16
+        m.upsample_stride = 2
+    return cif, caf, tcaf
+
+
+def main():
+    opp = reference_python.load()
+    torch = reference.load()
+    torch.set_num_threads(1)
+    reference.reset_statics()
+    from openpifpaf.decoder.tracking_pose import TrackingPose
+    from openpifpaf.decoder.track_annotation import TrackAnnotation
+    out = {}
+    for v, (seed, people, n_frames, appear) in enumerate(TRACKING_VIDEOS):
+        TrackAnnotation.track_id_counter = 0
+        tracker = TrackingPose(*reference_metas(opp))
+        frames = synth.synth_tracking_sequence(seed, people, n_frames, appear=appear)
+        for t, fields in enumerate(frames):
+            anns = tracker([torch.from_numpy(f) for f in fields])
+            out['video%d_frame%d_ids' % (v, t)] = np.asarray([a.id_ for a in anns], dtype=np.int64)
+            out['video%d_frame%d_data' % (v, t)] = np.asarray([a.data for a in anns], dtype=np.float32).reshape(-1, 17, 3)
+            out['video%d_frame%d_scales' % (v, t)] = np.asarray([a.joint_scales for a in anns], dtype=np.float32).reshape(-1, 17)
+            print('video %d frame %d: %d tracked poses, ids %s, active tracks %d'
+                  % (v, t, len(anns), [a.id_ for a in anns], len(tracker.active)))
+    path = os.path.join(HERE, 'tracking_pose_golden.npz')
+    np.savez_compressed(path, **out)
+    print('wrote', path, os.path.getsize(path), 'bytes')
+
+
+if __name__ == '__main__':
+    main()
