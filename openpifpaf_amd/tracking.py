@@ -362,4 +362,188 @@ class TrackingPose(TrackBase):
         return self.annotations(self.frame_number)
 
 
+# ----------------------------------------------------------------------------- PoseSimilarity
+def _track_pose_for(track, frame_number, track_frame):
+    """Common preamble of the reference's distance functions (``pose_distance/euclidean.py:24-37``): which
+    stored pose of the track to compare with, or None when the track was out of sight for too long."""
+    skipped_frames = frame_number - track.frame_pose[-1][0] - 1
+    assert skipped_frames >= 0
+    if skipped_frames > 12:
+        return None, skipped_frames
+    track_frame += skipped_frames
+    if track_frame > -1 or len(track.frame_pose) < -track_frame:
+        return None, skipped_frames
+    return track.frame_pose[track_frame][1], track_frame
+
+
+class Euclidean:
+    """Mean keypoint distance between a new pose and a track's pose ``track_frames`` back
+    (reference ``pose_distance/euclidean.py:4-46``)."""
+    invisible_penalty = 110.0
+
+    def __init__(self, *, track_frames=None):
+        self.track_frames = [-1] if track_frames is None else track_frames
+        assert all(t < 0 for t in self.track_frames)
+        self.valid_keypoints = None
+
+    def __call__(self, frame_number, pose, track, track_is_good):
+        return min(self.distance(frame_number, pose, track, track_is_good, t) for t in self.track_frames)
+
+    def distance(self, frame_number, pose, track, track_is_good, track_frame=-1):
+        other, _ = _track_pose_for(track, frame_number, track_frame)
+        if other is None:
+            return 1000.0
+        pose1, pose2 = pose.data[self.valid_keypoints], other.data[self.valid_keypoints]
+        d = np.clip(np.linalg.norm(pose2[:, :2] - pose1[:, :2], axis=1), 0.0, self.invisible_penalty)
+        d[pose1[:, 2] < 0.05] = self.invisible_penalty
+        d[pose2[:, 2] < 0.05] = self.invisible_penalty
+        return np.mean(d)
+
+
+class Oks:
+    """110 * (1 - object keypoint similarity) (reference ``pose_distance/oks.py:4-68``)."""
+    inflate = 1.0
+
+    def __init__(self, *, track_frames=None):
+        self.track_frames = [-1] if track_frames is None else track_frames
+        assert all(t < 0 for t in self.track_frames)
+        self.valid_keypoints = None
+        self.sigmas = None
+
+    def __call__(self, frame_number, pose, track, track_is_good):
+        return min(self.distance(frame_number, pose, track, track_is_good, t) for t in self.track_frames)
+
+    @staticmethod
+    def scale(pose):
+        pose = pose[pose[:, 2] > 0.0]
+        return np.sqrt((pose[:, 0].max() - pose[:, 0].min()) * (pose[:, 1].max() - pose[:, 1].min()))
+
+    def distance(self, frame_number, pose, track, track_is_good, track_frame=-1):
+        other, _ = _track_pose_for(track, frame_number, track_frame)
+        if other is None:
+            return 1000.0
+        pose1, pose2 = pose.data[self.valid_keypoints], other.data[self.valid_keypoints]
+        visible = np.logical_and(pose1[:, 2] > 0.0, pose2[:, 2] > 0.0)
+        if not np.any(visible):
+            return 1000.0
+        scale = max(1.0, 0.5 * (self.scale(pose1) + self.scale(pose2)))
+        d = np.linalg.norm(pose2[:, :2] - pose1[:, :2], axis=1)
+        k = 2.0 * self.sigmas[self.valid_keypoints] * self.inflate
+        g = np.exp(-0.5 * d ** 2 / (scale ** 2 * k ** 2))
+        return 110.0 * (1.0 - np.mean(g[visible]))
+
+
+class Crafted:
+    """Hand-crafted distance (reference ``pose_distance/crafted.py:7-90``): centred keypoint distance plus
+    penalties for young / bad tracks, weak poses and skipped frames.  (The reference calls ``pose.score()``
+    although ``score`` is a property, ``crafted.py:74-77``, so its version raises as soon as it gets
+    that far; this one reads the property.)"""
+    invisible_penalty = 110.0
+
+    def __init__(self):
+        self.valid_keypoints = None
+
+    def __call__(self, frame_number, pose, track, track_is_good):
+        return min(self.distance(frame_number, pose, track, track_is_good, t) for t in (-1, -4, -8, -12))
+
+    def distance(self, frame_number, pose, track, track_is_good, track_frame=-1):
+        other, track_frame = _track_pose_for(track, frame_number, track_frame)
+        if other is None:
+            return 1000.0
+        pose1, pose2 = pose.data[self.valid_keypoints], other.data[self.valid_keypoints]
+        best = np.argsort(pose1[:, 2] * pose2[:, 2])[::-1]
+        if pose1[best[2], 2] < 0.05 or pose2[best[2], 2] < 0.05:
+            return 1000.0
+        c1, c2 = np.mean(pose1[best[:3], :2], axis=0), np.mean(pose2[best[:3], :2], axis=0)
+        d = np.linalg.norm((pose2[:, :2] - c2) - (pose1[:, :2] - c1), axis=1)
+        d = np.clip(d, 0.0, self.invisible_penalty)
+        d[pose1[:, 2] < 0.05] = self.invisible_penalty
+        d[pose2[:, 2] < 0.05] = self.invisible_penalty
+        track_penalty = 40.0 if len(track.frame_pose) < 4 else (8.0 if len(track.frame_pose) < 8 else 0.0)
+        if not track_is_good:
+            track_penalty = max(track_penalty, 8.0)
+        pose_penalty = 40.0 if pose.score < 0.2 else (8.0 if pose.score < 0.5 else 0.0)
+        skipped_frame_cost = 40.0 if track_frame < -1 else 0.0
+        return np.linalg.norm(c2 - c1) / 10.0 + np.mean(d) + track_penalty + pose_penalty + skipped_frame_cost
+
+
+class PoseSimilarity(TrackBase):
+    """Tracking by matching single-frame poses (one HIP decode per frame) to the active tracks with the
+    Hungarian algorithm over a pose distance (reference ``decoder/pose_similarity.py:20-141``)."""
+    distance_type = Euclidean
+
+    def __init__(self, cif_meta: headmeta.Cif, caf_meta: headmeta.Caf, *, pose_generator=None):
+        super().__init__()
+        self.cif_meta, self.caf_meta = cif_meta, caf_meta
+        self.priority = -10.0 + (cif_meta.n_fields + caf_meta.n_fields) / 1000.0
+        self.distance_function = self.distance_type()
+        skip = ('left_ear', 'right_ear') if cif_meta.dataset == 'posetrack2018' else ()
+        self.distance_function.valid_keypoints = [i for i, kp in enumerate(cif_meta.keypoints) if kp not in skip]
+        self.distance_function.sigmas = np.asarray(cif_meta.sigmas)
+        self.pose_generator = pose_generator or CifCaf([cif_meta], [caf_meta])
+
+    @classmethod
+    def cli(cls, parser: argparse.ArgumentParser):
+        group = parser.add_argument_group('PoseSimilarity')
+        group.add_argument('--posesimilarity-distance', default='euclidean',
+                           choices=('crafted', 'euclidean', 'euclidean4', 'oks'))
+        group.add_argument('--posesimilarity-oks-inflate', default=Oks.inflate, type=float)
+
+    @classmethod
+    def configure(cls, args: argparse.Namespace):
+        choice = args.posesimilarity_distance
+        if choice == 'euclidean':
+            cls.distance_type = Euclidean
+        elif choice == 'euclidean4':
+            cls.distance_type = lambda _=None: Euclidean(track_frames=[-1, -4, -8, -12])
+        elif choice == 'oks':
+            cls.distance_type = Oks
+        elif choice == 'crafted':
+            cls.distance_type = Crafted
+        else:
+            raise RuntimeError('distance function type not known')
+        Oks.inflate = args.posesimilarity_oks_inflate
+
+    @classmethod
+    def factory(cls, head_metas):
+        if len(head_metas) < 2:
+            return []
+        return [cls(cif_meta, caf_meta) for cif_meta, caf_meta in zip(head_metas, head_metas[1:])
+                if isinstance(cif_meta, headmeta.Cif) and isinstance(caf_meta, headmeta.Caf)]
+
+    def prune_active(self, frame_number):                        # track_base.py:85-89
+        self.active = [t for t in self.active if frame_number - t.frame_pose[-1][0] <= 33]
+        self.active = [t for t in self.active
+                       if frame_number - t.frame_pose[-1][0] == 1 or len(t.frame_pose) > 2]
+
+    def __call__(self, fields, *, initial_annotations=None):
+        import scipy.optimize
+        self.frame_number += 1
+        self.prune_active(self.frame_number)
+        poses = self.pose_generator(fields)
+
+        # rows: every active track, then one "track is lost this frame" row per track at a flat cost
+        n_tracks = len(self.active)
+        cost = np.full((n_tracks * 2, len(poses)), 1000.0)
+        for track_i, track in enumerate(self.active):
+            good = self.track_is_good(track, self.frame_number)
+            for pose_i, pose in enumerate(poses):
+                cost[track_i, pose_i] = self.distance_function(self.frame_number, pose, track, good)
+                cost[track_i + n_tracks, pose_i] = 100.0
+        track_indices, pose_indices = scipy.optimize.linear_sum_assignment(cost)
+        matched = set()
+        for track_i, pose_i in zip(track_indices, pose_indices):
+            if track_i >= n_tracks:
+                continue
+            self.active[track_i].add(self.frame_number, poses[pose_i])
+            matched.add(pose_i)
+        for pose_i, pose in enumerate(poses):
+            if pose_i not in matched:
+                self.active.append(TrackAnnotation().add(self.frame_number, pose))
+
+        self.active = [t for t in self.active if self.track_is_viable(t, self.frame_number)]
+        return self.annotations(self.frame_number)
+
+
 _decoder.DECODERS.add(TrackingPose)
+_decoder.DECODERS.add(PoseSimilarity)

@@ -57,6 +57,22 @@ def main():
             out['video%d_frame%d_scales' % (v, t)] = np.asarray([a.joint_scales for a in anns], dtype=np.float32).reshape(-1, 17)
             print('video %d frame %d: %d tracked poses, ids %s, active tracks %d'
                   % (v, t, len(anns), [a.id_ for a in anns], len(tracker.active)))
+    # PoseSimilarity (decoder/pose_similarity.py): single-frame decodes matched to tracks, two distance functions
+    from openpifpaf.decoder.pose_similarity import PoseSimilarity
+    from openpifpaf.decoder import pose_distance
+    for name, dist in (('euclidean', pose_distance.Euclidean), ('oks', pose_distance.Oks)):
+        PoseSimilarity.distance_type = dist
+        for v, (seed, people, n_frames, appear) in enumerate(TRACKING_VIDEOS):
+            TrackAnnotation.track_id_counter = 0
+            cif, caf, _ = reference_metas(opp)
+            tracker = PoseSimilarity(cif, caf)
+            for t, fields in enumerate(synth.synth_tracking_sequence(seed, people, n_frames, appear=appear)):
+                anns = tracker([torch.from_numpy(f) for f in fields[:2]])
+                out['sim_%s_video%d_frame%d_ids' % (name, v, t)] = np.asarray([a.id_ for a in anns], dtype=np.int64)
+                out['sim_%s_video%d_frame%d_data' % (name, v, t)] = \
+                    np.asarray([a.data for a in anns], dtype=np.float32).reshape(-1, 17, 3)
+                print('PoseSimilarity/%s video %d frame %d: ids %s' % (name, v, t, [a.id_ for a in anns]))
+    PoseSimilarity.distance_type = pose_distance.Euclidean
     path = os.path.join(HERE, 'tracking_pose_golden.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, os.path.getsize(path), 'bytes')

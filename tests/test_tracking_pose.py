@@ -89,9 +89,50 @@ def test_host_logic_with_oracle_decode_matches_reference_tracker(v):
     assert tracker.frame_number == TRACKING_VIDEOS[v][2] and len(tracker.active) >= 1
 
 
+@pytest.mark.parametrize('name', ['euclidean', 'oks'])
+@pytest.mark.parametrize('v', range(len(TRACKING_VIDEOS)))
+def test_pose_similarity_with_oracle_decode_matches_reference(v, name):
+    from openpifpaf_amd import synth, tracking
+    golden = np.load(GOLDEN)
+    cif, caf, _ = metas()
+    tracking.TrackAnnotation.track_id_counter = 0
+    tracking.PoseSimilarity.distance_type = {'euclidean': tracking.Euclidean, 'oks': tracking.Oks}[name]
+    try:
+        tracker = tracking.PoseSimilarity(cif, caf, pose_generator=OraclePoseGenerator(cif.keypoints, caf.skeleton))
+        seed, people, n_frames, appear = TRACKING_VIDEOS[v]
+        for t, fields in enumerate(synth.synth_tracking_sequence(seed, people, n_frames, appear=appear)):
+            anns = tracker([torch.from_numpy(f) for f in fields[:2]])
+            assert [a.id_ for a in anns] == golden['sim_%s_video%d_frame%d_ids' % (name, v, t)].tolist()
+            got = np.asarray([a.data for a in anns], dtype=np.float32).reshape(-1, 17, 3)
+            # the reference tracker keeps ONE native decoder for the whole video, whose results drift with
+            # the call count (float32 revision offset): tolerance, not equality
+            want = golden['sim_%s_video%d_frame%d_data' % (name, v, t)]
+            assert got.shape == want.shape and np.abs(got - want).max() <= 1e-4
+    finally:
+        tracking.PoseSimilarity.distance_type = tracking.Euclidean
+
+
+def test_crafted_distance_prefers_the_same_person():
+    from openpifpaf_amd import tracking
+    from openpifpaf_amd.annotation import Annotation
+    cif, caf, _ = metas()
+
+    def pose(dx):
+        a = Annotation(cif.keypoints, caf.skeleton)
+        a.data[:, 0] = np.arange(17) * 3.0 + dx
+        a.data[:, 1] = np.arange(17) * 2.0
+        a.data[:, 2] = 0.8
+        return a
+    d = tracking.Crafted()
+    d.valid_keypoints = list(range(17))
+    track = tracking.TrackAnnotation().add(1, pose(0.0))
+    near, far = d(2, pose(1.0), track, True), d(2, pose(60.0), track, True)
+    assert near < far < 1000.0 and d(20, pose(0.0), track, True) == 1000.0      # out of sight for > 12 frames
+
+
 def test_factory_and_registry():
     from openpifpaf_amd import decoder, tracking
-    assert tracking.TrackingPose in decoder.DECODERS
+    assert tracking.TrackingPose in decoder.DECODERS and tracking.PoseSimilarity in decoder.DECODERS
     assert tracking.TrackingPose.factory(list(metas())[:2]) == []          # needs the three tracking heads
     import argparse
     parser = argparse.ArgumentParser()
