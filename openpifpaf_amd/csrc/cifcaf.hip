@@ -815,7 +815,7 @@ __device__ __forceinline__ double pose_score(const PoseView& q, int K) {
 // ------------------------------------------------------------------- kernel
 template <bool REG>
 __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArgs a, DevSkeleton sk, DevParams p,
-                                                                        int n_growers) {
+                                                                        int n_growers, int nms_waves) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1153,7 +1153,8 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
         unsigned char* nsp = work_base + (size_t)wave * nms_scratch_bytes(a.max_ann);
         OccBox* my_box = (OccBox*)nsp;
         int2* my_cell = (int2*)(nsp + sizeof(OccBox) * a.max_ann);
-        for (int k = wave; k < a.F; k += kAssocWaves) {       // :27-30: only joints with an occupancy field take part
+        // :27-30: only joints with an occupancy field take part; nms_waves = waves whose scratch fits the LDS
+        for (int k = wave; k < a.F && wave < nms_waves; k += nms_waves) {
             for (int r = lane; r < n_kept; r += kWave) {
                 const double* pose = anns + ((size_t)nms_order[r] * K + k) * 4;
                 OccBox bx; bx.minx = bx.miny = bx.maxx = bx.maxy = 0;
@@ -1256,7 +1257,9 @@ hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevPara
     if (shared + fixed + priv > budget) return hipErrorInvalidValue;
     int growers = (int)((budget - shared - fixed) / priv);
     if (growers > kAssocWaves) growers = kAssocWaves;
-    const size_t nms = (size_t)kAssocWaves * nms_scratch_bytes(a.max_ann);
+    int nms_waves = kAssocWaves;                     // large annotation capacities: fewer waves share the NMS pass
+    while (nms_waves > 1 && shared + (size_t)nms_waves * nms_scratch_bytes(a.max_ann) > budget) nms_waves--;
+    const size_t nms = (size_t)nms_waves * nms_scratch_bytes(a.max_ann);
     if (shared + nms > budget) return hipErrorInvalidValue;
     const size_t grow_bytes = fixed + (size_t)growers * priv;
     const size_t lds = shared + (grow_bytes > nms ? grow_bytes : nms);
@@ -1266,8 +1269,8 @@ hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevPara
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (reg) cifcaf_assoc_kernel<true><<<a.B, kAssocThreads, lds, st>>>(a, sk, p, growers);
-    else cifcaf_assoc_kernel<false><<<a.B, kAssocThreads, lds, st>>>(a, sk, p, growers);
+    if (reg) cifcaf_assoc_kernel<true><<<a.B, kAssocThreads, lds, st>>>(a, sk, p, growers, nms_waves);
+    else cifcaf_assoc_kernel<false><<<a.B, kAssocThreads, lds, st>>>(a, sk, p, growers, nms_waves);
     prof_mark(st, "cifcaf_assoc_kernel");
     return hipGetLastError();
 }

@@ -502,3 +502,16 @@ def test_random_geometry_sweep(native, port, coco_skeleton0):
         assert n == len(want), 'case %d (%dx%d, %d people): %d poses, oracle %d' % (case, H, W, people, n, len(want))
         ok, msg = compare_annotations(out[0, :n].cpu().numpy(), want)
         assert ok, 'case %d (%dx%d, %d people): %s' % (case, H, W, people, msg)
+
+
+def test_large_annotation_capacity(native, port, coco_skeleton0):
+    """max_annotations beyond what the keypoint-NMS scratch of eight waves fits in LDS: fewer waves share
+    the NMS pass; the result does not change."""
+    cif, caf = fields(95, 12)
+    want, _ = port.decode(cif, 8, caf, 8, coco_skeleton0)
+    for cap in (700, 2000):
+        dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0), max_annotations=cap)
+        out, ids, cnt = dec.call_batch(dev(cif[None]), 8, dev(caf[None]), 8)
+        n = int(cnt[0])
+        ok, msg = compare_annotations(out[0, :n].cpu().numpy(), want)
+        assert n == len(want) and ok, (cap, msg)

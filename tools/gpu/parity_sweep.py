@@ -1,0 +1,58 @@
+"""Randomised parity sweep of the HIP decode against the oracle: shapes, crowd sizes, strides and decoder
+options drawn at random, several images per launch.  Exit code 1 on the first mismatch.
+
+    PYTHONPATH=. python tools/gpu/parity_sweep.py [n_batches] [seed]"""
+import sys
+import time
+
+import numpy as np
+import torch
+
+from openpifpaf_amd import _lib, constants, native, synth
+from oracle import port
+
+n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+skel0 = np.asarray(constants.COCO_PERSON_SKELETON, dtype=np.int64) - 1
+dec = native.CifCaf(17, torch.from_numpy(skel0), max_annotations=512)
+OPTIONS = [dict(), dict(), dict(greedy=1), dict(reverse_match=0), dict(keypoint_threshold=0.3, keypoint_threshold_rel=0.7),
+           dict(force_complete=1, keypoint_threshold=0.0, keypoint_threshold_rel=0.0, nms_instance_threshold=0.0,
+                nms_keypoint_threshold=0.0),
+           dict(cif_threshold=0.2, seed_threshold=0.25, caf_threshold=0.2), dict(ablation_cifseeds_no_rescore=1),
+           dict(ablation_caf_no_rescore=1), dict(occupancy_reduction=1.0), dict(nms_suppression=0.5)]
+n_images = n_poses = 0
+worst = 0.0
+t0 = time.time()
+for batch_i in range(n_batches):
+    H, W = int(rng.integers(7, 91)), int(rng.integers(7, 91))
+    B = int(rng.integers(1, 7))
+    stride = int(rng.choice([4, 8, 8, 8, 16]))
+    kw = OPTIONS[int(rng.integers(len(OPTIONS)))]
+    lo = float(rng.uniform(0.15, 0.7))
+    cifs, cafs = [], []
+    for b in range(B):
+        people = int(rng.integers(0, 1 + max(1, min(24, H * W // 120))))
+        cif, caf = synth.synth_fields(int(rng.integers(1 << 30)), people, height=H, width=W,
+                                      noise=float(rng.uniform(0.0, 0.4)), size_range=(lo, min(1.3, lo + 0.6)))
+        cifs.append(cif); cafs.append(caf)
+    out, ids, cnt = dec.call_batch(torch.from_numpy(np.stack(cifs)).cuda(), stride, torch.from_numpy(np.stack(cafs)).cuda(),
+                                   stride, params=_lib.default_params(**kw))
+    out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
+    for b in range(B):
+        want, _ = port.decode(cifs[b], stride, cafs[b], stride, skel0, params=port.default_params(**kw))
+        n = int(cnt[b])
+        if n > dec.max_annotations:            # capacity overflow is flagged, not compared
+            assert len(want) > dec.max_annotations
+            continue
+        ok = n == len(want)
+        err = float(np.abs(out[b, :n].astype(np.float64) - want).max()) if ok and n else 0.0
+        presence = ok and np.array_equal(out[b, :n, :, 0] > 0, want[:, :, 0] > 0)
+        if not ok or err > 1e-4 or not presence:
+            print('MISMATCH batch %d image %d: %dx%d stride %d options %s: %d poses vs oracle %d, max err %g' % (
+                batch_i, b, H, W, stride, kw, n, len(want), err))
+            sys.exit(1)
+        worst = max(worst, err)
+        n_images += 1
+        n_poses += n
+print('parity sweep ok: %d launches, %d images, %d poses, worst |delta| %.3g, %.1f s' % (
+    n_batches, n_images, n_poses, worst, time.time() - t0))
