@@ -1,7 +1,10 @@
 """Randomised parity sweep of the HIP decode against the oracle: shapes, crowd sizes, strides and decoder
 options drawn at random, several images per launch.  Exit code 1 on the first mismatch.
 
-    PYTHONPATH=. python tools/gpu/parity_sweep.py [n_batches] [seed]"""
+    PYTHONPATH=. python tools/gpu/parity_sweep.py [n_batches] [seed] [coco|dense|tracking]
+
+coco: 17 joints / 19 bones (register-resident growth state); dense: + 25 dense bones (LDS growth state);
+tracking: 34 joints over 17 CIF fields, 36 bones, previous-frame poses as initial annotations."""
 import sys
 import time
 
@@ -13,8 +16,13 @@ from oracle import port
 
 n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-skel0 = np.asarray(constants.COCO_PERSON_SKELETON, dtype=np.int64) - 1
-dec = native.CifCaf(17, torch.from_numpy(skel0), max_annotations=512)
+mode = sys.argv[3] if len(sys.argv) > 3 else 'coco'
+skeleton1 = {'coco': list(constants.COCO_PERSON_SKELETON),
+             'dense': list(constants.COCO_PERSON_SKELETON) + list(constants.DENSER_COCO_PERSON_CONNECTIONS),
+             'tracking': synth.tracking_skeleton()}[mode]
+skel0 = np.asarray(skeleton1, dtype=np.int64) - 1
+K = 34 if mode == 'tracking' else 17
+dec = native.CifCaf(K, torch.from_numpy(skel0), max_annotations=512)
 OPTIONS = [dict(), dict(), dict(greedy=1), dict(reverse_match=0), dict(keypoint_threshold=0.3, keypoint_threshold_rel=0.7),
            dict(force_complete=1, keypoint_threshold=0.0, keypoint_threshold_rel=0.0, nms_instance_threshold=0.0,
                 nms_keypoint_threshold=0.0),
@@ -29,17 +37,32 @@ for batch_i in range(n_batches):
     stride = int(rng.choice([4, 8, 8, 8, 16]))
     kw = OPTIONS[int(rng.integers(len(OPTIONS)))]
     lo = float(rng.uniform(0.15, 0.7))
-    cifs, cafs = [], []
+    cifs, cafs, inits = [], [], []
+    n_init = int(rng.integers(0, 4)) if mode == 'tracking' else 0
     for b in range(B):
         people = int(rng.integers(0, 1 + max(1, min(24, H * W // 120))))
-        cif, caf = synth.synth_fields(int(rng.integers(1 << 30)), people, height=H, width=W,
-                                      noise=float(rng.uniform(0.0, 0.4)), size_range=(lo, min(1.3, lo + 0.6)))
+        seed_b = int(rng.integers(1 << 30))
+        if mode == 'tracking':
+            cif, caf, full = synth.synth_tracking_fields(seed_b, people, height=H, width=W,
+                                                         size_range=(lo, min(1.0, lo + 0.4)))
+            prev, _ = port.decode(full, stride, caf, stride, skel0)          # previous-frame poses: joints 17..33
+            init = np.zeros((n_init, 34, 4), dtype=np.float32)
+            init[:min(n_init, len(prev)), 17:] = prev[:n_init, 17:]
+            inits.append(init)
+        else:
+            cif, caf = synth.synth_fields(seed_b, people, height=H, width=W, skeleton=skeleton1,
+                                          noise=float(rng.uniform(0.0, 0.4)), size_range=(lo, min(1.3, lo + 0.6)))
         cifs.append(cif); cafs.append(caf)
-    out, ids, cnt = dec.call_batch(torch.from_numpy(np.stack(cifs)).cuda(), stride, torch.from_numpy(np.stack(cafs)).cuda(),
-                                   stride, params=_lib.default_params(**kw))
+    init_ids = np.tile(np.arange(50, 50 + n_init, dtype=np.int64), (B, 1))
+    out, ids, cnt = dec.call_batch(
+        torch.from_numpy(np.stack(cifs)).cuda(), stride, torch.from_numpy(np.stack(cafs)).cuda(), stride,
+        torch.from_numpy(np.stack(inits)).cuda() if n_init else None,
+        torch.from_numpy(init_ids).cuda() if n_init else None, params=_lib.default_params(**kw))
     out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
     for b in range(B):
-        want, _ = port.decode(cifs[b], stride, cafs[b], stride, skel0, params=port.default_params(**kw))
+        want, _ = port.decode(cifs[b], stride, cafs[b], stride, skel0, params=port.default_params(**kw),
+                              n_keypoints=K, initial_annotations=inits[b] if n_init else None,
+                              initial_ids=init_ids[b] if n_init else None)
         n = int(cnt[b])
         if n > dec.max_annotations:            # capacity overflow is flagged, not compared
             assert len(want) > dec.max_annotations
@@ -54,5 +77,5 @@ for batch_i in range(n_batches):
         worst = max(worst, err)
         n_images += 1
         n_poses += n
-print('parity sweep ok: %d launches, %d images, %d poses, worst |delta| %.3g, %.1f s' % (
+print('parity sweep (' + mode + ') ok: %d launches, %d images, %d poses, worst |delta| %.3g, %.1f s' % (
     n_batches, n_images, n_poses, worst, time.time() - t0))
