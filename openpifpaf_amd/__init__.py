@@ -16,6 +16,7 @@ _LAZY = {
     'DECODERS': ('decoder', 'DECODERS'),
     'Decoder': ('decoder', 'Decoder'),
     'CifCaf': ('decoder', 'CifCaf'),
+    'TrackingPose': ('tracking', 'TrackingPose'),
 }
 
 
@@ -24,7 +25,8 @@ def __getattr__(name):
     if name in _LAZY:
         mod, attr = _LAZY[name]
         return getattr(importlib.import_module('.' + mod, __name__), attr)
-    if name in ('decoder', 'native', 'network', 'predictor', 'annotation', '_lib', 'build'):
+    if name in ('decoder', 'native', 'network', 'predictor', 'annotation', '_lib', 'build', 'tracking',
+                'torchscript', 'fused', 'distributed'):
         return importlib.import_module('.' + name, __name__)
     raise AttributeError(name)
 
@@ -38,4 +40,11 @@ def register():
         import openpifpaf
     except ImportError:
         return
-    openpifpaf.DECODERS = {d for d in openpifpaf.DECODERS if d.__name__ != 'CifCaf'} | {decoder.CifCaf}
+    from . import tracking
+    ours = {decoder.CifCaf, decoder.CifCafDense, decoder.CifDet, tracking.TrackingPose, tracking.PoseSimilarity}
+    names = {d.__name__ for d in ours}
+    # mutate the set in place: the reference's factory iterates the very same object
+    # (decoder/factory.py:17, re-exported by openpifpaf/__init__.py:28)
+    for d in [d for d in openpifpaf.DECODERS if d.__name__ in names]:
+        openpifpaf.DECODERS.discard(d)
+    openpifpaf.DECODERS.update(ours)

@@ -71,3 +71,27 @@ def test_all_active_adversarial(ref, coco_skeleton0):
     r_out, _, r_hr = ref.decode(cif, 8, caf, 8, coco_skeleton0)
     o_out, _, o_hr = port.decode(cif, 8, caf, 8, coco_skeleton0, return_cifhr=True)
     assert np.array_equal(r_hr, o_hr) and np.array_equal(r_out, o_out)
+
+
+def test_register_swaps_decoders_inside_the_real_reference_package():
+    """The reference's own Python package (imported with oracle/_ref as its extension): after
+    ``openpifpaf_amd.register()`` the set its decoder factory iterates holds the HIP-backed classes."""
+    from oracle import reference_python
+    import os
+    if not os.path.isdir(reference_python.REF_SRC):
+        pytest.skip('reference sources not present')
+    opp = reference_python.load()
+    import openpifpaf_amd
+    from openpifpaf_amd import decoder, tracking
+    import sys
+    ref_factory = sys.modules['openpifpaf.decoder.factory']
+    before = set(opp.DECODERS)
+    try:
+        openpifpaf_amd.register()
+        assert ref_factory.DECODERS is opp.DECODERS
+        assert {decoder.CifCaf, decoder.CifCafDense, decoder.CifDet, tracking.TrackingPose,
+                tracking.PoseSimilarity} <= ref_factory.DECODERS
+        assert not [d for d in ref_factory.DECODERS if d.__module__.startswith('openpifpaf.')]
+    finally:
+        opp.DECODERS.clear()
+        opp.DECODERS.update(before)
