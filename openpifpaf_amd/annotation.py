@@ -95,6 +95,33 @@ class Annotation:
         return ann
 
 
+def inverse_transform_batch(annotations, metas):
+    """``Annotation.inverse_transform`` (reference ``annotation.py:162-200``) for a whole decoded batch at
+    once, on the device the decoder left it on: ``annotations`` ``[B, max, K, 4]`` (v, x, y, s) as returned by
+    ``native.CifCaf.call_batch`` -> same shape in original-image coordinates.  Offsets, scales and the
+    horizontal flip are handled; rotated inputs (a training-time augmentation) are not."""
+    import torch
+    B = annotations.shape[0]
+    assert len(metas) == B
+    rows = []
+    for m in metas:
+        m = m or {}
+        rot = m.get('rotation')
+        if rot is not None and rot.get('angle', 0.0) != 0.0:
+            raise NotImplementedError('inverse_transform_batch: rotated inputs')
+        off, sc = m.get('offset', (0.0, 0.0)), m.get('scale', (1.0, 1.0))
+        flip = bool(m.get('hflip'))
+        rows.append([float(off[0]), float(off[1]), float(sc[0]), float(sc[1]), 1.0 if flip else 0.0,
+                     float(m['width_height'][0]) - 1.0 if flip else 0.0])
+    t = torch.tensor(rows, dtype=annotations.dtype, device=annotations.device).view(B, 1, 1, 6)
+    out = annotations.clone()
+    out[..., 1] = (annotations[..., 1] + t[..., 0]) / t[..., 2]
+    out[..., 2] = (annotations[..., 2] + t[..., 1]) / t[..., 3]
+    out[..., 3] = annotations[..., 3] / t[..., 2]
+    out[..., 1] = torch.where(t[..., 4] > 0, -out[..., 1] + t[..., 5], out[..., 1])
+    return out
+
+
 class AnnotationDet:
     """Detection annotation (reference ``annotation.py:216-262``)."""
 

@@ -202,3 +202,27 @@ def test_register_replaces_cifcaf_in_a_host_openpifpaf(monkeypatch):
     monkeypatch.setitem(sys.modules, 'openpifpaf', host)
     openpifpaf_amd.register()
     assert decoder.CifCaf in host.DECODERS and OldCifCaf not in host.DECODERS and CifDetHost in host.DECODERS
+
+
+def test_batched_inverse_transform_equals_per_annotation():
+    import torch
+    from openpifpaf_amd import constants
+    from openpifpaf_amd.annotation import Annotation, inverse_transform_batch
+    rng = np.random.default_rng(3)
+    B, M, K = 3, 4, 17
+    t = torch.from_numpy(rng.uniform(0, 300, (B, M, K, 4)).astype(np.float32))
+    metas = [
+        {'offset': np.array((-12.0, 3.0)), 'scale': np.array((0.5, 0.52)), 'hflip': False,
+         'rotation': {'angle': 0.0, 'width': None, 'height': None}, 'width_height': np.array((640, 480))},
+        {'offset': np.array((0.0, 0.0)), 'scale': np.array((1.0, 1.0)), 'hflip': True,
+         'rotation': {'angle': 0.0, 'width': None, 'height': None}, 'width_height': np.array((321, 200))},
+        None,
+    ]
+    got = inverse_transform_batch(t, metas).numpy()
+    for b in range(B):
+        for m in range(M):
+            ann = Annotation(constants.COCO_KEYPOINTS, constants.COCO_PERSON_SKELETON)
+            ann.data[:, :2], ann.data[:, 2], ann.joint_scales[:] = t[b, m, :, 1:3].numpy(), t[b, m, :, 0].numpy(), t[b, m, :, 3].numpy()
+            want = ann.inverse_transform(metas[b])
+            assert np.allclose(got[b, m, :, 1:3], want.data[:, :2], rtol=1e-6, atol=1e-4)
+            assert np.allclose(got[b, m, :, 3], want.joint_scales, rtol=1e-6) and np.array_equal(got[b, m, :, 0], want.data[:, 2])
