@@ -95,3 +95,64 @@ def test_register_swaps_decoders_inside_the_real_reference_package():
     finally:
         opp.DECODERS.clear()
         opp.DECODERS.update(before)
+
+
+def test_annotation_objects_equal_the_reference_package():
+    """openpifpaf_amd.annotation.Annotation against the reference's own class: score, bbox, json_data and
+    inverse_transform on random poses."""
+    from oracle import reference_python
+    import os
+    if not os.path.isdir(reference_python.REF_SRC):
+        pytest.skip('reference sources not present')
+    opp = reference_python.load()
+    from openpifpaf_amd import constants
+    from openpifpaf_amd.annotation import Annotation
+    rng = np.random.default_rng(11)
+    meta = {'offset': np.array((-7.0, 12.0)), 'scale': np.array((0.8, 0.75)), 'hflip': True,
+            'rotation': {'angle': 0.0, 'width': None, 'height': None}, 'width_height': np.array((500, 375)),
+            'valid_area': np.array((0.0, 0.0, 499.0, 374.0))}
+    for _ in range(5):
+        data = rng.uniform(0, 200, (17, 3)).astype(np.float32)
+        data[:, 2] = rng.uniform(0, 1, 17) * (rng.random(17) > 0.3)
+        scales = rng.uniform(1, 9, 17).astype(np.float32)
+        pair = []
+        for cls in (Annotation, opp.Annotation):
+            a = cls(constants.COCO_KEYPOINTS, constants.COCO_PERSON_SKELETON,
+                    score_weights=constants.COCO_PERSON_SCORE_WEIGHTS)
+            a.data[:] = data
+            a.joint_scales[:] = scales
+            pair.append(a)
+        mine, ref = pair
+        assert np.isclose(mine.score, ref.score) and np.allclose(mine.bbox(), ref.bbox())
+        assert mine.json_data() == ref.json_data()
+        m2, r2 = mine.inverse_transform(meta), ref.inverse_transform(meta)
+        assert np.allclose(m2.data, r2.data, atol=1e-5) and np.allclose(m2.joint_scales, r2.joint_scales)
+
+
+def test_composite_field_head_equals_the_reference_package():
+    """network.CompositeField4 (conv 1x1 -> PixelShuffle -> crop -> sigmoid / cell offsets / softplus) against
+    the reference's ``network/heads.py:272-378`` with identical weights: the field layout the decoder reads."""
+    from oracle import reference_python
+    import os
+    if not os.path.isdir(reference_python.REF_SRC):
+        pytest.skip('reference sources not present')
+    opp = reference_python.load()
+    import torch
+    from openpifpaf_amd import headmeta, network
+    torch.manual_seed(0)
+    mine_metas = headmeta.cocokp_metas()
+    ref_cif = opp.headmeta.Cif('cif', 'cocokp', keypoints=mine_metas[0].keypoints, sigmas=mine_metas[0].sigmas,
+                               pose=np.asarray(mine_metas[0].pose), draw_skeleton=mine_metas[1].skeleton)
+    ref_caf = opp.headmeta.Caf('caf', 'cocokp', keypoints=mine_metas[0].keypoints, sigmas=mine_metas[0].sigmas,
+                               pose=np.asarray(mine_metas[0].pose), skeleton=mine_metas[1].skeleton)
+    for m in (ref_cif, ref_caf):
+        m.base_stride, m.upsample_stride = 16, 2
+    x = torch.randn(2, 64, 7, 9)
+    for mine_meta, ref_meta in zip(mine_metas, (ref_cif, ref_caf)):
+        mine = network.CompositeField4(mine_meta, 64).eval()
+        ref = opp.network.heads.CompositeField4(ref_meta, 64).eval()
+        ref.conv.load_state_dict(mine.conv.state_dict())
+        with torch.no_grad():
+            a, b = mine(x), ref(x)
+        assert a.shape == b.shape == (2, mine_meta.n_fields, 5 if mine_meta is mine_metas[0] else 8, 13, 17)
+        assert torch.allclose(a, b, atol=1e-6), float((a - b).abs().max())
