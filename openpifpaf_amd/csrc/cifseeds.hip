@@ -123,7 +123,7 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
         const bool owner = n_pad >= 32 || wave == 0;
         bool synced = true;                                  // a workgroup barrier separates us from the last local pass
         for (int k = 2; k <= n_pad; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int j = k >> 1; j > 0;) {
                 if (j >= E) {                                // far stride: any thread, any pair
                     if (!synced) __syncthreads();
                     for (int t = tid; t < (n_pad >> 1); t += 1024) {
@@ -135,7 +135,23 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
                     }
                     __syncthreads();
                     synced = true;
-                } else {                                     // stride inside this wave's block
+                    j >>= 1;
+                    continue;
+                }
+                if (j >= 2) {                                // two strides (j, j/2) per LDS round trip: 4 keys in registers
+                    const int h = j >> 1;
+                    if (owner) {
+                        for (int q = lane; q < (E >> 2); q += 64) {
+                            const int i0 = wave * E + (((q & ~(h - 1)) << 2) | (q & (h - 1)));
+                            const bool desc = (i0 & k) == 0;
+                            unsigned long long v0 = sk[i0], v1 = sk[i0 | h], v2 = sk[i0 | j], v3 = sk[i0 | j | h];
+                            compare_exchange_desc(v0, v2, desc); compare_exchange_desc(v1, v3, desc);   // stride j
+                            compare_exchange_desc(v0, v1, desc); compare_exchange_desc(v2, v3, desc);   // stride j/2
+                            sk[i0] = v0; sk[i0 | h] = v1; sk[i0 | j] = v2; sk[i0 | j | h] = v3;
+                        }
+                    }
+                    j >>= 2;
+                } else {                                     // last single stride of the stage
                     if (owner) {
                         for (int q = lane; q < (E >> 1); q += 64) {
                             const int i = wave * E + (((q & ~(j - 1)) << 1) | (q & (j - 1)));
@@ -145,10 +161,11 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
                             sk[i] = a; sk[p] = c;
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    synced = false;
+                    j >>= 1;
                 }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                synced = false;
             }
         }
         __syncthreads();
