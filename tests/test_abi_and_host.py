@@ -226,3 +226,37 @@ def test_batched_inverse_transform_equals_per_annotation():
             want = ann.inverse_transform(metas[b])
             assert np.allclose(got[b, m, :, 1:3], want.data[:, :2], rtol=1e-6, atol=1e-4)
             assert np.allclose(got[b, m, :, 3], want.joint_scales, rtol=1e-6) and np.array_equal(got[b, m, :, 0], want.data[:, 2])
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / 'decode_c_abi')
+    lib_dir = os.path.join(ROOT, 'openpifpaf_amd', 'lib')
+    subprocess.check_call(['gcc', '-std=c99', '-w', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include',
+                           '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'examples', 'decode_c_abi.c'),
+                           '-L' + lib_dir, '-lopenpifpaf_amd', '-L/opt/rocm/lib', '-lamdhip64',
+                           '-Wl,-rpath,' + lib_dir, '-Wl,-rpath,/opt/rocm/lib', '-o', exe])
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_host_links(tmp_path):
+    """include/openpifpaf_amd.h must be usable from C (no torch, no C++): strict C99 compile of the header, and
+    the C example links against the library and fails loudly without a device."""
+    import subprocess
+    import torch
+    src = tmp_path / 'hdr.c'
+    src.write_text('#include "openpifpaf_amd.h"\nint main(void) { return sizeof(opa_shape) + sizeof(opa_params) > 0 ? 0 : 1; }\n')
+    subprocess.check_call(['gcc', '-std=c99', '-pedantic', '-Wall', '-Wextra', '-Werror',
+                           '-I' + os.path.join(ROOT, 'include'), '-c', str(src), '-o', str(tmp_path / 'hdr.o')])
+    exe = _build_c_example(tmp_path)
+    if not torch.cuda.is_available():
+        proc = subprocess.run([exe], capture_output=True, text=True)
+        assert proc.returncode == 1 and 'no HIP device' in proc.stderr
+
+
+@pytest.mark.gpu
+def test_c_host_example_runs_on_the_gpu(tmp_path):
+    import subprocess
+    proc = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 0, proc.stderr
+    assert 'annotations per image: 0 0' in proc.stdout
