@@ -68,8 +68,40 @@ def preprocess_image(image, *, long_edge=None, batch_mode=False):
     return torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1))), meta
 
 
+def preprocess_batch_device(images, *, long_edge, device):
+    """Device-side form of ``preprocess_image`` for batch mode: the uint8 frames are
+    uploaded as they are (a quarter of the bytes of normalised float32), then rescaled to ``long_edge``
+    (bilinear with antialiasing, the filter PIL's BILINEAR resize applies), centre-padded to
+    ``long_edge x long_edge`` with the reference's fill colour and normalised -- all on ``device``.
+    -> (float32 ``[B,3,long_edge,long_edge]`` on ``device``, metas).  Pixel values agree with the host path
+    to within resampling round-off (PIL rounds the resized image to uint8, this path does not)."""
+    assert long_edge, '--long-edge must be provided for batch size > 1'
+    mean = torch.tensor(IMAGENET_MEAN, device=device).view(3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, device=device).view(3, 1, 1)
+    fill = (torch.tensor((124.0, 116.0, 104.0), device=device).view(3, 1, 1) / 255.0 - mean) / std
+    batch = fill.expand(3, long_edge, long_edge).unsqueeze(0).repeat(len(images), 1, 1, 1).contiguous()
+    metas = []
+    for b, image in enumerate(images):
+        frame = torch.from_numpy(np.ascontiguousarray(np.asarray(image, dtype=np.uint8)[..., :3]))
+        h0, w0 = frame.shape[:2]
+        s = long_edge / max(h0, w0)
+        tw, th = (int(w0 * s), int(long_edge)) if h0 > w0 else (int(long_edge), int(h0 * s))
+        x = frame.to(device, non_blocking=True).permute(2, 0, 1).unsqueeze(0).float()
+        x = torch.nn.functional.interpolate(x, size=(th, tw), mode='bilinear', antialias=True, align_corners=False)
+        x = (x[0] / 255.0 - mean) / std
+        left, top = max(0, int((long_edge - tw) / 2.0)), max(0, int((long_edge - th) / 2.0))
+        batch[b, :, top:top + th, left:left + tw] = x
+        sx, sy = (tw - 1) / (w0 - 1), (th - 1) / (h0 - 1)
+        metas.append({'offset': np.array((-float(left), -float(top))), 'scale': np.array((sx, sy)), 'hflip': False,
+                      'rotation': {'angle': 0.0, 'width': None, 'height': None},
+                      'valid_area': np.array((left, top, (w0 - 1) * sx, (h0 - 1) * sy), dtype=np.float64),
+                      'width_height': np.array((w0, h0))})
+    return batch, metas
+
+
 class Predictor:
     """Predict from various inputs with a common configuration."""
+    device_preprocess = False      #: batch mode: rescale / pad / normalise on the device instead of with PIL
     batch_size = 1
     device = torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
     long_edge = None
@@ -140,10 +172,14 @@ class Predictor:
     def _images(self, images):
         batch_mode = self.batch_size > 1
         for i in range(0, len(images), self.batch_size):
-            items = [preprocess_image(im, long_edge=self.long_edge, batch_mode=batch_mode)
-                     for im in images[i:i + self.batch_size]]
-            batch = torch.stack([t for t, _ in items])
-            metas = [m for _, m in items]
+            if batch_mode and self.device_preprocess and self.device.type == 'cuda':
+                batch, metas = preprocess_batch_device(images[i:i + self.batch_size], long_edge=self.long_edge,
+                                                       device=self.device)
+            else:
+                items = [preprocess_image(im, long_edge=self.long_edge, batch_mode=batch_mode)
+                         for im in images[i:i + self.batch_size]]
+                batch = torch.stack([t for t, _ in items])
+                metas = [m for _, m in items]
             for pred, meta in zip(self.tensor_batch(batch, metas), metas):
                 yield pred, [], meta
 

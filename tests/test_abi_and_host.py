@@ -260,3 +260,22 @@ def test_c_host_example_runs_on_the_gpu(tmp_path):
     proc = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=120)
     assert proc.returncode == 0, proc.stderr
     assert 'annotations per image: 0 0' in proc.stdout
+
+
+def test_device_preprocess_agrees_with_the_pil_path():
+    """preprocess_batch_device (resize + pad + normalise with torch ops, runs on any device) against the
+    PIL-based preprocess_image in batch mode: same geometry and meta, pixels within resampling round-off."""
+    import torch
+    from openpifpaf_amd import predictor
+    rng = np.random.default_rng(5)
+    smooth = rng.random((60, 80, 3))
+    for _ in range(3):                              # a smooth image: resampling filters agree on it
+        smooth = (smooth + np.roll(smooth, 1, 0) + np.roll(smooth, 1, 1)) / 3
+    images = [(smooth * 255).astype(np.uint8), (smooth[:40, :30] * 255).astype(np.uint8)]
+    batch, metas = predictor.preprocess_batch_device(images, long_edge=97, device=torch.device('cpu'))
+    assert batch.shape == (2, 3, 97, 97)
+    for b, image in enumerate(images):
+        want, wmeta = predictor.preprocess_image(image, long_edge=97, batch_mode=True)
+        assert np.allclose(metas[b]['offset'], wmeta['offset']) and np.allclose(metas[b]['scale'], wmeta['scale'])
+        assert float((batch[b] - want).abs().max()) < 0.12          # normalised units; 1/255/0.225 = 0.017 per uint8 step
+        assert float((batch[b] - want).abs().mean()) < 0.02
