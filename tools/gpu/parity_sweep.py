@@ -1,10 +1,11 @@
 """Randomised parity sweep of the HIP decode against the oracle: shapes, crowd sizes, strides and decoder
 options drawn at random, several images per launch.  Exit code 1 on the first mismatch.
 
-    PYTHONPATH=. python tools/gpu/parity_sweep.py [n_batches] [seed] [coco|dense|tracking]
+    PYTHONPATH=. python tools/gpu/parity_sweep.py [n_batches] [seed] [coco|dense|tracking|wholebody]
 
 coco: 17 joints / 19 bones (register-resident growth state); dense: + 25 dense bones (LDS growth state);
-tracking: 34 joints over 17 CIF fields, 36 bones, previous-frame poses as initial annotations."""
+tracking: 34 joints over 17 CIF fields, 36 bones, previous-frame poses as initial annotations;
+wholebody: 133 joints / 160 bones."""
 import sys
 import time
 
@@ -17,11 +18,12 @@ from oracle import port
 n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 mode = sys.argv[3] if len(sys.argv) > 3 else 'coco'
-skeleton1 = {'coco': list(constants.COCO_PERSON_SKELETON),
+wb = constants.wholebody() if mode == 'wholebody' else None
+skeleton1 = {'wholebody': wb['skeleton'] if wb else None, 'coco': list(constants.COCO_PERSON_SKELETON),
              'dense': list(constants.COCO_PERSON_SKELETON) + list(constants.DENSER_COCO_PERSON_CONNECTIONS),
              'tracking': synth.tracking_skeleton()}[mode]
 skel0 = np.asarray(skeleton1, dtype=np.int64) - 1
-K = 34 if mode == 'tracking' else 17
+K = {'tracking': 34, 'wholebody': 133}.get(mode, 17)
 dec = native.CifCaf(K, torch.from_numpy(skel0), max_annotations=512)
 OPTIONS = [dict(), dict(), dict(greedy=1), dict(reverse_match=0), dict(keypoint_threshold=0.3, keypoint_threshold_rel=0.7),
            dict(force_complete=1, keypoint_threshold=0.0, keypoint_threshold_rel=0.0, nms_instance_threshold=0.0,
@@ -50,7 +52,8 @@ for batch_i in range(n_batches):
             init[:min(n_init, len(prev)), 17:] = prev[:n_init, 17:]
             inits.append(init)
         else:
-            cif, caf = synth.synth_fields(seed_b, people, height=H, width=W, skeleton=skeleton1,
+            cif, caf = synth.synth_fields(seed_b, min(people, 6) if wb else people, height=H, width=W,
+                                          skeleton=skeleton1, pose=wb['standing_pose'] if wb else None,
                                           noise=float(rng.uniform(0.0, 0.4)), size_range=(lo, min(1.3, lo + 0.6)))
         cifs.append(cif); cafs.append(caf)
     init_ids = np.tile(np.arange(50, 50 + n_init, dtype=np.int64), (B, 1))
