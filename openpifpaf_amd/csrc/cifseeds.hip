@@ -172,9 +172,66 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
     } else {
         for (int t = n + tid; t < n_pad; t += 1024) K[t] = 0ull;
         sync_global();                                              // keys travel through HBM between threads here
-        for (int k = 2; k <= n_pad; k <<= 1) {
-            int j = k >> 1;
-            for (; j >= kSortLdsKeys; j >>= 1) {                    // far strides through L2
+        // strides j_first, j_first/2, ..., 1 of stage k over the 8192 keys in LDS (directions come from the key's
+        // GLOBAL index blk + i).  Like the in-LDS sort above: wave w owns keys [512 w, 512 w + 512), strides
+        // below 512 stay inside a wave (two per LDS round trip, no workgroup barrier), only 512..4096 synchronise.
+        auto lds_strides = [&](int blk, int k, int j_first) {
+            constexpr int EB = kSortLdsKeys / 16;
+            const int wave = tid >> 6, lane = tid & 63;
+            bool synced = true;
+            for (int jj = j_first; jj > 0;) {
+                if (jj >= EB) {
+                    if (!synced) __syncthreads();
+                    for (int t = tid; t < (kSortLdsKeys >> 1); t += 1024) {
+                        const int i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+                        const int p = i | jj;
+                        unsigned long long a = sk[i], c = sk[p];
+                        compare_exchange_desc(a, c, ((blk + i) & k) == 0);
+                        sk[i] = a; sk[p] = c;
+                    }
+                    __syncthreads();
+                    synced = true;
+                    jj >>= 1;
+                    continue;
+                }
+                if (jj >= 2) {
+                    const int h = jj >> 1;
+                    for (int q = lane; q < (EB >> 2); q += 64) {
+                        const int i0 = wave * EB + (((q & ~(h - 1)) << 2) | (q & (h - 1)));
+                        const bool desc = ((blk + i0) & k) == 0;
+                        unsigned long long v0 = sk[i0], v1 = sk[i0 | h], v2 = sk[i0 | jj], v3 = sk[i0 | jj | h];
+                        compare_exchange_desc(v0, v2, desc); compare_exchange_desc(v1, v3, desc);
+                        compare_exchange_desc(v0, v1, desc); compare_exchange_desc(v2, v3, desc);
+                        sk[i0] = v0; sk[i0 | h] = v1; sk[i0 | jj] = v2; sk[i0 | jj | h] = v3;
+                    }
+                    jj >>= 2;
+                } else {
+                    for (int q = lane; q < (EB >> 1); q += 64) {
+                        const int i = wave * EB + 2 * q;
+                        unsigned long long a = sk[i], c = sk[i | 1];
+                        compare_exchange_desc(a, c, ((blk + i) & k) == 0);
+                        sk[i] = a; sk[i | 1] = c;
+                    }
+                    jj >>= 1;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                synced = false;
+            }
+            __syncthreads();
+        };
+        // stages k <= 8192 never leave a block: ALL of them in one LDS visit per block
+        for (int blk = 0; blk < n_pad; blk += kSortLdsKeys) {
+            for (int t = tid; t < kSortLdsKeys; t += 1024) sk[t] = K[blk + t];
+            __syncthreads();
+            for (int k = 2; k <= kSortLdsKeys; k <<= 1) lds_strides(blk, k, k >> 1);
+            for (int t = tid; t < kSortLdsKeys; t += 1024) K[blk + t] = sk[t];
+            __syncthreads();
+        }
+        sync_global();
+        // stages k > 8192: far strides through L2, then the strides below 8192 in one LDS visit per block
+        for (int k = 2 * kSortLdsKeys; k <= n_pad; k <<= 1) {
+            for (int j = k >> 1; j >= kSortLdsKeys; j >>= 1) {
                 for (int t = tid; t < (n_pad >> 1); t += 1024) {
                     const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                     const int p = i | j;
@@ -184,22 +241,14 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
                 }
                 sync_global();
             }
-            for (int blk = 0; blk < n_pad; blk += kSortLdsKeys) {   // near strides inside LDS blocks
+            for (int blk = 0; blk < n_pad; blk += kSortLdsKeys) {
                 for (int t = tid; t < kSortLdsKeys; t += 1024) sk[t] = K[blk + t];
                 __syncthreads();
-                for (int jj = j; jj > 0; jj >>= 1) {
-                    for (int t = tid; t < (kSortLdsKeys >> 1); t += 1024) {
-                        const int i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
-                        const int p = i | jj;
-                        unsigned long long a = sk[i], c = sk[p];
-                        compare_exchange_desc(a, c, ((blk + i) & k) == 0);
-                        sk[i] = a; sk[p] = c;
-                    }
-                    __syncthreads();
-                }
+                lds_strides(blk, k, kSortLdsKeys >> 1);
                 for (int t = tid; t < kSortLdsKeys; t += 1024) K[blk + t] = sk[t];
-                sync_global();
+                __syncthreads();
             }
+            sync_global();
         }
     }
 
