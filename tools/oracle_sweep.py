@@ -2,7 +2,7 @@
 reference decoder (oracle/_ref, built from the reference's own C++ sources): the same case generator as
 tools/gpu/parity_sweep.py, every output compared bit for bit.  Runs on the CPU, where /root/reference exists.
 
-    PYTHONPATH=. python tools/oracle_sweep.py [n_images] [seed] [coco|dense|tracking|wholebody]
+    PYTHONPATH=. python tools/oracle_sweep.py [n_images] [seed] [coco|dense|tracking|wholebody|cifdet]
 
 Exit code 1 on the first difference.  The log of the committed run is profiles/r1/oracle_vs_reference_sweep.log."""
 import sys
@@ -19,6 +19,33 @@ mode = sys.argv[3] if len(sys.argv) > 3 else 'coco'
 if not reference.available():
     sys.exit('oracle/_ref is not built (needs /root/reference): python -c "import __graft_entry__ as g; g.build()"')
 reference.load().set_num_threads(1)
+if mode == 'cifdet':                     # CifDet::call (cifdet.cpp:24-80), fresh instance per image
+    torch = reference.load()
+    n_det = 0
+    t0 = time.time()
+    try:
+        for image_i in range(n_images):
+            H, W = int(rng.integers(12, 91)), int(rng.integers(12, 91))     # synth_det_field needs >= 9 cells
+            stride = int(rng.choice([4, 8, 8, 16]))
+            kw = [dict(), dict(), dict(cif_threshold=0.2), dict(seed_threshold=0.35), dict(cifhr_neighbors=9)][
+                int(rng.integers(5))]
+            seed_i = int(rng.integers(1 << 30))
+            field = synth.synth_det_field(seed_i, int(rng.integers(0, 13)), n_categories=int(rng.integers(1, 12)),
+                                          height=H, width=W)
+            p = port.default_params(**kw)
+            reference.apply_params(p)
+            torch.classes.openpifpaf_decoder_utils.CifDetSeeds.set_threshold(p.seed_threshold)
+            c, sc, bx = torch.classes.openpifpaf_decoder.CifDet().call(torch.from_numpy(field), stride)
+            oc, osc, obx = port.cifdet_decode(field, stride, params=p)
+            if not (np.array_equal(c.numpy(), oc) and np.array_equal(sc.numpy(), osc) and np.array_equal(bx.numpy(), obx)):
+                print('DIFFERENCE image %d: %dx%d stride %d seed %d options %s' % (image_i, H, W, stride, seed_i, kw))
+                sys.exit(1)
+            n_det += len(oc)
+    finally:
+        reference.reset_statics()
+    print('oracle == reference (cifdet): %d images, %d detections, bit-equal categories, scores and boxes, %.1f s' % (
+        n_images, n_det, time.time() - t0))
+    sys.exit(0)
 wb = constants.wholebody() if mode == 'wholebody' else None
 skeleton1 = {'wholebody': wb['skeleton'] if wb else None, 'coco': list(constants.COCO_PERSON_SKELETON),
              'dense': list(constants.COCO_PERSON_SKELETON) + list(constants.DENSER_COCO_PERSON_CONNECTIONS),
