@@ -184,6 +184,15 @@ int opa_cifseeds_fill(const float* cif_dev, int32_t batch, int32_t n_cif, int32_
                       int32_t* seed_f_dev, float* seed_vxys_dev, int32_t* seed_count_dev,
                       void* scratch_dev, size_t scratch_bytes, void* stream);
 
+/* ref: module.cpp:96-102  CifDetSeeds(cifhr, revision).fill(cifdet_field, stride) + get()
+ * (cif_seeds.cpp:69-90,117-139).  field_dev [B, F, 6, H, W]; same ordering rule as opa_cifseeds_fill.
+ *  seed_f_dev int32 [B, cap], seed_vxywh_dev [B, cap, 5] (v,x,y,w,h), seed_count_dev int32 [B],
+ *  cap = F*H*W;  scratch_dev: opa_cifseeds_scratch_bytes() bytes. */
+int opa_cifdetseeds_fill(const float* field_dev, int32_t batch, int32_t n_fields, int32_t field_h, int32_t field_w,
+                         int32_t stride, const float* cifhr_dev, const opa_params* params,
+                         int32_t* seed_f_dev, float* seed_vxywh_dev, int32_t* seed_count_dev,
+                         void* scratch_dev, size_t scratch_bytes, void* stream);
+
 /* ref: module.cpp:104-111  CafScored(cifhr, revision, score_th, cif_floor).fill(caf, stride, skeleton) + get()
  * (caf_scored.cpp:29-104).  Lists keep the reference's raster (j,i) order.
  *  skeleton_dev int64 [A,2] 0-based (device);  score_th < 0 -> params->caf_threshold

@@ -93,6 +93,8 @@ SYMBOLS = {
     'opa_cifseeds_scratch_bytes': (_sz, [_i32, _i32, _i32, _i32]),
     'opa_cifseeds_fill': (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _P(Params),
                                          _vp, _vp, _vp, _vp, _sz, _vp]),
+    'opa_cifdetseeds_fill': (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _P(Params),
+                                            _vp, _vp, _vp, _vp, _sz, _vp]),
     'opa_cafscored_fill': (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32,
                                           _vp, _dbl, _dbl, _P(Params), _vp, _vp, _vp]),
     'opa_grow_connection_blend': (ctypes.c_int, [_vp, _i32, _dbl, _dbl, _dbl, _dbl, _i32, _P(_dbl), _vp]),

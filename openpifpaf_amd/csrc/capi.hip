@@ -421,6 +421,26 @@ int opa_cifseeds_fill(const float* cif_dev, int32_t batch, int32_t n_cif, int32_
     return OPA_OK;
 }
 
+int opa_cifdetseeds_fill(const float* field_dev, int32_t batch, int32_t n_fields, int32_t field_h, int32_t field_w,
+                         int32_t stride, const float* cifhr_dev, const opa_params* params,
+                         int32_t* seed_f_dev, float* seed_vxywh_dev, int32_t* seed_count_dev,
+                         void* scratch_dev, size_t scratch_bytes, void* stream) {
+    if (!field_dev || !cifhr_dev || !seed_f_dev || !seed_vxywh_dev || !seed_count_dev || !scratch_dev ||
+        batch <= 0 || n_fields <= 0 || field_h <= 0 || field_w <= 0 || stride <= 0)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifdetseeds_fill: bad arguments");
+    if (scratch_bytes < opa_cifseeds_scratch_bytes(batch, n_fields, field_h, field_w))
+        return fail(OPA_ERR_WORKSPACE, "opa_cifdetseeds_fill: scratch too small");
+    opa_params hp; if (params) hp = *params; else opa_get_params(&hp);
+    const DevParams p = to_dev(hp);
+    hipError_t e = launch_cifseeds(field_dev, batch, n_fields, field_h, field_w, stride, cifhr_dev,
+                                   (field_h - 1) * stride + 1, (field_w - 1) * stride + 1,
+                                   opa_cifhr_pitch(field_w, stride), p, (unsigned long long*)scratch_dev,
+                                   sort_cap_for(n_fields * field_h * field_w), seed_count_dev, seed_f_dev,
+                                   seed_vxywh_dev, (hipStream_t)stream, true);
+    if (e != hipSuccess) return fail_hip(e, "cifdetseeds");
+    return OPA_OK;
+}
+
 int opa_cafscored_fill(const float* caf_dev, int32_t batch, int32_t n_caf, int32_t caf_h, int32_t caf_w,
                        int32_t stride, const float* cifhr_dev, int32_t n_cif, int32_t cif_h, int32_t cif_w,
                        int32_t cif_stride, const int64_t* skeleton_dev, double score_th, double cif_floor,

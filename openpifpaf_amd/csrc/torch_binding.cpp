@@ -9,16 +9,21 @@
 //     torch.classes.openpifpaf_amd_decoder.{CifCaf,CifDet} (+ call_batch)
 //     torch.ops.openpifpaf_amd_decoder.grow_connection_blend
 //     torch.classes.openpifpaf_amd_decoder_utils.{CifHr,CifSeeds,CafScored} (stage objects + static tunables),
-//                                               NMSKeypoints (static tunables)
-// Not exported: Occupancy / CifDetSeeds (module.cpp:66-73,96-102) -- the HIP path has no standalone
-// occupancy object (poses are tested inside the association kernel).
-// It contains no compute: every method marshals tensors into the C ABI of libopenpifpaf_amd.so.
+//                                               CifDetSeeds, NMSKeypoints (static tunables),
+//                                               Occupancy (host-side box map for host callers such as the
+//                                               trackers, decoder/tracking_pose.py:81 -- the decode itself
+//                                               tests occupancy inside the association kernel)
+// Apart from that small host map it contains no compute: every method marshals tensors into the C ABI of
+// libopenpifpaf_amd.so.
 // Host C++ only (g++); built by openpifpaf_amd/build.py into lib/libopenpifpaf_amd_torch.so.
 #include <torch/script.h>
 #include <torch/custom_class.h>
 #include <c10/hip/HIPStream.h>
 
+#include <algorithm>
+#include <cmath>
 #include <tuple>
+#include <vector>
 
 #include "../../include/openpifpaf_amd.h"
 
@@ -266,6 +271,84 @@ struct CifSeeds : torch::CustomClassHolder {
     }
 };
 
+// module.cpp:96-102
+struct CifDetSeeds : torch::CustomClassHolder {
+    torch::Tensor hr;
+    torch::Tensor f, vxywh, count, scratch;
+
+    CifDetSeeds(const torch::Tensor& cifhr, double revision) : hr(pitched_cifhr(cifhr)) {
+        TORCH_CHECK(revision == 1.0, "the HIP path stores the map at revision 1.0 (a fresh reference instance)");
+    }
+    void fill(const torch::Tensor& field_in, int64_t stride) {
+        torch::Tensor field = to_device_f32(field_in);
+        TORCH_CHECK(field.dim() == 4 && field.size(1) == 6, "expected a CifDet field [F,6,H,W]");
+        const int32_t F = (int32_t)field.size(0), H = (int32_t)field.size(2), W = (int32_t)field.size(3);
+        TORCH_CHECK(hr.size(0) == F && hr.size(1) == (int64_t)(H - 1) * stride + 1 && hr.size(2) == (int64_t)(W - 1) * stride + 1,
+                    "cifhr does not match the field shape and stride");
+        const int64_t cap = (int64_t)F * H * W;
+        auto opts = torch::TensorOptions().device(field.device());
+        f = torch::empty({cap}, opts.dtype(torch::kInt32));
+        vxywh = torch::empty({cap, 5}, opts.dtype(torch::kFloat32));
+        count = torch::empty({1}, opts.dtype(torch::kInt32));
+        const size_t nbytes = opa_cifseeds_scratch_bytes(1, F, H, W);
+        scratch = torch::empty({(int64_t)nbytes}, opts.dtype(torch::kUInt8));
+        check(opa_cifdetseeds_fill(field.data_ptr<float>(), 1, F, H, W, (int32_t)stride, hr.data_ptr<float>(), nullptr,
+                                   f.data_ptr<int32_t>(), vxywh.data_ptr<float>(), count.data_ptr<int32_t>(),
+                                   scratch.data_ptr(), nbytes, current_stream(field)),
+              "opa_cifdetseeds_fill");
+    }
+    std::tuple<torch::Tensor, torch::Tensor> get() {              // cif_seeds.cpp:117-139
+        TORCH_CHECK(count.defined(), "CifDetSeeds.fill() has not been called");
+        const int64_t n = count.cpu().item<int32_t>();
+        return std::make_tuple(f.narrow(0, 0, n).to(torch::kInt64), vxywh.narrow(0, 0, n).clone());
+    }
+};
+
+// module.cpp:67-73; semantics of csrc/src/occupancy.cpp:13-79.  A host-side map for host-side callers: cells carry
+// the epoch of their last set(), clear() starts a new epoch.
+struct Occupancy : torch::CustomClassHolder {
+    double reduction, min_scale_reduced;
+    int64_t n = 1, rows = 1, cols = 1;
+    uint32_t epoch = 1;
+    std::vector<uint32_t> stamp = std::vector<uint32_t>(1, 0u);
+
+    Occupancy(double reduction_, double min_scale) : reduction(reduction_), min_scale_reduced(min_scale / reduction_) {
+        TORCH_CHECK(reduction_ > 0.0, "Occupancy: reduction must be > 0");
+    }
+    static int64_t clampi(int64_t v, int64_t lo, int64_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+    void set(int64_t f, double x, double y, double sigma) {        // occupancy.cpp:13-29
+        TORCH_CHECK(f >= 0 && f < n, "Occupancy.set: field index out of range");
+        if (reduction != 1.0) {
+            x /= reduction; y /= reduction;
+            sigma = std::fmax(min_scale_reduced, sigma / reduction);
+        }
+        const int64_t minx = clampi((int64_t)(x - sigma), 0, cols - 1), miny = clampi((int64_t)(y - sigma), 0, rows - 1);
+        const int64_t maxx = clampi((int64_t)(x + sigma), minx + 1, cols), maxy = clampi((int64_t)(y + sigma), miny + 1, rows);
+        for (int64_t j = miny; j < maxy; j++) {
+            uint32_t* row = stamp.data() + (f * rows + j) * cols;
+            for (int64_t i = minx; i < maxx; i++) row[i] = epoch;
+        }
+    }
+    bool get(int64_t f, double x, double y) {                      // occupancy.cpp:32-43
+        if (f >= n) return true;
+        TORCH_CHECK(f >= 0, "Occupancy.get: negative field index");
+        if (reduction != 1.0) { x /= reduction; y /= reduction; }
+        const int64_t xi = clampi((int64_t)x, 0, cols - 1), yi = clampi((int64_t)y, 0, rows - 1);
+        return stamp[(f * rows + yi) * cols + xi] == epoch;
+    }
+    void reset(std::vector<int64_t> shape) {                       // occupancy.cpp:46-68
+        TORCH_CHECK(shape.size() == 3 && shape[0] > 0 && shape[1] >= 0 && shape[2] >= 0, "Occupancy.reset: shape must be [n, rows, cols]");
+        n = shape[0];
+        rows = (int64_t)((double)shape[1] / reduction) + 1;
+        cols = (int64_t)((double)shape[2] / reduction) + 1;
+        if ((int64_t)stamp.size() < n * rows * cols) stamp.assign((size_t)(n * rows * cols), 0u);
+        clear();
+    }
+    void clear() {                                                 // occupancy.cpp:71-77
+        if (++epoch == 0u) { std::fill(stamp.begin(), stamp.end(), 0u); epoch = 1; }
+    }
+};
+
 // module.cpp:104-111
 struct CafScored : torch::CustomClassHolder {
     torch::Tensor hr, lists, counts;
@@ -370,6 +453,17 @@ TORCH_LIBRARY(openpifpaf_amd_decoder_utils, m) {
         .def(torch::init<const torch::Tensor&, double>())
         .def("fill", &CifSeeds::fill)
         .def("get", &CifSeeds::get);
+    m.class_<CifDetSeeds>("CifDetSeeds")                                                 // :96-102
+        OPA_STATIC_GETSET_AS(threshold, seed_threshold, double)
+        .def(torch::init<const torch::Tensor&, double>())
+        .def("fill", &CifDetSeeds::fill)
+        .def("get", &CifDetSeeds::get);
+    m.class_<Occupancy>("Occupancy")                                                     // :67-73
+        .def(torch::init<double, double>())
+        .def("get", &Occupancy::get)
+        .def("set", &Occupancy::set)
+        .def("reset", &Occupancy::reset)
+        .def("clear", &Occupancy::clear);
     m.class_<CafScored>("CafScored")                                                     // :104-111
         OPA_STATIC_GETSET_AS(default_score_th, caf_threshold, double)
         OPA_STATIC_GETSET_AS(ablation_no_rescore, ablation_caf_no_rescore, bool)

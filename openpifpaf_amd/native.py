@@ -302,6 +302,47 @@ class CifSeeds:
         return f[image, :n].to(torch.int64), vxys[image, :n]
 
 
+class CifDetSeeds:
+    """``torch.classes.openpifpaf_decoder_utils.CifDetSeeds`` (module.cpp:96-102).  ``cifhr``: the detection
+    map ``[F, rows, cols]`` at revision 1.0 (any device; it is re-pitched on the GPU)."""
+    get_threshold, set_threshold = _static_getset('seed_threshold')
+
+    def __init__(self, cifhr, revision=1.0):
+        if revision != 1.0:
+            raise RuntimeError('the HIP path stores the map at revision 1.0 (a fresh reference instance)')
+        hr, _ = _prep(cifhr)
+        F, rows, cols = hr.shape
+        pitch = _lib.lib().opa_cifhr_pitch(cols, 1)
+        self.accumulated = torch.zeros((F, rows, pitch), dtype=torch.float32, device=hr.device)
+        self.accumulated[:, :, :cols] = hr
+        self.cols = cols
+        self._out = None
+
+    def fill(self, field, stride, *, params=None):
+        field, _ = _prep(field)
+        F, C, H, W = field.shape
+        if C != 6 or tuple(self.accumulated.shape[:2]) != (F, (H - 1) * stride + 1) or self.cols != (W - 1) * stride + 1:
+            raise RuntimeError('expected a CifDet field [F,6,H,W] matching the map')
+        cap = F * H * W
+        L = _lib.lib()
+        f = torch.empty((cap,), dtype=torch.int32, device=field.device)
+        vxywh = torch.empty((cap, 5), dtype=torch.float32, device=field.device)
+        count = torch.empty((1,), dtype=torch.int32, device=field.device)
+        nbytes = L.opa_cifseeds_scratch_bytes(1, F, H, W)
+        scratch = torch.empty(nbytes, dtype=torch.uint8, device=field.device)
+        _lib.check(L.opa_cifdetseeds_fill(_ptr(field), 1, F, H, W, int(stride), _ptr(self.accumulated),
+                                          ctypes.byref(params) if params is not None else None,
+                                          _ptr(f), _ptr(vxywh), _ptr(count), _ptr(scratch), nbytes, _stream()),
+                   'opa_cifdetseeds_fill')
+        self._out = (f, vxywh, count, scratch)
+
+    def get(self):
+        """-> (fields int64 [n], vxywh float32 [n,5]) sorted by v descending (cif_seeds.cpp:117-139)."""
+        f, vxywh, count, _ = self._out
+        n = int(count[0])
+        return f[:n].to(torch.int64), vxywh[:n]
+
+
 class CafScored:
     """``torch.classes.openpifpaf_decoder_utils.CafScored`` (module.cpp:104-111), batched."""
     get_default_score_th, set_default_score_th = _static_getset('caf_threshold')

@@ -464,6 +464,20 @@ int64_t oracle_cifseeds(const float* cif, int64_t F, int64_t H, int64_t W, int64
     return int64_t(s.size());
 }
 
+// CifDetSeeds(cifhr, revision).fill + get, cif_seeds.cpp:69-90,117-139; out_vxywh [cap,5]
+int64_t oracle_cifdetseeds(const float* field, int64_t F, int64_t H, int64_t W, int64_t stride,
+                           const float* cifhr, const oracle_params* p,
+                           int64_t* out_f, float* out_vxywh, int64_t cap) {
+    HiRes hr{const_cast<float*>(cifhr), F, (H - 1) * stride + 1, (W - 1) * stride + 1};
+    std::vector<DetSeed> s = cifdet_seeds(hr, field, F, H, W, stride, *p);
+    for (int64_t i = 0; i < int64_t(s.size()) && i < cap; i++) {
+        out_f[i] = s[i].c;
+        out_vxywh[5 * i + 0] = s[i].v; out_vxywh[5 * i + 1] = s[i].x; out_vxywh[5 * i + 2] = s[i].y;
+        out_vxywh[5 * i + 3] = s[i].w; out_vxywh[5 * i + 4] = s[i].h;
+    }
+    return int64_t(s.size());
+}
+
 // fwd/bwd: [A, cap, 7] row lists; n_fwd/n_bwd: [A]
 void oracle_cafscored(const float* caf, int64_t A, int64_t H, int64_t W, int64_t stride,
                       const float* cifhr, int64_t F, int64_t cif_H, int64_t cif_W, int64_t cif_stride,

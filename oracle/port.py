@@ -53,6 +53,7 @@ def lib():
             build()
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.oracle_cifseeds.restype = ctypes.c_int64
+        _lib.oracle_cifdetseeds.restype = ctypes.c_int64
         _lib.oracle_cifcaf_decode.restype = ctypes.c_int64
         _lib.oracle_cifcaf_decode_k.restype = ctypes.c_int64
         _lib.oracle_cifdet_decode.restype = ctypes.c_int64
@@ -104,6 +105,20 @@ def cifseeds(cif, stride, cifhr, *, params=None):
     out_v = np.empty((cap, 4), dtype=np.float32)
     n = lib().oracle_cifseeds(_ptr(cif), _i64(F), _i64(H), _i64(W), _i64(stride), _ptr(cifhr),
                               ctypes.byref(params), _ptr(out_f), _ptr(out_v), _i64(cap))
+    return out_f[:n].copy(), out_v[:n].copy()
+
+
+def cifdetseeds(field, stride, cifhr, *, params=None):
+    """CifDetSeeds (cif_seeds.cpp:69-90,117-139) -> (f int64[n], vxywh float32[n,5]) sorted by v descending."""
+    params = params or default_params()
+    field, cifhr = _f32(field), _f32(cifhr)
+    F, C, H, W = field.shape
+    assert C == 6
+    cap = F * H * W
+    out_f = np.empty((cap,), dtype=np.int64)
+    out_v = np.empty((cap, 5), dtype=np.float32)
+    n = lib().oracle_cifdetseeds(_ptr(field), _i64(F), _i64(H), _i64(W), _i64(stride), _ptr(cifhr),
+                                 ctypes.byref(params), _ptr(out_f), _ptr(out_v), _i64(cap))
     return out_f[:n].copy(), out_v[:n].copy()
 
 

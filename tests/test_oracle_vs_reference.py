@@ -92,6 +92,41 @@ def test_dense_connections_44_bones_bit_equal(ref, seed, people):
     assert np.array_equal(r_out, o_out) and np.array_equal(r_ids, o_ids)
 
 
+def test_cifdetseeds_and_occupancy_classes(ref):
+    """The two remaining openpifpaf_decoder_utils classes (module.cpp:67-73,96-102): the oracle's CifDetSeeds
+    restatement and the binding's host-side Occupancy against the real ones."""
+    from openpifpaf_amd import synth, torchscript
+    from oracle import port
+    torch = ref.load()
+    RU = torch.classes.openpifpaf_decoder_utils
+    for seed, n_obj, size in ((3, 5, 33), (4, 9, 49)):
+        field = synth.synth_det_field(seed, n_obj, height=size, width=size + 8)
+        _, _, _, hr = port.cifdet_decode(field, 8, return_cifhr=True)
+        hr_t = torch.from_numpy(hr)               # the real class keeps only an accessor: the tensor must outlive it
+        seeds = RU.CifDetSeeds(hr_t, 1.0)
+        seeds.fill(torch.from_numpy(field), 8)
+        r_f, r_v = seeds.get()
+        o_f, o_v = port.cifdetseeds(field, 8, hr)
+        assert len(o_f) > 0 and np.array_equal(r_f.numpy(), o_f) and np.array_equal(r_v.numpy(), o_v)
+    torchscript.load()
+    rng = np.random.default_rng(11)
+    for reduction, min_scale in ((2.0, 4.0), (1.0, 0.1)):
+        mine = torch.classes.openpifpaf_amd_decoder_utils.Occupancy(reduction, min_scale)
+        real = RU.Occupancy(reduction, min_scale)
+        for shape in ((3, 41, 57), (4, 18, 18), (3, 41, 57)):
+            mine.reset(list(shape)); real.reset(list(shape))
+            for _ in range(2):
+                for _ in range(20):
+                    f = int(rng.integers(shape[0]))
+                    x, y, sigma = rng.uniform(-8, shape[2] + 8), rng.uniform(-8, shape[1] + 8), rng.uniform(0.0, 9.0)
+                    mine.set(f, x, y, sigma); real.set(f, x, y, sigma)
+                for _ in range(200):
+                    f = int(rng.integers(shape[0] + 2))
+                    x, y = rng.uniform(-8, shape[2] + 8), rng.uniform(-8, shape[1] + 8)
+                    assert mine.get(f, x, y) == real.get(f, x, y), (reduction, shape, f, x, y)
+                mine.clear(); real.clear()
+
+
 def test_initial_annotations(ref, coco_skeleton0):
     from openpifpaf_amd import synth
     from oracle import port

@@ -15,6 +15,7 @@ STATICS = {
     ('openpifpaf_amd_decoder_utils', 'CifHr'): [('neighbors', 12), ('threshold', 0.25), ('ablation_skip', True)],
     ('openpifpaf_amd_decoder_utils', 'CifSeeds'): [
         ('threshold', 0.35), ('ablation_nms', True), ('ablation_no_rescore', True)],
+    ('openpifpaf_amd_decoder_utils', 'CifDetSeeds'): [('threshold', 0.35)],
     ('openpifpaf_amd_decoder_utils', 'CafScored'): [('default_score_th', 0.2), ('ablation_no_rescore', True)],
     ('openpifpaf_amd_decoder_utils', 'NMSKeypoints'): [
         ('instance_threshold', 0.2), ('keypoint_threshold', 0.25), ('suppression', 1e-4)],
@@ -52,6 +53,35 @@ def test_constructor_fails_loudly_without_gpu_and_checks_dtype():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match='no HIP device'):
             C(17, torch.zeros((19, 2), dtype=torch.int64))
+
+
+def test_occupancy_class_has_the_reference_semantics():
+    """openpifpaf_amd_decoder_utils.Occupancy (module.cpp:67-73, occupancy.cpp:13-79): a host-side map; checked
+    against the package's independent Python restatement on random boxes (and against the real class in
+    test_oracle_vs_reference.py)."""
+    from openpifpaf_amd import torchscript, tracking
+    torchscript.load()
+    rng = np.random.default_rng(5)
+    for reduction, min_scale in ((2.0, 4.0), (1.0, 0.1), (3.0, 2.0)):
+        occ = torch.classes.openpifpaf_amd_decoder_utils.Occupancy(reduction, min_scale)
+        want = tracking.Occupancy(reduction, min_scale)
+        assert occ.get(1, 3.0, 3.0) and not occ.get(0, 3.0, 3.0)          # before reset: one empty [1,1,1] map
+        for shape in ((3, 41, 57), (5, 20, 20), (3, 41, 57)):
+            occ.reset(list(shape)); want.reset(shape)
+            for _ in range(3):
+                for _ in range(25):
+                    f = int(rng.integers(shape[0]))
+                    x, y = rng.uniform(-10, shape[2] + 10), rng.uniform(-10, shape[1] + 10)
+                    sigma = rng.uniform(0.0, 9.0)
+                    occ.set(f, x, y, sigma); want.set(f, x, y, sigma)
+                for _ in range(300):
+                    f = int(rng.integers(shape[0] + 2))
+                    x, y = rng.uniform(-10, shape[2] + 10), rng.uniform(-10, shape[1] + 10)
+                    assert occ.get(f, x, y) == want.get(f, x, y), (reduction, shape, f, x, y)
+                occ.clear(); want.clear()
+                assert not occ.get(0, 5.0, 5.0)
+    with pytest.raises(RuntimeError, match='out of range'):
+        occ.set(99, 1.0, 1.0, 1.0)
 
 
 @pytest.mark.gpu
@@ -121,6 +151,7 @@ def test_binding_stage_objects_and_cifdet_equal_the_ctypes_mirror(coco_skeleton0
     """openpifpaf_amd_decoder_utils.{CifHr,CifSeeds,CafScored} and openpifpaf_amd_decoder.CifDet used the way
     the reference's tests/tools use theirs (module.cpp:57-111)."""
     from openpifpaf_amd import native, synth, torchscript
+    from oracle import port
     torchscript.load()
     U = torch.classes.openpifpaf_amd_decoder_utils
     cif, caf = synth.synth_fields(50, 4, height=41, width=41)
@@ -155,6 +186,15 @@ def test_binding_stage_objects_and_cifdet_equal_the_ctypes_mirror(coco_skeleton0
     assert all(torch.equal(a, b) for a, b in zip(fwd, wfwd)) and all(torch.equal(a, b) for a, b in zip(bwd, wbwd))
     with pytest.raises(RuntimeError, match='revision'):
         U.CifSeeds(acc, 2.0)
+    # CifDetSeeds on the detection map of the oracle (the reference exports no CifDetHr object either)
+    field_np = synth.synth_det_field(3, 5, height=33, width=41)
+    _, _, _, det_hr = port.cifdet_decode(field_np, 8, return_cifhr=True)
+    want_f, want_v = port.cifdetseeds(field_np, 8, det_hr)
+    for seeds_obj in (U.CifDetSeeds(torch.from_numpy(det_hr), 1.0), native.CifDetSeeds(torch.from_numpy(det_hr))):
+        seeds_obj.fill(torch.from_numpy(field_np).cuda(), 8)
+        got_f, got_v = seeds_obj.get()
+        assert len(want_f) > 0 and got_v.shape == (len(want_f), 5)
+        assert np.array_equal(got_f.cpu().numpy(), want_f) and np.array_equal(got_v.cpu().numpy(), want_v)
     # CifDet
     D = torch.classes.openpifpaf_amd_decoder.CifDet
     assert D.get_max_detections_before_nms() == 120
