@@ -349,7 +349,8 @@ def main():
             cpu = cpu_baseline(cifs_np, cafs_np, skeleton0, args.cpu_seconds, fc_kw if args.force_complete else None)
         value = world * B * args.steps / elapsed
         result = {
-            'metric': 'images/sec end-to-end (backbone+CifCaf decode), resnet50 641px',
+            'metric': ('images/sec end-to-end (backbone+CifCaf decode), resnet50 641px' if not args.decode_only else
+                       'images/sec DECODE ONLY (diagnostic: backbone skipped, not the headline metric)'),
             'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
