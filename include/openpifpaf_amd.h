@@ -38,6 +38,11 @@ extern "C" {
 #define OPA_ERR_WORKSPACE 4          /* workspace too small                         */
 #define OPA_ERR_NO_DEVICE 5          /* no gfx950 device visible                    */
 
+/* out_count of opa_cifcaf_decode: number of valid rows, plus this bit when poses were dropped for lack of
+ * capacity (max_annotations too small). */
+#define OPA_COUNT_OVERFLOW 0x40000000
+#define OPA_COUNT_ROWS(c) ((c) & 0x3FFFFFFF)
+
 /* The reference's process-global tunables (its C++ static members), one field
  * per STATIC_GETSET line of module.cpp:26-32,76-116 plus the constructor
  * constants of cifcaf.cpp:153 / cifcaf.hpp:103.  Defaults in comments. */
@@ -134,9 +139,11 @@ size_t opa_cifcaf_workspace_bytes(const opa_shape* shape);
  *  initial_ids_dev  optional int64 [B, n_initial] or NULL
  *  out_dev          [B, max_annotations, K, 4] (v,x,y,s)   (ref: cifcaf.cpp:246-258), K = the decoder's n_keypoints
  *  out_ids_dev      int64 [B, max_annotations]             (ref: cifcaf.cpp:259)
- *  out_count_dev    int32 [B]  number of annotations of each image; a value
- *                   > max_annotations means the capacity overflowed and only the
- *                   first max_annotations (by score) were written.
+ *  out_count_dev    int32 [B]  OPA_COUNT_ROWS(c) = number of valid rows of each image (<= max_annotations, in the
+ *                   reference's output order, score descending); rows behind them are not written.  The
+ *                   OPA_COUNT_OVERFLOW bit is set when the annotation capacity was too small: the poses the
+ *                   seed loop produced after the first max_annotations (in seed order, cifcaf.cpp:206-231) were
+ *                   dropped before keypoint NMS, and the workspace's "status" buffer holds how many.
  */
 int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_params* params,
                       const float* cif_dev, const float* caf_dev,
@@ -159,7 +166,12 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
  * classes of module.cpp:66-117).  what: "tile_bitmaps" (u32 [2][B*F][words]: tiles of the map written by
  * the previous / by this call), "cifhr", "seed_count", "seed_f", "seed_vxys", "seed_cell",
  * "lists", "list_counts", "lists_fc", "list_counts_fc", "occupancy",
- * "annotation_scratch", "status". */
+ * "annotation_scratch", "status" (int32 [B]: poses dropped for lack of capacity), "assoc_stats" (int32 [B,16]
+ * per image: 0 growths started, 1 poses accepted, 2 growths cancelled in flight, 3 finished growths dropped
+ * (their seed had died), 4 results given up to free a grower for the head, 5 mispredictions (seeds handed out
+ * after having been predicted dead), 6 pool refills, 7 seeds, 8 ticks until the growth phase ended, 9 ticks of
+ * the kernel, 10 sum of the growers' busy ticks, 11 list scans, 12 ticks the coordinator waited for the head's
+ * growth, 13 growers, 14 poses stored, 15 ticks of keypoint NMS; ticks are 10 ns). */
 int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what,
                               size_t* offset_bytes, size_t* size_bytes);
 

@@ -121,10 +121,13 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     L->off_list_counts = take(B * L->A * 2 * sizeof(int32_t));
     L->off_lists_fc = take(list_bytes);
     L->off_list_counts_fc = take(B * L->A * 2 * sizeof(int32_t));
-    L->off_occ = take(B * L->F * (size_t)L->occ_h * L->occ_w);
+    // occupancy bitmap, one bit per cell (occupancy.cpp:46-68 keeps an int16 map); 256-B multiple per image
+    L->occ_image_words = align_up((size_t)L->F * L->occ_h * ((L->occ_w + 31) / 32) * sizeof(unsigned)) / sizeof(unsigned);
+    L->off_occ = take(B * L->occ_image_words * sizeof(unsigned));
     L->off_anns = take(B * (size_t)L->max_ann * L->K * 4 * sizeof(double));
     L->off_ann_meta = take(B * (size_t)L->max_ann * sizeof(int64_t));
     L->off_status = take(B * sizeof(int32_t));
+    L->off_stats = take(B * 16 * sizeof(int32_t));
     L->total = off;
     return true;
 }
@@ -276,7 +279,7 @@ int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what, size_t* 
         {"lists", L.off_lists, L.off_list_counts}, {"list_counts", L.off_list_counts, L.off_lists_fc},
         {"lists_fc", L.off_lists_fc, L.off_list_counts_fc}, {"list_counts_fc", L.off_list_counts_fc, L.off_occ},
         {"occupancy", L.off_occ, L.off_anns}, {"annotation_scratch", L.off_anns, L.off_ann_meta},
-        {"status", L.off_status, L.total},
+        {"status", L.off_status, L.off_stats}, {"assoc_stats", L.off_stats, L.total},
     };
     for (const Entry& e : table)
         if (std::strcmp(e.name, what) == 0) {
@@ -344,10 +347,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
                              (int32_t*)(ws + L.off_list_counts_fc), st);
         if (e != hipSuccess) return fail_hip(e, "cafscored(force complete)");
     }
-    e = launch_zero(ws + L.off_occ, ((size_t)L.B * L.F * L.occ_h * L.occ_w + 3) & ~(size_t)3, st);   // :173
-    if (e != hipSuccess) return fail_hip(e, "occupancy memset");
-    prof_mark(st, "memset_occupancy");
-
+    // (the occupancy map of :173 is a bitmap the association kernel clears itself)
     AssocArgs a;
     a.B = L.B; a.K = L.K; a.F = L.F; a.A = L.A; a.max_ann = L.max_ann; a.n_initial = n_initial;
     a.hr_rows = L.hr_rows; a.hr_cols = L.hr_cols; a.occ_h = L.occ_h; a.occ_w = L.occ_w;
@@ -357,7 +357,8 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     a.seed_cell = (const int32_t*)(ws + L.off_seed_cell);
     a.lists = (const float*)(ws + L.off_lists); a.list_counts = (const int32_t*)(ws + L.off_list_counts);
     a.lists_fc = (const float*)(ws + L.off_lists_fc); a.list_counts_fc = (const int32_t*)(ws + L.off_list_counts_fc);
-    a.occ = ws + L.off_occ;
+    a.occ = (unsigned*)(ws + L.off_occ); a.occ_image_words = L.occ_image_words;
+    a.stats = (int32_t*)(ws + L.off_stats);
     a.anns = (double*)(ws + L.off_anns); a.ann_ids = (int64_t*)(ws + L.off_ann_meta);
     a.initial = initial_dev; a.initial_ids = initial_ids_dev;
     a.out = out_dev; a.out_ids = out_ids_dev; a.out_count = out_count_dev;

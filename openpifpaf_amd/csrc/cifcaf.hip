@@ -5,26 +5,30 @@
 // _flood_fill (csrc/src/cifcaf.cpp:32-449), Occupancy (occupancy.cpp:13-79) and
 // NMSKeypoints::call (nms_keypoints.cpp:17-70).
 //
-// One 8-wave workgroup per image (images are the data-parallel unit; a batch fills the
-// chip).  Per image the reference is one serial dependency chain -- seed k is skipped
-// iff an earlier pose occupies its cell -- but the GROWTH of a pose from a seed reads
-// only the CAF lists and the pose's own joints, never the occupancy map (cifcaf.cpp
-// :265-411).  So poses are grown SPECULATIVELY in parallel and only the accept/reject
-// decision is sequential:
+// One workgroup per image (images are the data-parallel unit).  Per image the reference is one serial
+// dependency chain -- seed k is skipped iff an earlier pose occupies its cell -- but the GROWTH of a
+// pose from a seed reads only the CAF lists and the pose's own joints, never the occupancy map
+// (cifcaf.cpp:265-411).  So poses are grown SPECULATIVELY by several wavefronts at once and only the
+// accept/reject decision stays sequential.  The workgroup is a small in-order-commit machine:
 //
-//   pool:   every wave keeps the same pool of up to 512 live, undecided seeds (8 slots per lane);
-//           a seed is fetched and tested against the occupancy map once, when it enters the pool;
-//           selection and the walk below run redundantly in every wave -- no barriers, no exchange;
-//   round:  candidates = the first pooled seed in score order, then the next ones outside the box an
-//           earlier candidate's own seed joint will occupy (the rest of its confidence blob), up to
-//           one per wavefront; every wave grows its candidate's pose on its own (no barriers):
-//           best-first search with the reference's lazy frontier;
-//           resolve walk in seed order: a seed is free iff it is not inside a joint box of a pose
-//           accepted earlier in this round (box containment on the LDS poses = what the map would
-//           say); a free candidate is accepted, a free non-candidate (wrong prediction) ends the
-//           round there -- exactly the seeds the sequential loop would accept, with exactly the
-//           poses it would grow.  Seeds of the same person turn into discarded work, distinct
-//           persons into parallel speed-up.
+//   wave 0, the coordinator, owns everything sequential: the pool of up to 512 live, undecided seeds
+//       (8 slots per lane; a seed is fetched and tested against the occupancy bitmap ONCE, when it enters
+//       the pool), the hand-out of candidates to idle growers, and the commits;
+//   waves 1.., the growers, poll a task slot in LDS, grow the pose of the seed they are handed (best-first
+//       search with the reference's lazy frontier, no barriers), leave pose + occupancy boxes in their
+//       private LDS block and report DONE.  There is no round barrier: a grower that finishes is handed
+//       the next candidate at once.
+//   candidates are handed out in seed order, skipping seeds inside the box an earlier IN-FLIGHT candidate's
+//       own seed joint will occupy (the other cells of the same confidence blob: certainly dead if that
+//       candidate is accepted) -- a prediction that costs nothing when right;
+//   commit is strictly in seed order: the HEAD = the smallest-index live pooled seed.  Everything before it
+//       is decided, so it is free exactly when the sequential loop would find it free (:211).  When its
+//       growth is DONE the pose is accepted: every pooled seed inside one of its joint boxes dies (box
+//       containment = what the map would say, occupancy.cpp:13-43), in-flight growths of dead seeds are
+//       cancelled (they poll a flag), the boxes go to the bitmap for seeds that enter the pool later.
+//       A wrong prediction shows up as a HEAD that was never handed out: it is handed out then (if every
+//       grower holds a later result, the latest one is dropped and redone).  So the accepted seeds are
+//       exactly those of the sequential loop, with exactly the poses it grows, whatever the predictions.
 //
 // Inside a growth the wave uses its 64 lanes where the reference has inner loops:
 // grow_connection_blend scans a CAF candidate list 64 entries per lane-step (coalesced
@@ -35,33 +39,34 @@
 // priorities are the norm (all edges leaving one joint share the bound sqrt(v); every
 // flood-filled joint carries 1e-5) and the pop order decides results; for skeletons that fit a
 // wave (K <= 64, 2A <= 64) pose, frontier and heap live in VGPR lanes (readlane), else in LDS.
-// Occupancy boxes of an accepted pose are dealt to the 8 waves; force-complete growth and flood
-// fill run one pose per wave; keypoint NMS needs no map at all (box containment per field, one
-// field per wave).  The occupancy map and the pose scratch are the only state in HBM that one wave
-// writes and another reads: those hand-overs go through sync_global() (common.hpp).
+// Force-complete growth and flood fill run one pose per grower; keypoint NMS needs no map at all (box
+// containment per field, one field per wave).  The occupancy bitmap is written and read by the coordinator
+// only; the pose scratch in HBM is written by the coordinator and read by everyone after sync_global().
 //
 // Joint confidences are double like the reference's Joint struct; every
 // float/double promotion follows the reference operation by operation and the
 // library is built with -ffp-contract=off.
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace opa {
 
-constexpr int kAssocWaves = 8;
-constexpr int kAssocThreads = kAssocWaves * kWave;
+constexpr int kAssocWavesDefault = 16;   // waves per workgroup of the association kernel (OPA_ASSOC_WAVES = 8 | 12 | 16)
 constexpr int kBlendChunks = 8;
        // list entries per lane held in registers by the single-pass scan
 
-// Optional phase timers (build with -DOPA_ASSOC_TIMING; tools/assoc_timing.py reads them).
-#ifdef OPA_ASSOC_TIMING
-#define OPA_T0(var) const long long var = wall_clock64()
-#define OPA_TACC(acc, var) (acc) += wall_clock64() - var
-#define OPA_TINC(acc, n) (acc) += (n)
-#else
-#define OPA_T0(var)
-#define OPA_TACC(acc, var)
-#define OPA_TINC(acc, n)
-#endif
+// LDS words shared between the coordinator and the growers: plain loads/stores made atomic at workgroup
+// scope (release = this wave's earlier LDS writes are visible before the flag, acquire = the reverse).
+__device__ __forceinline__ int flag_load(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int flag_peek(const int* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void flag_store(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -75,8 +80,10 @@ struct ImageCtx {
     int wave;
     const int32_t *adj_off, *adj_other, *adj_bone, *adj_fwd, *adj_first;
     const float* lists; const int32_t* list_counts; int list_cap;
-    unsigned char* occ; int occ_h, occ_w;
-    // private LDS (one copy per wave, kept identical)
+    unsigned* occ; int occ_h, occ_w, occ_wpr;   // occupancy bitmap [F][occ_h][occ_wpr] (one bit per cell)
+    const int* cancel;                   // this grower's cancel flag in LDS (polled between frontier pops), or null
+    int aborted;                         // set when a growth stopped because of it
+    // private LDS (one block per growing wave)
     float* tgt;                          // [3][kBlendChunks][64] target columns of the list being scanned
     struct OccBox* jbox;                 // occupancy boxes of the grown pose [K]
     double* jv; float *jx, *jy, *js;     // current pose [K]
@@ -86,7 +93,7 @@ struct ImageCtx {
     int heap_n, n_entries;
     // shared LDS
     int* sh_counts;                      // [2A] list lengths of the active list set
-    long long t[12];                     // OPA_ASSOC_TIMING: 0 blend 1 #blend 2 #chunks 3 rest 4 grow 5 mark 6 nms 7 total 8 cycles 9 rounds
+    int n_blend;                         // list scans of this wave (statistics)
 };
 
 __device__ __forceinline__ ListView list_view(const ImageCtx& c, int bone, int dir) {
@@ -206,14 +213,24 @@ __device__ __forceinline__ BlendResult blend_finish(float s1, float s2, bool hav
     return r;
 }
 
-// Lists of up to 64*R entries: ONE memory round trip.  Every lane issues all its
-// loads (6 planes x R chunks, global address space) back to back, an empty asm
-// pins them there (hipcc otherwise sinks each load into the branch that uses it and
-// waits for them one by one), scores and targets stay in registers, and both
-// reductions and the target lookups are register/cross-lane only.
+// Lists of up to 64*R entries: ONE memory round trip.  Every lane issues all its loads (6 planes x R
+// chunks, global address space) back to back and an empty asm pins them there (hipcc otherwise sinks each
+// load into the branch that uses it and waits for them one by one).  The window test (:54-57) runs on all
+// R chunks, and the few entries that pass -- a confidence blob's worth -- are COMPACTED, in list order,
+// into the first lanes through 1 KB of LDS, so that the double-precision exp (:63) is evaluated once per
+// scan instead of once per chunk that holds a passing entry.  Compaction keeps list order, so "position"
+// in the tie rules is the lane: first place = max score, LAST lane among equals (">=", :65); second place
+// = max score among the rest, among equals the last lane before the first if any, else the first after it
+// (the outcome of the sequential rule :65-73).  Both are a 32-bit DPP max plus a ballot.  More than 64
+// passing entries (rare: a window holding that many cells): the streamed two-pass scan below.
 typedef __attribute__((address_space(1))) const float gfloat;
 
 typedef __attribute__((address_space(3))) float lfloat;
+
+constexpr int kTgtFloats = 3 * kBlendChunks * kWave;     // target columns (x2, y2, s2) of the list being scanned
+constexpr int kBlendLdsFloats = kTgtFloats + 4 * kWave;  // + the compacted (x1, y1, c, position) of a scan
+
+__device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const BlendQuery& q, bool only_max);
 
 template <int R>
 __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const BlendQuery& q, bool only_max, float* tgt) {
@@ -231,7 +248,7 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
         __builtin_amdgcn_global_load_lds(g + 4 * L.cap + ii, t3 + (1 * R + r) * kWave, 4, 0, 0);
         __builtin_amdgcn_global_load_lds(g + 6 * L.cap + ii, t3 + (2 * R + r) * kWave, 4, 0, 0);
     }
-    float sc[R], x1[R], y1[R], cc[R];
+    float x1[R], y1[R], cc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int i = r * kWave + lane;
@@ -239,37 +256,52 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
         x1[r] = g[1 * L.cap + ii]; y1[r] = g[2 * L.cap + ii]; cc[r] = g[ii];
     }
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
-        sc[r] = -1.0f;
-    }
-    float s1 = 0.0f; int i1 = -1;
+    for (int r = 0; r < R; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
+    float* cx = tgt + kTgtFloats; float* cy = cx + kWave; float* cv = cy + kWave; int* ci = (int*)(cv + kWave);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int cnt = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int i = r * kWave + lane;
-        if (i < L.n && passes(q, x1[r], y1[r])) {
-            sc[r] = score_of(q, x1[r], y1[r], cc[r]);
-            if (sc[r] >= s1) { s1 = sc[r]; i1 = i; }
-        }
+        const bool pass = i < L.n && passes(q, x1[r], y1[r]);
+        const unsigned long long m = __ballot(pass);
+        if (m == 0ull) continue;
+        const int slot = cnt + __popcll(m & below);
+        if (pass && slot < kWave) { cx[slot] = x1[r]; cy[slot] = y1[r]; cv[slot] = cc[r]; ci[slot] = i; }
+        cnt += __popcll(m);
     }
-    reduce_first(s1, i1);
-    if (s1 == 0.0f || i1 < 0) {                                // :76
+    if (cnt == 0) {                                            // :76
         __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): the LDS loads must land before the area is reused
         return blend_none();
     }
-    float s2 = 0.0f; int r2 = -1;
-    if (!only_max) {
-#pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int i = r * kWave + lane;
-            if (i == i1 || !(sc[r] > 0.0f)) continue;
-            const int rank = i < i1 ? L.n + i : L.n - i;
-            if (sc[r] > s2 || (sc[r] == s2 && rank > r2)) { s2 = sc[r]; r2 = rank; }
-        }
-        reduce_second(s2, r2);
+    if (cnt > kWave) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        return blend_streamed(L, q, only_max);
     }
-    const bool have2 = r2 >= 0;
-    const int i2 = have2 ? (r2 >= L.n ? r2 - L.n : L.n - r2) : i1;
+    wave_sync();
+    const bool have = lane < cnt;
+    float sc = 0.0f; int pos = 0;
+    if (have) { sc = score_of(q, cx[lane], cy[lane], cv[lane]); pos = ci[lane]; }
+    const unsigned b1 = have && sc > 0.0f ? __float_as_uint(sc) : 0u;
+    const unsigned s1b = wave_max_u32(b1);
+    if (s1b == 0u) {                                           // :76
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        return blend_none();
+    }
+    const int l1 = 63 - __builtin_clzll(__ballot(b1 == s1b));
+    const int i1 = __builtin_amdgcn_readlane(pos, l1);
+    const float s1 = __uint_as_float(s1b);
+    float s2 = 0.0f; int i2 = i1; bool have2 = false;
+    if (!only_max) {
+        const unsigned b2 = lane != l1 ? b1 : 0u;
+        const unsigned s2b = wave_max_u32(b2);
+        if (s2b != 0u) {
+            const unsigned long long m2 = __ballot(b2 == s2b);
+            const unsigned long long before = m2 & ((1ull << l1) - 1ull);
+            const int l2 = before ? 63 - __builtin_clzll(before) : __builtin_ctzll(m2);
+            i2 = __builtin_amdgcn_readlane(pos, l2); s2 = __uint_as_float(s2b); have2 = true;
+        }
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): target columns are in LDS
     wave_sync();
     const float e1x = tgt[0 * R * kWave + i1], e1y = tgt[1 * R * kWave + i1], e1s = tgt[2 * R * kWave + i1];
@@ -278,11 +310,11 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
 }
 
 // Any list length (force-complete lists at caf_th 0.001 and all-active fields hold thousands of
-// entries): two passes over the list, each in groups of 8 chunks whose loads are issued together
-// and pinned like in blend_cached, so a pass costs one memory round trip per 512 entries instead of
+// entries): two passes over the list, each in groups of 4 chunks whose loads are issued together
+// and pinned like in blend_cached, so a pass costs one memory round trip per 256 entries instead of
 // one per 64.  Scores are recomputed in pass 2.
 __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const BlendQuery& q, bool only_max) {
-    constexpr int G = 8;
+    constexpr int G = 4;
     const int lane = lane_id();
     const gfloat* g = (const gfloat*)L.base;
     float s1 = 0.0f; int i1 = -1;
@@ -354,10 +386,8 @@ __device__ __forceinline__ BlendResult blend_impl(const float* base, int cap, in
 
 __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, double x, double y, double xy_scale,
                                              double filter_sigmas) {
-    OPA_T0(t0);
-    const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt);
-    OPA_TACC(c.t[0], t0); OPA_TINC(c.t[1], 1); OPA_TINC(c.t[2], (L.n + kWave - 1) / kWave);
-    return r;
+    c.n_blend++;
+    return blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt);
 }
 
 // -------------------------------------------------------------- frontier heap
@@ -469,6 +499,7 @@ __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool rever
     frontier_reset(c);
     for (int j = 0; j < c.K; j++) if (c.jv[j] != 0.0) frontier_add_from(c, j);
     while (c.heap_n > 0) {
+        if (c.cancel && flag_peek(c.cancel)) { c.aborted = 1; return; }  // the seed died while its pose grew
         const int e = heap_pop(c);
         const int start = c.e_se[e] >> 16, end = c.e_se[e] & 0xffff;
         if (c.jv[end] > 0.0) continue;                                   // :284
@@ -660,6 +691,7 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
     reg_load_pose(c, R);
     reg_frontier_start(R, sk, c.K);
     while (R.heap_n > 0) {
+        if (c.cancel && flag_peek(c.cancel)) { c.aborted = 1; return; }      // the seed died while its pose grew
         const int slot = reg_heap_pop(R);
         const int info = rlane(sk.slot_info, slot);
         const int start = info & 0xff, end = (info >> 8) & 0xff;
@@ -702,7 +734,7 @@ __device__ __forceinline__ void grow_pose(ImageCtx& c, const DevParams& p, const
         grow_reg(c, p, sk, reverse_match_, filter_sigmas, then_flood_fill);
     } else {
         grow(c, p, reverse_match_, filter_sigmas);
-        if (then_flood_fill) flood_fill(c);
+        if (then_flood_fill && !c.aborted) flood_fill(c);
         wave_sync();
     }
 }
@@ -715,15 +747,9 @@ __device__ __forceinline__ void occ_xy(const ImageCtx& c, const DevParams& p, do
     *xi = (int)clampll(trunc_ll(x), 0, c.occ_w - 1);
     *yi = (int)clampll(trunc_ll(y), 0, c.occ_h - 1);
 }
-__device__ __forceinline__ size_t occ_cell(const ImageCtx& c, const DevParams& p, int f, double x, double y) {
-    int xi, yi;
-    occ_xy(c, p, x, y, &xi, &yi);
-    return ((size_t)f * c.occ_h + yi) * c.occ_w + xi;
-}
 
-// occupancy.cpp:13-29: the half-open cell box [minx,maxx) x [miny,maxy) a joint occupies.  Used both to
-// fill the byte map and to test containment analytically (in-round resolve, keypoint NMS), so the two
-// can never disagree.
+// occupancy.cpp:13-29: the half-open cell box [minx,maxx) x [miny,maxy) a joint occupies.  Used to fill the
+// bitmap and to test containment analytically (commit, keypoint NMS), so the two can never disagree.
 struct __attribute__((aligned(16))) OccBox { int minx, miny, maxx, maxy; };
 __device__ __forceinline__ OccBox occ_box(const ImageCtx& c, const DevParams& p, double x, double y, double sigma) {
     if (p.occupancy_reduction != 1.0) {
@@ -741,32 +767,18 @@ __device__ __forceinline__ bool box_contains(const OccBox& b, int xi, int yi) {
     return xi >= b.minx && xi < b.maxx && yi >= b.miny && yi < b.maxy;
 }
 
-// the 64 lanes of one wave fill one box of the byte map
-__device__ __forceinline__ void occ_fill(const ImageCtx& c, int f, const OccBox& b) {
-    const int minx = b.minx, miny = b.miny, maxx = b.maxx, maxy = b.maxy;
-    const int bw = maxx - minx;
-    const int lane = lane_id();
-    unsigned char* plane = c.occ + (size_t)f * c.occ_h * c.occ_w;
-    if (bw <= 16) {                       // 4 rows x 16 columns per step
-        const int lx = lane & 15, ly = lane >> 4;
-        for (int yy = miny + ly; yy < maxy; yy += 4)
-            if (lx < bw) plane[(size_t)yy * c.occ_w + minx + lx] = 1;
-    } else if (bw <= 32) {                // 2 rows x 32 columns per step
-        const int lx = lane & 31, ly = lane >> 5;
-        for (int yy = miny + ly; yy < maxy; yy += 2)
-            if (lx < bw) plane[(size_t)yy * c.occ_w + minx + lx] = 1;
-    } else {
-        for (int yy = miny; yy < maxy; yy++)
-            for (int xx = minx + lane; xx < maxx; xx += kWave) plane[(size_t)yy * c.occ_w + xx] = 1;
-    }
+// Occupancy::get on the bitmap (one bit per cell, rows of occ_wpr 32-bit words)
+__device__ __forceinline__ bool occ_test(const ImageCtx& c, int f, int xi, int yi) {
+    const unsigned w = c.occ[((size_t)f * c.occ_h + yi) * c.occ_wpr + (xi >> 5)];
+    return (w >> (xi & 31)) & 1u;
 }
 
-// Private LDS block of one wave (pose boxes + pose + frontier); kept 16-byte sized.
+// Private LDS block of one growing wave (pose boxes + pose + frontier); kept 16-byte sized.
 __host__ __device__ inline size_t assoc_private_bytes(int K, int A) {
     const int P4 = 4 * A, E = 2 * A;
     const size_t b = 16 * (size_t)K + sizeof(double) * (K + P4) + sizeof(unsigned long long) * P4
                    + sizeof(float) * (3 * K + 3 * P4) + sizeof(int) * P4 + (E + 15) / 16 * 16;
-    return (b + 15) / 16 * 16 + sizeof(float) * 3 * kBlendChunks * kWave;      // + blend target columns
+    return (b + 15) / 16 * 16 + sizeof(float) * kBlendLdsFloats;               // + blend target columns and compaction
 }
 
 // LDS scratch of one wave during keypoint NMS (aliases the growth state): a box and a cell per pose
@@ -776,8 +788,8 @@ __host__ __device__ inline size_t nms_scratch_bytes(int max_ann) {
 
 struct PoseView { const OccBox* box; const double* v; const float *x, *y, *s; };
 
-__device__ __forceinline__ PoseView pose_of_wave(unsigned char* private_base, int wave, int K, int A) {
-    unsigned char* sp = private_base + (size_t)wave * assoc_private_bytes(K, A);
+__device__ __forceinline__ PoseView pose_of_block(unsigned char* private_base, int block, int K, int A) {
+    unsigned char* sp = private_base + (size_t)block * assoc_private_bytes(K, A);
     const int P4 = 4 * A;
     PoseView q;
     q.box = (const OccBox*)sp; sp += sizeof(OccBox) * K;
@@ -786,8 +798,7 @@ __device__ __forceinline__ PoseView pose_of_wave(unsigned char* private_base, in
     return q;
 }
 
-// occupancy boxes of the pose this wave just grew (empty box for an unfilled joint): used by the
-// in-round resolve and by mark_pose
+// occupancy boxes of the pose this wave just grew (empty box for an unfilled joint or one without a field)
 __device__ __forceinline__ void pose_boxes(ImageCtx& c, const DevParams& p) {
     for (int k = lane_id(); k < c.K; k += kWave) {
         OccBox b; b.minx = b.miny = b.maxx = b.maxy = 0;
@@ -796,44 +807,72 @@ __device__ __forceinline__ void pose_boxes(ImageCtx& c, const DevParams& p) {
     }
 }
 
-// mark every filled joint of a pose (cifcaf.cpp:225-229), boxes dealt to the waves
-__device__ __forceinline__ void mark_pose(const ImageCtx& c, const PoseView& q) {
-    int n = 0;
-    for (int f = 0; f < c.F; f++) {
-        if (q.v[f] == 0.0) continue;
-        if ((n++ % kAssocWaves) == c.wave) occ_fill(c, f, q.box[f]);
+// Occupancy::set for every filled joint of a pose (cifcaf.cpp:225-229), by the 64 lanes of ONE wave: four
+// boxes per step, 16 rows each, fire-and-forget atomics (nothing waits for them; the reader fences).
+__device__ __forceinline__ void occ_mark_pose(const ImageCtx& c, const PoseView& q) {
+    const int lane = lane_id(), sub = lane & 15, grp = lane >> 4;
+    for (int f0 = 0; f0 < c.F; f0 += 4) {
+        const int f = f0 + grp;
+        if (f >= c.F) continue;
+        const OccBox b = q.box[f];                    // empty for an unfilled joint
+        for (int yy = b.miny + sub; yy < b.maxy; yy += 16) {
+            unsigned* row = c.occ + ((size_t)f * c.occ_h + yy) * c.occ_wpr;
+            for (int w = b.minx >> 5; w <= (b.maxx - 1) >> 5; w++) {
+                const int lo = max(b.minx - w * 32, 0), hi = min(b.maxx - w * 32, 32);
+                const unsigned mask = (hi >= 32 ? 0xFFFFFFFFu : (1u << hi) - 1u) & ~((1u << lo) - 1u);
+                atomicOr(row + w, mask);
+            }
+        }
     }
 }
 
 // nms_keypoints.hpp:25-32 on an LDS pose
-__device__ __forceinline__ double pose_score(const PoseView& q, int K) {
+__device__ __forceinline__ double pose_score(const double* v, int K) {
     double acc = 0.0;
-    for (int k = 0; k < K; k++) { const float i = (float)acc; acc = (double)i + q.v[k]; }
+    for (int k = 0; k < K; k++) { const float i = (float)acc; acc = (double)i + v[k]; }
     return acc / (double)K;
 }
 
 // ------------------------------------------------------------------- kernel
-template <bool REG>
-__global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArgs a, DevSkeleton sk, DevParams p,
-                                                                        int n_growers, int nms_waves) {
+// One LDS task slot per wave: the coordinator hands a seed to grower g by filling task[g] and setting
+// state = ASSIGNED; the grower answers DONE (pose, boxes and score are in its private block / slot) or, if
+// `cancel` was raised while it grew, IDLE.  Only the coordinator moves a slot out of DONE.
+constexpr int kTaskIdle = 0, kTaskAssigned = 1, kTaskDone = 2;
+struct __attribute__((aligned(8))) TaskSlot { int state, cancel, seed, pk, f, pad; double score; };
+
+// statistics of one image, int32[kAssocStats] in the workspace ("assoc_stats"): see include/openpifpaf_amd.h
+constexpr int kAssocStats = 16;
+// The coordinator and the growers wait for each other in LDS polling loops.  A protocol error must not hang
+// the device: after this many 10-ns ticks inside one launch every wait gives up, the image reports no poses
+// and status -1 (never seen in the tests; one second is ~1000x the slowest image).
+constexpr long long kWatchdogTicks = 100000000ll;
+
+template <bool REG, int NW>
+__global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a, DevSkeleton sk, DevParams p,
+                                                                     int n_growers, int nms_waves) {
+    constexpr int kThreads = NW * kWave;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = a.K, A = a.A, E = 2 * A, P4 = 4 * A;
     const int KC = (K + kWave - 1) / kWave;          // 64-joint chunks per pose
-    const int S = n_growers;                         // speculative growers = waves with a private LDS block
+    const int S = n_growers;                         // growers = waves 1..S, each with a private LDS block
+    const long long t_kernel = wall_clock64();
 
     ImageCtx c;
     c.K = K; c.A = A; c.F = a.F; c.wave = wave;
     c.lists = a.lists + (size_t)b * A * 2 * 7 * a.list_cap;
     c.list_counts = a.list_counts + (size_t)b * A * 2;
     c.list_cap = a.list_cap;
-    c.occ = a.occ + (size_t)b * a.F * a.occ_h * a.occ_w; c.occ_h = a.occ_h; c.occ_w = a.occ_w;
+    c.occ_h = a.occ_h; c.occ_w = a.occ_w; c.occ_wpr = (a.occ_w + 31) >> 5;
+    c.occ = a.occ + (size_t)b * a.occ_image_words;
+    c.cancel = nullptr; c.aborted = 0; c.n_blend = 0;
 
     // ---- LDS carve: shared part, then one private block per growing wave
     unsigned char* sp = smem;
     double* nms_score = (double*)sp; sp += sizeof(double) * a.max_ann;
     unsigned long long* nms_supp = (unsigned long long*)sp; sp += sizeof(unsigned long long) * a.max_ann * KC;
+    TaskSlot* task = (TaskSlot*)sp; sp += sizeof(TaskSlot) * NW;
     c.sh_counts = (int*)sp; sp += sizeof(int) * E;
     int* l_off = (int*)sp; sp += sizeof(int) * (K + 1);
     int* l_other = (int*)sp; sp += sizeof(int) * E;
@@ -843,12 +882,12 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     if ((K + 1) & 1) sp += sizeof(int);             // keep 8-byte alignment for what follows
     int* nms_order = (int*)sp; sp += sizeof(int) * a.max_ann;
     int* nms_rank = (int*)sp; sp += sizeof(int) * a.max_ann;
+    int* sh_ctl = (int*)sp; sp += sizeof(int) * 8;   // 0 exit flag, 1 n_kept, 2 n_dropped, 3 grower ticks, 4 list scans, 5 watchdog
+    int* sh_stats = (int*)sp; sp += sizeof(int) * kAssocStats;
     sp = smem + (((size_t)(sp - smem) + 15) & ~(size_t)15);
-    unsigned char* work_base = sp;                   // growth phase: pool | private blocks; NMS phase: scratch
-    int* pool_save = (int*)sp + lane;                // the seed pool while poses grow (every wave holds and writes the same values)
-    sp += sizeof(int) * 2 * 8 * kWave;
+    unsigned char* work_base = sp;                   // growth phase: private blocks; NMS phase: scratch
     unsigned char* private_base = sp;
-    sp += (size_t)(wave < S ? wave : 0) * assoc_private_bytes(K, A);   // waves >= S never touch theirs
+    sp += (size_t)(wave >= 1 && wave <= S ? wave - 1 : 0) * assoc_private_bytes(K, A);   // other waves never touch theirs
     c.jbox = (OccBox*)sp; sp += sizeof(OccBox) * K;
     c.jv = (double*)sp; sp += sizeof(double) * K;
     c.e_v = (double*)sp; sp += sizeof(double) * P4;
@@ -863,20 +902,26 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     c.in_frontier = sp; sp += (E + 15) / 16 * 16;
     c.tgt = (float*)sp;
     c.heap_n = 0; c.n_entries = 0;
-    for (int k = 0; k < 12; k++) c.t[k] = 0;
-    OPA_T0(t_total);
-#ifdef OPA_ASSOC_TIMING
-    const long long cyc0 = clock64();
-#endif
 
+    // the image's occupancy bitmap starts empty (cifcaf.cpp:173); 16-byte stores, region is 256-B aligned
+    {
+        const int n16 = (a.F * a.occ_h * c.occ_wpr + 3) >> 2;
+        uint4* z = reinterpret_cast<uint4*>(c.occ);
+        for (int k = tid; k < n16; k += kThreads) z[k] = make_uint4(0u, 0u, 0u, 0u);
+    }
     // list lengths and the skeleton adjacency are consulted at every step of the search: keep them in LDS
-    for (int k = tid; k < E; k += kAssocThreads) {
+    for (int k = tid; k < E; k += kThreads) {
         c.sh_counts[k] = c.list_counts[k];
         l_other[k] = sk.adj_other[k]; l_bone[k] = sk.adj_bone[k]; l_fwd[k] = sk.adj_fwd[k]; l_first[k] = sk.adj_first[k];
     }
-    for (int k = tid; k <= K; k += kAssocThreads) l_off[k] = sk.adj_off[k];
+    for (int k = tid; k <= K; k += kThreads) l_off[k] = sk.adj_off[k];
+    if (tid < NW) {
+        TaskSlot t; t.state = kTaskIdle; t.cancel = 0; t.seed = -1; t.pk = 0; t.f = 0; t.pad = 0; t.score = 0.0;
+        task[tid] = t;
+    }
+    if (tid < 8) sh_ctl[tid] = 0;
     c.adj_off = l_off; c.adj_other = l_other; c.adj_bone = l_bone; c.adj_fwd = l_fwd; c.adj_first = l_first;
-    __syncthreads();
+    sync_global();                                   // bitmap zeros are in memory before anyone marks or tests
     RegSkeleton rs; rs.slot_info = 0; rs.slot_first = 0; rs.off = 0; rs.off1 = 0;
     if constexpr (REG) {                             // lane t: directed bone t; lane j: adjacency range of joint j
         if (lane < E) {
@@ -890,32 +935,29 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
 
     double* anns = a.anns + (size_t)b * a.max_ann * K * 4;
     int64_t* ann_ids = a.ann_ids + (size_t)b * a.max_ann;
-    int n_kept = 0, n_dropped = 0;
+    int n_kept = 0, n_dropped = 0;                   // coordinator's counters until the growth phase ends
     const bool prune = !p.force_complete;     // a pose scoring below the instance threshold before NMS cannot survive it
 
-    // Accept the pose grown by wave `g` (every wave executes this with the same arguments):
-    // mark its joints (boxes dealt to the waves) and, unless it cannot survive NMS, store it.
-    // Returns 0 = marked only (pruned), 1 = stored at slot n_kept, 2 = capacity overflow.
-    auto accept_pose = [&](int g, long long id, int slot) -> int {
-        const PoseView q = pose_of_wave(private_base, g, K, A);
-        mark_pose(c, q);
-        if (prune && pose_score(q, K) < p.nms_instance_threshold) return 0;
-        if (slot >= a.max_ann) return 2;
-        if (wave == g) {
-            double* dst = anns + (size_t)slot * K * 4;
-            for (int k = lane; k < K; k += kWave) {
-                dst[4 * k + 0] = q.v[k]; dst[4 * k + 1] = (double)q.x[k];
-                dst[4 * k + 2] = (double)q.y[k]; dst[4 * k + 3] = (double)q.s[k];
-            }
-            if (lane == 0) ann_ids[slot] = id;
+    // Coordinator: accept the pose in private block `blk`: mark its joints in the bitmap and, unless it
+    // cannot survive NMS, store it at slot n_kept.
+    auto accept_pose = [&](int blk, double score, long long id) {
+        const PoseView q = pose_of_block(private_base, blk, K, A);
+        occ_mark_pose(c, q);
+        if (prune && score < p.nms_instance_threshold) return;
+        if (n_kept >= a.max_ann) { n_dropped++; return; }
+        double* dst = anns + (size_t)n_kept * K * 4;
+        for (int k = lane; k < K; k += kWave) {
+            dst[4 * k + 0] = q.v[k]; dst[4 * k + 1] = (double)q.x[k];
+            dst[4 * k + 2] = (double)q.y[k]; dst[4 * k + 3] = (double)q.s[k];
         }
-        return 1;
+        if (lane == 0) ann_ids[n_kept] = id;
+        n_kept++;
     };
 
-    // ---- initial annotations (tracking API), cifcaf.cpp:177-202: S growths at a time
+    // ---- initial annotations (tracking API), cifcaf.cpp:177-202: S growths at a time, all of them accepted
     for (int n0 = 0; n0 < a.n_initial; n0 += S) {
-        const int n = n0 + wave;
-        if (wave < S && n < a.n_initial) {
+        const int n = n0 + wave - 1;
+        if (wave >= 1 && wave <= S && n < a.n_initial) {
             const float* src = a.initial + ((size_t)b * a.n_initial + n) * K * 4;
             for (int k = lane; k < K; k += kWave) {
                 c.jv[k] = (double)src[4 * k + 0]; c.jx[k] = src[4 * k + 1];
@@ -924,194 +966,305 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
             wave_sync();
             grow_pose<REG>(c, p, rs, true, 1.0, false);
             pose_boxes(c, p);
+            wave_sync();
+            const double sc = pose_score(c.jv, K);
+            if (lane == 0) task[wave].score = sc;
         }
         __syncthreads();
-        for (int g = 0; g < S && n0 + g < a.n_initial; g++) {
-            const int rc = accept_pose(g, a.initial_ids ? a.initial_ids[(size_t)b * a.n_initial + n0 + g] : -1, n_kept);
-            n_kept += rc == 1; n_dropped += rc == 2;
-        }
-        sync_global();
+        if (wave == 0)
+            for (int g = 0; g < S && n0 + g < a.n_initial; g++)
+                accept_pose(g, task[g + 1].score, a.initial_ids ? a.initial_ids[(size_t)b * a.n_initial + n0 + g] : -1);
+        __syncthreads();
     }
 
-    // ---- seeds in score order, cifcaf.cpp:206-231, in speculative rounds
-    // Every wave keeps the same pool of up to 512 LIVE, undecided seeds (8 slots per lane, any order) and
-    // runs candidate selection and the resolve walk redundantly on it: no barriers, no LDS exchange.
-    // Invariant: every seed below scan_pos is either in a slot or dead for good (inside a box of an
-    // accepted pose), so each seed is fetched and tested against the occupancy map exactly once.
+    // ---- seeds in score order, cifcaf.cpp:206-231
     int n_seeds = a.seed_count[b];
     if (n_seeds > a.seed_cap) n_seeds = a.seed_cap;
     const int32_t* seed_f = a.seed_f + (size_t)b * a.seed_cap;
     const float4* seed_vxys = reinterpret_cast<const float4*>(a.seed_vxys) + (size_t)b * a.seed_cap;
     const int32_t* seed_cell = a.seed_cell + (size_t)b * a.seed_cap;
-    constexpr int WR = 8;                            // slots per lane
-    constexpr int kIdxMask = 0xFFFFFF;
-    int s_pack[WR], s_if[WR];                        // cell x | cell y << 12 | box half-width << 24 ;  seed index | field << 24
-    unsigned occupied = 0u;                          // bit r: slot r holds a live undecided seed
-    int scan_pos = 0;
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+
+    if (wave == 0) {
+        int st[kAssocStats];
 #pragma unroll
-    for (int r = 0; r < WR; r++) { s_pack[r] = 0; s_if[r] = kIdxMask; }
-    for (;;) {
-        OPA_T0(tsel);
-        // 1. refill free slots with the next seeds that are still free in the occupancy map (:211 for
-        //    the poses of earlier rounds); slot (r, lane) takes the seed of its rank among the free slots.
-        //    Passes repeat only while the pool is less than half full.
-        while (scan_pos < n_seeds) {
-            int nidx[WR], base = 0;
+        for (int k = 0; k < kAssocStats; k++) st[k] = 0;
+        // ================================================================= coordinator
+        // The pool: up to 512 LIVE, undecided seeds, 8 slots per lane in any order.  Invariant: every seed
+        // below scan_pos is either in a slot or dead for good (inside a box of an accepted pose), so each
+        // seed is fetched and tested against the bitmap exactly once; afterwards it is tested against every
+        // newly accepted pose by box containment.
+        constexpr int WR = 8;                            // slots per lane
+        constexpr int kIdxMask = 0xFFFFFF;
+        constexpr unsigned kNone = 0xFFFFFFFFu;
+        int s_pack[WR], s_if[WR];                        // cell x | cell y << 12 | box half-width << 24 ;  seed index | field << 24
+        unsigned occupied = 0u;                          // bit r: slot r holds a live undecided seed
+        unsigned emitted = 0u;                           //        ... handed to a grower
+        unsigned shadow = 0u;                            //        ... inside the seed-joint box of an earlier in-flight candidate
+        unsigned ever = 0u;                              //        ... was shadowed at some time (statistics)
+        int scan_pos = 0;
+        bool bitmap_dirty = a.n_initial > 0, need_shadow = false, watchdog = false;
+        long long wait_ticks = 0;
+        const unsigned long long lanes_below = (1ull << lane) - 1ull;
+        const bool is_grower_lane = lane >= 1 && lane <= S;
 #pragma unroll
-            for (int r = 0; r < WR; r++) {
-                const bool fr = !((occupied >> r) & 1u);
-                const unsigned long long m = __ballot(fr);
-                nidx[r] = fr ? scan_pos + base + __popcll(m & lanes_below) : n_seeds;
-                base += __popcll(m);
-            }
-            if (base == 0) break;
-            int ff[WR], pk[WR]; unsigned char ob[WR];
-#pragma unroll
-            for (int r = 0; r < WR; r++) {
-                ff[r] = 0; pk[r] = 0;
-                if (nidx[r] < n_seeds) { ff[r] = seed_f[nidx[r]]; pk[r] = seed_cell[nidx[r]]; }
-            }
-#pragma unroll
-            for (int r = 0; r < WR; r++) {
-                ob[r] = 1;
-                if (nidx[r] < n_seeds)
-                    ob[r] = c.occ[((size_t)ff[r] * c.occ_h + ((pk[r] >> 12) & 0xfff)) * c.occ_w + (pk[r] & 0xfff)];
-            }
-#pragma unroll
-            for (int r = 0; r < WR; r++)
-                if (nidx[r] < n_seeds && ob[r] == 0) {
-                    s_pack[r] = pk[r]; s_if[r] = nidx[r] | (ff[r] << 24); occupied |= 1u << r;
-                }
-            scan_pos = scan_pos + base < n_seeds ? scan_pos + base : n_seeds;
+        for (int r = 0; r < WR; r++) { s_pack[r] = 0; s_if[r] = kIdxMask; }
+
+        // slot r lies in the box candidate (pk, fo, idx) will occupy with its own seed joint, and comes later
+        auto in_blob = [&](int r, int pk, int fo, int idx) -> bool {
+            const int ccx = pk & 0xfff, ccy = (pk >> 12) & 0xfff, half = (pk >> 24) & 0xff;
+            const int dx = (s_pack[r] & 0xfff) - ccx, dy = ((s_pack[r] >> 12) & 0xfff) - ccy;
+            return (int)((unsigned)s_if[r] >> 24) == fo && (s_if[r] & kIdxMask) > idx &&
+                   dx > -half && dx < half && dy > -half && dy < half;
+        };
+
+        for (;;) {
+            if (wall_clock64() - t_kernel > kWatchdogTicks) { watchdog = true; break; }
+            // ---- 1. refill free slots with the next seeds that are still free in the bitmap (:211 for the
+            //         poses accepted so far); slot (r, lane) takes the seed of its rank among the free slots
             int n_occ = 0;
 #pragma unroll
             for (int r = 0; r < WR; r++) n_occ += __popcll(__ballot((occupied >> r) & 1u));
-            if (2 * n_occ >= WR * kWave) break;
-        }
-        // 2. candidates in seed order: the first pooled seed, then the next ones that do not fall into the
-        //    box an earlier candidate's own seed joint will occupy (the other cells of the same confidence
-        //    blob: dead as soon as that candidate is accepted).  Skipping them is a PREDICTION that costs
-        //    nothing when right and is verified by the walk below.
-        unsigned elig = occupied;
-        int cand[kAssocWaves], n_cand = 0;
-#pragma unroll
-        for (int k = 0; k < kAssocWaves; k++) {
-            cand[k] = -1;
-            if (k >= S || n_cand < k) continue;
-            unsigned mn = 0xFFFFFFFFu;
-#pragma unroll
-            for (int r = 0; r < WR; r++)
-                if ((elig >> r) & 1u) mn = min(mn, (unsigned)(s_if[r] & kIdxMask));
-            mn = ~wave_max_u32(~mn);
-            if (mn == 0xFFFFFFFFu) continue;
-            int pk = 0, fo = 0; bool own = false;
-#pragma unroll
-            for (int r = 0; r < WR; r++)
-                if (((elig >> r) & 1u) && (unsigned)(s_if[r] & kIdxMask) == mn) {
-                    pk = s_pack[r]; fo = (int)((unsigned)s_if[r] >> 24); own = true; elig &= ~(1u << r);
+            if (scan_pos < n_seeds && 2 * n_occ < WR * kWave) {
+                if (bitmap_dirty) {                      // this wave's marks (atomics at L2) before its own reads
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    bitmap_dirty = false;
                 }
-            const int owner = __builtin_ctzll(__ballot(own));
-            pk = rlane(pk, owner); fo = rlane(fo, owner);
-            cand[k] = (int)mn; n_cand = k + 1;
-            const int ccx = pk & 0xfff, ccy = (pk >> 12) & 0xfff, half = (pk >> 24) & 0xff;
+                while (scan_pos < n_seeds) {
+                    int nidx[WR], base = 0;
 #pragma unroll
-            for (int r = 0; r < WR; r++) {
-                const int dx = (s_pack[r] & 0xfff) - ccx, dy = ((s_pack[r] >> 12) & 0xfff) - ccy;
-                if ((int)((unsigned)s_if[r] >> 24) == fo && dx > -half && dx < half && dy > -half && dy < half)
-                    elig &= ~(1u << r);
+                    for (int r = 0; r < WR; r++) {
+                        const bool fr = !((occupied >> r) & 1u);
+                        const unsigned long long m = __ballot(fr);
+                        nidx[r] = fr ? scan_pos + base + __popcll(m & lanes_below) : n_seeds;
+                        base += __popcll(m);
+                    }
+                    if (base == 0) break;
+                    int ff[WR], pk[WR]; unsigned ow[WR];
+#pragma unroll
+                    for (int r = 0; r < WR; r++) {
+                        ff[r] = 0; pk[r] = 0;
+                        if (nidx[r] < n_seeds) { ff[r] = seed_f[nidx[r]]; pk[r] = seed_cell[nidx[r]]; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < WR; r++) {
+                        ow[r] = 0xFFFFFFFFu;
+                        if (nidx[r] < n_seeds)
+                            ow[r] = c.occ[((size_t)ff[r] * c.occ_h + ((pk[r] >> 12) & 0xfff)) * c.occ_wpr + ((pk[r] & 0xfff) >> 5)];
+                    }
+#pragma unroll
+                    for (int r = 0; r < WR; r++)
+                        if (nidx[r] < n_seeds && !((ow[r] >> (pk[r] & 31)) & 1u)) {
+                            s_pack[r] = pk[r]; s_if[r] = nidx[r] | (ff[r] << 24);
+                            occupied |= 1u << r; emitted &= ~(1u << r); shadow &= ~(1u << r); ever &= ~(1u << r);
+                        }
+                    scan_pos = scan_pos + base < n_seeds ? scan_pos + base : n_seeds;
+                    n_occ = 0;
+#pragma unroll
+                    for (int r = 0; r < WR; r++) n_occ += __popcll(__ballot((occupied >> r) & 1u));
+                    if (2 * n_occ >= WR * kWave) break;
+                }
+                st[6]++;
+                need_shadow = true;                      // new seeds against the candidates in flight
             }
+
+            // ---- 2. the growers' states (lane g looks at grower g)
+            int g_state = is_grower_lane ? flag_load(&task[lane].state) : -1;
+            {   // a growth that finished after its seed died: drop the result
+                const bool rel = g_state == kTaskDone && flag_peek(&task[lane].cancel) != 0;
+                if (rel) { flag_store(&task[lane].state, kTaskIdle); g_state = kTaskIdle; }
+            }
+            if (need_shadow) {                           // which pooled seeds do the candidates in flight shadow?
+                shadow = 0u;
+                unsigned long long busy = __ballot(g_state == kTaskAssigned || g_state == kTaskDone);
+                while (busy) {
+                    const int g = __builtin_ctzll(busy);
+                    busy &= busy - 1;
+                    if (flag_peek(&task[g].cancel)) continue;
+                    const int pk = task[g].pk, fo = task[g].f, idx = task[g].seed;
+#pragma unroll
+                    for (int r = 0; r < WR; r++)
+                        if (((occupied & ~emitted) >> r) & 1u && in_blob(r, pk, fo, idx)) shadow |= 1u << r;
+                }
+                ever |= shadow;
+                need_shadow = false;
+            }
+
+            // ---- 3. hand the next candidates, in seed order, to the idle growers
+            unsigned long long idle = __ballot(g_state == kTaskIdle);
+            while (idle) {
+                const unsigned elig = occupied & ~emitted & ~shadow;
+                unsigned mn = kNone;
+#pragma unroll
+                for (int r = 0; r < WR; r++)
+                    if ((elig >> r) & 1u) mn = min(mn, (unsigned)(s_if[r] & kIdxMask));
+                mn = ~wave_max_u32(~mn);
+                if (mn == kNone) break;
+                int pk = 0, fo = 0; bool own = false, was_shadowed = false;
+#pragma unroll
+                for (int r = 0; r < WR; r++)
+                    if (((elig >> r) & 1u) && (unsigned)(s_if[r] & kIdxMask) == mn) {
+                        pk = s_pack[r]; fo = (int)((unsigned)s_if[r] >> 24); own = true;
+                        was_shadowed = (ever >> r) & 1u; emitted |= 1u << r;
+                    }
+                const int owner = __builtin_ctzll(__ballot(own));
+                pk = rlane(pk, owner); fo = rlane(fo, owner);
+                const int g = __builtin_ctzll(idle);
+                idle &= idle - 1;
+                if (lane == 0) {
+                    task[g].seed = (int)mn; task[g].pk = pk; task[g].f = fo;
+                    flag_store(&task[g].cancel, 0);
+                    flag_store(&task[g].state, kTaskAssigned);
+                }
+#pragma unroll
+                for (int r = 0; r < WR; r++)
+                    if (((occupied & ~emitted) >> r) & 1u && in_blob(r, pk, fo, (int)mn)) { shadow |= 1u << r; ever |= 1u << r; }
+                st[0]++;
+                st[5] += __ballot(was_shadowed) != 0ull ? 1 : 0;
+            }
+
+            // ---- 4. the head: the smallest-index live seed; everything before it is decided
+            unsigned hd = kNone;
+#pragma unroll
+            for (int r = 0; r < WR; r++)
+                if ((occupied >> r) & 1u) hd = min(hd, (unsigned)(s_if[r] & kIdxMask));
+            hd = ~wave_max_u32(~hd);
+            if (hd == kNone) {
+                if (scan_pos >= n_seeds) break;          // no live seed in the pool, none left to scan
+                continue;                                // pool ran empty: refill
+            }
+            bool head_emitted = false;
+#pragma unroll
+            for (int r = 0; r < WR; r++)
+                head_emitted |= ((occupied & emitted) >> r) & 1u && (unsigned)(s_if[r] & kIdxMask) == hd;
+            if (__ballot(head_emitted) == 0ull) {
+                // A head that was never handed out (a wrong prediction, or no grower was free): it is never
+                // shadowed -- a candidate shadowing it would be the head -- so step 3 takes it as soon as a
+                // grower is idle.  If every grower holds or grows a LATER seed, the latest of them is given up.
+                g_state = is_grower_lane ? flag_load(&task[lane].state) : -1;
+                if (__ballot(g_state == kTaskIdle) != 0ull) continue;
+                if (__ballot(g_state >= 0 && flag_peek(&task[lane].cancel) != 0) != 0ull) {   // one is about to be idle
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                const unsigned key = g_state >= 0 ? ((unsigned)task[lane].seed << 6) | (unsigned)lane : 0u;
+                const int victim = (int)(wave_max_u32(key) & 63u);
+                const int vseed = task[victim].seed;
+                if (lane == 0) flag_store(&task[victim].cancel, 1);
+                while (flag_load(&task[victim].state) == kTaskAssigned && wall_clock64() - t_kernel <= kWatchdogTicks)
+                    __builtin_amdgcn_s_sleep(2);
+                if (lane == 0) flag_store(&task[victim].state, kTaskIdle);
+#pragma unroll
+                for (int r = 0; r < WR; r++)
+                    if ((occupied >> r) & 1u && (s_if[r] & kIdxMask) == vseed) emitted &= ~(1u << r);
+                st[4]++;
+                need_shadow = true;
+                continue;
+            }
+            int hg = 0;                                  // the grower that has the head
+            {
+                const bool mine = is_grower_lane && g_state != kTaskIdle && task[lane].seed == (int)hd &&
+                                  flag_peek(&task[lane].cancel) == 0;
+                const unsigned long long m = __ballot(mine);
+                if (m == 0ull) continue;                 // (its state was read before step 3 handed it out)
+                hg = __builtin_ctzll(m);
+            }
+            if (flag_load(&task[hg].state) != kTaskDone) {
+                const long long t0 = wall_clock64();
+                __builtin_amdgcn_s_sleep(4);
+                wait_ticks += wall_clock64() - t0;
+                continue;
+            }
+
+            // ---- 5. commit: the head's pose is accepted (:213-230)
+            const PoseView q = pose_of_block(private_base, hg - 1, K, A);
+            unsigned dead = 0u;                          // pooled seeds inside one of its joint boxes (:211 for them)
+#pragma unroll
+            for (int r = 0; r < WR; r++)
+                if ((occupied >> r) & 1u &&
+                    (box_contains(q.box[(unsigned)s_if[r] >> 24], s_pack[r] & 0xfff, (s_pack[r] >> 12) & 0xfff) ||
+                     (unsigned)(s_if[r] & kIdxMask) == hd))
+                    dead |= 1u << r;
+#pragma unroll
+            for (int r = 0; r < WR; r++)
+                if ((dead >> r) & 1u) { occupied &= ~(1u << r); s_if[r] |= kIdxMask; }
+            {   // growths of seeds that just died: drop finished ones, stop running ones
+                g_state = is_grower_lane ? flag_load(&task[lane].state) : -1;
+                bool hit = false;
+                if (is_grower_lane && lane != hg && g_state != kTaskIdle && flag_peek(&task[lane].cancel) == 0) {
+                    const int pk = task[lane].pk;
+                    hit = box_contains(q.box[task[lane].f], pk & 0xfff, (pk >> 12) & 0xfff);
+                }
+                if (hit) {
+                    if (g_state == kTaskDone) flag_store(&task[lane].state, kTaskIdle);
+                    else flag_store(&task[lane].cancel, 1);
+                }
+                st[3] += __popcll(__ballot(hit && g_state == kTaskDone));
+                st[2] += __popcll(__ballot(hit && g_state != kTaskDone));
+            }
+            accept_pose(hg - 1, task[hg].score, -1);
+            bitmap_dirty = true;
+            st[1]++;
+            wave_sync();                                 // every lane has read block hg-1
+            if (lane == 0) flag_store(&task[hg].state, kTaskIdle);
+            need_shadow = true;
         }
-        if (n_cand == 0) break;                      // pool empty and no seeds left
-        OPA_TINC(c.t[9], 1);
-        OPA_TACC(c.t[10], tsel);
-        // 3. speculative growth, one pose per wave, no barriers inside (the pool waits in LDS meanwhile)
+        if (lane == 0) {
+            sh_ctl[1] = watchdog ? 0 : n_kept; sh_ctl[2] = n_dropped; sh_ctl[5] = watchdog ? 1 : 0;
+            flag_store(&sh_ctl[0], 1);                   // growers leave
+        }
+        st[7] = n_seeds;
+        st[8] = (int)(wall_clock64() - t_kernel);
+        st[12] = (int)wait_ticks;
+        if (lane == 0)
 #pragma unroll
-        for (int r = 0; r < WR; r++) { pool_save[r * kWave] = s_pack[r]; pool_save[(WR + r) * kWave] = s_if[r]; }
-        if (wave < n_cand) {
-            int mine = 0;
-#pragma unroll
-            for (int k = 0; k < kAssocWaves; k++) if (k == wave) mine = cand[k];
+            for (int k = 0; k < kAssocStats; k++) sh_stats[k] = st[k];
+    } else if (wave <= S) {
+        // ================================================================= grower
+        TaskSlot* my = &task[wave];
+        c.cancel = &my->cancel;
+        long long busy_ticks = 0;
+        for (;;) {
+            bool leave = false;
+            for (;;) {
+                if (flag_load(&my->state) == kTaskAssigned) break;
+                if (flag_load(&sh_ctl[0]) || wall_clock64() - t_kernel > 2 * kWatchdogTicks) { leave = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (leave) break;
+            const long long t0 = wall_clock64();
+            const int mine = __builtin_amdgcn_readfirstlane(my->seed);
             const int sf = seed_f[mine]; const float4 sd = seed_vxys[mine];
             for (int k = lane; k < K; k += kWave) { c.jv[k] = 0.0; c.jx[k] = 0.f; c.jy[k] = 0.f; c.js[k] = 0.f; }
             wave_sync();
             c.jv[sf] = (double)sd.x; c.jx[sf] = sd.y; c.jy[sf] = sd.z; c.js[sf] = sd.w;   // :213-218
             wave_sync();
-            OPA_T0(tg); grow_pose<REG>(c, p, rs, true, 1.0, false); OPA_TACC(c.t[4], tg);
-            pose_boxes(c, p);
+            c.aborted = 0;
+            grow_pose<REG>(c, p, rs, true, 1.0, false);
+            if (c.aborted) {
+                if (lane == 0) flag_store(&my->state, kTaskIdle);
+            } else {
+                pose_boxes(c, p);
+                wave_sync();
+                const double sc = pose_score(c.jv, K);
+                if (lane == 0) { my->score = sc; flag_store(&my->state, kTaskDone); }
+            }
+            busy_ticks += wall_clock64() - t0;
         }
-        OPA_T0(twait);
-        __syncthreads();
-        OPA_TACC(c.t[11], twait);
-#pragma unroll
-        for (int r = 0; r < WR; r++) { s_pack[r] = pool_save[r * kWave]; s_if[r] = pool_save[(WR + r) * kWave]; }
-        // 4. resolve walk in seed order.  `unc` = pooled and not inside a box of a pose accepted in this
-        //    round, i.e. what the sequential loop would find free at that seed's turn (:211).  A candidate
-        //    that is still free is accepted; a free seed that is NOT a candidate (a wrong prediction) ends
-        //    the round there and stays pooled -- it is the first candidate of the next round.
-        OPA_T0(tm);
-        unsigned unc = occupied, acc_mask = 0u;
-        int prev = -1, boundary = -1;
-        auto first_free_between = [&](int lo, int hi) -> int {     // smallest pooled free seed index in (lo, hi), or -1
-            unsigned mn = 0xFFFFFFFFu;
-#pragma unroll
-            for (int r = 0; r < WR; r++) {
-                const int idx = s_if[r] & kIdxMask;
-                if (((unc >> r) & 1u) && idx > lo && idx < hi) mn = min(mn, (unsigned)idx);
-            }
-            if (__ballot(mn != 0xFFFFFFFFu) == 0ull) return -1;
-            return (int)~wave_max_u32(~mn);
-        };
-#pragma unroll
-        for (int k = 0; k < kAssocWaves; k++) {
-            if (k >= n_cand || boundary >= 0) continue;
-            const int ck = cand[k];
-            boundary = first_free_between(prev, ck);
-            if (boundary >= 0) continue;
-            bool mine_free = false;
-#pragma unroll
-            for (int r = 0; r < WR; r++) mine_free |= ((unc >> r) & 1u) && (s_if[r] & kIdxMask) == ck;
-            if (__ballot(mine_free) != 0ull) {
-                acc_mask |= 1u << k;
-                const PoseView q = pose_of_wave(private_base, k, K, A);
-#pragma unroll
-                for (int r = 0; r < WR; r++)
-                    if (((unc >> r) & 1u) &&
-                        box_contains(q.box[(unsigned)s_if[r] >> 24], s_pack[r] & 0xfff, (s_pack[r] >> 12) & 0xfff))
-                        unc &= ~(1u << r);
-            }
-            prev = ck;
-        }
-        OPA_TINC(c.t[9], ((long long)n_cand << 32) + ((long long)__popc(acc_mask) << 48) + (boundary >= 0 ? (1 << 16) : 0));
-        if (boundary < 0) {
-            if (n_cand == S) boundary = prev + 1;                    // pooled seeds behind the last candidate are undecided
-            else {                                                   // every pooled seed was a candidate or predicted dead
-                boundary = first_free_between(prev, kIdxMask);
-                if (boundary < 0) boundary = kIdxMask;
-            }
-        }
-        // decided seeds (before the boundary) and seeds that are dead now leave the pool
-#pragma unroll
-        for (int r = 0; r < WR; r++)
-            if ((s_if[r] & kIdxMask) < boundary || !((unc >> r) & 1u)) { occupied &= ~(1u << r); s_if[r] |= kIdxMask; }
-        for (int g = 0; g < n_cand; g++)
-            if ((acc_mask >> g) & 1u) {
-                const int rc = accept_pose(g, -1, n_kept);
-                n_kept += rc == 1; n_dropped += rc == 2;
-            }
-        sync_global();                        // marks and stored poses visible to every wave
-        OPA_TACC(c.t[5], tm);
+        c.cancel = nullptr;
+        if (lane == 0) { atomicAdd(&sh_ctl[3], (int)busy_ticks); atomicAdd(&sh_ctl[4], c.n_blend); }
     }
-    __syncthreads();
+    sync_global();                        // stored poses visible to every wave; the private blocks are free
+    n_kept = sh_ctl[1]; n_dropped = sh_ctl[2];
 
-    // ---- force complete, cifcaf.cpp:233-236,414-449: poses are independent, one per wave
+    // ---- force complete, cifcaf.cpp:233-236,414-449: poses are independent, one per grower
     if (p.force_complete) {
         c.lists = a.lists_fc + (size_t)b * A * 2 * 7 * a.list_cap;
         c.list_counts = a.list_counts_fc + (size_t)b * A * 2;
-        for (int k = tid; k < E; k += kAssocThreads) c.sh_counts[k] = c.list_counts[k];
+        for (int k = tid; k < E; k += kThreads) c.sh_counts[k] = c.list_counts[k];
         __syncthreads();
-        if (wave < S) {
-            for (int n = wave; n < n_kept; n += S) {
+        if (wave >= 1 && wave <= S) {
+            for (int n = wave - 1; n < n_kept; n += S) {
                 double* src = anns + (size_t)n * K * 4;
                 for (int k = lane; k < K; k += kWave) {
                     c.jv[k] = src[4 * k + 0]; c.jx[k] = (float)src[4 * k + 1];
@@ -1129,15 +1282,15 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     }
 
     // ---- keypoint NMS, nms_keypoints.cpp:17-70
-    OPA_T0(t_nms);
-    for (int n = tid; n < n_kept; n += kAssocThreads) {  // UniformScore of every stored pose
+    const long long t_nms = wall_clock64();
+    for (int n = tid; n < n_kept; n += kThreads) {       // UniformScore of every stored pose
         const double* src = anns + (size_t)n * K * 4;
         double acc = 0.0;
         for (int k = 0; k < K; k++) { const float i = (float)acc; acc = (double)i + src[4 * k]; }
         nms_score[n] = acc / (double)K;
     }
     __syncthreads();
-    for (int n = tid; n < n_kept; n += kAssocThreads) {  // rank by score desc (ties: creation order)
+    for (int n = tid; n < n_kept; n += kThreads) {       // rank by score desc (ties: creation order)
         const double sn = nms_score[n];
         int rank = 0;
         for (int m = 0; m < n_kept; m++) { const double sm = nms_score[m]; rank += (sm > sn || (sm == sn && m < n)) ? 1 : 0; }
@@ -1146,7 +1299,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     }
     __syncthreads();
     // Occupancy pass (:27-43) without a map: joints of different fields never interact, so wave w takes
-    // fields w, w+8, ...; per field the poses are visited in score order and pose r's joint is suppressed
+    // fields w, w+nms_waves, ...; per field the poses are visited in score order and pose r's joint is suppressed
     // iff its cell lies in the box of an earlier, still unsuppressed joint (= Occupancy::get after the
     // earlier Occupancy::set calls).  Boxes and cells of the field sit in this wave's LDS scratch.
     {
@@ -1185,7 +1338,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     }
     __syncthreads();
     // suppression, keypoint threshold, instance threshold (:50,58-66); one thread per pose
-    for (int r = tid; r < n_kept; r += kAssocThreads) {
+    for (int r = tid; r < n_kept; r += kThreads) {
         double* pose = anns + (size_t)nms_order[r] * K * 4;
         double acc = 0.0;
         for (int k = 0; k < K; k++) {
@@ -1198,7 +1351,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
         nms_score[r] = acc / (double)K;                  // indexed by sorted position r now
     }
     sync_global();                                       // the rewritten confidences are read by other threads below
-    for (int r = tid; r < n_kept; r += kAssocThreads) {  // final order (:69); ties keep the previous order
+    for (int r = tid; r < n_kept; r += kThreads) {       // final order (:69); ties keep the previous order
         const double sr = nms_score[r];
         int rank = -1;
         if (!(sr < p.nms_instance_threshold)) {
@@ -1216,7 +1369,7 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
     int64_t* out_ids = a.out_ids + (size_t)b * a.max_ann;
     int n_out = 0;
     for (int r = 0; r < n_kept; r++) n_out += nms_rank[r] >= 0 ? 1 : 0;
-    for (int idx = tid; idx < n_kept * K; idx += kAssocThreads) {     // cifcaf.cpp:250-258
+    for (int idx = tid; idx < n_kept * K; idx += kThreads) {          // cifcaf.cpp:250-258
         const int r = idx / K, k = idx - r * K;
         const int dst = nms_rank[r];
         if (dst < 0) continue;
@@ -1229,50 +1382,72 @@ __global__ __launch_bounds__(kAssocThreads, 1) void cifcaf_assoc_kernel(AssocArg
         if (k == 0) out_ids[dst] = ann_ids[src_n];
     }
     if (tid == 0) {
-        a.out_count[b] = n_dropped > 0 ? a.max_ann + n_dropped : n_out;
-        a.status[b] = n_dropped;
+        // rows [0, n_out) are valid; poses dropped for lack of capacity raise the overflow flag
+        a.out_count[b] = n_out | (n_dropped > 0 ? OPA_COUNT_OVERFLOW : 0);
+        a.status[b] = sh_ctl[5] ? -1 : n_dropped;
     }
-#ifdef OPA_ASSOC_TIMING
-    __syncthreads();
-    OPA_TACC(c.t[6], t_nms); OPA_TACC(c.t[7], t_total);
-    c.t[3] = c.t[7] - c.t[4] - c.t[5] - c.t[6];           // seed scanning + waiting for the slowest grower
-    c.t[8] = clock64() - cyc0;
-    if (tid == 0) for (int k = 0; k < 12; k++) reinterpret_cast<long long*>(anns)[k] = c.t[k];   // scratch is free now
-#endif
+    if (tid == 0 && a.stats) {
+        sh_stats[9] = (int)(wall_clock64() - t_kernel);
+        sh_stats[10] = sh_ctl[3]; sh_stats[11] = sh_ctl[4];
+        sh_stats[13] = S; sh_stats[14] = n_kept; sh_stats[15] = (int)(wall_clock64() - t_nms);
+        for (int k = 0; k < kAssocStats; k++) a.stats[(size_t)b * kAssocStats + k] = sh_stats[k];
+    }
 }
 
-hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
+template <bool REG, int NW>
+static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
     const int K = a.K, A = a.A, E = 2 * A;
     const int KC = (K + kWave - 1) / kWave;
-    // the seed pool packs cell coordinates into 12 bits, the field into 8 and the seed index into 24
-    if (a.occ_w > 4096 || a.occ_h > 4096 || a.F > 256 || a.seed_cap > 0xFFFFFF) return hipErrorInvalidValue;
     const size_t shared = sizeof(double) * a.max_ann
                         + sizeof(unsigned long long) * ((size_t)a.max_ann * KC)
-                        + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann) + 32;
-    // work area behind it: the seed pool + one private block per grower while poses grow, the
-    // keypoint-NMS scratch afterwards
-    const size_t fixed = sizeof(int) * 2 * 8 * kWave;
+                        + sizeof(TaskSlot) * NW
+                        + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann + 8 + kAssocStats) + 32;
+    // work area behind it: one private block per grower while poses grow, the keypoint-NMS scratch afterwards
     const size_t priv = assoc_private_bytes(K, A);
     const size_t budget = 160 * 1024;
-    if (shared + fixed + priv > budget) return hipErrorInvalidValue;
-    int growers = (int)((budget - shared - fixed) / priv);
-    if (growers > kAssocWaves) growers = kAssocWaves;
-    int nms_waves = kAssocWaves;                     // large annotation capacities: fewer waves share the NMS pass
+    if (shared + priv > budget) return hipErrorInvalidValue;
+    int growers = (int)((budget - shared) / priv);
+    if (growers > NW - 1) growers = NW - 1;
+    if (const char* e = getenv("OPA_ASSOC_GROWERS")) {   // tests: other interleavings of the same result
+        const int v = atoi(e);
+        if (v >= 1 && v < growers) growers = v;
+    }
+    int nms_waves = NW;                              // large annotation capacities: fewer waves share the NMS pass
     while (nms_waves > 1 && shared + (size_t)nms_waves * nms_scratch_bytes(a.max_ann) > budget) nms_waves--;
     const size_t nms = (size_t)nms_waves * nms_scratch_bytes(a.max_ann);
     if (shared + nms > budget) return hipErrorInvalidValue;
-    const size_t grow_bytes = fixed + (size_t)growers * priv;
+    const size_t grow_bytes = (size_t)growers * priv;
     const size_t lds = shared + (grow_bytes > nms ? grow_bytes : nms);
-    const bool reg = K <= kWave && E <= kWave;       // pose, frontier and heap fit the lanes of a wave
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reg ? (const void*)cifcaf_assoc_kernel<true> : (const void*)cifcaf_assoc_kernel<false>,
+        hipError_t e = hipFuncSetAttribute((const void*)cifcaf_assoc_kernel<REG, NW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    if (reg) cifcaf_assoc_kernel<true><<<a.B, kAssocThreads, lds, st>>>(a, sk, p, growers, nms_waves);
-    else cifcaf_assoc_kernel<false><<<a.B, kAssocThreads, lds, st>>>(a, sk, p, growers, nms_waves);
-    prof_mark(st, "cifcaf_assoc_kernel");
+    cifcaf_assoc_kernel<REG, NW><<<a.B, NW * kWave, lds, st>>>(a, sk, p, growers, nms_waves);
     return hipGetLastError();
+}
+
+// waves per workgroup of the association kernel: 1 coordinator + up to NW-1 growers
+static int assoc_waves() {
+    const char* e = getenv("OPA_ASSOC_WAVES");
+    const int v = e ? atoi(e) : 0;
+    return v == 8 || v == 12 || v == 16 ? v : kAssocWavesDefault;
+}
+
+hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
+    const int K = a.K, E = 2 * a.A;
+    // the seed pool packs cell coordinates into 12 bits, the field into 8 and the seed index into 24
+    if (a.occ_w > 4096 || a.occ_h > 4096 || a.F > 256 || a.seed_cap > 0xFFFFFF) return hipErrorInvalidValue;
+    const bool reg = K <= kWave && E <= kWave;       // pose, frontier and heap fit the lanes of a wave
+    hipError_t e;
+    if (!reg) e = launch_assoc_nw<false, 8>(a, sk, p, st);   // LDS-resident growth state: 160 KB hold ~5 growers
+    else switch (assoc_waves()) {
+        case 8: e = launch_assoc_nw<true, 8>(a, sk, p, st); break;
+        case 12: e = launch_assoc_nw<true, 12>(a, sk, p, st); break;
+        default: e = launch_assoc_nw<true, 16>(a, sk, p, st); break;
+    }
+    prof_mark(st, "cifcaf_assoc_kernel");
+    return e;
 }
 
 // ------------------------------------------- exported grow_connection_blend op
@@ -1283,7 +1458,7 @@ __global__ __launch_bounds__(64) void blend_rows_kernel(const float* rows, int n
     for (int i = lane; i < n; i += kWave)
         for (int k = 0; k < 7; k++) soa[(size_t)k * n + i] = rows[(size_t)i * 7 + k];
     __threadfence_block();
-    __shared__ float tgt[3 * kBlendChunks * kWave];
+    __shared__ float tgt[kBlendLdsFloats];
     ListView L; L.base = soa; L.cap = n; L.n = n;
     const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, s, filter_sigmas, only_max, tgt);
     if (lane == 0) {

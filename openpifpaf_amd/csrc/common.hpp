@@ -28,8 +28,9 @@ struct Layout {
     // byte offsets into the workspace (all 256-B aligned)
     size_t off_hdr, off_tile_clean, off_cifhr, off_act, off_act_count, off_seed_keys, off_seed_count,
            off_seed_f, off_seed_vxys, off_seed_cell, off_lists, off_list_counts,
-           off_lists_fc, off_list_counts_fc, off_occ, off_anns, off_ann_meta, off_status,
+           off_lists_fc, off_list_counts_fc, off_occ, off_anns, off_ann_meta, off_status, off_stats,
            total;
+    size_t occ_image_words;               // 32-bit words of one image's occupancy bitmap (capacity)
 };
 
 bool make_layout(const opa_shape& s, Layout* L, const char** why);
@@ -97,7 +98,9 @@ struct AssocArgs {
     const int32_t* seed_cell;  // occupancy cell of the seed: x | y << 12 | box half-width << 24 (seed_cell_pack)
     const float* lists; const int32_t* list_counts;          // caf_th lists
     const float* lists_fc; const int32_t* list_counts_fc;    // force-complete lists (or null)
-    unsigned char* occ;
+    unsigned* occ;           // occupancy bitmap [B][occ_image_words]: per image [F][occ_h][(occ_w+31)/32] words, zeroed by the kernel
+    size_t occ_image_words;
+    int32_t* stats;          // [B, 16] statistics of the association (or null), see include/openpifpaf_amd.h
     double* anns;            // [B, max_ann, K, 4] doubles (v,x,y,s) scratch
     int64_t* ann_ids;        // [B, max_ann]
     const float* initial; const int64_t* initial_ids;

@@ -89,8 +89,10 @@ struct CifCaf : torch::CustomClassHolder {
         s.n_keypoints = (int32_t)n_keypoints;        // > n_cif in the tracking setup
         const size_t need = opa_cifcaf_workspace_bytes(&s);
         TORCH_CHECK(need > 0, "opa_cifcaf_workspace_bytes: ", opa_last_error());
-        if (!workspace.defined() || (size_t)workspace.numel() < need || workspace.device() != cif.device())
+        if (!workspace.defined() || (size_t)workspace.numel() < need || workspace.device() != cif.device()) {
             workspace = torch::empty({(int64_t)need}, torch::dtype(torch::kUInt8).device(cif.device()));
+            workspace.narrow(0, 0, 256).zero_();     // recycled allocator memory: the lazy-clear header starts invalid
+        }
         auto opts = torch::TensorOptions().device(cif.device());
         torch::Tensor out = torch::empty({s.batch, max_annotations, n_keypoints, 4}, opts.dtype(torch::kFloat32));
         torch::Tensor ids = torch::empty({s.batch, max_annotations}, opts.dtype(torch::kInt64));
@@ -127,9 +129,10 @@ struct CifCaf : torch::CustomClassHolder {
         if (initial.has_value()) ia = initial->unsqueeze(0);
         if (initial_ids.has_value()) ii = initial_ids->unsqueeze(0);
         auto [out, ids, counts] = call_batch_impl(cif.unsqueeze(0), cif_stride, caf.unsqueeze(0), caf_stride, ia, ii);
-        const int64_t n = counts.cpu().item<int32_t>();
-        TORCH_CHECK(n <= max_annotations, "annotation capacity overflow: ", n - max_annotations,
-                    " dropped; call set_max_annotations with a larger value");
+        const int64_t c = counts.cpu().item<int32_t>();
+        TORCH_CHECK(!(c & OPA_COUNT_OVERFLOW), "annotation capacity overflow: poses were dropped; call "
+                    "set_max_annotations with a larger value");
+        const int64_t n = OPA_COUNT_ROWS(c);
         torch::Tensor o = out[0].narrow(0, 0, n).clone(), i = ids[0].narrow(0, 0, n).clone();
         if (!cif.is_cuda()) { o = o.cpu(); i = i.cpu(); }
         return std::make_tuple(o, i);

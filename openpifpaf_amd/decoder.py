@@ -241,11 +241,9 @@ class CifCaf(Decoder):
         out, ids, counts = out.cpu().numpy(), ids.cpu().numpy(), counts.cpu().numpy()   # one small D2H
         result = []
         for b in range(len(counts)):
-            n = int(counts[b])
-            if n > self.cpp_decoder.max_annotations:
-                LOG.warning('image %d: %d annotations dropped (raise --cifcaf-max-annotations)',
-                            b, n - self.cpp_decoder.max_annotations)
-                n = self.cpp_decoder.max_annotations
+            n = int(counts[b]) & native.COUNT_ROWS_MASK           # valid rows
+            if int(counts[b]) & native.COUNT_OVERFLOW:
+                LOG.warning('image %d: annotations dropped for lack of capacity (raise --cifcaf-max-annotations)', b)
             result.append(self._annotations_py(out[b, :n], ids[b, :n]))
         self.last_decoder_time = time.perf_counter() - start_decoder
         LOG.debug('time: nn = %.1fms, dec = %.1fms', self.last_nn_time * 1e3, self.last_decoder_time * 1e3)

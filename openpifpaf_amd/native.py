@@ -25,6 +25,18 @@ import torch
 from . import _lib
 
 DEFAULT_MAX_ANNOTATIONS = 128
+COUNT_OVERFLOW = 0x40000000          # OPA_COUNT_OVERFLOW (include/openpifpaf_amd.h)
+COUNT_ROWS_MASK = 0x3FFFFFFF         # OPA_COUNT_ROWS
+
+
+def count_rows(counts):
+    """``counts`` as returned by ``call_batch`` (tensor, numpy array or int) -> number of valid rows."""
+    return counts & COUNT_ROWS_MASK
+
+
+def count_overflowed(counts):
+    """-> truthy where poses were dropped for lack of annotation capacity."""
+    return (counts & COUNT_OVERFLOW) != 0
 
 
 def set_quiet(quiet=True):
@@ -87,6 +99,7 @@ class CifCaf:
         self._handle = ctypes.c_void_p()
         self._workspaces = {}
         self._last = None
+        self._pinned = False                 # a captured graph holds raw pointers into the workspace
         _device()
         _lib.check(_lib.lib().opa_cifcaf_create(
             ctypes.byref(self._handle), self.n_keypoints,
@@ -126,8 +139,15 @@ class CifCaf:
             nbytes = _lib.lib().opa_cifcaf_workspace_bytes(ctypes.byref(shape))
             if nbytes == 0:
                 raise _lib.NativeError(_lib.lib().opa_last_error().decode())
+            if self._pinned:
+                raise _lib.NativeError('this decoder has a captured HIP graph that replays into its workspace: '
+                                       'use another CifCaf instance for a different shape')
             self._workspaces.clear()        # one live workspace per decoder
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            # The block comes from the caching allocator and may hold anything, including a stale header
+            # of an earlier workspace: the lazy tile clear trusts the header, so it starts out invalid
+            # (include/openpifpaf_amd.h, workspace contract).
+            ws[:256].zero_()
             self._workspaces[key] = ws
         return ws
 
@@ -137,7 +157,8 @@ class CifCaf:
 
         :param cif: ``[B,F,5,H,W]`` float32, :param caf: ``[B,A,8,H,W]`` float32 (device tensors)
         :returns: ``(annotations [B,max,K,4] (v,x,y,s), ids [B,max] int64, counts [B] int32)``
-                  device tensors; rows >= counts[b] are undefined.
+                  device tensors.  ``count_rows(counts[b])`` rows are valid, the rest is undefined;
+                  ``count_overflowed(counts[b])``: poses were dropped because ``max_annotations`` is too small.
         """
         cif, orig = _prep(cif)
         caf, _ = _prep(caf)
@@ -179,6 +200,9 @@ class CifCaf:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph, stream=stream):
             out = self.call_batch(cif, cif_stride, caf, caf_stride, params=params)
+        # the graph replays into this workspace: keep it alive with the graph and refuse to swap it
+        graph._opa_keepalive = (self, self._last[1], cif, caf)
+        self._pinned = True
         return graph, out
 
     def call_with_initial_annotations(self, cif_field, cif_stride, caf_field, caf_stride,
@@ -189,9 +213,9 @@ class CifCaf:
         out, ids, counts = self.call_batch(cif_field.unsqueeze(0), cif_stride, caf_field.unsqueeze(0),
                                            caf_stride, ia, ii)
         n = int(counts[0])
-        if n > self.max_annotations:
-            raise _lib.NativeError('annotation capacity overflow: %d dropped; construct CifCaf with a larger '
-                                   'max_annotations' % (n - self.max_annotations))
+        if n & COUNT_OVERFLOW:
+            raise _lib.NativeError('annotation capacity overflow: %d poses dropped; construct CifCaf with a '
+                                   'larger max_annotations' % int(self.workspace_view('status', torch.int32)[0]))
         return out[0, :n].clone(), ids[0, :n].clone()
 
     def call(self, cif_field, cif_stride, caf_field, caf_stride):
@@ -205,6 +229,13 @@ class CifCaf:
         _lib.check(_lib.lib().opa_cifcaf_workspace_view(ctypes.byref(shape), what.encode(), ctypes.byref(off),
                                                         ctypes.byref(size)), 'opa_cifcaf_workspace_view')
         return ws[off.value:off.value + size.value].view(dtype)
+
+    def assoc_stats(self):
+        """Statistics of the last ``call_batch``'s association kernel: int32 ``[B,16]`` (see
+        ``opa_cifcaf_workspace_view`` in the header): growths started / accepted / cancelled / dropped,
+        mispredictions, ticks."""
+        shape, _ = self._last
+        return self.workspace_view('assoc_stats', torch.int32).view(shape.batch, 16)
 
     def get_cifhr(self, image=0):
         """module.cpp:37-39 -> (Tensor [F,Hhr,Whr] view of the internal buffer, revision)."""

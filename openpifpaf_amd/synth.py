@@ -35,7 +35,7 @@ def _blob(conf_plane, targets, cx, cy, radius, peak, sigma, rng):
 
 
 def synth_fields(seed, n_people, *, height=81, width=81,
-                 pose=None, skeleton=None, noise=0.05, size_range=(0.25, 0.75)):
+                 pose=None, skeleton=None, noise=0.05, size_range=(0.25, 0.75), cif_noise=None):
     """Generate one image's (cif, caf) float32 field tensors.
 
     :param seed: numpy ``default_rng`` seed, fully determines the output
@@ -43,7 +43,12 @@ def synth_fields(seed, n_people, *, height=81, width=81,
     :param pose: ``[K, 2]`` pose template (x right, y up), default COCO upright
     :param skeleton: 1-based bone list, default COCO person skeleton
     :param size_range: person height as a fraction of min(height, width)
+    :param cif_noise: regression noise of the CIF blobs alone (default ``noise``): large values spread the
+        seeds of one confidence blob over several occupancy boxes (wrong blob-mate predictions in the
+        association kernel) while the CAF fields still connect the poses
     """
+    if cif_noise is None:
+        cif_noise = noise
     rng = np.random.default_rng(seed)
     if pose is None:
         pose = constants.COCO_UPRIGHT_POSE
@@ -94,8 +99,8 @@ def synth_fields(seed, n_people, *, height=81, width=81,
             x, y = joints[k]
             bj, bi = _blob(cif[k, 1], None, x, y, max(2.3, 1.5 + 0.5 * s), 0.9, max(1.3, 0.6 + 0.5 * s), rng)
             n = len(bj)
-            cif[k, 2, bj, bi] = x + rng.normal(0.0, noise, n)
-            cif[k, 3, bj, bi] = y + rng.normal(0.0, noise, n)
+            cif[k, 2, bj, bi] = x + rng.normal(0.0, cif_noise, n)
+            cif[k, 3, bj, bi] = y + rng.normal(0.0, cif_noise, n)
             cif[k, 4, bj, bi] = s * (1.0 + rng.normal(0.0, 0.03, n))
 
         for a, (j1, j2) in enumerate(skeleton):

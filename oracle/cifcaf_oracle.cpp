@@ -57,6 +57,13 @@ struct Params {                      // defaults = the reference's static member
 
 inline int64_t clamp64(int64_t v, int64_t lo, int64_t hi) { return std::min(std::max(v, lo), hi); }
 
+// Order of seeds with EXACTLY equal scores.  0 = whatever libstdc++'s unstable std::sort leaves (the
+// reference, cif_seeds.cpp:93-99: unspecified by the language, deterministic for one library build);
+// 1 = cell index ascending (the total order the HIP path sorts by); 2 = cell index descending.
+// Test-only knob (tools/tie_study.py, tests/test_tie_rule.py): it lets the CPU suite measure how often
+// the tie order changes a decode on quantised (bf16) fields.
+int g_seed_tie_rule = 0;
+
 // ---------------------------------------------------------------- CifHr
 // High-resolution confidence map, stored exactly like the reference buffer of a
 // fresh instance: 0.0 where never touched, otherwise revision(=1) + accumulated.
@@ -161,7 +168,12 @@ std::vector<Seed> cif_seeds(const HiRes& hr, const float* cif, int64_t F, int64_
             seeds.push_back(Seed{f, c, x, y, s});
         }
     }
-    std::sort(seeds.begin(), seeds.end(), [](const Seed& a, const Seed& b) { return a.v > b.v; });
+    if (g_seed_tie_rule == 0) {
+        std::sort(seeds.begin(), seeds.end(), [](const Seed& a, const Seed& b) { return a.v > b.v; });
+    } else {                         // seeds were pushed in cell-index order: a stable sort keeps it among equals
+        if (g_seed_tie_rule == 2) std::reverse(seeds.begin(), seeds.end());
+        std::stable_sort(seeds.begin(), seeds.end(), [](const Seed& a, const Seed& b) { return a.v > b.v; });
+    }
     return seeds;
 }
 
@@ -441,6 +453,8 @@ extern "C" {
 typedef Params oracle_params;
 
 void oracle_default_params(oracle_params* p) { *p = Params(); }
+void oracle_set_seed_tie_rule(int rule) { g_seed_tie_rule = rule; }
+int oracle_get_seed_tie_rule(void) { return g_seed_tie_rule; }
 
 // cifhr [F,Hhr,Whr] must be zero-filled by the caller; on return it holds the
 // raw reference buffer content at revision 1 (0 = untouched, else 1 + value).

@@ -60,6 +60,12 @@ def lib():
     return _lib
 
 
+def set_seed_tie_rule(rule):
+    """Order of seeds with exactly equal scores in the restatement: 0 = libstdc++'s unstable std::sort
+    (the reference, default), 1 = cell index ascending (the HIP path's total order), 2 = descending."""
+    lib().oracle_set_seed_tie_rule(ctypes.c_int(int(rule)))
+
+
 def default_params(**overrides):
     p = Params()
     lib().oracle_default_params(ctypes.byref(p))

@@ -15,6 +15,13 @@ GOLDEN_CASES = [
 DET_CASES = [(0, 1, 41, 41), (1, 5, 41, 41), (2, 12, 33, 49), (3, 30, 81, 81), (4, 150, 81, 81)]
 
 
+def to_bf16(a):
+    """float32 -> nearest-even bfloat16 -> float32 (what a bf16 head's output looks like once cast back)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
 def compare_annotations(a, b, tol=TOL):
     """a, b: [n,K,4] (v,x,y,s), both in the decoder's output order (score descending).
     Returns (ok, message).  Discrete mismatches (count, joint presence) are reported as such."""

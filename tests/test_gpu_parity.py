@@ -467,14 +467,26 @@ def test_workspace_state_across_different_images(native, port, coco_skeleton0):
 
 
 def test_annotation_capacity_overflow_is_flagged(native, port, coco_skeleton0):
-    """counts[b] > max_annotations flags dropped poses; the ones that fit are the first ones the sequential
-    loop creates (include/openpifpaf_amd.h: out_count_dev)."""
+    """Too small a capacity: the overflow bit is raised, the count says how many rows are VALID, and those rows
+    are real poses -- the first ones the sequential loop creates, after keypoint NMS among themselves
+    (include/openpifpaf_amd.h: out_count_dev).  Rows behind them are never handed out as poses."""
     cif, caf = fields(91, 9)
     want, _ = port.decode(cif, 8, caf, 8, coco_skeleton0)
     assert len(want) >= 6
     dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0), max_annotations=3)
     out, ids, cnt = dec.call_batch(dev(cif[None]), 8, dev(caf[None]), 8)
-    assert int(cnt[0]) > 3
+    c = int(cnt[0])
+    assert native.count_overflowed(c) and 1 <= native.count_rows(c) <= 3
+    assert int(dec.workspace_view('status', torch.int32)[0]) >= len(want) - 3     # poses dropped
+    rows = out[0, :native.count_rows(c)].cpu().numpy()
+    for row in rows:                                 # each valid row is one of the real poses (NMS only lowers v)
+        k0 = int(np.argmax(row[:, 0] > 0))
+        match = [w for w in want if w[k0, 0] > 0 and np.abs(w[k0, 1:] - row[k0, 1:]).max() <= TOL]
+        assert match, 'row is not a pose of the full decode'
+        both = (row[:, 0] > 0) & (match[0][:, 0] > 0)
+        assert np.abs(row[both] - match[0][both]).max() <= TOL
+    from openpifpaf_amd import distributed
+    assert len(distributed.unpack(out, ids, cnt)[0][0]) == native.count_rows(c)
     with pytest.raises(Exception, match='capacity overflow'):
         dec.call(dev(cif), 8, dev(caf), 8)
     # enough room again: same decoder class, full result
