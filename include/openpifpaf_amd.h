@@ -166,12 +166,13 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
  * classes of module.cpp:66-117).  what: "tile_bitmaps" (u32 [2][B*F][words]: tiles of the map written by
  * the previous / by this call), "cifhr", "seed_count", "seed_f", "seed_vxys", "seed_cell",
  * "lists", "list_counts", "lists_fc", "list_counts_fc", "occupancy",
- * "annotation_scratch", "status" (int32 [B]: poses dropped for lack of capacity), "assoc_stats" (int32 [B,16]
- * per image: 0 growths started, 1 poses accepted, 2 growths cancelled in flight, 3 finished growths dropped
- * (their seed had died), 4 results given up to free a grower for the head, 5 mispredictions (seeds handed out
- * after having been predicted dead), 6 pool refills, 7 seeds, 8 ticks until the growth phase ended, 9 ticks of
- * the kernel, 10 sum of the growers' busy ticks, 11 list scans, 12 ticks the coordinator waited for the head's
- * growth, 13 growers, 14 poses stored, 15 ticks of keypoint NMS; ticks are 10 ns). */
+ * "annotation_scratch", "status" (int32 [B]: poses dropped for lack of capacity; -1: the kernel's watchdog
+ * fired), "assoc_stats" (int32 [B,16] per image: 0 growths started, 1 poses accepted, 2 growths stopped because
+ * their seed died, 3 finished growths dropped for the same reason, 4 growths stopped or given up on a prediction
+ * (the seed stays pooled), 5 seeds handed out after having been predicted dead, 6 pool refills, 7 seeds,
+ * 8 ticks until the growth phase ended, 9 ticks of the kernel, 10 sum of the growers' busy ticks, 11 list
+ * scans, 12 coordinator ticks spent in iterations that only waited for the head's growth, 13 growers,
+ * 14 poses stored, 15 coordinator iterations; ticks are 10 ns). */
 int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what,
                               size_t* offset_bytes, size_t* size_bytes);
 

@@ -83,6 +83,7 @@ struct ImageCtx {
     unsigned* occ; int occ_h, occ_w, occ_wpr;   // occupancy bitmap [F][occ_h][occ_wpr] (one bit per cell)
     const int* cancel;                   // this grower's cancel flag in LDS (polled between frontier pops), or null
     int aborted;                         // set when a growth stopped because of it
+    int* pub; int n_pub;                 // the grower's "boxes published" counter in LDS (or null) and its value
     // private LDS (one block per growing wave)
     float* tgt;                          // [3][kBlendChunks][64] target columns of the list being scanned
     struct OccBox* jbox;                 // occupancy boxes of the grown pose [K]
@@ -390,6 +391,11 @@ __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, dou
     return blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt);
 }
 
+// A joint was assigned (cifcaf.cpp:310): during the seed pipeline the grower publishes the occupancy box the
+// joint WILL occupy if the pose is accepted, so that the coordinator can stop handing out -- and growing --
+// seeds this pose is going to cover (defined behind the occupancy helpers).
+__device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s);
+
 // -------------------------------------------------------------- frontier heap
 // Exact behaviour of std::priority_queue<FrontierEntry, vector, FrontierCompare>
 // (cifcaf.hpp:93, cifcaf.cpp:27-29): comp(a,b) = a.max_score < b.max_score.
@@ -514,6 +520,7 @@ __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool rever
             }
         }
         c.jv[end] = v; c.jx[end] = x; c.jy[end] = y; c.js[end] = s;     // :310
+        publish_joint(c, p, end, x, y, s);
         frontier_add_from(c, end);
     }
 }
@@ -711,6 +718,7 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
             x = rlanef(R.ex, slot); y = rlanef(R.ey, slot); s = rlanef(R.es, slot);
         }
         reg_set_joint(R, end, v, x, y, s);                                   // :310
+        publish_joint(c, p, end, x, y, s);
         reg_frontier_add_from(R, sk, end);
     }
     if (then_flood_fill) {                                                   // cifcaf.cpp:429-449
@@ -765,6 +773,13 @@ __device__ __forceinline__ OccBox occ_box(const ImageCtx& c, const DevParams& p,
 }
 __device__ __forceinline__ bool box_contains(const OccBox& b, int xi, int yi) {
     return xi >= b.minx && xi < b.maxx && yi >= b.miny && yi < b.maxy;
+}
+
+__device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s) {
+    if (!c.pub || k >= c.F) return;
+    const OccBox b = occ_box(c, p, (double)x, (double)y, (double)s);
+    if (lane_id() == 0) { c.jbox[k] = b; *c.pub = ++c.n_pub; }
+    else ++c.n_pub;
 }
 
 // Occupancy::get on the bitmap (one bit per cell, rows of occ_wpr 32-bit words)
@@ -838,7 +853,7 @@ __device__ __forceinline__ double pose_score(const double* v, int K) {
 // state = ASSIGNED; the grower answers DONE (pose, boxes and score are in its private block / slot) or, if
 // `cancel` was raised while it grew, IDLE.  Only the coordinator moves a slot out of DONE.
 constexpr int kTaskIdle = 0, kTaskAssigned = 1, kTaskDone = 2;
-struct __attribute__((aligned(8))) TaskSlot { int state, cancel, seed, pk, f, pad; double score; };
+struct __attribute__((aligned(16))) TaskSlot { int state, cancel, seed, npub, pk, f; double score; };
 
 // statistics of one image, int32[kAssocStats] in the workspace ("assoc_stats"): see include/openpifpaf_amd.h
 constexpr int kAssocStats = 16;
@@ -866,7 +881,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     c.list_cap = a.list_cap;
     c.occ_h = a.occ_h; c.occ_w = a.occ_w; c.occ_wpr = (a.occ_w + 31) >> 5;
     c.occ = a.occ + (size_t)b * a.occ_image_words;
-    c.cancel = nullptr; c.aborted = 0; c.n_blend = 0;
+    c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.pub = nullptr; c.n_pub = 0;
 
     // ---- LDS carve: shared part, then one private block per growing wave
     unsigned char* sp = smem;
@@ -916,7 +931,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     }
     for (int k = tid; k <= K; k += kThreads) l_off[k] = sk.adj_off[k];
     if (tid < NW) {
-        TaskSlot t; t.state = kTaskIdle; t.cancel = 0; t.seed = -1; t.pk = 0; t.f = 0; t.pad = 0; t.score = 0.0;
+        TaskSlot t; t.state = kTaskIdle; t.cancel = 0; t.seed = -1; t.npub = 0; t.pk = 0; t.f = 0; t.score = 0.0;
         task[tid] = t;
     }
     if (tid < 8) sh_ctl[tid] = 0;
@@ -998,12 +1013,14 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         constexpr unsigned kNone = 0xFFFFFFFFu;
         int s_pack[WR], s_if[WR];                        // cell x | cell y << 12 | box half-width << 24 ;  seed index | field << 24
         unsigned occupied = 0u;                          // bit r: slot r holds a live undecided seed
-        unsigned emitted = 0u;                           //        ... handed to a grower
-        unsigned shadow = 0u;                            //        ... inside the seed-joint box of an earlier in-flight candidate
+        unsigned emitted = 0u;                           //        ... handed to a grower (nibble r of gmap says which)
+        unsigned shadow = 0u;                            //        ... inside a joint box an EARLIER candidate in flight has published
         unsigned ever = 0u;                              //        ... was shadowed at some time (statistics)
-        int scan_pos = 0;
+        unsigned gmap = 0u;
+        int scan_pos = 0, n_live = 0, seen_pub = 0;
         bool bitmap_dirty = a.n_initial > 0, need_shadow = false, watchdog = false;
         long long wait_ticks = 0;
+        unsigned iter = 0;
         const unsigned long long lanes_below = (1ull << lane) - 1ull;
         const bool is_grower_lane = lane >= 1 && lane <= S;
 #pragma unroll
@@ -1016,15 +1033,19 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             return (int)((unsigned)s_if[r] >> 24) == fo && (s_if[r] & kIdxMask) > idx &&
                    dx > -half && dx < half && dy > -half && dy < half;
         };
+        auto count_live = [&]() {
+            n_live = 0;
+#pragma unroll
+            for (int r = 0; r < WR; r++) n_live += __popcll(__ballot((occupied >> r) & 1u));
+        };
 
         for (;;) {
-            if (wall_clock64() - t_kernel > kWatchdogTicks) { watchdog = true; break; }
+            const long long t_iter = wall_clock64();
+            if (t_iter - t_kernel > kWatchdogTicks) { watchdog = true; break; }
+            iter++;
             // ---- 1. refill free slots with the next seeds that are still free in the bitmap (:211 for the
             //         poses accepted so far); slot (r, lane) takes the seed of its rank among the free slots
-            int n_occ = 0;
-#pragma unroll
-            for (int r = 0; r < WR; r++) n_occ += __popcll(__ballot((occupied >> r) & 1u));
-            if (scan_pos < n_seeds && 2 * n_occ < WR * kWave) {
+            if (scan_pos < n_seeds && 2 * n_live < WR * kWave) {
                 if (bitmap_dirty) {                      // this wave's marks (atomics at L2) before its own reads
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1059,35 +1080,70 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                             occupied |= 1u << r; emitted &= ~(1u << r); shadow &= ~(1u << r); ever &= ~(1u << r);
                         }
                     scan_pos = scan_pos + base < n_seeds ? scan_pos + base : n_seeds;
-                    n_occ = 0;
-#pragma unroll
-                    for (int r = 0; r < WR; r++) n_occ += __popcll(__ballot((occupied >> r) & 1u));
-                    if (2 * n_occ >= WR * kWave) break;
+                    count_live();
+                    if (2 * n_live >= WR * kWave) break;
                 }
                 st[6]++;
                 need_shadow = true;                      // new seeds against the candidates in flight
             }
 
-            // ---- 2. the growers' states (lane g looks at grower g)
-            int g_state = is_grower_lane ? flag_load(&task[lane].state) : -1;
-            {   // a growth that finished after its seed died: drop the result
-                const bool rel = g_state == kTaskDone && flag_peek(&task[lane].cancel) != 0;
-                if (rel) { flag_store(&task[lane].state, kTaskIdle); g_state = kTaskIdle; }
+            // ---- 2. the growers (lane g looks at grower g): state, cancel flag, seed, published boxes
+            int g_state = -1, g_cancel = 0, g_seed = -1, g_pub = 0;
+            if (is_grower_lane) {
+                g_state = flag_load(&task[lane].state);
+                g_cancel = flag_peek(&task[lane].cancel); g_seed = task[lane].seed; g_pub = flag_peek(&task[lane].npub);
+                if (g_state == kTaskDone && g_cancel) {  // a growth that finished after its seed died: drop the result
+                    flag_store(&task[lane].state, kTaskIdle); g_state = kTaskIdle;
+                }
             }
-            if (need_shadow) {                           // which pooled seeds do the candidates in flight shadow?
+            const bool g_live = (g_state == kTaskAssigned || g_state == kTaskDone) && !g_cancel;
+            // Which pooled seeds lie in a joint box an EARLIER live candidate has published so far?  They die if
+            // that candidate is accepted: they are not handed out, and if they are being grown the growth is
+            // stopped and the seed waits (a prediction: it is handed out again should the candidate die instead).
+            if (need_shadow || __ballot(g_live && g_pub != seen_pub) != 0ull) {
+                seen_pub = g_pub;
                 shadow = 0u;
-                unsigned long long busy = __ballot(g_state == kTaskAssigned || g_state == kTaskDone);
+                unsigned long long busy = __ballot(g_live && g_pub > 0);
                 while (busy) {
                     const int g = __builtin_ctzll(busy);
                     busy &= busy - 1;
-                    if (flag_peek(&task[g].cancel)) continue;
-                    const int pk = task[g].pk, fo = task[g].f, idx = task[g].seed;
+                    const int idx = rlane(g_seed, g);
+                    const OccBox* bx = pose_of_block(private_base, g - 1, K, A).box;
 #pragma unroll
                     for (int r = 0; r < WR; r++)
-                        if (((occupied & ~emitted) >> r) & 1u && in_blob(r, pk, fo, idx)) shadow |= 1u << r;
+                        if ((occupied >> r) & 1u && (s_if[r] & kIdxMask) > idx &&
+                            box_contains(bx[(unsigned)s_if[r] >> 24], s_pack[r] & 0xfff, (s_pack[r] >> 12) & 0xfff))
+                            shadow |= 1u << r;
+                }
+                {   // candidates whose own seed box is not published yet still shadow their blob (see step 3)
+                    unsigned long long fresh = __ballot(g_live && g_pub == 0);
+                    while (fresh) {
+                        const int g = __builtin_ctzll(fresh);
+                        fresh &= fresh - 1;
+                        const int pk = task[g].pk, fo = task[g].f, idx = rlane(g_seed, g);
+#pragma unroll
+                        for (int r = 0; r < WR; r++)
+                            if ((occupied >> r) & 1u && in_blob(r, pk, fo, idx)) shadow |= 1u << r;
+                    }
                 }
                 ever |= shadow;
                 need_shadow = false;
+                // growths of shadowed seeds stop; the seeds stay pooled, not handed out
+                const unsigned pc = shadow & emitted & occupied;
+                int n_pc = 0;
+#pragma unroll
+                for (int r = 0; r < WR; r++)
+                    if ((pc >> r) & 1u) {
+                        const int g = (gmap >> (4 * r)) & 15;
+                        if (flag_load(&task[g].state) == kTaskAssigned) {
+                            flag_store(&task[g].cancel, 1);
+                            emitted &= ~(1u << r);
+                            n_pc++;
+                        }
+                    }
+#pragma unroll
+                for (int k = 0; k < WR; k++) st[4] += __popcll(__ballot(n_pc > k));
+                need_shadow = __ballot(n_pc > 0) != 0ull;    // without the stopped candidates' own shadows next time
             }
 
             // ---- 3. hand the next candidates, in seed order, to the idle growers
@@ -1100,25 +1156,26 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     if ((elig >> r) & 1u) mn = min(mn, (unsigned)(s_if[r] & kIdxMask));
                 mn = ~wave_max_u32(~mn);
                 if (mn == kNone) break;
+                const int g = __builtin_ctzll(idle);
+                idle &= idle - 1;
                 int pk = 0, fo = 0; bool own = false, was_shadowed = false;
 #pragma unroll
                 for (int r = 0; r < WR; r++)
                     if (((elig >> r) & 1u) && (unsigned)(s_if[r] & kIdxMask) == mn) {
                         pk = s_pack[r]; fo = (int)((unsigned)s_if[r] >> 24); own = true;
                         was_shadowed = (ever >> r) & 1u; emitted |= 1u << r;
+                        gmap = (gmap & ~(15u << (4 * r))) | ((unsigned)g << (4 * r));
                     }
                 const int owner = __builtin_ctzll(__ballot(own));
                 pk = rlane(pk, owner); fo = rlane(fo, owner);
-                const int g = __builtin_ctzll(idle);
-                idle &= idle - 1;
                 if (lane == 0) {
-                    task[g].seed = (int)mn; task[g].pk = pk; task[g].f = fo;
+                    task[g].seed = (int)mn; task[g].pk = pk; task[g].f = fo; task[g].npub = 0;
                     flag_store(&task[g].cancel, 0);
                     flag_store(&task[g].state, kTaskAssigned);
                 }
 #pragma unroll
                 for (int r = 0; r < WR; r++)
-                    if (((occupied & ~emitted) >> r) & 1u && in_blob(r, pk, fo, (int)mn)) { shadow |= 1u << r; ever |= 1u << r; }
+                    if ((occupied >> r) & 1u && in_blob(r, pk, fo, (int)mn)) { shadow |= 1u << r; ever |= 1u << r; }
                 st[0]++;
                 st[5] += __ballot(was_shadowed) != 0ull ? 1 : 0;
             }
@@ -1133,21 +1190,25 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 if (scan_pos >= n_seeds) break;          // no live seed in the pool, none left to scan
                 continue;                                // pool ran empty: refill
             }
-            bool head_emitted = false;
+            int hg = -1;                                 // the grower that has the head
+            {
+                int mine = -1;
 #pragma unroll
-            for (int r = 0; r < WR; r++)
-                head_emitted |= ((occupied & emitted) >> r) & 1u && (unsigned)(s_if[r] & kIdxMask) == hd;
-            if (__ballot(head_emitted) == 0ull) {
-                // A head that was never handed out (a wrong prediction, or no grower was free): it is never
-                // shadowed -- a candidate shadowing it would be the head -- so step 3 takes it as soon as a
-                // grower is idle.  If every grower holds or grows a LATER seed, the latest of them is given up.
-                g_state = is_grower_lane ? flag_load(&task[lane].state) : -1;
-                if (__ballot(g_state == kTaskIdle) != 0ull) continue;
-                if (__ballot(g_state >= 0 && flag_peek(&task[lane].cancel) != 0) != 0ull) {   // one is about to be idle
-                    __builtin_amdgcn_s_sleep(2);
+                for (int r = 0; r < WR; r++)
+                    if (((occupied & emitted) >> r) & 1u && (unsigned)(s_if[r] & kIdxMask) == hd) mine = (gmap >> (4 * r)) & 15;
+                const unsigned long long m = __ballot(mine >= 0);
+                if (m) hg = rlane(mine, __builtin_ctzll(m));
+            }
+            if (hg < 0) {
+                // A head that was never handed out, or whose growth was stopped by a prediction that did not
+                // come true.  It is never shadowed (a live candidate shadowing it would be the head), so step 3
+                // takes it as soon as a grower is idle.  If every grower holds or grows a LATER seed that
+                // none of the commits to come can free, the latest of them is given up.
+                if (__ballot(is_grower_lane && (flag_load(&task[lane].state) == kTaskIdle || flag_peek(&task[lane].cancel))) != 0ull) {
+                    __builtin_amdgcn_s_sleep(1);         // a grower is idle or about to be
                     continue;
                 }
-                const unsigned key = g_state >= 0 ? ((unsigned)task[lane].seed << 6) | (unsigned)lane : 0u;
+                const unsigned key = is_grower_lane ? ((unsigned)task[lane].seed << 6) | (unsigned)lane : 0u;
                 const int victim = (int)(wave_max_u32(key) & 63u);
                 const int vseed = task[victim].seed;
                 if (lane == 0) flag_store(&task[victim].cancel, 1);
@@ -1161,18 +1222,9 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 need_shadow = true;
                 continue;
             }
-            int hg = 0;                                  // the grower that has the head
-            {
-                const bool mine = is_grower_lane && g_state != kTaskIdle && task[lane].seed == (int)hd &&
-                                  flag_peek(&task[lane].cancel) == 0;
-                const unsigned long long m = __ballot(mine);
-                if (m == 0ull) continue;                 // (its state was read before step 3 handed it out)
-                hg = __builtin_ctzll(m);
-            }
             if (flag_load(&task[hg].state) != kTaskDone) {
-                const long long t0 = wall_clock64();
-                __builtin_amdgcn_s_sleep(4);
-                wait_ticks += wall_clock64() - t0;
+                __builtin_amdgcn_s_sleep(2);
+                wait_ticks += wall_clock64() - t_iter;   // an iteration that only waited for the head's growth
                 continue;
             }
 
@@ -1185,23 +1237,22 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     (box_contains(q.box[(unsigned)s_if[r] >> 24], s_pack[r] & 0xfff, (s_pack[r] >> 12) & 0xfff) ||
                      (unsigned)(s_if[r] & kIdxMask) == hd))
                     dead |= 1u << r;
+            {   // growths of seeds that just died: drop finished ones, stop running ones
+                int n_drop = 0, n_stop = 0;
+#pragma unroll
+                for (int r = 0; r < WR; r++)
+                    if (((dead & emitted) >> r) & 1u && (unsigned)(s_if[r] & kIdxMask) != hd) {
+                        const int g = (gmap >> (4 * r)) & 15;
+                        if (flag_load(&task[g].state) == kTaskDone) { flag_store(&task[g].state, kTaskIdle); n_drop++; }
+                        else { flag_store(&task[g].cancel, 1); n_stop++; }
+                    }
+#pragma unroll
+                for (int k = 0; k < WR; k++) { st[3] += __popcll(__ballot(n_drop > k)); st[2] += __popcll(__ballot(n_stop > k)); }
+            }
 #pragma unroll
             for (int r = 0; r < WR; r++)
-                if ((dead >> r) & 1u) { occupied &= ~(1u << r); s_if[r] |= kIdxMask; }
-            {   // growths of seeds that just died: drop finished ones, stop running ones
-                g_state = is_grower_lane ? flag_load(&task[lane].state) : -1;
-                bool hit = false;
-                if (is_grower_lane && lane != hg && g_state != kTaskIdle && flag_peek(&task[lane].cancel) == 0) {
-                    const int pk = task[lane].pk;
-                    hit = box_contains(q.box[task[lane].f], pk & 0xfff, (pk >> 12) & 0xfff);
-                }
-                if (hit) {
-                    if (g_state == kTaskDone) flag_store(&task[lane].state, kTaskIdle);
-                    else flag_store(&task[lane].cancel, 1);
-                }
-                st[3] += __popcll(__ballot(hit && g_state == kTaskDone));
-                st[2] += __popcll(__ballot(hit && g_state != kTaskDone));
-            }
+                if ((dead >> r) & 1u) { occupied &= ~(1u << r); emitted &= ~(1u << r); s_if[r] |= kIdxMask; }
+            count_live();
             accept_pose(hg - 1, task[hg].score, -1);
             bitmap_dirty = true;
             st[1]++;
@@ -1216,6 +1267,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         st[7] = n_seeds;
         st[8] = (int)(wall_clock64() - t_kernel);
         st[12] = (int)wait_ticks;
+        st[15] = (int)iter;
         if (lane == 0)
 #pragma unroll
             for (int k = 0; k < kAssocStats; k++) sh_stats[k] = st[k];
@@ -1235,12 +1287,19 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             const long long t0 = wall_clock64();
             const int mine = __builtin_amdgcn_readfirstlane(my->seed);
             const int sf = seed_f[mine]; const float4 sd = seed_vxys[mine];
-            for (int k = lane; k < K; k += kWave) { c.jv[k] = 0.0; c.jx[k] = 0.f; c.jy[k] = 0.f; c.js[k] = 0.f; }
+            for (int k = lane; k < K; k += kWave) {
+                c.jv[k] = 0.0; c.jx[k] = 0.f; c.jy[k] = 0.f; c.js[k] = 0.f;
+                OccBox e; e.minx = e.miny = e.maxx = e.maxy = 0;
+                c.jbox[k] = e;                           // nothing published yet
+            }
             wave_sync();
             c.jv[sf] = (double)sd.x; c.jx[sf] = sd.y; c.jy[sf] = sd.z; c.js[sf] = sd.w;   // :213-218
             wave_sync();
             c.aborted = 0;
+            c.pub = &my->npub; c.n_pub = 0;
+            publish_joint(c, p, sf, sd.y, sd.z, sd.w);   // the seed joint's own box: the rest of its blob
             grow_pose<REG>(c, p, rs, true, 1.0, false);
+            c.pub = nullptr;
             if (c.aborted) {
                 if (lane == 0) flag_store(&my->state, kTaskIdle);
             } else {
@@ -1282,7 +1341,6 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     }
 
     // ---- keypoint NMS, nms_keypoints.cpp:17-70
-    const long long t_nms = wall_clock64();
     for (int n = tid; n < n_kept; n += kThreads) {       // UniformScore of every stored pose
         const double* src = anns + (size_t)n * K * 4;
         double acc = 0.0;
@@ -1389,7 +1447,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     if (tid == 0 && a.stats) {
         sh_stats[9] = (int)(wall_clock64() - t_kernel);
         sh_stats[10] = sh_ctl[3]; sh_stats[11] = sh_ctl[4];
-        sh_stats[13] = S; sh_stats[14] = n_kept; sh_stats[15] = (int)(wall_clock64() - t_nms);
+        sh_stats[13] = S; sh_stats[14] = n_kept;
         for (int k = 0; k < kAssocStats; k++) a.stats[(size_t)b * kAssocStats + k] = sh_stats[k];
     }
 }

@@ -1,5 +1,6 @@
 """Fused inference epilogues for the field-producing network (HIP, ``csrc/epilogue.hip``)."""
 import ctypes
+import os
 
 import torch
 
@@ -40,11 +41,25 @@ def bias_act_(x, bias, residual=None, relu=True):
     return x
 
 
-def conv1x1_supported(x, weight):
-    """True if ``conv1x1_bias_act`` can run the HIP GEMM for this input / weight."""
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
+def conv1x1_supported(x, weight, bias=None, residual=None, a_bias=None):
+    """True if ``conv1x1_bias_act`` can run the HIP GEMM for these operands.  The kernel reads raw bf16
+    buffers: EVERY operand must be bfloat16 (autocast keeps parameters in float32 -- those take the
+    PyTorch path), the activation channels_last, the residual channels_last of the output's shape."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last)
-            and weight.shape[1] % 64 == 0 and weight.shape[0] % 64 == 0)
+            and weight.dtype == torch.bfloat16 and weight.is_cuda
+            and weight.shape[1] % 64 == 0 and weight.shape[0] % 64 == 0 and weight.shape[1] == x.shape[1]):
+        return False
+    for vec, n in ((bias, weight.shape[0]), (a_bias, weight.shape[1])):
+        if vec is not None and not (vec.dtype == torch.bfloat16 and vec.is_cuda and vec.is_contiguous()
+                                    and vec.numel() == n and vec.data_ptr() % 16 == 0):
+            return False
+    if residual is not None:
+        if not (residual.dtype == torch.bfloat16 and residual.is_cuda
+                and tuple(residual.shape) == (x.shape[0], weight.shape[0], x.shape[2], x.shape[3])
+                and residual.is_contiguous(memory_format=torch.channels_last) and residual.data_ptr() % 16 == 0):
+            return False
+    return x.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0
 
 
 def conv1x1_bias_act(x, weight2d, bias, residual=None, relu=True, a_bias=None):
@@ -74,7 +89,19 @@ def conv1x1_bias_act(x, weight2d, bias, residual=None, relu=True, a_bias=None):
     return out
 
 
-_CHOICE = {}     # (M, K, N, has_residual) -> 'gemm' | 'conv' : measured once per shape on first use
+# (device, M, K, N, has_residual, has_a_bias) -> 'gemm' | 'pass+gemm' | 'conv'.  The three paths round
+# bfloat16 differently, so the choice is part of the result: it is made once per shape and device, never
+# while a stream is being captured (timing synchronises), can be pinned with OPA_CONV1X1=gemm|conv, and can
+# be exported / imported (choices / set_choices) so that every rank of a job runs the same kernels.
+_CHOICE = {}
+
+
+def choices():
+    return dict(_CHOICE)
+
+
+def set_choices(table):
+    _CHOICE.update(table)
 
 
 def _time_ms(fn, reps=3):
@@ -99,13 +126,19 @@ def conv_bias_act(conv, x, bias, residual=None, relu=True, a_bias=None):
     fallback applies it in place first."""
     w = conv.weight
     if (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and conv.padding == (0, 0)
-            and conv1x1_supported(x, w)):
+            and conv1x1_supported(x, w, bias, residual, a_bias)):
         M = x.shape[0] * x.shape[2] * x.shape[3]
-        key = (M, w.shape[1], w.shape[0], residual is not None, a_bias is not None)
+        key = (x.device.index, M, w.shape[1], w.shape[0], residual is not None, a_bias is not None)
         w2d = w.reshape(w.shape[0], w.shape[1])
         if not w2d.is_contiguous():
             w2d = w2d.contiguous()
         choice = _CHOICE.get(key)
+        if choice is None:
+            forced = os.environ.get('OPA_CONV1X1', 'auto')
+            if forced in ('gemm', 'conv'):
+                choice = _CHOICE[key] = forced
+            elif torch.cuda.is_current_stream_capturing():
+                choice = 'gemm'                  # no timing inside a capture; not remembered
         if choice is None:
             times = {'gemm': _time_ms(lambda: conv1x1_bias_act(x, w2d, bias, residual, relu, a_bias))}
             if a_bias is None:

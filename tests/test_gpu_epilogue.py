@@ -102,3 +102,27 @@ def test_resnet50_fused_gemm_forward_close_to_unfused():
         assert u.shape == v.shape and u.dtype == torch.float32
         # bf16 network vs fp32 network: only a sanity bound (confidences are in [0,1])
         assert float((u[:, :, 1] - v[:, :, 1]).abs().mean()) < 0.05
+
+
+def test_fused_gemm_refuses_mixed_precision_operands():
+    """Autocast keeps parameters in float32: bf16 activations with fp32 weight / bias / prologue bias, or a
+    residual of another layout, must take the PyTorch path -- the kernel would reinterpret the raw buffers
+    (ADVICE r1).  The result has to match the fp32 reference either way."""
+    from openpifpaf_amd import fused
+    torch.manual_seed(3)
+    B, cin, cout, hw = 2, 64, 128, 17
+    x = (torch.randn(B, cin, hw, hw, device='cuda') * 0.5).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    conv = torch.nn.Conv2d(cin, cout, 1, bias=False).cuda()             # float32 parameters
+    bias32 = torch.randn(cout, device='cuda')
+    w16, b16 = conv.weight.detach().to(torch.bfloat16), bias32.to(torch.bfloat16)
+    res_nchw = torch.randn(B, cout, hw, hw, device='cuda').to(torch.bfloat16)       # NOT channels_last
+    assert fused.conv1x1_supported(x, w16, b16)
+    assert not fused.conv1x1_supported(x, conv.weight, b16)
+    assert not fused.conv1x1_supported(x, w16, bias32)
+    assert not fused.conv1x1_supported(x, w16, b16, a_bias=torch.zeros(cin, device='cuda'))
+    assert not fused.conv1x1_supported(x, w16, b16, residual=res_nchw)
+    assert not fused.conv1x1_supported(x, w16, b16, residual=res_nchw[:, :64].contiguous(memory_format=torch.channels_last))
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        got = fused.conv_bias_act(conv, x, bias32.to(torch.bfloat16), None, True)   # fp32 weight under autocast
+    want = torch.nn.functional.conv2d(x.float(), conv.weight.float(), bias32.to(torch.bfloat16).float()).clamp_min(0)
+    assert float((got.float() - want).abs().max()) <= 2.0 ** -6 * float(want.abs().max().clamp_min(1.0))

@@ -81,12 +81,12 @@ def test_bf16_network_head_outputs(native, port, coco_skeleton0):
     from openpifpaf_amd import headmeta, network
     cif_meta, caf_meta = headmeta.cocokp_metas()
     torch.manual_seed(7)
-    model = network.factory('resnet18', [cif_meta, caf_meta]).cuda().eval().to(torch.bfloat16)
-    images = torch.randn((2, 3, 129, 161), generator=torch.Generator().manual_seed(3)).cuda().to(torch.bfloat16)
+    model = network.factory('resnet50', [cif_meta, caf_meta]).cuda().eval().to(torch.bfloat16)
+    images = torch.randn((2, 3, 257, 321), generator=torch.Generator().manual_seed(3)).cuda().to(torch.bfloat16)
     with torch.no_grad():
         heads = model(images)
     cifs, cafs = heads[0].float().contiguous(), heads[1].float().contiguous()
-    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0), max_annotations=512)
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0), max_annotations=1024)
     out, ids, counts = dec.call_batch(cifs, cif_meta.stride, cafs, caf_meta.stride)
     out, counts = out.cpu().numpy(), counts.cpu().numpy()
     assert not native.count_overflowed(counts).any()

@@ -19,13 +19,13 @@ for _ in range(3):
 torch.cuda.synchronize()
 st = dec.assoc_stats().cpu().numpy()
 print('OPA_ASSOC_WAVES=%s  ticks are 10 ns' % os.environ.get('OPA_ASSOC_WAVES', 'default'))
-print('img people poses seeds | started accepted cancelled dropped given-up mispred refills | growth-us total-us nms-us '
-      'coord-wait-us grower-busy-us scans us/scan growers')
+print('img people poses seeds | started accepted stopped dropped pre-stop mispred refills | growth-us total-us iters '
+      'head-wait-us grower-busy-us scans us/scan growers')
 for b in range(min(B, 8)):
     s = st[b]
     print('%3d %6d %5d %5d | %7d %8d %9d %7d %8d %7d %7d | %9.0f %8.0f %6.0f %13.0f %14.0f %5d %7.2f %7d' % (
         b, synth.PEOPLE_CYCLE[b % 8], native.count_rows(int(counts[b])), s[7], s[0], s[1], s[2], s[3], s[4], s[5], s[6],
-        s[8] / 100, s[9] / 100, s[15] / 100, s[12] / 100, s[10] / 100, s[11], s[10] / 100 / max(1, s[11]), s[13]))
+        s[8] / 100, s[9] / 100, s[15], s[12] / 100, s[10] / 100, s[11], s[10] / 100 / max(1, s[11]), s[13]))
 tot = st.sum(axis=0)
 print('batch: started %d accepted %d cancelled %d dropped %d -> discarded share %.1f%% of growths; '
       'slowest image %.0f us, mean %.0f us' % (tot[0], tot[1], tot[2], tot[3],
