@@ -172,7 +172,9 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
  * (the seed stays pooled), 5 seeds handed out after having been predicted dead, 6 pool refills, 7 seeds,
  * 8 ticks until the growth phase ended, 9 ticks of the kernel, 10 sum of the growers' busy ticks, 11 list
  * scans, 12 coordinator ticks spent in iterations that only waited for the head's growth, 13 growers,
- * 14 poses stored, 15 coordinator iterations; ticks are 10 ns). */
+ * 14 poses stored, 15 coordinator iterations; ticks are 10 ns), "assoc_trace" (int32 [B,64,4]: for the first
+ * 64 accepted poses of an image the tick of the commit, of the hand-out and of the end of the growth, and
+ * seed index | grower << 24). */
 int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what,
                               size_t* offset_bytes, size_t* size_bytes);
 

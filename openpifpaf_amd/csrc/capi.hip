@@ -128,6 +128,7 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     L->off_ann_meta = take(B * (size_t)L->max_ann * sizeof(int64_t));
     L->off_status = take(B * sizeof(int32_t));
     L->off_stats = take(B * 16 * sizeof(int32_t));
+    L->off_trace = take(B * 64 * 4 * sizeof(int32_t));
     L->total = off;
     return true;
 }
@@ -279,7 +280,7 @@ int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what, size_t* 
         {"lists", L.off_lists, L.off_list_counts}, {"list_counts", L.off_list_counts, L.off_lists_fc},
         {"lists_fc", L.off_lists_fc, L.off_list_counts_fc}, {"list_counts_fc", L.off_list_counts_fc, L.off_occ},
         {"occupancy", L.off_occ, L.off_anns}, {"annotation_scratch", L.off_anns, L.off_ann_meta},
-        {"status", L.off_status, L.off_stats}, {"assoc_stats", L.off_stats, L.total},
+        {"status", L.off_status, L.off_stats}, {"assoc_stats", L.off_stats, L.off_trace}, {"assoc_trace", L.off_trace, L.total},
     };
     for (const Entry& e : table)
         if (std::strcmp(e.name, what) == 0) {
@@ -359,6 +360,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     a.lists_fc = (const float*)(ws + L.off_lists_fc); a.list_counts_fc = (const int32_t*)(ws + L.off_list_counts_fc);
     a.occ = (unsigned*)(ws + L.off_occ); a.occ_image_words = L.occ_image_words;
     a.stats = (int32_t*)(ws + L.off_stats);
+    a.trace = (int32_t*)(ws + L.off_trace);
     a.anns = (double*)(ws + L.off_anns); a.ann_ids = (int64_t*)(ws + L.off_ann_meta);
     a.initial = initial_dev; a.initial_ids = initial_ids_dev;
     a.out = out_dev; a.out_ids = out_ids_dev; a.out_count = out_count_dev;

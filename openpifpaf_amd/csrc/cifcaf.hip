@@ -84,6 +84,9 @@ struct ImageCtx {
     const int* cancel;                   // this grower's cancel flag in LDS (polled between frontier pops), or null
     int aborted;                         // set when a growth stopped because of it
     int* pub; int n_pub;                 // the grower's "boxes published" counter in LDS (or null) and its value
+    const int *pool_if, *pool_pack;      // LDS mirror of the coordinator's seed pool [8][64] (slot r of lane l at r*64+l)
+    unsigned* shadow_mine;               // [64] bit r of word l: pool slot (r, l) lies in a box this grower published
+    int my_idx;                          // index of the seed being grown
     // private LDS (one block per growing wave)
     float* tgt;                          // [3][kBlendChunks][64] target columns of the list being scanned
     struct OccBox* jbox;                 // occupancy boxes of the grown pose [K]
@@ -775,11 +778,27 @@ __device__ __forceinline__ bool box_contains(const OccBox& b, int xi, int yi) {
     return xi >= b.minx && xi < b.maxx && yi >= b.miny && yi < b.maxy;
 }
 
+constexpr int kPoolSlots = 8;             // seed-pool slots per coordinator lane
+constexpr int kPoolIdxMask = 0xFFFFFF;    // seed index bits of a slot word (all ones: empty slot); field above
+
 __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s) {
     if (!c.pub || k >= c.F) return;
     const OccBox b = occ_box(c, p, (double)x, (double)y, (double)s);
-    if (lane_id() == 0) { c.jbox[k] = b; *c.pub = ++c.n_pub; }
-    else ++c.n_pub;
+    const int lane = lane_id();
+    // every pooled seed of this field that comes later in seed order and lies in the box is shadowed: it dies
+    // if this pose is accepted.  Advisory only (the commit re-tests every seed against the final boxes).
+    int sif[kPoolSlots], spk[kPoolSlots];
+#pragma unroll
+    for (int r = 0; r < kPoolSlots; r++) { sif[r] = c.pool_if[r * kWave + lane]; spk[r] = c.pool_pack[r * kWave + lane]; }
+    unsigned bits = 0u;
+#pragma unroll
+    for (int r = 0; r < kPoolSlots; r++)
+        if ((int)((unsigned)sif[r] >> 24) == k && (sif[r] & kPoolIdxMask) != kPoolIdxMask &&
+            (sif[r] & kPoolIdxMask) > c.my_idx && box_contains(b, spk[r] & 0xfff, (spk[r] >> 12) & 0xfff))
+            bits |= 1u << r;
+    if (bits) atomicOr(&c.shadow_mine[lane], bits);
+    ++c.n_pub;
+    if (lane == 0) { c.jbox[k] = b; *c.pub = c.n_pub; }
 }
 
 // Occupancy::get on the bitmap (one bit per cell, rows of occ_wpr 32-bit words)
@@ -853,7 +872,8 @@ __device__ __forceinline__ double pose_score(const double* v, int K) {
 // state = ASSIGNED; the grower answers DONE (pose, boxes and score are in its private block / slot) or, if
 // `cancel` was raised while it grew, IDLE.  Only the coordinator moves a slot out of DONE.
 constexpr int kTaskIdle = 0, kTaskAssigned = 1, kTaskDone = 2;
-struct __attribute__((aligned(16))) TaskSlot { int state, cancel, seed, npub, pk, f; double score; };
+struct __attribute__((aligned(16))) TaskSlot { int state, cancel, seed, npub, pk, f; double score; int t_emit, t_done, pad0, pad1; };
+constexpr int kAssocTrace = 64;           // commits recorded per image in the optional trace ("assoc_trace")
 
 // statistics of one image, int32[kAssocStats] in the workspace ("assoc_stats"): see include/openpifpaf_amd.h
 constexpr int kAssocStats = 16;
@@ -882,6 +902,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     c.occ_h = a.occ_h; c.occ_w = a.occ_w; c.occ_wpr = (a.occ_w + 31) >> 5;
     c.occ = a.occ + (size_t)b * a.occ_image_words;
     c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.pub = nullptr; c.n_pub = 0;
+    c.pool_if = nullptr; c.pool_pack = nullptr; c.shadow_mine = nullptr; c.my_idx = 0;
 
     // ---- LDS carve: shared part, then one private block per growing wave
     unsigned char* sp = smem;
@@ -899,6 +920,9 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     int* nms_rank = (int*)sp; sp += sizeof(int) * a.max_ann;
     int* sh_ctl = (int*)sp; sp += sizeof(int) * 8;   // 0 exit flag, 1 n_kept, 2 n_dropped, 3 grower ticks, 4 list scans, 5 watchdog
     int* sh_stats = (int*)sp; sp += sizeof(int) * kAssocStats;
+    int* pool_if = (int*)sp; sp += sizeof(int) * kPoolSlots * kWave;        // the coordinator's seed pool, mirrored for the growers
+    int* pool_pack = (int*)sp; sp += sizeof(int) * kPoolSlots * kWave;
+    unsigned* shadow_by = (unsigned*)sp; sp += sizeof(unsigned) * NW * kWave; // [grower][lane]: pool slots in its published boxes
     sp = smem + (((size_t)(sp - smem) + 15) & ~(size_t)15);
     unsigned char* work_base = sp;                   // growth phase: private blocks; NMS phase: scratch
     unsigned char* private_base = sp;
@@ -932,9 +956,12 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     for (int k = tid; k <= K; k += kThreads) l_off[k] = sk.adj_off[k];
     if (tid < NW) {
         TaskSlot t; t.state = kTaskIdle; t.cancel = 0; t.seed = -1; t.npub = 0; t.pk = 0; t.f = 0; t.score = 0.0;
+        t.t_emit = t.t_done = t.pad0 = t.pad1 = 0;
         task[tid] = t;
     }
     if (tid < 8) sh_ctl[tid] = 0;
+    for (int k = tid; k < kPoolSlots * kWave; k += kThreads) { pool_if[k] = kPoolIdxMask; pool_pack[k] = 0; }
+    for (int k = tid; k < NW * kWave; k += kThreads) shadow_by[k] = 0u;
     c.adj_off = l_off; c.adj_other = l_other; c.adj_bone = l_bone; c.adj_fwd = l_fwd; c.adj_first = l_first;
     sync_global();                                   // bitmap zeros are in memory before anyone marks or tests
     RegSkeleton rs; rs.slot_info = 0; rs.slot_first = 0; rs.off = 0; rs.off1 = 0;
@@ -1004,21 +1031,20 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
 #pragma unroll
         for (int k = 0; k < kAssocStats; k++) st[k] = 0;
         // ================================================================= coordinator
-        // The pool: up to 512 LIVE, undecided seeds, 8 slots per lane in any order.  Invariant: every seed
-        // below scan_pos is either in a slot or dead for good (inside a box of an accepted pose), so each
-        // seed is fetched and tested against the bitmap exactly once; afterwards it is tested against every
-        // newly accepted pose by box containment.
-        constexpr int WR = 8;                            // slots per lane
-        constexpr int kIdxMask = 0xFFFFFF;
+        // The pool: up to 512 LIVE, undecided seeds, 8 slots per lane in any order (mirrored in LDS for the
+        // growers).  Invariant: every seed below scan_pos is either in a slot or dead for good (inside a box of
+        // an accepted pose), so each seed is fetched and tested against the bitmap exactly once; afterwards it
+        // is tested against every newly accepted pose by box containment.
+        constexpr int WR = kPoolSlots;                   // slots per lane
+        constexpr int kIdxMask = kPoolIdxMask;
         constexpr unsigned kNone = 0xFFFFFFFFu;
         int s_pack[WR], s_if[WR];                        // cell x | cell y << 12 | box half-width << 24 ;  seed index | field << 24
         unsigned occupied = 0u;                          // bit r: slot r holds a live undecided seed
         unsigned emitted = 0u;                           //        ... handed to a grower (nibble r of gmap says which)
-        unsigned shadow = 0u;                            //        ... inside a joint box an EARLIER candidate in flight has published
         unsigned ever = 0u;                              //        ... was shadowed at some time (statistics)
         unsigned gmap = 0u;
-        int scan_pos = 0, n_live = 0, seen_pub = 0;
-        bool bitmap_dirty = a.n_initial > 0, need_shadow = false, watchdog = false;
+        int scan_pos = 0, n_live = 0;
+        bool bitmap_dirty = a.n_initial > 0, watchdog = false;
         long long wait_ticks = 0;
         unsigned iter = 0;
         const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -1043,7 +1069,19 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             const long long t_iter = wall_clock64();
             if (t_iter - t_kernel > kWatchdogTicks) { watchdog = true; break; }
             iter++;
-            // ---- 1. refill free slots with the next seeds that are still free in the bitmap (:211 for the
+            // ---- 1. the growers (lane g looks at grower g): state, cancel flag, seed, published boxes
+            int g_state = -1, g_cancel = 0, g_seed = -1, g_pub = 0;
+            if (is_grower_lane) {
+                g_state = flag_load(&task[lane].state);
+                g_cancel = flag_peek(&task[lane].cancel); g_seed = task[lane].seed; g_pub = flag_peek(&task[lane].npub);
+                if (g_state == kTaskDone && g_cancel) {  // a growth that finished after its seed died: drop the result
+                    flag_store(&task[lane].state, kTaskIdle); g_state = kTaskIdle;
+                }
+            }
+            const bool g_live = (g_state == kTaskAssigned || g_state == kTaskDone) && !g_cancel;
+            const unsigned long long live_mask = __ballot(g_live);
+
+            // ---- 2. refill free slots with the next seeds that are still free in the bitmap (:211 for the
             //         poses accepted so far); slot (r, lane) takes the seed of its rank among the free slots
             if (scan_pos < n_seeds && 2 * n_live < WR * kWave) {
                 if (bitmap_dirty) {                      // this wave's marks (atomics at L2) before its own reads
@@ -1051,6 +1089,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                     bitmap_dirty = false;
                 }
+                unsigned fresh = 0u;                     // slots filled by this refill
                 while (scan_pos < n_seeds) {
                     int nidx[WR], base = 0;
 #pragma unroll
@@ -1077,76 +1116,77 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     for (int r = 0; r < WR; r++)
                         if (nidx[r] < n_seeds && !((ow[r] >> (pk[r] & 31)) & 1u)) {
                             s_pack[r] = pk[r]; s_if[r] = nidx[r] | (ff[r] << 24);
-                            occupied |= 1u << r; emitted &= ~(1u << r); shadow &= ~(1u << r); ever &= ~(1u << r);
+                            occupied |= 1u << r; emitted &= ~(1u << r); ever &= ~(1u << r); fresh |= 1u << r;
                         }
                     scan_pos = scan_pos + base < n_seeds ? scan_pos + base : n_seeds;
                     count_live();
                     if (2 * n_live >= WR * kWave) break;
                 }
                 st[6]++;
-                need_shadow = true;                      // new seeds against the candidates in flight
-            }
-
-            // ---- 2. the growers (lane g looks at grower g): state, cancel flag, seed, published boxes
-            int g_state = -1, g_cancel = 0, g_seed = -1, g_pub = 0;
-            if (is_grower_lane) {
-                g_state = flag_load(&task[lane].state);
-                g_cancel = flag_peek(&task[lane].cancel); g_seed = task[lane].seed; g_pub = flag_peek(&task[lane].npub);
-                if (g_state == kTaskDone && g_cancel) {  // a growth that finished after its seed died: drop the result
-                    flag_store(&task[lane].state, kTaskIdle); g_state = kTaskIdle;
-                }
-            }
-            const bool g_live = (g_state == kTaskAssigned || g_state == kTaskDone) && !g_cancel;
-            // Which pooled seeds lie in a joint box an EARLIER live candidate has published so far?  They die if
-            // that candidate is accepted: they are not handed out, and if they are being grown the growth is
-            // stopped and the seed waits (a prediction: it is handed out again should the candidate die instead).
-            if (need_shadow || __ballot(g_live && g_pub != seen_pub) != 0ull) {
-                seen_pub = g_pub;
-                shadow = 0u;
-                unsigned long long busy = __ballot(g_live && g_pub > 0);
-                while (busy) {
-                    const int g = __builtin_ctzll(busy);
-                    busy &= busy - 1;
-                    const int idx = rlane(g_seed, g);
-                    const OccBox* bx = pose_of_block(private_base, g - 1, K, A).box;
-#pragma unroll
-                    for (int r = 0; r < WR; r++)
-                        if ((occupied >> r) & 1u && (s_if[r] & kIdxMask) > idx &&
-                            box_contains(bx[(unsigned)s_if[r] >> 24], s_pack[r] & 0xfff, (s_pack[r] >> 12) & 0xfff))
-                            shadow |= 1u << r;
-                }
-                {   // candidates whose own seed box is not published yet still shadow their blob (see step 3)
-                    unsigned long long fresh = __ballot(g_live && g_pub == 0);
-                    while (fresh) {
-                        const int g = __builtin_ctzll(fresh);
-                        fresh &= fresh - 1;
-                        const int pk = task[g].pk, fo = task[g].f, idx = rlane(g_seed, g);
-#pragma unroll
-                        for (int r = 0; r < WR; r++)
-                            if ((occupied >> r) & 1u && in_blob(r, pk, fo, idx)) shadow |= 1u << r;
-                    }
-                }
-                ever |= shadow;
-                need_shadow = false;
-                // growths of shadowed seeds stop; the seeds stay pooled, not handed out
-                const unsigned pc = shadow & emitted & occupied;
-                int n_pc = 0;
+                // the new occupants: mirror them, forget what the growers said about the slots' former occupants,
+                // and test them against the boxes the candidates in flight have published so far
 #pragma unroll
                 for (int r = 0; r < WR; r++)
-                    if ((pc >> r) & 1u) {
-                        const int g = (gmap >> (4 * r)) & 15;
-                        if (flag_load(&task[g].state) == kTaskAssigned) {
-                            flag_store(&task[g].cancel, 1);
-                            emitted &= ~(1u << r);
-                            n_pc++;
-                        }
-                    }
+                    if ((fresh >> r) & 1u) { pool_if[r * kWave + lane] = s_if[r]; pool_pack[r * kWave + lane] = s_pack[r]; }
+                for (int g = 1; g <= S; g++) {
+                    unsigned* word = &shadow_by[g * kWave + lane];
+                    if (fresh) atomicAnd(word, ~fresh);
+                    if (!((live_mask >> g) & 1ull) || rlane(g_pub, g) == 0) continue;
+                    const int idx = rlane(g_seed, g);
+                    const OccBox* bx = pose_of_block(private_base, g - 1, K, A).box;
+                    OccBox bb[WR];
 #pragma unroll
-                for (int k = 0; k < WR; k++) st[4] += __popcll(__ballot(n_pc > k));
-                need_shadow = __ballot(n_pc > 0) != 0ull;    // without the stopped candidates' own shadows next time
+                    for (int r = 0; r < WR; r++) bb[r] = bx[(fresh >> r) & 1u ? (unsigned)s_if[r] >> 24 : 0u];
+                    unsigned bits = 0u;
+#pragma unroll
+                    for (int r = 0; r < WR; r++)
+                        if ((fresh >> r) & 1u && (s_if[r] & kIdxMask) > idx &&
+                            box_contains(bb[r], s_pack[r] & 0xfff, (s_pack[r] >> 12) & 0xfff)) bits |= 1u << r;
+                    if (bits) atomicOr(word, bits);
+                }
             }
 
-            // ---- 3. hand the next candidates, in seed order, to the idle growers
+            // ---- 3. Which pooled seeds lie in a joint box an EARLIER live candidate has published so far?  (The
+            // growers test the mirrored pool against every box they publish.)  Such a seed dies if that candidate
+            // is accepted: it is not handed out, and if it is being grown the growth is stopped and the seed waits
+            // -- a prediction; should the candidate die instead, the seed is handed out again.
+            unsigned shadow = 0u;
+            {
+                unsigned w[NW];
+#pragma unroll
+                for (int g = 1; g < NW; g++) w[g] = shadow_by[g * kWave + lane];
+#pragma unroll
+                for (int g = 1; g < NW; g++) shadow |= (live_mask >> g) & 1ull ? w[g] : 0u;
+                unsigned long long fresh_g = __ballot(g_live && g_pub == 0);   // own seed box not published yet: see step 4
+                while (fresh_g) {
+                    const int g = __builtin_ctzll(fresh_g);
+                    fresh_g &= fresh_g - 1;
+                    const int pk = task[g].pk, fo = task[g].f, idx = rlane(g_seed, g);
+#pragma unroll
+                    for (int r = 0; r < WR; r++)
+                        if ((occupied >> r) & 1u && in_blob(r, pk, fo, idx)) shadow |= 1u << r;
+                }
+                shadow &= occupied;
+                ever |= shadow;
+                const unsigned pc = shadow & emitted;    // growths of shadowed seeds stop; the seeds stay pooled
+                if (__ballot(pc != 0u) != 0ull) {
+                    int n_pc = 0;
+#pragma unroll
+                    for (int r = 0; r < WR; r++)
+                        if ((pc >> r) & 1u) {
+                            const int g = (gmap >> (4 * r)) & 15;
+                            if (flag_load(&task[g].state) == kTaskAssigned) {
+                                flag_store(&task[g].cancel, 1);
+                                emitted &= ~(1u << r);
+                                n_pc++;
+                            }
+                        }
+#pragma unroll
+                    for (int k = 0; k < WR; k++) st[4] += __popcll(__ballot(n_pc > k));
+                }
+            }
+
+            // ---- 4. hand the next candidates, in seed order, to the idle growers
             unsigned long long idle = __ballot(g_state == kTaskIdle);
             while (idle) {
                 const unsigned elig = occupied & ~emitted & ~shadow;
@@ -1168,11 +1208,14 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     }
                 const int owner = __builtin_ctzll(__ballot(own));
                 pk = rlane(pk, owner); fo = rlane(fo, owner);
+                shadow_by[g * kWave + lane] = 0u;        // nothing published for this task yet
                 if (lane == 0) {
                     task[g].seed = (int)mn; task[g].pk = pk; task[g].f = fo; task[g].npub = 0;
+                    task[g].t_emit = (int)(t_iter - t_kernel);
                     flag_store(&task[g].cancel, 0);
-                    flag_store(&task[g].state, kTaskAssigned);
                 }
+                wave_sync();
+                if (lane == 0) flag_store(&task[g].state, kTaskAssigned);
 #pragma unroll
                 for (int r = 0; r < WR; r++)
                     if ((occupied >> r) & 1u && in_blob(r, pk, fo, (int)mn)) { shadow |= 1u << r; ever |= 1u << r; }
@@ -1180,7 +1223,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 st[5] += __ballot(was_shadowed) != 0ull ? 1 : 0;
             }
 
-            // ---- 4. the head: the smallest-index live seed; everything before it is decided
+            // ---- 5. the head: the smallest-index live seed; everything before it is decided
             unsigned hd = kNone;
 #pragma unroll
             for (int r = 0; r < WR; r++)
@@ -1201,7 +1244,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             }
             if (hg < 0) {
                 // A head that was never handed out, or whose growth was stopped by a prediction that did not
-                // come true.  It is never shadowed (a live candidate shadowing it would be the head), so step 3
+                // come true.  It is never shadowed (a live candidate shadowing it would be the head), so step 4
                 // takes it as soon as a grower is idle.  If every grower holds or grows a LATER seed that
                 // none of the commits to come can free, the latest of them is given up.
                 if (__ballot(is_grower_lane && (flag_load(&task[lane].state) == kTaskIdle || flag_peek(&task[lane].cancel))) != 0ull) {
@@ -1219,7 +1262,6 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 for (int r = 0; r < WR; r++)
                     if ((occupied >> r) & 1u && (s_if[r] & kIdxMask) == vseed) emitted &= ~(1u << r);
                 st[4]++;
-                need_shadow = true;
                 continue;
             }
             if (flag_load(&task[hg].state) != kTaskDone) {
@@ -1228,15 +1270,19 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 continue;
             }
 
-            // ---- 5. commit: the head's pose is accepted (:213-230)
+            // ---- 6. commit: the head's pose is accepted (:213-230)
             const PoseView q = pose_of_block(private_base, hg - 1, K, A);
             unsigned dead = 0u;                          // pooled seeds inside one of its joint boxes (:211 for them)
+            {
+                OccBox bb[WR];
 #pragma unroll
-            for (int r = 0; r < WR; r++)
-                if ((occupied >> r) & 1u &&
-                    (box_contains(q.box[(unsigned)s_if[r] >> 24], s_pack[r] & 0xfff, (s_pack[r] >> 12) & 0xfff) ||
-                     (unsigned)(s_if[r] & kIdxMask) == hd))
-                    dead |= 1u << r;
+                for (int r = 0; r < WR; r++) bb[r] = q.box[(occupied >> r) & 1u ? (unsigned)s_if[r] >> 24 : 0u];
+#pragma unroll
+                for (int r = 0; r < WR; r++)
+                    if ((occupied >> r) & 1u &&
+                        (box_contains(bb[r], s_pack[r] & 0xfff, (s_pack[r] >> 12) & 0xfff) || (unsigned)(s_if[r] & kIdxMask) == hd))
+                        dead |= 1u << r;
+            }
             {   // growths of seeds that just died: drop finished ones, stop running ones
                 int n_drop = 0, n_stop = 0;
 #pragma unroll
@@ -1246,19 +1292,28 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                         if (flag_load(&task[g].state) == kTaskDone) { flag_store(&task[g].state, kTaskIdle); n_drop++; }
                         else { flag_store(&task[g].cancel, 1); n_stop++; }
                     }
+                if (__ballot(n_drop + n_stop > 0) != 0ull) {
 #pragma unroll
-                for (int k = 0; k < WR; k++) { st[3] += __popcll(__ballot(n_drop > k)); st[2] += __popcll(__ballot(n_stop > k)); }
+                    for (int k = 0; k < WR; k++) { st[3] += __popcll(__ballot(n_drop > k)); st[2] += __popcll(__ballot(n_stop > k)); }
+                }
             }
 #pragma unroll
             for (int r = 0; r < WR; r++)
-                if ((dead >> r) & 1u) { occupied &= ~(1u << r); emitted &= ~(1u << r); s_if[r] |= kIdxMask; }
+                if ((dead >> r) & 1u) {
+                    occupied &= ~(1u << r); emitted &= ~(1u << r); s_if[r] |= kIdxMask;
+                    pool_if[r * kWave + lane] = s_if[r];
+                }
             count_live();
+            if (a.trace && st[1] < kAssocTrace && lane == 0) {
+                int* tr = a.trace + ((size_t)b * kAssocTrace + st[1]) * 4;
+                tr[0] = (int)(wall_clock64() - t_kernel); tr[1] = task[hg].t_emit; tr[2] = task[hg].t_done;
+                tr[3] = (int)hd | (hg << 24);
+            }
             accept_pose(hg - 1, task[hg].score, -1);
             bitmap_dirty = true;
             st[1]++;
             wave_sync();                                 // every lane has read block hg-1
             if (lane == 0) flag_store(&task[hg].state, kTaskIdle);
-            need_shadow = true;
         }
         if (lane == 0) {
             sh_ctl[1] = watchdog ? 0 : n_kept; sh_ctl[2] = n_dropped; sh_ctl[5] = watchdog ? 1 : 0;
@@ -1296,7 +1351,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             c.jv[sf] = (double)sd.x; c.jx[sf] = sd.y; c.jy[sf] = sd.z; c.js[sf] = sd.w;   // :213-218
             wave_sync();
             c.aborted = 0;
-            c.pub = &my->npub; c.n_pub = 0;
+            c.pub = &my->npub; c.n_pub = 0; c.my_idx = mine;
+            c.pool_if = pool_if; c.pool_pack = pool_pack; c.shadow_mine = shadow_by + wave * kWave;
             publish_joint(c, p, sf, sd.y, sd.z, sd.w);   // the seed joint's own box: the rest of its blob
             grow_pose<REG>(c, p, rs, true, 1.0, false);
             c.pub = nullptr;
@@ -1306,7 +1362,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 pose_boxes(c, p);
                 wave_sync();
                 const double sc = pose_score(c.jv, K);
-                if (lane == 0) { my->score = sc; flag_store(&my->state, kTaskDone); }
+                if (lane == 0) { my->score = sc; my->t_done = (int)(wall_clock64() - t_kernel); flag_store(&my->state, kTaskDone); }
             }
             busy_ticks += wall_clock64() - t0;
         }
@@ -1459,7 +1515,8 @@ static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, con
     const size_t shared = sizeof(double) * a.max_ann
                         + sizeof(unsigned long long) * ((size_t)a.max_ann * KC)
                         + sizeof(TaskSlot) * NW
-                        + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann + 8 + kAssocStats) + 32;
+                        + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann + 8 + kAssocStats)
+                        + sizeof(int) * (2 * kPoolSlots + NW) * kWave + 32;
     // work area behind it: one private block per grower while poses grow, the keypoint-NMS scratch afterwards
     const size_t priv = assoc_private_bytes(K, A);
     const size_t budget = 160 * 1024;

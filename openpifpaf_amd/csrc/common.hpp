@@ -28,7 +28,7 @@ struct Layout {
     // byte offsets into the workspace (all 256-B aligned)
     size_t off_hdr, off_tile_clean, off_cifhr, off_act, off_act_count, off_seed_keys, off_seed_count,
            off_seed_f, off_seed_vxys, off_seed_cell, off_lists, off_list_counts,
-           off_lists_fc, off_list_counts_fc, off_occ, off_anns, off_ann_meta, off_status, off_stats,
+           off_lists_fc, off_list_counts_fc, off_occ, off_anns, off_ann_meta, off_status, off_stats, off_trace,
            total;
     size_t occ_image_words;               // 32-bit words of one image's occupancy bitmap (capacity)
 };
@@ -101,6 +101,7 @@ struct AssocArgs {
     unsigned* occ;           // occupancy bitmap [B][occ_image_words]: per image [F][occ_h][(occ_w+31)/32] words, zeroed by the kernel
     size_t occ_image_words;
     int32_t* stats;          // [B, 16] statistics of the association (or null), see include/openpifpaf_amd.h
+    int32_t* trace;          // [B, 64, 4] the first commits of each image (or null): commit / hand-out / done tick, seed | grower << 24
     double* anns;            // [B, max_ann, K, 4] doubles (v,x,y,s) scratch
     int64_t* ann_ids;        // [B, max_ann]
     const float* initial; const int64_t* initial_ids;

@@ -104,21 +104,22 @@ def test_bf16_network_head_outputs(native, port, coco_skeleton0):
         port.set_seed_tie_rule(0)
 
 
-def test_wrong_blob_mate_predictions_are_resolved(native, port, coco_skeleton0):
-    """The association kernel hands out candidates ahead of the commit point and PREDICTS that the other seeds
-    of a candidate's confidence blob die with it.  Noisy CIF regressions spread one blob's seeds over several
-    occupancy boxes, so candidates get cancelled while blob mates they shadowed are still free: those must be
-    handed out afterwards (statistics slot 5, "mispredictions") and the result must still be the sequential
-    loop's.  Also runs every image with 1 and 3 growers only (OPA_ASSOC_GROWERS): other interleavings."""
+def test_wrong_predictions_are_resolved(native, port, coco_skeleton0):
+    """The association kernel hands out candidates ahead of the commit point and PREDICTS which pooled seeds die
+    with a candidate in flight (those inside a joint box it has published); growths of such seeds are even
+    stopped.  When the candidate dies instead -- covered by an earlier pose -- the seeds it shadowed are free
+    again and must be handed out after all (statistics slot 5), and the result must still be the sequential
+    loop's.  Crowded images make that happen; noisy CIF regressions add blobs spread over several boxes.  Every
+    image is also decoded with 1 and 3 growers only (OPA_ASSOC_GROWERS): other interleavings, same result."""
     import os
     from openpifpaf_amd import synth
     rng = np.random.default_rng(11)
     cases = []
-    for i in range(24):
-        people = int(rng.integers(2, 12))
-        cases.append(synth.synth_fields(7000 + i, people, height=49, width=57,
-                                        cif_noise=float(rng.choice([0.4, 0.7, 1.0, 1.5])),
-                                        size_range=(0.3, 0.8)))
+    for i in range(12):
+        cases.append(synth.synth_fields(7000 + i, int(rng.integers(2, 12)), height=57, width=65,
+                                        cif_noise=float(rng.choice([0.2, 0.4, 0.7])), size_range=(0.3, 0.8)))
+    for i in range(12):
+        cases.append(synth.synth_fields(7100 + i, int(rng.integers(8, 22)), height=57, width=65))
     cifs = np.stack([c for c, _ in cases]); cafs = np.stack([f for _, f in cases])
     want = [port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)[0] for b in range(len(cases))]
     totals = None
@@ -137,10 +138,10 @@ def test_wrong_blob_mate_predictions_are_resolved(native, port, coco_skeleton0):
             totals = stats.sum(axis=0)
         else:
             assert (stats[:, 13] == int(growers)).all()
-    print('growths started %d, accepted %d, cancelled in flight %d, finished but dropped %d, given up %d, '
-          'mispredictions %d' % tuple(totals[:6]))
+    print('growths started %d, accepted %d, stopped (seed died) %d, finished but dropped %d, stopped or given up on '
+          'a prediction %d, handed out after a wrong prediction %d' % tuple(totals[:6]))
     assert totals[5] > 0, 'no wrong prediction occurred: the inputs no longer exercise that branch'
-    assert totals[2] + totals[3] > 0, 'no speculative growth was ever discarded'
+    assert totals[2] + totals[3] + totals[4] > 0, 'no speculative growth was ever discarded'
     assert totals[0] == totals[1] + totals[2] + totals[3] + totals[4]
 
 

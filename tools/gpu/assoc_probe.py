@@ -39,3 +39,14 @@ for _ in range(10):
         acc.setdefault(name, []).append(ms)
 print('  '.join('%s %.1f us' % (k.replace('_kernel', ''), 1e3 * np.mean(v)) for k, v in acc.items()),
       ' | decode %.3f ms' % sum(np.mean(v) for v in acc.values()))
+if os.environ.get('OPA_TRACE_IMAGE'):
+    b = int(os.environ['OPA_TRACE_IMAGE'])
+    tr = dec.workspace_view('assoc_trace', torch.int32).view(B, 64, 4)[b].cpu().numpy()
+    n = int(st[b][1])
+    print('image %d: commit#  seed  grower  handed-out-us  done-us  commit-us  (growth us, waited-for-growth us)' % b)
+    prev = 0
+    for k in range(min(n, 64)):
+        tc, te, td, sg = [int(v) for v in tr[k]]
+        print('  %3d %6d %3d %9.1f %9.1f %9.1f   growth %6.1f  head waited %6.1f' % (
+            k, sg & 0xFFFFFF, sg >> 24, te / 100, td / 100, tc / 100, (td - te) / 100, max(0, td - prev) / 100))
+        prev = tc
