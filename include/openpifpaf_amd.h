@@ -167,12 +167,13 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
  * the previous / by this call), "cifhr", "seed_count", "seed_f", "seed_vxys", "seed_cell",
  * "lists", "list_counts", "lists_fc", "list_counts_fc", "occupancy",
  * "annotation_scratch", "status" (int32 [B]: poses dropped for lack of capacity; -1: the kernel's watchdog
- * fired), "assoc_stats" (int32 [B,16] per image: 0 growths started, 1 poses accepted, 2 growths stopped because
+ * fired), "assoc_stats" (int32 [B,24] per image: 0 growths started, 1 poses accepted, 2 growths stopped because
  * their seed died, 3 finished growths dropped for the same reason, 4 growths stopped or given up on a prediction
  * (the seed stays pooled), 5 seeds handed out after having been predicted dead, 6 pool refills, 7 seeds,
  * 8 ticks until the growth phase ended, 9 ticks of the kernel, 10 sum of the growers' busy ticks, 11 list
  * scans, 12 coordinator ticks spent in iterations that only waited for the head's growth, 13 growers,
- * 14 poses stored, 15 coordinator iterations; ticks are 10 ns), "assoc_trace" (int32 [B,64,4]: for the first
+ * 14 poses stored, 15 coordinator iterations, 16 of them waiting, 17/18/19 ticks in commits / refills / hand-outs,
+ * 20-23 reserved; ticks are 10 ns), "assoc_trace" (int32 [B,64,4]: for the first
  * 64 accepted poses of an image the tick of the commit, of the hand-out and of the end of the growth, and
  * seed index | grower << 24). */
 int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what,

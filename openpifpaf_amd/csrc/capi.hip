@@ -127,7 +127,7 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     L->off_anns = take(B * (size_t)L->max_ann * L->K * 4 * sizeof(double));
     L->off_ann_meta = take(B * (size_t)L->max_ann * sizeof(int64_t));
     L->off_status = take(B * sizeof(int32_t));
-    L->off_stats = take(B * 16 * sizeof(int32_t));
+    L->off_stats = take(B * 24 * sizeof(int32_t));
     L->off_trace = take(B * 64 * 4 * sizeof(int32_t));
     L->total = off;
     return true;

@@ -110,7 +110,7 @@ __device__ __forceinline__ ListView list_view(const ImageCtx& c, int bone, int d
 
 // -------------------------------------------------------- grow_connection_blend
 // cifcaf.cpp:32-103.  Returns false for the all-zero joint.
-struct BlendQuery { double x, y, xlo, xhi, ylo, yhi; float sigma2; };
+struct BlendQuery { double x, y, xlo, xhi, ylo, yhi; float sigma2; float fxlo, fxhi, fylo, fyhi; };
 struct BlendResult { double v; float x, y, s; int ok; };
 
 __device__ __forceinline__ BlendQuery make_query(double x, double y, double xy_scale, double filter_sigmas) {
@@ -121,7 +121,18 @@ __device__ __forceinline__ BlendQuery make_query(double x, double y, double xy_s
     q.sigma2 = (float)(0.25 * xy_scale * xy_scale);            // :48
     q.xlo = x - (double)sigma_filter; q.xhi = x + (double)sigma_filter;
     q.ylo = y - (double)sigma_filter; q.yhi = y + (double)sigma_filter;
+    // The window test (:54-57) compares a float entry with these doubles.  For a float v: v >= lo  <=>  v >= the
+    // smallest float >= lo, and v <= hi  <=>  v <= the largest float <= hi -- four float compares per entry
+    // instead of two conversions and four double compares, same outcome for every input.
+    auto round_up = [](double t) { float f = (float)t; if ((double)f < t) f = nextafterf(f, __builtin_inff()); return f; };
+    auto round_down = [](double t) { float f = (float)t; if ((double)f > t) f = nextafterf(f, -__builtin_inff()); return f; };
+    q.fxlo = round_up(q.xlo); q.fxhi = round_down(q.xhi);
+    q.fylo = round_up(q.ylo); q.fyhi = round_down(q.yhi);
     return q;
+}
+
+__device__ __forceinline__ bool passes_f(const BlendQuery& q, float x1, float y1) {
+    return x1 >= q.fxlo && x1 <= q.fxhi && y1 >= q.fylo && y1 <= q.fyhi;
 }
 
 __device__ __forceinline__ bool passes(const BlendQuery& q, float x1, float y1) {
@@ -267,7 +278,7 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int i = r * kWave + lane;
-        const bool pass = i < L.n && passes(q, x1[r], y1[r]);
+        const bool pass = i < L.n && passes_f(q, x1[r], y1[r]);
         const unsigned long long m = __ballot(pass);
         if (m == 0ull) continue;
         const int slot = cnt + __popcll(m & below);
@@ -335,7 +346,7 @@ __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const B
 #pragma unroll
         for (int r = 0; r < G; r++) {
             const int i = base + r * kWave + lane;
-            if (i < L.n && passes(q, x1[r], y1[r])) {
+            if (i < L.n && passes_f(q, x1[r], y1[r])) {
                 const float sc = score_of(q, x1[r], y1[r], cc[r]);
                 if (sc >= s1) { s1 = sc; i1 = i; }
             }
@@ -358,7 +369,7 @@ __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const B
 #pragma unroll
             for (int r = 0; r < G; r++) {
                 const int i = base + r * kWave + lane;
-                if (i >= L.n || i == i1 || !passes(q, x1[r], y1[r])) continue;
+                if (i >= L.n || i == i1 || !passes_f(q, x1[r], y1[r])) continue;
                 const float sc = score_of(q, x1[r], y1[r], cc[r]);
                 if (!(sc > 0.0f)) continue;
                 const int rank = i < i1 ? L.n + i : L.n - i;
@@ -876,7 +887,7 @@ struct __attribute__((aligned(16))) TaskSlot { int state, cancel, seed, npub, pk
 constexpr int kAssocTrace = 64;           // commits recorded per image in the optional trace ("assoc_trace")
 
 // statistics of one image, int32[kAssocStats] in the workspace ("assoc_stats"): see include/openpifpaf_amd.h
-constexpr int kAssocStats = 16;
+constexpr int kAssocStats = 24;
 // The coordinator and the growers wait for each other in LDS polling loops.  A protocol error must not hang
 // the device: after this many 10-ns ticks inside one launch every wait gives up, the image reports no poses
 // and status -1 (never seen in the tests; one second is ~1000x the slowest image).
@@ -1049,6 +1060,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         unsigned iter = 0;
         const unsigned long long lanes_below = (1ull << lane) - 1ull;
         const bool is_grower_lane = lane >= 1 && lane <= S;
+        __builtin_amdgcn_s_setprio(3);                   // everything sequential runs here: issue ahead of the growers
 #pragma unroll
         for (int r = 0; r < WR; r++) { s_pack[r] = 0; s_if[r] = kIdxMask; }
 
@@ -1084,9 +1096,9 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             // ---- 2. refill free slots with the next seeds that are still free in the bitmap (:211 for the
             //         poses accepted so far); slot (r, lane) takes the seed of its rank among the free slots
             if (scan_pos < n_seeds && 2 * n_live < WR * kWave) {
-                if (bitmap_dirty) {                      // this wave's marks (atomics at L2) before its own reads
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                const long long t_ph = wall_clock64();
+                if (bitmap_dirty) {                      // this wave's marks (atomics, performed at L2) before its own reads,
+                    __builtin_amdgcn_s_waitcnt(0x0F70);  // which bypass the L1 (agent-scope loads): vmcnt(0) is all it takes
                     bitmap_dirty = false;
                 }
                 unsigned fresh = 0u;                     // slots filled by this refill
@@ -1110,7 +1122,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     for (int r = 0; r < WR; r++) {
                         ow[r] = 0xFFFFFFFFu;
                         if (nidx[r] < n_seeds)
-                            ow[r] = c.occ[((size_t)ff[r] * c.occ_h + ((pk[r] >> 12) & 0xfff)) * c.occ_wpr + ((pk[r] & 0xfff) >> 5)];
+                            ow[r] = __hip_atomic_load(&c.occ[((size_t)ff[r] * c.occ_h + ((pk[r] >> 12) & 0xfff)) * c.occ_wpr + ((pk[r] & 0xfff) >> 5)],
+                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
 #pragma unroll
                     for (int r = 0; r < WR; r++)
@@ -1129,9 +1142,10 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 for (int r = 0; r < WR; r++)
                     if ((fresh >> r) & 1u) { pool_if[r * kWave + lane] = s_if[r]; pool_pack[r * kWave + lane] = s_pack[r]; }
                 for (int g = 1; g <= S; g++) {
+                    if (!((live_mask >> g) & 1ull)) continue;         // (its word is cleared when it is handed a seed)
                     unsigned* word = &shadow_by[g * kWave + lane];
                     if (fresh) atomicAnd(word, ~fresh);
-                    if (!((live_mask >> g) & 1ull) || rlane(g_pub, g) == 0) continue;
+                    if (rlane(g_pub, g) == 0) continue;
                     const int idx = rlane(g_seed, g);
                     const OccBox* bx = pose_of_block(private_base, g - 1, K, A).box;
                     OccBox bb[WR];
@@ -1144,6 +1158,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                             box_contains(bb[r], s_pack[r] & 0xfff, (s_pack[r] >> 12) & 0xfff)) bits |= 1u << r;
                     if (bits) atomicOr(word, bits);
                 }
+                st[18] += (int)(wall_clock64() - t_ph);
             }
 
             // ---- 3. Which pooled seeds lie in a joint box an EARLIER live candidate has published so far?  (The
@@ -1188,6 +1203,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
 
             // ---- 4. hand the next candidates, in seed order, to the idle growers
             unsigned long long idle = __ballot(g_state == kTaskIdle);
+            const long long t_em = idle ? wall_clock64() : 0;
+            const bool had_idle = idle != 0ull;
             while (idle) {
                 const unsigned elig = occupied & ~emitted & ~shadow;
                 unsigned mn = kNone;
@@ -1222,6 +1239,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 st[0]++;
                 st[5] += __ballot(was_shadowed) != 0ull ? 1 : 0;
             }
+            if (had_idle) st[19] += (int)(wall_clock64() - t_em);
 
             // ---- 5. the head: the smallest-index live seed; everything before it is decided
             unsigned hd = kNone;
@@ -1267,8 +1285,10 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             if (flag_load(&task[hg].state) != kTaskDone) {
                 __builtin_amdgcn_s_sleep(2);
                 wait_ticks += wall_clock64() - t_iter;   // an iteration that only waited for the head's growth
+                st[16]++;
                 continue;
             }
+            const long long t_cm = wall_clock64();
 
             // ---- 6. commit: the head's pose is accepted (:213-230)
             const PoseView q = pose_of_block(private_base, hg - 1, K, A);
@@ -1314,11 +1334,13 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             st[1]++;
             wave_sync();                                 // every lane has read block hg-1
             if (lane == 0) flag_store(&task[hg].state, kTaskIdle);
+            st[17] += (int)(wall_clock64() - t_cm);
         }
         if (lane == 0) {
             sh_ctl[1] = watchdog ? 0 : n_kept; sh_ctl[2] = n_dropped; sh_ctl[5] = watchdog ? 1 : 0;
             flag_store(&sh_ctl[0], 1);                   // growers leave
         }
+        __builtin_amdgcn_s_setprio(0);
         st[7] = n_seeds;
         st[8] = (int)(wall_clock64() - t_kernel);
         st[12] = (int)wait_ticks;

@@ -231,11 +231,11 @@ class CifCaf:
         return ws[off.value:off.value + size.value].view(dtype)
 
     def assoc_stats(self):
-        """Statistics of the last ``call_batch``'s association kernel: int32 ``[B,16]`` (see
+        """Statistics of the last ``call_batch``'s association kernel: int32 ``[B,24]`` (see
         ``opa_cifcaf_workspace_view`` in the header): growths started / accepted / cancelled / dropped,
         mispredictions, ticks."""
         shape, _ = self._last
-        return self.workspace_view('assoc_stats', torch.int32).view(shape.batch, 16)
+        return self.workspace_view('assoc_stats', torch.int32).view(shape.batch, 24)
 
     def get_cifhr(self, image=0):
         """module.cpp:37-39 -> (Tensor [F,Hhr,Whr] view of the internal buffer, revision)."""
