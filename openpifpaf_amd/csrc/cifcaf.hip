@@ -52,7 +52,7 @@
 
 namespace opa {
 
-constexpr int kAssocWavesDefault = 16;   // waves per workgroup of the association kernel (OPA_ASSOC_WAVES = 8 | 12 | 16)
+constexpr int kAssocWavesDefault = 12;   // waves per workgroup of the association kernel (OPA_ASSOC_WAVES = 8 | 12 | 16)
 constexpr int kBlendChunks = 8;
        // list entries per lane held in registers by the single-pass scan
 
@@ -98,6 +98,7 @@ struct ImageCtx {
     // shared LDS
     int* sh_counts;                      // [2A] list lengths of the active list set
     int n_blend;                         // list scans of this wave (statistics)
+    int t_blend, t_blend_mem;            // ticks inside the scans, and of those until the loads had returned
 };
 
 __device__ __forceinline__ ListView list_view(const ImageCtx& c, int bone, int dir) {
@@ -248,8 +249,9 @@ constexpr int kBlendLdsFloats = kTgtFloats + 4 * kWave;  // + the compacted (x1,
 __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const BlendQuery& q, bool only_max);
 
 template <int R>
-__device__ __forceinline__ BlendResult blend_cached(const ListView& L, const BlendQuery& q, bool only_max, float* tgt) {
+__device__ __forceinline__ BlendResult blend_cached(const ListView& L, const BlendQuery& q, bool only_max, float* tgt, int* t_mem) {
     const int lane = lane_id();
+    const long long t_issue = t_mem ? wall_clock64() : 0;
     const gfloat* g = (const gfloat*)L.base;
     // The target columns (x2, y2, s2) are needed for two entries only: they travel HBM/L2 -> LDS
     // directly (global_load_lds, no VGPRs), in flight together with the register loads below; chunk r of
@@ -272,6 +274,7 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
     }
 #pragma unroll
     for (int r = 0; r < R; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
+    if (t_mem) *t_mem += (int)(wall_clock64() - t_issue);
     float* cx = tgt + kTgtFloats; float* cy = cx + kWave; float* cv = cy + kWave; int* ci = (int*)(cv + kWave);
     const unsigned long long below = (1ull << lane) - 1ull;
     int cnt = 0;
@@ -388,21 +391,25 @@ __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const B
 // The one real (non-inlined) device function of the kernel: everything is passed and
 // returned by value in registers.
 __device__ __forceinline__ BlendResult blend_impl(const float* base, int cap, int n, double x, double y,
-                                               double xy_scale, double filter_sigmas, int only_max, float* tgt) {
+                                               double xy_scale, double filter_sigmas, int only_max, float* tgt,
+                                               int* t_mem = nullptr) {
     if (n <= 0) return blend_none();
     ListView L; L.base = base; L.cap = cap; L.n = n;
     const BlendQuery q = make_query(x, y, xy_scale, filter_sigmas);
-    if (n <= kWave) return blend_cached<1>(L, q, only_max != 0, tgt);
-    if (n <= 2 * kWave) return blend_cached<2>(L, q, only_max != 0, tgt);
-    if (n <= 4 * kWave) return blend_cached<4>(L, q, only_max != 0, tgt);
-    if (n <= kBlendChunks * kWave) return blend_cached<kBlendChunks>(L, q, only_max != 0, tgt);
+    if (n <= kWave) return blend_cached<1>(L, q, only_max != 0, tgt, t_mem);
+    if (n <= 2 * kWave) return blend_cached<2>(L, q, only_max != 0, tgt, t_mem);
+    if (n <= 4 * kWave) return blend_cached<4>(L, q, only_max != 0, tgt, t_mem);
+    if (n <= kBlendChunks * kWave) return blend_cached<kBlendChunks>(L, q, only_max != 0, tgt, t_mem);
     return blend_streamed(L, q, only_max != 0);
 }
 
 __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, double x, double y, double xy_scale,
                                              double filter_sigmas) {
     c.n_blend++;
-    return blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt);
+    const long long t0 = wall_clock64();
+    const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt, &c.t_blend_mem);
+    c.t_blend += (int)(wall_clock64() - t0);
+    return r;
 }
 
 // A joint was assigned (cifcaf.cpp:310): during the seed pipeline the grower publishes the occupancy box the
@@ -912,7 +919,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     c.list_cap = a.list_cap;
     c.occ_h = a.occ_h; c.occ_w = a.occ_w; c.occ_wpr = (a.occ_w + 31) >> 5;
     c.occ = a.occ + (size_t)b * a.occ_image_words;
-    c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.pub = nullptr; c.n_pub = 0;
+    c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
     c.pool_if = nullptr; c.pool_pack = nullptr; c.shadow_mine = nullptr; c.my_idx = 0;
 
     // ---- LDS carve: shared part, then one private block per growing wave
@@ -1389,7 +1396,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             busy_ticks += wall_clock64() - t0;
         }
         c.cancel = nullptr;
-        if (lane == 0) { atomicAdd(&sh_ctl[3], (int)busy_ticks); atomicAdd(&sh_ctl[4], c.n_blend); }
+        if (lane == 0) { atomicAdd(&sh_ctl[3], (int)busy_ticks); atomicAdd(&sh_ctl[4], c.n_blend); atomicAdd(&sh_ctl[6], c.t_blend); atomicAdd(&sh_ctl[7], c.t_blend_mem); }
     }
     sync_global();                        // stored poses visible to every wave; the private blocks are free
     n_kept = sh_ctl[1]; n_dropped = sh_ctl[2];
@@ -1524,7 +1531,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     }
     if (tid == 0 && a.stats) {
         sh_stats[9] = (int)(wall_clock64() - t_kernel);
-        sh_stats[10] = sh_ctl[3]; sh_stats[11] = sh_ctl[4];
+        sh_stats[10] = sh_ctl[3]; sh_stats[11] = sh_ctl[4]; sh_stats[21] = sh_ctl[6]; sh_stats[22] = sh_ctl[7];
         sh_stats[13] = S; sh_stats[14] = n_kept;
         for (int k = 0; k < kAssocStats; k++) a.stats[(size_t)b * kAssocStats + k] = sh_stats[k];
     }

@@ -18,8 +18,28 @@ def shard_bounds(n_items, rank, world_size):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def pack(annotations, ids, counts):
+    """One fixed-size block per image -- what travels between GPUs: ``int32 [B, 1 + max_ann * (4 K + 2)]`` holding
+    the count, the float32 annotation bits and the int64 ids (as two int32 each)."""
+    B, M = annotations.shape[0], annotations.shape[1]
+    return torch.cat([counts.reshape(B, 1).to(torch.int32),
+                      annotations.contiguous().view(torch.int32).reshape(B, -1),
+                      ids.contiguous().view(torch.int32).reshape(B, 2 * M)], dim=1).contiguous()
+
+
+def unpack_block(block, max_ann, n_keypoints):
+    """Inverse of :func:`pack`."""
+    B = block.shape[0]
+    n = max_ann * n_keypoints * 4
+    counts = block[:, 0].contiguous()
+    annotations = block[:, 1:1 + n].contiguous().view(torch.float32).reshape(B, max_ann, n_keypoints, 4)
+    ids = block[:, 1 + n:].contiguous().view(torch.int64).reshape(B, max_ann)
+    return annotations, ids, counts
+
+
 def gather_annotations(annotations, ids, counts, group=None):
-    """All-gather per-rank decode results in rank order.
+    """All-gather per-rank decode results in rank order with ONE collective per batch: counts,
+    annotations and ids are packed into one fixed-size int32 block per image.
 
     :param annotations: ``[B_local, max_ann, K, 4]`` float32
     :param ids: ``[B_local, max_ann]`` int64, :param counts: ``[B_local]`` int32
@@ -30,14 +50,13 @@ def gather_annotations(annotations, ids, counts, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return annotations, ids, counts
     world = dist.get_world_size(group)
-    outs = []
-    for t in (annotations, ids, counts):
-        t = t.contiguous()
-        buf = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-        dist.all_gather_into_tensor(buf, t, group=group) if t.is_cuda else \
-            dist.all_gather(list(buf.unbind(0)), t, group=group)
-        outs.append(buf.reshape((world * t.shape[0],) + tuple(t.shape[1:])))
-    return tuple(outs)
+    block = pack(annotations, ids, counts)
+    buf = torch.empty((world,) + tuple(block.shape), dtype=block.dtype, device=block.device)
+    if block.is_cuda:
+        dist.all_gather_into_tensor(buf, block, group=group)          # RCCL over xGMI
+    else:
+        dist.all_gather(list(buf.unbind(0)), block, group=group)      # gloo (CPU tests)
+    return unpack_block(buf.reshape(world * block.shape[0], block.shape[1]), annotations.shape[1], annotations.shape[2])
 
 
 def unpack(annotations, ids, counts, max_annotations=None):

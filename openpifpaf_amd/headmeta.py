@@ -194,3 +194,19 @@ def cocokp_dense_metas(upsample_stride=2, base_stride=16):
     dcaf.base_stride = base_stride
     dcaf.upsample_stride = upsample_stride
     return cif, caf, dcaf
+
+
+def wholebody_metas(upsample_stride=2, base_stride=16):
+    """The (Cif, Caf) pair of the reference's ``wholebody`` datamodule: 133 keypoints, 160 bones
+    (reference ``plugins/wholebody/wholebody.py:91-109``, constants ``plugins/wholebody/constants.py``)."""
+    from . import constants
+    wb = constants.wholebody()
+    cif = Cif('cif', 'wholebody', keypoints=wb['keypoints'], sigmas=wb['sigmas'], pose=wb['standing_pose'],
+              draw_skeleton=wb['skeleton'], score_weights=wb['score_weights'])
+    caf = Caf('caf', 'wholebody', keypoints=wb['keypoints'], sigmas=wb['sigmas'], pose=wb['standing_pose'],
+              skeleton=wb['skeleton'])
+    for i, m in enumerate((cif, caf)):
+        m.head_index = i
+        m.base_stride = base_stride
+        m.upsample_stride = upsample_stride
+    return cif, caf

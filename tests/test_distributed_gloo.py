@@ -28,7 +28,13 @@ WORKER = textwrap.dedent('''
         counts[i] = g %% (max_ann + 1)
         ann[i, :int(counts[i])] = float(g + 1)
         ids[i, :int(counts[i])] = g
+    calls = []
+    real_all_gather = dist.all_gather
+    dist.all_gather = lambda *a_, **k_: (calls.append(1), real_all_gather(*a_, **k_))[1]
     a, i_, c = D.gather_annotations(ann, ids, counts)
+    dist.all_gather = real_all_gather
+    assert len(calls) == 1, 'the annotations of a batch travel in ONE collective (SURVEY 8e), saw %%d' %% len(calls)
+    assert torch.equal(i_[lo:hi], ids) and torch.equal(a[lo:hi], ann)
     assert a.shape == (n_images, max_ann, K, 4) and c.tolist() == [g %% (max_ann + 1) for g in range(n_images)]
     per_image = D.unpack(a, i_, c)
     for g, (pa, pi) in enumerate(per_image):
@@ -81,3 +87,18 @@ def test_gather_is_identity_without_process_group():
     a, i, c = torch.zeros((2, 3, 17, 4)), torch.zeros((2, 3), dtype=torch.int64), torch.zeros((2,), dtype=torch.int32)
     out = D.gather_annotations(a, i, c)
     assert out[0] is a and out[1] is i and out[2] is c
+
+
+def test_pack_roundtrip_is_bit_exact():
+    import torch
+    from openpifpaf_amd import distributed as D
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn((4, 6, 17, 4), generator=g)
+    a[0, 0, 0, 0] = float('nan')
+    i = torch.randint(-3, 1 << 40, (4, 6), generator=g)
+    c = torch.tensor([0, 6, 3, 0x40000002], dtype=torch.int32)
+    block = D.pack(a, i, c)
+    assert block.dtype == torch.int32 and block.shape == (4, 1 + 6 * (17 * 4 + 2))
+    a2, i2, c2 = D.unpack_block(block, 6, 17)
+    assert torch.equal(a.view(torch.int32), a2.view(torch.int32)) and torch.equal(i, i2) and torch.equal(c, c2)
+    assert len(D.unpack(a2, i2, c2)[3][0]) == 2          # overflow bit masked: two valid rows
