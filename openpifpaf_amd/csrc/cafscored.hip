@@ -42,11 +42,15 @@ __global__ __launch_bounds__(kScoredThreads) void cafscored_kernel(
         bool keep_f = false, keep_b = false;
         float c = 0.f, cf = 0.f, cb = 0.f, x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, s1 = 0.f, s2 = 0.f;
         if (o < HW) {
+            // all seven planes of the cell are requested at once (the stage's compulsory bytes): one memory
+            // round trip before the two CifHr gathers instead of two
             c = P[1 * HW + o];
+            const float r2 = P[2 * HW + o], r3 = P[3 * HW + o], r4 = P[4 * HW + o], r5 = P[5 * HW + o],
+                        r6 = P[6 * HW + o], r7 = P[7 * HW + o];
             if (!((double)c < score_th)) {                               // caf_scored.cpp:44
-                x1 = P[2 * HW + o] * stride_f; y1 = P[3 * HW + o] * stride_f;   // :46-54
-                x2 = P[4 * HW + o] * stride_f; y2 = P[5 * HW + o] * stride_f;
-                s1 = P[6 * HW + o] * stride_f; s2 = P[7 * HW + o] * stride_f;
+                x1 = r2 * stride_f; y1 = r3 * stride_f;                  // :46-54
+                x2 = r4 * stride_f; y2 = r5 * stride_f;
+                s1 = r6 * stride_f; s2 = r7 * stride_f;
                 cf = c; cb = c;
                 if (!no_rescore) {                                       // :66-71
                     const float fhr = cifhr_value(hr, F, hr_rows, hr_cols, hr_pitch, j2, x2, y2, 0.0f);

@@ -329,13 +329,14 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
         layout_hash = (layout_hash ^ (unsigned long long)v) * 1099511628211ull;
     e = launch_cifhr(cif_dev, L.B, L.F, L.H, L.W, L.stride, 0.0, 1.0, p, cifhr, L.hr_rows, L.hr_pitch,
                      (float*)(ws + L.off_act), (int32_t*)(ws + L.off_act_count), st, false,
-                     (unsigned long long*)(ws + L.off_hdr), layout_hash, ws + L.off_tile_clean);   // cifcaf.cpp:140-141
+                     (unsigned long long*)(ws + L.off_hdr), layout_hash, ws + L.off_tile_clean,
+                     (int32_t*)(ws + L.off_seed_count));                                         // cifcaf.cpp:140-141
     if (e != hipSuccess) return fail_hip(e, "cifhr");
     e = launch_cifseeds(cif_dev, L.B, L.F, L.H, L.W, L.stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
                         (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap,
                         (int32_t*)(ws + L.off_seed_count), (int32_t*)(ws + L.off_seed_f),
                         (float*)(ws + L.off_seed_vxys), st, false, (int32_t*)(ws + L.off_seed_cell),
-                        L.occ_h, L.occ_w);                                                   // :144-146
+                        L.occ_h, L.occ_w, true);                                             // :144-146
     if (e != hipSuccess) return fail_hip(e, "cifseeds");
     e = launch_cafscored(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols, L.hr_pitch,
                          dec->dev.skeleton, p.caf_threshold, p.cif_floor, p.ablation_caf_no_rescore,

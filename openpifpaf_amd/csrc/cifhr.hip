@@ -43,9 +43,11 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
         const float* __restrict__ cif, int HW, int stride, float min_scale_f, double threshold,
         float neighbors_f, double factor, float* __restrict__ act, int32_t* __restrict__ act_count,
         unsigned long long* ws_header, unsigned long long layout_hash,
-        unsigned* __restrict__ tile_touch, int touch_words, int rows, int cols, int tiles_x) {
+        unsigned* __restrict__ tile_touch, int touch_words, int rows, int cols, int tiles_x,
+        int32_t* __restrict__ zero_per_image, int F) {
     __shared__ int wave_tot[2][kActiveCells][kActiveThreads / 64];
     const int plane = blockIdx.x;
+    if (zero_per_image && threadIdx.x == 0 && plane % F == 0) zero_per_image[plane / F] = 0;   // the image's seed counter
     unsigned* touch = tile_touch ? tile_touch + (size_t)plane * touch_words : nullptr;   // one bit per tile of this plane
     if (touch) {
         for (int k = threadIdx.x; k < touch_words; k += kActiveThreads) touch[k] = 0u;
@@ -65,11 +67,16 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
     // kActiveCells cells per thread and step: their confidence loads are in flight together; cell order
     // (r, wave, lane) is raster order, and the list keeps it
     for (int c0 = 0; c0 < HW; c0 += kActiveThreads * kActiveCells, parity ^= 1) {
-        float vin[kActiveCells];
+        // all four planes of every cell are requested at once (they are this kernel's compulsory bytes anyway):
+        // one memory round trip per step instead of two dependent ones
+        float vin[kActiveCells], xin[kActiveCells], yin[kActiveCells], sin_[kActiveCells], hin[kActiveCells];
 #pragma unroll
         for (int r = 0; r < kActiveCells; r++) {
             const int o = c0 + r * kActiveThreads + tid;
-            vin[r] = o < HW ? P[HW + o] : -1.0f;
+            const int oo = o < HW ? o : 0;
+            vin[r] = o < HW ? P[HW + oo] : -1.0f;
+            xin[r] = P[2 * HW + oo]; yin[r] = P[3 * HW + oo]; sin_[r] = P[4 * HW + oo];
+            hin[r] = DET ? P[5 * HW + oo] : 0.0f;
         }
         bool on[kActiveCells];
         float v16[kActiveCells], x[kActiveCells], y[kActiveCells], sigma[kActiveCells];
@@ -79,11 +86,11 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
             on[r] = false; v16[r] = 0.f; x[r] = 0.f; y[r] = 0.f; sigma[r] = 0.f;
             const float v = vin[r];
             if (o < HW && !((double)v < threshold)) {             // cif_hr.cpp:39
-                const float scale = P[4 * HW + o];
+                const float scale = sin_[r];
                 bool big_enough;
                 double sigma_d;
                 if (DET) {                                        // cif_hr.cpp:135-141
-                    const float h = P[5 * HW + o];
+                    const float h = hin[r];
                     big_enough = !(scale < min_scale_f || h < min_scale_f);
                     sigma_d = 0.1 * (double)fminf(scale, h) * (double)stride;
                 } else {                                          // cif_hr.cpp:42,46
@@ -92,8 +99,8 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
                 }
                 if (big_enough) {
                     on[r] = true;
-                    x[r] = P[2 * HW + o] * stride_f;              // cif_hr.cpp:44-45
-                    y[r] = P[3 * HW + o] * stride_f;
+                    x[r] = xin[r] * stride_f;                     // cif_hr.cpp:44-45
+                    y[r] = yin[r] * stride_f;
                     sigma[r] = fmaxf(1.0f, (float)sigma_d);
                     v16[r] = (float)((double)(v / neighbors_f) * factor);                 // :51
                     if (touch) {                                  // tiles this cell's box overlaps
@@ -282,7 +289,8 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
                         double min_scale, double factor, const DevParams& p,
                         float* cifhr, int hr_rows, int hr_pitch,
                         float* act, int32_t* act_count, hipStream_t st, bool det,
-                        unsigned long long* ws_header, unsigned long long layout_hash, unsigned char* tile_state) {
+                        unsigned long long* ws_header, unsigned long long layout_hash, unsigned char* tile_state,
+                        int32_t* zero_per_image) {
     const int planes = B * F, HW = H * W;
     const int hr_cols = (W - 1) * stride + 1;
     const int tiles_x = hr_pitch / kHrTileW;
@@ -294,6 +302,7 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
     if (p.ablation_cifhr_skip && !det) {              // cif_hr.cpp:29
         hipError_t e = hipMemsetAsync(act_count, 0, sizeof(int32_t) * planes, st);
         if (e != hipSuccess) return e;
+        if (zero_per_image) { e = hipMemsetAsync(zero_per_image, 0, sizeof(int32_t) * B, st); if (e != hipSuccess) return e; }
         prof_mark(st, "memset_act_count");
         if (ws_header) {                              // no kernel validates the flags on this path: invalidate them
             e = hipMemsetAsync(ws_header, 0xFF, 32, st);
@@ -306,11 +315,11 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
         if (det)
             cif_active_kernel<true><<<planes, kActiveThreads, 0, st>>>(cif, HW, stride, min_scale_f, p.cif_threshold,
                                                              (float)p.cifhr_neighbors, factor, act, act_count, ws_header, layout_hash,
-                                                             tile_touch, touch_words, hr_rows, hr_cols, tiles_x);
+                                                             tile_touch, touch_words, hr_rows, hr_cols, tiles_x, zero_per_image, F);
         else
             cif_active_kernel<false><<<planes, kActiveThreads, 0, st>>>(cif, HW, stride, min_scale_f, p.cif_threshold,
                                                               (float)p.cifhr_neighbors, factor, act, act_count, ws_header, layout_hash,
-                                                              tile_touch, touch_words, hr_rows, hr_cols, tiles_x);
+                                                              tile_touch, touch_words, hr_rows, hr_cols, tiles_x, zero_per_image, F);
         prof_mark(st, "cif_active_kernel");
     }
     cifhr_tile_kernel<<<planes * kTileGroups, 256, 0, st>>>(act, act_count, HW, cifhr, hr_rows, hr_cols, hr_pitch,

@@ -17,6 +17,10 @@
 //      writes the sorted (f, v, x, y, s) arrays the association kernel streams.
 #include "common.hpp"
 
+#ifdef OPA_SORT_RADIX
+#include <rocprim/block/block_radix_sort.hpp>
+#endif
+
 namespace opa {
 
 __device__ __forceinline__ unsigned sortable_bits(float v) {
@@ -39,11 +43,13 @@ __global__ __launch_bounds__(256) void cifseeds_fill_kernel(
     const int b = plane / F, f = plane - b * F;
     const int lane = threadIdx.x & 63;
     const float* P = cif + (size_t)plane * NC * HW;
-    int o[kFillCells]; float c[kFillCells]; bool on[kFillCells];
+    int o[kFillCells]; float c[kFillCells], xin[kFillCells], yin[kFillCells]; bool on[kFillCells];
 #pragma unroll
-    for (int r = 0; r < kFillCells; r++) {
+    for (int r = 0; r < kFillCells; r++) {                           // confidence and position of every cell in one round trip
         o[r] = (blockIdx.y * kFillCells + r) * 256 + threadIdx.x;
-        c[r] = o[r] < HW ? P[HW + o[r]] : -1.0f;
+        const int oo = o[r] < HW ? o[r] : 0;
+        c[r] = o[r] < HW ? P[HW + oo] : -1.0f;
+        xin[r] = P[2 * HW + oo]; yin[r] = P[3 * HW + oo];
     }
 #pragma unroll
     for (int r = 0; r < kFillCells; r++) {
@@ -61,8 +67,8 @@ __global__ __launch_bounds__(256) void cifseeds_fill_kernel(
                 if (c[r] < m) on[r] = false;
             }
             if (on[r]) {
-                const float x = P[2 * HW + o[r]] * (float)stride;    // :53-54
-                const float y = P[3 * HW + o[r]] * (float)stride;
+                const float x = xin[r] * (float)stride;              // :53-54
+                const float y = yin[r] * (float)stride;
                 if (!no_rescore) {                                   // :56-58
                     const float hv = cifhr_value(cifhr + (size_t)b * F * hr_rows * hr_pitch,
                                                  F, hr_rows, hr_cols, hr_pitch, f, x, y, -1.0f);
@@ -98,12 +104,30 @@ __device__ __forceinline__ void compare_exchange_desc(unsigned long long& a, uns
     if ((a < b) == desc) { const unsigned long long t = a; a = b; b = t; }
 }
 
+// n <= 8192 keys: a block-wide LSD radix sort (rocPRIM's block primitive, 8 keys per thread, 64 KB LDS) over the
+// bits that can differ -- the 32 score bits and as many index bits as the field has cells -- instead of the 91
+// compare-exchange passes of a bitonic network.  The key order (score descending, then cell index ascending) is a
+// total order, so the result does not depend on the algorithm.
+// (Measured on the bench batch: 72.7 us against 74.0 us for the bitonic network below -- the kernel is bound by the
+// busiest image's serial passes either way -- so the hand-written network stays the default; -DOPA_SORT_RADIX.)
+#ifdef OPA_SORT_RADIX
+using SeedRadixSort = rocprim::block_radix_sort<unsigned long long, 1024, kSortLdsKeys / 1024>;
+#endif
+
 __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
         unsigned long long* keys, int sort_cap, int cap, const int32_t* __restrict__ seed_count,
         const float* __restrict__ cif, int F, int NC, int HW, int stride,
         int32_t* __restrict__ seed_f, float* __restrict__ seed_vxys,
         int32_t* __restrict__ seed_cell, int occ_h, int occ_w, DevParams p) {
+#ifdef OPA_SORT_RADIX
+    __shared__ union {
+        unsigned long long keys[kSortLdsKeys];
+        typename SeedRadixSort::storage_type radix;
+    } lds;
+    unsigned long long* sk = lds.keys;
+#else
     __shared__ unsigned long long sk[kSortLdsKeys];
+#endif
     const int b = blockIdx.x, tid = threadIdx.x;
     unsigned long long* K = keys + (size_t)b * sort_cap;
     int n = seed_count[b];
@@ -112,6 +136,29 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
     while (n_pad < n) n_pad <<= 1;
     const bool in_lds = n_pad <= kSortLdsKeys;
 
+#ifdef OPA_SORT_RADIX
+    if (in_lds && n_pad > 1024) {
+        constexpr int IPT = kSortLdsKeys / 1024;
+        int idx_bits = 1;
+        while ((1 << idx_bits) < cap) idx_bits++;                   // cell indices are < cap = F*H*W
+        const unsigned long long idx_mask = (1ull << idx_bits) - 1ull;
+        unsigned long long v[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {                             // blocked arrangement: thread t holds keys t*IPT ..
+            const int t = tid * IPT + i;
+            const unsigned long long key = t < n ? K[t] : 0ull;
+            v[i] = t < n ? ((key >> 32) << idx_bits) | (key & idx_mask) : 0ull;     // low word = ~cell index
+        }
+        SeedRadixSort().sort_desc(v, lds.radix, 0, 32 + idx_bits);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            const unsigned long long k2 = v[i];
+            sk[tid * IPT + i] = ((k2 >> idx_bits) << 32) | (0xFFFFFFFFull & ~idx_mask) | (k2 & idx_mask);
+        }
+        __syncthreads();
+    } else
+#endif
     if (in_lds) {
         for (int t = tid; t < n_pad; t += 1024) sk[t] = t < n ? K[t] : 0ull;
         __syncthreads();
@@ -282,11 +329,13 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
                            const float* cifhr, int hr_rows, int hr_cols, int hr_pitch, const DevParams& p,
                            unsigned long long* keys, int sort_cap, int32_t* seed_count,
                            int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det,
-                           int32_t* seed_cell, int occ_h, int occ_w) {
+                           int32_t* seed_cell, int occ_h, int occ_w, bool count_is_zero) {
     const int HW = H * W, cap = F * HW, NC = det ? 6 : 5;
-    hipError_t e = launch_zero(seed_count, sizeof(int32_t) * B, st);
-    if (e != hipSuccess) return e;
-    prof_mark(st, "memset_seed_count");
+    if (!count_is_zero) {                             // (the decode pipeline clears the counters in its first kernel)
+        hipError_t e = launch_zero(seed_count, sizeof(int32_t) * B, st);
+        if (e != hipSuccess) return e;
+        prof_mark(st, "memset_seed_count");
+    }
     dim3 grid(B * F, (HW + 256 * kFillCells - 1) / (256 * kFillCells));
     cifseeds_fill_kernel<<<grid, 256, 0, st>>>(cif, F, NC, H, W, stride, cifhr, hr_rows, hr_cols, hr_pitch,
                                                p.seed_threshold, det ? 0 : p.ablation_cifseeds_nms,

@@ -12,7 +12,10 @@ namespace opa {
 
 constexpr int kWave = 64;                 // CDNA4 wavefront width
 constexpr int kHrTileW = 64;              // CifHr tile width  (one 256-B row segment)
-constexpr int kHrTileH = 32;              // CifHr tile height
+#ifndef OPA_HR_TILE_H
+#define OPA_HR_TILE_H 32
+#endif
+constexpr int kHrTileH = OPA_HR_TILE_H;   // CifHr tile height
 constexpr int kHrLdsPitch = kHrTileW + 16;// LDS row pitch: +16 banks so a 16x4 patch is conflict free
 constexpr int kSortLdsKeys = 8192;        // 64 KiB of u64 keys sorted inside LDS
 
@@ -68,7 +71,7 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
                         float* cifhr, int hr_rows, int hr_pitch,
                         float* act, int32_t* act_count, hipStream_t st, bool det = false,
                         unsigned long long* ws_header = nullptr, unsigned long long layout_hash = 0,
-                        unsigned char* tile_state = nullptr);
+                        unsigned char* tile_state = nullptr, int32_t* zero_per_image = nullptr);
 
 // Workspace header (first 256 bytes): [0] magic, [1] hash of the layout the stored tile bitmap describes,
 // [2] 1 = stored bitmap invalid for this call (written by the first kernel of a call).
@@ -78,7 +81,7 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
                            const float* cifhr, int hr_rows, int hr_cols, int hr_pitch, const DevParams& p,
                            unsigned long long* keys, int sort_cap, int32_t* seed_count,
                            int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det = false,
-                           int32_t* seed_cell = nullptr, int occ_h = 0, int occ_w = 0);
+                           int32_t* seed_cell = nullptr, int occ_h = 0, int occ_w = 0, bool count_is_zero = false);
 
 hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
