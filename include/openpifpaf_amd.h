@@ -269,6 +269,18 @@ int opa_gemm_pro_bias_act_bf16(const void* a_dev, const void* a_bias_dev, const 
                                const void* residual_dev, void* out_dev, int64_t m, int32_t n, int32_t k,
                                int32_t relu, void* stream);
 
+/* The head of the field-producing network after its 1x1 convolution, in one pass (ref: network/heads.py:330-378
+ * CompositeField4.forward): PixelShuffle(upsample) -> crop -> [B, n_fields, n_components, H, W] float32 -> sigmoid on
+ * the n_confidences components after component 0, cell-index offsets on the vector components whose bit is set in
+ * vector_offset_mask (x index on the first, y index on the second of each pair), softplus on the n_scales
+ * components behind them.
+ *  conv_dev  the convolution's output, channels-last [B, hc, wc, n_fields*n_components*upsample^2],
+ *            dtype 0 = float32, 1 = float16, 2 = bfloat16
+ *  out_dev   float32 [B, n_fields, n_components, H, W], H = hc*upsample - (upsample-1) (likewise W); upsample 1 or 2 */
+int opa_head_epilogue(const void* conv_dev, int32_t dtype, int32_t batch, int32_t hc, int32_t wc,
+                      int32_t n_fields, int32_t n_components, int32_t upsample, int32_t n_confidences,
+                      int32_t n_vectors, uint32_t vector_offset_mask, int32_t n_scales, float* out_dev, void* stream);
+
 /* ---- measurement -------------------------------------------------------- */
 /* Per-kernel timing with HIP events on the launch stream (no reference
  * counterpart; bench.py's roofline leg uses it).  Between opa_profile_begin and

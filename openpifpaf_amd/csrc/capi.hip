@@ -605,6 +605,19 @@ int opa_gemm_pro_bias_act_bf16(const void* a_dev, const void* a_bias_dev, const 
     return OPA_OK;
 }
 
+int opa_head_epilogue(const void* conv_dev, int32_t dtype, int32_t batch, int32_t hc, int32_t wc,
+                      int32_t n_fields, int32_t n_components, int32_t upsample, int32_t n_confidences,
+                      int32_t n_vectors, uint32_t vector_offset_mask, int32_t n_scales, float* out_dev, void* stream) {
+    if (!conv_dev || !out_dev || batch <= 0 || hc <= 0 || wc <= 0 || n_fields <= 0 || n_components <= 0 ||
+        dtype < 0 || dtype > 2 || (upsample != 1 && upsample != 2) || n_confidences < 0 || n_vectors < 0 || n_scales < 0 ||
+        1 + n_confidences + 2 * n_vectors + n_scales > n_components)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_head_epilogue: bad arguments");
+    hipError_t e = launch_head_epilogue(conv_dev, dtype, batch, hc, wc, n_fields, n_components, upsample, n_confidences,
+                                        n_vectors, vector_offset_mask, n_scales, out_dev, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "head epilogue");
+    return OPA_OK;
+}
+
 int opa_profile_begin(void* stream) {
     for (hipEvent_t ev : g_prof.events) (void)hipEventDestroy(ev);
     g_prof.events.clear(); g_prof.names.clear();

@@ -225,8 +225,12 @@ class CifCaf(Decoder):
             heads[self.cif_metas[0].head_index], self.cif_metas[0].stride,
             heads[self.caf_metas[0].head_index], self.caf_metas[0].stride)
 
-    def batch(self, model, image_batch, *, device=None, gt_anns_batch=None):
-        """Image batch -> annotations batch, fields never leave the device."""
+    supports_device_inverse = True       # batch(..., meta_batch=...) undoes pad / rescale / flip on the device
+
+    def batch(self, model, image_batch, *, device=None, gt_anns_batch=None, meta_batch=None):
+        """Image batch -> annotations batch, fields never leave the device.  With ``meta_batch`` (the metas of the
+        preprocessing, no rotation) the annotations come back in ORIGINAL-image coordinates: the inverse transform
+        (reference ``annotation.py:162-200``) runs on the decoded tensor before its one small D2H copy."""
         start_nn = time.perf_counter()
         with torch.no_grad():
             if device is not None:
@@ -238,6 +242,9 @@ class CifCaf(Decoder):
 
         start_decoder = time.perf_counter()
         out, ids, counts = self.decode_heads(heads)
+        if meta_batch is not None:
+            from .annotation import inverse_transform_batch
+            out = inverse_transform_batch(out, meta_batch)
         out, ids, counts = out.cpu().numpy(), ids.cpu().numpy(), counts.cpu().numpy()   # one small D2H
         result = []
         for b in range(len(counts)):

@@ -156,3 +156,30 @@ def conv_bias_act(conv, x, bias, residual=None, relu=True, a_bias=None):
     if a_bias is not None:
         x = bias_act_(x, a_bias)
     return bias_act_(conv(x), bias, residual, relu)
+
+
+def head_epilogue_supported(x, meta, training=False):
+    """True if :func:`head_epilogue` can run for this convolution output and head meta."""
+    return (not training and x.is_cuda and x.dim() == 4 and x.dtype in _DTYPES and _lib.available()
+            and x.is_contiguous(memory_format=torch.channels_last) and meta.upsample_stride in (1, 2)
+            and x.shape[1] % (meta.upsample_stride ** 2) == 0 and x.data_ptr() % 16 == 0)
+
+
+def head_epilogue(x, meta):
+    """Everything ``CompositeField4`` does after its 1x1 convolution, in ONE kernel (reference
+    ``network/heads.py:330-378``): PixelShuffle -> crop -> ``[B, F, C, H, W]`` float32 -> sigmoid / index offsets /
+    softplus.  ``x``: the convolution output ``[B, F*C*us^2, hc, wc]``, channels_last."""
+    B, ctot, hc, wc = x.shape
+    us = meta.upsample_stride
+    n_comp = 1 + meta.n_confidences + meta.n_vectors * 2 + meta.n_scales
+    n_fields = ctot // (n_comp * us * us)
+    low_cut = (us - 1) // 2
+    high_cut = us - 1 - low_cut
+    H, W = hc * us - low_cut - high_cut, wc * us - low_cut - high_cut
+    out = torch.empty((B, n_fields, n_comp, H, W), dtype=torch.float32, device=x.device)
+    mask = sum(1 << i for i, on in enumerate(meta.vector_offsets) if on)
+    _lib.check(_lib.lib().opa_head_epilogue(
+        ctypes.c_void_p(x.data_ptr()), _DTYPES[x.dtype], B, hc, wc, n_fields, n_comp, us, meta.n_confidences,
+        meta.n_vectors, mask, meta.n_scales, ctypes.c_void_p(out.data_ptr()),
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'opa_head_epilogue')
+    return out

@@ -234,8 +234,12 @@ class CompositeField4(nn.Module):
         self.conv = nn.Conv2d(in_features, meta.n_fields * self.n_components * (meta.upsample_stride ** 2), 1)
         self.upsample_op = nn.PixelShuffle(meta.upsample_stride) if meta.upsample_stride > 1 else None
 
+    fused_epilogue = True      # one HIP kernel for everything behind the convolution (inference, channels_last)
+
     def forward(self, x):
         x = self.conv(x)
+        if self.fused_epilogue and fused.head_epilogue_supported(x, self.meta, self.training):
+            return fused.head_epilogue(x, self.meta)
         if self.upsample_op is not None:
             x = self.upsample_op(x)
             us = self.meta.upsample_stride

@@ -32,8 +32,47 @@ def _to_pil(image):
     return PIL.Image.fromarray(np.asarray(image, dtype=np.uint8)).convert('RGB')
 
 
-def preprocess_image(image, *, long_edge=None, batch_mode=False):
-    """-> (float32 tensor [3,H,W], meta) with the meta fields ``inverse_transform`` needs."""
+def zoom_linear_u8(frame, target_h, target_w):
+    """The reference's default rescale, ``scipy.ndimage.zoom(im, (th / h, tw / w, 1), order=1)`` on a uint8 image
+    (reference ``transforms/scale.py:57-63``), restated with torch ops so that it runs on the device: corner-aligned
+    coordinates ``j * (n_in - 1) / (n_out - 1)``, linear weights, the sum formed in double in scipy's order, rounded
+    like its uint8 output (``(uint8)(t + 0.5)``).  Pixel-equal to scipy (``tests/test_abi_and_host.py``).
+    ``frame``: uint8 ``[H, W, C]`` tensor on any device -> uint8 ``[target_h, target_w, C]``."""
+    h, w = frame.shape[:2]
+    dev = frame.device
+
+    def axis(n_in, n_out):
+        zoom = (n_in - 1) / (n_out - 1) if n_out > 1 else 0.0
+        cc = torch.arange(n_out, dtype=torch.float64, device=dev) * zoom
+        start = torch.floor(cc)
+        w0 = 1.0 - (cc - start)                      # each weight is 1 - |distance| of its own sample
+        w1 = 1.0 - ((start + 1.0) - cc)
+        i0 = start.to(torch.int64).clamp_(0, n_in - 1)
+        i1 = (i0 + 1).clamp_(max=n_in - 1)           # its weight is 0 wherever the clamp acts
+        outside = cc > (n_in - 1)                    # rounding can push the last coordinate past the edge: scipy's
+        return i0, i1, w0, w1, outside               # 'constant' mode then yields cval = 0 for that row / column
+    y0, y1, wy0, wy1, oy = axis(h, target_h)
+    x0, x1, wx0, wx1, ox = axis(w, target_w)
+    f = frame.to(torch.float64)
+    wy0, wy1 = wy0.view(-1, 1, 1), wy1.view(-1, 1, 1)
+    wx0, wx1 = wx0.view(1, -1, 1), wx1.view(1, -1, 1)
+    t = (f[y0][:, x0] * wy0) * wx0                   # (value * w_y) * w_x, summed in scipy's order
+    t = t + (f[y0][:, x1] * wy0) * wx1
+    t = t + (f[y1][:, x0] * wy1) * wx0
+    t = t + (f[y1][:, x1] * wy1) * wx1
+    t = torch.where(oy.view(-1, 1, 1) | ox.view(1, -1, 1), torch.zeros_like(t), t)
+    return torch.floor(t.clamp_(0.0, 255.0) + 0.5).to(torch.uint8)
+
+
+def _target_size(w0, h0, long_edge):
+    s = long_edge / max(h0, w0)                       # RescaleAbsolute, transforms/scale.py:160-165
+    return (int(w0 * s), int(long_edge)) if h0 > w0 else (int(long_edge), int(h0 * s))
+
+
+def preprocess_image(image, *, long_edge=None, batch_mode=False, fast=False):
+    """-> (float32 tensor [3,H,W], meta) with the meta fields ``inverse_transform`` needs.  ``fast``: the
+    reference's ``--fast-rescaling`` without OpenCV (PIL's antialiased bilinear resize) instead of its default,
+    scipy's order-1 zoom."""
     import PIL.Image
     image = _to_pil(image)
     w0, h0 = image.size
@@ -41,10 +80,11 @@ def preprocess_image(image, *, long_edge=None, batch_mode=False):
             'rotation': {'angle': 0.0, 'width': None, 'height': None},
             'valid_area': np.array((0.0, 0.0, w0 - 1, h0 - 1)), 'width_height': np.array((w0, h0))}
     if long_edge:
-        s = long_edge / max(h0, w0)
-        tw, th = (int(w0 * s), int(long_edge)) if h0 > w0 else (int(long_edge), int(h0 * s))
-        resample = getattr(PIL.Image, 'Resampling', PIL.Image).BILINEAR
-        image = image.resize((tw, th), resample)
+        tw, th = _target_size(w0, h0, long_edge)
+        if fast:
+            image = image.resize((tw, th), getattr(PIL.Image, 'Resampling', PIL.Image).BILINEAR)
+        else:                                         # the reference's default: scipy.ndimage.zoom, order 1
+            image = PIL.Image.fromarray(zoom_linear_u8(torch.from_numpy(np.array(image)), th, tw).numpy())
         sx, sy = (tw - 1) / (w0 - 1), (th - 1) / (h0 - 1)
         meta['offset'] *= (sx, sy)
         meta['scale'] *= (sx, sy)
@@ -70,33 +110,33 @@ def preprocess_image(image, *, long_edge=None, batch_mode=False):
 
 def preprocess_batch_device(images, *, long_edge, device):
     """Device-side form of ``preprocess_image`` for batch mode: the uint8 frames are
-    uploaded as they are (a quarter of the bytes of normalised float32), then rescaled to ``long_edge``
-    (bilinear with antialiasing, the filter PIL's BILINEAR resize applies), centre-padded to
+    uploaded as they are (a quarter of the bytes of normalised float32), rescaled to ``long_edge`` with the
+    reference's own arithmetic (:func:`zoom_linear_u8`, rounded to uint8 like the host path), centre-padded to
     ``long_edge x long_edge`` with the reference's fill colour and normalised -- all on ``device``.
-    -> (float32 ``[B,3,long_edge,long_edge]`` on ``device``, metas).  Pixel values agree with the host path
-    to within resampling round-off (PIL rounds the resized image to uint8, this path does not)."""
+    -> (float32 ``[B,3,long_edge,long_edge]`` on ``device``, metas).  The pixels EQUAL the host path's."""
     assert long_edge, '--long-edge must be provided for batch size > 1'
-    mean = torch.tensor(IMAGENET_MEAN, device=device).view(3, 1, 1)
-    std = torch.tensor(IMAGENET_STD, device=device).view(3, 1, 1)
-    fill = (torch.tensor((124.0, 116.0, 104.0), device=device).view(3, 1, 1) / 255.0 - mean) / std
-    batch = fill.expand(3, long_edge, long_edge).unsqueeze(0).repeat(len(images), 1, 1, 1).contiguous()
+    mean = torch.tensor(IMAGENET_MEAN, device=device, dtype=torch.float32).view(3, 1, 1)
+    std = torch.tensor(IMAGENET_STD, device=device, dtype=torch.float32).view(3, 1, 1)
+    canvas = torch.tensor((124, 116, 104), dtype=torch.uint8, device=device).view(1, 1, 1, 3)
+    canvas = canvas.expand(len(images), long_edge, long_edge, 3).contiguous()
     metas = []
     for b, image in enumerate(images):
-        frame = torch.from_numpy(np.ascontiguousarray(np.asarray(image, dtype=np.uint8)[..., :3]))
+        frame = torch.from_numpy(np.ascontiguousarray(np.asarray(_to_pil(image), dtype=np.uint8)))
         h0, w0 = frame.shape[:2]
-        s = long_edge / max(h0, w0)
-        tw, th = (int(w0 * s), int(long_edge)) if h0 > w0 else (int(long_edge), int(h0 * s))
-        x = frame.to(device, non_blocking=True).permute(2, 0, 1).unsqueeze(0).float()
-        x = torch.nn.functional.interpolate(x, size=(th, tw), mode='bilinear', antialias=True, align_corners=False)
-        x = (x[0] / 255.0 - mean) / std
+        tw, th = _target_size(w0, h0, long_edge)
+        x = zoom_linear_u8(frame.to(device, non_blocking=True), th, tw)
         left, top = max(0, int((long_edge - tw) / 2.0)), max(0, int((long_edge - th) / 2.0))
-        batch[b, :, top:top + th, left:left + tw] = x
+        canvas[b, top:top + th, left:left + tw] = x
         sx, sy = (tw - 1) / (w0 - 1), (th - 1) / (h0 - 1)
         metas.append({'offset': np.array((-float(left), -float(top))), 'scale': np.array((sx, sy)), 'hflip': False,
                       'rotation': {'angle': 0.0, 'width': None, 'height': None},
                       'valid_area': np.array((left, top, (w0 - 1) * sx, (h0 - 1) * sy), dtype=np.float64),
                       'width_height': np.array((w0, h0))})
-    return batch, metas
+    # ToTensor + Normalize exactly as the host path does them: float32(u8) / 255, then (x - mean) / std
+    # (a DEVICE tensor as divisor: dividing by a Python scalar is turned into a multiplication by 1/255 on the GPU,
+    # which rounds differently from the host's true division)
+    batch = canvas.permute(0, 3, 1, 2).to(torch.float32) / torch.full((1,), 255.0, dtype=torch.float32, device=device)
+    return ((batch - mean) / std).contiguous(), metas
 
 
 class Predictor:
@@ -153,7 +193,15 @@ class Predictor:
     def tensor_batch(self, processed_image_batch, meta_batch=None):
         """Predict from an already preprocessed ``[B,3,H,W]`` batch -> list (per image) of predictions."""
         model = _CallModel(self._forward)
-        pred_batch = self.processor.batch(model, processed_image_batch, device=None)
+        on_device = (meta_batch is not None and getattr(self.processor, 'supports_device_inverse', False)
+                     and self.device.type == 'cuda'
+                     and all((m.get('rotation') or {}).get('angle', 0.0) == 0.0 and not m.get('horizontal_swap')
+                             for m in meta_batch))
+        if on_device:            # pad / rescale / flip undone on the decoded tensor, before its one D2H copy
+            pred_batch = self.processor.batch(model, processed_image_batch, device=None, meta_batch=meta_batch)
+            meta_batch = [None] * len(pred_batch)
+        else:
+            pred_batch = self.processor.batch(model, processed_image_batch, device=None)
         self.last_decoder_time = self.processor.last_decoder_time
         self.last_nn_time = self.processor.last_nn_time
         self.total_decoder_time += self.last_decoder_time

@@ -126,3 +126,29 @@ def test_fused_gemm_refuses_mixed_precision_operands():
         got = fused.conv_bias_act(conv, x, bias32.to(torch.bfloat16), None, True)   # fp32 weight under autocast
     want = torch.nn.functional.conv2d(x.float(), conv.weight.float(), bias32.to(torch.bfloat16).float()).clamp_min(0)
     assert float((got.float() - want).abs().max()) <= 2.0 ** -6 * float(want.abs().max().clamp_min(1.0))
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('hw', [(41, 41), (9, 13)])
+def test_fused_head_epilogue_equals_the_composite_field(dtype, hw):
+    """opa_head_epilogue against the PyTorch restatement of CompositeField4's post-processing (itself pinned to the
+    reference's class in test_oracle_vs_reference.py): PixelShuffle, crop, layout, sigmoid, offsets, softplus.
+    Index offsets and the layout are exact; sigmoid / softplus may differ from ATen's device functions in the
+    last place (tolerance 2 ulp of float32)."""
+    from openpifpaf_amd import headmeta, network
+    torch.manual_seed(5)
+    for meta in headmeta.cocokp_metas():
+        head = network.CompositeField4(meta, 64).cuda().eval().to(memory_format=torch.channels_last)
+        if dtype != torch.float32:
+            head = head.to(dtype)
+        feat = (torch.randn(2, 64, hw[0], hw[1], device='cuda') * 3).to(dtype).contiguous(memory_format=torch.channels_last)
+        with torch.no_grad():
+            head.fused_epilogue = False
+            want = head(feat)
+            head.fused_epilogue = True
+            got = head(feat)
+        assert got.shape == want.shape == (2, meta.n_fields, head.n_components, 2 * hw[0] - 1, 2 * hw[1] - 1)
+        assert got.dtype == torch.float32
+        assert torch.equal(got[:, :, 0], want[:, :, 0])                   # raw component: layout only
+        ulp = torch.finfo(torch.float32).eps * want.abs().clamp_min(1e-30)
+        assert bool(((got - want).abs() <= 2 * ulp).all()), float(((got - want).abs() / ulp).max())

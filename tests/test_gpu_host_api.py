@@ -121,19 +121,41 @@ def test_captured_decode_graph_replays_equal_eager_results(coco_skeleton0):
 
 
 def test_predictor_with_device_side_preprocessing():
-    """Predictor.device_preprocess: uint8 frames go to the GPU as they are; same geometry as the PIL path."""
+    """Predictor.device_preprocess: uint8 frames go to the GPU as they are and are rescaled there with the reference's
+    own arithmetic: the network input equals the host path's pixel for pixel, and so do the annotations."""
     from openpifpaf_amd import Predictor, predictor
-    Predictor.long_edge, Predictor.batch_size, Predictor.device_preprocess = 193, 2, True
+    rng = np.random.default_rng(1)
+    images = [(rng.random((120, 160, 3)) * 255).astype(np.uint8), (rng.random((150, 90, 3)) * 255).astype(np.uint8)]
+    results = {}
+    for on_device in (True, False):
+        Predictor.long_edge, Predictor.batch_size, Predictor.device_preprocess = 193, 2, on_device
+        try:
+            pred = Predictor('resnet18')
+            results[on_device] = list(pred.numpy_images(images))
+            assert len(results[on_device]) == 2 and pred.total_images == 2
+        finally:
+            Predictor.long_edge, Predictor.batch_size, Predictor.device_preprocess = None, 1, False
+    batch, metas = predictor.preprocess_batch_device(images, long_edge=193, device=torch.device('cuda'))
+    assert batch.is_cuda and batch.shape == (2, 3, 193, 193)
+    for b, image in enumerate(images):
+        want, wmeta = predictor.preprocess_image(image, long_edge=193, batch_mode=True)
+        assert np.allclose(metas[b]['offset'], wmeta['offset']) and np.allclose(metas[b]['scale'], wmeta['scale'])
+        assert torch.equal(batch[b].cpu(), want), 'device and host preprocessing differ in %d values' % int(
+            (batch[b].cpu() != want).sum())
+    for (pred_d, _, meta_d), (pred_h, _, meta_h) in zip(results[True], results[False]):
+        assert len(pred_d) == len(pred_h)
+        for a_d, a_h in zip(pred_d, pred_h):
+            assert np.array_equal(a_d.data, a_h.data)
+    # the inverse transform ran on the device tensor (decoder.batch(meta_batch=...)); on the host, annotation by
+    # annotation like the reference (annotation.py:162-200), it gives the same coordinates
+    Predictor.long_edge, Predictor.batch_size = 193, 2
     try:
         pred = Predictor('resnet18')
-        rng = np.random.default_rng(1)
-        images = [(rng.random((120, 160, 3)) * 255).astype(np.uint8), (rng.random((150, 90, 3)) * 255).astype(np.uint8)]
-        out = list(pred.numpy_images(images))
-        assert len(out) == 2 and pred.total_images == 2
-        batch, metas = predictor.preprocess_batch_device(images, long_edge=193, device=torch.device('cuda'))
-        assert batch.is_cuda and batch.shape == (2, 3, 193, 193)
-        for b, image in enumerate(images):
-            want, wmeta = predictor.preprocess_image(image, long_edge=193, batch_mode=True)
-            assert np.allclose(metas[b]['offset'], wmeta['offset']) and np.allclose(metas[b]['scale'], wmeta['scale'])
+        pred.processor.supports_device_inverse = False
+        host_inverse = list(pred.numpy_images(images))
     finally:
-        Predictor.long_edge, Predictor.batch_size, Predictor.device_preprocess = None, 1, False
+        Predictor.long_edge, Predictor.batch_size = None, 1
+    for (pred_d, _, _), (pred_h, _, _) in zip(results[False], host_inverse):
+        assert len(pred_d) == len(pred_h)
+        for a_d, a_h in zip(pred_d, pred_h):
+            assert np.allclose(a_d.data, a_h.data, rtol=0, atol=1e-4) and np.allclose(a_d.joint_scales, a_h.joint_scales, atol=1e-4)
