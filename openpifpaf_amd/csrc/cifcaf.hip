@@ -18,17 +18,23 @@
 //       search with the reference's lazy frontier, no barriers), leave pose + occupancy boxes in their
 //       private LDS block and report DONE.  There is no round barrier: a grower that finishes is handed
 //       the next candidate at once.
-//   candidates are handed out in seed order, skipping seeds inside the box an earlier IN-FLIGHT candidate's
-//       own seed joint will occupy (the other cells of the same confidence blob: certainly dead if that
-//       candidate is accepted) -- a prediction that costs nothing when right;
-//   commit is strictly in seed order: the HEAD = the smallest-index live pooled seed.  Everything before it
-//       is decided, so it is free exactly when the sequential loop would find it free (:211).  When its
-//       growth is DONE the pose is accepted: every pooled seed inside one of its joint boxes dies (box
-//       containment = what the map would say, occupancy.cpp:13-43), in-flight growths of dead seeds are
-//       cancelled (they poll a flag), the boxes go to the bitmap for seeds that enter the pool later.
-//       A wrong prediction shows up as a HEAD that was never handed out: it is handed out then (if every
-//       grower holds a later result, the latest one is dropped and redone).  So the accepted seeds are
-//       exactly those of the sequential loop, with exactly the poses it grows, whatever the predictions.
+//   predictions keep the growers on different people.  A grower PUBLISHES the occupancy box of every joint the
+//       moment it assigns it (the joint is final from then on), and tests the coordinator's pool -- mirrored in
+//       LDS -- against the box: pooled seeds that come later in seed order and lie inside are "shadowed" (one bit
+//       per pool slot and grower).  A shadowed seed dies if that candidate is accepted, so the coordinator does not
+//       hand it out, and if it is being grown already it stops the growth (the seed stays pooled).  The prediction
+//       is wrong when the candidate dies itself -- covered by a pose committed before it, typically an overlapping
+//       person -- and then costs nothing but time: the shadow bits of a dead candidate are ignored and the seed is
+//       handed out after all;
+//   commit is strictly in seed order: the HEAD = the smallest-index live pooled seed.  Everything before it is
+//       decided, so it is free exactly when the sequential loop would find it free (:211); a candidate that
+//       shadows it would be the head itself.  When the head's growth is DONE the pose is accepted: every pooled
+//       seed inside one of its joint boxes dies (box containment = what the map would say, occupancy.cpp:13-43),
+//       growths of dead seeds are cancelled (they poll a flag), the boxes go to the bitmap for the seeds that enter
+//       the pool later.  A head that is not being grown (its growth was stopped on a prediction that did not come
+//       true) is handed out then; if every grower holds a later result, the latest one is dropped and redone.  So
+//       the accepted seeds are exactly those of the sequential loop, with exactly the poses it grows, whatever
+//       the predictions and the interleaving (tests run the same inputs with 1, 3 and all growers).
 //
 // Inside a growth the wave uses its 64 lanes where the reference has inner loops:
 // grow_connection_blend scans a CAF candidate list 64 entries per lane-step (coalesced
@@ -125,8 +131,16 @@ __device__ __forceinline__ BlendQuery make_query(double x, double y, double xy_s
     // The window test (:54-57) compares a float entry with these doubles.  For a float v: v >= lo  <=>  v >= the
     // smallest float >= lo, and v <= hi  <=>  v <= the largest float <= hi -- four float compares per entry
     // instead of two conversions and four double compares, same outcome for every input.
-    auto round_up = [](double t) { float f = (float)t; if ((double)f < t) f = nextafterf(f, __builtin_inff()); return f; };
-    auto round_down = [](double t) { float f = (float)t; if ((double)f > t) f = nextafterf(f, -__builtin_inff()); return f; };
+    auto next_up = [](float f) {                               // smallest float > f (finite f)
+        const unsigned u = __float_as_uint(f);
+        return f == 0.0f ? __uint_as_float(1u) : __uint_as_float((u >> 31) ? u - 1u : u + 1u);
+    };
+    auto next_down = [](float f) {
+        const unsigned u = __float_as_uint(f);
+        return f == 0.0f ? __uint_as_float(0x80000001u) : __uint_as_float((u >> 31) ? u + 1u : u - 1u);
+    };
+    auto round_up = [&](double t) { float f = (float)t; if ((double)f < t) f = next_up(f); return f; };
+    auto round_down = [&](double t) { float f = (float)t; if ((double)f > t) f = next_down(f); return f; };
     q.fxlo = round_up(q.xlo); q.fxhi = round_down(q.xhi);
     q.fylo = round_up(q.ylo); q.fyhi = round_down(q.yhi);
     return q;
@@ -406,10 +420,14 @@ __device__ __forceinline__ BlendResult blend_impl(const float* base, int cap, in
 __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, double x, double y, double xy_scale,
                                              double filter_sigmas) {
     c.n_blend++;
+#ifdef OPA_ASSOC_SCAN_TIMING            // four clock reads per scan: diagnostic builds only (tools/gpu/assoc_probe.py)
     const long long t0 = wall_clock64();
     const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt, &c.t_blend_mem);
     c.t_blend += (int)(wall_clock64() - t0);
     return r;
+#else
+    return blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt);
+#endif
 }
 
 // A joint was assigned (cifcaf.cpp:310): during the seed pipeline the grower publishes the occupancy box the
