@@ -269,6 +269,21 @@ int opa_gemm_pro_bias_act_bf16(const void* a_dev, const void* a_bias_dev, const 
                                const void* residual_dev, void* out_dev, int64_t m, int32_t n, int32_t k,
                                int32_t relu, void* stream);
 
+/* Depthwise k x k convolution (k = 3 or 5, stride 1 or 2, padding k/2) of a channels-last activation, with the
+ * folded batch-norm bias and optionally ReLU fused (the ShuffleNetV2K unit of the reference,
+ * network/basenetworks.py:186-268; MIOpen runs it as a grouped MFMA convolution, ~100x slower).
+ *  x_dev [B, h, w, *] with x_pixel_stride elements between pixels (a channel slice of a wider tensor is fine),
+ *  w_dev [k*k, channels] (tap-major), bias_dev [channels] or NULL, out_dev [B, ho, wo, *] with out_pixel_stride;
+ *  dtype 0 = float32, 2 = bfloat16 (float32 accumulation). */
+int opa_dwconv_bias_act(const void* x_dev, int64_t x_pixel_stride, const void* w_dev, const void* bias_dev,
+                        void* out_dev, int64_t out_pixel_stride, int32_t batch, int32_t h, int32_t w,
+                        int32_t channels, int32_t k, int32_t stride, int32_t dtype, int32_t relu, void* stream);
+
+/* torch.cat((a, b), 1) followed by channel_shuffle(groups = 2) of the same unit, in one pass over channels-last rows:
+ * out[r, 2i] = a[r, i], out[r, 2i+1] = b[r, i]; a / b with their own pixel strides, out dense [rows, 2*half]. */
+int opa_channel_interleave(const void* a_dev, int64_t a_pixel_stride, const void* b_dev, int64_t b_pixel_stride,
+                           void* out_dev, int64_t rows, int32_t half, int32_t dtype, void* stream);
+
 /* The head of the field-producing network after its 1x1 convolution, in one pass (ref: network/heads.py:330-378
  * CompositeField4.forward): PixelShuffle(upsample) -> crop -> [B, n_fields, n_components, H, W] float32 -> sigmoid on
  * the n_confidences components after component 0, cell-index offsets on the vector components whose bit is set in

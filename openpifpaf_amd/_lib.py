@@ -103,6 +103,8 @@ SYMBOLS = {
     'opa_bias_act': (ctypes.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     'opa_gemm_bias_act_bf16': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     'opa_gemm_pro_bias_act_bf16': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    'opa_dwconv_bias_act': (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    'opa_channel_interleave': (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp]),
     'opa_head_epilogue': (ctypes.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, ctypes.c_uint32, _i32, _vp, _vp]),
     'opa_profile_begin': (ctypes.c_int, [_vp]),
     'opa_profile_end': (ctypes.c_int, [_i32, _P(ctypes.c_char_p), _P(ctypes.c_float), _P(_i32)]),

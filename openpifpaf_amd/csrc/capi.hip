@@ -605,6 +605,29 @@ int opa_gemm_pro_bias_act_bf16(const void* a_dev, const void* a_bias_dev, const 
     return OPA_OK;
 }
 
+int opa_dwconv_bias_act(const void* x_dev, int64_t x_pixel_stride, const void* w_dev, const void* bias_dev,
+                        void* out_dev, int64_t out_pixel_stride, int32_t batch, int32_t h, int32_t w,
+                        int32_t channels, int32_t k, int32_t stride, int32_t dtype, int32_t relu, void* stream) {
+    if (!x_dev || !w_dev || !out_dev || batch <= 0 || h <= 0 || w <= 0 || channels <= 0 || x_pixel_stride < channels ||
+        out_pixel_stride < channels || (k != 3 && k != 5) || (stride != 1 && stride != 2) || (dtype != 0 && dtype != 2))
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_dwconv_bias_act: bad arguments");
+    hipError_t e = launch_dwconv(x_dev, x_pixel_stride, w_dev, bias_dev, out_dev, out_pixel_stride, batch, h, w, channels,
+                                 k, stride, dtype, relu, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "depthwise convolution");
+    return OPA_OK;
+}
+
+int opa_channel_interleave(const void* a_dev, int64_t a_pixel_stride, const void* b_dev, int64_t b_pixel_stride,
+                           void* out_dev, int64_t rows, int32_t half, int32_t dtype, void* stream) {
+    if (!a_dev || !b_dev || !out_dev || rows <= 0 || half <= 0 || a_pixel_stride < half || b_pixel_stride < half ||
+        dtype < 0 || dtype > 2)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_channel_interleave: bad arguments");
+    hipError_t e = launch_channel_interleave(a_dev, a_pixel_stride, b_dev, b_pixel_stride, out_dev, rows, half, dtype,
+                                             (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "channel interleave");
+    return OPA_OK;
+}
+
 int opa_head_epilogue(const void* conv_dev, int32_t dtype, int32_t batch, int32_t hc, int32_t wc,
                       int32_t n_fields, int32_t n_components, int32_t upsample, int32_t n_confidences,
                       int32_t n_vectors, uint32_t vector_offset_mask, int32_t n_scales, float* out_dev, void* stream) {

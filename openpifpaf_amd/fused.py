@@ -183,3 +183,52 @@ def head_epilogue(x, meta):
         meta.n_vectors, mask, meta.n_scales, ctypes.c_void_p(out.data_ptr()),
         ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'opa_head_epilogue')
     return out
+
+
+def _pixel_stride(x):
+    """Elements between neighbouring pixels of a channels-innermost (NHWC in memory) 4-d tensor or channel slice of
+    one; None if ``x`` is laid out differently."""
+    if x.dim() != 4 or x.stride(1) != 1:
+        return None
+    B, C, H, W = x.shape
+    ps = x.stride(3) if W > 1 else (x.stride(2) if H > 1 else C)
+    if ps < C or (H > 1 and x.stride(2) != W * ps) or (B > 1 and x.stride(0) != H * W * ps):
+        return None
+    return ps
+
+
+def dwconv_supported(x, kernel_size, stride):
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and kernel_size in (3, 5) and stride in (1, 2)
+            and _pixel_stride(x) is not None and _lib.available())
+
+
+def dwconv_bias_act(x, w_taps, bias, kernel_size, stride, relu=False):
+    """Depthwise ``kernel_size`` x ``kernel_size`` convolution (padding k//2) + bias (+ ReLU) of a channels-last
+    activation or channel slice, one HIP stencil kernel.  ``w_taps``: ``[k*k, C]`` (tap-major) in ``x``'s dtype."""
+    B, C, H, W = x.shape
+    pad = kernel_size // 2
+    Ho, Wo = (H + 2 * pad - kernel_size) // stride + 1, (W + 2 * pad - kernel_size) // stride + 1
+    out = torch.empty((B, C, Ho, Wo), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().opa_dwconv_bias_act(
+        ctypes.c_void_p(x.data_ptr()), _pixel_stride(x), ctypes.c_void_p(w_taps.data_ptr()),
+        ctypes.c_void_p(bias.data_ptr()) if bias is not None else None, ctypes.c_void_p(out.data_ptr()), C,
+        B, H, W, C, kernel_size, stride, _DTYPES[x.dtype], int(bool(relu)),
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'opa_dwconv_bias_act')
+    return out
+
+
+def channel_interleave(a, b):
+    """``channel_shuffle(torch.cat((a, b), 1), groups=2)`` in one pass: out[:, 2i] = a[:, i], out[:, 2i+1] = b[:, i]."""
+    pa, pb = _pixel_stride(a), _pixel_stride(b)
+    if not (a.is_cuda and a.dtype in _DTYPES and a.dtype == b.dtype and a.shape == b.shape and pa and pb
+            and _lib.available()):
+        x = torch.cat((a, b), dim=1)
+        n, c, h, w = x.shape
+        return x.view(n, 2, c // 2, h, w).transpose(1, 2).reshape(n, c, h, w)
+    B, half, H, W = a.shape
+    out = torch.empty((B, 2 * half, H, W), dtype=a.dtype, device=a.device, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().opa_channel_interleave(
+        ctypes.c_void_p(a.data_ptr()), pa, ctypes.c_void_p(b.data_ptr()), pb, ctypes.c_void_p(out.data_ptr()),
+        B * H * W, half, _DTYPES[a.dtype], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+        'opa_channel_interleave')
+    return out

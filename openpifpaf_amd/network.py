@@ -180,7 +180,36 @@ class _InvertedResidualK(nn.Module):
             nn.Conv2d(bf, bf, kernel_size, stride, pad, groups=bf, bias=False), nn.BatchNorm2d(bf),
             nn.Conv2d(bf, bf, 1, bias=False), nn.BatchNorm2d(bf), nn.ReLU(inplace=True))
 
+    fused = False
+
+    def enable_fused_(self):
+        """After conv+BN folding: the depthwise convolutions run as one HIP stencil kernel each (bias fused) and
+        cat + channel_shuffle as one interleave pass.  Keeps the tap-major copies of the depthwise weights."""
+        for branch in (self.branch1, self.branch2):
+            if branch is None:
+                continue
+            for m in branch:
+                if isinstance(m, nn.Conv2d) and m.groups == m.in_channels and m.groups > 1:
+                    k = m.kernel_size[0]
+                    m.register_buffer('w_taps', m.weight.detach().reshape(m.out_channels, k * k).t().contiguous())
+        self.fused = True
+
+    @staticmethod
+    def _run(branch, x):
+        for m in branch:
+            if isinstance(m, nn.Conv2d) and hasattr(m, 'w_taps') and m.w_taps.dtype == x.dtype \
+                    and fused.dwconv_supported(x, m.kernel_size[0], m.stride[0]):
+                x = fused.dwconv_bias_act(x, m.w_taps, m.bias, m.kernel_size[0], m.stride[0])
+            else:
+                x = m(x)
+        return x
+
     def forward(self, x):
+        if self.fused and x.is_cuda:
+            if self.branch1 is None:
+                x1, x2 = x.chunk(2, dim=1)
+                return fused.channel_interleave(x1, self._run(self.branch2, x2))
+            return fused.channel_interleave(self._run(self.branch1, x), self._run(self.branch2, x))
         if self.branch1 is None:
             x1, x2 = x.chunk(2, dim=1)
             out = torch.cat((x1, self.branch2(x2)), dim=1)
@@ -338,10 +367,10 @@ def fuse_conv_bn_(model):
 
 def optimize_for_inference_(model):
     """Fold every conv+BN pair, then switch the ResNet blocks to the fused-epilogue forward
-    (conv without bias followed by ONE ``fused.bias_act_`` pass).  Other backbones keep the
-    folded convs with their biases."""
+    (conv without bias followed by ONE ``fused.bias_act_`` pass) and the ShuffleNetV2K units to the HIP depthwise /
+    interleave kernels."""
     fuse_conv_bn_(model)
     for m in model.modules():
-        if isinstance(m, (_Bottleneck, _BasicBlock, Resnet)):
+        if isinstance(m, (_Bottleneck, _BasicBlock, Resnet, _InvertedResidualK)):
             m.enable_fused_()
     return model
