@@ -790,7 +790,8 @@ __device__ __forceinline__ void grow_pose(ImageCtx& c, const DevParams& p, const
 // ---------------------------------------------------------------- occupancy
 // occupancy.cpp:32-43: the cell a query (x, y) falls into
 __device__ __forceinline__ void occ_xy(const ImageCtx& c, const DevParams& p, double x, double y, int* xi, int* yi) {
-    if (p.occupancy_reduction != 1.0) { x /= p.occupancy_reduction; y /= p.occupancy_reduction; }
+    if (p.occupancy_inv_reduction != 0.0) { x *= p.occupancy_inv_reduction; y *= p.occupancy_inv_reduction; }
+    else if (p.occupancy_reduction != 1.0) { x /= p.occupancy_reduction; y /= p.occupancy_reduction; }
     *xi = (int)clampll(trunc_ll(x), 0, c.occ_w - 1);
     *yi = (int)clampll(trunc_ll(y), 0, c.occ_h - 1);
 }
@@ -799,7 +800,10 @@ __device__ __forceinline__ void occ_xy(const ImageCtx& c, const DevParams& p, do
 // bitmap and to test containment analytically (commit, keypoint NMS), so the two can never disagree.
 struct __attribute__((aligned(16))) OccBox { int minx, miny, maxx, maxy; };
 __device__ __forceinline__ OccBox occ_box(const ImageCtx& c, const DevParams& p, double x, double y, double sigma) {
-    if (p.occupancy_reduction != 1.0) {
+    if (p.occupancy_inv_reduction != 0.0) {           // power-of-two reduction (the reference's 2.0): exact either way
+        x *= p.occupancy_inv_reduction; y *= p.occupancy_inv_reduction;
+        sigma = fmax(p.occupancy_min_scale_reduced, sigma * p.occupancy_inv_reduction);
+    } else if (p.occupancy_reduction != 1.0) {
         x /= p.occupancy_reduction; y /= p.occupancy_reduction;
         sigma = fmax(p.occupancy_min_scale_reduced, sigma / p.occupancy_reduction);
     }

@@ -44,6 +44,7 @@ struct DevParams {
     double keypoint_threshold, keypoint_threshold_rel;
     double nms_suppression, nms_instance_threshold, nms_keypoint_threshold;
     double force_complete_caf_th, occupancy_reduction, occupancy_min_scale_reduced;
+    double occupancy_inv_reduction;       // 1 / reduction when the reduction is a power of two (x / r == x * (1/r) exactly), else 0
     int64_t cifhr_neighbors;
     int reverse_match, force_complete, greedy;
     int ablation_cifseeds_nms, ablation_cifseeds_no_rescore, ablation_caf_no_rescore, ablation_cifhr_skip;
@@ -171,7 +172,10 @@ __device__ __forceinline__ long long trunc_ll(float v) { return (long long)v; }
 __device__ __forceinline__ long long trunc_ll(double v) { return (long long)v; }
 
 __device__ __forceinline__ int seed_cell_pack(const DevParams& p, int occ_h, int occ_w, double x, double y, double sigma) {
-    if (p.occupancy_reduction != 1.0) {
+    if (p.occupancy_inv_reduction != 0.0) {
+        x *= p.occupancy_inv_reduction; y *= p.occupancy_inv_reduction;
+        sigma = fmax(p.occupancy_min_scale_reduced, sigma * p.occupancy_inv_reduction);
+    } else if (p.occupancy_reduction != 1.0) {
         x /= p.occupancy_reduction; y /= p.occupancy_reduction;
         sigma = fmax(p.occupancy_min_scale_reduced, sigma / p.occupancy_reduction);
     }

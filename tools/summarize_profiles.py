@@ -84,10 +84,10 @@ def pmc(sub, counter):
     return {k: sorted(v)[len(v) // 2] for k, v in acc.items() if v}
 
 
-print('# rocprofv3 summary (round 1)\n')
+print('# rocprofv3 summary (round 2)\n')
 print('Commands: see tools/collect_profiles.sh.  Batch 32 per launch, COCO-17 fields 81x81, stride 8.\n')
-steady_state_step('bench', 'bench.py (backbone + decode): ONE steady-state step, batch 32')
-kernel_stats('bench', 'bench.py --steps 5 --warmup 2 whole run (includes MIOpen find candidates), kernel trace', top=12)
+steady_state_step('bench', 'bench.py headline leg (float32 network + decode): ONE steady-state step, batch 32')
+steady_state_step('bench_bf16', 'bench.py --backbone-dtype bf16 (bfloat16 network + decode): ONE steady-state step, batch 32')
 kernel_stats('decode', 'bench.py --decode-only --steps 10 --warmup 2, kernel trace')
 fetch, write = pmc('pmc_FETCH_SIZE', 'FETCH_SIZE'), pmc('pmc_WRITE_SIZE', 'WRITE_SIZE')
 print('## HBM traffic counters per launch (decode only)\n')
@@ -123,7 +123,13 @@ if hit or conf or valu:
 
 # machine-readable PMC traffic for bench.py's roofline.traffic
 import json
-out = {'batch': 32, 'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --decode-only, per launch; '
+import hashlib
+_h = hashlib.sha256()
+_csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'openpifpaf_amd', 'csrc')
+for _n in sorted(os.listdir(_csrc)):
+    if _n.endswith(('.hip', '.hpp')):
+        _h.update(open(os.path.join(_csrc, _n), 'rb').read())
+out = {'batch': 32, 'config': 2, 'kernel_source_hash': _h.hexdigest()[:16], 'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --decode-only, per launch; '
        'units KiB of TCC_EA requests; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 x2 read correction '
        'of MI355X_MICROARCH.md (calibrated for 16-B/lane streams only; 4-B/lane reads are uncalibrated)', 'kernels': {}}
 for k in sorted(set(fetch) | set(write)):
