@@ -56,33 +56,55 @@ template <> struct Elem<2> {   // bf16
     }
 };
 
+// Four vectors per thread and step: their loads (x and residual: up to 128 B per thread) are all in flight before the
+// first add -- a pure stream needs that much outstanding traffic per CU to approach the HBM rate (one vector per step
+// ran at 2.8 TB/s on the 850 MB float32 activations of ResNet layer 1) -- and the bias column advances by a 32-bit
+// add instead of a 64-bit modulo per vector.
+constexpr int kEpiUnroll = 4;
+
 template <int DT, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bias_act_kernel(Vec16* __restrict__ x, const Vec16* __restrict__ bias,
                                                        const Vec16* __restrict__ res, long long n_vec, int vec_per_row) {
     constexpr int N = Elem<DT>::kPerVec;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
-        const Vec16 xv = x[i];
-        const Vec16 bv = bias[(int)(i % vec_per_row)];
-        float a[N], b[N];
-        Elem<DT>::unpack(xv, a);
-        Elem<DT>::unpack(bv, b);
-        if (RES) {
-            float r[N];
-            Elem<DT>::unpack(res[i], r);
+    const int col_step = (int)(stride % vec_per_row);
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    int col = (int)(i % vec_per_row);
+    for (; i < n_vec; i += kEpiUnroll * stride) {
+        Vec16 xv[kEpiUnroll], rv[kEpiUnroll];
+        int cols[kEpiUnroll];
 #pragma unroll
-            for (int k = 0; k < N; k++) a[k] = a[k] + b[k] + r[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < N; k++) a[k] = a[k] + b[k];
+        for (int u = 0; u < kEpiUnroll; u++) {
+            const long long j = i + u * stride;
+            cols[u] = col;
+            col += col_step; if (col >= vec_per_row) col -= vec_per_row;
+            if (j < n_vec) { xv[u] = x[j]; if (RES) rv[u] = res[j]; }
         }
-        if (RELU) {
 #pragma unroll
-            for (int k = 0; k < N; k++) a[k] = fmaxf(a[k], 0.0f);
+        for (int u = 0; u < kEpiUnroll; u++) {
+            const long long j = i + u * stride;
+            if (j >= n_vec) break;
+            const Vec16 bv = bias[cols[u]];
+            float a[N], b[N];
+            Elem<DT>::unpack(xv[u], a);
+            Elem<DT>::unpack(bv, b);
+            if (RES) {
+                float r[N];
+                Elem<DT>::unpack(rv[u], r);
+#pragma unroll
+                for (int k = 0; k < N; k++) a[k] = a[k] + b[k] + r[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < N; k++) a[k] = a[k] + b[k];
+            }
+            if (RELU) {
+#pragma unroll
+                for (int k = 0; k < N; k++) a[k] = fmaxf(a[k], 0.0f);
+            }
+            Vec16 o;
+            Elem<DT>::pack(a, o);
+            x[j] = o;
         }
-        Vec16 o;
-        Elem<DT>::pack(a, o);
-        x[i] = o;
     }
 }
 
@@ -93,6 +115,7 @@ static hipError_t launch_dt(void* x, const void* bias, const void* res, long lon
     const int vec_per_row = channels / N;
     const long long n_vec = rows * vec_per_row;
     long long blocks = (n_vec + 255) / 256;
+    blocks = (blocks + kEpiUnroll - 1) / kEpiUnroll;
     if (blocks > 256 * 16) blocks = 256 * 16;          // 256 CUs x 16 blocks, grid-stride the rest
     if (blocks < 1) blocks = 1;
     Vec16* xv = (Vec16*)x; const Vec16* bv = (const Vec16*)bias; const Vec16* rv = (const Vec16*)res;
