@@ -20,12 +20,15 @@ namespace opa {
 
 constexpr int kScoredThreads = 1024;     // one workgroup walks a field: fewer, wider steps (each ends in a barrier)
 
-__global__ __launch_bounds__(kScoredThreads) void cafscored_kernel(
+__global__ __launch_bounds__(kScoredThreads, 2) void cafscored_kernel(
         const float* __restrict__ caf, int A, int HW, int stride,
         const float* __restrict__ cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
         const int64_t* __restrict__ skeleton, double score_th, double cif_floor, int no_rescore,
-        float* __restrict__ lists, int32_t* __restrict__ counts) {
+        float* __restrict__ lists, int32_t* __restrict__ counts, float* __restrict__ chunk_bbox) {
     __shared__ int wave_tot[2][kScoredThreads / 64];
+    __shared__ float bb[2][kListBboxChunks][4];      // (xmin, xmax, ymin, ymax) of the (x1, y1) columns per list chunk
+    if (threadIdx.x < 2 * kListBboxChunks * 4) (&bb[0][0][0])[threadIdx.x] = (threadIdx.x & 1) ? -__builtin_inff() : __builtin_inff();
+    __syncthreads();
     const int plane = blockIdx.x;                  // b*A + a
     const int b = plane / A, a = plane - b * A;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -74,6 +77,18 @@ __global__ __launch_bounds__(kScoredThreads) void cafscored_kernel(
             if (k < w) { off_f += t & 0xffff; off_b += t >> 16; }
             tot_f += t & 0xffff; tot_b += t >> 16;
         }
+        if (chunk_bbox) {
+            // LDS float min/max (ds_min_f32 / ds_max_f32); a NaN coordinate never passes the window test and must
+            // not poison the box
+            auto widen = [](float* q, float x, float y) {
+                if (x == x) { __hip_atomic_fetch_min(q + 0, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                              __hip_atomic_fetch_max(q + 1, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                if (y == y) { __hip_atomic_fetch_min(q + 2, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                              __hip_atomic_fetch_max(q + 3, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+            };
+            if (keep_f && off_f < kListBboxChunks * 64) widen(bb[0][off_f >> 6], x1, y1);
+            if (keep_b && off_b < kListBboxChunks * 64) widen(bb[1][off_b >> 6], x2, y2);
+        }
         if (keep_f) {
             Lf[0 * HW + off_f] = cf; Lf[1 * HW + off_f] = x1; Lf[2 * HW + off_f] = y1;
             Lf[3 * HW + off_f] = x2; Lf[4 * HW + off_f] = y2; Lf[5 * HW + off_f] = s1; Lf[6 * HW + off_f] = s2;
@@ -85,14 +100,19 @@ __global__ __launch_bounds__(kScoredThreads) void cafscored_kernel(
         base_f += tot_f; base_b += tot_b;
     }
     if (tid == 0) { counts[plane * 2 + 0] = base_f; counts[plane * 2 + 1] = base_b; }
+    if (chunk_bbox) {                                 // the chunk boxes (common.hpp), gathered in LDS while the lists were built
+        __syncthreads();
+        if (tid < 2 * kListBboxChunks * 4)
+            chunk_bbox[(size_t)plane * 2 * kListBboxChunks * 4 + tid] = (&bb[0][0][0])[tid];
+    }
 }
 
 hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
-                            float* lists, int32_t* counts, hipStream_t st) {
+                            float* lists, int32_t* counts, hipStream_t st, float* chunk_bbox) {
     cafscored_kernel<<<B * A, kScoredThreads, 0, st>>>(caf, A, cH * cW, cstride, cifhr, F, hr_rows, hr_cols, hr_pitch,
-                                            skeleton, score_th, cif_floor, no_rescore, lists, counts);
+                                            skeleton, score_th, cif_floor, no_rescore, lists, counts, chunk_bbox);
     prof_mark(st, "cafscored_kernel");
     return hipGetLastError();
 }

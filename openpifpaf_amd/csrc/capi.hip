@@ -127,6 +127,7 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     L->off_list_counts = take(B * L->A * 2 * sizeof(int32_t));
     L->off_lists_fc = take(list_bytes);
     L->off_list_counts_fc = take(B * L->A * 2 * sizeof(int32_t));
+    L->off_list_bbox = take(B * L->A * 2 * kListBboxChunks * 4 * sizeof(float));
     // occupancy bitmap, one bit per cell (occupancy.cpp:46-68 keeps an int16 map); 256-B multiple per image
     L->occ_image_words = align_up((size_t)L->F * L->occ_h * ((L->occ_w + 31) / 32) * sizeof(unsigned)) / sizeof(unsigned);
     L->off_occ = take(B * L->occ_image_words * sizeof(unsigned));
@@ -284,7 +285,8 @@ int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what, size_t* 
         {"tile_bitmaps", L.off_tile_clean, L.off_cifhr}, {"cifhr", L.off_cifhr, L.off_act}, {"seed_count", L.off_seed_count, L.off_seed_f},
         {"seed_f", L.off_seed_f, L.off_seed_vxys}, {"seed_vxys", L.off_seed_vxys, L.off_seed_cell}, {"seed_cell", L.off_seed_cell, L.off_lists},
         {"lists", L.off_lists, L.off_list_counts}, {"list_counts", L.off_list_counts, L.off_lists_fc},
-        {"lists_fc", L.off_lists_fc, L.off_list_counts_fc}, {"list_counts_fc", L.off_list_counts_fc, L.off_occ},
+        {"lists_fc", L.off_lists_fc, L.off_list_counts_fc}, {"list_counts_fc", L.off_list_counts_fc, L.off_list_bbox},
+        {"list_bbox", L.off_list_bbox, L.off_occ},
         {"occupancy", L.off_occ, L.off_anns}, {"annotation_scratch", L.off_anns, L.off_ann_meta},
         {"status", L.off_status, L.off_stats}, {"assoc_stats", L.off_stats, L.off_trace}, {"assoc_trace", L.off_trace, L.total},
     };
@@ -346,7 +348,8 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     if (e != hipSuccess) return fail_hip(e, "cifseeds");
     e = launch_cafscored(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols, L.hr_pitch,
                          dec->dev.skeleton, p.caf_threshold, p.cif_floor, p.ablation_caf_no_rescore,
-                         (float*)(ws + L.off_lists), (int32_t*)(ws + L.off_list_counts), st);   // :153-161
+                         (float*)(ws + L.off_lists), (int32_t*)(ws + L.off_list_counts), st,
+                         (float*)(ws + L.off_list_bbox));                                    // :153-161
     if (e != hipSuccess) return fail_hip(e, "cafscored");
     if (p.force_complete) {                                                                   // :419-420
         e = launch_cafscored(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols,
@@ -365,6 +368,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     a.seed_cell = (const int32_t*)(ws + L.off_seed_cell);
     a.lists = (const float*)(ws + L.off_lists); a.list_counts = (const int32_t*)(ws + L.off_list_counts);
     a.lists_fc = (const float*)(ws + L.off_lists_fc); a.list_counts_fc = (const int32_t*)(ws + L.off_list_counts_fc);
+    a.list_bbox = (const float*)(ws + L.off_list_bbox);
     a.occ = (unsigned*)(ws + L.off_occ); a.occ_image_words = L.occ_image_words;
     a.stats = (int32_t*)(ws + L.off_stats);
     a.trace = (int32_t*)(ws + L.off_trace);

@@ -79,7 +79,29 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-struct ListView { const float* base; int cap; int n; };   // 7 SoA planes: c,x1,y1,x2,y2,s1,s2
+// 7 SoA planes: c,x1,y1,x2,y2,s1,s2; `bbox` (LDS, or null): (xmin, xmax, ymin, ymax) of the (x1, y1) columns of the
+// list's first kListBboxChunks chunks of 64 entries (cafscored writes them, common.hpp)
+struct ListView { const float* base; int cap; int n; const float4* bbox; };
+
+// Diagnostic builds only (-DOPA_ASSOC_PHASE_TIMING, tools/gpu/assoc_probe.py): shader-clock time of the growers
+// by phase of the search, summed over the growers of an image; printed by the kernel for images 0 and 3.
+#ifdef OPA_ASSOC_PHASE_TIMING
+constexpr int kPhases = 20;
+__shared__ int g_ph[kPhases], g_phn[kPhases];
+__shared__ long long g_ph_last[16];
+__device__ __forceinline__ void ph_stamp(int k) {
+    const long long t = clock64();
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_ph[k], (int)(t - g_ph_last[w])); atomicAdd(&g_phn[k], 1);
+    }
+    __builtin_amdgcn_wave_barrier();
+    if ((threadIdx.x & 63) == 0) g_ph_last[w] = clock64();
+}
+#define PH(k) ph_stamp(k)
+#else
+#define PH(k)
+#endif
 
 struct ImageCtx {
     int K, A, F;                         // F = occupancy fields = n_cif
@@ -102,6 +124,7 @@ struct ImageCtx {
     unsigned char* in_frontier;          // [2A]
     int heap_n, n_entries;
     // shared LDS
+    const float4* bbox;                  // [2A][kListBboxChunks] chunk boxes of the active list set, or null
     int* sh_counts;                      // [2A] list lengths of the active list set
     int n_blend;                         // list scans of this wave (statistics)
     int t_blend, t_blend_mem;            // ticks inside the scans, and of those until the loads had returned
@@ -112,6 +135,7 @@ __device__ __forceinline__ ListView list_view(const ImageCtx& c, int bone, int d
     v.base = c.lists + ((size_t)bone * 2 + dir) * 7 * c.list_cap;
     v.cap = c.list_cap;
     v.n = c.sh_counts[bone * 2 + dir];
+    v.bbox = c.bbox ? c.bbox + (bone * 2 + dir) * kListBboxChunks : nullptr;
     return v;
 }
 
@@ -262,10 +286,15 @@ constexpr int kBlendLdsFloats = kTgtFloats + 4 * kWave;  // + the compacted (x1,
 
 __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const BlendQuery& q, bool only_max);
 
+// `chunks`: the R chunks of the list to look at, ascending, 8 bits each (0xff: none) -- all of them
+// (kDenseChunks) or, for a list with chunk boxes, those whose box meets the window.
+constexpr unsigned long long kDenseChunks = 0x0706050403020100ull;
 template <int R>
-__device__ __forceinline__ BlendResult blend_cached(const ListView& L, const BlendQuery& q, bool only_max, float* tgt, int* t_mem) {
+__device__ __forceinline__ BlendResult blend_cached(const ListView& L, const BlendQuery& q, bool only_max, float* tgt, int* t_mem,
+                                                    unsigned long long chunks = kDenseChunks) {
     const int lane = lane_id();
     const long long t_issue = t_mem ? wall_clock64() : 0;
+    PH(1);
     const gfloat* g = (const gfloat*)L.base;
     // The target columns (x2, y2, s2) are needed for two entries only: they travel HBM/L2 -> LDS
     // directly (global_load_lds, no VGPRs), in flight together with the register loads below; chunk r of
@@ -273,7 +302,7 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
     lfloat* t3 = (lfloat*)tgt;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const int i = r * kWave + lane;
+        const int i = (int)((chunks >> (8 * r)) & 0xffull) * kWave + lane;
         const int ii = i < L.n ? i : 0;
         __builtin_amdgcn_global_load_lds(g + 3 * L.cap + ii, t3 + (0 * R + r) * kWave, 4, 0, 0);
         __builtin_amdgcn_global_load_lds(g + 4 * L.cap + ii, t3 + (1 * R + r) * kWave, 4, 0, 0);
@@ -282,24 +311,26 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
     float x1[R], y1[R], cc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const int i = r * kWave + lane;
+        const int i = (int)((chunks >> (8 * r)) & 0xffull) * kWave + lane;
         const int ii = i < L.n ? i : 0;
         x1[r] = g[1 * L.cap + ii]; y1[r] = g[2 * L.cap + ii]; cc[r] = g[ii];
     }
 #pragma unroll
     for (int r = 0; r < R; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
     if (t_mem) *t_mem += (int)(wall_clock64() - t_issue);
+    PH(2);
     float* cx = tgt + kTgtFloats; float* cy = cx + kWave; float* cv = cy + kWave; int* ci = (int*)(cv + kWave);
     const unsigned long long below = (1ull << lane) - 1ull;
     int cnt = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        const int i = r * kWave + lane;
+        const int i = (int)((chunks >> (8 * r)) & 0xffull) * kWave + lane;
         const bool pass = i < L.n && passes_f(q, x1[r], y1[r]);
         const unsigned long long m = __ballot(pass);
         if (m == 0ull) continue;
         const int slot = cnt + __popcll(m & below);
-        if (pass && slot < kWave) { cx[slot] = x1[r]; cy[slot] = y1[r]; cv[slot] = cc[r]; ci[slot] = i; }
+        // position among the chunks looked at: ascending like the list index, and where the targets landed
+        if (pass && slot < kWave) { cx[slot] = x1[r]; cy[slot] = y1[r]; cv[slot] = cc[r]; ci[slot] = r * kWave + lane; }
         cnt += __popcll(m);
     }
     if (cnt == 0) {                                            // :76
@@ -311,9 +342,12 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
         return blend_streamed(L, q, only_max);
     }
     wave_sync();
+    PH(3);
     const bool have = lane < cnt;
     float sc = 0.0f; int pos = 0;
     if (have) { sc = score_of(q, cx[lane], cy[lane], cv[lane]); pos = ci[lane]; }
+    asm volatile("" : "+v"(sc));
+    PH(4);
     const unsigned b1 = have && sc > 0.0f ? __float_as_uint(sc) : 0u;
     const unsigned s1b = wave_max_u32(b1);
     if (s1b == 0u) {                                           // :76
@@ -334,6 +368,7 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
             i2 = __builtin_amdgcn_readlane(pos, l2); s2 = __uint_as_float(s2b); have2 = true;
         }
     }
+    PH(5);
     __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): target columns are in LDS
     wave_sync();
     const float e1x = tgt[0 * R * kWave + i1], e1y = tgt[1 * R * kWave + i1], e1s = tgt[2 * R * kWave + i1];
@@ -408,7 +443,7 @@ __device__ __forceinline__ BlendResult blend_impl(const float* base, int cap, in
                                                double xy_scale, double filter_sigmas, int only_max, float* tgt,
                                                int* t_mem = nullptr) {
     if (n <= 0) return blend_none();
-    ListView L; L.base = base; L.cap = cap; L.n = n;
+    ListView L; L.base = base; L.cap = cap; L.n = n; L.bbox = nullptr;
     const BlendQuery q = make_query(x, y, xy_scale, filter_sigmas);
     if (n <= kWave) return blend_cached<1>(L, q, only_max != 0, tgt, t_mem);
     if (n <= 2 * kWave) return blend_cached<2>(L, q, only_max != 0, tgt, t_mem);
@@ -417,16 +452,63 @@ __device__ __forceinline__ BlendResult blend_impl(const float* base, int cap, in
     return blend_streamed(L, q, only_max != 0);
 }
 
+// A list with chunk boxes: only the chunks whose box meets the window are loaded (no entry of any other chunk can
+// pass the window test, cifcaf.cpp:54-57); list order among the loaded chunks is kept, so the tie rules hold.
+template <int R>
+__device__ __forceinline__ unsigned long long pack_chunks(unsigned m) {
+    unsigned long long chunks = 0ull;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const unsigned cidx = m ? (unsigned)__builtin_ctz(m) : 0xffu;
+        m &= m - 1u;
+        chunks |= (unsigned long long)cidx << (8 * r);
+    }
+    return chunks;
+}
+__device__ __forceinline__ BlendResult blend_boxed(const ListView& L, double x, double y, double xy_scale,
+                                                   double filter_sigmas, float* tgt) {
+    const BlendQuery q = make_query(x, y, xy_scale, filter_sigmas);
+    const int lane = lane_id();
+    const float4 bb = L.bbox[lane & (kListBboxChunks - 1)];
+    const bool hit = lane * kWave < L.n && lane < kListBboxChunks &&
+                     bb.x <= q.fxhi && bb.y >= q.fxlo && bb.z <= q.fyhi && bb.w >= q.fylo;
+    const unsigned m = (unsigned)__ballot(hit);
+    const int nh = __popc(m);
+    if (nh == 0) return blend_none();                          // :76
+    if (nh == 1) return blend_cached<1>(L, q, false, tgt, nullptr, pack_chunks<1>(m));
+    if (nh == 2) return blend_cached<2>(L, q, false, tgt, nullptr, pack_chunks<2>(m));
+    if (nh <= 4) return blend_cached<4>(L, q, false, tgt, nullptr, pack_chunks<4>(m));
+    if (nh <= kBlendChunks) return blend_cached<kBlendChunks>(L, q, false, tgt, nullptr, pack_chunks<kBlendChunks>(m));
+    return blend_streamed(L, q, false);
+}
+
 __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, double x, double y, double xy_scale,
                                              double filter_sigmas) {
     c.n_blend++;
+    if (L.bbox && L.n > kWave && L.n <= kListBboxChunks * kWave) {
+#ifdef OPA_ASSOC_PHASE_TIMING
+        PH(17);
+        const BlendResult r = blend_boxed(L, x, y, xy_scale, filter_sigmas, c.tgt);
+        PH(6);
+        return r;
+#else
+        return blend_boxed(L, x, y, xy_scale, filter_sigmas, c.tgt);
+#endif
+    }
 #ifdef OPA_ASSOC_SCAN_TIMING            // four clock reads per scan: diagnostic builds only (tools/gpu/assoc_probe.py)
     const long long t0 = wall_clock64();
     const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt, &c.t_blend_mem);
     c.t_blend += (int)(wall_clock64() - t0);
     return r;
 #else
+#ifdef OPA_ASSOC_PHASE_TIMING
+    PH(17);
+    const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt);
+    PH(6);
+    return r;
+#else
     return blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt);
+#endif
 #endif
 }
 
@@ -698,6 +780,8 @@ __device__ __forceinline__ bool reg_connection_value(ImageCtx& c, const DevParam
     caf_b.base = c.lists + ((size_t)bone * 2 + (fwd ? 1 : 0)) * 7 * c.list_cap;
     caf_f.n = rlane(R.list_n, bone * 2 + (fwd ? 0 : 1));
     caf_b.n = rlane(R.list_n, bone * 2 + (fwd ? 1 : 0));
+    caf_f.bbox = c.bbox ? c.bbox + (bone * 2 + (fwd ? 0 : 1)) * kListBboxChunks : nullptr;
+    caf_b.bbox = c.bbox ? c.bbox + (bone * 2 + (fwd ? 1 : 0)) * kListBboxChunks : nullptr;
     const double sv = reg_jv(R, start);
     const double sx = (double)rlanef(R.jx, start), sy = (double)rlanef(R.jy, start), ss = (double)rlanef(R.js, start);
     const BlendResult nj = blend(c, caf_f, sx, sy, ss, filter_sigmas);
@@ -741,24 +825,32 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
         const int slot = reg_heap_pop(R);
         const int info = rlane(sk.slot_info, slot);
         const int start = info & 0xff, end = (info >> 8) & 0xff;
-        if (reg_jv(R, end) > 0.0) continue;                                  // :284
+        if (reg_jv(R, end) > 0.0) { PH(0); continue; }                       // :284
         double v = __hiloint2double(rlane(R.ev_hi, slot), rlane(R.ev_lo, slot));
         float x, y, s;
+        PH(0);
         if (v == 0.0) {                                                      // :287: not computed yet
-            if (!reg_connection_value(c, p, R, start, info, reverse_match_, filter_sigmas, &v, &x, &y, &s))
+            if (!reg_connection_value(c, p, R, start, info, reverse_match_, filter_sigmas, &v, &x, &y, &s)) {
+                PH(7);
                 continue;                                                    // :290-296 (block_joints is a no-op)
+            }
+            PH(7);
             if (!p.greedy) {                                                 // :298-303
                 wlane(R.ev_lo, __double2loint(v), slot); wlane(R.ev_hi, __double2hiint(v), slot);
                 wlanef(R.ex, x, slot); wlanef(R.ey, y, slot); wlanef(R.es, s, slot);
                 reg_heap_push(R, (float)v, slot);
+                PH(8);
                 continue;
             }
         } else {
             x = rlanef(R.ex, slot); y = rlanef(R.ey, slot); s = rlanef(R.es, slot);
         }
         reg_set_joint(R, end, v, x, y, s);                                   // :310
+        PH(9);
         publish_joint(c, p, end, x, y, s);
+        PH(10);
         reg_frontier_add_from(R, sk, end);
+        PH(11);
     }
     if (then_flood_fill) {                                                   // cifcaf.cpp:429-449
         reg_frontier_start(R, sk, c.K);
@@ -926,6 +1018,7 @@ template <bool REG, int NW>
 __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a, DevSkeleton sk, DevParams p,
                                                                      int n_growers, int nms_waves) {
     constexpr int kThreads = NW * kWave;
+    const bool use_bbox = REG && a.list_bbox != nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -943,6 +1036,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     c.occ = a.occ + (size_t)b * a.occ_image_words;
     c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
     c.pool_if = nullptr; c.pool_pack = nullptr; c.shadow_mine = nullptr; c.my_idx = 0;
+    c.bbox = nullptr;
 
     // ---- LDS carve: shared part, then one private block per growing wave
     unsigned char* sp = smem;
@@ -964,6 +1058,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     int* pool_pack = (int*)sp; sp += sizeof(int) * kPoolSlots * kWave;
     unsigned* shadow_by = (unsigned*)sp; sp += sizeof(unsigned) * NW * kWave; // [grower][lane]: pool slots in its published boxes
     sp = smem + (((size_t)(sp - smem) + 15) & ~(size_t)15);
+    float4* sh_bbox = (float4*)sp;                   // chunk boxes of the caf_th lists (register variant only)
+    if (use_bbox) sp += sizeof(float4) * E * kListBboxChunks;
     unsigned char* work_base = sp;                   // growth phase: private blocks; NMS phase: scratch
     unsigned char* private_base = sp;
     sp += (size_t)(wave >= 1 && wave <= S ? wave - 1 : 0) * assoc_private_bytes(K, A);   // other waves never touch theirs
@@ -994,12 +1090,21 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         l_other[k] = sk.adj_other[k]; l_bone[k] = sk.adj_bone[k]; l_fwd[k] = sk.adj_fwd[k]; l_first[k] = sk.adj_first[k];
     }
     for (int k = tid; k <= K; k += kThreads) l_off[k] = sk.adj_off[k];
+    if (use_bbox) {
+        const float4* src = reinterpret_cast<const float4*>(a.list_bbox) + (size_t)b * E * kListBboxChunks;
+        for (int k = tid; k < E * kListBboxChunks; k += kThreads) sh_bbox[k] = src[k];
+        c.bbox = sh_bbox;
+    }
     if (tid < NW) {
         TaskSlot t; t.state = kTaskIdle; t.cancel = 0; t.seed = -1; t.npub = 0; t.pk = 0; t.f = 0; t.score = 0.0;
         t.t_emit = t.t_done = t.pad0 = t.pad1 = 0;
         task[tid] = t;
     }
     if (tid < 8) sh_ctl[tid] = 0;
+#ifdef OPA_ASSOC_PHASE_TIMING
+    if (tid < kPhases) { g_ph[tid] = 0; g_phn[tid] = 0; }
+    if (tid < 16) g_ph_last[tid] = clock64();
+#endif
     for (int k = tid; k < kPoolSlots * kWave; k += kThreads) { pool_if[k] = kPoolIdxMask; pool_pack[k] = 0; }
     for (int k = tid; k < NW * kWave; k += kThreads) shadow_by[k] = 0u;
     c.adj_off = l_off; c.adj_other = l_other; c.adj_bone = l_bone; c.adj_fwd = l_fwd; c.adj_first = l_first;
@@ -1391,6 +1496,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             }
             if (leave) break;
             const long long t0 = wall_clock64();
+            PH(15);                                      // idle / waiting for a task
+            PH(16);                                      // (empty interval: the cost of a stamp)
             const int mine = __builtin_amdgcn_readfirstlane(my->seed);
             const int sf = seed_f[mine]; const float4 sd = seed_vxys[mine];
             for (int k = lane; k < K; k += kWave) {
@@ -1405,7 +1512,9 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             c.pub = &my->npub; c.n_pub = 0; c.my_idx = mine;
             c.pool_if = pool_if; c.pool_pack = pool_pack; c.shadow_mine = shadow_by + wave * kWave;
             publish_joint(c, p, sf, sd.y, sd.z, sd.w);   // the seed joint's own box: the rest of its blob
+            PH(12);
             grow_pose<REG>(c, p, rs, true, 1.0, false);
+            PH(13);
             c.pub = nullptr;
             if (c.aborted) {
                 if (lane == 0) flag_store(&my->state, kTaskIdle);
@@ -1415,16 +1524,22 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 const double sc = pose_score(c.jv, K);
                 if (lane == 0) { my->score = sc; my->t_done = (int)(wall_clock64() - t_kernel); flag_store(&my->state, kTaskDone); }
             }
+            PH(14);
             busy_ticks += wall_clock64() - t0;
         }
         c.cancel = nullptr;
         if (lane == 0) { atomicAdd(&sh_ctl[3], (int)busy_ticks); atomicAdd(&sh_ctl[4], c.n_blend); atomicAdd(&sh_ctl[6], c.t_blend); atomicAdd(&sh_ctl[7], c.t_blend_mem); }
     }
     sync_global();                        // stored poses visible to every wave; the private blocks are free
+#ifdef OPA_ASSOC_PHASE_TIMING
+    if (tid == 0 && (b == 0 || b == 3))
+        for (int k = 0; k < kPhases; k++) printf("PHASE img %d k %d cycles %d n %d\n", b, k, g_ph[k], g_phn[k]);
+#endif
     n_kept = sh_ctl[1]; n_dropped = sh_ctl[2];
 
     // ---- force complete, cifcaf.cpp:233-236,414-449: poses are independent, one per grower
     if (p.force_complete) {
+        c.bbox = nullptr;                                // the force-complete lists have no chunk boxes
         c.lists = a.lists_fc + (size_t)b * A * 2 * 7 * a.list_cap;
         c.list_counts = a.list_counts_fc + (size_t)b * A * 2;
         for (int k = tid; k < E; k += kThreads) c.sh_counts[k] = c.list_counts[k];
@@ -1567,10 +1682,15 @@ static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, con
                         + sizeof(unsigned long long) * ((size_t)a.max_ann * KC)
                         + sizeof(TaskSlot) * NW
                         + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann + 8 + kAssocStats)
-                        + sizeof(int) * (2 * kPoolSlots + NW) * kWave + 32;
+                        + sizeof(int) * (2 * kPoolSlots + NW) * kWave + 32
+                        + (REG && a.list_bbox ? sizeof(float4) * E * kListBboxChunks : 0);
     // work area behind it: one private block per grower while poses grow, the keypoint-NMS scratch afterwards
     const size_t priv = assoc_private_bytes(K, A);
+#ifdef OPA_ASSOC_PHASE_TIMING
+    const size_t budget = 159 * 1024;                // the diagnostic's static LDS
+#else
     const size_t budget = 160 * 1024;
+#endif
     if (shared + priv > budget) return hipErrorInvalidValue;
     int growers = (int)((budget - shared) / priv);
     if (growers > NW - 1) growers = NW - 1;
@@ -1600,7 +1720,9 @@ static int assoc_waves() {
     return v == 8 || v == 12 || v == 16 ? v : kAssocWavesDefault;
 }
 
-hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
+hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
+    AssocArgs a = args;
+    if (const char* e = getenv("OPA_ASSOC_BBOX")) { if (atoi(e) == 0) a.list_bbox = nullptr; }   // A/B: scan every chunk
     const int K = a.K, E = 2 * a.A;
     // the seed pool packs cell coordinates into 12 bits, the field into 8 and the seed index into 24
     if (a.occ_w > 4096 || a.occ_h > 4096 || a.F > 256 || a.seed_cap > 0xFFFFFF) return hipErrorInvalidValue;
@@ -1625,7 +1747,7 @@ __global__ __launch_bounds__(64) void blend_rows_kernel(const float* rows, int n
         for (int k = 0; k < 7; k++) soa[(size_t)k * n + i] = rows[(size_t)i * 7 + k];
     __threadfence_block();
     __shared__ float tgt[kBlendLdsFloats];
-    ListView L; L.base = soa; L.cap = n; L.n = n;
+    ListView L; L.base = soa; L.cap = n; L.n = n; L.bbox = nullptr;
     const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, s, filter_sigmas, only_max, tgt);
     if (lane == 0) {
         if (r.ok) { out4[0] = (double)r.x; out4[1] = (double)r.y; out4[2] = (double)r.s; out4[3] = r.v; }

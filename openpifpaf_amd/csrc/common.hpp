@@ -31,7 +31,7 @@ struct Layout {
     // byte offsets into the workspace (all 256-B aligned)
     size_t off_hdr, off_tile_clean, off_cifhr, off_act, off_act_count, off_seed_keys, off_seed_count,
            off_seed_f, off_seed_vxys, off_seed_cell, off_lists, off_list_counts,
-           off_lists_fc, off_list_counts_fc, off_occ, off_anns, off_ann_meta, off_status, off_stats, off_trace,
+           off_lists_fc, off_list_counts_fc, off_list_bbox, off_occ, off_anns, off_ann_meta, off_status, off_stats, off_trace,
            total;
     size_t occ_image_words;               // 32-bit words of one image's occupancy bitmap (capacity)
 };
@@ -87,7 +87,13 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
 hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
-                            float* lists, int32_t* counts, hipStream_t st);
+                            float* lists, int32_t* counts, hipStream_t st, float* chunk_bbox = nullptr);
+
+// The first kListBboxChunks 64-entry chunks of every CAF list get a bounding box of their (x1, y1) columns
+// (xmin, xmax, ymin, ymax; an empty chunk: +inf, -inf, +inf, -inf), written by cafscored behind the list:
+// grow_connection_blend's window test (cifcaf.cpp:54-57) cannot pass for any entry of a chunk whose box misses
+// the window, so the association kernel only loads the chunks that can matter.
+constexpr int kListBboxChunks = 16;
 
 // zero-fill on the stream with a kernel of this library (the runtime's memset / small-copy nodes are the
 // one thing that faulted when the decode was replayed as a captured HIP graph); bytes % 4 == 0
@@ -102,6 +108,7 @@ struct AssocArgs {
     const int32_t* seed_cell;  // occupancy cell of the seed: x | y << 12 | box half-width << 24 (seed_cell_pack)
     const float* lists; const int32_t* list_counts;          // caf_th lists
     const float* lists_fc; const int32_t* list_counts_fc;    // force-complete lists (or null)
+    const float* list_bbox;  // [B][A][2][kListBboxChunks][4] chunk boxes of `lists` (or null)
     unsigned* occ;           // occupancy bitmap [B][occ_image_words]: per image [F][occ_h][(occ_w+31)/32] words, zeroed by the kernel
     size_t occ_image_words;
     int32_t* stats;          // [B, 16] statistics of the association (or null), see include/openpifpaf_amd.h
@@ -149,9 +156,13 @@ namespace opa {
 // annotation scratch live in HBM and are written by one wave and read by the others.  A plain
 // __syncthreads() compiles to "s_waitcnt lgkmcnt(0); s_barrier" -- stores may still be in flight
 // when the barrier releases (observed: waves disagreeing on an occupancy test, then running one
-// barrier apart).  Release = wait for this wave's stores, acquire = drop stale L1 lines.
+// barrier apart).  Release = wait for this wave's stores to be acknowledged by the L2 (workgroup scope: all
+// waves of a workgroup sit behind the same L2; an agent-scope release would also write the whole L2 back,
+// `buffer_wbl2`, which costs microseconds per call and 170 us when 600 workgroups do it at once), acquire =
+// drop stale L1 lines (agent scope: atomics are performed at the L2 and do not update the L1).
 __device__ __forceinline__ void sync_global() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): on gfx9 stores count too, until the L2 has them
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
