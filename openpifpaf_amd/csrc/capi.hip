@@ -3,6 +3,7 @@
 #include "common.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <mutex>

@@ -280,6 +280,8 @@ __device__ __forceinline__ BlendResult blend_finish(float s1, float s2, bool hav
 typedef __attribute__((address_space(1))) const float gfloat;
 
 typedef __attribute__((address_space(3))) float lfloat;
+typedef __attribute__((address_space(1))) const int gint;
+typedef __attribute__((address_space(3))) int lint;
 
 constexpr int kTgtFloats = 3 * kBlendChunks * kWave;     // target columns (x2, y2, s2) of the list being scanned
 constexpr int kBlendLdsFloats = kTgtFloats + 4 * kWave;  // + the compacted (x1, y1, c, position) of a scan
@@ -911,6 +913,7 @@ __device__ __forceinline__ bool box_contains(const OccBox& b, int xi, int yi) {
 }
 
 constexpr int kPoolSlots = 8;             // seed-pool slots per coordinator lane
+constexpr int kSeedStage = 1024;          // seeds (field, cell) the coordinator keeps staged in LDS beyond its scan position (ring)
 constexpr int kPoolIdxMask = 0xFFFFFF;    // seed index bits of a slot word (all ones: empty slot); field above
 
 __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s) {
@@ -1002,8 +1005,10 @@ __device__ __forceinline__ double pose_score(const double* v, int K) {
 // ------------------------------------------------------------------- kernel
 // One LDS task slot per wave: the coordinator hands a seed to grower g by filling task[g] and setting
 // state = ASSIGNED; the grower answers DONE (pose, boxes and score are in its private block / slot) or, if
-// `cancel` was raised while it grew, IDLE.  Only the coordinator moves a slot out of DONE.
-constexpr int kTaskIdle = 0, kTaskAssigned = 1, kTaskDone = 2;
+// `cancel` was raised while it grew, IDLE.  Only the coordinator moves a slot out of DONE: to IDLE (result
+// dropped) or to ACCEPTED -- then the grower itself marks the pose's boxes in the bitmap and stores the pose at
+// scratch slot `pad0` (-1: not stored), off the coordinator's critical path, and returns to IDLE.
+constexpr int kTaskIdle = 0, kTaskAssigned = 1, kTaskDone = 2, kTaskAccepted = 3;
 struct __attribute__((aligned(16))) TaskSlot { int state, cancel, seed, npub, pk, f; double score; int t_emit, t_done, pad0, pad1; };
 constexpr int kAssocTrace = 64;           // commits recorded per image in the optional trace ("assoc_trace")
 
@@ -1057,6 +1062,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     int* pool_if = (int*)sp; sp += sizeof(int) * kPoolSlots * kWave;        // the coordinator's seed pool, mirrored for the growers
     int* pool_pack = (int*)sp; sp += sizeof(int) * kPoolSlots * kWave;
     unsigned* shadow_by = (unsigned*)sp; sp += sizeof(unsigned) * NW * kWave; // [grower][lane]: pool slots in its published boxes
+    int* stage_f = (int*)sp; sp += sizeof(int) * kSeedStage;                // the next seeds' field and cell, staged ahead of the pool refill
+    int* stage_pk = (int*)sp; sp += sizeof(int) * kSeedStage;
     sp = smem + (((size_t)(sp - smem) + 15) & ~(size_t)15);
     float4* sh_bbox = (float4*)sp;                   // chunk boxes of the caf_th lists (register variant only)
     if (use_bbox) sp += sizeof(float4) * E * kListBboxChunks;
@@ -1189,7 +1196,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         unsigned ever = 0u;                              //        ... was shadowed at some time (statistics)
         unsigned gmap = 0u;
         int scan_pos = 0, n_live = 0;
-        bool bitmap_dirty = a.n_initial > 0, watchdog = false;
+        bool watchdog = false, marks_pending = false;
         long long wait_ticks = 0;
         unsigned iter = 0;
         const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -1205,6 +1212,24 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             return (int)((unsigned)s_if[r] >> 24) == fo && (s_if[r] & kIdxMask) > idx &&
                    dx > -half && dx < half && dy > -half && dy < half;
         };
+        // Seeds enter the pool through two dependent memory round trips (their field and cell, then the bitmap
+        // word of that cell).  The first is taken off the refill: the (field, cell) of the next kSeedStage
+        // seeds travel HBM/L2 -> LDS directly, in 64-seed blocks, issued after a refill and landed by the next.
+        int pf_end = 0;                                  // seeds below it are staged (multiple of 64)
+        auto stage_seeds = [&]() {
+            int limit = (scan_pos & ~(kWave - 1)) + kSeedStage;
+            const int n_round = (n_seeds + kWave - 1) & ~(kWave - 1);
+            if (limit > n_round) limit = n_round;
+#pragma unroll
+            for (int r = 0; r < 8; r++)
+                if (pf_end < limit) {
+                    const int idx = pf_end + lane, ii = idx < n_seeds ? idx : 0;
+                    __builtin_amdgcn_global_load_lds((gint*)seed_f + ii, (lint*)stage_f + (pf_end & (kSeedStage - 1)), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gint*)seed_cell + ii, (lint*)stage_pk + (pf_end & (kSeedStage - 1)), 4, 0, 0);
+                    pf_end += kWave;
+                }
+        };
+        stage_seeds(); stage_seeds();
         auto count_live = [&]() {
             n_live = 0;
 #pragma unroll
@@ -1231,10 +1256,17 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             //         poses accepted so far); slot (r, lane) takes the seed of its rank among the free slots
             if (scan_pos < n_seeds && 2 * n_live < WR * kWave) {
                 const long long t_ph = wall_clock64();
-                if (bitmap_dirty) {                      // this wave's marks (atomics, performed at L2) before its own reads,
-                    __builtin_amdgcn_s_waitcnt(0x0F70);  // which bypass the L1 (agent-scope loads): vmcnt(0) is all it takes
-                    bitmap_dirty = false;
+                if (marks_pending) {                     // accepted poses are marked by their growers: all of them are done
+                    while (__ballot(is_grower_lane && flag_load(&task[lane].state) == kTaskAccepted) != 0ull &&
+                           wall_clock64() - t_kernel <= kWatchdogTicks)
+                        __builtin_amdgcn_s_sleep(1);
+                    marks_pending = false;
+                    st[20] += (int)(wall_clock64() - t_ph);
                 }
+                // this wave's marks (atomics, performed at L2) before its own reads, which bypass the L1 (agent-scope
+                // loads): vmcnt(0) is all it takes -- and the staged seeds have landed in LDS
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                wave_sync();
                 unsigned fresh = 0u;                     // slots filled by this refill
                 while (scan_pos < n_seeds) {
                     int nidx[WR], base = 0;
@@ -1246,19 +1278,29 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                         base += __popcll(m);
                     }
                     if (base == 0) break;
+                    // Straight-line code on clamped indices: the eight bitmap words of a lane are ONE memory round
+                    // trip (loads inside `if`s are waited for one by one).
                     int ff[WR], pk[WR]; unsigned ow[WR];
+                    bool beyond = false;                 // a seed beyond the staged window (second round of a refill)
 #pragma unroll
-                    for (int r = 0; r < WR; r++) {
-                        ff[r] = 0; pk[r] = 0;
-                        if (nidx[r] < n_seeds) { ff[r] = seed_f[nidx[r]]; pk[r] = seed_cell[nidx[r]]; }
+                    for (int r = 0; r < WR; r++) beyond |= nidx[r] >= pf_end && nidx[r] < n_seeds;
+                    if (__ballot(beyond) != 0ull) {
+#pragma unroll
+                        for (int r = 0; r < WR; r++) { const int ii = nidx[r] < n_seeds ? nidx[r] : 0; ff[r] = seed_f[ii]; pk[r] = seed_cell[ii]; }
+#pragma unroll
+                        for (int r = 0; r < WR; r++) asm volatile("" : "+v"(ff[r]), "+v"(pk[r]) :: "memory");
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < WR; r++) { ff[r] = stage_f[nidx[r] & (kSeedStage - 1)]; pk[r] = stage_pk[nidx[r] & (kSeedStage - 1)]; }
                     }
 #pragma unroll
                     for (int r = 0; r < WR; r++) {
-                        ow[r] = 0xFFFFFFFFu;
-                        if (nidx[r] < n_seeds)
-                            ow[r] = __hip_atomic_load(&c.occ[((size_t)ff[r] * c.occ_h + ((pk[r] >> 12) & 0xfff)) * c.occ_wpr + ((pk[r] & 0xfff) >> 5)],
-                                                      __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const bool valid = nidx[r] < n_seeds;
+                        const size_t word = valid ? ((size_t)ff[r] * c.occ_h + ((pk[r] >> 12) & 0xfff)) * c.occ_wpr + ((pk[r] & 0xfff) >> 5) : 0;
+                        ow[r] = __hip_atomic_load(&c.occ[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+#pragma unroll
+                    for (int r = 0; r < WR; r++) asm volatile("" : "+v"(ow[r]) :: "memory");
 #pragma unroll
                     for (int r = 0; r < WR; r++)
                         if (nidx[r] < n_seeds && !((ow[r] >> (pk[r] & 31)) & 1u)) {
@@ -1270,6 +1312,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     if (2 * n_live >= WR * kWave) break;
                 }
                 st[6]++;
+                stage_seeds();
+                const long long t_sh = wall_clock64();
                 // the new occupants: mirror them, forget what the growers said about the slots' former occupants,
                 // and test them against the boxes the candidates in flight have published so far
 #pragma unroll
@@ -1293,6 +1337,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     if (bits) atomicOr(word, bits);
                 }
                 st[18] += (int)(wall_clock64() - t_ph);
+                st[23] += (int)(wall_clock64() - t_sh);
             }
 
             // ---- 3. Which pooled seeds lie in a joint box an EARLIER live candidate has published so far?  (The
@@ -1399,7 +1444,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 // come true.  It is never shadowed (a live candidate shadowing it would be the head), so step 4
                 // takes it as soon as a grower is idle.  If every grower holds or grows a LATER seed that
                 // none of the commits to come can free, the latest of them is given up.
-                if (__ballot(is_grower_lane && (flag_load(&task[lane].state) == kTaskIdle || flag_peek(&task[lane].cancel))) != 0ull) {
+                const int vstate = is_grower_lane ? flag_load(&task[lane].state) : kTaskAssigned;
+                if (__ballot(is_grower_lane && (vstate == kTaskIdle || vstate == kTaskAccepted || flag_peek(&task[lane].cancel))) != 0ull) {
                     __builtin_amdgcn_s_sleep(1);         // a grower is idle or about to be
                     continue;
                 }
@@ -1463,11 +1509,19 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 tr[0] = (int)(wall_clock64() - t_kernel); tr[1] = task[hg].t_emit; tr[2] = task[hg].t_done;
                 tr[3] = (int)hd | (hg << 24);
             }
-            accept_pose(hg - 1, task[hg].score, -1);
-            bitmap_dirty = true;
+            {   // accepted: its grower marks the bitmap and stores the pose (cifcaf.cpp:225-230)
+                const double score = task[hg].score;
+                int slot = -1;
+                if (!(prune && score < p.nms_instance_threshold)) {
+                    if (n_kept >= a.max_ann) n_dropped++;
+                    else slot = n_kept++;
+                }
+                if (lane == 0) task[hg].pad0 = slot;
+                marks_pending = true;
+            }
             st[1]++;
             wave_sync();                                 // every lane has read block hg-1
-            if (lane == 0) flag_store(&task[hg].state, kTaskIdle);
+            if (lane == 0) flag_store(&task[hg].state, kTaskAccepted);
             st[17] += (int)(wall_clock64() - t_cm);
         }
         if (lane == 0) {
@@ -1490,7 +1544,25 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         for (;;) {
             bool leave = false;
             for (;;) {
-                if (flag_load(&my->state) == kTaskAssigned) break;
+                const int state = flag_load(&my->state);
+                if (state == kTaskAssigned) break;
+                if (state == kTaskAccepted) {            // the pose this wave grew was accepted: Occupancy::set + store
+                    const PoseView q = pose_of_block(private_base, wave - 1, K, A);
+                    const int slot = __builtin_amdgcn_readfirstlane(my->pad0);
+                    occ_mark_pose(c, q);
+                    if (slot >= 0) {
+                        double* dst = anns + (size_t)slot * K * 4;
+                        for (int k = lane; k < K; k += kWave) {
+                            dst[4 * k + 0] = q.v[k]; dst[4 * k + 1] = (double)q.x[k];
+                            dst[4 * k + 2] = (double)q.y[k]; dst[4 * k + 3] = (double)q.s[k];
+                        }
+                        if (lane == 0) ann_ids[slot] = -1;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the marks are at the L2 before the coordinator reads the bitmap
+                    wave_sync();
+                    if (lane == 0) flag_store(&my->state, kTaskIdle);
+                    continue;
+                }
                 if (flag_load(&sh_ctl[0]) || wall_clock64() - t_kernel > 2 * kWatchdogTicks) { leave = true; break; }
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -1682,7 +1754,7 @@ static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, con
                         + sizeof(unsigned long long) * ((size_t)a.max_ann * KC)
                         + sizeof(TaskSlot) * NW
                         + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann + 8 + kAssocStats)
-                        + sizeof(int) * (2 * kPoolSlots + NW) * kWave + 32
+                        + sizeof(int) * (2 * kPoolSlots + NW) * kWave + 32 + sizeof(int) * 2 * kSeedStage
                         + (REG && a.list_bbox ? sizeof(float4) * E * kListBboxChunks : 0);
     // work area behind it: one private block per grower while poses grow, the keypoint-NMS scratch afterwards
     const size_t priv = assoc_private_bytes(K, A);
