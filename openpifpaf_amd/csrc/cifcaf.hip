@@ -113,6 +113,9 @@ struct ImageCtx {
     int aborted;                         // set when a growth stopped because of it
     int* pub; int n_pub;                 // the grower's "boxes published" counter in LDS (or null) and its value
     const int *pool_if, *pool_pack;      // LDS mirror of the coordinator's seed pool [8][64] (slot r of lane l at r*64+l)
+    const int* pool_ep;                  // ... and the refill epoch at which each slot got its occupant
+    const int* epoch; int* ack;          // the coordinator's refill epoch; this grower's "tested everything up to" answer
+    int my_epoch;
     unsigned* shadow_mine;               // [64] bit r of word l: pool slot (r, l) lies in a box this grower published
     int my_idx;                          // index of the seed being grown
     // private LDS (one block per growing wave)
@@ -518,6 +521,7 @@ __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, dou
 // joint WILL occupy if the pose is accepted, so that the coordinator can stop handing out -- and growing --
 // seeds this pose is going to cover (defined behind the occupancy helpers).
 __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s);
+__device__ __forceinline__ void pool_catch_up(ImageCtx& c);
 
 // -------------------------------------------------------------- frontier heap
 // Exact behaviour of std::priority_queue<FrontierEntry, vector, FrontierCompare>
@@ -629,6 +633,7 @@ __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool rever
     for (int j = 0; j < c.K; j++) if (c.jv[j] != 0.0) frontier_add_from(c, j);
     while (c.heap_n > 0) {
         if (c.cancel && flag_peek(c.cancel)) { c.aborted = 1; return; }  // the seed died while its pose grew
+        pool_catch_up(c);
         const int e = heap_pop(c);
         const int start = c.e_se[e] >> 16, end = c.e_se[e] & 0xffff;
         if (c.jv[end] > 0.0) continue;                                   // :284
@@ -824,6 +829,7 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
     reg_frontier_start(R, sk, c.K);
     while (R.heap_n > 0) {
         if (c.cancel && flag_peek(c.cancel)) { c.aborted = 1; return; }      // the seed died while its pose grew
+        pool_catch_up(c);
         const int slot = reg_heap_pop(R);
         const int info = rlane(sk.slot_info, slot);
         const int start = info & 0xff, end = (info >> 8) & 0xff;
@@ -936,6 +942,28 @@ __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, i
     if (lane == 0) { c.jbox[k] = b; *c.pub = c.n_pub; }
 }
 
+// Seeds that entered the pool after this growth published a box were not there when publish_joint tested the pool:
+// the coordinator bumps an epoch at every refill, and each candidate in flight tests the newcomers against ITS
+// boxes (published so far, or final) -- eleven waves in parallel instead of the coordinator alone -- and acknowledges.
+__device__ __forceinline__ void pool_catch_up(ImageCtx& c) {
+    if (!c.epoch) return;
+    const int e = flag_load(c.epoch);
+    if (e == c.my_epoch) return;
+    const int lane = lane_id();
+    unsigned bits = 0u;
+#pragma unroll
+    for (int r = 0; r < kPoolSlots; r++) {
+        const int ep = c.pool_ep[r * kWave + lane], sif = c.pool_if[r * kWave + lane], spk = c.pool_pack[r * kWave + lane];
+        const int f = (int)((unsigned)sif >> 24), idx = sif & kPoolIdxMask;
+        if (ep - c.my_epoch > 0 && idx != kPoolIdxMask && idx > c.my_idx && f < c.F &&
+            box_contains(c.jbox[f], spk & 0xfff, (spk >> 12) & 0xfff)) bits |= 1u << r;
+    }
+    if (bits) atomicOr(&c.shadow_mine[lane], bits);
+    c.my_epoch = e;
+    wave_sync();
+    if (lane == 0) flag_store(c.ack, e);
+}
+
 // Occupancy::get on the bitmap (one bit per cell, rows of occ_wpr 32-bit words)
 __device__ __forceinline__ bool occ_test(const ImageCtx& c, int f, int xi, int yi) {
     const unsigned w = c.occ[((size_t)f * c.occ_h + yi) * c.occ_wpr + (xi >> 5)];
@@ -1041,6 +1069,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     c.occ = a.occ + (size_t)b * a.occ_image_words;
     c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
     c.pool_if = nullptr; c.pool_pack = nullptr; c.shadow_mine = nullptr; c.my_idx = 0;
+    c.pool_ep = nullptr; c.epoch = nullptr; c.ack = nullptr; c.my_epoch = 0;
     c.bbox = nullptr;
 
     // ---- LDS carve: shared part, then one private block per growing wave
@@ -1057,10 +1086,12 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     if ((K + 1) & 1) sp += sizeof(int);             // keep 8-byte alignment for what follows
     int* nms_order = (int*)sp; sp += sizeof(int) * a.max_ann;
     int* nms_rank = (int*)sp; sp += sizeof(int) * a.max_ann;
-    int* sh_ctl = (int*)sp; sp += sizeof(int) * 8;   // 0 exit flag, 1 n_kept, 2 n_dropped, 3 grower ticks, 4 list scans, 5 watchdog
+    int* sh_ctl = (int*)sp; sp += sizeof(int) * 12;  // 0 exit flag, 1 n_kept, 2 n_dropped, 3 grower ticks, 4 list scans, 5 watchdog,
+                                                     // 6-7 scan timing (diagnostic builds), 8 refill epoch
     int* sh_stats = (int*)sp; sp += sizeof(int) * kAssocStats;
     int* pool_if = (int*)sp; sp += sizeof(int) * kPoolSlots * kWave;        // the coordinator's seed pool, mirrored for the growers
     int* pool_pack = (int*)sp; sp += sizeof(int) * kPoolSlots * kWave;
+    int* pool_ep = (int*)sp; sp += sizeof(int) * kPoolSlots * kWave;
     unsigned* shadow_by = (unsigned*)sp; sp += sizeof(unsigned) * NW * kWave; // [grower][lane]: pool slots in its published boxes
     int* stage_f = (int*)sp; sp += sizeof(int) * kSeedStage;                // the next seeds' field and cell, staged ahead of the pool refill
     int* stage_pk = (int*)sp; sp += sizeof(int) * kSeedStage;
@@ -1107,12 +1138,12 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         t.t_emit = t.t_done = t.pad0 = t.pad1 = 0;
         task[tid] = t;
     }
-    if (tid < 8) sh_ctl[tid] = 0;
+    if (tid < 12) sh_ctl[tid] = 0;
 #ifdef OPA_ASSOC_PHASE_TIMING
     if (tid < kPhases) { g_ph[tid] = 0; g_phn[tid] = 0; }
     if (tid < 16) g_ph_last[tid] = clock64();
 #endif
-    for (int k = tid; k < kPoolSlots * kWave; k += kThreads) { pool_if[k] = kPoolIdxMask; pool_pack[k] = 0; }
+    for (int k = tid; k < kPoolSlots * kWave; k += kThreads) { pool_if[k] = kPoolIdxMask; pool_pack[k] = 0; pool_ep[k] = 0; }
     for (int k = tid; k < NW * kWave; k += kThreads) shadow_by[k] = 0u;
     c.adj_off = l_off; c.adj_other = l_other; c.adj_bone = l_bone; c.adj_fwd = l_fwd; c.adj_first = l_first;
     sync_global();                                   // bitmap zeros are in memory before anyone marks or tests
@@ -1197,6 +1228,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         unsigned gmap = 0u;
         int scan_pos = 0, n_live = 0;
         bool watchdog = false, marks_pending = false;
+        int epoch = 0;                                   // refills so far; `unver`: slots filled by refills not every candidate in flight has tested yet
+        unsigned unver = 0u;
         long long wait_ticks = 0;
         unsigned iter = 0;
         const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -1241,9 +1274,10 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             if (t_iter - t_kernel > kWatchdogTicks) { watchdog = true; break; }
             iter++;
             // ---- 1. the growers (lane g looks at grower g): state, cancel flag, seed, published boxes
-            int g_state = -1, g_cancel = 0, g_seed = -1, g_pub = 0;
+            int g_state = -1, g_cancel = 0, g_seed = -1, g_pub = 0, g_ack = 0;
             if (is_grower_lane) {
                 g_state = flag_load(&task[lane].state);
+                g_ack = flag_peek(&task[lane].pad1);
                 g_cancel = flag_peek(&task[lane].cancel); g_seed = task[lane].seed; g_pub = flag_peek(&task[lane].npub);
                 if (g_state == kTaskDone && g_cancel) {  // a growth that finished after its seed died: drop the result
                     flag_store(&task[lane].state, kTaskIdle); g_state = kTaskIdle;
@@ -1251,6 +1285,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             }
             const bool g_live = (g_state == kTaskAssigned || g_state == kTaskDone) && !g_cancel;
             const unsigned long long live_mask = __ballot(g_live);
+            if (__ballot(unver != 0u) != 0ull && __ballot(g_live && g_ack != epoch) == 0ull) unver = 0u;   // everyone has tested the newcomers
 
             // ---- 2. refill free slots with the next seeds that are still free in the bitmap (:211 for the
             //         poses accepted so far); slot (r, lane) takes the seed of its rank among the free slots
@@ -1313,31 +1348,20 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 }
                 st[6]++;
                 stage_seeds();
-                const long long t_sh = wall_clock64();
-                // the new occupants: mirror them, forget what the growers said about the slots' former occupants,
-                // and test them against the boxes the candidates in flight have published so far
+                // the new occupants: mirror them, forget what the growers said about the slots' former occupants, and
+                // have every candidate in flight test them against the boxes it has published (pool_catch_up)
+                epoch++;
 #pragma unroll
                 for (int r = 0; r < WR; r++)
-                    if ((fresh >> r) & 1u) { pool_if[r * kWave + lane] = s_if[r]; pool_pack[r * kWave + lane] = s_pack[r]; }
-                for (int g = 1; g <= S; g++) {
-                    if (!((live_mask >> g) & 1ull)) continue;         // (its word is cleared when it is handed a seed)
-                    unsigned* word = &shadow_by[g * kWave + lane];
-                    if (fresh) atomicAnd(word, ~fresh);
-                    if (rlane(g_pub, g) == 0) continue;
-                    const int idx = rlane(g_seed, g);
-                    const OccBox* bx = pose_of_block(private_base, g - 1, K, A).box;
-                    OccBox bb[WR];
-#pragma unroll
-                    for (int r = 0; r < WR; r++) bb[r] = bx[(fresh >> r) & 1u ? (unsigned)s_if[r] >> 24 : 0u];
-                    unsigned bits = 0u;
-#pragma unroll
-                    for (int r = 0; r < WR; r++)
-                        if ((fresh >> r) & 1u && (s_if[r] & kIdxMask) > idx &&
-                            box_contains(bb[r], s_pack[r] & 0xfff, (s_pack[r] >> 12) & 0xfff)) bits |= 1u << r;
-                    if (bits) atomicOr(word, bits);
-                }
+                    if ((fresh >> r) & 1u) {
+                        pool_if[r * kWave + lane] = s_if[r]; pool_pack[r * kWave + lane] = s_pack[r]; pool_ep[r * kWave + lane] = epoch;
+                    }
+                if (fresh)
+                    for (int g = 1; g <= S; g++) atomicAnd(&shadow_by[g * kWave + lane], ~fresh);
+                unver |= fresh;
+                wave_sync();
+                if (lane == 0) flag_store(&sh_ctl[8], epoch);
                 st[18] += (int)(wall_clock64() - t_ph);
-                st[23] += (int)(wall_clock64() - t_sh);
             }
 
             // ---- 3. Which pooled seeds lie in a joint box an EARLIER live candidate has published so far?  (The
@@ -1380,7 +1404,15 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 }
             }
 
-            // ---- 4. hand the next candidates, in seed order, to the idle growers
+            // the head: the smallest-index live seed; everything before it is decided
+            unsigned hd = kNone;
+#pragma unroll
+            for (int r = 0; r < WR; r++)
+                if ((occupied >> r) & 1u) hd = min(hd, (unsigned)(s_if[r] & kIdxMask));
+            hd = ~wave_max_u32(~hd);
+
+            // ---- 4. hand the next candidates, in seed order, to the idle growers (newcomers the candidates in
+            //         flight have not tested yet wait for that -- except the head, which nothing can shadow)
             unsigned long long idle = __ballot(g_state == kTaskIdle);
             const long long t_em = idle ? wall_clock64() : 0;
             const bool had_idle = idle != 0ull;
@@ -1389,7 +1421,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 unsigned mn = kNone;
 #pragma unroll
                 for (int r = 0; r < WR; r++)
-                    if ((elig >> r) & 1u) mn = min(mn, (unsigned)(s_if[r] & kIdxMask));
+                    if ((elig >> r) & 1u && (!((unver >> r) & 1u) || (unsigned)(s_if[r] & kIdxMask) == hd))
+                        mn = min(mn, (unsigned)(s_if[r] & kIdxMask));
                 mn = ~wave_max_u32(~mn);
                 if (mn == kNone) break;
                 const int g = __builtin_ctzll(idle);
@@ -1420,12 +1453,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             }
             if (had_idle) st[19] += (int)(wall_clock64() - t_em);
 
-            // ---- 5. the head: the smallest-index live seed; everything before it is decided
-            unsigned hd = kNone;
-#pragma unroll
-            for (int r = 0; r < WR; r++)
-                if ((occupied >> r) & 1u) hd = min(hd, (unsigned)(s_if[r] & kIdxMask));
-            hd = ~wave_max_u32(~hd);
+            // ---- 5. commit the head when its growth is done
             if (hd == kNone) {
                 if (scan_pos >= n_seeds) break;          // no live seed in the pool, none left to scan
                 continue;                                // pool ran empty: refill
@@ -1546,6 +1574,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             for (;;) {
                 const int state = flag_load(&my->state);
                 if (state == kTaskAssigned) break;
+                if (state == kTaskDone) pool_catch_up(c);
+                else c.epoch = nullptr;
                 if (state == kTaskAccepted) {            // the pose this wave grew was accepted: Occupancy::set + store
                     const PoseView q = pose_of_block(private_base, wave - 1, K, A);
                     const int slot = __builtin_amdgcn_readfirstlane(my->pad0);
@@ -1583,11 +1613,16 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             c.aborted = 0;
             c.pub = &my->npub; c.n_pub = 0; c.my_idx = mine;
             c.pool_if = pool_if; c.pool_pack = pool_pack; c.shadow_mine = shadow_by + wave * kWave;
+            c.pool_ep = pool_ep; c.epoch = &sh_ctl[8]; c.ack = &my->pad1;
+            c.my_epoch = flag_load(c.epoch);             // publish_joint tests the whole pool as of now; later refills: pool_catch_up
+            if (lane == 0) flag_store(c.ack, c.my_epoch);
             publish_joint(c, p, sf, sd.y, sd.z, sd.w);   // the seed joint's own box: the rest of its blob
             PH(12);
             grow_pose<REG>(c, p, rs, true, 1.0, false);
             PH(13);
             c.pub = nullptr;
+            const int* epoch_ptr = c.epoch;
+            c.epoch = nullptr;                           // (pose_boxes rewrites the boxes: no tests in between)
             if (c.aborted) {
                 if (lane == 0) flag_store(&my->state, kTaskIdle);
             } else {
@@ -1595,6 +1630,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 wave_sync();
                 const double sc = pose_score(c.jv, K);
                 if (lane == 0) { my->score = sc; my->t_done = (int)(wall_clock64() - t_kernel); flag_store(&my->state, kTaskDone); }
+                c.epoch = epoch_ptr;                     // still a candidate in flight: keeps testing newcomers while it waits
             }
             PH(14);
             busy_ticks += wall_clock64() - t0;
@@ -1753,8 +1789,8 @@ static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, con
     const size_t shared = sizeof(double) * a.max_ann
                         + sizeof(unsigned long long) * ((size_t)a.max_ann * KC)
                         + sizeof(TaskSlot) * NW
-                        + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann + 8 + kAssocStats)
-                        + sizeof(int) * (2 * kPoolSlots + NW) * kWave + 32 + sizeof(int) * 2 * kSeedStage
+                        + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann + 12 + kAssocStats)
+                        + sizeof(int) * (3 * kPoolSlots + NW) * kWave + 32 + sizeof(int) * 2 * kSeedStage
                         + (REG && a.list_bbox ? sizeof(float4) * E * kListBboxChunks : 0);
     // work area behind it: one private block per grower while poses grow, the keypoint-NMS scratch afterwards
     const size_t priv = assoc_private_bytes(K, A);
