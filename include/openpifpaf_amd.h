@@ -269,6 +269,12 @@ int opa_gemm_pro_bias_act_bf16(const void* a_dev, const void* a_bias_dev, const 
                                const void* residual_dev, void* out_dev, int64_t m, int32_t n, int32_t k,
                                int32_t relu, void* stream);
 
+/* Both of the above in float32 (v_mfma_f32_32x32x2f32, f32 operands and accumulation): the network at the
+ * reference's precision.  a_bias_dev may be NULL (no prologue).  K % 32 == 0, N % 64 == 0, pointers 16-B aligned. */
+int opa_gemm_bias_act_f32(const float* a_dev, const float* a_bias_dev, const float* w_dev, const float* bias_dev,
+                          const float* residual_dev, float* out_dev, int64_t m, int32_t n, int32_t k,
+                          int32_t relu, void* stream);
+
 /* Depthwise k x k convolution (k = 3 or 5, stride 1 or 2, padding k/2) of a channels-last activation, with the
  * folded batch-norm bias and optionally ReLU fused (the ShuffleNetV2K unit of the reference,
  * network/basenetworks.py:186-268; MIOpen runs it as a grouped MFMA convolution, ~100x slower).

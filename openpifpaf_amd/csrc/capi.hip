@@ -616,6 +616,24 @@ int opa_gemm_pro_bias_act_bf16(const void* a_dev, const void* a_bias_dev, const 
     return OPA_OK;
 }
 
+int opa_gemm_bias_act_f32(const float* a_dev, const float* a_bias_dev, const float* w_dev, const float* bias_dev,
+                          const float* residual_dev, float* out_dev, int64_t m, int32_t n, int32_t k,
+                          int32_t relu, void* stream) {
+    if (!a_dev || !w_dev || !bias_dev || !out_dev || m < 0 || n <= 0 || k <= 0 || m > 0x7fffffffll)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_gemm_bias_act_f32: bad arguments");
+    if (k % 32 != 0 || n % 64 != 0)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_gemm_bias_act_f32: K must be a multiple of 32 and N of 64");
+    if (((uintptr_t)a_dev | (uintptr_t)a_bias_dev | (uintptr_t)w_dev | (uintptr_t)out_dev | (uintptr_t)residual_dev |
+         (uintptr_t)bias_dev) & 15)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_gemm_bias_act_f32: pointers must be 16-B aligned");
+    if (m == 0) return OPA_OK;
+    hipError_t e = launch_gemm_f32_bias_act(a_dev, w_dev, bias_dev, residual_dev, out_dev, (int)m, n, k, relu,
+                                            (hipStream_t)stream, a_bias_dev);
+    if (e != hipSuccess) return fail_hip(e, "gemm_f32_bias_act");
+    prof_mark((hipStream_t)stream, a_bias_dev ? "gemm_f32_pro_bias_act_kernel" : "gemm_f32_bias_act_kernel");
+    return OPA_OK;
+}
+
 int opa_dwconv_bias_act(const void* x_dev, int64_t x_pixel_stride, const void* w_dev, const void* bias_dev,
                         void* out_dev, int64_t out_pixel_stride, int32_t batch, int32_t h, int32_t w,
                         int32_t channels, int32_t k, int32_t stride, int32_t dtype, int32_t relu, void* stream) {

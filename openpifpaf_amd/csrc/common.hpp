@@ -135,6 +135,9 @@ hipError_t launch_bias_act(void* x, const void* bias, const void* res, long long
 hipError_t launch_gemm_bias_act(const void* A, const void* W, const void* bias, const void* res, void* out,
                                 int M, int N, int K, int relu, hipStream_t st, const void* a_bias = nullptr);
 
+hipError_t launch_gemm_f32_bias_act(const float* A, const float* W, const float* bias, const float* res, float* out,
+                                    int M, int N, int K, int relu, hipStream_t st, const float* a_bias = nullptr);
+
 hipError_t launch_dwconv(const void* x, long long xs, const void* w, const void* bias, void* out, long long os,
                          int B, int H, int W, int C, int K, int S, int dtype, int relu, hipStream_t st);
 hipError_t launch_channel_interleave(const void* a, long long as, const void* b, long long bs, void* out,

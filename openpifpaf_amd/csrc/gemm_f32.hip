@@ -1,0 +1,196 @@
+// The float32 twin of gemm_epilogue.hip: 1x1 convolution as an MFMA GEMM with the whole epilogue fused,
+//     out[M,N] = act( A[M,K] * W[N,K]^T + bias[N] (+ residual[M,N]) )        (f32 in/out, f32 math)
+// for the network at the reference's precision.  At 641 px / batch 32 the expanding 1x1 convolution of a
+// ResNet bottleneck writes a 3.4 GB (layer 1) tensor that the separate bias + residual + ReLU pass then reads,
+// adds the 3.4 GB residual to and writes again: 2.1 ms beside a 1.2 ms convolution.  Fused, the product never
+// leaves the registers before the epilogue: one read of the residual, one write of the output.
+//
+// v_mfma_f32_32x32x2f32: lane l supplies A[row l&31][k = l>>5] and B[k = l>>5][col l&31].  Operands are staged
+// K-major in LDS like in the bf16 kernel; a lane reads FOUR consecutive k of its row with one ds_read_b128 and
+// feeds them to four MFMAs, so MFMA m of a group multiplies the k pair (8j + m, 8j + 4 + m) -- every k once, the
+// order of the sum over k being as arbitrary as in any GEMM.
+// Tile 128 x BN (BN = 128 | 64) per 256-thread workgroup, BK = 32 floats (the bf16 kernel's 128-B rows and its
+// 144-B LDS pitch); 4 waves as 2(M) x 2(N); XCD-aware tile order; epilogue through a wave-private LDS patch.
+#include "common.hpp"
+
+namespace opa {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;      // (HIP's float4 struct keeps register arrays on the stack)
+
+constexpr int kF32BM = 128, kF32BK = 32, kF32Pitch = kF32BK + 4;      // LDS row pitch in floats
+
+template <int BN, bool RES, bool RELU, bool PRO>
+__global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void gemm_f32_bias_act_kernel(
+        const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+        const float* __restrict__ res, float* __restrict__ out, int M, int N, int K, const float* __restrict__ a_bias) {
+    constexpr int WN = BN / 2;                 // wave tile width
+    constexpr int NT = WN / 32;                // 32-wide MFMA blocks per wave in N (2 or 1)
+    constexpr int LDS_A = kF32BM * kF32Pitch, LDS_B = BN * kF32Pitch;
+    constexpr int STAGE_BYTES = 2 * (LDS_A + LDS_B) * 4;   // two stages: the next K-step is stored while this one multiplies
+    constexpr int EPI_BYTES = 4 * 32 * WN * 4; // per wave a 32 x WN f32 patch
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES];
+    float* stage0 = reinterpret_cast<float*>(smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_tiles = N / BN;
+    // XCD-aware tile order (see gemm_epilogue.hip): the N-tiles sharing one A row-block run on ONE L2
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3;
+    const unsigned q = nwg >> 3, r8 = nwg & 7u;
+    const unsigned logical = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + in_xcd;
+    const int m0 = (int)(logical / n_tiles) * kF32BM;
+    const int n0 = (int)(logical % n_tiles) * BN;
+
+    f32x16_t acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    // staging map: a 32-float row is 8 x 16 B; 256 threads cover 32 rows per pass
+    const int s_row = tid >> 3, s_col = (tid & 7) * 4;
+    f32x4_t ra[kF32BM / 32], rb[BN / 32];
+    auto fetch = [&](int k0) {                 // global -> registers for K-step k0 (with the operand prologue)
+#pragma unroll
+        for (int p = 0; p < kF32BM / 32; p++) {
+            const int m = m0 + p * 32 + s_row;
+            ra[p] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            if (m < M) ra[p] = *reinterpret_cast<const f32x4_t*>(A + (size_t)m * K + k0 + s_col);
+        }
+#pragma unroll
+        for (int p = 0; p < BN / 32; p++)
+            rb[p] = *reinterpret_cast<const f32x4_t*>(W + (size_t)(n0 + p * 32 + s_row) * K + k0 + s_col);
+        if (PRO) {                             // the preceding convolution's bias + ReLU, applied to the raw operand
+            const f32x4_t ab = *reinterpret_cast<const f32x4_t*>(a_bias + k0 + s_col);
+#pragma unroll
+            for (int p = 0; p < kF32BM / 32; p++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) ra[p][e] = fmaxf(ra[p][e] + ab[e], 0.0f);
+        }
+    };
+    auto store = [&](int buf) {                // registers -> LDS stage `buf`
+        float* sA = stage0 + buf * (LDS_A + LDS_B);
+        float* sB = sA + LDS_A;
+#pragma unroll
+        for (int p = 0; p < kF32BM / 32; p++)
+            *reinterpret_cast<f32x4_t*>(sA + (p * 32 + s_row) * kF32Pitch + s_col) = ra[p];
+#pragma unroll
+        for (int p = 0; p < BN / 32; p++)
+            *reinterpret_cast<f32x4_t*>(sB + (p * 32 + s_row) * kF32Pitch + s_col) = rb[p];
+    };
+    fetch(0);
+    store(0);
+    __syncthreads();
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += kF32BK, buf ^= 1) {
+        const bool more = k0 + kF32BK < K;
+        if (more) fetch(k0 + kF32BK);          // the next K-step's operands travel while this one multiplies
+        const float* sA = stage0 + buf * (LDS_A + LDS_B);
+        const float* sB = sA + LDS_A;
+#pragma unroll
+        for (int kk = 0; kk < kF32BK; kk += 8) {
+            f32x4_t fa[2], fb[NT];
+            const int kof = kk + (lane >> 5) * 4;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+                fa[i] = *reinterpret_cast<const f32x4_t*>(sA + (wm * 64 + i * 32 + (lane & 31)) * kF32Pitch + kof);
+#pragma unroll
+            for (int j = 0; j < NT; j++)
+                fb[j] = *reinterpret_cast<const f32x4_t*>(sB + (wn * WN + j * 32 + (lane & 31)) * kF32Pitch + kof);
+            // consecutive MFMAs go to different accumulators (a dependent MFMA waits for all 16 passes of its predecessor)
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < NT; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][m], fb[j][m], acc[i][j], 0, 0, 0);
+        }
+        if (more) store(buf ^ 1);              // (the other stage: its readers passed the barrier of the previous step)
+        __syncthreads();
+    }
+    // (the loop's last barrier: staging LDS is free, reuse it for the epilogue)
+
+    // epilogue, one 32-row block of the wave tile at a time through a wave-private f32 patch: the residual load and
+    // the output store are row-contiguous 16-B vectors
+    constexpr int VEC_PER_ROW = WN / 4;
+    constexpr int VPL = 32 * VEC_PER_ROW / 64;
+    float* patch = reinterpret_cast<float*>(smem) + wave * (32 * WN);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        constexpr int VPRE = VPL > 4 ? 4 : VPL; // residual vectors fetched ahead (16 registers); the rest in the loop
+        f32x4_t rv[VPRE];
+        if (RES) {                             // they travel while the patch is written
+#pragma unroll
+            for (int t = 0; t < VPRE; t++) {
+                const int v = t * 64 + lane;
+                const int row = v / VEC_PER_ROW, c4 = (v % VEC_PER_ROW) * 4;
+                const int m = m0 + wm * 64 + i * 32 + row;
+                rv[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                if (m < M) rv[t] = *reinterpret_cast<const f32x4_t*>(res + (size_t)m * N + n0 + wn * WN + c4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int col = j * 32 + (lane & 31);
+            const float b = bias[n0 + wn * WN + col];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {     // C layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                patch[row * WN + col] = acc[i][j][r] + b;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < VPL; t++) {
+            const int v = t * 64 + lane;
+            const int row = v / VEC_PER_ROW, c4 = (v % VEC_PER_ROW) * 4;
+            const int m = m0 + wm * 64 + i * 32 + row;
+            if (m < M) {
+                f32x4_t f = *reinterpret_cast<const f32x4_t*>(patch + row * WN + c4);
+                if (RES) {
+                    if (t < VPRE) f += rv[t < VPRE ? t : 0];
+                    else f += *reinterpret_cast<const f32x4_t*>(res + (size_t)m * N + n0 + wn * WN + c4);
+                }
+                if (RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) f[e] = fmaxf(f[e], 0.0f);
+                }
+                *reinterpret_cast<f32x4_t*>(out + (size_t)m * N + n0 + wn * WN + c4) = f;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");         // (keeps the second block's residual loads -- 32 registers -- behind this block)
+    }
+}
+
+template <int BN, bool PRO>
+static hipError_t launch_f32_bn(const float* a, const float* w, const float* b, const float* r, float* o,
+                                int M, int N, int K, int relu, const float* ab, hipStream_t st) {
+    const long long blocks = (long long)((M + kF32BM - 1) / kF32BM) * (N / BN);
+    if (r) {
+        if (relu) gemm_f32_bias_act_kernel<BN, true, true, PRO><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab);
+        else gemm_f32_bias_act_kernel<BN, true, false, PRO><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab);
+    } else {
+        if (relu) gemm_f32_bias_act_kernel<BN, false, true, PRO><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab);
+        else gemm_f32_bias_act_kernel<BN, false, false, PRO><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_gemm_f32_bias_act(const float* A, const float* W, const float* bias, const float* res, float* out,
+                                    int M, int N, int K, int relu, hipStream_t st, const float* a_bias) {
+    if (a_bias) {
+        if (N % 128 == 0) return launch_f32_bn<128, true>(A, W, bias, res, out, M, N, K, relu, a_bias, st);
+        return launch_f32_bn<64, true>(A, W, bias, res, out, M, N, K, relu, a_bias, st);
+    }
+    if (N % 128 == 0) return launch_f32_bn<128, false>(A, W, bias, res, out, M, N, K, relu, nullptr, st);
+    return launch_f32_bn<64, false>(A, W, bias, res, out, M, N, K, relu, nullptr, st);
+}
+
+}  // namespace opa

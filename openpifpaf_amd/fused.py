@@ -42,20 +42,23 @@ def bias_act_(x, bias, residual=None, relu=True):
 
 
 def conv1x1_supported(x, weight, bias=None, residual=None, a_bias=None):
-    """True if ``conv1x1_bias_act`` can run the HIP GEMM for these operands.  The kernel reads raw bf16
-    buffers: EVERY operand must be bfloat16 (autocast keeps parameters in float32 -- those take the
-    PyTorch path), the activation channels_last, the residual channels_last of the output's shape."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4
+    """True if ``conv1x1_bias_act`` can run the HIP GEMM for these operands.  The kernels read raw buffers:
+    EVERY operand must have the activation's dtype, bfloat16 or float32 (autocast keeps parameters in float32
+    next to bfloat16 activations -- those take the PyTorch path), the activation channels_last, the residual
+    channels_last of the output's shape."""
+    dt = x.dtype
+    if not (x.is_cuda and dt in (torch.bfloat16, torch.float32) and x.dim() == 4
             and x.is_contiguous(memory_format=torch.channels_last)
-            and weight.dtype == torch.bfloat16 and weight.is_cuda
-            and weight.shape[1] % 64 == 0 and weight.shape[0] % 64 == 0 and weight.shape[1] == x.shape[1]):
+            and weight.dtype == dt and weight.is_cuda
+            and weight.shape[1] % (64 if dt == torch.bfloat16 else 32) == 0 and weight.shape[0] % 64 == 0
+            and weight.shape[1] == x.shape[1]):
         return False
     for vec, n in ((bias, weight.shape[0]), (a_bias, weight.shape[1])):
-        if vec is not None and not (vec.dtype == torch.bfloat16 and vec.is_cuda and vec.is_contiguous()
+        if vec is not None and not (vec.dtype == dt and vec.is_cuda and vec.is_contiguous()
                                     and vec.numel() == n and vec.data_ptr() % 16 == 0):
             return False
     if residual is not None:
-        if not (residual.dtype == torch.bfloat16 and residual.is_cuda
+        if not (residual.dtype == dt and residual.is_cuda
                 and tuple(residual.shape) == (x.shape[0], weight.shape[0], x.shape[2], x.shape[3])
                 and residual.is_contiguous(memory_format=torch.channels_last) and residual.data_ptr() % 16 == 0):
             return False
@@ -65,15 +68,23 @@ def conv1x1_supported(x, weight, bias=None, residual=None, a_bias=None):
 def conv1x1_bias_act(x, weight2d, bias, residual=None, relu=True, a_bias=None):
     """``act(conv1x1(x, weight) + bias (+ residual))`` as ONE MFMA GEMM kernel with fused epilogue.
 
-    :param x: ``[B, C_in, H, W]`` bfloat16, channels_last
-    :param weight2d: ``[C_out, C_in]`` bfloat16 contiguous
+    :param x: ``[B, C_in, H, W]`` bfloat16 or float32, channels_last
+    :param weight2d: ``[C_out, C_in]`` of the same dtype, contiguous
     :param a_bias: ``[C_in]``: ``x`` is the RAW output of the preceding convolution and
         ``relu(x + a_bias)`` -- that convolution's epilogue -- is applied while the operand is staged
-    :returns: ``[B, C_out, H, W]`` bfloat16, channels_last
+    :returns: ``[B, C_out, H, W]`` of that dtype, channels_last
     """
     B, K, H, W = x.shape
     N = weight2d.shape[0]
     out = torch.empty((B, N, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    if x.dtype == torch.float32:
+        _lib.check(_lib.lib().opa_gemm_bias_act_f32(
+            ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(a_bias.data_ptr()) if a_bias is not None else None,
+            ctypes.c_void_p(weight2d.data_ptr()), ctypes.c_void_p(bias.data_ptr()),
+            ctypes.c_void_p(residual.data_ptr()) if residual is not None else None,
+            ctypes.c_void_p(out.data_ptr()), B * H * W, N, K, int(bool(relu)),
+            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'opa_gemm_bias_act_f32')
+        return out
     if a_bias is not None:
         _lib.check(_lib.lib().opa_gemm_pro_bias_act_bf16(
             ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(a_bias.data_ptr()), ctypes.c_void_p(weight2d.data_ptr()),
@@ -89,8 +100,8 @@ def conv1x1_bias_act(x, weight2d, bias, residual=None, relu=True, a_bias=None):
     return out
 
 
-# (device, M, K, N, has_residual, has_a_bias) -> 'gemm' | 'pass+gemm' | 'conv'.  The three paths round
-# bfloat16 differently, so the choice is part of the result: it is made once per shape and device, never
+# (device, dtype, M, K, N, has_residual, has_a_bias) -> 'gemm' | 'pass+gemm' | 'conv'.  The three paths round
+# differently, so the choice is part of the result: it is made once per shape and device, never
 # while a stream is being captured (timing synchronises), can be pinned with OPA_CONV1X1=gemm|conv, and can
 # be exported / imported (choices / set_choices) so that every rank of a job runs the same kernels.
 _CHOICE = {}
@@ -128,7 +139,7 @@ def conv_bias_act(conv, x, bias, residual=None, relu=True, a_bias=None):
     if (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and conv.padding == (0, 0)
             and conv1x1_supported(x, w, bias, residual, a_bias)):
         M = x.shape[0] * x.shape[2] * x.shape[3]
-        key = (x.device.index, M, w.shape[1], w.shape[0], residual is not None, a_bias is not None)
+        key = (x.device.index, str(x.dtype), M, w.shape[1], w.shape[0], residual is not None, a_bias is not None)
         w2d = w.reshape(w.shape[0], w.shape[1])
         if not w2d.is_contiguous():
             w2d = w2d.contiguous()

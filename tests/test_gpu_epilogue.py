@@ -85,6 +85,67 @@ def test_gemm_with_fused_operand_prologue_equals_two_passes(cin, cout, hw, with_
     assert torch.equal(got, want)
 
 
+@pytest.mark.parametrize('cin,cout,hw,with_res,pro', [(64, 256, 37, True, False), (64, 256, 37, True, True), (256, 64, 41, False, False),
+                                                      (2048, 512, 9, False, False), (96, 192, 23, True, True), (32, 64, 5, False, False)])
+def test_float32_conv1x1_gemm_matches_the_convolution(cin, cout, hw, with_res, pro):
+    """opa_gemm_bias_act_f32 (v_mfma_f32_32x32x2f32, f32 operands and accumulation): the float32 1x1 convolution with
+    bias / residual / ReLU -- and optionally the preceding convolution's bias + ReLU on its operand -- against
+    PyTorch's float32 convolution.  Tolerance: a float32 dot product of `cin` terms summed in another order."""
+    from openpifpaf_amd import fused
+    torch.manual_seed(4)
+    B = 3                                   # M = 3*hw*hw is not a multiple of the 128-row tile
+    x = (torch.randn(B, cin, hw, hw, device='cuda') * 0.5).contiguous(memory_format=torch.channels_last)
+    w4 = torch.randn(cout, cin, 1, 1, device='cuda') / cin ** 0.5
+    b = torch.randn(cout, device='cuda')
+    ab = torch.randn(cin, device='cuda') * 0.3 if pro else None
+    r = torch.randn(B, cout, hw, hw, device='cuda').contiguous(memory_format=torch.channels_last) if with_res else None
+    assert fused.conv1x1_supported(x, w4, b, r, ab)
+    xin = (x + ab.view(1, -1, 1, 1)).clamp_min(0) if pro else x
+    ref = torch.nn.functional.conv2d(xin.double(), w4.double(), b.double())
+    if with_res:
+        ref = ref + r.double()
+    for relu in (True, False):
+        want = ref.clamp_min(0) if relu else ref
+        got = fused.conv1x1_bias_act(x, w4.reshape(cout, cin).contiguous(), b, r, relu, ab)
+        assert got.dtype == torch.float32 and got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        err = float((got.double() - want).abs().max())
+        assert err <= 2e-6 * cin ** 0.5 * float(want.abs().max().clamp_min(1.0)), err
+    # not for these: another dtype among the operands, K not a multiple of 32
+    assert not fused.conv1x1_supported(x, w4.to(torch.bfloat16), b, r, ab)
+    assert not fused.conv1x1_supported(x[:, :cin - 8].contiguous(memory_format=torch.channels_last), w4[:, :cin - 8], b)
+
+
+def test_resnet50_float32_fused_gemm_forward_equals_unfused():
+    """The float32 network with the fused 1x1 GEMMs forced on against the unfused PyTorch network."""
+    import os
+    from openpifpaf_amd import fused, network
+    net = network.factory('resnet50').cuda()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    x = torch.randn((2, 3, 161, 193), device='cuda')
+    old, saved = os.environ.get('OPA_CONV1X1'), fused.choices()
+    try:
+        os.environ['OPA_CONV1X1'] = 'gemm'
+        with torch.no_grad():
+            want = net(x)
+            network.optimize_for_inference_(net)
+            net = net.to(memory_format=torch.channels_last)
+            got = net(x.contiguous(memory_format=torch.channels_last))
+        assert any(k[1] == 'torch.float32' and v == 'gemm' for k, v in fused.choices().items())
+    finally:
+        if old is None:
+            os.environ.pop('OPA_CONV1X1', None)
+        else:
+            os.environ['OPA_CONV1X1'] = old
+        fused._CHOICE.clear()
+        fused.set_choices(saved)
+    for u, v in zip(got, want):
+        assert u.shape == v.shape and u.dtype == torch.float32
+        assert float((u - v).abs().max()) <= 2e-3 * float(v.abs().max().clamp_min(1.0))
+
+
 def test_resnet50_fused_gemm_forward_close_to_unfused():
     from openpifpaf_amd import network
     net = network.factory('resnet50').cuda()
