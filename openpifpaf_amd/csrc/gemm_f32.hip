@@ -11,6 +11,8 @@
 // order of the sum over k being as arbitrary as in any GEMM.
 // Tile 128 x BN (BN = 128 | 64) per 256-thread workgroup, BK = 32 floats (the bf16 kernel's 128-B rows and its
 // 144-B LDS pitch); 4 waves as 2(M) x 2(N); XCD-aware tile order; epilogue through a wave-private LDS patch.
+// Measured (tools/gpu/gemm_f32_probe.py, batch 32 at 641 px): layer-1 expand 64->256 + residual 1.70 ms against 3.3 ms
+// for MIOpen's convolution + the epilogue pass; 105-119 TFLOP/s on the compute-bound shapes (dense f32 MFMA peak 157).
 #include "common.hpp"
 
 namespace opa {
@@ -19,15 +21,25 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;      // (HIP's float4 struct keeps register arrays on the stack)
 
 constexpr int kF32BM = 128, kF32BK = 32, kF32Pitch = kF32BK + 4;      // LDS row pitch in floats
+// One LDS stage and three workgroups per CU (three waves per SIMD take turns on the MFMA pipe while the others load,
+// store and wait at barriers) beat two stages with two workgroups on every bench shape: 105-119 against 95-106
+// TFLOP/s, 4.5 against 3.9 TB/s on the bandwidth-bound layer-1 shape.  (-DOPA_F32_STAGES=2 -DOPA_F32_WGS=2: the other.)
+#ifndef OPA_F32_STAGES
+#define OPA_F32_STAGES 1
+#endif
+#ifndef OPA_F32_WGS
+#define OPA_F32_WGS 3
+#endif
+constexpr int kF32Stages = OPA_F32_STAGES;       // LDS stages (2: the next K-step is stored while this one multiplies)
 
 template <int BN, bool RES, bool RELU, bool PRO>
-__global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void gemm_f32_bias_act_kernel(
+__global__ __launch_bounds__(256, BN == 128 ? OPA_F32_WGS : 3) void gemm_f32_bias_act_kernel(
         const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
         const float* __restrict__ res, float* __restrict__ out, int M, int N, int K, const float* __restrict__ a_bias) {
     constexpr int WN = BN / 2;                 // wave tile width
     constexpr int NT = WN / 32;                // 32-wide MFMA blocks per wave in N (2 or 1)
     constexpr int LDS_A = kF32BM * kF32Pitch, LDS_B = BN * kF32Pitch;
-    constexpr int STAGE_BYTES = 2 * (LDS_A + LDS_B) * 4;   // two stages: the next K-step is stored while this one multiplies
+    constexpr int STAGE_BYTES = kF32Stages * (LDS_A + LDS_B) * 4;
     constexpr int EPI_BYTES = 4 * 32 * WN * 4; // per wave a 32 x WN f32 patch
     __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES];
     float* stage0 = reinterpret_cast<float*>(smem);
@@ -85,7 +97,7 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void gemm_f32_bias_act_kern
     store(0);
     __syncthreads();
     int buf = 0;
-    for (int k0 = 0; k0 < K; k0 += kF32BK, buf ^= 1) {
+    for (int k0 = 0; k0 < K; k0 += kF32BK, buf ^= (kF32Stages - 1)) {
         const bool more = k0 + kF32BK < K;
         if (more) fetch(k0 + kF32BK);          // the next K-step's operands travel while this one multiplies
         const float* sA = stage0 + buf * (LDS_A + LDS_B);
@@ -109,7 +121,8 @@ __global__ __launch_bounds__(256, BN == 128 ? 2 : 3) void gemm_f32_bias_act_kern
                     for (int j = 0; j < NT; j++)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][m], fb[j][m], acc[i][j], 0, 0, 0);
         }
-        if (more) store(buf ^ 1);              // (the other stage: its readers passed the barrier of the previous step)
+        if (kF32Stages == 1) __syncthreads(); // one stage: every wave is done reading it
+        if (more) store(buf ^ (kF32Stages - 1)); // (two stages: the other one, whose readers passed the previous step's barrier)
         __syncthreads();
     }
     // (the loop's last barrier: staging LDS is free, reuse it for the epilogue)
