@@ -165,7 +165,9 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
  * (debugging / tests; the reference exposes its intermediates through the utility
  * classes of module.cpp:66-117).  what: "tile_bitmaps" (u32 [2][B*F][words]: tiles of the map written by
  * the previous / by this call), "cifhr", "seed_count", "seed_f", "seed_vxys", "seed_cell",
- * "lists", "list_counts", "lists_fc", "list_counts_fc", "occupancy",
+ * "lists", "list_counts", "lists_fc", "list_counts_fc", "list_bbox" (f32 [B,A,2,16,4]: xmin, xmax, ymin, ymax of
+ * the (x1, y1) columns of the first 16 chunks of 64 entries of every "lists" list; an empty chunk: +inf, -inf, +inf,
+ * -inf), "occupancy",
  * "annotation_scratch", "status" (int32 [B]: poses dropped for lack of capacity; -1: the kernel's watchdog
  * fired), "assoc_stats" (int32 [B,24] per image: 0 growths started, 1 poses accepted, 2 growths stopped because
  * their seed died, 3 finished growths dropped for the same reason, 4 growths stopped or given up on a prediction
@@ -173,7 +175,7 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
  * 8 ticks until the growth phase ended, 9 ticks of the kernel, 10 sum of the growers' busy ticks, 11 list
  * scans, 12 coordinator ticks spent in iterations that only waited for the head's growth, 13 growers,
  * 14 poses stored, 15 coordinator iterations, 16 of them waiting, 17/18/19 ticks in commits / refills / hand-outs,
- * 20-23 reserved; ticks are 10 ns), "assoc_trace" (int32 [B,64,4]: for the first
+ * 20 ticks of the refills spent waiting for the growers' occupancy marks, 21-23 reserved; ticks are 10 ns), "assoc_trace" (int32 [B,64,4]: for the first
  * 64 accepted poses of an image the tick of the commit, of the hand-out and of the end of the growth, and
  * seed index | grower << 24). */
 int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what,

@@ -163,3 +163,40 @@ def test_wholebody_batch16(native, port):
         assert ok, 'image %d: %s' % (b, msg)
         n_poses += len(want)
     assert n_poses >= 4 * (1 + 3 + 6 + 10) * 0.8
+
+
+def test_list_chunk_boxes_bound_their_chunks_and_do_not_change_the_decode(native, port, coco_skeleton0, monkeypatch):
+    """The association kernel skips the 64-entry chunks of a CAF list whose (x1, y1) bounding box misses the query
+    window.  The boxes cafscored leaves in the workspace ("list_bbox") must contain every entry of
+    their chunk (empty chunks: an inverted box), and crowded images -- lists of several hundred entries, well past
+    one chunk -- must decode to the oracle's poses, and to exactly the same poses with the boxes switched off."""
+    from openpifpaf_amd import synth
+    cases = [(70_001, 20), (70_002, 30), (70_003, 12), (70_004, 25)]
+    fields = [synth.synth_fields(seed, people, height=81, width=81) for seed, people in cases]
+    cifs, cafs = np.stack([f[0] for f in fields]), np.stack([f[1] for f in fields])
+    got, dec = _decode_all(native, coco_skeleton0, cifs, cafs, max_annotations=128)
+    B, A, HW = len(cases), cafs.shape[1], 81 * 81
+    counts = dec.workspace_view('list_counts', torch.int32).view(B, A, 2).cpu().numpy()
+    lists = dec.workspace_view('lists', torch.float32).view(B, A, 2, 7, HW).cpu().numpy()
+    boxes = dec.workspace_view('list_bbox', torch.float32).view(B, A, 2, 16, 4).cpu().numpy()
+    assert counts.max() > 256, 'the case should have lists spanning several chunks (longest: %d)' % counts.max()
+    for b in range(B):
+        for a in range(A):
+            for d in range(2):
+                n = int(counts[b, a, d])
+                for c in range(16):
+                    lo, hi = c * 64, min(n, c * 64 + 64)
+                    xmin, xmax, ymin, ymax = boxes[b, a, d, c]
+                    if lo >= n:
+                        assert xmin > xmax and ymin > ymax, 'empty chunk with a box'
+                        continue
+                    x1, y1 = lists[b, a, d, 1, lo:hi], lists[b, a, d, 2, lo:hi]
+                    assert xmin == x1.min() and xmax == x1.max() and ymin == y1.min() and ymax == y1.max(), (b, a, d, c)
+    for b, (seed, people) in enumerate(cases):
+        want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)
+        ok, msg = compare_annotations(got[b], want)
+        assert ok, 'seed %d: %s' % (seed, msg)
+    monkeypatch.setenv('OPA_ASSOC_BBOX', '0')
+    plain, _ = _decode_all(native, coco_skeleton0, cifs, cafs, max_annotations=128)
+    for b in range(B):
+        assert plain[b].shape == got[b].shape and np.array_equal(plain[b], got[b]), 'image %d changes with the chunk boxes' % b

@@ -29,7 +29,7 @@ for b in range(min(B, 8)):
 tot = st.sum(axis=0)
 print('coordinator us (image: wait-iters wait commit refill hand-out other): ' + '  '.join('%d: %d %.0f %.0f %.0f %.0f %.0f' % (b, st[b][16], st[b][12] / 100, st[b][17] / 100, st[b][18] / 100, st[b][19] / 100, (st[b][8] - st[b][12] - st[b][17] - st[b][18] - st[b][19]) / 100) for b in range(min(B, 8))))
 print('grower time per scan (image: all-in us, inside the scan us, of that until loads returned us): ' + '  '.join('%d: %.2f %.2f %.2f' % (b, st[b][10] / 100 / max(1, st[b][11]), st[b][21] / 100 / max(1, st[b][11]), st[b][22] / 100 / max(1, st[b][11])) for b in range(min(B, 8))))
-print('refill us (image: waiting for the growers\' marks, shadow bits of the new seeds): ' + '  '.join('%d: %.0f %.0f' % (b, st[b][20] / 100, st[b][23] / 100) for b in range(min(B, 8))))
+print('refill us spent waiting for the growers\' occupancy marks (image: us): ' + '  '.join('%d: %.0f' % (b, st[b][20] / 100) for b in range(min(B, 8))))
 print('batch: started %d accepted %d cancelled %d dropped %d -> discarded share %.1f%% of growths; '
       'slowest image %.0f us, mean %.0f us' % (tot[0], tot[1], tot[2], tot[3],
                                                100.0 * (tot[2] + tot[3] + tot[4]) / max(1, tot[0]),
