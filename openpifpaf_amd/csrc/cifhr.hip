@@ -232,7 +232,10 @@ __device__ __forceinline__ void build_tile(const float* __restrict__ A, int n, i
 // workspace remembers the bitmap of the previous call (`prev`); only tiles in cur | prev are visited --
 // built if in cur, zeroed if only in prev -- and every other tile is already all-zero in HBM.  Most of the
 // map is such tiles.  Without workspace state (stage-level entry point, invalid header) every tile is built.
-constexpr int kTileGroups = 8;
+#ifndef OPA_TILE_GROUPS
+#define OPA_TILE_GROUPS 8
+#endif
+constexpr int kTileGroups = OPA_TILE_GROUPS;
 
 __global__ __launch_bounds__(256) void cifhr_tile_kernel(
         const float* __restrict__ act, const int32_t* __restrict__ act_count, int HW,

@@ -5,7 +5,7 @@ export PYTHONUNBUFFERED=1
 timeout 900 python bench.py > gpurun_out/bench_config2.json 2> gpurun_out/bench_config2.err; echo "config2 rc=$?"
 timeout 900 python bench.py --config 3 --steps 8 --warmup 2 > gpurun_out/bench_config3.json 2> gpurun_out/bench_config3.err; echo "config3 rc=$?"
 timeout 900 python bench.py --config 4 --steps 8 --warmup 2 > gpurun_out/bench_config4.json 2> gpurun_out/bench_config4.err; echo "config4 rc=$?"
-timeout 600 python -m pytest tests/test_gpu_multiprocess.py tests/test_integration_doc.py tests/test_gpu_epilogue.py -q -m gpu 2>&1 | tail -5
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -5
 for f in gpurun_out/bench_config*.json; do echo "== $f"; python - "$f" <<'PY'
 import json, sys
 try:
