@@ -521,7 +521,16 @@ __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, dou
 // joint WILL occupy if the pose is accepted, so that the coordinator can stop handing out -- and growing --
 // seeds this pose is going to cover (defined behind the occupancy helpers).
 __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s);
-__device__ __forceinline__ void pool_catch_up(ImageCtx& c);
+__device__ __forceinline__ void pool_catch_up(ImageCtx& c, int e);
+// cancel flag and refill epoch of this grower's task slot, one LDS read
+__device__ __forceinline__ bool poll_task(ImageCtx& c) {
+    if (!c.cancel) return false;
+    const unsigned long long ce = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(c.cancel), __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((int)ce) return true;
+    if (c.epoch && (int)(ce >> 32) != c.my_epoch) pool_catch_up(c, (int)(ce >> 32));
+    return false;
+}
 
 // -------------------------------------------------------------- frontier heap
 // Exact behaviour of std::priority_queue<FrontierEntry, vector, FrontierCompare>
@@ -632,8 +641,7 @@ __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool rever
     frontier_reset(c);
     for (int j = 0; j < c.K; j++) if (c.jv[j] != 0.0) frontier_add_from(c, j);
     while (c.heap_n > 0) {
-        if (c.cancel && flag_peek(c.cancel)) { c.aborted = 1; return; }  // the seed died while its pose grew
-        pool_catch_up(c);
+        if (poll_task(c)) { c.aborted = 1; return; }                     // the seed died while its pose grew
         const int e = heap_pop(c);
         const int start = c.e_se[e] >> 16, end = c.e_se[e] & 0xffff;
         if (c.jv[end] > 0.0) continue;                                   // :284
@@ -754,10 +762,15 @@ __device__ __forceinline__ int reg_heap_pop(RegState& R) {      // returns the t
 // cifcaf.cpp:316-346
 __device__ __forceinline__ void reg_frontier_add_from(RegState& R, const RegSkeleton& sk, int start) {
     const float max_score = (float)sqrt(reg_jv(R, start));
-    const int t1 = rlane(sk.off1, start);
-    for (int t = rlane(sk.off, start); t < t1; t++) {
-        const int other = (rlane(sk.slot_info, t) >> 8) & 0xff;
-        if (reg_jv(R, other) > 0.0) continue;
+    // the bones leaving `start` whose other end is still empty, found by all lanes at once (lane t = bone t, lane j =
+    // joint j), then pushed in bone order like the reference's loop
+    const int lane = lane_id();
+    const unsigned long long filled = __ballot(__hiloint2double(R.jv_hi, R.jv_lo) > 0.0);
+    const int other = (sk.slot_info >> 8) & 0xff;
+    unsigned long long cand = __ballot(lane >= rlane(sk.off, start) && lane < rlane(sk.off1, start) && !((filled >> other) & 1ull));
+    while (cand) {
+        const int t = __builtin_ctzll(cand);
+        cand &= cand - 1;
         const int first = rlane(sk.slot_first, t);
         if ((R.in_frontier >> first) & 1ull) continue;
         wlane(R.ev_lo, 0, first); wlane(R.ev_hi, 0, first);
@@ -828,8 +841,7 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
     reg_load_pose(c, R);
     reg_frontier_start(R, sk, c.K);
     while (R.heap_n > 0) {
-        if (c.cancel && flag_peek(c.cancel)) { c.aborted = 1; return; }      // the seed died while its pose grew
-        pool_catch_up(c);
+        if (poll_task(c)) { c.aborted = 1; return; }                         // the seed died while its pose grew
         const int slot = reg_heap_pop(R);
         const int info = rlane(sk.slot_info, slot);
         const int start = info & 0xff, end = (info >> 8) & 0xff;
@@ -907,11 +919,18 @@ __device__ __forceinline__ OccBox occ_box(const ImageCtx& c, const DevParams& p,
         x /= p.occupancy_reduction; y /= p.occupancy_reduction;
         sigma = fmax(p.occupancy_min_scale_reduced, sigma / p.occupancy_reduction);
     }
+    // clamp(trunc_toward_zero(t), lo, hi) for 0 <= lo <= hi < 2^30 without the 64-bit conversion: the double is
+    // clamped to [lo - 1, hi + 1] first (a NaN lands on lo - 1; the 64-bit conversion made it 0, which clamps to lo
+    // as well), truncated by v_cvt_i32_f64, and clamped again as an integer -- the same value for every input.
+    auto tc = [](double t, int lo, int hi) {
+        const int i = (int)fmin(fmax(t, (double)lo - 1.0), (double)hi + 1.0);
+        return min(max(i, lo), hi);
+    };
     OccBox b;
-    b.minx = (int)clampll(trunc_ll(x - sigma), 0, c.occ_w - 1);
-    b.miny = (int)clampll(trunc_ll(y - sigma), 0, c.occ_h - 1);
-    b.maxx = (int)clampll(trunc_ll(x + sigma), b.minx + 1, c.occ_w);
-    b.maxy = (int)clampll(trunc_ll(y + sigma), b.miny + 1, c.occ_h);
+    b.minx = tc(x - sigma, 0, c.occ_w - 1);
+    b.miny = tc(y - sigma, 0, c.occ_h - 1);
+    b.maxx = tc(x + sigma, b.minx + 1, c.occ_w);
+    b.maxy = tc(y + sigma, b.miny + 1, c.occ_h);
     return b;
 }
 __device__ __forceinline__ bool box_contains(const OccBox& b, int xi, int yi) {
@@ -931,12 +950,17 @@ __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, i
     int sif[kPoolSlots], spk[kPoolSlots];
 #pragma unroll
     for (int r = 0; r < kPoolSlots; r++) { sif[r] = c.pool_if[r * kWave + lane]; spk[r] = c.pool_pack[r * kWave + lane]; }
+    // field k, a seed index in (my_idx, empty): two unsigned compares on the packed word; inside the box: one unsigned
+    // compare per axis (cell - min < extent)
+    const unsigned lo = ((unsigned)k << 24) | (unsigned)c.my_idx, hi = ((unsigned)k << 24) | (unsigned)kPoolIdxMask;
+    const unsigned ex = (unsigned)(b.maxx - b.minx), ey = (unsigned)(b.maxy - b.miny);
     unsigned bits = 0u;
 #pragma unroll
-    for (int r = 0; r < kPoolSlots; r++)
-        if ((int)((unsigned)sif[r] >> 24) == k && (sif[r] & kPoolIdxMask) != kPoolIdxMask &&
-            (sif[r] & kPoolIdxMask) > c.my_idx && box_contains(b, spk[r] & 0xfff, (spk[r] >> 12) & 0xfff))
-            bits |= 1u << r;
+    for (int r = 0; r < kPoolSlots; r++) {
+        const unsigned w = (unsigned)sif[r];
+        const unsigned dx = (unsigned)((spk[r] & 0xfff) - b.minx), dy = (unsigned)(((spk[r] >> 12) & 0xfff) - b.miny);
+        if (w > lo && w < hi && dx < ex && dy < ey) bits |= 1u << r;
+    }
     if (bits) atomicOr(&c.shadow_mine[lane], bits);
     ++c.n_pub;
     if (lane == 0) { c.jbox[k] = b; *c.pub = c.n_pub; }
@@ -945,10 +969,8 @@ __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, i
 // Seeds that entered the pool after this growth published a box were not there when publish_joint tested the pool:
 // the coordinator bumps an epoch at every refill, and each candidate in flight tests the newcomers against ITS
 // boxes (published so far, or final) -- eleven waves in parallel instead of the coordinator alone -- and acknowledges.
-__device__ __forceinline__ void pool_catch_up(ImageCtx& c) {
-    if (!c.epoch) return;
-    const int e = flag_load(c.epoch);
-    if (e == c.my_epoch) return;
+__device__ __forceinline__ void pool_catch_up(ImageCtx& c, int e) {
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (the epoch was read relaxed: the pool mirror written before it)
     const int lane = lane_id();
     unsigned bits = 0u;
 #pragma unroll
@@ -1037,7 +1059,8 @@ __device__ __forceinline__ double pose_score(const double* v, int K) {
 // dropped) or to ACCEPTED -- then the grower itself marks the pose's boxes in the bitmap and stores the pose at
 // scratch slot `pad0` (-1: not stored), off the coordinator's critical path, and returns to IDLE.
 constexpr int kTaskIdle = 0, kTaskAssigned = 1, kTaskDone = 2, kTaskAccepted = 3;
-struct __attribute__((aligned(16))) TaskSlot { int state, cancel, seed, npub, pk, f; double score; int t_emit, t_done, pad0, pad1; };
+// (`cancel` and `epoch` share an aligned 8 bytes: a grower polls both with one LDS read between frontier pops)
+struct __attribute__((aligned(16))) TaskSlot { int state, seed, cancel, epoch, npub, pk, f, pad0; double score; int t_emit, t_done, pad1, pad2; };
 constexpr int kAssocTrace = 64;           // commits recorded per image in the optional trace ("assoc_trace")
 
 // statistics of one image, int32[kAssocStats] in the workspace ("assoc_stats"): see include/openpifpaf_amd.h
@@ -1134,8 +1157,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         c.bbox = sh_bbox;
     }
     if (tid < NW) {
-        TaskSlot t; t.state = kTaskIdle; t.cancel = 0; t.seed = -1; t.npub = 0; t.pk = 0; t.f = 0; t.score = 0.0;
-        t.t_emit = t.t_done = t.pad0 = t.pad1 = 0;
+        TaskSlot t; t.state = kTaskIdle; t.cancel = 0; t.epoch = 0; t.seed = -1; t.npub = 0; t.pk = 0; t.f = 0; t.score = 0.0;
+        t.t_emit = t.t_done = t.pad0 = t.pad1 = t.pad2 = 0;
         task[tid] = t;
     }
     if (tid < 12) sh_ctl[tid] = 0;
@@ -1360,7 +1383,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     for (int g = 1; g <= S; g++) atomicAnd(&shadow_by[g * kWave + lane], ~fresh);
                 unver |= fresh;
                 wave_sync();
-                if (lane == 0) flag_store(&sh_ctl[8], epoch);
+                if (is_grower_lane) flag_store(&task[lane].epoch, epoch);
                 st[18] += (int)(wall_clock64() - t_ph);
             }
 
@@ -1574,7 +1597,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             for (;;) {
                 const int state = flag_load(&my->state);
                 if (state == kTaskAssigned) break;
-                if (state == kTaskDone) pool_catch_up(c);
+                if (state == kTaskDone && c.epoch) { const int e = flag_load(c.epoch); if (e != c.my_epoch) pool_catch_up(c, e); }
                 else c.epoch = nullptr;
                 if (state == kTaskAccepted) {            // the pose this wave grew was accepted: Occupancy::set + store
                     const PoseView q = pose_of_block(private_base, wave - 1, K, A);
@@ -1613,7 +1636,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             c.aborted = 0;
             c.pub = &my->npub; c.n_pub = 0; c.my_idx = mine;
             c.pool_if = pool_if; c.pool_pack = pool_pack; c.shadow_mine = shadow_by + wave * kWave;
-            c.pool_ep = pool_ep; c.epoch = &sh_ctl[8]; c.ack = &my->pad1;
+            c.pool_ep = pool_ep; c.epoch = &my->epoch; c.ack = &my->pad1;
             c.my_epoch = flag_load(c.epoch);             // publish_joint tests the whole pool as of now; later refills: pool_catch_up
             if (lane == 0) flag_store(c.ack, c.my_epoch);
             publish_joint(c, p, sf, sd.y, sd.z, sd.w);   // the seed joint's own box: the rest of its blob
