@@ -157,19 +157,21 @@ __device__ __forceinline__ BlendQuery make_query(double x, double y, double xy_s
     q.ylo = y - (double)sigma_filter; q.yhi = y + (double)sigma_filter;
     // The window test (:54-57) compares a float entry with these doubles.  For a float v: v >= lo  <=>  v >= the
     // smallest float >= lo, and v <= hi  <=>  v <= the largest float <= hi -- four float compares per entry
-    // instead of two conversions and four double compares, same outcome for every input.
-    auto next_up = [](float f) {                               // smallest float > f (finite f)
-        const unsigned u = __float_as_uint(f);
-        return f == 0.0f ? __uint_as_float(1u) : __uint_as_float((u >> 31) ? u - 1u : u + 1u);
-    };
-    auto next_down = [](float f) {
-        const unsigned u = __float_as_uint(f);
-        return f == 0.0f ? __uint_as_float(0x80000001u) : __uint_as_float((u >> 31) ? u + 1u : u - 1u);
-    };
-    auto round_up = [&](double t) { float f = (float)t; if ((double)f < t) f = next_up(f); return f; };
-    auto round_down = [&](double t) { float f = (float)t; if ((double)f > t) f = next_down(f); return f; };
-    q.fxlo = round_up(q.xlo); q.fxhi = round_down(q.xhi);
-    q.fylo = round_up(q.ylo); q.fyhi = round_down(q.yhi);
+    // instead of two conversions and four double compares, same outcome for every input.  The directed roundings are
+    // v_cvt_f32_f64 under the MODE register's round-to-+inf / round-to--inf (both the single and the double/half
+    // field are set; one asm block, so no other floating-point instruction can be scheduled into it).
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 4), 5\n\t"
+                 "s_nop 2\n\t"
+                 "v_cvt_f32_f64 %0, %4\n\t"
+                 "v_cvt_f32_f64 %1, %5\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 4), 10\n\t"
+                 "s_nop 2\n\t"
+                 "v_cvt_f32_f64 %2, %6\n\t"
+                 "v_cvt_f32_f64 %3, %7\n\t"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 4), 0\n\t"
+                 "s_nop 2"
+                 : "=&v"(q.fxlo), "=&v"(q.fylo), "=&v"(q.fxhi), "=&v"(q.fyhi)
+                 : "v"(q.xlo), "v"(q.ylo), "v"(q.xhi), "v"(q.yhi));
     return q;
 }
 
@@ -324,33 +326,46 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
     for (int r = 0; r < R; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
     if (t_mem) *t_mem += (int)(wall_clock64() - t_issue);
     PH(2);
-    float* cx = tgt + kTgtFloats; float* cy = cx + kWave; float* cv = cy + kWave; int* ci = (int*)(cv + kWave);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    int cnt = 0;
+    bool have; float sc = 0.0f; int pos = 0;
+    if constexpr (R == 1) {
+        // one chunk: its lanes ARE in list order -- no compaction, the score is evaluated where the entry was loaded
+        const int i = (int)(chunks & 0xffull) * kWave + lane;
+        have = i < L.n && passes_f(q, x1[0], y1[0]);
+        if (__ballot(have) == 0ull) {                          // :76
+            __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the LDS loads must land before the area is reused
+            return blend_none();
+        }
+        PH(3);
+        if (have) sc = score_of(q, x1[0], y1[0], cc[0]);
+        pos = lane;
+    } else {
+        float* cx = tgt + kTgtFloats; float* cy = cx + kWave; float* cv = cy + kWave; int* ci = (int*)(cv + kWave);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        int cnt = 0;
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        const int i = (int)((chunks >> (8 * r)) & 0xffull) * kWave + lane;
-        const bool pass = i < L.n && passes_f(q, x1[r], y1[r]);
-        const unsigned long long m = __ballot(pass);
-        if (m == 0ull) continue;
-        const int slot = cnt + __popcll(m & below);
-        // position among the chunks looked at: ascending like the list index, and where the targets landed
-        if (pass && slot < kWave) { cx[slot] = x1[r]; cy[slot] = y1[r]; cv[slot] = cc[r]; ci[slot] = r * kWave + lane; }
-        cnt += __popcll(m);
+        for (int r = 0; r < R; r++) {
+            const int i = (int)((chunks >> (8 * r)) & 0xffull) * kWave + lane;
+            const bool pass = i < L.n && passes_f(q, x1[r], y1[r]);
+            const unsigned long long m = __ballot(pass);
+            if (m == 0ull) continue;
+            const int slot = cnt + __popcll(m & below);
+            // position among the chunks looked at: ascending like the list index, and where the targets landed
+            if (pass && slot < kWave) { cx[slot] = x1[r]; cy[slot] = y1[r]; cv[slot] = cc[r]; ci[slot] = r * kWave + lane; }
+            cnt += __popcll(m);
+        }
+        if (cnt == 0) {                                        // :76
+            __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the LDS loads must land before the area is reused
+            return blend_none();
+        }
+        if (cnt > kWave) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            return blend_streamed(L, q, only_max);
+        }
+        wave_sync();
+        PH(3);
+        have = lane < cnt;
+        if (have) { sc = score_of(q, cx[lane], cy[lane], cv[lane]); pos = ci[lane]; }
     }
-    if (cnt == 0) {                                            // :76
-        __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0): the LDS loads must land before the area is reused
-        return blend_none();
-    }
-    if (cnt > kWave) {
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        return blend_streamed(L, q, only_max);
-    }
-    wave_sync();
-    PH(3);
-    const bool have = lane < cnt;
-    float sc = 0.0f; int pos = 0;
-    if (have) { sc = score_of(q, cx[lane], cy[lane], cv[lane]); pos = ci[lane]; }
     asm volatile("" : "+v"(sc));
     PH(4);
     const unsigned b1 = have && sc > 0.0f ? __float_as_uint(sc) : 0u;

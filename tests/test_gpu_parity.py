@@ -135,6 +135,37 @@ def test_grow_connection_blend(native, port, coco_skeleton0):
     assert native.grow_connection_blend(dev(ref_f[0]), -1e4, -1e4, 1.0) == [0.0, 0.0, 0.0, 0.0]
 
 
+def test_grow_connection_blend_window_edges(native, port):
+    """Entries exactly on, one float below and one float above the four edges of the filter window
+    (cifcaf.cpp:54-57 compares the float entry with double bounds): the kernel tests floats against directed-rounded
+    float bounds, which must select exactly the same entries -- for queries whose bounds are and are not floats."""
+    rng = np.random.default_rng(7)
+    checked = 0
+    for _ in range(40):
+        x, y = float(rng.uniform(5, 600)), float(rng.uniform(5, 600))
+        if rng.random() < 0.5:
+            x, y = float(np.float32(x)), float(np.float32(y))           # bounds representable as floats
+        s = float(rng.choice([1.0, 3.0, 7.3, 12.0, 25.5]))
+        for fs in (1.0, 4.0):
+            sigma = float(np.float32(fs * max(s, 0.5) / 2.0))               # :47 (a float in the reference)
+            rows = []
+            for bound, other in ((x - sigma, y), (x + sigma, y)):
+                f = np.float32(bound)
+                for v in (np.nextafter(f, np.float32(-np.inf)), f, np.nextafter(f, np.float32(np.inf))):
+                    rows.append([0.5 + 0.4 * rng.random(), float(v), other, 100.0 + len(rows), 200.0, 4.0, 4.0])
+            for bound, other in ((y - sigma, x), (y + sigma, x)):
+                f = np.float32(bound)
+                for v in (np.nextafter(f, np.float32(-np.inf)), f, np.nextafter(f, np.float32(np.inf))):
+                    rows.append([0.5 + 0.4 * rng.random(), other, float(v), 100.0 + len(rows), 200.0, 4.0, 4.0])
+            rows = np.asarray(rows, dtype=np.float32)
+            for only_max in (False, True):
+                want = port.grow_connection_blend(rows, x, y, s, fs, only_max)
+                got = np.asarray(native.grow_connection_blend(dev(rows), x, y, s, fs, only_max))
+                assert np.allclose(got, want, rtol=1e-6, atol=1e-6), (x, y, s, fs, got, want)
+                checked += 1
+    assert checked == 160
+
+
 def test_grow_connection_blend_ties(native, port):
     """Exactly equal scores: the reference's '>=' / '>' rules pick by list position."""
     base = np.array([[0.8, 10.0, 10.0, 50.0, 60.0, 4.0, 4.0]], dtype=np.float32)
