@@ -5,7 +5,7 @@
 // and the mirrored backward tuple; each is rescored with the CifHr value at its
 // TARGET joint, c * (floor + (1-floor) * hr), and kept when the result is > th.
 //
-// One 1024-thread workgroup per (image, CAF field) walks the 7 used component
+// One 512-thread workgroup per (image, CAF field) walks the 7 used component
 // planes in raster order with coalesced loads (this is the bandwidth-bound stage
 // of the decode), gathers the two CifHr values from the L2-resident map, and
 // stream-compacts survivors IN RASTER ORDER (wave ballot + cross-wave prefix in
@@ -18,7 +18,9 @@
 
 namespace opa {
 
-constexpr int kScoredThreads = 1024;     // one workgroup walks a field: fewer, wider steps (each ends in a barrier)
+// One workgroup walks a field.  8 waves at 76 VGPRs: three workgroups per CU, so the 608 planes of a bench batch are
+// all resident at once; with 1024 threads a CU held one workgroup and the batch took three rounds (50 -> 37 us).
+constexpr int kScoredThreads = 512;
 
 __global__ __launch_bounds__(kScoredThreads, 2) void cafscored_kernel(
         const float* __restrict__ caf, int A, int HW, int stride,
