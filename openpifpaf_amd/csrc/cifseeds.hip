@@ -6,7 +6,7 @@
 //
 //  cifseeds_fill_kernel  four CIF cells per thread (coalesced plane reads, one
 //      gather into the L2-resident CifHr map), survivors appended to the image's
-//      key array with ONE atomic per wavefront (ballot + popcount prefix).
+//      key array with ONE atomic per workgroup (ballot + popcount prefix, wave totals in LDS).
 //      key = sortable(score) << 32 | ~cell_index, so that a descending key sort is
 //      "score descending, then cell index ascending" -- a total order, which makes
 //      the result independent of the append order and of the sort algorithm.
@@ -78,14 +78,22 @@ __global__ __launch_bounds__(256) void cifseeds_fill_kernel(
             }
         }
     }
+    // Survivors are appended to the image's key array.  ONE atomic per workgroup: 15 000 per-wave atomics on the 32
+    // per-image counters of a batch serialise at the L2 (~470 per address) and were most of this kernel's time.
+    __shared__ int wave_total[4];
+    __shared__ int wg_base;
     unsigned long long mask[kFillCells];
     int total = 0;
 #pragma unroll
     for (int r = 0; r < kFillCells; r++) { mask[r] = __ballot(on[r]); total += __popcll(mask[r]); }
-    if (total == 0) return;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&seed_count[b], total);          // one atomic per wave
-    base = __builtin_amdgcn_readfirstlane(base);
+    const int w = threadIdx.x >> 6;
+    if (lane == 0) wave_total[w] = total;
+    __syncthreads();
+    const int t0 = wave_total[0], t1 = wave_total[1], t2 = wave_total[2], t3 = wave_total[3];
+    if (t0 + t1 + t2 + t3 == 0) return;              // (uniform over the workgroup)
+    if (threadIdx.x == 0) wg_base = atomicAdd(&seed_count[b], t0 + t1 + t2 + t3);
+    __syncthreads();
+    int base = wg_base + (w > 0 ? t0 : 0) + (w > 1 ? t1 : 0) + (w > 2 ? t2 : 0);
 #pragma unroll
     for (int r = 0; r < kFillCells; r++) {
         if (on[r]) {
