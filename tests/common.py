@@ -68,3 +68,33 @@ def tracking_problem(seed, people, height, width):
 
 # (seed, people, frames, first frame each person is visible in) of tests/golden/make_golden_tracking_pose.py
 TRACKING_VIDEOS = [(3, 3, 5, (0, 0, 2)), (4, 5, 4, (0, 1, 0, 0, 2))]
+
+
+def nms_cases():
+    """Crafted initial annotations for the keypoint-NMS tests (with EMPTY fields the decode of initial annotations is
+    NMSKeypoints::call alone): duplicates, shifted copies, disjoint partial poses, poses around the thresholds, a pile.
+    Returns (list of [n,17,4] float32 arrays, list of NMS settings)."""
+    rng = np.random.default_rng(11)
+
+    def pose(cx, cy, scale, conf, missing=()):
+        p = np.zeros((17, 4), dtype=np.float32)
+        ang = np.linspace(0, 2 * np.pi, 17, endpoint=False)
+        p[:, 0] = conf * (0.6 + 0.4 * rng.random(17))
+        p[:, 1] = cx + scale * np.cos(ang) * (1 + 0.1 * rng.random(17))
+        p[:, 2] = cy + scale * np.sin(ang) * (1 + 0.1 * rng.random(17))
+        p[:, 3] = rng.uniform(2.0, 9.0, 17)
+        p[list(missing)] = 0.0
+        return p
+
+    a = pose(120, 120, 60, 0.9)
+    cases = [
+        np.stack([a, a.copy()]),                                                     # an exact duplicate
+        np.stack([a, a + np.array([0, 1.5, -1.0, 0], dtype=np.float32)]),            # a shifted copy inside the boxes
+        np.stack([pose(80, 90, 40, 0.5), pose(83, 92, 40, 0.95), pose(250, 200, 50, 0.3)]),   # the later pose wins
+        np.stack([pose(100, 100, 50, 0.9, missing=range(5, 17)), pose(101, 100, 50, 0.8, missing=range(0, 5))]),
+        np.stack([pose(60, 60, 30, 0.16), pose(200, 220, 30, 0.14), pose(140, 60, 30, 0.9)]),    # around the thresholds
+        np.stack([pose(150 + 3 * i, 150 - 2 * i, 70, 0.4 + 0.05 * i) for i in range(9)]),        # a pile of nine
+    ]
+    settings = [dict(), dict(nms_suppression=0.5), dict(nms_keypoint_threshold=0.4), dict(nms_instance_threshold=0.45),
+                dict(nms_suppression=0.0, nms_keypoint_threshold=0.0, nms_instance_threshold=0.0)]
+    return cases, settings

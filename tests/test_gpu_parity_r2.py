@@ -4,7 +4,7 @@ wholebody configuration (BASELINE configs[3]) at its batch size."""
 import numpy as np
 import pytest
 
-from common import TOL, compare_annotations, to_bf16
+from common import TOL, compare_annotations, nms_cases, to_bf16
 
 pytestmark = pytest.mark.gpu
 
@@ -212,29 +212,7 @@ def test_keypoint_nms_in_isolation(native, port, coco_skeleton0):
     H = W = 41
     cif = np.zeros((17, 5, H, W), dtype=np.float32)
     caf = np.zeros((19, 8, H, W), dtype=np.float32)
-    rng = np.random.default_rng(11)
-
-    def pose(cx, cy, scale, conf, missing=()):
-        p = np.zeros((17, 4), dtype=np.float32)
-        ang = np.linspace(0, 2 * np.pi, 17, endpoint=False)
-        p[:, 0] = conf * (0.6 + 0.4 * rng.random(17))
-        p[:, 1] = cx + scale * np.cos(ang) * (1 + 0.1 * rng.random(17))
-        p[:, 2] = cy + scale * np.sin(ang) * (1 + 0.1 * rng.random(17))
-        p[:, 3] = rng.uniform(2.0, 9.0, 17)
-        p[list(missing)] = 0.0
-        return p
-
-    a = pose(120, 120, 60, 0.9)
-    cases = [
-        np.stack([a, a.copy()]),                                                     # an exact duplicate
-        np.stack([a, a + np.array([0, 1.5, -1.0, 0], dtype=np.float32)]),            # a shifted copy inside the boxes
-        np.stack([pose(80, 90, 40, 0.5), pose(83, 92, 40, 0.95), pose(250, 200, 50, 0.3)]),   # the later pose wins
-        np.stack([pose(100, 100, 50, 0.9, missing=range(5, 17)), pose(101, 100, 50, 0.8, missing=range(0, 5))]),  # disjoint joints
-        np.stack([pose(60, 60, 30, 0.16), pose(200, 220, 30, 0.14), pose(140, 60, 30, 0.9)]),    # around the thresholds
-        np.stack([pose(150 + 3 * i, 150 - 2 * i, 70, 0.4 + 0.05 * i) for i in range(9)]),        # a pile of nine
-    ]
-    settings = [dict(), dict(nms_suppression=0.5), dict(nms_keypoint_threshold=0.4), dict(nms_instance_threshold=0.45),
-                dict(nms_suppression=0.0, nms_keypoint_threshold=0.0, nms_instance_threshold=0.0)]
+    cases, settings = nms_cases()
     checked = 0
     for init in cases:
         init_ids = np.arange(100, 100 + len(init), dtype=np.int64)

@@ -140,6 +140,32 @@ def test_initial_annotations(ref, coco_skeleton0):
     assert np.array_equal(r_out, o_out) and np.array_equal(r_ids, o_ids)
 
 
+def test_keypoint_nms_in_isolation(ref, coco_skeleton0):
+    """NMSKeypoints::call alone (empty fields, crafted initial annotations; tests/common.py::nms_cases): the restatement
+    against the real reference, bit for bit -- the same cases the HIP path is checked on against the restatement
+    (tests/test_gpu_parity_r2.py::test_keypoint_nms_in_isolation)."""
+    from common import nms_cases
+    from oracle import port
+    cif = np.zeros((17, 5, 41, 41), dtype=np.float32)
+    caf = np.zeros((19, 8, 41, 41), dtype=np.float32)
+    cases, settings = nms_cases()
+    removed = 0
+    for init in cases:
+        ids = np.arange(100, 100 + len(init), dtype=np.int64)
+        for kw in settings:
+            p = port.default_params(**kw)
+            ref.apply_params(p)
+            try:
+                r_out, r_ids, _ = ref.decode(cif, 8, caf, 8, coco_skeleton0, initial_annotations=init, initial_ids=ids)
+            finally:
+                ref.reset_statics()
+            o_out, o_ids = port.decode(cif, 8, caf, 8, coco_skeleton0, params=p, initial_annotations=init, initial_ids=ids)
+            assert r_out.shape == o_out.shape and np.array_equal(r_out, o_out), kw
+            assert np.array_equal(r_ids, o_ids), kw
+            removed += len(init) - len(o_out)
+    assert removed > 10          # the cases do exercise suppression and removal
+
+
 def test_all_active_adversarial(ref, coco_skeleton0):
     from openpifpaf_amd import synth
     from oracle import port
