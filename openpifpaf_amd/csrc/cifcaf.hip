@@ -1590,6 +1590,13 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             if (lane == 0) flag_store(&task[hg].state, kTaskAccepted);
             st[17] += (int)(wall_clock64() - t_cm);
         }
+        // The last commit may still be in its grower's hands (ACCEPTED: marks + pose store).  A grower reads its
+        // state once per polling round and then the exit flag: raised inside that window it would leave with the
+        // pose unstored.  So the flag goes up only when no slot is in ACCEPTED any more (the same wait a refill does).
+        while (__ballot(is_grower_lane && flag_load(&task[lane].state) == kTaskAccepted) != 0ull &&
+               wall_clock64() - t_kernel <= kWatchdogTicks)
+            __builtin_amdgcn_s_sleep(1);
+        if (wall_clock64() - t_kernel > kWatchdogTicks) watchdog = true;
         if (lane == 0) {
             sh_ctl[1] = watchdog ? 0 : n_kept; sh_ctl[2] = n_dropped; sh_ctl[5] = watchdog ? 1 : 0;
             flag_store(&sh_ctl[0], 1);                   // growers leave

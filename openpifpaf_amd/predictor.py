@@ -5,10 +5,13 @@ Same constructor/attribute/method surface for the inputs that work offline
 (``numpy_image(s)``, ``pil_image(s)``, ``image(s)``, ``tensor_batch``); the model
 is a randomly initialised ``Shell`` unless one is passed (no checkpoints offline).
 Preprocessing restates the evaluation pipeline without torchvision:
-``RescaleAbsolute(long_edge)`` (reference ``transforms/scale.py:150-174``, Pillow
-bilinear = the reference's no-OpenCV "fast" path), ``CenterPad(long_edge)`` for
-batch > 1 / ``CenterPadTight(16)`` for batch 1 (reference ``transforms/pad.py:15-112``),
-ImageNet normalisation (reference ``transforms/__init__.py:26-33``).
+``RescaleAbsolute(long_edge, fast=Predictor.fast_rescaling)`` (reference ``transforms/scale.py:42-63,150-174``;
+``predictor.py:17,88``).  Like the reference's Predictor the DEFAULT is ``fast_rescaling = True``: without OpenCV
+(absent in this image) that is Pillow's antialiased ``BILINEAR`` resize (``scale.py:55-58``) -- on the host Pillow
+itself, on the device :func:`resize_bilinear_u8`, a restatement of Pillow's 8-bit resampler that is pixel-equal to
+it; ``--precise-rescaling`` selects ``scipy.ndimage.zoom(order=1)`` (``scale.py:59-67``), restated for host and
+device by :func:`zoom_linear_u8`.  Then ``CenterPad(long_edge)`` for batch > 1 / ``CenterPadTight(16)`` for batch 1
+(reference ``transforms/pad.py:15-112``) and the ImageNet normalisation (reference ``transforms/__init__.py:26-33``).
 """
 import argparse
 import logging
@@ -32,9 +35,73 @@ def _to_pil(image):
     return PIL.Image.fromarray(np.asarray(image, dtype=np.uint8)).convert('RGB')
 
 
+PIL_PRECISION_BITS = 32 - 8 - 2      # Pillow's fixed-point coefficient precision for 8-bit images
+
+
+def _pil_bilinear_coeffs(in_size, out_size):
+    """Pillow's coefficient table for the BILINEAR (triangle) filter along one axis, as its 8-bit resampler uses
+    it: per output sample the first input sample and ``ksize`` fixed-point weights.  The filter support grows with
+    the downscale factor (antialiasing); weights are normalised in double, in Pillow's summation order, then
+    rounded half away from zero to 22 fractional bits.  Computed on the host (a few hundred values)."""
+    scale = in_size / out_size
+    filterscale = max(scale, 1.0)
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    center = (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    inv = 1.0 / filterscale
+    first = np.trunc(center - support + 0.5).astype(np.int64)
+    first[first < 0] = 0
+    count = np.trunc(center + support + 0.5).astype(np.int64)
+    count[count > in_size] = in_size
+    count -= first
+    k = np.zeros((out_size, ksize), dtype=np.float64)
+    total = np.zeros(out_size, dtype=np.float64)
+    for x in range(ksize):                            # sequential accumulation like the C loop
+        arg = np.abs((x + first - center + 0.5) * inv)
+        w = np.where((arg < 1.0) & (x < count), 1.0 - arg, 0.0)
+        k[:, x] = w
+        total = total + w
+    nz = total != 0.0
+    k[nz] = k[nz] / total[nz, None]
+    one = float(1 << PIL_PRECISION_BITS)
+    fixed = np.where(k < 0, np.trunc(-0.5 + k * one), np.trunc(0.5 + k * one)).astype(np.int64)
+    return first, fixed
+
+
+def _pil_resample_axis(frame, axis, out_size):
+    in_size = frame.shape[axis]
+    first, fixed = _pil_bilinear_coeffs(in_size, out_size)
+    dev = frame.device
+    first_t, fixed_t = torch.from_numpy(first).to(dev), torch.from_numpy(fixed).to(dev)
+    shape = [frame.shape[0], frame.shape[1], frame.shape[2]]
+    shape[axis] = out_size
+    wshape = [1, 1, 1]
+    wshape[axis] = out_size
+    acc = torch.full(shape, 1 << (PIL_PRECISION_BITS - 1), dtype=torch.int64, device=dev)
+    for x in range(fixed.shape[1]):                   # taps beyond a sample's count carry weight 0
+        idx = (first_t + x).clamp_(max=in_size - 1)
+        acc += frame.index_select(axis, idx).to(torch.int64) * fixed_t[:, x].view(wshape)
+    return (acc >> PIL_PRECISION_BITS).clamp_(0, 255).to(torch.uint8)
+
+
+def resize_bilinear_u8(frame, target_h, target_w):
+    """The reference Predictor's DEFAULT rescale where OpenCV is not installed: ``image.resize((tw, th), BILINEAR)``
+    of Pillow (reference ``transforms/scale.py:55-58`` with ``predictor.py:17,88``), restated with torch integer ops
+    so that it runs on the device: a separable triangle filter whose support scales with the downscale factor,
+    22-bit fixed-point weights, the horizontal pass rounded to uint8 before the vertical one -- Pillow's 8-bit
+    resampler.  Pixel-EQUAL to Pillow (``tests/test_abi_and_host.py``).
+    ``frame``: uint8 ``[H, W, C]`` tensor on any device -> uint8 ``[target_h, target_w, C]``."""
+    h, w = frame.shape[:2]
+    if target_w != w:
+        frame = _pil_resample_axis(frame, 1, target_w)
+    if target_h != h:
+        frame = _pil_resample_axis(frame, 0, target_h)
+    return frame
+
+
 def zoom_linear_u8(frame, target_h, target_w):
-    """The reference's default rescale, ``scipy.ndimage.zoom(im, (th / h, tw / w, 1), order=1)`` on a uint8 image
-    (reference ``transforms/scale.py:57-63``), restated with torch ops so that it runs on the device: corner-aligned
+    """The reference's ``--precise-rescaling`` rescale, ``scipy.ndimage.zoom(im, (th / h, tw / w, 1), order=1)`` on a
+    uint8 image (reference ``transforms/scale.py:59-67``), restated with torch ops so that it runs on the device: corner-aligned
     coordinates ``j * (n_in - 1) / (n_out - 1)``, linear weights, the sum formed in double in scipy's order, rounded
     like its uint8 output (``(uint8)(t + 0.5)``).  Pixel-equal to scipy (``tests/test_abi_and_host.py``).
     ``frame``: uint8 ``[H, W, C]`` tensor on any device -> uint8 ``[target_h, target_w, C]``."""
@@ -69,10 +136,10 @@ def _target_size(w0, h0, long_edge):
     return (int(w0 * s), int(long_edge)) if h0 > w0 else (int(long_edge), int(h0 * s))
 
 
-def preprocess_image(image, *, long_edge=None, batch_mode=False, fast=False):
-    """-> (float32 tensor [3,H,W], meta) with the meta fields ``inverse_transform`` needs.  ``fast``: the
-    reference's ``--fast-rescaling`` without OpenCV (PIL's antialiased bilinear resize) instead of its default,
-    scipy's order-1 zoom."""
+def preprocess_image(image, *, long_edge=None, batch_mode=False, fast=True):
+    """-> (float32 tensor [3,H,W], meta) with the meta fields ``inverse_transform`` needs.  ``fast`` (the
+    reference Predictor's default, ``predictor.py:17``): Pillow's antialiased bilinear resize; ``fast=False``
+    (``--precise-rescaling``): scipy's order-1 zoom."""
     import PIL.Image
     image = _to_pil(image)
     w0, h0 = image.size
@@ -83,7 +150,7 @@ def preprocess_image(image, *, long_edge=None, batch_mode=False, fast=False):
         tw, th = _target_size(w0, h0, long_edge)
         if fast:
             image = image.resize((tw, th), getattr(PIL.Image, 'Resampling', PIL.Image).BILINEAR)
-        else:                                         # the reference's default: scipy.ndimage.zoom, order 1
+        else:                                         # --precise-rescaling: scipy.ndimage.zoom, order 1
             image = PIL.Image.fromarray(zoom_linear_u8(torch.from_numpy(np.array(image)), th, tw).numpy())
         sx, sy = (tw - 1) / (w0 - 1), (th - 1) / (h0 - 1)
         meta['offset'] *= (sx, sy)
@@ -108,10 +175,11 @@ def preprocess_image(image, *, long_edge=None, batch_mode=False, fast=False):
     return torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1))), meta
 
 
-def preprocess_batch_device(images, *, long_edge, device):
+def preprocess_batch_device(images, *, long_edge, device, fast=True):
     """Device-side form of ``preprocess_image`` for batch mode: the uint8 frames are
     uploaded as they are (a quarter of the bytes of normalised float32), rescaled to ``long_edge`` with the
-    reference's own arithmetic (:func:`zoom_linear_u8`, rounded to uint8 like the host path), centre-padded to
+    reference's own arithmetic (:func:`resize_bilinear_u8` = Pillow, or with ``fast=False``
+    :func:`zoom_linear_u8` = scipy; rounded to uint8 like the host path), centre-padded to
     ``long_edge x long_edge`` with the reference's fill colour and normalised -- all on ``device``.
     -> (float32 ``[B,3,long_edge,long_edge]`` on ``device``, metas).  The pixels EQUAL the host path's."""
     assert long_edge, '--long-edge must be provided for batch size > 1'
@@ -124,7 +192,7 @@ def preprocess_batch_device(images, *, long_edge, device):
         frame = torch.from_numpy(np.ascontiguousarray(np.asarray(_to_pil(image), dtype=np.uint8)))
         h0, w0 = frame.shape[:2]
         tw, th = _target_size(w0, h0, long_edge)
-        x = zoom_linear_u8(frame.to(device, non_blocking=True), th, tw)
+        x = (resize_bilinear_u8 if fast else zoom_linear_u8)(frame.to(device, non_blocking=True), th, tw)
         left, top = max(0, int((long_edge - tw) / 2.0)), max(0, int((long_edge - th) / 2.0))
         canvas[b, top:top + th, left:left + tw] = x
         sx, sy = (tw - 1) / (w0 - 1), (th - 1) / (h0 - 1)
@@ -144,6 +212,7 @@ class Predictor:
     device_preprocess = False      #: batch mode: rescale / pad / normalise on the device instead of with PIL
     batch_size = 1
     device = torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
+    fast_rescaling = True          #: reference predictor.py:17 (False = --precise-rescaling, scipy zoom)
     long_edge = None
     base_name = 'resnet50'
     channels_last = True
@@ -171,12 +240,15 @@ class Predictor:
             group.add_argument('--batch-size', default=cls.batch_size, type=int, help='processing batch size')
         group.add_argument('--long-edge', default=cls.long_edge, type=int,
                            help='rescale the long side of the image (aspect ratio maintained)')
+        group.add_argument('--precise-rescaling', dest='fast_rescaling', default=True, action='store_false',
+                           help='use more exact image rescaling (requires scipy)')      # reference predictor.py:72-74
         group.add_argument('--basenet', default=cls.base_name, choices=sorted(network.BASE_FACTORIES))
 
     @classmethod
     def configure(cls, args: argparse.Namespace):
         cls.batch_size = args.batch_size
         cls.long_edge = args.long_edge
+        cls.fast_rescaling = getattr(args, 'fast_rescaling', cls.fast_rescaling)
         cls.base_name = getattr(args, 'basenet', cls.base_name)
         if getattr(args, 'device', None) is not None:
             cls.device = args.device
@@ -222,9 +294,9 @@ class Predictor:
         for i in range(0, len(images), self.batch_size):
             if batch_mode and self.device_preprocess and self.device.type == 'cuda':
                 batch, metas = preprocess_batch_device(images[i:i + self.batch_size], long_edge=self.long_edge,
-                                                       device=self.device)
+                                                       device=self.device, fast=self.fast_rescaling)
             else:
-                items = [preprocess_image(im, long_edge=self.long_edge, batch_mode=batch_mode)
+                items = [preprocess_image(im, long_edge=self.long_edge, batch_mode=batch_mode, fast=self.fast_rescaling)
                          for im in images[i:i + self.batch_size]]
                 batch = torch.stack([t for t, _ in items])
                 metas = [m for _, m in items]

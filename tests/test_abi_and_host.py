@@ -281,20 +281,66 @@ def test_rescale_restatement_equals_scipy_zoom_pixel_for_pixel():
         assert np.array_equal(got, want), '%s -> %s: %d pixels differ' % ((h, w), (th, tw), int((got != want).sum()))
 
 
+def test_fast_rescale_restatement_equals_pillow_pixel_for_pixel():
+    """The reference Predictor's DEFAULT rescale (``fast_rescaling = True``, reference predictor.py:17,88) without
+    OpenCV is Pillow's antialiased ``image.resize(size, BILINEAR)`` (transforms/scale.py:55-58).
+    ``predictor.resize_bilinear_u8`` restates Pillow's 8-bit resampler with torch integer ops so that it can run on
+    the device: every pixel equal, up- and downscaling, degenerate sizes included."""
+    import PIL.Image
+    import torch
+    from openpifpaf_amd import predictor
+    rng = np.random.default_rng(4)
+    sizes = [((480, 640), (481, 641)), ((427, 640), (427, 641)), ((1080, 1920), (361, 641)), ((100, 130), (321, 417)),
+             ((333, 500), (641, 962)), ((64, 64), (64, 64)), ((375, 500), (241, 321)), ((17, 23), (5, 9)),
+             ((50, 60), (50, 120)), ((719, 1279), (360, 640)), ((9, 300), (3, 641)), ((2, 2), (7, 5))]
+    sizes += [((int(rng.integers(3, 400)), int(rng.integers(3, 400))), (int(rng.integers(2, 400)), int(rng.integers(2, 400))))
+              for _ in range(50)]
+    resample = getattr(PIL.Image, 'Resampling', PIL.Image).BILINEAR
+    for (h, w), (th, tw) in sizes:
+        im = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        want = np.asarray(PIL.Image.fromarray(im).resize((tw, th), resample))
+        got = predictor.resize_bilinear_u8(torch.from_numpy(im), th, tw).numpy()
+        assert want.shape == got.shape == (th, tw, 3)
+        assert np.array_equal(got, want), '%s -> %s: %d pixels differ' % ((h, w), (th, tw), int((got != want).sum()))
+
+
+def test_predictor_rescaling_default_and_flag_follow_the_reference():
+    """reference predictor.py:17 (``fast_rescaling = True``) and :72-74,81 (``--precise-rescaling`` clears it)."""
+    import argparse
+    from openpifpaf_amd import Predictor
+    assert Predictor.fast_rescaling is True
+    parser = argparse.ArgumentParser()
+    Predictor.cli(parser)
+    try:
+        args = parser.parse_args(['--long-edge', '97', '--precise-rescaling'])
+        assert args.fast_rescaling is False
+        Predictor.configure(args)
+        assert Predictor.fast_rescaling is False and Predictor.long_edge == 97
+        Predictor.configure(parser.parse_args([]))
+        assert Predictor.fast_rescaling is True
+    finally:
+        Predictor.fast_rescaling, Predictor.long_edge, Predictor.batch_size = True, None, 1
+
+
 def test_device_preprocess_equals_the_host_path():
     """preprocess_batch_device (rescale + pad + normalise with torch ops, runs on any device) against the host
-    preprocess_image in batch mode: same geometry, same meta, the SAME pixels."""
+    preprocess_image in batch mode: same geometry, same meta, the SAME pixels -- with the
+    reference's default rescale (Pillow) and with --precise-rescaling (scipy)."""
     import torch
     from openpifpaf_amd import predictor
     rng = np.random.default_rng(5)
-    images = [(rng.random((60, 80, 3)) * 255).astype(np.uint8), (rng.random((40, 30, 3)) * 255).astype(np.uint8)]
-    batch, metas = predictor.preprocess_batch_device(images, long_edge=97, device=torch.device('cpu'))
-    assert batch.shape == (2, 3, 97, 97)
-    for b, image in enumerate(images):
-        want, wmeta = predictor.preprocess_image(image, long_edge=97, batch_mode=True)
-        assert np.allclose(metas[b]['offset'], wmeta['offset']) and np.allclose(metas[b]['scale'], wmeta['scale'])
-        assert np.allclose(metas[b]['valid_area'], wmeta['valid_area'])
-        assert torch.equal(batch[b], want)
-    # the reference's "fast" variant (PIL's antialiased bilinear) is a different filter: close, not equal
-    fast, _ = predictor.preprocess_image(images[0], long_edge=97, batch_mode=True, fast=True)
-    assert float((fast - batch[0]).abs().mean()) < 0.6
+    images = [(rng.random((60, 80, 3)) * 255).astype(np.uint8), (rng.random((40, 30, 3)) * 255).astype(np.uint8),
+              (rng.random((300, 180, 3)) * 255).astype(np.uint8)]
+    batches = {}
+    for fast in (True, False):
+        batch, metas = predictor.preprocess_batch_device(images, long_edge=97, device=torch.device('cpu'), fast=fast)
+        assert batch.shape == (3, 3, 97, 97)
+        for b, image in enumerate(images):
+            want, wmeta = predictor.preprocess_image(image, long_edge=97, batch_mode=True, fast=fast)
+            assert np.allclose(metas[b]['offset'], wmeta['offset']) and np.allclose(metas[b]['scale'], wmeta['scale'])
+            assert np.allclose(metas[b]['valid_area'], wmeta['valid_area'])
+            assert torch.equal(batch[b], want), (fast, b)
+        batches[fast] = batch
+    # the two are different filters: close, not equal
+    assert not torch.equal(batches[True], batches[False])
+    assert float((batches[True][0] - batches[False][0]).abs().mean()) < 0.6

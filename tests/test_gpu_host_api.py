@@ -135,13 +135,14 @@ def test_predictor_with_device_side_preprocessing():
             assert len(results[on_device]) == 2 and pred.total_images == 2
         finally:
             Predictor.long_edge, Predictor.batch_size, Predictor.device_preprocess = None, 1, False
-    batch, metas = predictor.preprocess_batch_device(images, long_edge=193, device=torch.device('cuda'))
-    assert batch.is_cuda and batch.shape == (2, 3, 193, 193)
-    for b, image in enumerate(images):
-        want, wmeta = predictor.preprocess_image(image, long_edge=193, batch_mode=True)
-        assert np.allclose(metas[b]['offset'], wmeta['offset']) and np.allclose(metas[b]['scale'], wmeta['scale'])
-        assert torch.equal(batch[b].cpu(), want), 'device and host preprocessing differ in %d values' % int(
-            (batch[b].cpu() != want).sum())
+    for fast in (True, False):       # the reference's default (Pillow bilinear) and --precise-rescaling (scipy zoom)
+        batch, metas = predictor.preprocess_batch_device(images, long_edge=193, device=torch.device('cuda'), fast=fast)
+        assert batch.is_cuda and batch.shape == (2, 3, 193, 193)
+        for b, image in enumerate(images):
+            want, wmeta = predictor.preprocess_image(image, long_edge=193, batch_mode=True, fast=fast)
+            assert np.allclose(metas[b]['offset'], wmeta['offset']) and np.allclose(metas[b]['scale'], wmeta['scale'])
+            assert torch.equal(batch[b].cpu(), want), 'device and host preprocessing (fast=%s) differ in %d values' % (
+                fast, int((batch[b].cpu() != want).sum()))
     for (pred_d, _, meta_d), (pred_h, _, meta_h) in zip(results[True], results[False]):
         assert len(pred_d) == len(pred_h)
         for a_d, a_h in zip(pred_d, pred_h):
