@@ -387,7 +387,7 @@ def main():
     primary = args.backbone_dtype
     elapsed, model, images = run_leg(primary, args.steps, args.warmup)
     legs[primary] = dict(elapsed=elapsed, value=world * B * args.steps / elapsed)
-    n_ann = int((host_counts & 0x3FFFFFFF).sum())           # OPA_COUNT_ROWS
+    n_ann = int((host_counts & 0x0FFFFFFF).sum())           # OPA_COUNT_ROWS
     if args.dump_annotations and rank == 0:
         a_, i_, c_ = gathered[0] if gathered[0] is not None else (host_out, None, host_counts)
         np.savez(args.dump_annotations, annotations=a_.cpu().numpy(), counts=c_.cpu().numpy())

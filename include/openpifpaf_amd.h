@@ -38,10 +38,13 @@ extern "C" {
 #define OPA_ERR_WORKSPACE 4          /* workspace too small                         */
 #define OPA_ERR_NO_DEVICE 5          /* no gfx950 device visible                    */
 
-/* out_count of opa_cifcaf_decode: number of valid rows, plus this bit when poses were dropped for lack of
- * capacity (max_annotations too small). */
+/* out_count of opa_cifcaf_decode: number of valid rows, plus OPA_COUNT_OVERFLOW when poses were dropped for lack
+ * of capacity (max_annotations too small), plus OPA_COUNT_FAILED when the association kernel gave up on the image
+ * (its watchdog fired: a protocol error, never seen outside the test that provokes it; the image has 0 rows and
+ * its result must not be used).  Both flags travel with the count, so a caller that reads the counts sees them. */
 #define OPA_COUNT_OVERFLOW 0x40000000
-#define OPA_COUNT_ROWS(c) ((c) & 0x3FFFFFFF)
+#define OPA_COUNT_FAILED 0x20000000
+#define OPA_COUNT_ROWS(c) ((c) & 0x0FFFFFFF)
 
 /* The reference's process-global tunables (its C++ static members), one field
  * per STATIC_GETSET line of module.cpp:26-32,76-116 plus the constructor
@@ -144,6 +147,8 @@ size_t opa_cifcaf_workspace_bytes(const opa_shape* shape);
  *                   OPA_COUNT_OVERFLOW bit is set when the annotation capacity was too small: the poses the
  *                   seed loop produced after the first max_annotations (in seed order, cifcaf.cpp:206-231) were
  *                   dropped before keypoint NMS, and the workspace's "status" buffer holds how many.
+ *                   OPA_COUNT_FAILED: see above (environment OPA_ASSOC_WATCHDOG_TICKS = the watchdog in 10-ns
+ *                   ticks, default 1e8 = one second; tests shorten it to provoke the failure).
  */
 int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_params* params,
                       const float* cif_dev, const float* caf_dev,
@@ -165,9 +170,10 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
  * (debugging / tests; the reference exposes its intermediates through the utility
  * classes of module.cpp:66-117).  what: "tile_bitmaps" (u32 [2][B*F][words]: tiles of the map written by
  * the previous / by this call), "cifhr", "seed_count", "seed_f", "seed_vxys", "seed_cell",
- * "lists", "list_counts", "lists_fc", "list_counts_fc", "list_bbox" (f32 [B,A,2,16,4]: xmin, xmax, ymin, ymax of
- * the (x1, y1) columns of the first 16 chunks of 64 entries of every "lists" list; an empty chunk: +inf, -inf, +inf,
- * -inf), "occupancy",
+ * "lists", "list_counts", "lists_fc", "list_counts_fc", "list_bbox" (f32 [B,A,2,C,4], C = min(ceil(caf_h*caf_w/64),
+ * 255): xmin, xmax, ymin, ymax of the (x1, y1) columns of the first min(C, 16) chunks of 64 entries of every "lists"
+ * list -- the rest of a list's C boxes is not written; an empty chunk: +inf, -inf, +inf, -inf), "list_bbox_fc" (the
+ * boxes of ALL C chunks of every "lists_fc" list; written only by a force-complete decode), "occupancy",
  * "annotation_scratch", "status" (int32 [B]: poses dropped for lack of capacity; -1: the kernel's watchdog
  * fired), "assoc_stats" (int32 [B,24] per image: 0 growths started, 1 poses accepted, 2 growths stopped because
  * their seed died, 3 finished growths dropped for the same reason, 4 growths stopped or given up on a prediction

@@ -9,8 +9,9 @@ CSRC = os.path.join(HERE, 'csrc')
 OUT = os.path.join(HERE, 'lib', 'libopenpifpaf_amd.so')
 # -ffp-contract=off: the decode must reproduce the reference's float/double
 # operation sequence; the reference's x86-64 build has no FMA contraction.
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-shared',
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC',
          '-Wall', '-Wno-unused-result']
+OBJ_DIR = os.path.join(HERE, 'lib', 'obj')
 
 
 def sources():
@@ -27,14 +28,30 @@ def needs_build():
 
 
 def build_native(force=False, verbose=True):
+    """One object per .hip file (compiled in parallel, rebuilt only when the file or a shared header changed),
+    then one link."""
     if not force and not needs_build():
         return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
     hipcc = os.environ.get('HIPCC', 'hipcc')
-    cmd = [hipcc] + FLAGS + ['-o', OUT] + sources()
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.check_call(cmd)
+    headers = glob.glob(os.path.join(CSRC, '*.hpp')) + [os.path.join(HERE, '..', 'include', 'openpifpaf_amd.h')]
+    t_hdr = max(os.path.getmtime(h) for h in headers)
+    jobs, objs = [], []
+    for src in sources():
+        obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + '.o')
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), t_hdr):
+            jobs.append([hipcc] + FLAGS + ['-c', src, '-o', obj])
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    if jobs:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as pool:
+            list(pool.map(run, jobs))
+    run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)
     return OUT
 
 

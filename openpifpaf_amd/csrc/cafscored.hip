@@ -22,14 +22,66 @@ namespace opa {
 // all resident at once; with 1024 threads a CU held one workgroup and the batch took three rounds (50 -> 37 us).
 constexpr int kScoredThreads = 512;
 
+// Wave-wide min / max of a float with DPP row operations (register only; result broadcast from lane 63).
+// (A NaN coordinate never passes the window test and must not poison a box: callers feed the identity for it.)
+template <bool MAX>
+__device__ __forceinline__ float wave_minmax_f32(float v) {
+    auto step = [](float x, int o) { const float y = __int_as_float(o); return MAX ? fmaxf(x, y) : fminf(x, y); };
+    v = step(v, __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0xB1, 0xF, 0xF, false));
+    v = step(v, __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x4E, 0xF, 0xF, false));
+    v = step(v, __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x141, 0xF, 0xF, false));
+    v = step(v, __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x140, 0xF, 0xF, false));
+    v = step(v, __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x142, 0xA, 0xF, false));
+    v = step(v, __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x143, 0xC, 0xF, false));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// The entries a wave keeps in one step land on consecutive list positions, i.e. in at most two chunks: their
+// (x, y) are reduced inside the wave and ONE lane widens the two boxes in LDS (64 lanes hammering one LDS word with
+// ds_min_f32 serialise; the force-complete lists keep most cells of a field).
+__device__ __forceinline__ void widen_boxes(float* bb, int nb, bool keep, int off, float x, float y) {
+    const unsigned long long m = __ballot(keep);
+    if (m == 0ull) return;
+    const int lane = threadIdx.x & 63;
+    const int c0 = __builtin_amdgcn_readlane(off, __builtin_ctzll(m)) >> 6;
+    if (c0 >= nb) return;
+    const float inf = __builtin_inff();
+    const bool in0 = keep && (off >> 6) == c0, in1 = keep && !in0;
+    const bool xok = x == x, yok = y == y;
+    const float x0lo = wave_minmax_f32<false>(in0 && xok ? x : inf), x0hi = wave_minmax_f32<true>(in0 && xok ? x : -inf);
+    const float y0lo = wave_minmax_f32<false>(in0 && yok ? y : inf), y0hi = wave_minmax_f32<true>(in0 && yok ? y : -inf);
+    const bool any1 = __ballot(in1) != 0ull && c0 + 1 < nb;
+    float x1lo = inf, x1hi = -inf, y1lo = inf, y1hi = -inf;
+    if (any1) {
+        x1lo = wave_minmax_f32<false>(in1 && xok ? x : inf); x1hi = wave_minmax_f32<true>(in1 && xok ? x : -inf);
+        y1lo = wave_minmax_f32<false>(in1 && yok ? y : inf); y1hi = wave_minmax_f32<true>(in1 && yok ? y : -inf);
+    }
+    if (lane == 0) {
+        float* q = bb + c0 * 4;
+        __hip_atomic_fetch_min(q + 0, x0lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(q + 1, x0hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_min(q + 2, y0lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(q + 3, y0hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (any1) {
+            __hip_atomic_fetch_min(q + 4, x1lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(q + 5, x1hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_min(q + 6, y1lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_max(q + 7, y1hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
 __global__ __launch_bounds__(kScoredThreads, 2) void cafscored_kernel(
         const float* __restrict__ caf, int A, int HW, int stride,
         const float* __restrict__ cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
         const int64_t* __restrict__ skeleton, double score_th, double cif_floor, int no_rescore,
-        float* __restrict__ lists, int32_t* __restrict__ counts, float* __restrict__ chunk_bbox) {
+        float* __restrict__ lists, int32_t* __restrict__ counts, float* __restrict__ chunk_bbox, int nb, int nb_stride) {
+    // nb: chunks per list that get a box (the first kListBboxChunks for the caf_th set, whose lists are short and whose
+    // boxes the association kernel keeps in LDS; all of them for the force-complete set); nb_stride: boxes per list in memory
     __shared__ int wave_tot[2][kScoredThreads / 64];
-    __shared__ float bb[2][kListBboxChunks][4];      // (xmin, xmax, ymin, ymax) of the (x1, y1) columns per list chunk
-    if (threadIdx.x < 2 * kListBboxChunks * 4) (&bb[0][0][0])[threadIdx.x] = (threadIdx.x & 1) ? -__builtin_inff() : __builtin_inff();
+    extern __shared__ float bb[];                    // [2][nb][4]: (xmin, xmax, ymin, ymax) of the (x1, y1) columns per list chunk
+    if (chunk_bbox)
+        for (int k = threadIdx.x; k < 2 * nb * 4; k += kScoredThreads) bb[k] = (k & 1) ? -__builtin_inff() : __builtin_inff();
     __syncthreads();
     const int plane = blockIdx.x;                  // b*A + a
     const int b = plane / A, a = plane - b * A;
@@ -80,16 +132,21 @@ __global__ __launch_bounds__(kScoredThreads, 2) void cafscored_kernel(
             tot_f += t & 0xffff; tot_b += t >> 16;
         }
         if (chunk_bbox) {
-            // LDS float min/max (ds_min_f32 / ds_max_f32); a NaN coordinate never passes the window test and must
-            // not poison the box
-            auto widen = [](float* q, float x, float y) {
-                if (x == x) { __hip_atomic_fetch_min(q + 0, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                              __hip_atomic_fetch_max(q + 1, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-                if (y == y) { __hip_atomic_fetch_min(q + 2, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                              __hip_atomic_fetch_max(q + 3, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-            };
-            if (keep_f && off_f < kListBboxChunks * 64) widen(bb[0][off_f >> 6], x1, y1);
-            if (keep_b && off_b < kListBboxChunks * 64) widen(bb[1][off_b >> 6], x2, y2);
+            if (nb > kListBboxChunks) {              // long lists: one LDS update per wave and chunk
+                widen_boxes(bb, nb, keep_f, off_f, x1, y1);
+                widen_boxes(bb + nb * 4, nb, keep_b, off_b, x2, y2);
+            } else {
+                // short lists, few kept entries per step: LDS float min/max per entry (ds_min_f32 / ds_max_f32); a NaN
+                // coordinate never passes the window test and must not poison the box
+                auto widen = [](float* q, float x, float y) {
+                    if (x == x) { __hip_atomic_fetch_min(q + 0, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                  __hip_atomic_fetch_max(q + 1, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                    if (y == y) { __hip_atomic_fetch_min(q + 2, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                  __hip_atomic_fetch_max(q + 3, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                };
+                if (keep_f && off_f < nb * 64) widen(bb + (off_f >> 6) * 4, x1, y1);
+                if (keep_b && off_b < nb * 64) widen(bb + (nb + (off_b >> 6)) * 4, x2, y2);
+            }
         }
         if (keep_f) {
             Lf[0 * HW + off_f] = cf; Lf[1 * HW + off_f] = x1; Lf[2 * HW + off_f] = y1;
@@ -104,17 +161,24 @@ __global__ __launch_bounds__(kScoredThreads, 2) void cafscored_kernel(
     if (tid == 0) { counts[plane * 2 + 0] = base_f; counts[plane * 2 + 1] = base_b; }
     if (chunk_bbox) {                                 // the chunk boxes (common.hpp), gathered in LDS while the lists were built
         __syncthreads();
-        if (tid < 2 * kListBboxChunks * 4)
-            chunk_bbox[(size_t)plane * 2 * kListBboxChunks * 4 + tid] = (&bb[0][0][0])[tid];
+        for (int k = tid; k < 2 * nb * 4; k += kScoredThreads) {
+            const int dir = k / (nb * 4), rest = k - dir * nb * 4;
+            chunk_bbox[((size_t)plane * 2 + dir) * nb_stride * 4 + rest] = bb[k];
+        }
     }
 }
 
 hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
-                            float* lists, int32_t* counts, hipStream_t st, float* chunk_bbox) {
-    cafscored_kernel<<<B * A, kScoredThreads, 0, st>>>(caf, A, cH * cW, cstride, cifhr, F, hr_rows, hr_cols, hr_pitch,
-                                            skeleton, score_th, cif_floor, no_rescore, lists, counts, chunk_bbox);
+                            float* lists, int32_t* counts, hipStream_t st, float* chunk_bbox, int bbox_chunks,
+                            int bbox_stride) {
+    if (bbox_chunks <= 0) chunk_bbox = nullptr;
+    if (bbox_stride < bbox_chunks) bbox_stride = bbox_chunks;
+    const size_t lds = chunk_bbox ? sizeof(float) * 2 * bbox_chunks * 4 : 0;
+    cafscored_kernel<<<B * A, kScoredThreads, lds, st>>>(caf, A, cH * cW, cstride, cifhr, F, hr_rows, hr_cols, hr_pitch,
+                                            skeleton, score_th, cif_floor, no_rescore, lists, counts, chunk_bbox, bbox_chunks,
+                                            bbox_stride);
     prof_mark(st, "cafscored_kernel");
     return hipGetLastError();
 }

@@ -107,6 +107,8 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     int sc = 2; while (sc < L->cif_cells) sc <<= 1;
     if (sc < kSortLdsKeys) sc = kSortLdsKeys;
     L->sort_cap = sc;
+    L->bbox_chunks = (L->caf_cells + kWave - 1) / kWave;
+    if (L->bbox_chunks > kListBboxMax) L->bbox_chunks = kListBboxMax;
     const size_t B = s.batch;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes); return o; };
@@ -128,7 +130,9 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     L->off_list_counts = take(B * L->A * 2 * sizeof(int32_t));
     L->off_lists_fc = take(list_bytes);
     L->off_list_counts_fc = take(B * L->A * 2 * sizeof(int32_t));
-    L->off_list_bbox = take(B * L->A * 2 * kListBboxChunks * 4 * sizeof(float));
+    L->off_list_bbox = take(B * L->A * 2 * (size_t)L->bbox_chunks * 4 * sizeof(float));
+    L->off_list_bbox_fc = take(B * L->A * 2 * (size_t)L->bbox_chunks * 4 * sizeof(float));
+    L->off_fc_meta = take(B * 4 * sizeof(int32_t));
     // occupancy bitmap, one bit per cell (occupancy.cpp:46-68 keeps an int16 map); 256-B multiple per image
     L->occ_image_words = align_up((size_t)L->F * L->occ_h * ((L->occ_w + 31) / 32) * sizeof(unsigned)) / sizeof(unsigned);
     L->off_occ = take(B * L->occ_image_words * sizeof(unsigned));
@@ -287,7 +291,7 @@ int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what, size_t* 
         {"seed_f", L.off_seed_f, L.off_seed_vxys}, {"seed_vxys", L.off_seed_vxys, L.off_seed_cell}, {"seed_cell", L.off_seed_cell, L.off_lists},
         {"lists", L.off_lists, L.off_list_counts}, {"list_counts", L.off_list_counts, L.off_lists_fc},
         {"lists_fc", L.off_lists_fc, L.off_list_counts_fc}, {"list_counts_fc", L.off_list_counts_fc, L.off_list_bbox},
-        {"list_bbox", L.off_list_bbox, L.off_occ},
+        {"list_bbox", L.off_list_bbox, L.off_list_bbox_fc}, {"list_bbox_fc", L.off_list_bbox_fc, L.off_fc_meta},
         {"occupancy", L.off_occ, L.off_anns}, {"annotation_scratch", L.off_anns, L.off_ann_meta},
         {"status", L.off_status, L.off_stats}, {"assoc_stats", L.off_stats, L.off_trace}, {"assoc_trace", L.off_trace, L.total},
     };
@@ -350,13 +354,15 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     e = launch_cafscored(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols, L.hr_pitch,
                          dec->dev.skeleton, p.caf_threshold, p.cif_floor, p.ablation_caf_no_rescore,
                          (float*)(ws + L.off_lists), (int32_t*)(ws + L.off_list_counts), st,
-                         (float*)(ws + L.off_list_bbox));                                    // :153-161
+                         (float*)(ws + L.off_list_bbox), L.bbox_chunks < kListBboxChunks ? L.bbox_chunks : kListBboxChunks,
+                         L.bbox_chunks);                                                     // :153-161
     if (e != hipSuccess) return fail_hip(e, "cafscored");
     if (p.force_complete) {                                                                   // :419-420
         e = launch_cafscored(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols,
                              L.hr_pitch, dec->dev.skeleton, p.force_complete_caf_th, 0.1,
                              p.ablation_caf_no_rescore, (float*)(ws + L.off_lists_fc),
-                             (int32_t*)(ws + L.off_list_counts_fc), st);
+                             (int32_t*)(ws + L.off_list_counts_fc), st,
+                             (float*)(ws + L.off_list_bbox_fc), L.bbox_chunks, L.bbox_chunks);
         if (e != hipSuccess) return fail_hip(e, "cafscored(force complete)");
     }
     // (the occupancy map of :173 is a bitmap the association kernel clears itself)
@@ -370,6 +376,9 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     a.lists = (const float*)(ws + L.off_lists); a.list_counts = (const int32_t*)(ws + L.off_list_counts);
     a.lists_fc = (const float*)(ws + L.off_lists_fc); a.list_counts_fc = (const int32_t*)(ws + L.off_list_counts_fc);
     a.list_bbox = (const float*)(ws + L.off_list_bbox);
+    a.list_bbox_fc = (const float*)(ws + L.off_list_bbox_fc);
+    a.bbox_chunks = L.bbox_chunks;
+    a.fc_meta = (int32_t*)(ws + L.off_fc_meta);
     a.occ = (unsigned*)(ws + L.off_occ); a.occ_image_words = L.occ_image_words;
     a.stats = (int32_t*)(ws + L.off_stats);
     a.trace = (int32_t*)(ws + L.off_trace);

@@ -81,7 +81,8 @@ __device__ __forceinline__ void wave_sync() {
 
 // 7 SoA planes: c,x1,y1,x2,y2,s1,s2; `bbox` (LDS, or null): (xmin, xmax, ymin, ymax) of the (x1, y1) columns of the
 // list's first kListBboxChunks chunks of 64 entries (cafscored writes them, common.hpp)
-struct ListView { const float* base; int cap; int n; const float4* bbox; };
+// `gbbox` (global memory, or null): the boxes of ALL chunks (up to `nb`) where cafscored wrote them
+struct ListView { const float* base; int cap; int n; const float4* bbox; const float4* gbbox; int nb; };
 
 // Diagnostic builds only (-DOPA_ASSOC_PHASE_TIMING, tools/gpu/assoc_probe.py): shader-clock time of the growers
 // by phase of the search, summed over the growers of an image; printed by the kernel for images 0 and 3.
@@ -128,6 +129,7 @@ struct ImageCtx {
     int heap_n, n_entries;
     // shared LDS
     const float4* bbox;                  // [2A][kListBboxChunks] chunk boxes of the active list set, or null
+    const float4* gbbox; int nb;         // global memory: [2A][nb] boxes of every chunk of the active list set, or null
     int* sh_counts;                      // [2A] list lengths of the active list set
     int n_blend;                         // list scans of this wave (statistics)
     int t_blend, t_blend_mem;            // ticks inside the scans, and of those until the loads had returned
@@ -139,6 +141,7 @@ __device__ __forceinline__ ListView list_view(const ImageCtx& c, int bone, int d
     v.cap = c.list_cap;
     v.n = c.sh_counts[bone * 2 + dir];
     v.bbox = c.bbox ? c.bbox + (bone * 2 + dir) * kListBboxChunks : nullptr;
+    v.gbbox = c.gbbox ? c.gbbox + (size_t)(bone * 2 + dir) * c.nb : nullptr; v.nb = c.nb;
     return v;
 }
 
@@ -291,6 +294,9 @@ typedef __attribute__((address_space(3))) int lint;
 constexpr int kTgtFloats = 3 * kBlendChunks * kWave;     // target columns (x2, y2, s2) of the list being scanned
 constexpr int kBlendLdsFloats = kTgtFloats + 4 * kWave;  // + the compacted (x1, y1, c, position) of a scan
 
+// More than 64 entries pass the window test (rare: a window holding that many cells): blend_cached reports it
+// (ok < 0) and the caller takes one of the streamed scans below.
+__device__ __forceinline__ BlendResult blend_overflow() { BlendResult r; r.v = 0.0; r.x = r.y = r.s = 0.f; r.ok = -1; return r; }
 __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const BlendQuery& q, bool only_max);
 
 // `chunks`: the R chunks of the list to look at, ascending, 8 bits each (0xff: none) -- all of them
@@ -359,7 +365,7 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
         }
         if (cnt > kWave) {
             __builtin_amdgcn_s_waitcnt(0x0F70);
-            return blend_streamed(L, q, only_max);
+            return blend_overflow();
         }
         wave_sync();
         PH(3);
@@ -463,12 +469,14 @@ __device__ __forceinline__ BlendResult blend_impl(const float* base, int cap, in
                                                double xy_scale, double filter_sigmas, int only_max, float* tgt,
                                                int* t_mem = nullptr) {
     if (n <= 0) return blend_none();
-    ListView L; L.base = base; L.cap = cap; L.n = n; L.bbox = nullptr;
+    ListView L; L.base = base; L.cap = cap; L.n = n; L.bbox = nullptr; L.gbbox = nullptr; L.nb = 0;
     const BlendQuery q = make_query(x, y, xy_scale, filter_sigmas);
     if (n <= kWave) return blend_cached<1>(L, q, only_max != 0, tgt, t_mem);
-    if (n <= 2 * kWave) return blend_cached<2>(L, q, only_max != 0, tgt, t_mem);
-    if (n <= 4 * kWave) return blend_cached<4>(L, q, only_max != 0, tgt, t_mem);
-    if (n <= kBlendChunks * kWave) return blend_cached<kBlendChunks>(L, q, only_max != 0, tgt, t_mem);
+    BlendResult r = blend_overflow();
+    if (n <= 2 * kWave) r = blend_cached<2>(L, q, only_max != 0, tgt, t_mem);
+    else if (n <= 4 * kWave) r = blend_cached<4>(L, q, only_max != 0, tgt, t_mem);
+    else if (n <= kBlendChunks * kWave) r = blend_cached<kBlendChunks>(L, q, only_max != 0, tgt, t_mem);
+    if (r.ok >= 0) return r;
     return blend_streamed(L, q, only_max != 0);
 }
 
@@ -496,15 +504,216 @@ __device__ __forceinline__ BlendResult blend_boxed(const ListView& L, double x, 
     const int nh = __popc(m);
     if (nh == 0) return blend_none();                          // :76
     if (nh == 1) return blend_cached<1>(L, q, false, tgt, nullptr, pack_chunks<1>(m));
-    if (nh == 2) return blend_cached<2>(L, q, false, tgt, nullptr, pack_chunks<2>(m));
-    if (nh <= 4) return blend_cached<4>(L, q, false, tgt, nullptr, pack_chunks<4>(m));
-    if (nh <= kBlendChunks) return blend_cached<kBlendChunks>(L, q, false, tgt, nullptr, pack_chunks<kBlendChunks>(m));
+    BlendResult r = blend_overflow();
+    if (nh == 2) r = blend_cached<2>(L, q, false, tgt, nullptr, pack_chunks<2>(m));
+    else if (nh <= 4) r = blend_cached<4>(L, q, false, tgt, nullptr, pack_chunks<4>(m));
+    else if (nh <= kBlendChunks) r = blend_cached<kBlendChunks>(L, q, false, tgt, nullptr, pack_chunks<kBlendChunks>(m));
+    if (r.ok >= 0) return r;
     return blend_streamed(L, q, false);
 }
 
+// ---- long lists (more than kListBboxChunks chunks: the force-complete set, all-active fields) ----------------
+// The boxes of all chunks are tested where cafscored wrote them: lane l looks at chunks l, l + 64, l + 128,
+// l + 192 (<= kListBboxMax chunks), one 16-byte load each, all in flight together.  Up to kBlendChunks hit chunks
+// take the one-round-trip scan above.  More hit chunks, or more than 64 passing entries (the force-complete window is
+// 4 sigma wide: dozens of cells), are COMPACTED over as many round trips as it takes -- (x1, y1, c, list index) of
+// every passing entry, in list order, into the wave's LDS area -- so that the double-precision exp runs once per 64
+// passing entries instead of twice per chunk, and the top-2 rules are those of the streamed scan on list indices.
+struct ChunkMask { unsigned long long m[4]; };
+__device__ __forceinline__ int chunk_pop(ChunkMask& k) {       // lowest set chunk index, or -1 (wave-uniform)
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+        if (k.m[g]) { const int ci = g * kWave + __builtin_ctzll(k.m[g]); k.m[g] &= k.m[g] - 1ull; return ci; }
+    return -1;
+}
+
+constexpr int kCompactCap = kBlendLdsFloats / 4;              // passing entries the LDS area of a wave holds (448)
+
+// blend_streamed over the chunks of `hit` only (ascending, so list positions -- and with them the tie rules --
+// are those of the full scan; no entry of another chunk can pass the window test): the last resort, when more than
+// kCompactCap entries pass.
+__device__ __forceinline__ BlendResult blend_streamed_masked(const ListView& L, const BlendQuery& q, const ChunkMask& hit) {
+    constexpr int G = 4;
+    const int lane = lane_id();
+    const gfloat* g = (const gfloat*)L.base;
+    float s1 = 0.0f; int i1 = -1;
+    {
+        ChunkMask k = hit;
+        for (;;) {
+            int ci[G];
+#pragma unroll
+            for (int r = 0; r < G; r++) ci[r] = chunk_pop(k);
+            if (ci[0] < 0) break;
+            float x1[G], y1[G], cc[G];
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+                const int i = ci[r] * kWave + lane;
+                const int ii = ci[r] >= 0 && i < L.n ? i : 0;
+                x1[r] = g[1 * L.cap + ii]; y1[r] = g[2 * L.cap + ii]; cc[r] = g[ii];
+            }
+#pragma unroll
+            for (int r = 0; r < G; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+                const int i = ci[r] * kWave + lane;
+                if (ci[r] >= 0 && i < L.n && passes_f(q, x1[r], y1[r])) {
+                    const float sc = score_of(q, x1[r], y1[r], cc[r]);
+                    if (sc >= s1) { s1 = sc; i1 = i; }
+                }
+            }
+        }
+    }
+    reduce_first(s1, i1);
+    if (s1 == 0.0f || i1 < 0) return blend_none();             // :76
+    float s2 = 0.0f; int r2 = -1;
+    {
+        ChunkMask k = hit;
+        for (;;) {
+            int ci[G];
+#pragma unroll
+            for (int r = 0; r < G; r++) ci[r] = chunk_pop(k);
+            if (ci[0] < 0) break;
+            float x1[G], y1[G], cc[G];
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+                const int i = ci[r] * kWave + lane;
+                const int ii = ci[r] >= 0 && i < L.n ? i : 0;
+                x1[r] = g[1 * L.cap + ii]; y1[r] = g[2 * L.cap + ii]; cc[r] = g[ii];
+            }
+#pragma unroll
+            for (int r = 0; r < G; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+                const int i = ci[r] * kWave + lane;
+                if (ci[r] < 0 || i >= L.n || i == i1 || !passes_f(q, x1[r], y1[r])) continue;
+                const float sc = score_of(q, x1[r], y1[r], cc[r]);
+                if (!(sc > 0.0f)) continue;
+                const int rank = i < i1 ? L.n + i : L.n - i;
+                if (sc > s2 || (sc == s2 && rank > r2)) { s2 = sc; r2 = rank; }
+            }
+        }
+    }
+    reduce_second(s2, r2);
+    const bool have2 = r2 >= 0;
+    const int i2 = have2 ? (r2 >= L.n ? r2 - L.n : L.n - r2) : i1;
+    const float e1x = g[3 * L.cap + i1], e1y = g[4 * L.cap + i1], e1s = g[6 * L.cap + i1];
+    const float e2x = g[3 * L.cap + i2], e2y = g[4 * L.cap + i2], e2s = g[6 * L.cap + i2];
+    return blend_finish(s1, s2, have2, false, e1x, e1y, e1s, e2x, e2y, e2s);
+}
+
+__device__ __forceinline__ BlendResult blend_compacted(const ListView& L, const BlendQuery& q, const ChunkMask& hit, float* tgt) {
+    constexpr int G = 4;
+    const int lane = lane_id();
+    const gfloat* g = (const gfloat*)L.base;
+    float* cx = tgt; float* cy = cx + kCompactCap; float* cv = cy + kCompactCap; int* ci_ = (int*)(cv + kCompactCap);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int cnt = 0;
+    {
+        ChunkMask k = hit;
+        for (;;) {
+            int ci[G];
+#pragma unroll
+            for (int r = 0; r < G; r++) ci[r] = chunk_pop(k);
+            if (ci[0] < 0) break;
+            float x1[G], y1[G], cc[G];
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+                const int i = ci[r] * kWave + lane;
+                const int ii = ci[r] >= 0 && i < L.n ? i : 0;
+                x1[r] = g[1 * L.cap + ii]; y1[r] = g[2 * L.cap + ii]; cc[r] = g[ii];
+            }
+#pragma unroll
+            for (int r = 0; r < G; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
+#pragma unroll
+            for (int r = 0; r < G; r++) {
+                const int i = ci[r] * kWave + lane;
+                const bool pass = ci[r] >= 0 && i < L.n && passes_f(q, x1[r], y1[r]);
+                const unsigned long long m = __ballot(pass);
+                if (m == 0ull) continue;
+                const int slot = cnt + __popcll(m & below);
+                if (pass && slot < kCompactCap) { cx[slot] = x1[r]; cy[slot] = y1[r]; cv[slot] = cc[r]; ci_[slot] = i; }
+                cnt += __popcll(m);
+            }
+        }
+    }
+    if (cnt == 0) return blend_none();                         // :76
+    if (cnt > kCompactCap) return blend_streamed_masked(L, q, hit);
+    wave_sync();
+    float s1 = 0.0f; int i1 = -1;
+    for (int e = lane; e < cnt; e += kWave) {                  // ascending list index per lane: ">=" keeps the last among equals
+        const float sc = score_of(q, cx[e], cy[e], cv[e]);
+        cv[e] = sc;                                            // (this lane's own slot: read again below)
+        if (sc >= s1) { s1 = sc; i1 = ci_[e]; }
+    }
+    reduce_first(s1, i1);
+    if (s1 == 0.0f || i1 < 0) return blend_none();             // :76
+    float s2 = 0.0f; int r2 = -1;
+    for (int e = lane; e < cnt; e += kWave) {
+        const int i = ci_[e];
+        const float sc = cv[e];
+        if (i == i1 || !(sc > 0.0f)) continue;
+        const int rank = i < i1 ? L.n + i : L.n - i;
+        if (sc > s2 || (sc == s2 && rank > r2)) { s2 = sc; r2 = rank; }
+    }
+    reduce_second(s2, r2);
+    wave_sync();                                               // the area is free for the next scan
+    const bool have2 = r2 >= 0;
+    const int i2 = have2 ? (r2 >= L.n ? r2 - L.n : L.n - r2) : i1;
+    const float e1x = g[3 * L.cap + i1], e1y = g[4 * L.cap + i1], e1s = g[6 * L.cap + i1];
+    const float e2x = g[3 * L.cap + i2], e2y = g[4 * L.cap + i2], e2s = g[6 * L.cap + i2];
+    return blend_finish(s1, s2, have2, false, e1x, e1y, e1s, e2x, e2y, e2s);
+}
+
+__device__ __forceinline__ BlendResult blend_long(const ListView& L, const BlendQuery& q, float* tgt) {
+    const int lane = lane_id();
+    const int nch = (L.n + kWave - 1) >> 6;                     // <= L.nb <= kListBboxMax
+    const float4* gb = L.gbbox;
+    float4 bb[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int ci = g * kWave + lane;
+        if (g * kWave < nch) bb[g] = gb[ci < nch ? ci : 0];
+    }
+    ChunkMask hit;
+    int nh = 0;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        hit.m[g] = 0ull;
+        if (g * kWave < nch) {
+            const int ci = g * kWave + lane;
+            hit.m[g] = __ballot(ci < nch && bb[g].x <= q.fxhi && bb[g].y >= q.fxlo && bb[g].z <= q.fyhi && bb[g].w >= q.fylo);
+            nh += __popcll(hit.m[g]);
+        }
+    }
+    if (nh == 0) return blend_none();                          // :76
+    if (nh <= kBlendChunks) {
+        unsigned long long chunks = ~0ull;                     // 0xff: no chunk
+        ChunkMask k = hit;
+#pragma unroll
+        for (int r = 0; r < kBlendChunks; r++) {
+            const int ci = chunk_pop(k);
+            if (ci >= 0) chunks = (chunks & ~(0xffull << (8 * r))) | ((unsigned long long)ci << (8 * r));
+        }
+        BlendResult r;
+        if (nh == 1) r = blend_cached<1>(L, q, false, tgt, nullptr, chunks);
+        else if (nh == 2) r = blend_cached<2>(L, q, false, tgt, nullptr, chunks);
+        else if (nh <= 4) r = blend_cached<4>(L, q, false, tgt, nullptr, chunks);
+        else r = blend_cached<kBlendChunks>(L, q, false, tgt, nullptr, chunks);
+        if (r.ok >= 0) return r;
+    }
+    return blend_compacted(L, q, hit, tgt);
+}
+
+// LONG: the list set has a box for every chunk in global memory (the force-complete kernel); the seed kernel keeps
+// its scan code as small as its lists are (inlined at every scan site, the long-list path cost it 77 spilled VGPRs).
+template <bool LONG>
 __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, double x, double y, double xy_scale,
                                              double filter_sigmas) {
     c.n_blend++;
+    if constexpr (LONG) {
+        if (L.gbbox && L.n > kWave && L.n <= L.nb * kWave)
+            return blend_long(L, make_query(x, y, xy_scale, filter_sigmas), c.tgt);
+    }
     if (L.bbox && L.n > kWave && L.n <= kListBboxChunks * kWave) {
 #ifdef OPA_ASSOC_PHASE_TIMING
         PH(17);
@@ -605,6 +814,7 @@ __device__ __forceinline__ int new_entry(ImageCtx& c, double v, float x, float y
 }
 
 // cifcaf.cpp:349-411 ; t = adjacency slot of (start -> end)
+template <bool LONG>
 __device__ __forceinline__ bool connection_value(ImageCtx& c, const DevParams& p, int start, int t,
                                  bool reverse_match_, double filter_sigmas,
                                  double* nv, float* nx, float* ny, float* ns) {
@@ -612,13 +822,13 @@ __device__ __forceinline__ bool connection_value(ImageCtx& c, const DevParams& p
     const ListView caf_f = list_view(c, bone, fwd ? 0 : 1);
     const ListView caf_b = list_view(c, bone, fwd ? 1 : 0);
     const double sv = c.jv[start], sx = (double)c.jx[start], sy = (double)c.jy[start], ss = (double)c.js[start];
-    const BlendResult nj = blend(c, caf_f, sx, sy, ss, filter_sigmas);
+    const BlendResult nj = blend<LONG>(c, caf_f, sx, sy, ss, filter_sigmas);
     if (!nj.ok) return false;
     *nx = nj.x; *ny = nj.y; *ns = nj.s;
     *nv = sqrt(nj.v * sv);                                                      // :386
     if (*nv < p.keypoint_threshold || *nv < sv * p.keypoint_threshold_rel) return false;   // :387-390
     if (p.reverse_match && reverse_match_ && start < c.F) {                     // :397
-        const BlendResult rj = blend(c, caf_b, (double)*nx, (double)*ny, (double)*ns, filter_sigmas);
+        const BlendResult rj = blend<LONG>(c, caf_b, (double)*nx, (double)*ny, (double)*ns, filter_sigmas);
         if (!rj.ok) return false;
         if (fabs(sx - (double)rj.x) + fabs(sy - (double)rj.y) > ss) return false;   // :404
     }
@@ -652,6 +862,7 @@ __device__ __forceinline__ int find_adj_slot(const ImageCtx& c, int start, int e
 }
 
 // cifcaf.cpp:265-313 -- one wavefront, no workgroup barriers
+template <bool LONG>
 __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool reverse_match_, double filter_sigmas) {
     frontier_reset(c);
     for (int j = 0; j < c.K; j++) if (c.jv[j] != 0.0) frontier_add_from(c, j);
@@ -663,7 +874,7 @@ __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool rever
         double v = c.e_v[e]; float x = c.e_x[e], y = c.e_y[e], s = c.e_s[e];
         if (v == 0.0) {                                                  // :287: not computed yet
             const int slot = find_adj_slot(c, start, end);
-            if (!connection_value(c, p, start, slot, reverse_match_, filter_sigmas, &v, &x, &y, &s))
+            if (!connection_value<LONG>(c, p, start, slot, reverse_match_, filter_sigmas, &v, &x, &y, &s))
                 continue;                                                // :290-296 (block_joints is a no-op)
             if (!p.greedy) {                                             // :298-303
                 heap_push(c, (float)v, new_entry(c, v, x, y, s, start, end));
@@ -805,27 +1016,32 @@ __device__ __forceinline__ void reg_frontier_start(RegState& R, const RegSkeleto
 }
 
 // cifcaf.cpp:349-411 for the directed bone `slot` leaving joint `start`
+template <bool LONG>
 __device__ __forceinline__ bool reg_connection_value(ImageCtx& c, const DevParams& p, const RegState& R, int start,
                                                      int info, bool reverse_match_, double filter_sigmas,
                                                      double* nv, float* nx, float* ny, float* ns) {
     const int bone = (info >> 16) & 0xff, fwd = (info >> 24) & 1;
-    ListView caf_f, caf_b;
-    caf_f.cap = caf_b.cap = c.list_cap;
-    caf_f.base = c.lists + ((size_t)bone * 2 + (fwd ? 0 : 1)) * 7 * c.list_cap;
-    caf_b.base = c.lists + ((size_t)bone * 2 + (fwd ? 1 : 0)) * 7 * c.list_cap;
-    caf_f.n = rlane(R.list_n, bone * 2 + (fwd ? 0 : 1));
-    caf_b.n = rlane(R.list_n, bone * 2 + (fwd ? 1 : 0));
-    caf_f.bbox = c.bbox ? c.bbox + (bone * 2 + (fwd ? 0 : 1)) * kListBboxChunks : nullptr;
-    caf_b.bbox = c.bbox ? c.bbox + (bone * 2 + (fwd ? 1 : 0)) * kListBboxChunks : nullptr;
+    // (the view of the reverse list is built after the forward scan: nothing of it has to stay live across that scan)
+    auto view = [&](int dir) {
+        ListView v;
+        v.cap = c.list_cap;
+        v.base = c.lists + ((size_t)bone * 2 + dir) * 7 * c.list_cap;
+        v.n = rlane(R.list_n, bone * 2 + dir);
+        v.bbox = c.bbox ? c.bbox + (bone * 2 + dir) * kListBboxChunks : nullptr;
+        v.gbbox = c.gbbox ? c.gbbox + (size_t)(bone * 2 + dir) * c.nb : nullptr; v.nb = c.nb;
+        return v;
+    };
+    const ListView caf_f = view(fwd ? 0 : 1);
     const double sv = reg_jv(R, start);
     const double sx = (double)rlanef(R.jx, start), sy = (double)rlanef(R.jy, start), ss = (double)rlanef(R.js, start);
-    const BlendResult nj = blend(c, caf_f, sx, sy, ss, filter_sigmas);
+    const BlendResult nj = blend<LONG>(c, caf_f, sx, sy, ss, filter_sigmas);
     if (!nj.ok) return false;
     *nx = uniform_f32(nj.x); *ny = uniform_f32(nj.y); *ns = uniform_f32(nj.s);
     *nv = uniform_f64(sqrt(nj.v * sv));                                         // :386
     if (*nv < p.keypoint_threshold || *nv < sv * p.keypoint_threshold_rel) return false;   // :387-390
     if (p.reverse_match && reverse_match_ && start < c.F) {                     // :397
-        const BlendResult rj = blend(c, caf_b, (double)*nx, (double)*ny, (double)*ns, filter_sigmas);
+        const ListView caf_b = view(fwd ? 1 : 0);
+        const BlendResult rj = blend<LONG>(c, caf_b, (double)*nx, (double)*ny, (double)*ns, filter_sigmas);
         if (!rj.ok) return false;
         if (fabs(sx - (double)rj.x) + fabs(sy - (double)rj.y) > ss) return false;   // :404
     }
@@ -850,6 +1066,7 @@ __device__ __forceinline__ void reg_store_pose(ImageCtx& c, const RegState& R) {
 }
 
 // cifcaf.cpp:265-313 on the pose in this wave's LDS block
+template <bool LONG>
 __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const RegSkeleton& sk, bool reverse_match_,
                                          double filter_sigmas, bool then_flood_fill) {
     RegState R;
@@ -865,7 +1082,7 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
         float x, y, s;
         PH(0);
         if (v == 0.0) {                                                      // :287: not computed yet
-            if (!reg_connection_value(c, p, R, start, info, reverse_match_, filter_sigmas, &v, &x, &y, &s)) {
+            if (!reg_connection_value<LONG>(c, p, R, start, info, reverse_match_, filter_sigmas, &v, &x, &y, &s)) {
                 PH(7);
                 continue;                                                    // :290-296 (block_joints is a no-op)
             }
@@ -901,13 +1118,13 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
     reg_store_pose(c, R);
 }
 
-template <bool REG>
+template <bool REG, bool LONG = false>
 __device__ __forceinline__ void grow_pose(ImageCtx& c, const DevParams& p, const RegSkeleton& sk, bool reverse_match_,
                                           double filter_sigmas, bool then_flood_fill) {
     if constexpr (REG) {
-        grow_reg(c, p, sk, reverse_match_, filter_sigmas, then_flood_fill);
+        grow_reg<LONG>(c, p, sk, reverse_match_, filter_sigmas, then_flood_fill);
     } else {
-        grow(c, p, reverse_match_, filter_sigmas);
+        grow<LONG>(c, p, reverse_match_, filter_sigmas);
         if (then_flood_fill && !c.aborted) flood_fill(c);
         wave_sync();
     }
@@ -1083,7 +1300,124 @@ constexpr int kAssocStats = 24;
 // The coordinator and the growers wait for each other in LDS polling loops.  A protocol error must not hang
 // the device: after this many 10-ns ticks inside one launch every wait gives up, the image reports no poses
 // and status -1 (never seen in the tests; one second is ~1000x the slowest image).
-constexpr long long kWatchdogTicks = 100000000ll;
+constexpr long long kWatchdogTicksDefault = 100000000ll;   // (OPA_ASSOC_WATCHDOG_TICKS overrides: tests provoke the failure)
+
+// ---- keypoint NMS + output (nms_keypoints.cpp:17-70, cifcaf.cpp:246-261), by all threads of a workgroup, on the
+// poses stored in the HBM scratch `anns`.  Shared by the seed kernel (default flags) and the force-complete kernel.
+struct NmsLds { double* nms_score; unsigned long long* nms_supp; int* nms_order; int* nms_rank; unsigned char* work_base; };
+template <int kThreads>
+__device__ __forceinline__ void nms_and_store(const AssocArgs& a, const DevParams& p, const ImageCtx& c, const NmsLds& l, int b,
+                                              int n_kept, int n_dropped, bool failed, double* anns, const int64_t* ann_ids,
+                                              int nms_waves) {
+    const int tid = threadIdx.x, lane = lane_id(), wave = c.wave, K = a.K;
+    const int KC = (K + kWave - 1) / kWave;
+    double* nms_score = l.nms_score; unsigned long long* nms_supp = l.nms_supp;
+    int* nms_order = l.nms_order; int* nms_rank = l.nms_rank; unsigned char* work_base = l.work_base;
+    // ---- keypoint NMS, nms_keypoints.cpp:17-70
+    for (int n = tid; n < n_kept; n += kThreads) {       // UniformScore of every stored pose
+        const double* src = anns + (size_t)n * K * 4;
+        double acc = 0.0;
+        for (int k = 0; k < K; k++) { const float i = (float)acc; acc = (double)i + src[4 * k]; }
+        nms_score[n] = acc / (double)K;
+    }
+    __syncthreads();
+    for (int n = tid; n < n_kept; n += kThreads) {       // rank by score desc (ties: creation order)
+        const double sn = nms_score[n];
+        int rank = 0;
+        for (int m = 0; m < n_kept; m++) { const double sm = nms_score[m]; rank += (sm > sn || (sm == sn && m < n)) ? 1 : 0; }
+        nms_order[rank] = n;
+        for (int kc = 0; kc < KC; kc++) nms_supp[n * KC + kc] = 0ull;
+    }
+    __syncthreads();
+    // Occupancy pass (:27-43) without a map: joints of different fields never interact, so wave w takes
+    // fields w, w+nms_waves, ...; per field the poses are visited in score order and pose r's joint is suppressed
+    // iff its cell lies in the box of an earlier, still unsuppressed joint (= Occupancy::get after the
+    // earlier Occupancy::set calls).  Boxes and cells of the field sit in this wave's LDS scratch.
+    {
+        unsigned char* nsp = work_base + (size_t)wave * nms_scratch_bytes(a.max_ann);
+        OccBox* my_box = (OccBox*)nsp;
+        int2* my_cell = (int2*)(nsp + sizeof(OccBox) * a.max_ann);
+        // :27-30: only joints with an occupancy field take part; nms_waves = waves whose scratch fits the LDS
+        for (int k = wave; k < a.F && wave < nms_waves; k += nms_waves) {
+            for (int r = lane; r < n_kept; r += kWave) {
+                const double* pose = anns + ((size_t)nms_order[r] * K + k) * 4;
+                OccBox bx; bx.minx = bx.miny = bx.maxx = bx.maxy = 0;
+                int2 cell; cell.x = -1; cell.y = -1;          // v == 0: neither tested nor set (:36)
+                if (pose[0] != 0.0) {
+                    occ_xy(c, p, pose[1], pose[2], &cell.x, &cell.y);
+                    bx = occ_box(c, p, pose[1], pose[2], pose[3]);
+                }
+                my_box[r] = bx; my_cell[r] = cell;
+            }
+            wave_sync();
+            for (int r = 1; r < n_kept; r++) {
+                const int2 cell = my_cell[r];
+                if (cell.x < 0) continue;
+                bool cover = false;
+                for (int q = lane; q < r; q += kWave) cover |= box_contains(my_box[q], cell.x, cell.y);
+                if (__ballot(cover) != 0ull) {                // :37-38 suppressed, sets no box
+                    if (lane == 0) {
+                        atomicOr(&nms_supp[r * KC + (k >> 6)], 1ull << (k & 63));
+                        OccBox e; e.minx = e.miny = e.maxx = e.maxy = 0;
+                        my_box[r] = e;
+                    }
+                    wave_sync();
+                }
+            }
+            wave_sync();
+        }
+    }
+    __syncthreads();
+    // suppression, keypoint threshold, instance threshold (:50,58-66); one thread per pose
+    for (int r = tid; r < n_kept; r += kThreads) {
+        double* pose = anns + (size_t)nms_order[r] * K * 4;
+        double acc = 0.0;
+        for (int k = 0; k < K; k++) {
+            double v = pose[4 * k];
+            if ((nms_supp[r * KC + (k >> 6)] >> (k & 63)) & 1ull) v *= p.nms_suppression;
+            if (!(v > p.nms_keypoint_threshold)) v = 0.0;
+            pose[4 * k] = v;
+            const float i = (float)acc; acc = (double)i + v;
+        }
+        nms_score[r] = acc / (double)K;                  // indexed by sorted position r now
+    }
+    sync_global();                                       // the rewritten confidences are read by other threads below
+    for (int r = tid; r < n_kept; r += kThreads) {       // final order (:69); ties keep the previous order
+        const double sr = nms_score[r];
+        int rank = -1;
+        if (!(sr < p.nms_instance_threshold)) {
+            rank = 0;
+            for (int m = 0; m < n_kept; m++) {
+                const double sm = nms_score[m];
+                if (sm < p.nms_instance_threshold) continue;
+                rank += (sm > sr || (sm == sr && m < r)) ? 1 : 0;
+            }
+        }
+        nms_rank[r] = rank;
+    }
+    __syncthreads();
+    float* out = a.out + (size_t)b * a.max_ann * K * 4;
+    int64_t* out_ids = a.out_ids + (size_t)b * a.max_ann;
+    int n_out = 0;
+    for (int r = 0; r < n_kept; r++) n_out += nms_rank[r] >= 0 ? 1 : 0;
+    for (int idx = tid; idx < n_kept * K; idx += kThreads) {          // cifcaf.cpp:250-258
+        const int r = idx / K, k = idx - r * K;
+        const int dst = nms_rank[r];
+        if (dst < 0) continue;
+        const int src_n = nms_order[r];
+        const double* pose = anns + (size_t)src_n * K * 4;
+        float4 o;
+        o.x = (float)pose[4 * k]; o.y = (float)pose[4 * k + 1];
+        o.z = (float)pose[4 * k + 2]; o.w = (float)pose[4 * k + 3];
+        reinterpret_cast<float4*>(out)[(size_t)dst * K + k] = o;
+        if (k == 0) out_ids[dst] = ann_ids[src_n];
+    }
+    if (tid == 0) {
+        // rows [0, n_out) are valid; poses dropped for lack of capacity raise the overflow flag
+        a.out_count[b] = n_out | (n_dropped > 0 ? OPA_COUNT_OVERFLOW : 0) | (failed ? OPA_COUNT_FAILED : 0);
+        a.status[b] = failed ? -1 : n_dropped;
+    }
+}
 
 template <bool REG, int NW>
 __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a, DevSkeleton sk, DevParams p,
@@ -1097,6 +1431,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     const int KC = (K + kWave - 1) / kWave;          // 64-joint chunks per pose
     const int S = n_growers;                         // growers = waves 1..S, each with a private LDS block
     const long long t_kernel = wall_clock64();
+    const long long kWatchdogTicks = a.watchdog_ticks;
 
     ImageCtx c;
     c.K = K; c.A = A; c.F = a.F; c.wave = wave;
@@ -1109,6 +1444,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     c.pool_if = nullptr; c.pool_pack = nullptr; c.shadow_mine = nullptr; c.my_idx = 0;
     c.pool_ep = nullptr; c.epoch = nullptr; c.ack = nullptr; c.my_epoch = 0;
     c.bbox = nullptr;
+    c.nb = a.bbox_chunks;
+    c.gbbox = a.list_bbox ? reinterpret_cast<const float4*>(a.list_bbox) + (size_t)b * 2 * a.A * a.bbox_chunks : nullptr;
 
     // ---- LDS carve: shared part, then one private block per growing wave
     unsigned char* sp = smem;
@@ -1166,9 +1503,13 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         l_other[k] = sk.adj_other[k]; l_bone[k] = sk.adj_bone[k]; l_fwd[k] = sk.adj_fwd[k]; l_first[k] = sk.adj_first[k];
     }
     for (int k = tid; k <= K; k += kThreads) l_off[k] = sk.adj_off[k];
-    if (use_bbox) {
-        const float4* src = reinterpret_cast<const float4*>(a.list_bbox) + (size_t)b * E * kListBboxChunks;
-        for (int k = tid; k < E * kListBboxChunks; k += kThreads) sh_bbox[k] = src[k];
+    if (use_bbox) {                                  // the first kListBboxChunks boxes of every caf_th list
+        const float4* src = reinterpret_cast<const float4*>(a.list_bbox) + (size_t)b * E * a.bbox_chunks;
+        const float inf = __builtin_inff();
+        for (int k = tid; k < E * kListBboxChunks; k += kThreads) {
+            const int ch = k & (kListBboxChunks - 1);
+            sh_bbox[k] = ch < a.bbox_chunks ? src[(size_t)(k / kListBboxChunks) * a.bbox_chunks + ch] : make_float4(inf, -inf, inf, -inf);
+        }
         c.bbox = sh_bbox;
     }
     if (tid < NW) {
@@ -1690,134 +2031,17 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
 #endif
     n_kept = sh_ctl[1]; n_dropped = sh_ctl[2];
 
-    // ---- force complete, cifcaf.cpp:233-236,414-449: poses are independent, one per grower
+    // ---- force complete (cifcaf.cpp:233-236,414-449) and the keypoint NMS behind it run in cifcaf_fc_kernel: the
+    // stored poses are independent there, so they spread over several workgroups per image
     if (p.force_complete) {
-        c.bbox = nullptr;                                // the force-complete lists have no chunk boxes
-        c.lists = a.lists_fc + (size_t)b * A * 2 * 7 * a.list_cap;
-        c.list_counts = a.list_counts_fc + (size_t)b * A * 2;
-        for (int k = tid; k < E; k += kThreads) c.sh_counts[k] = c.list_counts[k];
-        __syncthreads();
-        if (wave >= 1 && wave <= S) {
-            for (int n = wave - 1; n < n_kept; n += S) {
-                double* src = anns + (size_t)n * K * 4;
-                for (int k = lane; k < K; k += kWave) {
-                    c.jv[k] = src[4 * k + 0]; c.jx[k] = (float)src[4 * k + 1];
-                    c.jy[k] = (float)src[4 * k + 2]; c.js[k] = (float)src[4 * k + 3];
-                }
-                wave_sync();
-                grow_pose<REG>(c, p, rs, false, 4.0, true);   // :419-425, :235
-                for (int k = lane; k < K; k += kWave) {
-                    src[4 * k + 0] = c.jv[k]; src[4 * k + 1] = (double)c.jx[k];
-                    src[4 * k + 2] = (double)c.jy[k]; src[4 * k + 3] = (double)c.js[k];
-                }
-            }
+        if (tid == 0) {
+            int* meta = a.fc_meta + (size_t)b * 4;
+            meta[0] = n_kept; meta[1] = n_dropped; meta[2] = sh_ctl[5]; meta[3] = 0;
         }
-        sync_global();
-    }
-
-    // ---- keypoint NMS, nms_keypoints.cpp:17-70
-    for (int n = tid; n < n_kept; n += kThreads) {       // UniformScore of every stored pose
-        const double* src = anns + (size_t)n * K * 4;
-        double acc = 0.0;
-        for (int k = 0; k < K; k++) { const float i = (float)acc; acc = (double)i + src[4 * k]; }
-        nms_score[n] = acc / (double)K;
-    }
-    __syncthreads();
-    for (int n = tid; n < n_kept; n += kThreads) {       // rank by score desc (ties: creation order)
-        const double sn = nms_score[n];
-        int rank = 0;
-        for (int m = 0; m < n_kept; m++) { const double sm = nms_score[m]; rank += (sm > sn || (sm == sn && m < n)) ? 1 : 0; }
-        nms_order[rank] = n;
-        for (int kc = 0; kc < KC; kc++) nms_supp[n * KC + kc] = 0ull;
-    }
-    __syncthreads();
-    // Occupancy pass (:27-43) without a map: joints of different fields never interact, so wave w takes
-    // fields w, w+nms_waves, ...; per field the poses are visited in score order and pose r's joint is suppressed
-    // iff its cell lies in the box of an earlier, still unsuppressed joint (= Occupancy::get after the
-    // earlier Occupancy::set calls).  Boxes and cells of the field sit in this wave's LDS scratch.
-    {
-        unsigned char* nsp = work_base + (size_t)wave * nms_scratch_bytes(a.max_ann);
-        OccBox* my_box = (OccBox*)nsp;
-        int2* my_cell = (int2*)(nsp + sizeof(OccBox) * a.max_ann);
-        // :27-30: only joints with an occupancy field take part; nms_waves = waves whose scratch fits the LDS
-        for (int k = wave; k < a.F && wave < nms_waves; k += nms_waves) {
-            for (int r = lane; r < n_kept; r += kWave) {
-                const double* pose = anns + ((size_t)nms_order[r] * K + k) * 4;
-                OccBox bx; bx.minx = bx.miny = bx.maxx = bx.maxy = 0;
-                int2 cell; cell.x = -1; cell.y = -1;          // v == 0: neither tested nor set (:36)
-                if (pose[0] != 0.0) {
-                    occ_xy(c, p, pose[1], pose[2], &cell.x, &cell.y);
-                    bx = occ_box(c, p, pose[1], pose[2], pose[3]);
-                }
-                my_box[r] = bx; my_cell[r] = cell;
-            }
-            wave_sync();
-            for (int r = 1; r < n_kept; r++) {
-                const int2 cell = my_cell[r];
-                if (cell.x < 0) continue;
-                bool cover = false;
-                for (int q = lane; q < r; q += kWave) cover |= box_contains(my_box[q], cell.x, cell.y);
-                if (__ballot(cover) != 0ull) {                // :37-38 suppressed, sets no box
-                    if (lane == 0) {
-                        atomicOr(&nms_supp[r * KC + (k >> 6)], 1ull << (k & 63));
-                        OccBox e; e.minx = e.miny = e.maxx = e.maxy = 0;
-                        my_box[r] = e;
-                    }
-                    wave_sync();
-                }
-            }
-            wave_sync();
-        }
-    }
-    __syncthreads();
-    // suppression, keypoint threshold, instance threshold (:50,58-66); one thread per pose
-    for (int r = tid; r < n_kept; r += kThreads) {
-        double* pose = anns + (size_t)nms_order[r] * K * 4;
-        double acc = 0.0;
-        for (int k = 0; k < K; k++) {
-            double v = pose[4 * k];
-            if ((nms_supp[r * KC + (k >> 6)] >> (k & 63)) & 1ull) v *= p.nms_suppression;
-            if (!(v > p.nms_keypoint_threshold)) v = 0.0;
-            pose[4 * k] = v;
-            const float i = (float)acc; acc = (double)i + v;
-        }
-        nms_score[r] = acc / (double)K;                  // indexed by sorted position r now
-    }
-    sync_global();                                       // the rewritten confidences are read by other threads below
-    for (int r = tid; r < n_kept; r += kThreads) {       // final order (:69); ties keep the previous order
-        const double sr = nms_score[r];
-        int rank = -1;
-        if (!(sr < p.nms_instance_threshold)) {
-            rank = 0;
-            for (int m = 0; m < n_kept; m++) {
-                const double sm = nms_score[m];
-                if (sm < p.nms_instance_threshold) continue;
-                rank += (sm > sr || (sm == sr && m < r)) ? 1 : 0;
-            }
-        }
-        nms_rank[r] = rank;
-    }
-    __syncthreads();
-    float* out = a.out + (size_t)b * a.max_ann * K * 4;
-    int64_t* out_ids = a.out_ids + (size_t)b * a.max_ann;
-    int n_out = 0;
-    for (int r = 0; r < n_kept; r++) n_out += nms_rank[r] >= 0 ? 1 : 0;
-    for (int idx = tid; idx < n_kept * K; idx += kThreads) {          // cifcaf.cpp:250-258
-        const int r = idx / K, k = idx - r * K;
-        const int dst = nms_rank[r];
-        if (dst < 0) continue;
-        const int src_n = nms_order[r];
-        const double* pose = anns + (size_t)src_n * K * 4;
-        float4 o;
-        o.x = (float)pose[4 * k]; o.y = (float)pose[4 * k + 1];
-        o.z = (float)pose[4 * k + 2]; o.w = (float)pose[4 * k + 3];
-        reinterpret_cast<float4*>(out)[(size_t)dst * K + k] = o;
-        if (k == 0) out_ids[dst] = ann_ids[src_n];
-    }
-    if (tid == 0) {
-        // rows [0, n_out) are valid; poses dropped for lack of capacity raise the overflow flag
-        a.out_count[b] = n_out | (n_dropped > 0 ? OPA_COUNT_OVERFLOW : 0);
-        a.status[b] = sh_ctl[5] ? -1 : n_dropped;
+    } else {
+        NmsLds nl; nl.nms_score = nms_score; nl.nms_supp = nms_supp; nl.nms_order = nms_order; nl.nms_rank = nms_rank;
+        nl.work_base = work_base;
+        nms_and_store<kThreads>(a, p, c, nl, b, n_kept, n_dropped, sh_ctl[5] != 0, anns, ann_ids, nms_waves);
     }
     if (tid == 0 && a.stats) {
         sh_stats[9] = (int)(wall_clock64() - t_kernel);
@@ -1825,6 +2049,150 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         sh_stats[13] = S; sh_stats[14] = n_kept;
         for (int k = 0; k < kAssocStats; k++) a.stats[(size_t)b * kAssocStats + k] = sh_stats[k];
     }
+}
+
+// ------------------------------------------------------------ force complete
+// cifcaf.cpp:233-236,414-449 + the keypoint NMS behind it, as a kernel of its own.  The stored poses of an image
+// are independent here (each is grown on with the caf_th 0.001 lists, no reverse match, a 4 sigma window, then flood
+// filled), so they are spread over `S` workgroups per image, every wave a grower: a crowded image's 60 poses grow at
+// once instead of eleven at a time inside the seed kernel's one workgroup.  The lists of this set hold most cells
+// of a field (~100 chunks of 64): scans go through the chunk boxes cafscored left in global memory (blend_long).
+// The workgroup of an image that finishes LAST (a counter in the workspace) runs the keypoint NMS and writes the
+// output.  Keeping this code out of the seed kernel also keeps that kernel's registers where round 2 left them.
+template <bool REG, int NW>
+__global__ __launch_bounds__(NW * kWave, 1) void cifcaf_fc_kernel(AssocArgs a, DevSkeleton sk, DevParams p,
+                                                                  int n_growers, int nms_waves, int S) {
+    constexpr int kThreads = NW * kWave;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int b = blockIdx.x / S, part = blockIdx.x - b * S, tid = threadIdx.x, lane = lane_id();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = a.K, A = a.A, E = 2 * A, P4 = 4 * A;
+    const int KC = (K + kWave - 1) / kWave;
+    int* meta = a.fc_meta + (size_t)b * 4;
+    const int n_kept = meta[0], n_dropped = meta[1], failed = meta[2];
+
+    ImageCtx c;
+    c.K = K; c.A = A; c.F = a.F; c.wave = wave;
+    c.lists = a.lists_fc + (size_t)b * A * 2 * 7 * a.list_cap;
+    c.list_counts = a.list_counts_fc + (size_t)b * A * 2;
+    c.list_cap = a.list_cap;
+    c.occ_h = a.occ_h; c.occ_w = a.occ_w; c.occ_wpr = (a.occ_w + 31) >> 5;
+    c.occ = nullptr;
+    c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
+    c.pool_if = nullptr; c.pool_pack = nullptr; c.shadow_mine = nullptr; c.my_idx = 0;
+    c.pool_ep = nullptr; c.epoch = nullptr; c.ack = nullptr; c.my_epoch = 0;
+    c.bbox = nullptr;
+    c.nb = a.bbox_chunks;
+    c.gbbox = a.list_bbox_fc ? reinterpret_cast<const float4*>(a.list_bbox_fc) + (size_t)b * E * a.bbox_chunks : nullptr;
+
+    unsigned char* sp = smem;
+    NmsLds nl;
+    nl.nms_score = (double*)sp; sp += sizeof(double) * a.max_ann;
+    nl.nms_supp = (unsigned long long*)sp; sp += sizeof(unsigned long long) * a.max_ann * KC;
+    c.sh_counts = (int*)sp; sp += sizeof(int) * E;
+    int* l_off = (int*)sp; sp += sizeof(int) * (K + 1);
+    int* l_other = (int*)sp; sp += sizeof(int) * E;
+    int* l_bone = (int*)sp; sp += sizeof(int) * E;
+    int* l_fwd = (int*)sp; sp += sizeof(int) * E;
+    int* l_first = (int*)sp; sp += sizeof(int) * E;
+    nl.nms_order = (int*)sp; sp += sizeof(int) * a.max_ann;
+    nl.nms_rank = (int*)sp; sp += sizeof(int) * a.max_ann;
+    int* sh_last = (int*)sp; sp += sizeof(int) * 4;
+    sp = smem + (((size_t)(sp - smem) + 15) & ~(size_t)15);
+    nl.work_base = sp;
+    sp += (size_t)(wave < n_growers ? wave : 0) * assoc_private_bytes(K, A);
+    c.jbox = (OccBox*)sp; sp += sizeof(OccBox) * K;
+    c.jv = (double*)sp; sp += sizeof(double) * K;
+    c.e_v = (double*)sp; sp += sizeof(double) * P4;
+    c.heap = (unsigned long long*)sp; sp += sizeof(unsigned long long) * P4;
+    c.jx = (float*)sp; sp += sizeof(float) * K;
+    c.jy = (float*)sp; sp += sizeof(float) * K;
+    c.js = (float*)sp; sp += sizeof(float) * K;
+    c.e_x = (float*)sp; sp += sizeof(float) * P4;
+    c.e_y = (float*)sp; sp += sizeof(float) * P4;
+    c.e_s = (float*)sp; sp += sizeof(float) * P4;
+    c.e_se = (int*)sp; sp += sizeof(int) * P4;
+    c.in_frontier = sp; sp += (E + 15) / 16 * 16;
+    c.tgt = (float*)sp;
+    c.heap_n = 0; c.n_entries = 0;
+
+    for (int k = tid; k < E; k += kThreads) {
+        c.sh_counts[k] = c.list_counts[k];
+        l_other[k] = sk.adj_other[k]; l_bone[k] = sk.adj_bone[k]; l_fwd[k] = sk.adj_fwd[k]; l_first[k] = sk.adj_first[k];
+    }
+    for (int k = tid; k <= K; k += kThreads) l_off[k] = sk.adj_off[k];
+    c.adj_off = l_off; c.adj_other = l_other; c.adj_bone = l_bone; c.adj_fwd = l_fwd; c.adj_first = l_first;
+    __syncthreads();
+    RegSkeleton rs; rs.slot_info = 0; rs.slot_first = 0; rs.off = 0; rs.off1 = 0;
+    if constexpr (REG) {
+        if (lane < E) {
+            int start = 0;
+            while (l_off[start + 1] <= lane) start++;
+            rs.slot_info = start | (l_other[lane] << 8) | (l_bone[lane] << 16) | (l_fwd[lane] << 24);
+            rs.slot_first = l_first[lane];
+        }
+        if (lane < K) { rs.off = l_off[lane]; rs.off1 = l_off[lane + 1]; }
+    }
+
+    double* anns = a.anns + (size_t)b * a.max_ann * K * 4;
+    const int64_t* ann_ids = a.ann_ids + (size_t)b * a.max_ann;
+    if (wave < n_growers && !failed) {
+        // pose n belongs to workgroup n % S, and there to wave (n / S) % n_growers
+        for (int n = part + S * wave; n < n_kept; n += S * n_growers) {
+            double* src = anns + (size_t)n * K * 4;
+            for (int k = lane; k < K; k += kWave) {
+                c.jv[k] = src[4 * k + 0]; c.jx[k] = (float)src[4 * k + 1];
+                c.jy[k] = (float)src[4 * k + 2]; c.js[k] = (float)src[4 * k + 3];
+            }
+            wave_sync();
+            grow_pose<REG, true>(c, p, rs, false, 4.0, true);    // :419-425, :235
+            for (int k = lane; k < K; k += kWave) {
+                src[4 * k + 0] = c.jv[k]; src[4 * k + 1] = (double)c.jx[k];
+                src[4 * k + 2] = (double)c.jy[k]; src[4 * k + 3] = (double)c.js[k];
+            }
+            wave_sync();
+        }
+    }
+    // the last workgroup of the image to get here sees every pose (agent-scope release / acquire around the counter)
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) sh_last[0] = (atomicAdd(&meta[3], 1) == S - 1) ? 1 : 0;
+    __syncthreads();
+    if (!sh_last[0]) return;
+    __threadfence();
+    nms_and_store<kThreads>(a, p, c, nl, b, failed ? 0 : n_kept, n_dropped, failed != 0, anns, ann_ids, nms_waves);
+}
+
+template <bool REG, int NW>
+static hipError_t launch_fc_nw(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
+    const int K = a.K, A = a.A, E = 2 * A;
+    const int KC = (K + kWave - 1) / kWave;
+    const size_t shared = sizeof(double) * a.max_ann + sizeof(unsigned long long) * ((size_t)a.max_ann * KC)
+                        + sizeof(int) * (5 * E + K + 1 + 2 * a.max_ann + 4) + 32;
+    const size_t priv = assoc_private_bytes(K, A);
+    const size_t budget = 160 * 1024;
+    if (shared + priv > budget) return hipErrorInvalidValue;
+    int growers = (int)((budget - shared) / priv);
+    if (growers > NW) growers = NW;
+    int nms_waves = NW;
+    while (nms_waves > 1 && shared + (size_t)nms_waves * nms_scratch_bytes(a.max_ann) > budget) nms_waves--;
+    const size_t nms = (size_t)nms_waves * nms_scratch_bytes(a.max_ann);
+    if (shared + nms > budget) return hipErrorInvalidValue;
+    const size_t grow_bytes = (size_t)growers * priv;
+    const size_t lds = shared + (grow_bytes > nms ? grow_bytes : nms);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)cifcaf_fc_kernel<REG, NW>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    // workgroups per image: enough to put every stored pose of a crowded image on a wave of its own, and the chip to work
+    int S = (a.max_ann + growers - 1) / growers;
+    const int fill = (256 + a.B - 1) / a.B;
+    if (S > fill) S = fill;
+    if (S < 1) S = 1;
+    if (const char* e = getenv("OPA_FC_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 64) S = v; }   // tests: other splits
+    cifcaf_fc_kernel<REG, NW><<<a.B * S, NW * kWave, lds, st>>>(a, sk, p, growers, nms_waves, S);
+    return hipGetLastError();
 }
 
 template <bool REG, int NW>
@@ -1866,16 +2234,24 @@ static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, con
     return hipGetLastError();
 }
 
-// waves per workgroup of the association kernel: 1 coordinator + up to NW-1 growers
+// waves per workgroup of the association kernel: 1 coordinator + up to NW-1 growers.  12 is what ships; the 8- and
+// 16-wave instantiations (OPA_ASSOC_WAVES, interleaving experiments of round 2) double the compile time of this file
+// and are built only with -DOPA_ASSOC_ALL_WAVES.
 static int assoc_waves() {
+#ifdef OPA_ASSOC_ALL_WAVES
     const char* e = getenv("OPA_ASSOC_WAVES");
     const int v = e ? atoi(e) : 0;
     return v == 8 || v == 12 || v == 16 ? v : kAssocWavesDefault;
+#else
+    return kAssocWavesDefault;
+#endif
 }
 
 hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
     AssocArgs a = args;
-    if (const char* e = getenv("OPA_ASSOC_BBOX")) { if (atoi(e) == 0) a.list_bbox = nullptr; }   // A/B: scan every chunk
+    if (const char* e = getenv("OPA_ASSOC_BBOX")) { if (atoi(e) == 0) a.list_bbox = a.list_bbox_fc = nullptr; }   // A/B: scan every chunk
+    a.watchdog_ticks = kWatchdogTicksDefault;
+    if (const char* e = getenv("OPA_ASSOC_WATCHDOG_TICKS")) { const long long v = atoll(e); if (v > 0) a.watchdog_ticks = v; }
     const int K = a.K, E = 2 * a.A;
     // the seed pool packs cell coordinates into 12 bits, the field into 8 and the seed index into 24
     if (a.occ_w > 4096 || a.occ_h > 4096 || a.F > 256 || a.seed_cap > 0xFFFFFF) return hipErrorInvalidValue;
@@ -1883,11 +2259,18 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     hipError_t e;
     if (!reg) e = launch_assoc_nw<false, 8>(a, sk, p, st);   // LDS-resident growth state: 160 KB hold ~5 growers
     else switch (assoc_waves()) {
+#ifdef OPA_ASSOC_ALL_WAVES
         case 8: e = launch_assoc_nw<true, 8>(a, sk, p, st); break;
-        case 12: e = launch_assoc_nw<true, 12>(a, sk, p, st); break;
-        default: e = launch_assoc_nw<true, 16>(a, sk, p, st); break;
+        case 16: e = launch_assoc_nw<true, 16>(a, sk, p, st); break;
+#endif
+        default: e = launch_assoc_nw<true, 12>(a, sk, p, st); break;
     }
     prof_mark(st, "cifcaf_assoc_kernel");
+    if (e == hipSuccess && p.force_complete) {
+        if (!a.fc_meta || !a.lists_fc) return hipErrorInvalidValue;
+        e = reg ? launch_fc_nw<true, 12>(a, sk, p, st) : launch_fc_nw<false, 8>(a, sk, p, st);
+        prof_mark(st, "cifcaf_fc_kernel");
+    }
     return e;
 }
 
@@ -1900,7 +2283,7 @@ __global__ __launch_bounds__(64) void blend_rows_kernel(const float* rows, int n
         for (int k = 0; k < 7; k++) soa[(size_t)k * n + i] = rows[(size_t)i * 7 + k];
     __threadfence_block();
     __shared__ float tgt[kBlendLdsFloats];
-    ListView L; L.base = soa; L.cap = n; L.n = n; L.bbox = nullptr;
+    ListView L; L.base = soa; L.cap = n; L.n = n; L.bbox = nullptr; L.gbbox = nullptr; L.nb = 0;
     const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, s, filter_sigmas, only_max, tgt);
     if (lane == 0) {
         if (r.ok) { out4[0] = (double)r.x; out4[1] = (double)r.y; out4[2] = (double)r.s; out4[3] = r.v; }

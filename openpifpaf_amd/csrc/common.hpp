@@ -28,10 +28,11 @@ struct Layout {
     int cif_cells;                        // F*H*W  (seed capacity)
     int caf_cells;                        // cH*cW  (list capacity per (field, direction))
     int sort_cap;                         // next pow2 >= cif_cells
+    int bbox_chunks;                      // 64-entry chunks of a CAF list that get a bounding box (all of them, up to kListBboxMax)
     // byte offsets into the workspace (all 256-B aligned)
     size_t off_hdr, off_tile_clean, off_cifhr, off_act, off_act_count, off_seed_keys, off_seed_count,
            off_seed_f, off_seed_vxys, off_seed_cell, off_lists, off_list_counts,
-           off_lists_fc, off_list_counts_fc, off_list_bbox, off_occ, off_anns, off_ann_meta, off_status, off_stats, off_trace,
+           off_lists_fc, off_list_counts_fc, off_list_bbox, off_list_bbox_fc, off_fc_meta, off_occ, off_anns, off_ann_meta, off_status, off_stats, off_trace,
            total;
     size_t occ_image_words;               // 32-bit words of one image's occupancy bitmap (capacity)
 };
@@ -87,13 +88,18 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
 hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
-                            float* lists, int32_t* counts, hipStream_t st, float* chunk_bbox = nullptr);
+                            float* lists, int32_t* counts, hipStream_t st, float* chunk_bbox = nullptr,
+                            int bbox_chunks = 0, int bbox_stride = 0);
 
-// The first kListBboxChunks 64-entry chunks of every CAF list get a bounding box of their (x1, y1) columns
-// (xmin, xmax, ymin, ymax; an empty chunk: +inf, -inf, +inf, -inf), written by cafscored behind the list:
+// 64-entry chunks of the CAF lists get a bounding box of their (x1, y1) columns (xmin, xmax, ymin, ymax; an empty
+// chunk: +inf, -inf, +inf, -inf), written by cafscored next to the list ([list][bbox_chunks][4] floats):
 // grow_connection_blend's window test (cifcaf.cpp:54-57) cannot pass for any entry of a chunk whose box misses
-// the window, so the association kernel only loads the chunks that can matter.
+// the window, so the association kernels only load the chunks that can matter.  caf_th set: the first
+// kListBboxChunks chunks of a list (crowded images have 3-4), kept in LDS by the seed kernel.  Force-complete set (caf_th
+// 0.001 keeps most cells of a field: ~100 chunks): every chunk, tested where cafscored wrote them (L2).  Lists of
+// more than kListBboxMax chunks (fields of more than 16 320 cells) are scanned without boxes.
 constexpr int kListBboxChunks = 16;
+constexpr int kListBboxMax = 255;
 
 // zero-fill on the stream with a kernel of this library (the runtime's memset / small-copy nodes are the
 // one thing that faulted when the decode was replayed as a captured HIP graph); bytes % 4 == 0
@@ -108,7 +114,11 @@ struct AssocArgs {
     const int32_t* seed_cell;  // occupancy cell of the seed: x | y << 12 | box half-width << 24 (seed_cell_pack)
     const float* lists; const int32_t* list_counts;          // caf_th lists
     const float* lists_fc; const int32_t* list_counts_fc;    // force-complete lists (or null)
-    const float* list_bbox;  // [B][A][2][kListBboxChunks][4] chunk boxes of `lists` (or null)
+    const float* list_bbox;  // [B][A][2][bbox_chunks][4] chunk boxes of `lists` (or null)
+    const float* list_bbox_fc;  // ... of `lists_fc` (or null)
+    int bbox_chunks;
+    int32_t* fc_meta;           // [B, 4] seed kernel -> force-complete kernel: poses stored, dropped, failed, workgroup counter
+    long long watchdog_ticks;   // 10-ns ticks after which every wait inside one launch gives up (status -1)
     unsigned* occ;           // occupancy bitmap [B][occ_image_words]: per image [F][occ_h][(occ_w+31)/32] words, zeroed by the kernel
     size_t occ_image_words;
     int32_t* stats;          // [B, 16] statistics of the association (or null), see include/openpifpaf_amd.h

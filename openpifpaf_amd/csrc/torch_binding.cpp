@@ -130,6 +130,8 @@ struct CifCaf : torch::CustomClassHolder {
         if (initial_ids.has_value()) ii = initial_ids->unsqueeze(0);
         auto [out, ids, counts] = call_batch_impl(cif.unsqueeze(0), cif_stride, caf.unsqueeze(0), caf_stride, ia, ii);
         const int64_t c = counts.cpu().item<int32_t>();
+        TORCH_CHECK(!(c & OPA_COUNT_FAILED), "the association kernel gave up on the image (watchdog, status -1): "
+                    "the decode is invalid");
         TORCH_CHECK(!(c & OPA_COUNT_OVERFLOW), "annotation capacity overflow: poses were dropped; call "
                     "set_max_annotations with a larger value");
         const int64_t n = OPA_COUNT_ROWS(c);

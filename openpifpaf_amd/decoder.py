@@ -246,6 +246,7 @@ class CifCaf(Decoder):
             from .annotation import inverse_transform_batch
             out = inverse_transform_batch(out, meta_batch)
         out, ids, counts = out.cpu().numpy(), ids.cpu().numpy(), counts.cpu().numpy()   # one small D2H
+        native.check_counts(counts)                 # a watchdog failure raises instead of decoding to "no poses"
         result = []
         for b in range(len(counts)):
             n = int(counts[b]) & native.COUNT_ROWS_MASK           # valid rows

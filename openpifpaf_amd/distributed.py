@@ -65,6 +65,6 @@ def unpack(annotations, ids, counts, max_annotations=None):
     cap = annotations.shape[1] if max_annotations is None else max_annotations
     out = []
     for b in range(len(counts)):
-        n = min(int(counts[b]) & 0x3FFFFFFF, cap)           # OPA_COUNT_ROWS: the valid rows
+        n = min(int(counts[b]) & 0x0FFFFFFF, cap)           # OPA_COUNT_ROWS: the valid rows
         out.append((annotations[b, :n], ids[b, :n]))
     return out

@@ -26,7 +26,8 @@ from . import _lib
 
 DEFAULT_MAX_ANNOTATIONS = 128
 COUNT_OVERFLOW = 0x40000000          # OPA_COUNT_OVERFLOW (include/openpifpaf_amd.h)
-COUNT_ROWS_MASK = 0x3FFFFFFF         # OPA_COUNT_ROWS
+COUNT_FAILED = 0x20000000            # OPA_COUNT_FAILED: the association kernel's watchdog gave up on the image
+COUNT_ROWS_MASK = 0x0FFFFFFF         # OPA_COUNT_ROWS
 
 
 def count_rows(counts):
@@ -37,6 +38,23 @@ def count_rows(counts):
 def count_overflowed(counts):
     """-> truthy where poses were dropped for lack of annotation capacity."""
     return (counts & COUNT_OVERFLOW) != 0
+
+
+def count_failed(counts):
+    """-> truthy where the association kernel gave up on the image (``OPA_COUNT_FAILED``)."""
+    return (counts & COUNT_FAILED) != 0
+
+
+def check_counts(counts):
+    """``counts`` ON THE HOST (numpy array, CPU tensor or int; they travel with the result's one D2H copy): raise
+    when the association kernel's watchdog fired for an image -- such an image reports no poses, and handing that
+    on as "nobody in the picture" would be a silent wrong answer."""
+    import numpy as np
+    c = np.asarray(counts.cpu() if hasattr(counts, 'cpu') else counts).reshape(-1)
+    bad = np.nonzero(c & COUNT_FAILED)[0]
+    if len(bad):
+        raise _lib.NativeError('openpifpaf_amd: the association kernel gave up on image(s) %s of the batch (its '
+                               'watchdog fired, status -1); the decode of these images is invalid' % bad.tolist())
 
 
 def set_quiet(quiet=True):
@@ -213,9 +231,11 @@ class CifCaf:
         out, ids, counts = self.call_batch(cif_field.unsqueeze(0), cif_stride, caf_field.unsqueeze(0),
                                            caf_stride, ia, ii)
         n = int(counts[0])
+        check_counts(n)
         if n & COUNT_OVERFLOW:
             raise _lib.NativeError('annotation capacity overflow: %d poses dropped; construct CifCaf with a '
                                    'larger max_annotations' % int(self.workspace_view('status', torch.int32)[0]))
+        n &= COUNT_ROWS_MASK
         return out[0, :n].clone(), ids[0, :n].clone()
 
     def call(self, cif_field, cif_stride, caf_field, caf_stride):

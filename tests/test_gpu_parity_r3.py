@@ -1,0 +1,191 @@
+"""Round-3 parity cases: chunk boxes of every chunk of both CAF list sets (the force-complete scans read them),
+the reference benchmark's setting (force complete + zero thresholds) on whole batches, the bench batch itself on
+every image, and the watchdog's failure flag on every host path."""
+import os
+
+import numpy as np
+import pytest
+
+from common import compare_annotations
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+FC_KW = dict(force_complete=1, keypoint_threshold=0.0, keypoint_threshold_rel=0.0,
+             nms_instance_threshold=0.0, nms_keypoint_threshold=0.0)       # reference decoder/cifcaf.py:180-185
+
+
+@pytest.fixture(scope='module')
+def native():
+    from openpifpaf_amd import native as n
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    return n
+
+
+@pytest.fixture(scope='module')
+def port():
+    from oracle import port as p
+    return p
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _decode(native, skeleton0, cifs, cafs, params=None, **kw):
+    dec = native.CifCaf(cifs.shape[1], torch.from_numpy(skeleton0), **kw)
+    out, ids, counts = dec.call_batch(dev(cifs), 8, dev(cafs), 8, params=params)
+    out, counts = out.cpu().numpy(), counts.cpu().numpy()
+    native.check_counts(counts)
+    assert not native.count_overflowed(counts).any()
+    return [out[b, :native.count_rows(int(counts[b]))] for b in range(len(counts))], dec
+
+
+def _check_boxes(dec, what_boxes, what_lists, what_counts, B, A, HW, n_boxed=None):
+    nb = (HW + 63) // 64
+    counts = dec.workspace_view(what_counts, torch.int32)[:B * A * 2].view(B, A, 2).cpu().numpy()
+    lists = dec.workspace_view(what_lists, torch.float32)[:B * A * 2 * 7 * HW].view(B, A, 2, 7, HW).cpu().numpy()
+    boxes = dec.workspace_view(what_boxes, torch.float32)[:B * A * 2 * nb * 4].view(B, A, 2, nb, 4).cpu().numpy()
+    checked = 0
+    for b in range(B):
+        for a in range(A):
+            for d in range(2):
+                n = int(counts[b, a, d])
+                x1 = np.full(nb * 64, np.nan, dtype=np.float32)
+                y1 = x1.copy()
+                x1[:n], y1[:n] = lists[b, a, d, 1, :n], lists[b, a, d, 2, :n]
+                x1, y1 = x1.reshape(nb, 64), y1.reshape(nb, 64)
+                full = np.arange(nb) * 64 < n
+                with np.errstate(all='ignore'):
+                    want = np.stack([np.nanmin(x1, 1), np.nanmax(x1, 1), np.nanmin(y1, 1), np.nanmax(y1, 1)], 1)
+                got = boxes[b, a, d]
+                if n_boxed is not None:                 # only the first n_boxed chunks of a list carry a box
+                    got, want, full = got[:n_boxed], want[:n_boxed], full[:n_boxed]
+                assert np.array_equal(got[full], want[full]), (what_boxes, b, a, d)
+                assert (got[~full, 0] > got[~full, 1]).all() and (got[~full, 2] > got[~full, 3]).all(), 'empty chunk with a box'
+                checked += int(full.sum())
+    return counts, checked
+
+
+def test_chunk_boxes_of_both_list_sets_and_force_complete_scans(native, port, coco_skeleton0, monkeypatch):
+    """cafscored leaves the (x1, y1) bounding box of EVERY 64-entry chunk of every list of the force-complete set
+    (and of the first 16 chunks of the caf_th set) in the workspace; the force-complete kernel (cifcaf.cpp:414-427:
+    lists at caf_th 0.001 hold most cells of a field, ~100 chunks) loads only the chunks whose box meets the query
+    window.  The boxes must be exact, the decode must equal the oracle's, it must be bit-identical with the boxes
+    switched off, and with the stored poses split over 1, 3 or the default number of workgroups per image."""
+    import warnings
+    from openpifpaf_amd import _lib, synth
+    cases = [(71_001, 20), (71_002, 9), (71_003, 3), (71_004, 14)]
+    fields = [synth.synth_fields(seed, people, height=81, width=81) for seed, people in cases]
+    cifs, cafs = np.stack([f[0] for f in fields]), np.stack([f[1] for f in fields])
+    B, A, HW = len(cases), cafs.shape[1], 81 * 81
+    for kw in (FC_KW, dict(force_complete=1)):
+        got, dec = _decode(native, coco_skeleton0, cifs, cafs, params=_lib.default_params(**kw))
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            _, n1 = _check_boxes(dec, 'list_bbox', 'lists', 'list_counts', B, A, HW, n_boxed=16)
+            counts_fc, n2 = _check_boxes(dec, 'list_bbox_fc', 'lists_fc', 'list_counts_fc', B, A, HW)
+        assert counts_fc.max() > 16 * 64, 'force-complete lists should span far more than the 16 LDS-resident boxes'
+        assert n2 > 20 * n1 > 0
+        for b, (seed, people) in enumerate(cases):
+            want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0, params=port.default_params(**kw))
+            ok, msg = compare_annotations(got[b], want)
+            assert ok, 'seed %d %s: %s' % (seed, sorted(kw), msg)
+        for env, value in (('OPA_ASSOC_BBOX', '0'), ('OPA_FC_SPLIT', '1'), ('OPA_FC_SPLIT', '3')):
+            monkeypatch.setenv(env, value)
+            plain, _ = _decode(native, coco_skeleton0, cifs, cafs, params=_lib.default_params(**kw))
+            monkeypatch.delenv(env)
+            for b in range(B):
+                assert plain[b].shape == got[b].shape and np.array_equal(plain[b], got[b]), \
+                    'image %d changes with %s=%s (%s)' % (b, env, value, sorted(kw))
+
+
+def test_long_default_lists(native, port, coco_skeleton0, monkeypatch):
+    """Lists of more than 16 chunks in the DEFAULT set (here: a CAF threshold of 0.002, which the synthetic
+    background passes) are past the boxes the seed kernel keeps: they take its streamed two-pass scan.  Against the
+    oracle, and bit-identical with the boxes off."""
+    from openpifpaf_amd import _lib, synth
+    cases = [(72_001, 12), (72_002, 25)]
+    fields = [synth.synth_fields(seed, people, height=81, width=81) for seed, people in cases]
+    cifs, cafs = np.stack([f[0] for f in fields]), np.stack([f[1] for f in fields])
+    kw = dict(caf_threshold=0.002)
+    got, dec = _decode(native, coco_skeleton0, cifs, cafs, params=_lib.default_params(**kw))
+    counts = dec.workspace_view('list_counts', torch.int32)[:2 * 19 * 2].cpu().numpy()
+    assert counts.max() > 16 * 64, counts.max()
+    for b in range(len(cases)):
+        want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0, params=port.default_params(**kw))
+        ok, msg = compare_annotations(got[b], want)
+        assert ok, msg
+    monkeypatch.setenv('OPA_ASSOC_BBOX', '0')
+    plain, _ = _decode(native, coco_skeleton0, cifs, cafs, params=_lib.default_params(**kw))
+    for b in range(len(cases)):
+        assert np.array_equal(plain[b], got[b])
+
+
+@pytest.mark.parametrize('seed0', [0, 1000])
+def test_bench_batches_every_image_equals_the_oracle(native, port, coco_skeleton0, seed0):
+    """bench.py alternates ``synth_batch(32, seed0=0)`` and ``synth_batch(32, seed0=1000)``: every image of both against
+    the oracle, default flags and the reference benchmark's force-complete setting (benchmark.py:77-79)."""
+    from openpifpaf_amd import _lib, synth
+    cifs, cafs = synth.synth_batch(32, seed0=seed0)
+    for kw in (None, FC_KW):
+        got, _ = _decode(native, coco_skeleton0, cifs, cafs, params=_lib.default_params(**kw) if kw else None)
+        n = 0
+        for b in range(32):
+            want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0, params=port.default_params(**kw) if kw else None)
+            ok, msg = compare_annotations(got[b], want)
+            assert ok, 'seed0 %d image %d %s: %s' % (seed0, b, 'fc' if kw else 'default', msg)
+            n += len(want)
+        assert n > 200
+
+
+def test_wholebody_force_complete_batch(native, port):
+    """BASELINE configs[3] shapes with the reference benchmark's setting: 133 keypoints / 160 bones, the
+    force-complete growth over lists of ~5 000 entries (LDS-resident growth state, boxes read from global memory)."""
+    from openpifpaf_amd import _lib, constants, synth
+    wb = constants.wholebody()
+    skel0 = np.asarray(wb['skeleton'], dtype=np.int64) - 1
+    cifs, cafs = synth.synth_batch(4, seed0=40, people=(1, 3, 6, 2), pose=wb['standing_pose'], skeleton=wb['skeleton'])
+    got, _ = _decode(native, skel0, cifs, cafs, params=_lib.default_params(**FC_KW))
+    for b in range(4):
+        want, _ = port.decode(cifs[b], 8, cafs[b], 8, skel0, params=port.default_params(**FC_KW))
+        ok, msg = compare_annotations(got[b], want)
+        assert ok, 'image %d: %s' % (b, msg)
+        assert len(want) and (want[..., 0] > 0).all(), 'force complete fills every joint'
+
+
+def test_watchdog_failure_is_flagged_and_raises_on_every_host_path(native, coco_skeleton0, monkeypatch):
+    """VERDICT r2 "weak" 13: when the association kernel's watchdog fires the image reports status -1 and zero poses.
+    That must not pass for "nobody in the picture": the failure travels with the counts (OPA_COUNT_FAILED) and
+    every host entry point that brings the counts to the host raises.  The watchdog is shortened to one tick
+    (OPA_ASSOC_WATCHDOG_TICKS) so that the coordinator gives up in its first iteration."""
+    from openpifpaf_amd import _lib, decoder, headmeta, synth
+    cif, caf = synth.synth_fields(3, 4, height=41, width=41)
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    out, ids, counts = dec.call_batch(dev(cif)[None], 8, dev(caf)[None], 8)
+    assert native.count_rows(int(counts[0])) == 4 and not native.count_failed(counts).any()
+    monkeypatch.setenv('OPA_ASSOC_WATCHDOG_TICKS', '1')
+    out, ids, counts = dec.call_batch(dev(cif)[None], 8, dev(caf)[None], 8)
+    c = int(counts[0])
+    assert c & native.COUNT_FAILED and native.count_rows(c) == 0
+    assert int(dec.workspace_view('status', torch.int32)[0]) == -1
+    with pytest.raises(_lib.NativeError, match='watchdog'):
+        native.check_counts(counts)
+    with pytest.raises(_lib.NativeError, match='watchdog'):
+        dec.call(dev(cif), 8, dev(caf), 8)
+    cif_meta, caf_meta = headmeta.cocokp_metas()
+    host = decoder.CifCaf([cif_meta], [caf_meta])
+    with pytest.raises(_lib.NativeError, match='watchdog'):
+        host([dev(cif), dev(caf)])
+    with pytest.raises(_lib.NativeError, match='watchdog'):
+        host.batch(lambda x: (dev(cif)[None], dev(caf)[None]), torch.zeros((1, 3, 8, 8)))
+    from openpifpaf_amd import torchscript
+    torchscript.load()
+    ts = torch.classes.openpifpaf_amd_decoder.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    with pytest.raises(RuntimeError, match='watchdog'):
+        ts.call(dev(cif), 8, dev(caf), 8)
+    monkeypatch.delenv('OPA_ASSOC_WATCHDOG_TICKS')
+    out, ids, counts = dec.call_batch(dev(cif)[None], 8, dev(caf)[None], 8)      # and the decoder is fine afterwards
+    assert native.count_rows(int(counts[0])) == 4 and not native.count_failed(counts).any()
+    assert len(ts.call(dev(cif), 8, dev(caf), 8)[0]) == 4
