@@ -9,8 +9,9 @@ A step = one pass of the inference path over one batch resident in HBM:
      synthetic image batch -- the real network work;
   2. the HIP CifCaf decode (CifHr -> CifSeeds -> CafScored -> association -> NMS) of COCO-shaped
      synthetic field tensors of exactly the heads' output shapes.  A randomly initialised head emits
-     structureless fields, so decode inputs are injected after the heads.  They are
-     resident in HBM before the timed region; nothing is skipped or cached;
+     structureless fields, so decode inputs are injected after the heads.  TWO different field
+     batches alternate step by step (the lazy tile clear and the caches see changing input); both are resident
+     in HBM before the timed region; nothing is skipped or cached;
   3. final annotations: device -> pinned host copy; with N > 1 ONE RCCL all_gather of the packed
      annotation blocks over xGMI (images shard one batch per GPU, no other collective).
 The decode runs on a second HIP stream so that batch i's decode overlaps batch i+1's backbone.
@@ -21,17 +22,26 @@ the metric is quoted on): 2 resnet50 COCO-17, 3 shufflenetv2k16 COCO-17, 4 shuff
 
 LIKE FOR LIKE.  The reference runs its network in float32 (``predictor.py:33-41``), so ``value`` is the
 end-to-end rate with a FLOAT32 backbone; the bfloat16-backbone rate is reported beside it
-(``bf16_backbone``).  ``vs_baseline`` divides ``value`` by the reference's own data flow measured in the
-same run with the same backbone precision: backbone on the MI355X -> ``.cpu()`` of the head fields
-(``decoder/decoder.py:96-100``) -> the reference's C++ CifCaf decoder (oracle/_ref) on one host thread,
-one decoder instance reused across images like ``decoder/cifcaf.py:119`` does.  The all-host-cores
-variant (``--decoder-workers``, a fork pool) is in ``reference_pipeline`` too.
+(``bf16_backbone``; its decode inputs are the same fields rounded to bfloat16, what a bf16 head emits, and its
+parity stamp carries the seed-tie mismatch rate against the real reference).  ``vs_baseline`` divides ``value``
+by the reference's own data flow RUN in the same process at the same backbone precision: backbone on the
+MI355X -> ``.cpu()`` of the head fields (``decoder/decoder.py:96-100``) -> the reference's C++ CifCaf decoder
+(oracle/_ref) on one host thread, one decoder instance reused across images like ``decoder/cifcaf.py:119``.
+
+The default single-GPU run (no ``--config``) also carries, under ``"configs"``, short legs of the other BASELINE
+configurations and settings, each with its own roofline / cpu_baseline / parity: ``config3`` (shufflenetv2k16
+batch 32), ``config4`` (shufflenetv2k30 wholebody batch 16), ``force_complete`` (the reference benchmark CLI's
+decoder setting, ``benchmark.py:77-79``), ``batch1`` (the literal configs[1]: resnet50 641x641 batch 1 latency,
+eager and as one HIP graph, the reference flow at batch 1 beside it) and ``decode_two_in_flight``.
 
 Besides the contract fields the line carries
   "roofline":     HBM roofline of the decode kernel that dominates the decode time: SURVEY 8d bytes per
-                  launch / its HIP-event time, with the kernel's own compulsory bytes beside it;
+                  launch / its HIP-event time, the kernel's own compulsory bytes beside it, and ``traffic`` =
+                  PMC HBM bytes of the whole decode path per launch (profiles/r3/pmc_traffic.json, hash-stamped);
   "cpu_baseline": the reference CPU decoder timed on this box's host cores on a bounded sample of the
-                  same fields (reused instance, fresh instance, all cores).
+                  same fields (reused instance, fresh instance, all cores);
+  "parity":       what the timed decode produces, compared image by image with the reference decoder OUTSIDE
+                  the timed region.
 """
 import argparse
 import hashlib
@@ -53,12 +63,17 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}     # dense matrix peaks, MI355X_MICROARCH.md
+TORCH_DTYPE = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}
+VARIANT_SEED = 100_000   # field batch v of rank r is synth_batch(B, seed0 = v * VARIANT_SEED + r * B)
+TOL = 1e-4               # BASELINE.json north_star: keypoint coordinates / scores within 1e-4
 
 CONFIGS = {
     2: dict(name='configs[1] scaled to a batch', backbone='resnet50', batch=32, wholebody=False),
     3: dict(name='configs[2]', backbone='shufflenetv2k16', batch=32, wholebody=False),
     4: dict(name='configs[3]', backbone='shufflenetv2k30', batch=16, wholebody=True),
 }
+FC_KW = dict(force_complete=1, keypoint_threshold=0.0, keypoint_threshold_rel=0.0,
+             nms_instance_threshold=0.0, nms_keypoint_threshold=0.0)     # reference decoder/cifcaf.py:180-185
 
 
 def parse_args():
@@ -66,28 +81,33 @@ def parse_args():
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=20)
     p.add_argument('--warmup', type=int, default=3)
-    p.add_argument('--config', type=int, default=2, choices=sorted(CONFIGS))
+    p.add_argument('--config', type=int, default=None, choices=sorted(CONFIGS),
+                   help='one BASELINE configuration only (default: 2 as the headline plus short legs of the others)')
     p.add_argument('--batch', type=int, default=None, help='images per GPU per step (default: the config\'s)')
     p.add_argument('--backbone', default=None, help='override the config\'s backbone')
     p.add_argument('--backbone-dtype', default='fp32', choices=('bf16', 'fp16', 'fp32'),
                    help='precision of the HEADLINE leg (fp32 = the reference\'s)')
     p.add_argument('--no-bf16-leg', action='store_true', help='skip the second, bfloat16-backbone leg')
+    p.add_argument('--no-extras', action='store_true', help='skip the short legs of the other configurations')
+    p.add_argument('--extra-steps', type=int, default=5)
     p.add_argument('--long-edge', type=int, default=641)
     p.add_argument('--no-overlap', action='store_true', help='decode on the backbone stream')
     p.add_argument('--cpu-seconds', type=float, default=12.0, help='CPU baseline budget (rank 0, N=1)')
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-parity', action='store_true', help='skip the parity stamp (it runs outside the timed region)')
     p.add_argument('--decode-only', action='store_true', help='skip the backbone (kernel work only; diagnostic)')
     p.add_argument('--graph', action='store_true',
-                   help='decode-only: replay each decoder\'s call as a captured HIP graph')
+                   help='decode-only: replay each decoder\'s call as a captured HIP graph (one field batch)')
     p.add_argument('--decode-streams', type=int, default=1,
                    help='decode-only: round-robin the batches over this many decoders, each with its own '
                         'stream and workspace')
-    p.add_argument('--profile-steps', type=int, default=5)
+    p.add_argument('--profile-steps', type=int, default=6)
     p.add_argument('--force-complete', action='store_true',
                    help='decode like the reference\'s benchmark CLI (--force-complete-pose, thresholds 0)')
     p.add_argument('--fields', default='synthetic', choices=('synthetic', 'network'),
                    help='decode COCO-shaped synthetic fields injected after the heads (default), or the '
                         'random-init network\'s own all-active head outputs (adversarial case, reported separately)')
+    p.add_argument('--single-batch', action='store_true', help='do not alternate field batches (round-2 behaviour)')
     p.add_argument('--dist-backend', default='nccl', choices=('nccl', 'gloo'),
                    help='nccl = RCCL over xGMI (default); gloo only to exercise the N>1 control flow on one GPU')
     p.add_argument('--share-device', action='store_true', help='testing: every rank uses cuda:0')
@@ -103,17 +123,18 @@ def algorithmic_bytes(B, F, A, H, W, stride, max_ann, K=None):
     rows, cols = (H - 1) * stride + 1, (W - 1) * stride + 1
     return {
         'cif_active_kernel': B * F * 4 * hw * 4,                 # reads conf,x,y,scale planes
-        'cifhr_tile_kernel': B * F * rows * cols * 4,            # whole map; replaced below by the tiles actually written
+        'cifhr_tile_kernel': B * F * rows * cols * 4,            # whole map; replaced by the tiles actually written
         'cifseeds_fill_kernel': B * F * hw * 4,                  # reads the confidence plane
         'cifseeds_sort_kernel': 0,
         'cafscored_kernel': B * A * 7 * hw * 4,                  # reads the 7 used component planes
         'cifcaf_assoc_kernel': B * max_ann * K * 4 * 4,          # writes the annotations (lists are data dependent)
+        'cifcaf_fc_kernel': B * max_ann * K * 4 * 4,
         'decode_path': B * (F * 5 * hw * 4 + A * 8 * hw * 4 + max_ann * K * 4 * 4),
     }
 
 
 def kernel_source_hash():
-    """Identifies the kernels a PMC traffic file was measured on (profiles/r2/pmc_traffic.json)."""
+    """Identifies the kernels a PMC traffic file was measured on (profiles/r3/pmc_traffic.json)."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, 'openpifpaf_amd', 'csrc')
     for name in sorted(os.listdir(csrc)):
@@ -122,9 +143,27 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def pmc_traffic(config_id, B, force_complete=False):
+    """PMC HBM bytes of the WHOLE decode path per launch (rocprofv3 passes cannot run inside bench.py;
+    tools/collect_profiles.sh writes them, stamped with the hash of the kernel sources they were measured on)."""
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r3', 'pmc_traffic.json')))
+    except (OSError, ValueError):
+        return None, 'no PMC file (run tools/collect_profiles.sh)'
+    if pmc.get('kernel_source_hash') != kernel_source_hash():
+        return None, 'profiles/r3/pmc_traffic.json was measured on other kernel sources'
+    key = 'config%d%s_batch%d' % (config_id, '_fc' if force_complete else '', B)
+    entry = pmc.get('workloads', {}).get(key)
+    if not entry:
+        return None, 'profiles/r3/pmc_traffic.json holds no entry %s' % key
+    return entry, 'profiles/r3/pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 read ' \
+                  'correction; sum over the decode kernels of one launch)' % key
+
+
+# ----------------------------------------------------------------------------------------------- CPU side
 def reference_decoder(skeleton0, n_keypoints, fc_kw=None):
-    """-> (kind, make_decode) where make_decode(reuse) returns decode(cif, caf) on the host: the reference's own
-    C++ decoder (oracle/_ref) when it is present, the restatement otherwise."""
+    """-> (kind, make_decode, torch) where make_decode(reuse) returns decode(cif, caf) on the host: the reference's
+    own C++ decoder (oracle/_ref) when it is present, the restatement otherwise."""
     from oracle import reference
     if not reference.available():
         from oracle import port
@@ -148,6 +187,12 @@ def reference_decoder(skeleton0, n_keypoints, fc_kw=None):
     return 'reference', make, torch_
 
 
+def reset_reference():
+    from oracle import reference
+    if reference.available():
+        reference.reset_statics()
+
+
 def time_loop(decode, cifs, cafs, seconds, min_items):
     n = len(cifs)
     decode(cifs[0], cafs[0])                       # warm-up
@@ -167,7 +212,7 @@ def cpu_baseline(cifs, cafs, skeleton0, n_keypoints, seconds, fc_kw=None):
     instance per image, and a fork pool on all cores."""
     kind, make, torch_ = reference_decoder(skeleton0, n_keypoints, fc_kw)
     n = len(cifs)
-    reused, n_reused = time_loop(make(True), cifs, cafs, seconds * 0.3, n)
+    reused, n_reused = time_loop(make(True), cifs, cafs, seconds * 0.3, min(n, 16))
     fresh, n_fresh = time_loop(make(False), cifs, cafs, seconds * 0.3, min(n, 8))
 
     # all host cores: the reference's --decoder-workers mechanism is a fork pool
@@ -177,7 +222,7 @@ def cpu_baseline(cifs, cafs, skeleton0, n_keypoints, seconds, fc_kw=None):
     try:
         import multiprocessing as mp
         ctx = mp.get_context('fork')
-        budget = max(3.0, 0.4 * seconds)
+        budget = max(2.5, 0.4 * seconds)
         decode = make(True)
 
         def work(i, q, t_end):
@@ -201,14 +246,173 @@ def cpu_baseline(cifs, cafs, skeleton0, n_keypoints, seconds, fc_kw=None):
     except Exception as e:   # pragma: no cover
         multi = None
         print('cpu_baseline: multi-process leg failed: %r' % (e,), file=sys.stderr)
+    if fc_kw:
+        reset_reference()
     return {
         'value': round(reused, 2), 'unit': 'images/s (decode only, 1 thread, decoder instance reused)', 'cores': 1,
         'kind': kind, 'fresh_instance_value': round(fresh, 2),
         'all_cores_value': round(multi, 2) if multi else None, 'all_cores': cores,
-        'sample': '%d decodes of the rank-0 batch fields with one reused decoder instance (what the reference\'s '
+        'sample': '%d decodes of the rank-0 field batch with one reused decoder instance (what the reference\'s '
                   'Decoder does), %d with a fresh instance per image (the parity definition: revision drift), '
                   'then %d forked single-thread workers for a fixed time budget' % (n_reused, n_fresh, cores),
     }
+
+
+def parity_stamp(decode_device, variants, skeleton0, n_keypoints, fc_kw=None, max_images=None):
+    """Decode every field batch once more OUTSIDE the timed region and compare every image with the reference
+    decoder (fresh instance per image = the parity definition).  -> dict for the JSON line."""
+    from openpifpaf_amd import native
+    kind, make, _ = reference_decoder(skeleton0, n_keypoints, fc_kw)
+    decode_ref = make(False)
+    images = mismatches = poses = differing = 0
+    worst = 0.0
+    t0 = time.perf_counter()
+    for cifs_np, cafs_np, cif_d, caf_d in variants:
+        out, ids, counts = decode_device(cif_d, caf_d)
+        out, counts = out.cpu().numpy(), counts.cpu().numpy()
+        native.check_counts(counts)
+        n_img = len(counts) if max_images is None else min(len(counts), max_images)
+        for b in range(n_img):
+            want = decode_ref(cifs_np[b], cafs_np[b])
+            want = np.asarray(want[0].numpy() if hasattr(want[0], 'numpy') else want[0])
+            got = out[b, :int(counts[b]) & native.COUNT_ROWS_MASK]
+            images += 1
+            poses += len(want)
+            if got.shape != want.shape or not np.array_equal(got[..., 0] > 0, want[..., 0] > 0):
+                mismatches += 1
+                differing += 1
+                continue
+            d = float(np.abs(got.astype(np.float64) - want).max()) if got.size else 0.0
+            worst = max(worst, d)
+            differing += d > TOL
+    if fc_kw:
+        reset_reference()
+    return {'images': images, 'poses': poses, 'max_abs_delta': worst, 'discrete_mismatches': mismatches,
+            'images_beyond_tolerance': int(differing), 'tolerance': TOL, 'against': kind,
+            'field_batches': len(variants), 'seconds': round(time.perf_counter() - t0, 2)}
+
+
+# ----------------------------------------------------------------------------------------------- the workload
+class Workload:
+    """Field batches, decoder and host buffers of one BASELINE configuration on this rank."""
+
+    def __init__(self, config_id, B, rank, device, long_edge, n_variants, backbone=None, max_annotations=None):
+        from openpifpaf_amd import constants, headmeta, native, synth
+        cfg = CONFIGS[config_id]
+        self.config_id, self.cfg, self.B, self.device = config_id, cfg, B, device
+        self.backbone = backbone or cfg['backbone']
+        if cfg['wholebody']:
+            wb = constants.wholebody()
+            self.cif_meta, self.caf_meta = headmeta.wholebody_metas()
+            skeleton1, pose, self.people = wb['skeleton'], wb['standing_pose'], (1, 3, 6, 10)
+        else:
+            self.cif_meta, self.caf_meta = headmeta.cocokp_metas()
+            skeleton1, pose, self.people = constants.COCO_PERSON_SKELETON, None, synth.PEOPLE_CYCLE
+        self.skeleton0 = np.asarray(skeleton1, dtype=np.int64) - 1
+        self.K, self.A = self.cif_meta.n_fields, self.caf_meta.n_fields
+        self.stride = self.cif_meta.stride
+        self.long_edge = long_edge
+        self.fh = (long_edge - 1) // 16 * 2 + 1            # 641 -> 41 -> 82 -> 81
+        self.variants = []
+        for v in range(n_variants):
+            cifs, cafs = synth.synth_batch(B, seed0=v * VARIANT_SEED + rank * B, height=self.fh, width=self.fh,
+                                           people=self.people, pose=pose,
+                                           skeleton=skeleton1 if cfg['wholebody'] else None)
+            self.variants.append((cifs, cafs, torch.from_numpy(cifs).to(device), torch.from_numpy(cafs).to(device)))
+        self._quantised = None
+        kw = {} if max_annotations is None else {'max_annotations': max_annotations}
+        self.dec = native.CifCaf(self.K, torch.from_numpy(self.skeleton0), **kw)
+        self.host_out = torch.empty((B, self.dec.max_annotations, self.K, 4), dtype=torch.float32).pin_memory()
+        self.host_counts = torch.empty((B,), dtype=torch.int32).pin_memory()
+
+    def quantised(self):
+        """The field batches rounded to bfloat16 (nearest even) and held as float32: what a bf16 head emits."""
+        if self._quantised is None:
+            self._quantised = []
+            for cifs, cafs, cif_d, caf_d in self.variants:
+                cq, fq = cif_d.to(torch.bfloat16).to(torch.float32), caf_d.to(torch.bfloat16).to(torch.float32)
+                self._quantised.append((cq.cpu().numpy(), fq.cpu().numpy(), cq, fq))
+        return self._quantised
+
+    def workload_text(self):
+        return ('BASELINE %s: %s %dx%d, batch %d per GPU, CIF/CAF fields [%d,%d,5,%d,%d]+[%d,%d,8,%d,%d]'
+                % (self.cfg['name'], self.backbone, self.long_edge, self.long_edge, self.B, self.B, self.K, self.fh,
+                   self.fh, self.B, self.A, self.fh, self.fh))
+
+
+def build_model(wl, dtype_name):
+    from openpifpaf_amd import network
+    model = network.factory(wl.backbone, [wl.cif_meta, wl.caf_meta]).to(wl.device)
+    network.optimize_for_inference_(model)
+    model = model.to(memory_format=torch.channels_last)
+    if dtype_name != 'fp32':
+        model = model.to(TORCH_DTYPE[dtype_name])
+    return model
+
+
+def kernel_profile(wl, variants, params, steps):
+    """Per-kernel HIP-event times of the decode (events recorded by the library on the stream the kernels are launched
+    on), averaged over `steps` launches that alternate the field batches."""
+    from openpifpaf_amd import _lib, native
+    per_kernel = {}
+    for i in range(max(2, steps)):
+        _, _, cif_d, caf_d = variants[i % len(variants)]
+        _lib.profile_begin(native._stream())
+        wl.dec.call_batch(cif_d, wl.stride, caf_d, wl.stride, params=params)
+        for name, ms in _lib.profile_end():
+            per_kernel.setdefault(name, []).append(ms)
+    return {k: float(np.mean(v)) for k, v in per_kernel.items()}
+
+
+def tiles_written_per_call(wl, variants, params):
+    """32x64 tiles of the CifHr map one call writes when the field batches alternate: touched(this call) | touched(previous
+    call) (lazy clear), counted from the per-call bitmaps the workspace keeps."""
+    rows = (wl.fh - 1) * wl.stride + 1
+    words = ((((rows + 63) // 64) * ((rows + 31) // 32)) + 31) // 32
+    maps = []
+    for _, _, cif_d, caf_d in variants:
+        wl.dec.call_batch(cif_d, wl.stride, caf_d, wl.stride, params=params)
+        bm = wl.dec.workspace_view('tile_bitmaps', torch.int32).cpu().numpy().view(np.uint32)
+        maps.append(bm[:wl.B * wl.K * words].copy())
+    union = maps[0]
+    for m in maps[1:]:
+        union = union | m
+    return int(np.unpackbits(union.view(np.uint8)).sum())
+
+
+def decode_roofline(wl, variants, params, steps, force_complete=False):
+    avg_ms = kernel_profile(wl, variants, params, steps)
+    alg = algorithmic_bytes(wl.B, wl.K, wl.A, wl.fh, wl.fh, wl.stride, wl.dec.max_annotations)
+    alg['cifhr_tile_kernel'] = tiles_written_per_call(wl, variants, params) * 32 * 64 * 4
+    decode_ms = sum(avg_ms.values())
+    dominant = max(avg_ms, key=avg_ms.get)
+    dom_ms = avg_ms[dominant]
+    achieved = alg['decode_path'] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0        # SURVEY 8d bytes per launch
+    own = alg.get(dominant, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    entry, note = pmc_traffic(wl.config_id, wl.B, force_complete)
+    roofline = {
+        'bound': 'hbm', 'kernel': dominant, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBPS,
+        'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5),
+        'traffic': entry['decode_path_hbm_bytes'] if entry else None, 'traffic_source': note,
+        'traffic_definition': 'PMC HBM bytes of the WHOLE decode path per launch (comparable with '
+                              'algorithmic_bytes_per_launch); per kernel under traffic_per_kernel',
+        'traffic_per_kernel': entry.get('kernels') if entry else None,
+        'avg_launch_ms': round(dom_ms, 4), 'algorithmic_bytes_per_launch': alg['decode_path'],
+        'algorithmic_bytes_definition': 'SURVEY 8d: CIF + CAF + annotations of one image x images per launch',
+        'own_bytes': {'bytes_per_launch': alg.get(dominant, 0), 'GBps': round(own, 2),
+                      'frac': round(own / HBM_PEAK_GBPS, 6),
+                      'note': 'the kernel\'s own compulsory bytes (the association kernels only write the '
+                              'annotations: a latency-bound dependency chain, not a bandwidth problem)'},
+        'kernels': {k: {'ms': round(v, 4),
+                        'GBps': round(alg.get(k, 0) / (v * 1e-3) / 1e9, 1) if v > 0 else None}
+                    for k, v in avg_ms.items()},
+        'decode_path': {'ms_per_batch': round(decode_ms, 4),
+                        'images_per_s': round(wl.B / (decode_ms * 1e-3), 1),
+                        'GBps': round(alg['decode_path'] / (decode_ms * 1e-3) / 1e9, 2),
+                        'frac': round(alg['decode_path'] / (decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
+        'field_batches_alternating': len(variants),
+    }
+    return roofline
 
 
 def main():
@@ -233,61 +437,25 @@ def main():
     if args.gpus != world and rank == 0 and world > 1:
         print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
 
-    from openpifpaf_amd import _lib, constants, distributed, headmeta, native, network, synth
+    from openpifpaf_amd import _lib, distributed, native
 
-    cfg = CONFIGS[args.config]
-    backbone = args.backbone or cfg['backbone']
-    B = args.batch or cfg['batch']
-    if cfg['wholebody']:
-        wb = constants.wholebody()
-        cif_meta, caf_meta = headmeta.wholebody_metas()
-        skeleton1, pose, people = wb['skeleton'], wb['standing_pose'], (1, 3, 6, 10)
-    else:
-        cif_meta, caf_meta = headmeta.cocokp_metas()
-        skeleton1, pose, people = constants.COCO_PERSON_SKELETON, None, synth.PEOPLE_CYCLE
-    skeleton0 = np.asarray(skeleton1, dtype=np.int64) - 1
-    K, A = cif_meta.n_fields, caf_meta.n_fields
-    TORCH_DTYPE = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}
-
-    # ---- resident inputs
-    g = torch.Generator(device='cpu').manual_seed(1000 + rank)
-    images32 = torch.randn((B, 3, args.long_edge, args.long_edge), generator=g).to(device)
-    images32 = images32.contiguous(memory_format=torch.channels_last)
-    fh = (args.long_edge - 1) // 16 * 2 + 1            # 641 -> 41 -> 82 -> 81
-    cifs_np, cafs_np = synth.synth_batch(B, seed0=rank * B, height=fh, width=fh, people=people, pose=pose,
-                                         skeleton=skeleton1 if cfg['wholebody'] else None)
-    cif_syn = torch.from_numpy(cifs_np).to(device)
-    caf_syn = torch.from_numpy(cafs_np).to(device)
-    stride = cif_meta.stride
-
-    fc_kw = dict(force_complete=1, keypoint_threshold=0.0, keypoint_threshold_rel=0.0,
-                 nms_instance_threshold=0.0, nms_keypoint_threshold=0.0)     # reference decoder/cifcaf.py:180-185
-    dec_params = _lib.default_params(**fc_kw) if args.force_complete else None
-    dec = native.CifCaf(K, torch.from_numpy(skeleton0))
-    n_streams = max(1, args.decode_streams) if args.decode_only else 1
-    extra = [(native.CifCaf(K, torch.from_numpy(skeleton0)), torch.cuda.Stream(priority=-1))
-             for _ in range(n_streams - 1)]
-    graphs = None
-    if args.decode_only and args.graph:              # one captured decode per (decoder, stream)
-        lanes = [(dec, torch.cuda.Stream(priority=-1))] + extra
-        graphs = []
-        for d, st in lanes:
-            gr, outs = d.capture(cif_syn, stride, caf_syn, stride, params=dec_params, stream=st)
-            graphs.append((gr, st, outs))
-    host_out = torch.empty((B, dec.max_annotations, K, 4), dtype=torch.float32).pin_memory()
-    host_counts = torch.empty((B,), dtype=torch.int32).pin_memory()
+    t_program = time.perf_counter()
+    config_id = args.config or 2
+    extras = (args.config is None and world == 1 and not args.no_extras and not args.decode_only
+              and args.fields == 'synthetic' and not args.force_complete and args.backbone is None and args.batch is None)
+    n_variants = 1 if (args.single_batch or args.graph) else 2
+    wl = Workload(config_id, args.batch or CONFIGS[config_id]['batch'], rank, device, args.long_edge, n_variants,
+                  backbone=args.backbone)
+    B, K, A, stride = wl.B, wl.K, wl.A, wl.stride
+    dec = wl.dec
+    dec_params = _lib.default_params(**FC_KW) if args.force_complete else None
     main_stream = torch.cuda.current_stream()
     # high priority: the few decode workgroups slip in between the backbone's waves instead of queueing behind them
     dec_stream = main_stream if args.no_overlap else torch.cuda.Stream(priority=-1)
-    gathered = [None]
 
-    def build_model(dtype_name):
-        model = network.factory(backbone, [cif_meta, caf_meta]).to(device)
-        network.optimize_for_inference_(model)
-        model = model.to(memory_format=torch.channels_last)
-        if dtype_name != 'fp32':
-            model = model.to(TORCH_DTYPE[dtype_name])
-        return model
+    g = torch.Generator(device='cpu').manual_seed(1000 + rank)
+    images32 = torch.randn((B, 3, args.long_edge, args.long_edge), generator=g).to(device)
+    images32 = images32.contiguous(memory_format=torch.channels_last)
 
     def sync_all():
         torch.cuda.synchronize(device)
@@ -296,13 +464,26 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
-    def run_leg(dtype_name, steps, warmup):
-        """W warm-up steps, then EXACTLY `steps` timed steps between barrier + synchronize; -> (max-over-ranks
-        seconds, the model)."""
-        model = None if args.decode_only else build_model(dtype_name)
+    def run_leg(wl, images32, dtype_name, steps, warmup, *, params=None, decode_only=False, fields='synthetic',
+                quantised=False, n_streams=1, graph=False, dump=None):
+        """W warm-up steps, then EXACTLY `steps` timed steps between barrier + synchronize.  -> dict(elapsed = max over
+        ranks, per-rank times, model, images, annotations of the last step)."""
+        model = None if decode_only else build_model(wl, dtype_name)
         images = images32 if dtype_name == 'fp32' else images32.to(TORCH_DTYPE[dtype_name])
+        variants = wl.quantised() if quantised else wl.variants
+        lanes = native.DecodeLanes(wl.K, torch.from_numpy(wl.skeleton0), lanes=n_streams) if n_streams > 1 else None
+        graphs = None
+        if graph:                                          # one captured decode per (decoder, stream), one field batch
+            decs = [wl.dec] + [native.CifCaf(wl.K, torch.from_numpy(wl.skeleton0)) for _ in range(n_streams - 1)]
+            graphs = []
+            for d in decs:
+                st = torch.cuda.Stream(priority=-1)
+                gr, outs = d.capture(variants[0][2], wl.stride, variants[0][3], wl.stride, params=params, stream=st)
+                graphs.append((gr, st, outs))
         step_no = [0]
         shapes_checked = [False]
+        gathered = [None]
+        tickets = []
 
         def step():
             heads = None
@@ -310,62 +491,81 @@ def main():
                 with torch.no_grad():
                     heads = model(images)
                 if not shapes_checked[0]:
-                    assert tuple(heads[0].shape) == tuple(cif_syn.shape), (heads[0].shape, cif_syn.shape)
-                    assert tuple(heads[1].shape) == tuple(caf_syn.shape), (heads[1].shape, caf_syn.shape)
+                    assert tuple(heads[0].shape) == tuple(variants[0][2].shape), (heads[0].shape, variants[0][2].shape)
+                    assert tuple(heads[1].shape) == tuple(variants[0][3].shape), (heads[1].shape, variants[0][3].shape)
                     shapes_checked[0] = True
+            _, _, cif_d, caf_d = variants[step_no[0] % len(variants)]      # the field batches alternate
             step_no[0] += 1
             if graphs is not None:
-                gr, st, (out, ids, counts) = graphs[step_no[0] % n_streams]
+                gr, st, (out, ids, counts) = graphs[step_no[0] % len(graphs)]
                 with torch.cuda.stream(st):
                     gr.replay()
-                    host_out.copy_(out, non_blocking=True)
-                    host_counts.copy_(counts, non_blocking=True)
+                    wl.host_out.copy_(out, non_blocking=True)
+                    wl.host_counts.copy_(counts, non_blocking=True)
                 return
-            if n_streams > 1 and step_no[0] % n_streams:   # decode-only: this batch goes to one of the extra decoders
-                d, st = extra[step_no[0] % n_streams - 1]
-                with torch.cuda.stream(st):
-                    out, ids, counts = d.call_batch(cif_syn, stride, caf_syn, stride, params=dec_params)
-                    host_out.copy_(out, non_blocking=True)
-                    host_counts.copy_(counts, non_blocking=True)
+            if lanes is not None:                          # decode-only: several batches in flight
+                t = lanes.submit(cif_d, wl.stride, caf_d, wl.stride, params=params)
+                tickets.append(t)
+                if len(tickets) > n_streams:               # the host copy of the oldest, on its lane's stream order
+                    out, ids, counts = tickets.pop(0).result()
+                    wl.host_out.copy_(out, non_blocking=True)
+                    wl.host_counts.copy_(counts, non_blocking=True)
                 return
             ev = torch.cuda.Event()
             ev.record(main_stream)
             with torch.cuda.stream(dec_stream):
                 dec_stream.wait_event(ev)                  # decode of batch i follows its backbone
-                if args.fields == 'network' and model is not None:
-                    out, ids, counts = dec.call_batch(heads[0], stride, heads[1], stride, params=dec_params)
+                if fields == 'network' and model is not None:
+                    out, ids, counts = wl.dec.call_batch(heads[0], wl.stride, heads[1], wl.stride, params=params)
                 else:
-                    out, ids, counts = dec.call_batch(cif_syn, stride, caf_syn, stride, params=dec_params)
+                    out, ids, counts = wl.dec.call_batch(cif_d, wl.stride, caf_d, wl.stride, params=params)
                 if world > 1:                              # final annotations only, ONE collective (RCCL over xGMI)
                     if args.dist_backend == 'nccl':
                         gathered[0] = distributed.gather_annotations(out, ids, counts)
                     else:
                         gathered[0] = distributed.gather_annotations(out.cpu(), ids.cpu(), counts.cpu())
-                host_out.copy_(out, non_blocking=True)
-                host_counts.copy_(counts, non_blocking=True)
+                wl.host_out.copy_(out, non_blocking=True)
+                wl.host_counts.copy_(counts, non_blocking=True)
 
         t_setup = time.perf_counter()
         for _ in range(warmup):
             step()
         sync_all()
+        if world > 1 and model is not None:
+            # each process picked its 1x1-convolution kernels by wall clock during the warm-up and the paths round
+            # differently: from here on every rank runs rank 0's choices
+            distributed.broadcast_conv_choices()
+            step()
+            sync_all()
         if rank == 0:
-            print('bench: %s leg warm-up (incl. MIOpen find) %.1f s' % (dtype_name, time.perf_counter() - t_setup),
-                  file=sys.stderr)
+            print('bench: config %d %s leg warm-up (incl. MIOpen find) %.1f s' % (wl.config_id, dtype_name,
+                                                                                  time.perf_counter() - t_setup), file=sys.stderr)
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
+        for t in tickets:
+            t.result()
         sync_all()
         elapsed = time.perf_counter() - t0
+        per_rank = [elapsed]
         if world > 1:
             import torch.distributed as dist
             t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.dist_backend == 'nccl' else 'cpu')
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        return elapsed, model, images
+            every = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(every, t)
+            per_rank = [float(x.item()) for x in every]
+            elapsed = max(per_rank)
+        native.check_counts(wl.host_counts)
+        if dump and rank == 0:
+            a_, i_, c_ = gathered[0] if gathered[0] is not None else (wl.host_out, None, wl.host_counts)
+            np.savez(dump, annotations=a_.cpu().numpy(), counts=c_.cpu().numpy(),
+                     variant=(step_no[0] - 1) % len(variants), variant_seed=VARIANT_SEED)
+        return dict(elapsed=elapsed, per_rank=per_rank, model=model, images=images,
+                    n_ann=int((wl.host_counts & native.COUNT_ROWS_MASK).sum()), variants=variants)
 
-    def backbone_only_ms(model, images, reps=5):
-        """Network alone (backbone + heads) per batch, and the host copy of its field tensors the reference
-        makes before decoding (decoder/decoder.py:96-100)."""
+    def network_only(model, images, wl, reps=5):
+        """Network alone (backbone + heads) per batch, the host copy of its field tensors the reference makes before
+        decoding (decoder/decoder.py:96-100), and the heads of the last forward."""
         with torch.no_grad():
             heads = model(images)
         torch.cuda.synchronize(device)
@@ -382,148 +582,341 @@ def main():
         d2h_ms = (time.perf_counter() - t0) / 3 * 1e3
         return nn_ms, d2h_ms, sum(h.numel() * h.element_size() for h in host)
 
-    # ---- the headline leg (reference precision), then the bfloat16 one
-    legs = {}
-    primary = args.backbone_dtype
-    elapsed, model, images = run_leg(primary, args.steps, args.warmup)
-    legs[primary] = dict(elapsed=elapsed, value=world * B * args.steps / elapsed)
-    n_ann = int((host_counts & 0x0FFFFFFF).sum())           # OPA_COUNT_ROWS
-    if args.dump_annotations and rank == 0:
-        a_, i_, c_ = gathered[0] if gathered[0] is not None else (host_out, None, host_counts)
-        np.savez(args.dump_annotations, annotations=a_.cpu().numpy(), counts=c_.cpu().numpy())
-    nn = {}
-    if model is not None and rank == 0 and world == 1:
-        nn[primary] = backbone_only_ms(model, images)
-    del model
-    if not args.decode_only and not args.no_bf16_leg and primary != 'bf16':
-        elapsed2, model2, images2 = run_leg('bf16', args.steps, args.warmup)
-        legs['bf16'] = dict(elapsed=elapsed2, value=world * B * args.steps / elapsed2)
-        if rank == 0 and world == 1:
-            nn['bf16'] = backbone_only_ms(model2, images2)
-        del model2
+    def reference_flow_run(model, images, wl, steps, fc_kw=None):
+        """The reference's data flow, RUN (not composed): network on the GPU -> .cpu() of its head fields -> the
+        reference C++ decoder on one host thread, one instance reused, image after image (the decode works on the
+        synthetic fields of the same shapes: a random-init head's own output decodes ~30x slower)."""
+        kind, make, _ = reference_decoder(wl.skeleton0, wl.K, fc_kw)
+        decode = make(True)
+        cifs, cafs = wl.variants[0][0], wl.variants[0][1]
+        n = len(images)
+        with torch.no_grad():
+            [h.cpu() for h in model(images)]
+        t0 = time.perf_counter()
+        for s in range(steps):
+            with torch.no_grad():
+                host = [h.cpu() for h in model(images)]                 # blocks until the network is done
+            assert host[0].shape[0] == n
+            for b in range(n):
+                decode(cifs[b % len(cifs)], cafs[b % len(cafs)])
+        dt = (time.perf_counter() - t0) / steps
+        if fc_kw:
+            reset_reference()
+        return {'images_per_s_1thread': round(n / dt, 2), 'ms_per_batch': round(dt * 1e3, 1), 'steps': steps,
+                'decoder': kind, 'measured': 'run end to end in this process'}
 
-    # ---- rank 0: roofline leg (per-kernel HIP-event timings) and CPU legs
-    result = None
-    if rank == 0:
-        per_kernel = {}
+    def leg_summary(wl, leg, steps):
+        return dict(value=world * wl.B * steps / leg['elapsed'], ms_per_step=leg['elapsed'] / steps * 1e3)
+
+    def full_config(wl, images32, steps, warmup, *, primary, bf16_leg, cpu_seconds, profile_steps, params, dump=None,
+                    decode_only=False, fields='synthetic', n_streams=1, graph=False, reference_steps=3, fc=False):
+        """All legs of one configuration on this rank -> result dict (rank 0) or None."""
+        legs, nn, ref_run = {}, {}, {}
+        leg = run_leg(wl, images32, primary, steps, warmup, params=params, decode_only=decode_only, fields=fields,
+                      n_streams=n_streams, graph=graph, dump=dump)
+        legs[primary] = leg
+        single = rank == 0 and world == 1
+        if leg['model'] is not None and single:
+            nn[primary] = network_only(leg['model'], leg['images'], wl)
+            if not args.no_cpu_baseline:
+                ref_run[primary] = reference_flow_run(leg['model'], leg['images'], wl, reference_steps, FC_KW if fc else None)
+        leg['model'] = None
+        torch.cuda.empty_cache()
+        if bf16_leg and not decode_only and primary != 'bf16':
+            leg2 = run_leg(wl, images32, 'bf16', steps, warmup, params=params, quantised=True)
+            legs['bf16'] = leg2
+            if single:
+                nn['bf16'] = network_only(leg2['model'], leg2['images'], wl)
+                if not args.no_cpu_baseline:
+                    ref_run['bf16'] = reference_flow_run(leg2['model'], leg2['images'], wl, reference_steps, FC_KW if fc else None)
+            leg2['model'] = None
+            torch.cuda.empty_cache()
+        if rank != 0:
+            return None
+        fc_kw = FC_KW if fc else None
         with torch.cuda.stream(dec_stream):
-            for _ in range(max(1, args.profile_steps)):
-                _lib.profile_begin(native._stream())
-                dec.call_batch(cif_syn, stride, caf_syn, stride, params=dec_params)
-                for name, ms in _lib.profile_end():
-                    per_kernel.setdefault(name, []).append(ms)
-        avg_ms = {k: float(np.mean(v)) for k, v in per_kernel.items()}
-        alg = algorithmic_bytes(B, K, A, fh, fh, stride, dec.max_annotations)
-        # the tile kernel writes only the 32x64 tiles this call's or the previous call's cells reach
-        # (lazy clear): its compulsory bytes are those tiles, counted from the bitmaps in the workspace
-        bitmaps = dec.workspace_view('tile_bitmaps', torch.int32).cpu().numpy().view(np.uint32)
-        words = ((((fh - 1) * stride + 1 + 63) // 64) * (((fh - 1) * stride + 1 + 31) // 32) + 31) // 32
-        tiles_written = int(np.unpackbits(bitmaps[:B * K * words].view(np.uint8)).sum())
-        alg['cifhr_tile_kernel'] = tiles_written * 32 * 64 * 4
-        decode_ms = sum(avg_ms.values())
-        dominant = max(avg_ms, key=avg_ms.get)
-        dom_ms = avg_ms[dominant]
-        achieved = alg['decode_path'] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0       # SURVEY 8d bytes per launch
-        own = alg.get(dominant, 0) / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        # HBM bytes per launch: rocprofv3 PMC passes cannot run inside bench.py; tools/collect_profiles.sh writes them
-        # to profiles/r2/pmc_traffic.json stamped with the hash of the kernel sources they were measured on
-        traffic, traffic_note = None, 'no PMC file for these kernel sources (run tools/collect_profiles.sh)'
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r2', 'pmc_traffic.json')))
-            if pmc.get('batch') == B and pmc.get('config') == args.config and \
-                    pmc.get('kernel_source_hash') == kernel_source_hash():
-                traffic = pmc['kernels'].get(dominant, {}).get('hbm_bytes')
-                traffic_note = 'profiles/r2/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, x2 read correction)'
-        except (OSError, ValueError):
-            pass
-        roofline = {
-            'bound': 'hbm', 'kernel': dominant, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBPS,
-            'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBPS, 5), 'traffic': traffic, 'traffic_source': traffic_note,
-            'avg_launch_ms': round(dom_ms, 4), 'algorithmic_bytes_per_launch': alg['decode_path'],
-            'algorithmic_bytes_definition': 'SURVEY 8d: CIF + CAF + annotations of one image x images per launch',
-            'own_bytes': {'bytes_per_launch': alg.get(dominant, 0), 'GBps': round(own, 2),
-                          'frac': round(own / HBM_PEAK_GBPS, 6),
-                          'note': 'the kernel\'s own compulsory bytes (the association kernel only writes the '
-                                  'annotations: a latency-bound dependency chain, not a bandwidth problem)'},
-            'kernels': {k: {'ms': round(v, 4),
-                            'GBps': round(alg.get(k, 0) / (v * 1e-3) / 1e9, 1) if v > 0 else None}
-                        for k, v in avg_ms.items()},
-            'decode_path': {'ms_per_batch': round(decode_ms, 4),
-                            'images_per_s': round(B / (decode_ms * 1e-3), 1),
-                            'GBps': round(alg['decode_path'] / (decode_ms * 1e-3) / 1e9, 2),
-                            'frac': round(alg['decode_path'] / (decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
-        }
-        if not args.decode_only and not cfg['wholebody'] and backbone == 'resnet50' and nn:
-            gflop = 274.0 * B                             # 137 GMAC per 641x641 image
+            roofline = decode_roofline(wl, wl.variants, params, profile_steps, force_complete=fc)
+        if not decode_only and not wl.cfg['wholebody'] and wl.backbone == 'resnet50' and nn:
+            gflop = 274.0 * wl.B                          # SURVEY 8d: 137 GMAC per 641x641 image
             roofline['backbone_mfma'] = {
                 d: {'ms_per_batch': round(nn[d][0], 2), 'TFLOPs': round(gflop / nn[d][0], 1),
                     'frac_of_dense_peak': round(gflop / nn[d][0] / MFMA_PEAK_TFLOPS[d], 3)} for d in nn}
-        cpu = None
-        ref_pipe = None
+        cpu = ref_pipe = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(cifs_np, cafs_np, skeleton0, K, args.cpu_seconds, fc_kw if args.force_complete else None)
+            cpu = cpu_baseline(wl.variants[0][0], wl.variants[0][1], wl.skeleton0, wl.K, cpu_seconds, fc_kw)
             if nn:
-                # the reference's data flow, per batch: network on the GPU, head fields to the host, CPU decode
                 ref_pipe = {}
                 for d, (nn_ms, d2h_ms, field_bytes) in nn.items():
-                    one = B / ((nn_ms + d2h_ms) * 1e-3 + B / cpu['value'])
-                    allc = B / ((nn_ms + d2h_ms) * 1e-3 + B / cpu['all_cores_value']) if cpu.get('all_cores_value') else None
-                    ref_pipe[d] = {
+                    allc = wl.B / ((nn_ms + d2h_ms) * 1e-3 + wl.B / cpu['all_cores_value']) if cpu.get('all_cores_value') else None
+                    ref_pipe[d] = dict(ref_run.get(d, {}))
+                    ref_pipe[d].update({
                         'network_ms_per_batch': round(nn_ms, 2), 'fields_to_host_ms_per_batch': round(d2h_ms, 2),
                         'field_bytes_per_batch': field_bytes,
-                        'cpu_decode_ms_per_batch_1thread': round(B / cpu['value'] * 1e3, 1),
-                        'images_per_s_1thread': round(one, 1),
-                        'images_per_s_all_cores': round(allc, 1) if allc else None, 'cores': cpu['all_cores'],
-                    }
-        value = legs[primary]['value']
+                        'cpu_decode_ms_per_batch_1thread': round(wl.B / cpu['value'] * 1e3, 1),
+                        'images_per_s_all_cores_composed': round(allc, 1) if allc else None, 'cores': cpu['all_cores'],
+                    })
+        parity = None
+        if world == 1 and not args.no_parity:
+            with torch.cuda.stream(dec_stream):
+                parity = parity_stamp(lambda c, f: wl.dec.call_batch(c, wl.stride, f, wl.stride, params=params),
+                                      wl.variants, wl.skeleton0, wl.K, fc_kw)
+                if 'bf16' in legs:
+                    q = parity_stamp(lambda c, f: wl.dec.call_batch(c, wl.stride, f, wl.stride, params=params),
+                                     wl.quantised(), wl.skeleton0, wl.K, fc_kw)
+                    q['note'] = ('decode inputs of the bf16 leg: the fields rounded to bfloat16.  8-bit mantissas make seed '
+                                 'scores tie; the HIP path orders tied seeds by cell index, the reference by whatever its '
+                                 'unstable std::sort leaves (cif_seeds.cpp:94) -- images_beyond_tolerance / images is the '
+                                 'tie mismatch rate (never a pose-count or joint-presence change in the studies)')
+                    parity['bf16_fields'] = q
+        s = leg_summary(wl, legs[primary], steps)
+        value = s['value']
+        base = ref_pipe[primary].get('images_per_s_1thread') if ref_pipe and primary in ref_pipe else None
         result = {
-            'metric': ('images/sec end-to-end (backbone+CifCaf decode), %s 641px' % backbone if not args.decode_only else
-                       'images/sec DECODE ONLY (diagnostic: backbone skipped, not the headline metric)'),
-            'value': round(value, 2), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(legs[primary]['elapsed'] / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': round(value / ref_pipe[primary]['images_per_s_1thread'], 2) if ref_pipe else None,
-            'vs_baseline_definition': 'value / the reference data flow measured in this run at the same backbone '
-                                      'precision: network on the MI355X -> .cpu() of the fields -> reference C++ '
-                                      'decoder, 1 host thread (reference_pipeline)',
-            'dtype': 'f32', 'data': 'synthetic',
+            'value': round(value, 2), 'unit': 'images/s', 'ms_per_step': round(s['ms_per_step'], 3),
+            'vs_baseline': round(value / base, 2) if base else None,
             'config': {
-                'workload': 'BASELINE %s: %s %dx%d, batch %d per GPU, CIF/CAF fields [%d,%d,5,%d,%d]+[%d,%d,8,%d,%d]'
-                            % (cfg['name'], backbone, args.long_edge, args.long_edge, B, B, K, fh, fh, B, A, fh, fh),
-                'backbone': 'none (decode only)' if args.decode_only else backbone,
+                'workload': wl.workload_text(),
+                'backbone': 'none (decode only)' if decode_only else wl.backbone,
                 'backbone_dtype': primary, 'decode_dtype': 'f32 (+f64 where the reference uses double)',
-                'global_batch': world * B,
-                'fields': ('COCO-shaped synthetic fields injected after the heads (people per image cycle %s)'
-                           % (list(people),)) if args.fields == 'synthetic' else
+                'global_batch': world * wl.B,
+                'fields': ('COCO-shaped synthetic fields injected after the heads (people per image cycle %s); %d different '
+                           'field batches alternate step by step' % (list(wl.people), len(wl.variants)))
+                          if fields == 'synthetic' else
                           'the random-init network\'s own head outputs (all-active adversarial case)',
                 'parallelism': 'images sharded one batch per GPU (dp%d); one RCCL all_gather of the packed annotations' % world
                                if world > 1 else 'single GPU',
                 'decode_overlapped_on_second_stream': not args.no_overlap,
-                'decode_streams': n_streams, 'hip_graph': graphs is not None,
-                'force_complete_pose': bool(args.force_complete),
-                'annotations_per_batch': n_ann,
+                'decode_streams': n_streams, 'hip_graph': bool(graph),
+                'force_complete_pose': bool(fc),
+                'annotations_per_batch': legs[primary]['n_ann'],
             },
-            'roofline': roofline,
-            'cpu_baseline': cpu,
-            'reference_pipeline': ref_pipe,
+            'roofline': roofline, 'cpu_baseline': cpu, 'reference_pipeline': ref_pipe, 'parity': parity,
         }
+        if world > 1:
+            pr = legs[primary]['per_rank']
+            result['per_rank_ms_per_step'] = {'min': round(min(pr) / steps * 1e3, 3), 'max': round(max(pr) / steps * 1e3, 3)}
         if 'bf16' in legs and primary != 'bf16':
-            v16 = legs['bf16']['value']
+            s16 = leg_summary(wl, legs['bf16'], steps)
+            b16 = ref_pipe['bf16'].get('images_per_s_1thread') if ref_pipe and 'bf16' in ref_pipe else None
             result['bf16_backbone'] = {
-                'value': round(v16, 2), 'ms_per_step': round(legs['bf16']['elapsed'] / args.steps * 1e3, 3),
-                'vs_baseline_same_precision': round(v16 / ref_pipe['bf16']['images_per_s_1thread'], 2) if ref_pipe else None,
-                'vs_reference_fp32_pipeline': round(v16 / ref_pipe[primary]['images_per_s_1thread'], 2)
-                if ref_pipe and primary in ref_pipe else None,
-                'note': 'same step with the network in bfloat16 (reduced precision relative to the reference; not the headline)',
+                'value': round(s16['value'], 2), 'ms_per_step': round(s16['ms_per_step'], 3),
+                'vs_baseline_same_precision': round(s16['value'] / b16, 2) if b16 else None,
+                'vs_reference_fp32_pipeline': round(s16['value'] / base, 2) if base else None,
+                'note': 'same step with the network in bfloat16 and the decode inputs rounded to bfloat16 (reduced precision '
+                        'relative to the reference; not the headline)',
             }
         if cpu is not None:
             result['decode_vs_cpu_1thread'] = round(roofline['decode_path']['images_per_s'] / cpu['value'], 1)
-        print(json.dumps(result))
+        return result
+
+    # ------------------------------------------------------------------------------------- the headline
+    primary = args.backbone_dtype
+    result = full_config(wl, images32, args.steps, args.warmup, primary=primary,
+                         bf16_leg=not args.no_bf16_leg, cpu_seconds=args.cpu_seconds,
+                         profile_steps=args.profile_steps, params=dec_params, dump=args.dump_annotations,
+                         decode_only=args.decode_only, fields=args.fields,
+                         n_streams=max(1, args.decode_streams) if args.decode_only else 1, graph=args.graph and args.decode_only,
+                         fc=args.force_complete)
+    line = None
+    if rank == 0:
+        line = {
+            'metric': ('images/sec end-to-end (backbone+CifCaf decode), %s 641px' % wl.backbone if not args.decode_only else
+                       'images/sec DECODE ONLY (diagnostic: backbone skipped, not the headline metric)'),
+            'value': result['value'], 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': result['ms_per_step'],
+            'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': result['vs_baseline'],
+            'vs_baseline_definition': 'value / the reference data flow RUN in this process at the same backbone '
+                                      'precision: network on the MI355X -> .cpu() of the fields -> reference C++ '
+                                      'decoder, 1 host thread (reference_pipeline)',
+            'dtype': 'f32', 'data': 'synthetic',
+        }
+        for k in ('config', 'roofline', 'cpu_baseline', 'reference_pipeline', 'parity', 'bf16_backbone',
+                  'decode_vs_cpu_1thread', 'per_rank_ms_per_step'):
+            if k in result:
+                line[k] = result[k]
+        rp = result.get('reference_pipeline') or {}
+        if primary in rp and 'ms_per_batch' in rp[primary]:
+            nn_ms, ref_ms = rp[primary]['network_ms_per_batch'], rp[primary]['ms_per_batch']
+            line['target_15x'] = {
+                'reachable_at_reference_precision': False,
+                'bound': round(ref_ms / nn_ms, 2),
+                'why': 'north_star asks >= 15x end to end vs the reference CPU decode path.  Both flows run the SAME %s '
+                       'network on the MI355X (%.1f ms per batch); the reference flow then spends %.1f ms on the host copy '
+                       'and the CPU decode.  Even a decode that costs nothing gives %.1f / %.1f = %.2fx; every millisecond '
+                       'taken off the network is taken off both flows.  15x needs a faster network than the reference\'s '
+                       'float32 one: see bf16_backbone (reduced precision, reported beside the headline, not as it).'
+                       % (primary, nn_ms, ref_ms - nn_ms, ref_ms, nn_ms, ref_ms / nn_ms)}
+
+    # ------------------------------------------------------------------------------------- the other configurations
+    if extras:
+        others = {}
+        del images32
+        torch.cuda.empty_cache()
+
+        def guarded(name, fn):
+            t0 = time.perf_counter()
+            try:
+                others[name] = fn()
+            except Exception as e:            # an extra leg must not take the headline line with it
+                import traceback
+                traceback.print_exc()
+                others[name] = {'error': repr(e)}
+            if isinstance(others[name], dict):
+                others[name]['leg_seconds'] = round(time.perf_counter() - t0, 1)
+
+        # the reference benchmark CLI's decoder setting on the headline's fields (decode only: the network is the same)
+        def fc_leg():
+            fc_params = _lib.default_params(**FC_KW)
+            leg = run_leg(wl, None, 'fp32', 10, 2, params=fc_params, decode_only=True)
+            with torch.cuda.stream(dec_stream):
+                roof = decode_roofline(wl, wl.variants, fc_params, args.profile_steps, force_complete=True)
+                par = None if args.no_parity else parity_stamp(
+                    lambda c, f: wl.dec.call_batch(c, wl.stride, f, wl.stride, params=fc_params), wl.variants,
+                    wl.skeleton0, wl.K, FC_KW)
+            cpu = None if args.no_cpu_baseline else cpu_baseline(wl.variants[0][0], wl.variants[0][1], wl.skeleton0,
+                                                                 wl.K, 6.0, FC_KW)
+            return {'setting': 'reference benchmark.py:77-79: --force-complete-pose and zero keypoint / instance thresholds '
+                               '(decoder/cifcaf.py:180-185); decode only, config 2 fields',
+                    'decode_only_images_per_s': round(wl.B * 10 / leg['elapsed'], 1),
+                    'ms_per_batch_wall': round(leg['elapsed'] / 10 * 1e3, 3), 'annotations_per_batch': leg['n_ann'],
+                    'roofline': roof, 'cpu_baseline': cpu, 'parity': par,
+                    'decode_vs_cpu_1thread': round(roof['decode_path']['images_per_s'] / cpu['value'], 1) if cpu else None}
+        guarded('force_complete', fc_leg)
+
+        # two batches in flight (stages 1-5 of batch i+1 beside the association of batch i)
+        def lanes_leg():
+            one = run_leg(wl, None, 'fp32', 40, 4, decode_only=True)
+            two = run_leg(wl, None, 'fp32', 40, 4, decode_only=True, n_streams=2)
+            return {'decode_only_images_per_s': {'one_in_flight': round(wl.B * 40 / one['elapsed'], 1),
+                                                 'two_in_flight': round(wl.B * 40 / two['elapsed'], 1)},
+                    'what': 'decode only, config 2 fields, alternating batches, annotations copied to the host; '
+                            'native.DecodeLanes(lanes=2): two decoders / workspaces / streams'}
+        guarded('decode_two_in_flight', lanes_leg)
+
+        # the literal configs[1]: batch 1
+        def batch1_leg():
+            w1 = Workload(2, 1, 0, device, args.long_edge, 2)
+            w1.variants = [(c[i:i + 1], f[i:i + 1], cd[i:i + 1].contiguous(), fd[i:i + 1].contiguous())
+                           for (c, f, cd, fd) in wl.variants for i in (3, 2)]      # 20-, 10-, ... person images
+            img1 = torch.randn((1, 3, args.long_edge, args.long_edge), generator=torch.Generator().manual_seed(7)).to(device)
+            img1 = img1.contiguous(memory_format=torch.channels_last)
+            model = build_model(w1, 'fp32')
+            out = {}
+            n = 30
+
+            def one_eager(i):
+                _, _, cif_d, caf_d = w1.variants[i % len(w1.variants)]
+                with torch.no_grad():
+                    model(img1)
+                o, ids, counts = w1.dec.call_batch(cif_d, w1.stride, caf_d, w1.stride)
+                w1.host_out.copy_(o, non_blocking=True)
+                w1.host_counts.copy_(counts, non_blocking=True)
+                torch.cuda.synchronize(device)
+            for i in range(5):
+                one_eager(i)
+            t0 = time.perf_counter()
+            for i in range(n):
+                one_eager(i)
+            out['eager_ms_per_image'] = round((time.perf_counter() - t0) / n * 1e3, 3)
+            # network alone / decode alone at batch 1
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for i in range(n):
+                with torch.no_grad():
+                    model(img1)
+            torch.cuda.synchronize(device)
+            out['network_ms_per_image'] = round((time.perf_counter() - t0) / n * 1e3, 3)
+            t0 = time.perf_counter()
+            for i in range(n):
+                _, _, cif_d, caf_d = w1.variants[i % len(w1.variants)]
+                w1.dec.call_batch(cif_d, w1.stride, caf_d, w1.stride)
+                torch.cuda.synchronize(device)
+            out['decode_ms_per_image_eager'] = round((time.perf_counter() - t0) / n * 1e3, 3)
+            out['decode_kernels_ms'] = {k: round(v, 4) for k, v in kernel_profile(w1, w1.variants, None, 8).items()}
+            # the whole step as ONE HIP graph: network + decode captured together, fields refilled in place
+            try:
+                st = torch.cuda.Stream()
+                cif_s, caf_s = w1.variants[0][2].clone(), w1.variants[0][3].clone()
+                gdec = native.CifCaf(w1.K, torch.from_numpy(w1.skeleton0))
+                with torch.cuda.stream(st):
+                    with torch.no_grad():
+                        model(img1)
+                    gdec.call_batch(cif_s, w1.stride, caf_s, w1.stride)
+                st.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=st):
+                    with torch.no_grad():
+                        model(img1)
+                    g_out, g_ids, g_counts = gdec.call_batch(cif_s, w1.stride, caf_s, w1.stride)
+                gdec._pinned = True
+
+                def one_graph(i):
+                    _, _, cif_d, caf_d = w1.variants[i % len(w1.variants)]
+                    with torch.cuda.stream(st):
+                        cif_s.copy_(cif_d, non_blocking=True)
+                        caf_s.copy_(caf_d, non_blocking=True)
+                        graph.replay()
+                        w1.host_out.copy_(g_out, non_blocking=True)
+                        w1.host_counts.copy_(g_counts, non_blocking=True)
+                    st.synchronize()
+                for i in range(5):
+                    one_graph(i)
+                t0 = time.perf_counter()
+                for i in range(n):
+                    one_graph(i)
+                out['hip_graph_ms_per_image'] = round((time.perf_counter() - t0) / n * 1e3, 3)
+                native.check_counts(w1.host_counts)
+            except Exception as e:
+                out['hip_graph_ms_per_image'] = None
+                out['hip_graph_error'] = repr(e)
+            # the reference flow at batch 1, run: network -> .cpu() -> reference decoder (1 thread, reused instance)
+            if not args.no_cpu_baseline:
+                kind, make, _ = reference_decoder(w1.skeleton0, w1.K)
+                decode = make(True)
+                with torch.no_grad():
+                    [h.cpu() for h in model(img1)]
+                t0 = time.perf_counter()
+                for i in range(n):
+                    with torch.no_grad():
+                        [h.cpu() for h in model(img1)]
+                    c, f = w1.variants[i % len(w1.variants)][:2]
+                    decode(c[0], f[0])
+                out['reference_flow_ms_per_image'] = round((time.perf_counter() - t0) / n * 1e3, 3)
+                out['vs_reference_flow'] = {'eager': round(out['reference_flow_ms_per_image'] / out['eager_ms_per_image'], 2),
+                                            'hip_graph': round(out['reference_flow_ms_per_image'] / out['hip_graph_ms_per_image'], 2)
+                                            if out.get('hip_graph_ms_per_image') else None}
+            if not args.no_parity:
+                out['parity'] = parity_stamp(lambda c, f: w1.dec.call_batch(c, w1.stride, f, w1.stride), w1.variants,
+                                             w1.skeleton0, w1.K)
+            out['what'] = ('BASELINE configs[1] literally: resnet50 641x641, batch 1 (reference predictor.py:15), float32; latency '
+                           'per image incl. the host copy of the annotations and a device synchronise; fields: the 20- and '
+                           '10-person images of the headline\'s two field batches in turn')
+            return out
+        guarded('batch1', batch1_leg)
+
+        for cid in (3, 4):
+            def cfg_leg(cid=cid):
+                w = Workload(cid, CONFIGS[cid]['batch'], 0, device, args.long_edge, 2)
+                gi = torch.Generator(device='cpu').manual_seed(1000)
+                im = torch.randn((w.B, 3, args.long_edge, args.long_edge), generator=gi).to(device)
+                im = im.contiguous(memory_format=torch.channels_last)
+                r = full_config(w, im, args.extra_steps, 2, primary='fp32', bf16_leg=False,
+                                cpu_seconds=5.0 if cid == 3 else 8.0, profile_steps=4, params=None, reference_steps=1)
+                r['steps'] = args.extra_steps
+                return r
+            guarded('config%d' % cid, cfg_leg)
+            torch.cuda.empty_cache()
+        if line is not None:
+            line['configs'] = others
+    if rank == 0:
+        line['bench_seconds'] = round(time.perf_counter() - t_program, 1)
+        print(json.dumps(line))
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
-    return result
+    return line
 
 
 if __name__ == '__main__':

@@ -100,10 +100,12 @@ def conv1x1_bias_act(x, weight2d, bias, residual=None, relu=True, a_bias=None):
     return out
 
 
-# (device, dtype, M, K, N, has_residual, has_a_bias) -> 'gemm' | 'pass+gemm' | 'conv'.  The three paths round
-# differently, so the choice is part of the result: it is made once per shape and device, never
-# while a stream is being captured (timing synchronises), can be pinned with OPA_CONV1X1=gemm|conv, and can
-# be exported / imported (choices / set_choices) so that every rank of a job runs the same kernels.
+# (dtype, M, K, N, has_residual, has_a_bias) -> 'gemm' | 'pass+gemm' | 'conv'.  The three paths round
+# differently, so the choice is part of the result: it is made once per shape (the key holds no device index: a
+# table exported on rank 0 must match the lookups of every other rank), never by timing while a stream is being
+# captured (timing synchronises; the capture-time default is remembered, so a captured graph and a later eager
+# run use the same kernel), can be pinned with OPA_CONV1X1=gemm|conv, and can be exported / imported
+# (choices / set_choices; distributed.broadcast_conv_choices) so that every rank of a job runs the same kernels.
 _CHOICE = {}
 
 
@@ -111,7 +113,9 @@ def choices():
     return dict(_CHOICE)
 
 
-def set_choices(table):
+def set_choices(table, *, replace=False):
+    if replace:
+        _CHOICE.clear()
     _CHOICE.update(table)
 
 
@@ -139,7 +143,7 @@ def conv_bias_act(conv, x, bias, residual=None, relu=True, a_bias=None):
     if (conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.groups == 1 and conv.padding == (0, 0)
             and conv1x1_supported(x, w, bias, residual, a_bias)):
         M = x.shape[0] * x.shape[2] * x.shape[3]
-        key = (x.device.index, str(x.dtype), M, w.shape[1], w.shape[0], residual is not None, a_bias is not None)
+        key = (str(x.dtype), M, w.shape[1], w.shape[0], residual is not None, a_bias is not None)
         w2d = w.reshape(w.shape[0], w.shape[1])
         if not w2d.is_contiguous():
             w2d = w2d.contiguous()
@@ -149,7 +153,7 @@ def conv_bias_act(conv, x, bias, residual=None, relu=True, a_bias=None):
             if forced in ('gemm', 'conv'):
                 choice = _CHOICE[key] = forced
             elif torch.cuda.is_current_stream_capturing():
-                choice = 'gemm'                  # no timing inside a capture; not remembered
+                choice = _CHOICE[key] = 'gemm'   # no timing inside a capture; remembered, so eager runs agree with the graph
         if choice is None:
             times = {'gemm': _time_ms(lambda: conv1x1_bias_act(x, w2d, bias, residual, relu, a_bias))}
             if a_bias is None:
@@ -171,9 +175,12 @@ def conv_bias_act(conv, x, bias, residual=None, relu=True, a_bias=None):
 
 def head_epilogue_supported(x, meta, training=False):
     """True if :func:`head_epilogue` can run for this convolution output and head meta."""
+    us = meta.upsample_stride
     return (not training and x.is_cuda and x.dim() == 4 and x.dtype in _DTYPES and _lib.available()
-            and x.is_contiguous(memory_format=torch.channels_last) and meta.upsample_stride in (1, 2)
-            and x.shape[1] % (meta.upsample_stride ** 2) == 0 and x.data_ptr() % 16 == 0)
+            and not (torch.is_grad_enabled() and x.requires_grad)           # the kernel has no backward
+            and x.is_contiguous(memory_format=torch.channels_last) and us in (1, 2)
+            and x.shape[1] % (us ** 2) == 0 and x.data_ptr() % 16 == 0
+            and 16 * us * us * (x.shape[3] + 1) * 4 <= 64 * 1024)           # the kernel's LDS row buffer (head.hip)
 
 
 def head_epilogue(x, meta):
@@ -209,7 +216,11 @@ def _pixel_stride(x):
 
 
 def dwconv_supported(x, kernel_size, stride):
-    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and kernel_size in (3, 5) and stride in (1, 2)
+    if not (x.is_cuda and x.dim() == 4):
+        return False
+    rows_out = (x.shape[2] + 2 * (kernel_size // 2) - kernel_size) // stride + 1
+    return (x.dtype in (torch.float32, torch.bfloat16) and kernel_size in (3, 5) and stride in (1, 2)
+            and x.shape[0] * rows_out <= 65535                              # grid.y of the stencil kernel (dwconv.hip)
             and _pixel_stride(x) is not None and _lib.available())
 
 

@@ -272,6 +272,52 @@ class CifCaf:
         return flat.view(shape.batch, F, rows.value, pitch.value)[image, :, :, :cols.value], rev.value
 
 
+class DecodeLanes:
+    """Several batched decodes in flight at once.  One decode is six kernels in a row whose longest, the
+    association, keeps one workgroup per image busy (32 of 256 compute units for a batch of 32) -- the stages of the
+    NEXT batch fit beside it.  Each lane is a :class:`CifCaf` of its own (workspace) on a stream of its own;
+    ``submit`` round-robins over them and returns a ticket instead of making the caller's stream wait::
+
+        lanes = DecodeLanes(17, skeleton, lanes=2)
+        tickets = [lanes.submit(cif_i, 8, caf_i, 8) for ...]      # field tensors stay valid until the ticket is done
+        out, ids, counts = tickets[0].result()                     # current stream waits for that decode only
+    """
+
+    class Ticket:
+        def __init__(self, tensors, event):
+            self.tensors, self.event = tensors, event
+
+        def result(self):
+            """The decode's ``(annotations, ids, counts)``, safe to use on the current stream."""
+            torch.cuda.current_stream().wait_event(self.event)
+            return self.tensors
+
+        def synchronize(self):
+            self.event.synchronize()
+            return self.tensors
+
+    def __init__(self, n_keypoints, skeleton, *, lanes=2, max_annotations=DEFAULT_MAX_ANNOTATIONS):
+        self.decoders = [CifCaf(n_keypoints, skeleton, max_annotations=max_annotations) for _ in range(max(1, lanes))]
+        self.streams = [torch.cuda.Stream(priority=-1) for _ in self.decoders]
+        self._next = 0
+
+    def submit(self, cif, cif_stride, caf, caf_stride, *, params=None):
+        lane = self._next
+        self._next = (self._next + 1) % len(self.decoders)
+        stream = self.streams[lane]
+        ready = torch.cuda.Event()
+        ready.record()                                   # the fields are complete on the caller's stream
+        with torch.cuda.stream(stream):
+            stream.wait_event(ready)
+            tensors = self.decoders[lane].call_batch(cif, cif_stride, caf, caf_stride, params=params)
+            for t in (cif, caf):
+                if t.is_cuda:
+                    t.record_stream(stream)              # the allocator must not hand the fields out before the lane is done
+            done = torch.cuda.Event()
+            done.record(stream)
+        return DecodeLanes.Ticket(tensors, done)
+
+
 def grow_connection_blend(caf, x, y, s, filter_sigmas=1.0, only_max=False):
     """``torch.ops.openpifpaf_decoder.grow_connection_blend`` (module.cpp:55) -> [x, y, s, v]."""
     caf, _ = _prep(caf)

@@ -217,11 +217,15 @@ class Predictor:
     base_name = 'resnet50'
     channels_last = True
     dtype = torch.float32          #: backbone compute dtype (heads always emit float32 fields)
+    conv1x1_choices = None         #: a ``fused.choices()`` table to adopt (multi-rank jobs: rank 0's, so all ranks run the same kernels)
 
     def __init__(self, checkpoint=None, head_metas=None, *, model=None, json_data=False):
         if checkpoint is not None and model is None:
             self.base_name = str(checkpoint)
         self.json_data = json_data
+        if self.conv1x1_choices is not None:
+            from . import fused
+            fused.set_choices(self.conv1x1_choices, replace=True)
         self.model_cpu = model if model is not None else network.factory(self.base_name, head_metas)
         self.model = self.model_cpu.to(self.device)
         if self.channels_last and self.device.type == 'cuda':

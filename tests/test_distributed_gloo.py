@@ -40,6 +40,12 @@ WORKER = textwrap.dedent('''
     for g, (pa, pi) in enumerate(per_image):
         assert len(pa) == g %% (max_ann + 1)
         assert (pa == g + 1).all() and (pi == g).all()
+    # every rank adopts rank 0's table of 1x1-convolution kernel choices (the paths round differently)
+    from openpifpaf_amd import fused
+    key = ('torch.float32', 32 * 81 * 81, 64, 256, True, False)
+    fused.set_choices({key: 'gemm' if rank == 0 else 'conv', ('only-on', rank): 'conv'}, replace=True)
+    table = D.broadcast_conv_choices()
+    assert table == {key: 'gemm', ('only-on', 0): 'conv'} and fused.choices() == table, table
     dist.barrier()
     dist.destroy_process_group()
     print('rank', rank, 'ok')

@@ -133,7 +133,7 @@ def test_resnet50_float32_fused_gemm_forward_equals_unfused():
             network.optimize_for_inference_(net)
             net = net.to(memory_format=torch.channels_last)
             got = net(x.contiguous(memory_format=torch.channels_last))
-        assert any(k[1] == 'torch.float32' and v == 'gemm' for k, v in fused.choices().items())
+        assert any(k[0] == 'torch.float32' and v == 'gemm' for k, v in fused.choices().items())
     finally:
         if old is None:
             os.environ.pop('OPA_CONV1X1', None)

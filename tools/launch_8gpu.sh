@@ -1,5 +1,7 @@
 #!/bin/bash
-# The 8-GPU form of BASELINE configs[4] (256 images = 32 per GPU, one rank per MI355X, RCCL over xGMI):
+# N-GPU bench runs (one rank per MI355X, RCCL over xGMI; images shard one batch per GPU).  Default: the headline, config 2
+# (resnet50, 32 images per GPU).  BASELINE configs[4] (shufflenetv2k16, 256 images = 32 per GPU on 8 GPUs) is
+#     bash tools/launch_8gpu.sh 8 --config 3
 #     bash tools/launch_8gpu.sh [N] [extra bench.py flags]
 # This is exactly what the driver runs for its scaling curve (N = 1, 2, 4, 8).
 N=${1:-8}; shift || true
