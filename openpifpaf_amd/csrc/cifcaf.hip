@@ -107,7 +107,8 @@ __device__ __forceinline__ void ph_stamp(int k) {
 struct ImageCtx {
     int K, A, F;                         // F = occupancy fields = n_cif
     int wave;
-    const int32_t *adj_off, *adj_other, *adj_bone, *adj_fwd, *adj_first;
+    const int32_t *adj_off, *slot_info, *adj_first;   // LDS: adjacency range of a joint; per directed-bone slot: start | other << 8 |
+                                                      // bone << 16 | forward << 24; first slot of the same (start, other) pair
     const float* lists; const int32_t* list_counts; int list_cap;
     unsigned* occ; int occ_h, occ_w, occ_wpr;   // occupancy bitmap [F][occ_h][occ_wpr] (one bit per cell)
     const int* cancel;                   // this grower's cancel flag in LDS (polled between frontier pops), or null
@@ -119,14 +120,16 @@ struct ImageCtx {
     int my_epoch;
     unsigned* shadow_mine;               // [64] bit r of word l: pool slot (r, l) lies in a box this grower published
     int my_idx;                          // index of the seed being grown
+    const int* head_g; int prio;         // LDS: the grower that holds the HEAD seed (or -1); whether this wave runs at raised priority
     // private LDS (one block per growing wave)
     float* tgt;                          // [3][kBlendChunks][64] target columns of the list being scanned
     struct OccBox* jbox;                 // occupancy boxes of the grown pose [K]
     double* jv; float *jx, *jy, *js;     // current pose [K]
-    unsigned long long* heap;            // [4A] nodes: float bits of max_score << 32 | entry id
-    double* e_v; float *e_x, *e_y, *e_s; int* e_se;   // frontier entry pool [4A]
+    unsigned long long* heap;            // [2A] nodes: float bits of max_score << 32 | slot
+    double* e_v; float *e_x, *e_y, *e_s;   // LDS variant: the frontier entry of every directed-bone slot [2A] (v == 0: not computed yet)
     unsigned char* in_frontier;          // [2A]
-    int heap_n, n_entries;
+    int heap_n;
+    int max_r;                           // chunks of a list the LDS target area holds (8, or 2 when LDS is short)
     // shared LDS
     const float4* bbox;                  // [2A][kListBboxChunks] chunk boxes of the active list set, or null
     const float4* gbbox; int nb;         // global memory: [2A][nb] boxes of every chunk of the active list set, or null
@@ -345,7 +348,7 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
         if (have) sc = score_of(q, x1[0], y1[0], cc[0]);
         pos = lane;
     } else {
-        float* cx = tgt + kTgtFloats; float* cy = cx + kWave; float* cv = cy + kWave; int* ci = (int*)(cv + kWave);
+        float* cx = tgt + 3 * R * kWave; float* cy = cx + kWave; float* cv = cy + kWave; int* ci = (int*)(cv + kWave);   // behind the R chunks' targets
         const unsigned long long below = (1ull << lane) - 1ull;
         int cnt = 0;
 #pragma unroll
@@ -467,15 +470,15 @@ __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const B
 // returned by value in registers.
 __device__ __forceinline__ BlendResult blend_impl(const float* base, int cap, int n, double x, double y,
                                                double xy_scale, double filter_sigmas, int only_max, float* tgt,
-                                               int* t_mem = nullptr) {
+                                               int* t_mem = nullptr, int max_r = kBlendChunks) {
     if (n <= 0) return blend_none();
     ListView L; L.base = base; L.cap = cap; L.n = n; L.bbox = nullptr; L.gbbox = nullptr; L.nb = 0;
     const BlendQuery q = make_query(x, y, xy_scale, filter_sigmas);
     if (n <= kWave) return blend_cached<1>(L, q, only_max != 0, tgt, t_mem);
     BlendResult r = blend_overflow();
     if (n <= 2 * kWave) r = blend_cached<2>(L, q, only_max != 0, tgt, t_mem);
-    else if (n <= 4 * kWave) r = blend_cached<4>(L, q, only_max != 0, tgt, t_mem);
-    else if (n <= kBlendChunks * kWave) r = blend_cached<kBlendChunks>(L, q, only_max != 0, tgt, t_mem);
+    else if (n <= 4 * kWave && max_r >= 4) r = blend_cached<4>(L, q, only_max != 0, tgt, t_mem);
+    else if (n <= kBlendChunks * kWave && max_r >= kBlendChunks) r = blend_cached<kBlendChunks>(L, q, only_max != 0, tgt, t_mem);
     if (r.ok >= 0) return r;
     return blend_streamed(L, q, only_max != 0);
 }
@@ -726,17 +729,17 @@ __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, dou
     }
 #ifdef OPA_ASSOC_SCAN_TIMING            // four clock reads per scan: diagnostic builds only (tools/gpu/assoc_probe.py)
     const long long t0 = wall_clock64();
-    const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt, &c.t_blend_mem);
+    const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt, &c.t_blend_mem, c.max_r);
     c.t_blend += (int)(wall_clock64() - t0);
     return r;
 #else
 #ifdef OPA_ASSOC_PHASE_TIMING
     PH(17);
-    const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt);
+    const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt, nullptr, c.max_r);
     PH(6);
     return r;
 #else
-    return blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt);
+    return blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt, nullptr, c.max_r);
 #endif
 #endif
 }
@@ -751,6 +754,13 @@ __device__ __forceinline__ bool poll_task(ImageCtx& c) {
     if (!c.cancel) return false;
     const unsigned long long ce = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(c.cancel), __ATOMIC_RELAXED,
                                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+    // The commit waits for the growth of the HEAD seed and for nothing else, and twelve waves share the issue slots of
+    // one compute unit: the grower that holds the head runs at raised priority, speculative growths take what is left.
+    const int want = c.head_g && flag_peek(c.head_g) == c.wave ? 1 : 0;
+    if (want != c.prio) {
+        if (want) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
+        c.prio = want;
+    }
     if ((int)ce) return true;
     if (c.epoch && (int)(ce >> 32) != c.my_epoch) pool_catch_up(c, (int)(ce >> 32));
     return false;
@@ -806,21 +816,18 @@ __device__ __forceinline__ int heap_pop(ImageCtx& c) {          // returns the t
     return top;
 }
 
-__device__ __forceinline__ int new_entry(ImageCtx& c, double v, float x, float y, float s, int start, int end) {
-    const int e = c.n_entries++;
-    c.e_v[e] = v; c.e_x[e] = x; c.e_y[e] = y; c.e_s[e] = s;
-    c.e_se[e] = (start << 16) | end;
-    return e;
-}
+// LDS variant of the growth state (skeletons past 64 joints / 64 directed bones).  Like in the register variant
+// below, the frontier entry of a directed bone lives in ITS slot: an entry is popped before it is pushed again
+// (cifcaf.cpp:298-303) and in_frontier admits a bone once (:329), so 2A entries and heap nodes suffice (round 2
+// appended entries to a pool of 4A and searched the adjacency for the slot at every evaluation).
 
-// cifcaf.cpp:349-411 ; t = adjacency slot of (start -> end)
+// cifcaf.cpp:349-411 for the directed bone `info` (its first slot: the bone _connection_value's scan finds, :361-374)
 template <bool LONG>
-__device__ __forceinline__ bool connection_value(ImageCtx& c, const DevParams& p, int start, int t,
+__device__ __forceinline__ bool connection_value(ImageCtx& c, const DevParams& p, int info,
                                  bool reverse_match_, double filter_sigmas,
                                  double* nv, float* nx, float* ny, float* ns) {
-    const int bone = c.adj_bone[t], fwd = c.adj_fwd[t];
+    const int start = info & 0xff, bone = (info >> 16) & 0xff, fwd = (info >> 24) & 1;
     const ListView caf_f = list_view(c, bone, fwd ? 0 : 1);
-    const ListView caf_b = list_view(c, bone, fwd ? 1 : 0);
     const double sv = c.jv[start], sx = (double)c.jx[start], sy = (double)c.jy[start], ss = (double)c.js[start];
     const BlendResult nj = blend<LONG>(c, caf_f, sx, sy, ss, filter_sigmas);
     if (!nj.ok) return false;
@@ -828,6 +835,7 @@ __device__ __forceinline__ bool connection_value(ImageCtx& c, const DevParams& p
     *nv = sqrt(nj.v * sv);                                                      // :386
     if (*nv < p.keypoint_threshold || *nv < sv * p.keypoint_threshold_rel) return false;   // :387-390
     if (p.reverse_match && reverse_match_ && start < c.F) {                     // :397
+        const ListView caf_b = list_view(c, bone, fwd ? 1 : 0);
         const BlendResult rj = blend<LONG>(c, caf_b, (double)*nx, (double)*ny, (double)*ns, filter_sigmas);
         if (!rj.ok) return false;
         if (fabs(sx - (double)rj.x) + fabs(sy - (double)rj.y) > ss) return false;   // :404
@@ -835,65 +843,87 @@ __device__ __forceinline__ bool connection_value(ImageCtx& c, const DevParams& p
     return true;
 }
 
-// cifcaf.cpp:316-346
+// cifcaf.cpp:316-346: the bones leaving `start` whose other end is still empty and that are not in the frontier yet
+// are found by all lanes at once (lane = adjacency slot), then pushed in bone order like the reference's loop.  A
+// second bone between the same two joints never gets in: it shares the pair's in_frontier entry with the first.
 __device__ __forceinline__ void frontier_add_from(ImageCtx& c, int start) {
     const float max_score = (float)sqrt(c.jv[start]);
-    for (int t = c.adj_off[start]; t < c.adj_off[start + 1]; t++) {
-        const int other = c.adj_other[t];
-        if (c.jv[other] > 0.0) continue;
-        const int first = c.adj_first[t];
-        if (c.in_frontier[first]) continue;
-        heap_push(c, max_score, new_entry(c, 0.0, 0.f, 0.f, 0.f, start, other));
-        c.in_frontier[first] = 1;
+    const int t0 = c.adj_off[start], t1 = c.adj_off[start + 1];
+    const int lane = lane_id();
+    for (int base = t0; base < t1; base += kWave) {
+        const int t = base + lane;
+        bool cand = false;
+        if (t < t1) {
+            const int other = (c.slot_info[t] >> 8) & 0xff;
+            cand = c.adj_first[t] == t && !(c.jv[other] > 0.0) && !c.in_frontier[t];
+        }
+        unsigned long long m = __ballot(cand);
+        while (m) {
+            const int tt = base + __builtin_ctzll(m);
+            m &= m - 1;
+            c.e_v[tt] = 0.0;
+            heap_push(c, max_score, tt);
+            c.in_frontier[tt] = 1;
+        }
     }
 }
 
-__device__ __forceinline__ void frontier_reset(ImageCtx& c) {
+__device__ __forceinline__ void frontier_start(ImageCtx& c) {
     const int lane = lane_id();
     for (int t = lane; t < 2 * c.A; t += kWave) c.in_frontier[t] = 0;
-    c.heap_n = 0; c.n_entries = 0;
+    c.heap_n = 0;
     wave_sync();
-}
-
-__device__ __forceinline__ int find_adj_slot(const ImageCtx& c, int start, int end) {
-    for (int t = c.adj_off[start]; t < c.adj_off[start + 1]; t++)
-        if (c.adj_other[t] == end) return c.adj_first[t];
-    return -1;
+    for (int j0 = 0; j0 < c.K; j0 += kWave) {
+        unsigned long long filled = __ballot(j0 + lane < c.K && c.jv[j0 + lane < c.K ? j0 + lane : 0] != 0.0);
+        while (filled) {
+            const int j = j0 + __builtin_ctzll(filled);
+            filled &= filled - 1;
+            frontier_add_from(c, j);
+        }
+    }
 }
 
 // cifcaf.cpp:265-313 -- one wavefront, no workgroup barriers
 template <bool LONG>
 __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool reverse_match_, double filter_sigmas) {
-    frontier_reset(c);
-    for (int j = 0; j < c.K; j++) if (c.jv[j] != 0.0) frontier_add_from(c, j);
+    frontier_start(c);
     while (c.heap_n > 0) {
         if (poll_task(c)) { c.aborted = 1; return; }                     // the seed died while its pose grew
-        const int e = heap_pop(c);
-        const int start = c.e_se[e] >> 16, end = c.e_se[e] & 0xffff;
-        if (c.jv[end] > 0.0) continue;                                   // :284
-        double v = c.e_v[e]; float x = c.e_x[e], y = c.e_y[e], s = c.e_s[e];
+        const int slot = heap_pop(c);
+        const int info = c.slot_info[slot];
+        const int end = (info >> 8) & 0xff;
+        if (c.jv[end] > 0.0) { PH(0); continue; }                        // :284
+        double v = c.e_v[slot]; float x = c.e_x[slot], y = c.e_y[slot], s = c.e_s[slot];
+        PH(0);
         if (v == 0.0) {                                                  // :287: not computed yet
-            const int slot = find_adj_slot(c, start, end);
-            if (!connection_value<LONG>(c, p, start, slot, reverse_match_, filter_sigmas, &v, &x, &y, &s))
+            if (!connection_value<LONG>(c, p, info, reverse_match_, filter_sigmas, &v, &x, &y, &s)) {
+                PH(7);
                 continue;                                                // :290-296 (block_joints is a no-op)
+            }
+            PH(7);
             if (!p.greedy) {                                             // :298-303
-                heap_push(c, (float)v, new_entry(c, v, x, y, s, start, end));
+                c.e_v[slot] = v; c.e_x[slot] = x; c.e_y[slot] = y; c.e_s[slot] = s;
+                heap_push(c, (float)v, slot);
+                PH(8);
                 continue;
             }
         }
         c.jv[end] = v; c.jx[end] = x; c.jy[end] = y; c.js[end] = s;     // :310
+        PH(9);
         publish_joint(c, p, end, x, y, s);
+        PH(10);
         frontier_add_from(c, end);
+        PH(11);
     }
 }
 
 // cifcaf.cpp:429-449
 __device__ __forceinline__ void flood_fill(ImageCtx& c) {
-    frontier_reset(c);
-    for (int j = 0; j < c.K; j++) if (c.jv[j] != 0.0) frontier_add_from(c, j);
+    frontier_start(c);
     while (c.heap_n > 0) {
-        const int e = heap_pop(c);
-        const int start = c.e_se[e] >> 16, end = c.e_se[e] & 0xffff;
+        const int slot = heap_pop(c);
+        const int info = c.slot_info[slot];
+        const int start = info & 0xff, end = (info >> 8) & 0xff;
         if (c.jv[end] > 0.0) continue;
         c.jv[end] = 0.00001; c.jx[end] = c.jx[start]; c.jy[end] = c.jy[start]; c.js[end] = c.js[start];
         frontier_add_from(c, end);
@@ -1205,12 +1235,32 @@ __device__ __forceinline__ void pool_catch_up(ImageCtx& c, int e) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (the epoch was read relaxed: the pool mirror written before it)
     const int lane = lane_id();
     unsigned bits = 0u;
+    // four slots at a time, straight-line: their twelve pool words are ONE LDS round trip, their four boxes a second one
+    // (inside the `if`s of a per-slot loop the compiler waited for every load on its own: 24 round trips per call)
 #pragma unroll
-    for (int r = 0; r < kPoolSlots; r++) {
-        const int ep = c.pool_ep[r * kWave + lane], sif = c.pool_if[r * kWave + lane], spk = c.pool_pack[r * kWave + lane];
-        const int f = (int)((unsigned)sif >> 24), idx = sif & kPoolIdxMask;
-        if (ep - c.my_epoch > 0 && idx != kPoolIdxMask && idx > c.my_idx && f < c.F &&
-            box_contains(c.jbox[f], spk & 0xfff, (spk >> 12) & 0xfff)) bits |= 1u << r;
+    for (int r0 = 0; r0 < kPoolSlots; r0 += 4) {
+        int ep[4], sif[4], spk[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            ep[r] = c.pool_ep[(r0 + r) * kWave + lane]; sif[r] = c.pool_if[(r0 + r) * kWave + lane];
+            spk[r] = c.pool_pack[(r0 + r) * kWave + lane];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) asm volatile("" : "+v"(ep[r]), "+v"(sif[r]), "+v"(spk[r]) :: "memory");
+        OccBox bx[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int f = (int)((unsigned)sif[r] >> 24);
+            bx[r] = c.jbox[f < c.F ? f : 0];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) asm volatile("" : "+v"(bx[r].minx), "+v"(bx[r].miny), "+v"(bx[r].maxx), "+v"(bx[r].maxy) :: "memory");
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int f = (int)((unsigned)sif[r] >> 24), idx = sif[r] & kPoolIdxMask;
+            if (ep[r] - c.my_epoch > 0 && idx != kPoolIdxMask && idx > c.my_idx && f < c.F &&
+                box_contains(bx[r], spk[r] & 0xfff, (spk[r] >> 12) & 0xfff)) bits |= 1u << (r0 + r);
+        }
     }
     if (bits) atomicOr(&c.shadow_mine[lane], bits);
     c.my_epoch = e;
@@ -1224,27 +1274,61 @@ __device__ __forceinline__ bool occ_test(const ImageCtx& c, int f, int xi, int y
     return (w >> (xi & 31)) & 1u;
 }
 
-// Private LDS block of one growing wave (pose boxes + pose + frontier); kept 16-byte sized.
-__host__ __device__ inline size_t assoc_private_bytes(int K, int A) {
-    const int P4 = 4 * A, E = 2 * A;
-    const size_t b = 16 * (size_t)K + sizeof(double) * (K + P4) + sizeof(unsigned long long) * P4
-                   + sizeof(float) * (3 * K + 3 * P4) + sizeof(int) * P4 + (E + 15) / 16 * 16;
-    return (b + 15) / 16 * 16 + sizeof(float) * kBlendLdsFloats;               // + blend target columns and compaction
+// Private LDS block of one growing wave: the pose's occupancy boxes and the pose (the coordinator reads both at a
+// commit), for the LDS variant the frontier (entries + heap + in_frontier, one per directed-bone slot), and the scan
+// area (`tgt_floats`: kBlendLdsFloats, or kSmallTgtFloats when that buys more growers).  16-byte sized.
+constexpr int kSmallTgtChunks = 2;
+constexpr int kSmallTgtFloats = 3 * kSmallTgtChunks * kWave + 4 * kWave;
+__host__ __device__ inline size_t assoc_pose_bytes(int K) {
+    return (16 * (size_t)K + sizeof(double) * K + sizeof(float) * 3 * K + 15) / 16 * 16;
+}
+__host__ __device__ inline size_t assoc_private_bytes(int K, int A, bool reg, int tgt_floats) {
+    const int E = 2 * A;
+    size_t b = assoc_pose_bytes(K);
+    if (!reg) b += sizeof(double) * E + sizeof(unsigned long long) * E + sizeof(float) * 3 * E + (E + 15) / 16 * 16;
+    return b + sizeof(float) * tgt_floats;
+}
+template <bool REG>
+__device__ __forceinline__ void carve_private(ImageCtx& c, unsigned char* sp, int tgt_floats) {
+    const int K = c.K, E = 2 * c.A;
+    unsigned char* base = sp;
+    c.jbox = (OccBox*)sp; sp += sizeof(OccBox) * K;
+    c.jv = (double*)sp; sp += sizeof(double) * K;
+    c.jx = (float*)sp; sp += sizeof(float) * K;
+    c.jy = (float*)sp; sp += sizeof(float) * K;
+    c.js = (float*)sp; sp += sizeof(float) * K;
+    sp = base + assoc_pose_bytes(K);
+    c.e_v = nullptr; c.heap = nullptr; c.e_x = c.e_y = c.e_s = nullptr; c.in_frontier = nullptr;
+    if constexpr (!REG) {
+        c.e_v = (double*)sp; sp += sizeof(double) * E;
+        c.heap = (unsigned long long*)sp; sp += sizeof(unsigned long long) * E;
+        c.e_x = (float*)sp; sp += sizeof(float) * E;
+        c.e_y = (float*)sp; sp += sizeof(float) * E;
+        c.e_s = (float*)sp; sp += sizeof(float) * E;
+        c.in_frontier = sp; sp += (E + 15) / 16 * 16;
+    }
+    c.tgt = (float*)sp;
+    c.max_r = tgt_floats >= kBlendLdsFloats ? kBlendChunks : kSmallTgtChunks;
+    c.heap_n = 0;
 }
 
 // LDS scratch of one wave during keypoint NMS (aliases the growth state): a box and a cell per pose
 __host__ __device__ inline size_t nms_scratch_bytes(int max_ann) {
     return (sizeof(int) * 4 + sizeof(int) * 2) * (size_t)max_ann;
 }
+// ... behind the arrays all waves share during the NMS: score, suppression bits, order, rank
+__host__ __device__ inline size_t nms_shared_bytes(int max_ann, int K) {
+    const int KC = (K + kWave - 1) / kWave;
+    return (sizeof(double) * max_ann + sizeof(unsigned long long) * (size_t)max_ann * KC + sizeof(int) * 2 * max_ann + 15) / 16 * 16;
+}
 
 struct PoseView { const OccBox* box; const double* v; const float *x, *y, *s; };
 
-__device__ __forceinline__ PoseView pose_of_block(unsigned char* private_base, int block, int K, int A) {
-    unsigned char* sp = private_base + (size_t)block * assoc_private_bytes(K, A);
-    const int P4 = 4 * A;
+__device__ __forceinline__ PoseView pose_of_block(unsigned char* private_base, int block, size_t private_bytes, int K) {
+    unsigned char* sp = private_base + (size_t)block * private_bytes;
     PoseView q;
     q.box = (const OccBox*)sp; sp += sizeof(OccBox) * K;
-    q.v = (const double*)sp; sp += sizeof(double) * (K + P4) + sizeof(unsigned long long) * P4;
+    q.v = (const double*)sp; sp += sizeof(double) * K;
     q.x = (const float*)sp; q.y = q.x + K; q.s = q.y + K;
     return q;
 }
@@ -1305,6 +1389,18 @@ constexpr long long kWatchdogTicksDefault = 100000000ll;   // (OPA_ASSOC_WATCHDO
 // ---- keypoint NMS + output (nms_keypoints.cpp:17-70, cifcaf.cpp:246-261), by all threads of a workgroup, on the
 // poses stored in the HBM scratch `anns`.  Shared by the seed kernel (default flags) and the force-complete kernel.
 struct NmsLds { double* nms_score; unsigned long long* nms_supp; int* nms_order; int* nms_rank; unsigned char* work_base; };
+// the NMS arrays alias the work area (the growers' private blocks are free by then): shared arrays first, then one
+// scratch block per wave
+__device__ __forceinline__ NmsLds nms_carve(unsigned char* work_base, int max_ann, int K) {
+    const int KC = (K + kWave - 1) / kWave;
+    NmsLds l; unsigned char* sp = work_base;
+    l.nms_score = (double*)sp; sp += sizeof(double) * max_ann;
+    l.nms_supp = (unsigned long long*)sp; sp += sizeof(unsigned long long) * (size_t)max_ann * KC;
+    l.nms_order = (int*)sp; sp += sizeof(int) * max_ann;
+    l.nms_rank = (int*)sp;
+    l.work_base = work_base + nms_shared_bytes(max_ann, K);
+    return l;
+}
 template <int kThreads>
 __device__ __forceinline__ void nms_and_store(const AssocArgs& a, const DevParams& p, const ImageCtx& c, const NmsLds& l, int b,
                                               int n_kept, int n_dropped, bool failed, double* anns, const int64_t* ann_ids,
@@ -1421,14 +1517,13 @@ __device__ __forceinline__ void nms_and_store(const AssocArgs& a, const DevParam
 
 template <bool REG, int NW>
 __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a, DevSkeleton sk, DevParams p,
-                                                                     int n_growers, int nms_waves) {
+                                                                     int n_growers, int nms_waves, int tgt_floats) {
     constexpr int kThreads = NW * kWave;
     const bool use_bbox = REG && a.list_bbox != nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int K = a.K, A = a.A, E = 2 * A, P4 = 4 * A;
-    const int KC = (K + kWave - 1) / kWave;          // 64-joint chunks per pose
+    const int K = a.K, A = a.A, E = 2 * A;
     const int S = n_growers;                         // growers = waves 1..S, each with a private LDS block
     const long long t_kernel = wall_clock64();
     const long long kWatchdogTicks = a.watchdog_ticks;
@@ -1443,26 +1538,21 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
     c.pool_if = nullptr; c.pool_pack = nullptr; c.shadow_mine = nullptr; c.my_idx = 0;
     c.pool_ep = nullptr; c.epoch = nullptr; c.ack = nullptr; c.my_epoch = 0;
+    c.head_g = nullptr; c.prio = 0;
     c.bbox = nullptr;
     c.nb = a.bbox_chunks;
     c.gbbox = a.list_bbox ? reinterpret_cast<const float4*>(a.list_bbox) + (size_t)b * 2 * a.A * a.bbox_chunks : nullptr;
 
-    // ---- LDS carve: shared part, then one private block per growing wave
+    // ---- LDS carve: shared part, then the work area: one private block per growing wave while poses grow, the
+    //      keypoint-NMS arrays afterwards
     unsigned char* sp = smem;
-    double* nms_score = (double*)sp; sp += sizeof(double) * a.max_ann;
-    unsigned long long* nms_supp = (unsigned long long*)sp; sp += sizeof(unsigned long long) * a.max_ann * KC;
-    TaskSlot* task = (TaskSlot*)sp; sp += sizeof(TaskSlot) * NW;
+    TaskSlot* task = (TaskSlot*)sp; sp += sizeof(TaskSlot) * NW;            // (16-byte aligned: first)
     c.sh_counts = (int*)sp; sp += sizeof(int) * E;
     int* l_off = (int*)sp; sp += sizeof(int) * (K + 1);
-    int* l_other = (int*)sp; sp += sizeof(int) * E;
-    int* l_bone = (int*)sp; sp += sizeof(int) * E;
-    int* l_fwd = (int*)sp; sp += sizeof(int) * E;
+    int* l_info = (int*)sp; sp += sizeof(int) * E;
     int* l_first = (int*)sp; sp += sizeof(int) * E;
-    if ((K + 1) & 1) sp += sizeof(int);             // keep 8-byte alignment for what follows
-    int* nms_order = (int*)sp; sp += sizeof(int) * a.max_ann;
-    int* nms_rank = (int*)sp; sp += sizeof(int) * a.max_ann;
     int* sh_ctl = (int*)sp; sp += sizeof(int) * 12;  // 0 exit flag, 1 n_kept, 2 n_dropped, 3 grower ticks, 4 list scans, 5 watchdog,
-                                                     // 6-7 scan timing (diagnostic builds), 8 refill epoch
+                                                     // 6-7 scan timing (diagnostic builds), 8 refill epoch, 9 grower of the head seed
     int* sh_stats = (int*)sp; sp += sizeof(int) * kAssocStats;
     int* pool_if = (int*)sp; sp += sizeof(int) * kPoolSlots * kWave;        // the coordinator's seed pool, mirrored for the growers
     int* pool_pack = (int*)sp; sp += sizeof(int) * kPoolSlots * kWave;
@@ -1473,23 +1563,10 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     sp = smem + (((size_t)(sp - smem) + 15) & ~(size_t)15);
     float4* sh_bbox = (float4*)sp;                   // chunk boxes of the caf_th lists (register variant only)
     if (use_bbox) sp += sizeof(float4) * E * kListBboxChunks;
-    unsigned char* work_base = sp;                   // growth phase: private blocks; NMS phase: scratch
+    unsigned char* work_base = sp;                   // growth phase: private blocks; NMS phase: its arrays and scratch
     unsigned char* private_base = sp;
-    sp += (size_t)(wave >= 1 && wave <= S ? wave - 1 : 0) * assoc_private_bytes(K, A);   // other waves never touch theirs
-    c.jbox = (OccBox*)sp; sp += sizeof(OccBox) * K;
-    c.jv = (double*)sp; sp += sizeof(double) * K;
-    c.e_v = (double*)sp; sp += sizeof(double) * P4;
-    c.heap = (unsigned long long*)sp; sp += sizeof(unsigned long long) * P4;
-    c.jx = (float*)sp; sp += sizeof(float) * K;
-    c.jy = (float*)sp; sp += sizeof(float) * K;
-    c.js = (float*)sp; sp += sizeof(float) * K;
-    c.e_x = (float*)sp; sp += sizeof(float) * P4;
-    c.e_y = (float*)sp; sp += sizeof(float) * P4;
-    c.e_s = (float*)sp; sp += sizeof(float) * P4;
-    c.e_se = (int*)sp; sp += sizeof(int) * P4;
-    c.in_frontier = sp; sp += (E + 15) / 16 * 16;
-    c.tgt = (float*)sp;
-    c.heap_n = 0; c.n_entries = 0;
+    const size_t private_bytes = assoc_private_bytes(K, A, REG, tgt_floats);
+    carve_private<REG>(c, private_base + (size_t)(wave >= 1 && wave <= S ? wave - 1 : 0) * private_bytes, tgt_floats);   // other waves never touch theirs
 
     // the image's occupancy bitmap starts empty (cifcaf.cpp:173); 16-byte stores, region is 256-B aligned
     {
@@ -1500,7 +1577,10 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     // list lengths and the skeleton adjacency are consulted at every step of the search: keep them in LDS
     for (int k = tid; k < E; k += kThreads) {
         c.sh_counts[k] = c.list_counts[k];
-        l_other[k] = sk.adj_other[k]; l_bone[k] = sk.adj_bone[k]; l_fwd[k] = sk.adj_fwd[k]; l_first[k] = sk.adj_first[k];
+        int lo = 0, hi = K;                          // the joint whose adjacency range holds slot k
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sk.adj_off[mid] <= k) lo = mid; else hi = mid; }
+        l_info[k] = lo | (sk.adj_other[k] << 8) | (sk.adj_bone[k] << 16) | (sk.adj_fwd[k] << 24);
+        l_first[k] = sk.adj_first[k];
     }
     for (int k = tid; k <= K; k += kThreads) l_off[k] = sk.adj_off[k];
     if (use_bbox) {                                  // the first kListBboxChunks boxes of every caf_th list
@@ -1517,23 +1597,18 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         t.t_emit = t.t_done = t.pad0 = t.pad1 = t.pad2 = 0;
         task[tid] = t;
     }
-    if (tid < 12) sh_ctl[tid] = 0;
+    if (tid < 12) sh_ctl[tid] = tid == 9 ? -1 : 0;   // (9: the grower holding the head seed)
 #ifdef OPA_ASSOC_PHASE_TIMING
     if (tid < kPhases) { g_ph[tid] = 0; g_phn[tid] = 0; }
     if (tid < 16) g_ph_last[tid] = clock64();
 #endif
     for (int k = tid; k < kPoolSlots * kWave; k += kThreads) { pool_if[k] = kPoolIdxMask; pool_pack[k] = 0; pool_ep[k] = 0; }
     for (int k = tid; k < NW * kWave; k += kThreads) shadow_by[k] = 0u;
-    c.adj_off = l_off; c.adj_other = l_other; c.adj_bone = l_bone; c.adj_fwd = l_fwd; c.adj_first = l_first;
+    c.adj_off = l_off; c.slot_info = l_info; c.adj_first = l_first;
     sync_global();                                   // bitmap zeros are in memory before anyone marks or tests
     RegSkeleton rs; rs.slot_info = 0; rs.slot_first = 0; rs.off = 0; rs.off1 = 0;
     if constexpr (REG) {                             // lane t: directed bone t; lane j: adjacency range of joint j
-        if (lane < E) {
-            int start = 0;
-            while (l_off[start + 1] <= lane) start++;
-            rs.slot_info = start | (l_other[lane] << 8) | (l_bone[lane] << 16) | (l_fwd[lane] << 24);
-            rs.slot_first = l_first[lane];
-        }
+        if (lane < E) { rs.slot_info = l_info[lane]; rs.slot_first = l_first[lane]; }
         if (lane < K) { rs.off = l_off[lane]; rs.off1 = l_off[lane + 1]; }
     }
 
@@ -1545,7 +1620,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     // Coordinator: accept the pose in private block `blk`: mark its joints in the bitmap and, unless it
     // cannot survive NMS, store it at slot n_kept.
     auto accept_pose = [&](int blk, double score, long long id) {
-        const PoseView q = pose_of_block(private_base, blk, K, A);
+        const PoseView q = pose_of_block(private_base, blk, private_bytes, K);
         occ_mark_pose(c, q);
         if (prune && score < p.nms_instance_threshold) return;
         if (n_kept >= a.max_ann) { n_dropped++; return; }
@@ -1607,6 +1682,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         unsigned gmap = 0u;
         int scan_pos = 0, n_live = 0;
         bool watchdog = false, marks_pending = false;
+        int last_hg = -1;                                // what sh_ctl[9] says
         int epoch = 0;                                   // refills so far; `unver`: slots filled by refills not every candidate in flight has tested yet
         unsigned unver = 0u;
         long long wait_ticks = 0;
@@ -1846,6 +1922,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 const unsigned long long m = __ballot(mine >= 0);
                 if (m) hg = rlane(mine, __builtin_ctzll(m));
             }
+            if (hg != last_hg) { if (lane == 0) __hip_atomic_store(&sh_ctl[9], hg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); last_hg = hg; }
             if (hg < 0) {
                 // A head that was never handed out, or whose growth was stopped by a prediction that did not
                 // come true.  It is never shadowed (a live candidate shadowing it would be the head), so step 4
@@ -1878,7 +1955,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             const long long t_cm = wall_clock64();
 
             // ---- 6. commit: the head's pose is accepted (:213-230)
-            const PoseView q = pose_of_block(private_base, hg - 1, K, A);
+            const PoseView q = pose_of_block(private_base, hg - 1, private_bytes, K);
             unsigned dead = 0u;                          // pooled seeds inside one of its joint boxes (:211 for them)
             {
                 OccBox bb[WR];
@@ -1963,7 +2040,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 if (state == kTaskDone && c.epoch) { const int e = flag_load(c.epoch); if (e != c.my_epoch) pool_catch_up(c, e); }
                 else c.epoch = nullptr;
                 if (state == kTaskAccepted) {            // the pose this wave grew was accepted: Occupancy::set + store
-                    const PoseView q = pose_of_block(private_base, wave - 1, K, A);
+                    const PoseView q = pose_of_block(private_base, wave - 1, private_bytes, K);
                     const int slot = __builtin_amdgcn_readfirstlane(my->pad0);
                     occ_mark_pose(c, q);
                     if (slot >= 0) {
@@ -1999,7 +2076,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             c.aborted = 0;
             c.pub = &my->npub; c.n_pub = 0; c.my_idx = mine;
             c.pool_if = pool_if; c.pool_pack = pool_pack; c.shadow_mine = shadow_by + wave * kWave;
-            c.pool_ep = pool_ep; c.epoch = &my->epoch; c.ack = &my->pad1;
+            c.pool_ep = pool_ep; c.epoch = &my->epoch; c.ack = &my->pad1; c.head_g = &sh_ctl[9];
             c.my_epoch = flag_load(c.epoch);             // publish_joint tests the whole pool as of now; later refills: pool_catch_up
             if (lane == 0) flag_store(c.ack, c.my_epoch);
             publish_joint(c, p, sf, sd.y, sd.z, sd.w);   // the seed joint's own box: the rest of its blob
@@ -2007,6 +2084,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             grow_pose<REG>(c, p, rs, true, 1.0, false);
             PH(13);
             c.pub = nullptr;
+            if (c.prio) { __builtin_amdgcn_s_setprio(0); c.prio = 0; }
             const int* epoch_ptr = c.epoch;
             c.epoch = nullptr;                           // (pose_boxes rewrites the boxes: no tests in between)
             if (c.aborted) {
@@ -2039,8 +2117,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             meta[0] = n_kept; meta[1] = n_dropped; meta[2] = sh_ctl[5]; meta[3] = 0;
         }
     } else {
-        NmsLds nl; nl.nms_score = nms_score; nl.nms_supp = nms_supp; nl.nms_order = nms_order; nl.nms_rank = nms_rank;
-        nl.work_base = work_base;
+        const NmsLds nl = nms_carve(work_base, a.max_ann, K);
         nms_and_store<kThreads>(a, p, c, nl, b, n_kept, n_dropped, sh_ctl[5] != 0, anns, ann_ids, nms_waves);
     }
     if (tid == 0 && a.stats) {
@@ -2066,8 +2143,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_fc_kernel(AssocArgs a, D
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x / S, part = blockIdx.x - b * S, tid = threadIdx.x, lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int K = a.K, A = a.A, E = 2 * A, P4 = 4 * A;
-    const int KC = (K + kWave - 1) / kWave;
+    const int K = a.K, A = a.A, E = 2 * A;
     int* meta = a.fc_meta + (size_t)b * 4;
     const int n_kept = meta[0], n_dropped = meta[1], failed = meta[2];
 
@@ -2081,56 +2157,35 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_fc_kernel(AssocArgs a, D
     c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
     c.pool_if = nullptr; c.pool_pack = nullptr; c.shadow_mine = nullptr; c.my_idx = 0;
     c.pool_ep = nullptr; c.epoch = nullptr; c.ack = nullptr; c.my_epoch = 0;
+    c.head_g = nullptr; c.prio = 0;
     c.bbox = nullptr;
     c.nb = a.bbox_chunks;
     c.gbbox = a.list_bbox_fc ? reinterpret_cast<const float4*>(a.list_bbox_fc) + (size_t)b * E * a.bbox_chunks : nullptr;
 
     unsigned char* sp = smem;
-    NmsLds nl;
-    nl.nms_score = (double*)sp; sp += sizeof(double) * a.max_ann;
-    nl.nms_supp = (unsigned long long*)sp; sp += sizeof(unsigned long long) * a.max_ann * KC;
     c.sh_counts = (int*)sp; sp += sizeof(int) * E;
     int* l_off = (int*)sp; sp += sizeof(int) * (K + 1);
-    int* l_other = (int*)sp; sp += sizeof(int) * E;
-    int* l_bone = (int*)sp; sp += sizeof(int) * E;
-    int* l_fwd = (int*)sp; sp += sizeof(int) * E;
+    int* l_info = (int*)sp; sp += sizeof(int) * E;
     int* l_first = (int*)sp; sp += sizeof(int) * E;
-    nl.nms_order = (int*)sp; sp += sizeof(int) * a.max_ann;
-    nl.nms_rank = (int*)sp; sp += sizeof(int) * a.max_ann;
     int* sh_last = (int*)sp; sp += sizeof(int) * 4;
     sp = smem + (((size_t)(sp - smem) + 15) & ~(size_t)15);
-    nl.work_base = sp;
-    sp += (size_t)(wave < n_growers ? wave : 0) * assoc_private_bytes(K, A);
-    c.jbox = (OccBox*)sp; sp += sizeof(OccBox) * K;
-    c.jv = (double*)sp; sp += sizeof(double) * K;
-    c.e_v = (double*)sp; sp += sizeof(double) * P4;
-    c.heap = (unsigned long long*)sp; sp += sizeof(unsigned long long) * P4;
-    c.jx = (float*)sp; sp += sizeof(float) * K;
-    c.jy = (float*)sp; sp += sizeof(float) * K;
-    c.js = (float*)sp; sp += sizeof(float) * K;
-    c.e_x = (float*)sp; sp += sizeof(float) * P4;
-    c.e_y = (float*)sp; sp += sizeof(float) * P4;
-    c.e_s = (float*)sp; sp += sizeof(float) * P4;
-    c.e_se = (int*)sp; sp += sizeof(int) * P4;
-    c.in_frontier = sp; sp += (E + 15) / 16 * 16;
-    c.tgt = (float*)sp;
-    c.heap_n = 0; c.n_entries = 0;
+    unsigned char* work_base = sp;                   // the growers' private blocks, then the keypoint-NMS arrays and scratch
+    const size_t private_bytes = assoc_private_bytes(K, A, REG, kBlendLdsFloats);
+    carve_private<REG>(c, work_base + (size_t)(wave < n_growers ? wave : 0) * private_bytes, kBlendLdsFloats);
 
     for (int k = tid; k < E; k += kThreads) {
         c.sh_counts[k] = c.list_counts[k];
-        l_other[k] = sk.adj_other[k]; l_bone[k] = sk.adj_bone[k]; l_fwd[k] = sk.adj_fwd[k]; l_first[k] = sk.adj_first[k];
+        int lo = 0, hi = K;                          // the joint whose adjacency range holds slot k
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sk.adj_off[mid] <= k) lo = mid; else hi = mid; }
+        l_info[k] = lo | (sk.adj_other[k] << 8) | (sk.adj_bone[k] << 16) | (sk.adj_fwd[k] << 24);
+        l_first[k] = sk.adj_first[k];
     }
     for (int k = tid; k <= K; k += kThreads) l_off[k] = sk.adj_off[k];
-    c.adj_off = l_off; c.adj_other = l_other; c.adj_bone = l_bone; c.adj_fwd = l_fwd; c.adj_first = l_first;
+    c.adj_off = l_off; c.slot_info = l_info; c.adj_first = l_first;
     __syncthreads();
     RegSkeleton rs; rs.slot_info = 0; rs.slot_first = 0; rs.off = 0; rs.off1 = 0;
     if constexpr (REG) {
-        if (lane < E) {
-            int start = 0;
-            while (l_off[start + 1] <= lane) start++;
-            rs.slot_info = start | (l_other[lane] << 8) | (l_bone[lane] << 16) | (l_fwd[lane] << 24);
-            rs.slot_first = l_first[lane];
-        }
+        if (lane < E) { rs.slot_info = l_info[lane]; rs.slot_first = l_first[lane]; }
         if (lane < K) { rs.off = l_off[lane]; rs.off1 = l_off[lane + 1]; }
     }
 
@@ -2160,23 +2215,23 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_fc_kernel(AssocArgs a, D
     __syncthreads();
     if (!sh_last[0]) return;
     __threadfence();
+    const NmsLds nl = nms_carve(work_base, a.max_ann, K);
     nms_and_store<kThreads>(a, p, c, nl, b, failed ? 0 : n_kept, n_dropped, failed != 0, anns, ann_ids, nms_waves);
 }
 
 template <bool REG, int NW>
 static hipError_t launch_fc_nw(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
     const int K = a.K, A = a.A, E = 2 * A;
-    const int KC = (K + kWave - 1) / kWave;
-    const size_t shared = sizeof(double) * a.max_ann + sizeof(unsigned long long) * ((size_t)a.max_ann * KC)
-                        + sizeof(int) * (5 * E + K + 1 + 2 * a.max_ann + 4) + 32;
-    const size_t priv = assoc_private_bytes(K, A);
+    const size_t shared = (sizeof(int) * (3 * E + K + 1 + 4) + 15) / 16 * 16;
+    const size_t priv = assoc_private_bytes(K, A, REG, kBlendLdsFloats);
     const size_t budget = 160 * 1024;
     if (shared + priv > budget) return hipErrorInvalidValue;
     int growers = (int)((budget - shared) / priv);
     if (growers > NW) growers = NW;
     int nms_waves = NW;
-    while (nms_waves > 1 && shared + (size_t)nms_waves * nms_scratch_bytes(a.max_ann) > budget) nms_waves--;
-    const size_t nms = (size_t)nms_waves * nms_scratch_bytes(a.max_ann);
+    const size_t nms_fixed = nms_shared_bytes(a.max_ann, K);
+    while (nms_waves > 1 && shared + nms_fixed + (size_t)nms_waves * nms_scratch_bytes(a.max_ann) > budget) nms_waves--;
+    const size_t nms = nms_fixed + (size_t)nms_waves * nms_scratch_bytes(a.max_ann);
     if (shared + nms > budget) return hipErrorInvalidValue;
     const size_t grow_bytes = (size_t)growers * priv;
     const size_t lds = shared + (grow_bytes > nms ? grow_bytes : nms);
@@ -2198,30 +2253,35 @@ static hipError_t launch_fc_nw(const AssocArgs& a, const DevSkeleton& sk, const 
 template <bool REG, int NW>
 static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
     const int K = a.K, A = a.A, E = 2 * A;
-    const int KC = (K + kWave - 1) / kWave;
-    const size_t shared = sizeof(double) * a.max_ann
-                        + sizeof(unsigned long long) * ((size_t)a.max_ann * KC)
-                        + sizeof(TaskSlot) * NW
-                        + sizeof(int) * (5 * E + K + 2 + 2 * a.max_ann + 12 + kAssocStats)
-                        + sizeof(int) * (3 * kPoolSlots + NW) * kWave + 32 + sizeof(int) * 2 * kSeedStage
-                        + (REG && a.list_bbox ? sizeof(float4) * E * kListBboxChunks : 0);
-    // work area behind it: one private block per grower while poses grow, the keypoint-NMS scratch afterwards
-    const size_t priv = assoc_private_bytes(K, A);
+    size_t shared = sizeof(TaskSlot) * NW + sizeof(int) * (3 * E + K + 1 + 12 + kAssocStats)
+                  + sizeof(int) * (3 * kPoolSlots + NW) * kWave + sizeof(int) * 2 * kSeedStage;
+    shared = (shared + 15) / 16 * 16 + (REG && a.list_bbox ? sizeof(float4) * E * kListBboxChunks : 0);
+    // work area behind it: one private block per grower while poses grow, the keypoint-NMS arrays afterwards
 #ifdef OPA_ASSOC_PHASE_TIMING
     const size_t budget = 159 * 1024;                // the diagnostic's static LDS
 #else
     const size_t budget = 160 * 1024;
 #endif
-    if (shared + priv > budget) return hipErrorInvalidValue;
-    int growers = (int)((budget - shared) / priv);
+    // the scan area of a grower: the full one (lists of up to 8 chunks in one round trip), or the small one when that
+    // buys more growers (large skeletons: the frontier lives in LDS too, and their lists are short)
+    int tgt_floats = kBlendLdsFloats;
+    size_t priv = assoc_private_bytes(K, A, REG, tgt_floats);
+    int growers = shared + priv <= budget ? (int)((budget - shared) / priv) : 0;
+    if (growers < NW - 1) {
+        const size_t priv_small = assoc_private_bytes(K, A, REG, kSmallTgtFloats);
+        const int growers_small = shared + priv_small <= budget ? (int)((budget - shared) / priv_small) : 0;
+        if (growers_small > growers) { growers = growers_small; priv = priv_small; tgt_floats = kSmallTgtFloats; }
+    }
+    if (growers < 1) return hipErrorInvalidValue;
     if (growers > NW - 1) growers = NW - 1;
     if (const char* e = getenv("OPA_ASSOC_GROWERS")) {   // tests: other interleavings of the same result
         const int v = atoi(e);
         if (v >= 1 && v < growers) growers = v;
     }
     int nms_waves = NW;                              // large annotation capacities: fewer waves share the NMS pass
-    while (nms_waves > 1 && shared + (size_t)nms_waves * nms_scratch_bytes(a.max_ann) > budget) nms_waves--;
-    const size_t nms = (size_t)nms_waves * nms_scratch_bytes(a.max_ann);
+    const size_t nms_fixed = nms_shared_bytes(a.max_ann, K);
+    while (nms_waves > 1 && shared + nms_fixed + (size_t)nms_waves * nms_scratch_bytes(a.max_ann) > budget) nms_waves--;
+    const size_t nms = nms_fixed + (size_t)nms_waves * nms_scratch_bytes(a.max_ann);
     if (shared + nms > budget) return hipErrorInvalidValue;
     const size_t grow_bytes = (size_t)growers * priv;
     const size_t lds = shared + (grow_bytes > nms ? grow_bytes : nms);
@@ -2230,7 +2290,7 @@ static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, con
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    cifcaf_assoc_kernel<REG, NW><<<a.B, NW * kWave, lds, st>>>(a, sk, p, growers, nms_waves);
+    cifcaf_assoc_kernel<REG, NW><<<a.B, NW * kWave, lds, st>>>(a, sk, p, growers, nms_waves, tgt_floats);
     return hipGetLastError();
 }
 
@@ -2255,9 +2315,10 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     const int K = a.K, E = 2 * a.A;
     // the seed pool packs cell coordinates into 12 bits, the field into 8 and the seed index into 24
     if (a.occ_w > 4096 || a.occ_h > 4096 || a.F > 256 || a.seed_cap > 0xFFFFFF) return hipErrorInvalidValue;
+    if (K > 256 || a.A > 256) return hipErrorInvalidValue;      // a slot's joints and bone are packed into 8 bits each
     const bool reg = K <= kWave && E <= kWave;       // pose, frontier and heap fit the lanes of a wave
     hipError_t e;
-    if (!reg) e = launch_assoc_nw<false, 8>(a, sk, p, st);   // LDS-resident growth state: 160 KB hold ~5 growers
+    if (!reg) e = launch_assoc_nw<false, 12>(a, sk, p, st);  // LDS-resident growth state: 160 KB hold 8 growers of a 133-joint skeleton
     else switch (assoc_waves()) {
 #ifdef OPA_ASSOC_ALL_WAVES
         case 8: e = launch_assoc_nw<true, 8>(a, sk, p, st); break;
@@ -2268,7 +2329,7 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     prof_mark(st, "cifcaf_assoc_kernel");
     if (e == hipSuccess && p.force_complete) {
         if (!a.fc_meta || !a.lists_fc) return hipErrorInvalidValue;
-        e = reg ? launch_fc_nw<true, 12>(a, sk, p, st) : launch_fc_nw<false, 8>(a, sk, p, st);
+        e = reg ? launch_fc_nw<true, 12>(a, sk, p, st) : launch_fc_nw<false, 12>(a, sk, p, st);
         prof_mark(st, "cifcaf_fc_kernel");
     }
     return e;

@@ -122,6 +122,43 @@ __device__ __forceinline__ void compare_exchange_desc(unsigned long long& a, uns
 using SeedRadixSort = rocprim::block_radix_sort<unsigned long long, 1024, kSortLdsKeys / 1024>;
 #endif
 
+// Images with more than 8192 seeds (wholebody: 133 fields, ~20 000 seeds): every 8192-key block is sorted by a
+// workgroup of its own (kSortBlocksMax per image in the sort kernel's grid), then cifseeds_rankmerge_kernel gives every
+// key its final position -- its rank in its own block plus, by binary search, the number of larger keys in each
+// other block (keys are unique: the cell index is part of them) -- and writes the decoded seed there.  One workgroup
+// per image bitonic-merging the blocks through L2 took 430 us for 16 wholebody images.  Beyond kSortBlocksMax
+// blocks (all-active fields) the single-workgroup network below still does it.
+constexpr int kSortBlocksMax = 8;
+constexpr int kSortSmallBlock = 2048;
+__host__ __device__ inline int sort_block_size(int n) { return n <= kSortLdsKeys ? kSortSmallBlock : kSortLdsKeys; }
+
+// keys -> sorted seeds (cif_seeds.cpp:100-113): the seed of rank t
+__device__ __forceinline__ void store_seed(unsigned long long key, int t, int b, const float* __restrict__ cif, int F, int NC,
+                                           int HW, int stride, int cap, int32_t* __restrict__ seed_f,
+                                           float* __restrict__ seed_vxys, int32_t* __restrict__ seed_cell, int occ_h,
+                                           int occ_w, const DevParams& p) {
+    int32_t* sf = seed_f + (size_t)b * cap;
+    const int ncol = NC - 1;                    // (v,x,y,s) for CIF; (v,x,y,w,h) for CifDet, cif_seeds.cpp:124-137
+    float* sv = seed_vxys + (size_t)b * cap * ncol;
+    const float* image = cif + (size_t)b * F * NC * HW;
+    const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
+    const int f = (int)(idx / (unsigned)HW), o = (int)(idx - (unsigned)f * (unsigned)HW);
+    const float* P = image + (size_t)f * NC * HW;
+    sf[t] = f;
+    float4 r;
+    r.x = from_sortable((unsigned)(key >> 32));
+    r.y = P[2 * HW + o] * (float)stride;
+    r.z = P[3 * HW + o] * (float)stride;
+    r.w = P[4 * HW + o] * (float)stride;                        // cif_seeds.cpp:61
+    if (seed_cell) seed_cell[(size_t)b * cap + t] = seed_cell_pack(p, occ_h, occ_w, (double)r.y, (double)r.z, (double)r.w);
+    if (NC == 5) {
+        reinterpret_cast<float4*>(sv)[t] = r;
+    } else {                                                    // cif_seeds.cpp:85-87
+        float* row = sv + (size_t)t * 5;
+        row[0] = r.x; row[1] = r.y; row[2] = r.z; row[3] = r.w; row[4] = P[5 * HW + o] * (float)stride;
+    }
+}
+
 __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
         unsigned long long* keys, int sort_cap, int cap, const int32_t* __restrict__ seed_count,
         const float* __restrict__ cif, int F, int NC, int HW, int stride,
@@ -136,52 +173,83 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
 #else
     __shared__ unsigned long long sk[kSortLdsKeys];
 #endif
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x / kSortBlocksMax, part = blockIdx.x - b * kSortBlocksMax, tid = threadIdx.x;
     unsigned long long* K = keys + (size_t)b * sort_cap;
     int n = seed_count[b];
     if (n > cap) n = cap;
     int n_pad = 2;
     while (n_pad < n) n_pad <<= 1;
-    const bool in_lds = n_pad <= kSortLdsKeys;
+    // one workgroup per block of BS keys + the rank merge: 2048-key blocks for up to 8192 seeds (66 compare-exchange
+    // passes on a quarter of the keys instead of 91 on all of them), 8192-key blocks beyond
+    const int BS = sort_block_size(n);
+    const bool in_lds = n <= BS;                       // one block: sorted and decoded here
+    const bool split = !in_lds && n <= kSortBlocksMax * BS;
+    if (part != 0 && !split) return;
+    if (split && part * BS >= n) return;
+    if (in_lds) n_pad = n_pad < 2 ? 2 : n_pad;
 
-#ifdef OPA_SORT_RADIX
-    if (in_lds && n_pad > 1024) {
-        constexpr int IPT = kSortLdsKeys / 1024;
-        int idx_bits = 1;
-        while ((1 << idx_bits) < cap) idx_bits++;                   // cell indices are < cap = F*H*W
-        const unsigned long long idx_mask = (1ull << idx_bits) - 1ull;
-        unsigned long long v[IPT];
-#pragma unroll
-        for (int i = 0; i < IPT; i++) {                             // blocked arrangement: thread t holds keys t*IPT ..
-            const int t = tid * IPT + i;
-            const unsigned long long key = t < n ? K[t] : 0ull;
-            v[i] = t < n ? ((key >> 32) << idx_bits) | (key & idx_mask) : 0ull;     // low word = ~cell index
+    // strides j_first, j_first/2, ..., 1 of stage k over the 8192 keys in LDS (directions come from the key's
+    // GLOBAL index blk + i).  Like the in-LDS sort below: wave w owns keys [512 w, 512 w + 512), strides
+    // below 512 stay inside a wave (two per LDS round trip, no workgroup barrier), only 512..4096 synchronise.
+    auto lds_strides = [&](int blk, int k, int j_first) {
+        constexpr int EB = kSortLdsKeys / 16;
+        const int wave = tid >> 6, lane = tid & 63;
+        bool synced = true;
+        for (int jj = j_first; jj > 0;) {
+            if (jj >= EB) {
+                if (!synced) __syncthreads();
+                for (int t = tid; t < (kSortLdsKeys >> 1); t += 1024) {
+                    const int i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
+                    const int p = i | jj;
+                    unsigned long long a = sk[i], c = sk[p];
+                    compare_exchange_desc(a, c, ((blk + i) & k) == 0);
+                    sk[i] = a; sk[p] = c;
+                }
+                __syncthreads();
+                synced = true;
+                jj >>= 1;
+                continue;
+            }
+            if (jj >= 2) {
+                const int h = jj >> 1;
+                for (int q = lane; q < (EB >> 2); q += 64) {
+                    const int i0 = wave * EB + (((q & ~(h - 1)) << 2) | (q & (h - 1)));
+                    const bool desc = ((blk + i0) & k) == 0;
+                    unsigned long long v0 = sk[i0], v1 = sk[i0 | h], v2 = sk[i0 | jj], v3 = sk[i0 | jj | h];
+                    compare_exchange_desc(v0, v2, desc); compare_exchange_desc(v1, v3, desc);
+                    compare_exchange_desc(v0, v1, desc); compare_exchange_desc(v2, v3, desc);
+                    sk[i0] = v0; sk[i0 | h] = v1; sk[i0 | jj] = v2; sk[i0 | jj | h] = v3;
+                }
+                jj >>= 2;
+            } else {
+                for (int q = lane; q < (EB >> 1); q += 64) {
+                    const int i = wave * EB + 2 * q;
+                    unsigned long long a = sk[i], c = sk[i | 1];
+                    compare_exchange_desc(a, c, ((blk + i) & k) == 0);
+                    sk[i] = a; sk[i | 1] = c;
+                }
+                jj >>= 1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            synced = false;
         }
-        SeedRadixSort().sort_desc(v, lds.radix, 0, 32 + idx_bits);
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < IPT; i++) {
-            const unsigned long long k2 = v[i];
-            sk[tid * IPT + i] = ((k2 >> idx_bits) << 32) | (0xFFFFFFFFull & ~idx_mask) | (k2 & idx_mask);
-        }
-        __syncthreads();
-    } else
-#endif
-    if (in_lds) {
-        for (int t = tid; t < n_pad; t += 1024) sk[t] = t < n ? K[t] : 0ull;
-        __syncthreads();
-        // Wave w owns the contiguous block of E = n_pad / 16 keys: every pass whose stride stays inside a
+    };
+    // bitonic sort (descending) of sk[0, m), m a power of two, in LDS
+    auto sort_lds = [&](const int m) {
+        // Wave w owns the contiguous block of E = m / 16 keys: every pass whose stride stays inside a
         // block (j < E) touches only keys this wave wrote, so it needs no workgroup barrier -- for 8192 keys
         // that is 81 of the 91 passes.  Only the far strides (j >= E) synchronise the workgroup.
-        const int E = n_pad >= 32 ? n_pad / 16 : n_pad;      // tiny inputs: wave 0 does everything
+        const int E = m >= 32 ? m / 16 : m;      // tiny inputs: wave 0 does everything
         const int wave = tid >> 6, lane = tid & 63;
-        const bool owner = n_pad >= 32 || wave == 0;
+        const bool owner = m >= 32 || wave == 0;
         bool synced = true;                                  // a workgroup barrier separates us from the last local pass
-        for (int k = 2; k <= n_pad; k <<= 1) {
+        for (int k = 2; k <= m; k <<= 1) {
             for (int j = k >> 1; j > 0;) {
                 if (j >= E) {                                // far stride: any thread, any pair
                     if (!synced) __syncthreads();
-                    for (int t = tid; t < (n_pad >> 1); t += 1024) {
+                    for (int t = tid; t < (m >> 1); t += 1024) {
                         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                         const int p = i | j;
                         unsigned long long a = sk[i], c = sk[p];
@@ -224,57 +292,46 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
             }
         }
         __syncthreads();
+    };
+    if (split) {            // this workgroup's block, sorted descending on its own; the rank merge kernel does the rest
+        const int blk = part * BS;
+        for (int t = tid; t < BS; t += 1024) sk[t] = blk + t < n ? K[blk + t] : 0ull;
+        __syncthreads();
+        sort_lds(BS);
+        for (int t = tid; t < BS; t += 1024) K[blk + t] = sk[t];
+        return;
+    }
+
+#ifdef OPA_SORT_RADIX
+    if (in_lds && n_pad > 1024) {
+        constexpr int IPT = kSortLdsKeys / 1024;
+        int idx_bits = 1;
+        while ((1 << idx_bits) < cap) idx_bits++;                   // cell indices are < cap = F*H*W
+        const unsigned long long idx_mask = (1ull << idx_bits) - 1ull;
+        unsigned long long v[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {                             // blocked arrangement: thread t holds keys t*IPT ..
+            const int t = tid * IPT + i;
+            const unsigned long long key = t < n ? K[t] : 0ull;
+            v[i] = t < n ? ((key >> 32) << idx_bits) | (key & idx_mask) : 0ull;     // low word = ~cell index
+        }
+        SeedRadixSort().sort_desc(v, lds.radix, 0, 32 + idx_bits);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < IPT; i++) {
+            const unsigned long long k2 = v[i];
+            sk[tid * IPT + i] = ((k2 >> idx_bits) << 32) | (0xFFFFFFFFull & ~idx_mask) | (k2 & idx_mask);
+        }
+        __syncthreads();
+    } else
+#endif
+    if (in_lds) {
+        for (int t = tid; t < n_pad; t += 1024) sk[t] = t < n ? K[t] : 0ull;
+        __syncthreads();
+        sort_lds(n_pad);
     } else {
         for (int t = n + tid; t < n_pad; t += 1024) K[t] = 0ull;
         sync_global();                                              // keys travel through HBM between threads here
-        // strides j_first, j_first/2, ..., 1 of stage k over the 8192 keys in LDS (directions come from the key's
-        // GLOBAL index blk + i).  Like the in-LDS sort above: wave w owns keys [512 w, 512 w + 512), strides
-        // below 512 stay inside a wave (two per LDS round trip, no workgroup barrier), only 512..4096 synchronise.
-        auto lds_strides = [&](int blk, int k, int j_first) {
-            constexpr int EB = kSortLdsKeys / 16;
-            const int wave = tid >> 6, lane = tid & 63;
-            bool synced = true;
-            for (int jj = j_first; jj > 0;) {
-                if (jj >= EB) {
-                    if (!synced) __syncthreads();
-                    for (int t = tid; t < (kSortLdsKeys >> 1); t += 1024) {
-                        const int i = ((t & ~(jj - 1)) << 1) | (t & (jj - 1));
-                        const int p = i | jj;
-                        unsigned long long a = sk[i], c = sk[p];
-                        compare_exchange_desc(a, c, ((blk + i) & k) == 0);
-                        sk[i] = a; sk[p] = c;
-                    }
-                    __syncthreads();
-                    synced = true;
-                    jj >>= 1;
-                    continue;
-                }
-                if (jj >= 2) {
-                    const int h = jj >> 1;
-                    for (int q = lane; q < (EB >> 2); q += 64) {
-                        const int i0 = wave * EB + (((q & ~(h - 1)) << 2) | (q & (h - 1)));
-                        const bool desc = ((blk + i0) & k) == 0;
-                        unsigned long long v0 = sk[i0], v1 = sk[i0 | h], v2 = sk[i0 | jj], v3 = sk[i0 | jj | h];
-                        compare_exchange_desc(v0, v2, desc); compare_exchange_desc(v1, v3, desc);
-                        compare_exchange_desc(v0, v1, desc); compare_exchange_desc(v2, v3, desc);
-                        sk[i0] = v0; sk[i0 | h] = v1; sk[i0 | jj] = v2; sk[i0 | jj | h] = v3;
-                    }
-                    jj >>= 2;
-                } else {
-                    for (int q = lane; q < (EB >> 1); q += 64) {
-                        const int i = wave * EB + 2 * q;
-                        unsigned long long a = sk[i], c = sk[i | 1];
-                        compare_exchange_desc(a, c, ((blk + i) & k) == 0);
-                        sk[i] = a; sk[i | 1] = c;
-                    }
-                    jj >>= 1;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                synced = false;
-            }
-            __syncthreads();
-        };
         // stages k <= 8192 never leave a block: ALL of them in one LDS visit per block
         for (int blk = 0; blk < n_pad; blk += kSortLdsKeys) {
             for (int t = tid; t < kSortLdsKeys; t += 1024) sk[t] = K[blk + t];
@@ -308,29 +365,43 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
     }
 
     // epilogue: decode keys -> sorted seeds (cif_seeds.cpp:100-113)
-    int32_t* sf = seed_f + (size_t)b * cap;
-    const int ncol = NC - 1;                    // (v,x,y,s) for CIF; (v,x,y,w,h) for CifDet, cif_seeds.cpp:124-137
-    float* sv = seed_vxys + (size_t)b * cap * ncol;
-    const float* image = cif + (size_t)b * F * NC * HW;
-    for (int t = tid; t < n; t += 1024) {
-        const unsigned long long key = in_lds ? sk[t] : K[t];
-        const unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
-        const int f = (int)(idx / (unsigned)HW), o = (int)(idx - (unsigned)f * (unsigned)HW);
-        const float* P = image + (size_t)f * NC * HW;
-        sf[t] = f;
-        float4 r;
-        r.x = from_sortable((unsigned)(key >> 32));
-        r.y = P[2 * HW + o] * (float)stride;
-        r.z = P[3 * HW + o] * (float)stride;
-        r.w = P[4 * HW + o] * (float)stride;                        // cif_seeds.cpp:61
-        if (seed_cell) seed_cell[(size_t)b * cap + t] = seed_cell_pack(p, occ_h, occ_w, (double)r.y, (double)r.z, (double)r.w);
-        if (NC == 5) {
-            reinterpret_cast<float4*>(sv)[t] = r;
-        } else {                                                    // cif_seeds.cpp:85-87
-            float* row = sv + (size_t)t * 5;
-            row[0] = r.x; row[1] = r.y; row[2] = r.z; row[3] = r.w; row[4] = P[5 * HW + o] * (float)stride;
-        }
+    for (int t = tid; t < n; t += 1024)
+        store_seed(in_lds ? sk[t] : K[t], t, b, cif, F, NC, HW, stride, cap, seed_f, seed_vxys, seed_cell, occ_h, occ_w, p);
+}
+
+// final position of every key of a block-sorted image (see kSortBlocksMax) + the decoded seed
+__global__ __launch_bounds__(256) void cifseeds_rankmerge_kernel(
+        const unsigned long long* __restrict__ keys, int sort_cap, int cap, const int32_t* __restrict__ seed_count,
+        const float* __restrict__ cif, int F, int NC, int HW, int stride,
+        int32_t* __restrict__ seed_f, float* __restrict__ seed_vxys,
+        int32_t* __restrict__ seed_cell, int occ_h, int occ_w, DevParams p) {
+    const int b = blockIdx.y;
+    int n = seed_count[b];
+    if (n > cap) n = cap;
+    const int BS = sort_block_size(n);
+    if (n <= BS || n > kSortBlocksMax * BS) return;    // the sort kernel did (or does) it all
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) {
+        // (positions behind the keys of the last block hold its zero padding: nothing to place) -- but a key's
+        // position inside its block can exceed n only in the last block, whose keys sit before the padding
+        return;
     }
+    const unsigned long long* K = keys + (size_t)b * sort_cap;
+    const int blk = t / BS;
+    const unsigned long long key = K[t];
+    int pos = t - blk * BS;                            // larger keys of its own block
+    const int nblk = (n + BS - 1) / BS;
+    for (int o = 0; o < nblk; o++) {
+        if (o == blk) continue;
+        const unsigned long long* Ko = K + (size_t)o * BS;
+        int lo = 0, hi = min(BS, n - o * BS);          // first index whose key is smaller (descending block)
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (Ko[mid] > key) lo = mid + 1; else hi = mid;
+        }
+        pos += lo;
+    }
+    store_seed(key, pos, b, cif, F, NC, HW, stride, cap, seed_f, seed_vxys, seed_cell, occ_h, occ_w, p);
 }
 
 hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int stride,
@@ -349,8 +420,13 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
                                                p.seed_threshold, det ? 0 : p.ablation_cifseeds_nms,
                                                det ? 0 : p.ablation_cifseeds_no_rescore, keys, sort_cap, cap, seed_count);
     prof_mark(st, "cifseeds_fill_kernel");
-    cifseeds_sort_kernel<<<B, 1024, 0, st>>>(keys, sort_cap, cap, seed_count, cif, F, NC, HW, stride,
-                                             seed_f, seed_vxys, seed_cell, occ_h, occ_w, p);
+    cifseeds_sort_kernel<<<B * kSortBlocksMax, 1024, 0, st>>>(keys, sort_cap, cap, seed_count, cif, F, NC, HW, stride,
+                                                              seed_f, seed_vxys, seed_cell, occ_h, occ_w, p);
+    if (cap > kSortSmallBlock) {                      // images of more than one block of seeds are possible
+        const int most = cap < kSortBlocksMax * kSortLdsKeys ? cap : kSortBlocksMax * kSortLdsKeys;
+        cifseeds_rankmerge_kernel<<<dim3((most + 255) / 256, B), 256, 0, st>>>(keys, sort_cap, cap, seed_count, cif, F, NC, HW,
+                                                                                 stride, seed_f, seed_vxys, seed_cell, occ_h, occ_w, p);
+    }
     prof_mark(st, "cifseeds_sort_kernel");
     return hipGetLastError();
 }
