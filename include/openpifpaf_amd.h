@@ -132,6 +132,12 @@ int opa_cifcaf_get_state(const opa_cifcaf* dec, int32_t* n_keypoints,
  * that alone makes the next call treat every tile as dirty. */
 size_t opa_cifcaf_workspace_bytes(const opa_shape* shape);
 
+/* The same for one set of tunables (NULL = the process-global ones): without params->force_complete the second
+ * CAF list set, its chunk boxes and counters -- about 30 % of the workspace -- are left out (they sit at the end of
+ * the layout; every other offset is unchanged).  opa_cifcaf_decode with force_complete set refuses such a
+ * workspace (OPA_ERR_WORKSPACE).  opa_cifcaf_workspace_bytes(shape) is the size that serves every setting. */
+size_t opa_cifcaf_workspace_bytes_for(const opa_shape* shape, const opa_params* params);
+
 /* ref: module.cpp:35-36  CifCaf.call / CifCaf.call_with_initial_annotations,
  * i.e. cifcaf.cpp:116-262, batched over B images and reading the field
  * tensors where the network wrote them (device memory; the reference

@@ -82,6 +82,7 @@ SYMBOLS = {
     'opa_cifcaf_destroy': (None, [_vp]),
     'opa_cifcaf_get_state': (ctypes.c_int, [_vp, _P(_i32), _vp, _P(_i32)]),
     'opa_cifcaf_workspace_bytes': (_sz, [_P(Shape)]),
+    'opa_cifcaf_workspace_bytes_for': (_sz, [_P(Shape), _P(Params)]),
     'opa_cifcaf_decode': (ctypes.c_int, [_vp, _P(Shape), _P(Params), _vp, _vp, _vp, _vp, _i32,
                                          _vp, _sz, _vp, _vp, _vp, _vp]),
     'opa_cifcaf_cifhr_view': (ctypes.c_int, [_P(Shape), _P(_sz), _P(_i32), _P(_i32), _P(_i32), _P(_dbl)]),

@@ -128,11 +128,7 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     const size_t list_bytes = B * L->A * 2 * 7 * (size_t)L->caf_cells * sizeof(float);
     L->off_lists = take(list_bytes);
     L->off_list_counts = take(B * L->A * 2 * sizeof(int32_t));
-    L->off_lists_fc = take(list_bytes);
-    L->off_list_counts_fc = take(B * L->A * 2 * sizeof(int32_t));
     L->off_list_bbox = take(B * L->A * 2 * (size_t)L->bbox_chunks * 4 * sizeof(float));
-    L->off_list_bbox_fc = take(B * L->A * 2 * (size_t)L->bbox_chunks * 4 * sizeof(float));
-    L->off_fc_meta = take(B * 4 * sizeof(int32_t));
     // occupancy bitmap, one bit per cell (occupancy.cpp:46-68 keeps an int16 map); 256-B multiple per image
     L->occ_image_words = align_up((size_t)L->F * L->occ_h * ((L->occ_w + 31) / 32) * sizeof(unsigned)) / sizeof(unsigned);
     L->off_occ = take(B * L->occ_image_words * sizeof(unsigned));
@@ -141,6 +137,12 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     L->off_status = take(B * sizeof(int32_t));
     L->off_stats = take(B * 24 * sizeof(int32_t));
     L->off_trace = take(B * 64 * 4 * sizeof(int32_t));
+    L->total_no_fc = off;
+    // what only a force-complete decode touches sits behind everything else: a workspace for decodes without it can stop here
+    L->off_lists_fc = take(list_bytes);
+    L->off_list_counts_fc = take(B * L->A * 2 * sizeof(int32_t));
+    L->off_list_bbox_fc = take(B * L->A * 2 * (size_t)L->bbox_chunks * 4 * sizeof(float));
+    L->off_fc_meta = take(B * 4 * sizeof(int32_t));
     L->total = off;
     return true;
 }
@@ -270,6 +272,14 @@ size_t opa_cifcaf_workspace_bytes(const opa_shape* shape) {
     return L.total;
 }
 
+size_t opa_cifcaf_workspace_bytes_for(const opa_shape* shape, const opa_params* params) {
+    Layout L; const char* why = nullptr;
+    if (!shape || !make_layout(*shape, &L, &why)) { g_error = why ? why : "null shape"; return 0; }
+    opa_params hp;
+    if (params) hp = *params; else opa_get_params(&hp);
+    return hp.force_complete ? L.total : L.total_no_fc;
+}
+
 int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats, int32_t* rows, int32_t* cols,
                           int32_t* pitch, double* revision) {
     Layout L; const char* why = nullptr;
@@ -289,11 +299,12 @@ int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what, size_t* 
     const Entry table[] = {
         {"tile_bitmaps", L.off_tile_clean, L.off_cifhr}, {"cifhr", L.off_cifhr, L.off_act}, {"seed_count", L.off_seed_count, L.off_seed_f},
         {"seed_f", L.off_seed_f, L.off_seed_vxys}, {"seed_vxys", L.off_seed_vxys, L.off_seed_cell}, {"seed_cell", L.off_seed_cell, L.off_lists},
-        {"lists", L.off_lists, L.off_list_counts}, {"list_counts", L.off_list_counts, L.off_lists_fc},
-        {"lists_fc", L.off_lists_fc, L.off_list_counts_fc}, {"list_counts_fc", L.off_list_counts_fc, L.off_list_bbox},
-        {"list_bbox", L.off_list_bbox, L.off_list_bbox_fc}, {"list_bbox_fc", L.off_list_bbox_fc, L.off_fc_meta},
+        {"lists", L.off_lists, L.off_list_counts}, {"list_counts", L.off_list_counts, L.off_list_bbox},
+        {"list_bbox", L.off_list_bbox, L.off_occ},
         {"occupancy", L.off_occ, L.off_anns}, {"annotation_scratch", L.off_anns, L.off_ann_meta},
-        {"status", L.off_status, L.off_stats}, {"assoc_stats", L.off_stats, L.off_trace}, {"assoc_trace", L.off_trace, L.total},
+        {"status", L.off_status, L.off_stats}, {"assoc_stats", L.off_stats, L.off_trace}, {"assoc_trace", L.off_trace, L.total_no_fc},
+        {"lists_fc", L.off_lists_fc, L.off_list_counts_fc}, {"list_counts_fc", L.off_list_counts_fc, L.off_list_bbox_fc},
+        {"list_bbox_fc", L.off_list_bbox_fc, L.off_fc_meta},
     };
     for (const Entry& e : table)
         if (std::strcmp(e.name, what) == 0) {
@@ -325,7 +336,10 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
         return fail(OPA_ERR_UNSUPPORTED, "opa_cifcaf_decode: occupancy_reduction < 1 is not supported");
     L.occ_h = (int)((double)L.hr_rows / hp.occupancy_reduction) + 1;       // occupancy.cpp:47-48
     L.occ_w = (int)((double)L.hr_cols / hp.occupancy_reduction) + 1;
-    if (workspace_bytes < L.total) return fail(OPA_ERR_WORKSPACE, "opa_cifcaf_decode: workspace too small");
+    if (workspace_bytes < (hp.force_complete ? L.total : L.total_no_fc))
+        return fail(OPA_ERR_WORKSPACE, hp.force_complete && workspace_bytes >= L.total_no_fc
+                    ? "opa_cifcaf_decode: workspace too small for a force-complete decode (sized with opa_cifcaf_workspace_bytes_for "
+                      "without the flag?)" : "opa_cifcaf_decode: workspace too small");
     if (((uintptr_t)workspace_dev & 255) != 0 || ((uintptr_t)out_dev & 15) != 0)
         return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_decode: workspace must be 256-B and out 16-B aligned");
 
@@ -338,7 +352,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     // the clean-tile flags are valid for exactly this carving of the workspace
     unsigned long long layout_hash = 1469598103934665603ull;
     for (long long v : {(long long)L.B, (long long)L.F, (long long)L.H, (long long)L.W, (long long)L.stride,
-                        (long long)L.A, (long long)L.cH, (long long)L.cW, (long long)L.max_ann, (long long)L.K, (long long)L.total})
+                        (long long)L.A, (long long)L.cH, (long long)L.cW, (long long)L.max_ann, (long long)L.K, (long long)L.total_no_fc})
         layout_hash = (layout_hash ^ (unsigned long long)v) * 1099511628211ull;
     e = launch_cifhr(cif_dev, L.B, L.F, L.H, L.W, L.stride, 0.0, 1.0, p, cifhr, L.hr_rows, L.hr_pitch,
                      (float*)(ws + L.off_act), (int32_t*)(ws + L.off_act_count), st, false,

@@ -33,7 +33,7 @@ struct Layout {
     size_t off_hdr, off_tile_clean, off_cifhr, off_act, off_act_count, off_seed_keys, off_seed_count,
            off_seed_f, off_seed_vxys, off_seed_cell, off_lists, off_list_counts,
            off_lists_fc, off_list_counts_fc, off_list_bbox, off_list_bbox_fc, off_fc_meta, off_occ, off_anns, off_ann_meta, off_status, off_stats, off_trace,
-           total;
+           total_no_fc, total;           // total_no_fc: everything but the regions only a force-complete decode uses (they come last)
     size_t occ_image_words;               // 32-bit words of one image's occupancy bitmap (capacity)
 };
 

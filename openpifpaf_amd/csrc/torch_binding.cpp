@@ -87,8 +87,9 @@ struct CifCaf : torch::CustomClassHolder {
         s.cif_stride = (int32_t)cif_stride; s.caf_stride = (int32_t)caf_stride;
         s.max_annotations = (int32_t)max_annotations;
         s.n_keypoints = (int32_t)n_keypoints;        // > n_cif in the tracking setup
-        const size_t need = opa_cifcaf_workspace_bytes(&s);
-        TORCH_CHECK(need > 0, "opa_cifcaf_workspace_bytes: ", opa_last_error());
+        // (the decode below runs with the process-global tunables: without force_complete the second list set is left out)
+        const size_t need = opa_cifcaf_workspace_bytes_for(&s, nullptr);
+        TORCH_CHECK(need > 0, "opa_cifcaf_workspace_bytes_for: ", opa_last_error());
         if (!workspace.defined() || (size_t)workspace.numel() < need || workspace.device() != cif.device()) {
             workspace = torch::empty({(int64_t)need}, torch::dtype(torch::kUInt8).device(cif.device()));
             workspace.narrow(0, 0, 256).zero_();     // recycled allocator memory: the lazy-clear header starts invalid

@@ -118,6 +118,7 @@ class CifCaf:
         self._workspaces = {}
         self._last = None
         self._pinned = False                 # a captured graph holds raw pointers into the workspace
+        self._workspace_fc = False           # the live workspace has the force-complete regions
         _device()
         _lib.check(_lib.lib().opa_cifcaf_create(
             ctypes.byref(self._handle), self.n_keypoints,
@@ -150,11 +151,20 @@ class CifCaf:
         return _lib.Shape(B, F, A, H, W, cH, cW, int(cif_stride), int(caf_stride), self.max_annotations,
                           self.n_keypoints)
 
-    def _workspace(self, shape, device):
+    def _workspace(self, shape, device, params=None):
+        """The decoder's workspace for this shape; the regions only a force-complete decode uses (a second set of CAF
+        lists: ~30 % of it) are allocated only once such a decode is asked for."""
+        fc = bool((params if params is not None else _lib.get_params()).force_complete)
         key = tuple(getattr(shape, n) for n, _ in _lib.Shape._fields_) + (device.index,)
         ws = self._workspaces.get(key)
+        if ws is not None and fc and not self._workspace_fc:
+            if self._pinned:
+                raise _lib.NativeError('this decoder has a captured HIP graph that replays into a workspace without the '
+                                       'force-complete regions: use another CifCaf instance')
+            ws = None                        # grow: the lazy tile clear starts over with the new block
         if ws is None:
-            nbytes = _lib.lib().opa_cifcaf_workspace_bytes(ctypes.byref(shape))
+            fc_params = _lib.default_params(force_complete=int(fc))
+            nbytes = _lib.lib().opa_cifcaf_workspace_bytes_for(ctypes.byref(shape), ctypes.byref(fc_params))
             if nbytes == 0:
                 raise _lib.NativeError(_lib.lib().opa_last_error().decode())
             if self._pinned:
@@ -167,6 +177,7 @@ class CifCaf:
             # (include/openpifpaf_amd.h, workspace contract).
             ws[:256].zero_()
             self._workspaces[key] = ws
+            self._workspace_fc = fc
         return ws
 
     def call_batch(self, cif, cif_stride, caf, caf_stride, initial_annotations=None, initial_ids=None,
@@ -181,7 +192,7 @@ class CifCaf:
         cif, orig = _prep(cif)
         caf, _ = _prep(caf)
         shape = self._shape(cif, cif_stride, caf, caf_stride)
-        ws = self._workspace(shape, cif.device)
+        ws = self._workspace(shape, cif.device, params)
         B, K = shape.batch, self.n_keypoints
         out = torch.empty((B, self.max_annotations, K, 4), dtype=torch.float32, device=cif.device)
         ids = torch.empty((B, self.max_annotations), dtype=torch.int64, device=cif.device)

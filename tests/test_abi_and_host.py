@@ -64,6 +64,10 @@ def test_invalid_arguments_fail_loudly_without_gpu():
     shape = _lib.Shape(32, 17, 19, 81, 81, 81, 81, 8, 8, 128)
     nbytes = L.opa_cifcaf_workspace_bytes(ctypes.byref(shape))
     assert 1.0e9 < nbytes < 3.0e9                                      # ~50 MB per image
+    # without force complete the second CAF list set is left out ("weak" 15): ~7 MB per image less
+    plain = L.opa_cifcaf_workspace_bytes_for(ctypes.byref(shape), ctypes.byref(_lib.default_params()))
+    full = L.opa_cifcaf_workspace_bytes_for(ctypes.byref(shape), ctypes.byref(_lib.default_params(force_complete=1)))
+    assert full == nbytes and 32 * 6.5e6 < nbytes - plain < 32 * 8e6
     h = ctypes.c_void_p()
     skel = (ctypes.c_int64 * 4)(0, 1, 1, 99)
     assert L.opa_cifcaf_create(ctypes.byref(h), 17, skel, 2) == 1      # index out of range

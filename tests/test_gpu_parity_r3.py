@@ -189,3 +189,34 @@ def test_watchdog_failure_is_flagged_and_raises_on_every_host_path(native, coco_
     out, ids, counts = dec.call_batch(dev(cif)[None], 8, dev(caf)[None], 8)      # and the decoder is fine afterwards
     assert native.count_rows(int(counts[0])) == 4 and not native.count_failed(counts).any()
     assert len(ts.call(dev(cif), 8, dev(caf), 8)[0]) == 4
+
+
+def test_workspace_without_force_complete_regions(native, port, coco_skeleton0):
+    """A decoder that never force-completes does not pay for the second CAF list set ("weak" 15): the
+    workspace is allocated without it, grows when a force-complete decode is asked for, and the C ABI refuses a
+    force-complete decode into the smaller block instead of writing past it."""
+    import ctypes
+    from openpifpaf_amd import _lib, synth
+    cif, caf = synth.synth_fields(9, 4, height=41, width=41)
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    out, ids, counts = dec.call_batch(dev(cif)[None], 8, dev(caf)[None], 8)
+    shape, ws = dec._last
+    small = ws.numel()
+    assert small == _lib.lib().opa_cifcaf_workspace_bytes_for(ctypes.byref(shape), ctypes.byref(_lib.default_params()))
+    assert small < _lib.lib().opa_cifcaf_workspace_bytes(ctypes.byref(shape))
+    fc = _lib.default_params(force_complete=1)
+    o2 = torch.empty_like(out)
+    rc = _lib.lib().opa_cifcaf_decode(dec._handle, ctypes.byref(shape), ctypes.byref(fc), native._ptr(dev(cif)[None].contiguous()),
+                                      native._ptr(dev(caf)[None].contiguous()), None, None, 0, native._ptr(ws), ws.numel(),
+                                      native._ptr(o2), native._ptr(ids), native._ptr(counts), native._stream())
+    assert rc == 4 and b'force-complete' in _lib.lib().opa_last_error()          # OPA_ERR_WORKSPACE
+    out, ids, counts = dec.call_batch(dev(cif)[None], 8, dev(caf)[None], 8, params=fc)     # the wrapper grows the block
+    assert dec._last[1].numel() == _lib.lib().opa_cifcaf_workspace_bytes(ctypes.byref(shape)) > small
+    want, _ = port.decode(cif, 8, caf, 8, coco_skeleton0, params=port.default_params(force_complete=1))
+    n = native.count_rows(int(counts[0]))
+    ok, msg = compare_annotations(out[0, :n].cpu().numpy(), want)
+    assert ok, msg
+    out, ids, counts = dec.call_batch(dev(cif)[None], 8, dev(caf)[None], 8)                 # and back to the default flags
+    want, _ = port.decode(cif, 8, caf, 8, coco_skeleton0)
+    ok, msg = compare_annotations(out[0, :native.count_rows(int(counts[0]))].cpu().numpy(), want)
+    assert ok, msg

@@ -1,12 +1,28 @@
-"""Turns rocprofv3 CSV output (tools/collect_profiles.sh) into the markdown summary
-committed under profiles/."""
+"""Turns rocprofv3 CSV output (tools/collect_profiles.sh) into the markdown summary and the machine-readable PMC
+traffic file committed under profiles/r3/.
+
+    python tools/summarize_profiles.py <output root of collect_profiles.sh>
+
+Layout of the root: ``<workload>/stats`` (kernel trace + stats of tools/gpu/r3_probe.py on that workload),
+``<workload>/pmc_<COUNTER...>`` (one rocprofv3 --pmc pass each), ``bench`` / ``bench_bf16`` (kernel trace of bench.py's
+headline / bfloat16 leg).  Workloads: config2 (COCO-17 batch 32), config2_fc, config4 (wholebody batch 16), config4_fc.
+"""
 import csv
 import glob
+import hashlib
+import json
 import os
 import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+WORKLOADS = [('config2', 'COCO-17 (configs 2 / 3 fields), batch 32, default flags', 2, 32, False),
+             ('config2_fc', 'COCO-17, batch 32, the reference benchmark\'s force-complete setting', 2, 32, True),
+             ('config4', 'wholebody 133 keypoints / 160 bones (config 4), batch 16, default flags', 4, 16, False),
+             ('config4_fc', 'wholebody, batch 16, force complete', 4, 16, True)]
+DECODE_KERNELS = ('cif_active_kernel', 'cifhr_tile_kernel', 'tile_state_roll_kernel', 'cifseeds_fill_kernel',
+                  'cifseeds_sort_kernel', 'cifseeds_rankmerge_kernel', 'cafscored_kernel', 'cifcaf_assoc_kernel',
+                  'cifcaf_fc_kernel')
 
 
 def find(sub, pattern):
@@ -21,20 +37,29 @@ def short(name):
     return name if len(name) < 90 else name[:87] + '...'
 
 
-def kernel_stats(sub, title, top=25):
+def base(name):
+    """opa::cifcaf_assoc_kernel<true, 12> -> cifcaf_assoc_kernel"""
+    s = short(name)
+    return s.split('::')[-1].split('<')[0] if s.startswith('opa::') else s
+
+
+def kernel_stats(sub, title, top=14):
     path = find(sub, '*kernel_stats.csv')
-    print('## %s\n' % title)
+    print('### %s\n' % title)
     if not path:
         print('(no kernel_stats.csv found)\n')
-        return
+        return {}
     rows = list(csv.DictReader(open(path)))
     print('| kernel | calls | total ms | avg us | % |')
     print('|---|---|---|---|---|')
+    out = {}
     for r in rows[:top]:
         print('| `%s` | %s | %.3f | %.2f | %.2f |' % (
             short(r['Name']), r['Calls'], float(r['TotalDurationNs']) / 1e6,
             float(r['AverageNs']) / 1e3, float(r['Percentage'])))
+        out[base(r['Name'])] = float(r['AverageNs']) / 1e3
     print()
+    return out
 
 
 def steady_state_step(sub, title, top=16):
@@ -69,74 +94,104 @@ def steady_state_step(sub, title, top=16):
     print()
 
 
-def pmc(sub, counter):
+def pmc_per_decode(sub, counter, last_calls=4):
+    """Counter value per kernel and per DECODE CALL: the sum over the kernel's launches inside the last `last_calls`
+    decode calls of the run / last_calls (a call = everything up to and including its last association-stage kernel;
+    the first call on a workspace writes the whole CifHr map, and the probe alternates two field batches)."""
     path = find(sub, '*counter_collection.csv')
     if not path:
         return {}
-    acc = defaultdict(list)
-    for r in csv.DictReader(open(path)):
-        if r.get('Counter_Name') != counter:
-            continue
-        k = short(r['Kernel_Name'])
-        acc[k].append(float(r['Counter_Value']))
-    # median over the launches: the first call on a workspace writes the whole CifHr map (lazy clear not
-    # primed yet) and would dominate a mean
-    return {k: sorted(v)[len(v) // 2] for k, v in acc.items() if v}
+    rows = [r for r in csv.DictReader(open(path)) if r.get('Counter_Name') == counter]
+    if not rows:
+        return {}
+    rows.sort(key=lambda r: int(r['Dispatch_Id']))
+    names = [base(r['Kernel_Name']) for r in rows]
+    last_stage = 'cifcaf_fc_kernel' if 'cifcaf_fc_kernel' in names else 'cifcaf_assoc_kernel'
+    ends = [i for i, n in enumerate(names) if n == last_stage]
+    if len(ends) < last_calls + 1:
+        return {}
+    lo, hi = ends[-last_calls - 1] + 1, ends[-1] + 1
+    acc = defaultdict(float)
+    for r, n in zip(rows[lo:hi], names[lo:hi]):
+        acc[n] += float(r['Counter_Value'])
+    return {k: v / last_calls for k, v in acc.items()}
 
 
-print('# rocprofv3 summary (round 2)\n')
-print('Commands: see tools/collect_profiles.sh.  Batch 32 per launch, COCO-17 fields 81x81, stride 8.\n')
+print('# rocprofv3 summary (round 3)\n')
+print('Commands: tools/collect_profiles.sh (every pass: `rocprofv3 ... -- python tools/gpu/r3_probe.py --config ... --alternate`,'
+      ' i.e. two different field batches decoded in turn; counters in their own passes with --kernel-trace only).\n')
 steady_state_step('bench', 'bench.py headline leg (float32 network + decode): ONE steady-state step, batch 32')
 steady_state_step('bench_bf16', 'bench.py --backbone-dtype bf16 (bfloat16 network + decode): ONE steady-state step, batch 32')
-kernel_stats('decode', 'bench.py --decode-only --steps 10 --warmup 2, kernel trace')
-fetch, write = pmc('pmc_FETCH_SIZE', 'FETCH_SIZE'), pmc('pmc_WRITE_SIZE', 'WRITE_SIZE')
-print('## HBM traffic counters per launch (decode only)\n')
-print('FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB-like units of the TCC_EA request counters; on gfx950 '
-      'FETCH_SIZE under-counts wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section): the "corrected" column '
-      'doubles it.\n')
-print('| kernel | FETCH_SIZE (KB) | x2 corrected (MB) | WRITE_SIZE (KB) | write (MB) |')
-print('|---|---|---|---|---|')
-for k in sorted(set(fetch) | set(write)):
-    if not k.startswith('opa::') and 'fillBuffer' not in k:
-        continue
-    f, w = fetch.get(k, 0.0), write.get(k, 0.0)
-    print('| `%s` | %.1f | %.2f | %.1f | %.2f |' % (k, f, 2 * f * 1024 / 1e6, w, w * 1024 / 1e6))
 
-# cache / LDS / instruction mix of the decode kernels
-hit, miss = pmc('pmc_TCC_HIT_sum', 'TCC_HIT_sum'), pmc('pmc_TCC_HIT_sum', 'TCC_MISS_sum')
-conf, lds_act, lds_inst = (pmc('pmc_SQ_LDS_BANK_CONFLICT', c) for c in ('SQ_LDS_BANK_CONFLICT', 'SQ_ACTIVE_INST_LDS', 'SQ_INSTS_LDS'))
-valu, salu, wcyc = (pmc('pmc_SQ_INSTS_VALU', c) for c in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES'))
-if hit or conf or valu:
-    print('\n## L2 hit rate, LDS bank conflicts, instruction mix (decode only, per launch, median)\n')
-    print('L2 hit rate = TCC_HIT / (TCC_HIT + TCC_MISS); LDS conflict share = SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS '
-          '(cycles); instructions are per launch, summed over all waves.\n')
+print('## Decode kernels per workload (kernel trace, averages over the run)\n')
+stats = {}
+for key, title, cfg, B, fc in WORKLOADS:
+    stats[key] = kernel_stats(os.path.join(key, 'stats'), '%s -- %s' % (key, title))
+
+h = hashlib.sha256()
+csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'openpifpaf_amd', 'csrc')
+for n in sorted(os.listdir(csrc)):
+    if n.endswith(('.hip', '.hpp')):
+        h.update(open(os.path.join(csrc, n), 'rb').read())
+out = {'kernel_source_hash': h.hexdigest()[:16],
+       'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/gpu/r3_probe.py --alternate, per decode call '
+               '(sum over the launches of a kernel inside one call, mean of the last 4 calls); units KiB of TCC_EA requests; '
+               'hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 x2 read correction of MI355X_MICROARCH.md '
+               '(calibrated for 16-B/lane streams; 4-B/lane reads are uncalibrated)',
+       'workloads': {}}
+print('## HBM traffic counters per decode call\n')
+print('FETCH_SIZE / WRITE_SIZE are reported in KiB of the L2\'s memory-side requests; on gfx950 FETCH_SIZE counts a wide '
+      'coalesced read at half its bytes (MI355X_MICROARCH.md, HBM section): "read MB" doubles it.  Infinity-Cache hits are '
+      'counted as traffic.  Algorithmic bytes = SURVEY 8d (CIF + CAF + annotations) x images per call.\n')
+for key, title, cfg, B, fc in WORKLOADS:
+    fetch = pmc_per_decode(os.path.join(key, 'pmc_FETCH_SIZE'), 'FETCH_SIZE')
+    write = pmc_per_decode(os.path.join(key, 'pmc_WRITE_SIZE'), 'WRITE_SIZE')
+    if not fetch and not write:
+        continue
+    print('### %s\n' % key)
+    print('| kernel | FETCH_SIZE (KiB) | read MB (x2) | WRITE_SIZE (KiB) | write MB | HBM MB |')
+    print('|---|---|---|---|---|---|')
+    entry = {'kernels': {}, 'batch': B, 'config': cfg, 'force_complete': fc}
+    total = 0
+    for k in DECODE_KERNELS:
+        if k not in fetch and k not in write:
+            continue
+        f, w = fetch.get(k, 0.0), write.get(k, 0.0)
+        hbm = int((2 * f + w) * 1024)
+        total += hbm
+        entry['kernels'][k] = {'FETCH_SIZE': round(f, 1), 'WRITE_SIZE': round(w, 1), 'hbm_bytes': hbm}
+        print('| `%s` | %.1f | %.2f | %.1f | %.2f | %.2f |' % (k, f, 2 * f * 1024 / 1e6, w, w * 1024 / 1e6, hbm / 1e6))
+    K, A = (17, 19) if cfg != 4 else (133, 160)
+    alg = B * (K * 5 * 6561 * 4 + A * 8 * 6561 * 4 + 128 * K * 4 * 4)
+    entry['decode_path_hbm_bytes'] = total
+    entry['algorithmic_bytes'] = alg
+    print('| **decode path** | | | | | **%.1f** = %.2f x the %.1f MB of SURVEY 8d |\n' % (total / 1e6, total / alg, alg / 1e6))
+    out['workloads']['config%d%s_batch%d' % (cfg, '_fc' if fc else '', B)] = entry
+
+print('## L2 hit rate, LDS bank conflicts, instruction mix (per decode call)\n')
+print('L2 hit rate = TCC_HIT / (TCC_HIT + TCC_MISS); LDS conflict share = SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS '
+      '(cycles); instructions summed over all waves.\n')
+for key, title, cfg, B, fc in WORKLOADS:
+    hit = pmc_per_decode(os.path.join(key, 'pmc_TCC_HIT_sum'), 'TCC_HIT_sum')
+    miss = pmc_per_decode(os.path.join(key, 'pmc_TCC_HIT_sum'), 'TCC_MISS_sum')
+    conf, act, inst = (pmc_per_decode(os.path.join(key, 'pmc_SQ_LDS_BANK_CONFLICT'), c)
+                       for c in ('SQ_LDS_BANK_CONFLICT', 'SQ_ACTIVE_INST_LDS', 'SQ_INSTS_LDS'))
+    valu, salu, wcyc = (pmc_per_decode(os.path.join(key, 'pmc_SQ_INSTS_VALU'), c)
+                        for c in ('SQ_INSTS_VALU', 'SQ_INSTS_SALU', 'SQ_WAVE_CYCLES'))
+    if not (hit or conf or valu):
+        continue
+    print('### %s\n' % key)
     print('| kernel | L2 hit rate | LDS bank-conflict cycles / LDS active cycles | LDS instr | VALU instr | SALU instr | wave cycles |')
     print('|---|---|---|---|---|---|---|')
-    for k in sorted(set(hit) | set(conf) | set(valu)):
-        if not k.startswith('opa::'):
+    for k in DECODE_KERNELS:
+        if k not in hit and k not in conf and k not in valu:
             continue
-        h, m = hit.get(k, 0.0), miss.get(k, 0.0)
+        hh, mm = hit.get(k, 0.0), miss.get(k, 0.0)
         print('| `%s` | %s | %s | %.3g | %.3g | %.3g | %.3g |' % (
-            k, '%.1f %%' % (100 * h / (h + m)) if h + m else '-',
-            '%.1f %%' % (100 * conf.get(k, 0.0) / lds_act[k]) if lds_act.get(k) else '-',
-            lds_inst.get(k, 0.0), valu.get(k, 0.0), salu.get(k, 0.0), wcyc.get(k, 0.0)))
+            k, '%.1f %%' % (100 * hh / (hh + mm)) if hh + mm else '-',
+            '%.1f %%' % (100 * conf.get(k, 0.0) / act[k]) if act.get(k) else '-',
+            inst.get(k, 0.0), valu.get(k, 0.0), salu.get(k, 0.0), wcyc.get(k, 0.0)))
+    print()
 
-# machine-readable PMC traffic for bench.py's roofline.traffic
-import json
-import hashlib
-_h = hashlib.sha256()
-_csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'openpifpaf_amd', 'csrc')
-for _n in sorted(os.listdir(_csrc)):
-    if _n.endswith(('.hip', '.hpp')):
-        _h.update(open(os.path.join(_csrc, _n), 'rb').read())
-out = {'batch': 32, 'config': 2, 'kernel_source_hash': _h.hexdigest()[:16], 'note': 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --decode-only, per launch; '
-       'units KiB of TCC_EA requests; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 with the gfx950 x2 read correction '
-       'of MI355X_MICROARCH.md (calibrated for 16-B/lane streams only; 4-B/lane reads are uncalibrated)', 'kernels': {}}
-for k in sorted(set(fetch) | set(write)):
-    if not k.startswith('opa::'):
-        continue
-    name = k.split('::')[1].split('<')[0]
-    out['kernels'][name] = {'FETCH_SIZE': round(fetch.get(k, 0.0), 1), 'WRITE_SIZE': round(write.get(k, 0.0), 1),
-                            'hbm_bytes': int((2 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024)}
-if out['kernels']:
+if out['workloads']:
     json.dump(out, open(os.path.join(root, 'pmc_traffic.json'), 'w'), indent=1)
