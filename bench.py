@@ -127,6 +127,7 @@ def algorithmic_bytes(B, F, A, H, W, stride, max_ann, K=None):
         'cifseeds_fill_kernel': B * F * hw * 4,                  # reads the confidence plane
         'cifseeds_sort_kernel': 0,
         'cafscored_kernel': B * A * 7 * hw * 4,                  # reads the 7 used component planes
+        'sort_cafscored_kernel': B * A * 7 * hw * 4,             # the decode's fused launch: seed sort (LDS resident) + cafscored
         'cifcaf_assoc_kernel': B * max_ann * K * 4 * 4,          # writes the annotations (lists are data dependent)
         'cifcaf_fc_kernel': B * max_ann * K * 4 * 4,
         'decode_path': B * (F * 5 * hw * 4 + A * 8 * hw * 4 + max_ann * K * 4 * 4),

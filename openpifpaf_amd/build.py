@@ -55,16 +55,16 @@ def build_native(force=False, verbose=True):
     return OUT
 
 
-def build_diagnostic(define, suffix, verbose=True):
+def build_diagnostic(define, suffix, verbose=True, source='cifcaf.hip'):
     """A second library with one diagnostic switch of the association kernel compiled in (``-D<define>``), e.g.
     ``build_diagnostic('OPA_ASSOC_PHASE_TIMING', 'ph')`` -> ``lib/libopenpifpaf_amd_ph.so``; load it with
     ``OPA_LIB_PATH``.  Only cifcaf.hip is recompiled, the other objects are the production ones."""
     build_native(verbose=verbose)
     hipcc = os.environ.get('HIPCC', 'hipcc')
-    obj = os.path.join(OBJ_DIR, 'cifcaf_%s.o' % suffix)
+    obj = os.path.join(OBJ_DIR, '%s_%s.o' % (source[:-4], suffix))
     out = os.path.join(HERE, 'lib', 'libopenpifpaf_amd_%s.so' % suffix)
-    subprocess.check_call([hipcc] + FLAGS + ['-D' + define, '-c', os.path.join(CSRC, 'cifcaf.hip'), '-o', obj])
-    objs = [os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + '.o') for src in sources() if not src.endswith('cifcaf.hip')]
+    subprocess.check_call([hipcc] + FLAGS + ['-D' + define, '-c', os.path.join(CSRC, source), '-o', obj])
+    objs = [os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + '.o') for src in sources() if not src.endswith(os.sep + source)]
     subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out, obj] + objs)
     return out
 

@@ -359,25 +359,47 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
                      (unsigned long long*)(ws + L.off_hdr), layout_hash, ws + L.off_tile_clean,
                      (int32_t*)(ws + L.off_seed_count));                                         // cifcaf.cpp:140-141
     if (e != hipSuccess) return fail_hip(e, "cifhr");
+    // CafScored::fill (:153-161) of the caf_th list set and, for force complete, of the second one (:419-420): launches of
+    // their own.  (OPA_FUSE_SCORED=1 lets them ride in the seed sort's launch, two 512-thread groups per workgroup beside
+    // the sort's workgroups -- measured in round 3: 90 us against 42 + 41 us one after the other, 323 against 170 us with
+    // the force-complete set: under the sort kernel's 64 KiB of static LDS and 1024-thread workgroups the list building
+    // gets two workgroups per compute unit instead of its six, and loses more than the overlap gives.)
+    ScoredArgs scored[2];
+    int n_scored = 0;
+    scored[n_scored++] = make_scored_args(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols, L.hr_pitch,
+                                          dec->dev.skeleton, p.caf_threshold, p.cif_floor, p.ablation_caf_no_rescore,
+                                          (float*)(ws + L.off_lists), (int32_t*)(ws + L.off_list_counts),
+                                          (float*)(ws + L.off_list_bbox),
+                                          L.bbox_chunks < kListBboxChunks ? L.bbox_chunks : kListBboxChunks, L.bbox_chunks);
+    if (p.force_complete)
+        scored[n_scored++] = make_scored_args(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols,
+                                              L.hr_pitch, dec->dev.skeleton, p.force_complete_caf_th, 0.1,
+                                              p.ablation_caf_no_rescore, (float*)(ws + L.off_lists_fc),
+                                              (int32_t*)(ws + L.off_list_counts_fc), (float*)(ws + L.off_list_bbox_fc),
+                                              L.bbox_chunks, L.bbox_chunks);
+    const char* fuse_env = std::getenv("OPA_FUSE_SCORED");
+    const bool fuse = fuse_env && std::atoi(fuse_env) != 0;
     e = launch_cifseeds(cif_dev, L.B, L.F, L.H, L.W, L.stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
                         (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap,
                         (int32_t*)(ws + L.off_seed_count), (int32_t*)(ws + L.off_seed_f),
                         (float*)(ws + L.off_seed_vxys), st, false, (int32_t*)(ws + L.off_seed_cell),
-                        L.occ_h, L.occ_w, true);                                             // :144-146
+                        L.occ_h, L.occ_w, true, fuse ? scored : nullptr, fuse ? n_scored : 0);   // :144-146
     if (e != hipSuccess) return fail_hip(e, "cifseeds");
-    e = launch_cafscored(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols, L.hr_pitch,
-                         dec->dev.skeleton, p.caf_threshold, p.cif_floor, p.ablation_caf_no_rescore,
-                         (float*)(ws + L.off_lists), (int32_t*)(ws + L.off_list_counts), st,
-                         (float*)(ws + L.off_list_bbox), L.bbox_chunks < kListBboxChunks ? L.bbox_chunks : kListBboxChunks,
-                         L.bbox_chunks);                                                     // :153-161
-    if (e != hipSuccess) return fail_hip(e, "cafscored");
-    if (p.force_complete) {                                                                   // :419-420
-        e = launch_cafscored(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols,
-                             L.hr_pitch, dec->dev.skeleton, p.force_complete_caf_th, 0.1,
-                             p.ablation_caf_no_rescore, (float*)(ws + L.off_lists_fc),
-                             (int32_t*)(ws + L.off_list_counts_fc), st,
-                             (float*)(ws + L.off_list_bbox_fc), L.bbox_chunks, L.bbox_chunks);
-        if (e != hipSuccess) return fail_hip(e, "cafscored(force complete)");
+    if (!fuse) {
+        e = launch_cafscored(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols, L.hr_pitch,
+                             dec->dev.skeleton, p.caf_threshold, p.cif_floor, p.ablation_caf_no_rescore,
+                             (float*)(ws + L.off_lists), (int32_t*)(ws + L.off_list_counts), st,
+                             (float*)(ws + L.off_list_bbox), L.bbox_chunks < kListBboxChunks ? L.bbox_chunks : kListBboxChunks,
+                             L.bbox_chunks);                                                     // :153-161
+        if (e != hipSuccess) return fail_hip(e, "cafscored");
+        if (p.force_complete) {                                                               // :419-420
+            e = launch_cafscored(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols,
+                                 L.hr_pitch, dec->dev.skeleton, p.force_complete_caf_th, 0.1,
+                                 p.ablation_caf_no_rescore, (float*)(ws + L.off_lists_fc),
+                                 (int32_t*)(ws + L.off_list_counts_fc), st,
+                                 (float*)(ws + L.off_list_bbox_fc), L.bbox_chunks, L.bbox_chunks);
+            if (e != hipSuccess) return fail_hip(e, "cafscored(force complete)");
+        }
     }
     // (the occupancy map of :173 is a bitmap the association kernel clears itself)
     AssocArgs a;

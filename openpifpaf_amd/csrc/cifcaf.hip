@@ -125,9 +125,9 @@ struct ImageCtx {
     float* tgt;                          // [3][kBlendChunks][64] target columns of the list being scanned
     struct OccBox* jbox;                 // occupancy boxes of the grown pose [K]
     double* jv; float *jx, *jy, *js;     // current pose [K]
-    unsigned long long* heap;            // [2A] nodes: float bits of max_score << 32 | slot
-    double* e_v; float *e_x, *e_y, *e_s;   // LDS variant: the frontier entry of every directed-bone slot [2A] (v == 0: not computed yet)
-    unsigned char* in_frontier;          // [2A]
+    unsigned long long* heap;            // [A] nodes: float bits of max_score << 32 | directed-bone slot
+    double* e_v; float *e_x, *e_y, *e_s;   // LDS variant: the frontier entry of every bone [A] (v == 0: not computed yet)
+    unsigned char* in_frontier;          // [A] (LDS variant)
     int heap_n;
     int max_r;                           // chunks of a list the LDS target area holds (8, or 2 when LDS is short)
     // shared LDS
@@ -816,10 +816,12 @@ __device__ __forceinline__ int heap_pop(ImageCtx& c) {          // returns the t
     return top;
 }
 
-// LDS variant of the growth state (skeletons past 64 joints / 64 directed bones).  Like in the register variant
-// below, the frontier entry of a directed bone lives in ITS slot: an entry is popped before it is pushed again
-// (cifcaf.cpp:298-303) and in_frontier admits a bone once (:329), so 2A entries and heap nodes suffice (round 2
-// appended entries to a pool of 4A and searched the adjacency for the slot at every evaluation).
+// LDS variant of the growth state (skeletons past 64 joints / 64 directed bones).  The frontier entry of a bone lives
+// in the BONE's slot: an entry is popped before it is pushed again (cifcaf.cpp:298-303), in_frontier admits a
+// directed bone once (:329), and of the two directions of a bone only one can ever be pushed during a growth -- (a -> b)
+// needs a filled and b empty, (b -> a) the opposite, and joints never empty again -- so A entries, heap nodes and
+// in_frontier flags suffice (round 2 appended entries to a pool of 4A and searched the adjacency for the slot at
+// every evaluation).  A heap node carries the directed slot (start, end, list), the entry is found through its bone.
 
 // cifcaf.cpp:349-411 for the directed bone `info` (its first slot: the bone _connection_value's scan finds, :361-374)
 template <bool LONG>
@@ -853,24 +855,28 @@ __device__ __forceinline__ void frontier_add_from(ImageCtx& c, int start) {
     for (int base = t0; base < t1; base += kWave) {
         const int t = base + lane;
         bool cand = false;
+        int bone = 0;
         if (t < t1) {
-            const int other = (c.slot_info[t] >> 8) & 0xff;
-            cand = c.adj_first[t] == t && !(c.jv[other] > 0.0) && !c.in_frontier[t];
+            const int info = c.slot_info[t];
+            const int other = (info >> 8) & 0xff;
+            bone = (info >> 16) & 0xff;
+            cand = c.adj_first[t] == t && !(c.jv[other] > 0.0) && !c.in_frontier[bone];
         }
         unsigned long long m = __ballot(cand);
         while (m) {
-            const int tt = base + __builtin_ctzll(m);
+            const int l = __builtin_ctzll(m);
             m &= m - 1;
-            c.e_v[tt] = 0.0;
-            heap_push(c, max_score, tt);
-            c.in_frontier[tt] = 1;
+            const int bn = __builtin_amdgcn_readlane(bone, l);
+            c.e_v[bn] = 0.0;
+            heap_push(c, max_score, base + l);
+            c.in_frontier[bn] = 1;
         }
     }
 }
 
 __device__ __forceinline__ void frontier_start(ImageCtx& c) {
     const int lane = lane_id();
-    for (int t = lane; t < 2 * c.A; t += kWave) c.in_frontier[t] = 0;
+    for (int t = lane; t < c.A; t += kWave) c.in_frontier[t] = 0;
     c.heap_n = 0;
     wave_sync();
     for (int j0 = 0; j0 < c.K; j0 += kWave) {
@@ -891,9 +897,9 @@ __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool rever
         if (poll_task(c)) { c.aborted = 1; return; }                     // the seed died while its pose grew
         const int slot = heap_pop(c);
         const int info = c.slot_info[slot];
-        const int end = (info >> 8) & 0xff;
+        const int end = (info >> 8) & 0xff, bn = (info >> 16) & 0xff;
         if (c.jv[end] > 0.0) { PH(0); continue; }                        // :284
-        double v = c.e_v[slot]; float x = c.e_x[slot], y = c.e_y[slot], s = c.e_s[slot];
+        double v = c.e_v[bn]; float x = c.e_x[bn], y = c.e_y[bn], s = c.e_s[bn];
         PH(0);
         if (v == 0.0) {                                                  // :287: not computed yet
             if (!connection_value<LONG>(c, p, info, reverse_match_, filter_sigmas, &v, &x, &y, &s)) {
@@ -902,7 +908,7 @@ __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool rever
             }
             PH(7);
             if (!p.greedy) {                                             // :298-303
-                c.e_v[slot] = v; c.e_x[slot] = x; c.e_y[slot] = y; c.e_s[slot] = s;
+                c.e_v[bn] = v; c.e_x[bn] = x; c.e_y[bn] = y; c.e_s[bn] = s;
                 heap_push(c, (float)v, slot);
                 PH(8);
                 continue;
@@ -1201,6 +1207,7 @@ __device__ __forceinline__ bool box_contains(const OccBox& b, int xi, int yi) {
 
 constexpr int kPoolSlots = 8;             // seed-pool slots per coordinator lane
 constexpr int kSeedStage = 1024;          // seeds (field, cell) the coordinator keeps staged in LDS beyond its scan position (ring)
+constexpr int kDedupBits = 10;            // buckets (log2) of the coordinator's first-seed-of-a-cell table
 constexpr int kPoolIdxMask = 0xFFFFFF;    // seed index bits of a slot word (all ones: empty slot); field above
 
 __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s) {
@@ -1283,14 +1290,13 @@ __host__ __device__ inline size_t assoc_pose_bytes(int K) {
     return (16 * (size_t)K + sizeof(double) * K + sizeof(float) * 3 * K + 15) / 16 * 16;
 }
 __host__ __device__ inline size_t assoc_private_bytes(int K, int A, bool reg, int tgt_floats) {
-    const int E = 2 * A;
     size_t b = assoc_pose_bytes(K);
-    if (!reg) b += sizeof(double) * E + sizeof(unsigned long long) * E + sizeof(float) * 3 * E + (E + 15) / 16 * 16;
-    return b + sizeof(float) * tgt_floats;
+    if (!reg) b += sizeof(double) * A + sizeof(unsigned long long) * A + sizeof(float) * 3 * A + (A + 15) / 16 * 16 + (A & 1 ? 4 : 0);
+    return (b + 15) / 16 * 16 + sizeof(float) * tgt_floats;
 }
 template <bool REG>
 __device__ __forceinline__ void carve_private(ImageCtx& c, unsigned char* sp, int tgt_floats) {
-    const int K = c.K, E = 2 * c.A;
+    const int K = c.K, A = c.A;
     unsigned char* base = sp;
     c.jbox = (OccBox*)sp; sp += sizeof(OccBox) * K;
     c.jv = (double*)sp; sp += sizeof(double) * K;
@@ -1300,12 +1306,13 @@ __device__ __forceinline__ void carve_private(ImageCtx& c, unsigned char* sp, in
     sp = base + assoc_pose_bytes(K);
     c.e_v = nullptr; c.heap = nullptr; c.e_x = c.e_y = c.e_s = nullptr; c.in_frontier = nullptr;
     if constexpr (!REG) {
-        c.e_v = (double*)sp; sp += sizeof(double) * E;
-        c.heap = (unsigned long long*)sp; sp += sizeof(unsigned long long) * E;
-        c.e_x = (float*)sp; sp += sizeof(float) * E;
-        c.e_y = (float*)sp; sp += sizeof(float) * E;
-        c.e_s = (float*)sp; sp += sizeof(float) * E;
-        c.in_frontier = sp; sp += (E + 15) / 16 * 16;
+        c.e_v = (double*)sp; sp += sizeof(double) * A;
+        c.heap = (unsigned long long*)sp; sp += sizeof(unsigned long long) * A;
+        c.e_x = (float*)sp; sp += sizeof(float) * A;
+        c.e_y = (float*)sp; sp += sizeof(float) * A;
+        c.e_s = (float*)sp; sp += sizeof(float) * A;
+        c.in_frontier = sp; sp += (A + 15) / 16 * 16 + (A & 1 ? 4 : 0);
+        sp = base + (((size_t)(sp - base) + 15) & ~(size_t)15);
     }
     c.tgt = (float*)sp;
     c.max_r = tgt_floats >= kBlendLdsFloats ? kBlendChunks : kSmallTgtChunks;
@@ -1547,6 +1554,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     //      keypoint-NMS arrays afterwards
     unsigned char* sp = smem;
     TaskSlot* task = (TaskSlot*)sp; sp += sizeof(TaskSlot) * NW;            // (16-byte aligned: first)
+    unsigned long long* dedup = (unsigned long long*)sp; sp += sizeof(unsigned long long) << kDedupBits;   // refill: first seed of a cell
     c.sh_counts = (int*)sp; sp += sizeof(int) * E;
     int* l_off = (int*)sp; sp += sizeof(int) * (K + 1);
     int* l_info = (int*)sp; sp += sizeof(int) * E;
@@ -1604,6 +1612,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
 #endif
     for (int k = tid; k < kPoolSlots * kWave; k += kThreads) { pool_if[k] = kPoolIdxMask; pool_pack[k] = 0; pool_ep[k] = 0; }
     for (int k = tid; k < NW * kWave; k += kThreads) shadow_by[k] = 0u;
+    for (int k = tid; k < (1 << kDedupBits); k += kThreads) dedup[k] = ~0ull;
+    const bool dedup_on = a.dedup != 0;
     c.adj_off = l_off; c.slot_info = l_info; c.adj_first = l_first;
     sync_global();                                   // bitmap zeros are in memory before anyone marks or tests
     RegSkeleton rs; rs.slot_info = 0; rs.slot_first = 0; rs.off = 0; rs.off1 = 0;
@@ -1758,7 +1768,10 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 __builtin_amdgcn_s_waitcnt(0x0F70);
                 wave_sync();
                 unsigned fresh = 0u;                     // slots filled by this refill
+                bool first_round = true;
                 while (scan_pos < n_seeds) {
+                    if (!first_round) __builtin_amdgcn_s_waitcnt(0x0F70);   // the cells marked by the round before are at the L2
+                    first_round = false;
                     int nidx[WR], base = 0;
 #pragma unroll
                     for (int r = 0; r < WR; r++) {
@@ -1791,12 +1804,51 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     }
 #pragma unroll
                     for (int r = 0; r < WR; r++) asm volatile("" : "+v"(ow[r]) :: "memory");
+                    // Of the seeds of ONE occupancy cell of a field only the first can ever be free at its turn: if it is,
+                    // its pose is accepted with the seed as joint f and the box of that joint contains the seed's own cell
+                    // (occupancy.cpp:13-29: sigma >= 2 cells around it); if it is not, the box that covers its cell covers
+                    // the same cell of the later seeds.  So a later seed of a cell already seen is dead for good, whatever
+                    // happens to the first -- and a confidence blob's cells all regress to the same point, i.e. mostly the
+                    // same cell.  Each admitted seed therefore marks its own cell in the bitmap (the next refills test
+                    // against it), and inside one refill round the first seed of a cell is found through a small LDS
+                    // table (64-bit min of cell key << 32 | seed index; a bucket taken by another key just admits).
+                    bool cand[WR]; unsigned key[WR]; int bkt[WR];
 #pragma unroll
-                    for (int r = 0; r < WR; r++)
-                        if (nidx[r] < n_seeds && !((ow[r] >> (pk[r] & 31)) & 1u)) {
+                    for (int r = 0; r < WR; r++) {
+                        cand[r] = nidx[r] < n_seeds && !((ow[r] >> (pk[r] & 31)) & 1u);
+                        key[r] = ((unsigned)ff[r] << 24) | ((unsigned)pk[r] & 0xFFFFFFu);
+                        bkt[r] = (int)((key[r] * 2654435761u) >> (32 - kDedupBits));
+                        if (cand[r] && dedup_on)
+                            __hip_atomic_fetch_min(&dedup[bkt[r]], ((unsigned long long)key[r] << 32) | (unsigned)nidx[r],
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    wave_sync();
+                    unsigned long long seen[WR];
+#pragma unroll
+                    for (int r = 0; r < WR; r++) seen[r] = dedup[bkt[r]];
+#pragma unroll
+                    for (int r = 0; r < WR; r++) asm volatile("" : "+v"(seen[r]) :: "memory");
+                    wave_sync();                         // every lane has read its buckets: give them back
+#pragma unroll
+                    for (int r = 0; r < WR; r++) if (cand[r] && dedup_on) dedup[bkt[r]] = ~0ull;
+                    int n_dup = 0;
+#pragma unroll
+                    for (int r = 0; r < WR; r++) {
+                        const bool later = dedup_on && (unsigned)(seen[r] >> 32) == key[r] && (unsigned)seen[r] != (unsigned)nidx[r];
+                        if (cand[r] && !later) {
                             s_pack[r] = pk[r]; s_if[r] = nidx[r] | (ff[r] << 24);
                             occupied |= 1u << r; emitted &= ~(1u << r); ever &= ~(1u << r); fresh |= 1u << r;
+                            if (dedup_on) {
+                                const size_t word = ((size_t)ff[r] * c.occ_h + ((pk[r] >> 12) & 0xfff)) * c.occ_wpr + ((pk[r] & 0xfff) >> 5);
+                                atomicOr(&c.occ[word], 1u << (pk[r] & 31));
+                            }
                         }
+                        n_dup += cand[r] && later ? 1 : 0;
+                    }
+                    if (__ballot(n_dup > 0) != 0ull) {
+#pragma unroll
+                        for (int k = 0; k < WR; k++) st[23] += __popcll(__ballot(n_dup > k));
+                    }
                     scan_pos = scan_pos + base < n_seeds ? scan_pos + base : n_seeds;
                     count_live();
                     if (2 * n_live >= WR * kWave) break;
@@ -2253,7 +2305,7 @@ static hipError_t launch_fc_nw(const AssocArgs& a, const DevSkeleton& sk, const 
 template <bool REG, int NW>
 static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
     const int K = a.K, A = a.A, E = 2 * A;
-    size_t shared = sizeof(TaskSlot) * NW + sizeof(int) * (3 * E + K + 1 + 12 + kAssocStats)
+    size_t shared = sizeof(TaskSlot) * NW + (sizeof(unsigned long long) << kDedupBits) + sizeof(int) * (3 * E + K + 1 + 12 + kAssocStats)
                   + sizeof(int) * (3 * kPoolSlots + NW) * kWave + sizeof(int) * 2 * kSeedStage;
     shared = (shared + 15) / 16 * 16 + (REG && a.list_bbox ? sizeof(float4) * E * kListBboxChunks : 0);
     // work area behind it: one private block per grower while poses grow, the keypoint-NMS arrays afterwards
@@ -2310,6 +2362,10 @@ static int assoc_waves() {
 hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
     AssocArgs a = args;
     if (const char* e = getenv("OPA_ASSOC_BBOX")) { if (atoi(e) == 0) a.list_bbox = a.list_bbox_fc = nullptr; }   // A/B: scan every chunk
+    // (the argument needs a joint's box to hold the joint's own cell: true for a reduced minimum scale >= 1 cell --
+    // the reference's is 2 -- not for a box that may shrink to the one cell next to it)
+    a.dedup = p.occupancy_min_scale_reduced >= 1.0 ? 1 : 0;
+    if (const char* e = getenv("OPA_ASSOC_DEDUP")) { if (atoi(e) == 0) a.dedup = 0; }   // A/B and tests: same result without it
     a.watchdog_ticks = kWatchdogTicksDefault;
     if (const char* e = getenv("OPA_ASSOC_WATCHDOG_TICKS")) { const long long v = atoll(e); if (v > 0) a.watchdog_ticks = v; }
     const int K = a.K, E = 2 * a.A;

@@ -35,7 +35,10 @@ __device__ __forceinline__ void gauss_box(float cx, float cy, float sigma, int r
 
 // ---------------------------------------------------------------- pass 1
 // DET: CifDet fields [F,6,H,W] (w,h instead of scale), CifDetHr::accumulate cif_hr.cpp:124-150
-constexpr int kActiveThreads = 256;
+#ifndef OPA_ACTIVE_THREADS
+#define OPA_ACTIVE_THREADS 256
+#endif
+constexpr int kActiveThreads = OPA_ACTIVE_THREADS;
 constexpr int kActiveCells = 4;
 
 template <bool DET>
@@ -184,6 +187,9 @@ __device__ __forceinline__ void build_tile(const float* __restrict__ A, int n, i
             hit = minx < x1 && maxx > x0 && miny < y1 && maxy > y0;
         }
         unsigned long long mask = __ballot(hit);
+#ifdef OPA_TILE_WALK_ONLY               // diagnostic: the list walk without the accumulation (what tile-binned lists could save)
+        mask = 0ull;
+#endif
         while (mask) {
             const int l = __builtin_ctzll(mask);
             mask &= mask - 1;

@@ -15,11 +15,8 @@
 //      u64 keys, entirely in LDS when n <= 8192 (64 KiB), otherwise LDS-blocked
 //      with the far strides done through L2.  The epilogue decodes the keys and
 //      writes the sorted (f, v, x, y, s) arrays the association kernel streams.
-#include "common.hpp"
+#include "cafscored_impl.hpp"
 
-#ifdef OPA_SORT_RADIX
-#include <rocprim/block/block_radix_sort.hpp>
-#endif
 
 namespace opa {
 
@@ -118,9 +115,6 @@ __device__ __forceinline__ void compare_exchange_desc(unsigned long long& a, uns
 // total order, so the result does not depend on the algorithm.
 // (Measured on the bench batch: 72.7 us against 74.0 us for the bitonic network below -- the kernel is bound by the
 // busiest image's serial passes either way -- so the hand-written network stays the default; -DOPA_SORT_RADIX.)
-#ifdef OPA_SORT_RADIX
-using SeedRadixSort = rocprim::block_radix_sort<unsigned long long, 1024, kSortLdsKeys / 1024>;
-#endif
 
 // Images with more than 8192 seeds (wholebody: 133 fields, ~20 000 seeds): every 8192-key block is sorted by a
 // workgroup of its own (kSortBlocksMax per image in the sort kernel's grid), then cifseeds_rankmerge_kernel gives every
@@ -159,21 +153,23 @@ __device__ __forceinline__ void store_seed(unsigned long long key, int t, int b,
     }
 }
 
-__global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
-        unsigned long long* keys, int sort_cap, int cap, const int32_t* __restrict__ seed_count,
-        const float* __restrict__ cif, int F, int NC, int HW, int stride,
-        int32_t* __restrict__ seed_f, float* __restrict__ seed_vxys,
-        int32_t* __restrict__ seed_cell, int occ_h, int occ_w, DevParams p) {
+struct SortArgs {
+    unsigned long long* keys; int sort_cap, cap; const int32_t* seed_count;
+    const float* cif; int F, NC, HW, stride;
+    int32_t* seed_f; float* seed_vxys; int32_t* seed_cell; int occ_h, occ_w;
+};
+
 #ifdef OPA_SORT_RADIX
-    __shared__ union {
-        unsigned long long keys[kSortLdsKeys];
-        typename SeedRadixSort::storage_type radix;
-    } lds;
-    unsigned long long* sk = lds.keys;
-#else
-    __shared__ unsigned long long sk[kSortLdsKeys];
+#error "the rocPRIM variant predates the block split (round 2 experiment)"
 #endif
-    const int b = blockIdx.x / kSortBlocksMax, part = blockIdx.x - b * kSortBlocksMax, tid = threadIdx.x;
+
+// the sort of one workgroup (block `block` of the grid's sort part); `sk`: 64 KiB of LDS
+__device__ __forceinline__ void cifseeds_sort_body(const SortArgs& g, const DevParams& p, int block, unsigned long long* sk) {
+    unsigned long long* keys = g.keys; const int sort_cap = g.sort_cap, cap = g.cap;
+    const int32_t* __restrict__ seed_count = g.seed_count; const float* __restrict__ cif = g.cif;
+    const int F = g.F, NC = g.NC, HW = g.HW, stride = g.stride, occ_h = g.occ_h, occ_w = g.occ_w;
+    int32_t* __restrict__ seed_f = g.seed_f; float* __restrict__ seed_vxys = g.seed_vxys; int32_t* __restrict__ seed_cell = g.seed_cell;
+    const int b = block / kSortBlocksMax, part = block - b * kSortBlocksMax, tid = threadIdx.x;
     unsigned long long* K = keys + (size_t)b * sort_cap;
     int n = seed_count[b];
     if (n > cap) n = cap;
@@ -302,29 +298,6 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
         return;
     }
 
-#ifdef OPA_SORT_RADIX
-    if (in_lds && n_pad > 1024) {
-        constexpr int IPT = kSortLdsKeys / 1024;
-        int idx_bits = 1;
-        while ((1 << idx_bits) < cap) idx_bits++;                   // cell indices are < cap = F*H*W
-        const unsigned long long idx_mask = (1ull << idx_bits) - 1ull;
-        unsigned long long v[IPT];
-#pragma unroll
-        for (int i = 0; i < IPT; i++) {                             // blocked arrangement: thread t holds keys t*IPT ..
-            const int t = tid * IPT + i;
-            const unsigned long long key = t < n ? K[t] : 0ull;
-            v[i] = t < n ? ((key >> 32) << idx_bits) | (key & idx_mask) : 0ull;     // low word = ~cell index
-        }
-        SeedRadixSort().sort_desc(v, lds.radix, 0, 32 + idx_bits);
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < IPT; i++) {
-            const unsigned long long k2 = v[i];
-            sk[tid * IPT + i] = ((k2 >> idx_bits) << 32) | (0xFFFFFFFFull & ~idx_mask) | (k2 & idx_mask);
-        }
-        __syncthreads();
-    } else
-#endif
     if (in_lds) {
         for (int t = tid; t < n_pad; t += 1024) sk[t] = t < n ? K[t] : 0ull;
         __syncthreads();
@@ -369,6 +342,27 @@ __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(
         store_seed(in_lds ? sk[t] : K[t], t, b, cif, F, NC, HW, stride, cap, seed_f, seed_vxys, seed_cell, occ_h, occ_w, p);
 }
 
+__global__ __launch_bounds__(1024) void cifseeds_sort_kernel(SortArgs g, DevParams p) {
+    __shared__ unsigned long long sk[kSortLdsKeys];
+    cifseeds_sort_body(g, p, blockIdx.x, sk);
+}
+
+// The decode's form: the same launch also builds the CAF lists (CafScored::fill).  Seed sort and list building only
+// share the finished CifHr map; the sort keeps a handful of workgroups busy for ~40 us (its passes are serial), the list
+// building streams 128 MB through all of the chip in about the same time -- side by side instead of one after the other.
+// Blocks [0, n_sort): sort; behind them, two 512-thread groups per workgroup, one (image, CAF field) plane each, list set
+// 0 first, then list set 1 (force complete).
+__global__ __launch_bounds__(1024) void cifseeds_sort_scored_kernel(SortArgs g, DevParams p, int n_sort, ScoredArgs s0, ScoredArgs s1,
+                                                                    int wgs0) {
+    __shared__ unsigned long long sk[kSortLdsKeys];
+    if ((int)blockIdx.x < n_sort) { cifseeds_sort_body(g, p, blockIdx.x, sk); return; }
+    __shared__ int wave_tot[2][2][kScoredThreads / 64];
+    extern __shared__ float bb_dyn[];
+    const int wg = blockIdx.x - n_sort, group = threadIdx.x >> 9, tid = threadIdx.x & (kScoredThreads - 1);
+    if (wg < wgs0) cafscored_plane(s0, 2 * wg + group, tid, wave_tot[group], bb_dyn + group * 2 * s0.nb * 4);
+    else cafscored_plane(s1, 2 * (wg - wgs0) + group, tid, wave_tot[group], bb_dyn + group * 2 * s1.nb * 4);
+}
+
 // final position of every key of a block-sorted image (see kSortBlocksMax) + the decoded seed
 __global__ __launch_bounds__(256) void cifseeds_rankmerge_kernel(
         const unsigned long long* __restrict__ keys, int sort_cap, int cap, const int32_t* __restrict__ seed_count,
@@ -408,7 +402,9 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
                            const float* cifhr, int hr_rows, int hr_cols, int hr_pitch, const DevParams& p,
                            unsigned long long* keys, int sort_cap, int32_t* seed_count,
                            int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det,
-                           int32_t* seed_cell, int occ_h, int occ_w, bool count_is_zero) {
+                           int32_t* seed_cell, int occ_h, int occ_w, bool count_is_zero,
+                           const ScoredArgs* scored, int n_scored) {
+    static_assert(kScoredThreads == 512, "the fused launch packs two cafscored groups into a 1024-thread workgroup");
     const int HW = H * W, cap = F * HW, NC = det ? 6 : 5;
     if (!count_is_zero) {                             // (the decode pipeline clears the counters in its first kernel)
         hipError_t e = launch_zero(seed_count, sizeof(int32_t) * B, st);
@@ -420,14 +416,26 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
                                                p.seed_threshold, det ? 0 : p.ablation_cifseeds_nms,
                                                det ? 0 : p.ablation_cifseeds_no_rescore, keys, sort_cap, cap, seed_count);
     prof_mark(st, "cifseeds_fill_kernel");
-    cifseeds_sort_kernel<<<B * kSortBlocksMax, 1024, 0, st>>>(keys, sort_cap, cap, seed_count, cif, F, NC, HW, stride,
-                                                              seed_f, seed_vxys, seed_cell, occ_h, occ_w, p);
+    SortArgs g;
+    g.keys = keys; g.sort_cap = sort_cap; g.cap = cap; g.seed_count = seed_count; g.cif = cif; g.F = F; g.NC = NC; g.HW = HW;
+    g.stride = stride; g.seed_f = seed_f; g.seed_vxys = seed_vxys; g.seed_cell = seed_cell; g.occ_h = occ_h; g.occ_w = occ_w;
+    const int n_sort = B * kSortBlocksMax;
+    if (scored && n_scored > 0) {
+        const ScoredArgs& s0 = scored[0];
+        const ScoredArgs& s1 = scored[n_scored > 1 ? 1 : 0];
+        const int wgs0 = (s0.planes + 1) / 2, wgs1 = n_scored > 1 ? (s1.planes + 1) / 2 : 0;
+        const int nb_max = s0.nb > s1.nb || n_scored < 2 ? s0.nb : s1.nb;
+        const size_t lds = sizeof(float) * 2 * 2 * nb_max * 4;
+        cifseeds_sort_scored_kernel<<<n_sort + wgs0 + wgs1, 1024, lds, st>>>(g, p, n_sort, s0, s1, wgs0);
+    } else {
+        cifseeds_sort_kernel<<<n_sort, 1024, 0, st>>>(g, p);
+    }
     if (cap > kSortSmallBlock) {                      // images of more than one block of seeds are possible
         const int most = cap < kSortBlocksMax * kSortLdsKeys ? cap : kSortBlocksMax * kSortLdsKeys;
         cifseeds_rankmerge_kernel<<<dim3((most + 255) / 256, B), 256, 0, st>>>(keys, sort_cap, cap, seed_count, cif, F, NC, HW,
                                                                                  stride, seed_f, seed_vxys, seed_cell, occ_h, occ_w, p);
     }
-    prof_mark(st, "cifseeds_sort_kernel");
+    prof_mark(st, scored && n_scored > 0 ? "sort_cafscored_kernel" : "cifseeds_sort_kernel");
     return hipGetLastError();
 }
 

@@ -79,11 +79,31 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
 // [2] 1 = stored bitmap invalid for this call (written by the first kernel of a call).
 constexpr unsigned long long kWsMagic = 0x6f70615f63696668ull;   // "opa_cifh"
 
+struct ScoredArgs;
 hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int stride,
                            const float* cifhr, int hr_rows, int hr_cols, int hr_pitch, const DevParams& p,
                            unsigned long long* keys, int sort_cap, int32_t* seed_count,
                            int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det = false,
-                           int32_t* seed_cell = nullptr, int occ_h = 0, int occ_w = 0, bool count_is_zero = false);
+                           int32_t* seed_cell = nullptr, int occ_h = 0, int occ_w = 0, bool count_is_zero = false,
+                           const ScoredArgs* scored = nullptr, int n_scored = 0);
+// (`scored`: up to two CafScored list sets built by the SAME launch as the seed sort -- they only share the finished
+// map, and the sort's few workgroups leave the chip to them)
+
+// CafScored::fill of one list set (cafscored_impl.hpp)
+struct ScoredArgs {
+    const float* caf; int A, HW, stride;
+    const float* cifhr; int F, hr_rows, hr_cols, hr_pitch;
+    const int64_t* skeleton; double score_th, cif_floor; int no_rescore;
+    float* lists; int32_t* counts;
+    float* chunk_bbox; int nb, nb_stride;     // nb: chunks per list that get a box (the first kListBboxChunks for the caf_th
+                                              // set; all of them for the force-complete set); nb_stride: boxes per list in memory
+    int planes;                               // B * A
+};
+
+ScoredArgs make_scored_args(const float* caf, int B, int A, int cH, int cW, int cstride,
+                            const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
+                            const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
+                            float* lists, int32_t* counts, float* chunk_bbox, int bbox_chunks, int bbox_stride);
 
 hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
@@ -117,6 +137,7 @@ struct AssocArgs {
     const float* list_bbox;  // [B][A][2][bbox_chunks][4] chunk boxes of `lists` (or null)
     const float* list_bbox_fc;  // ... of `lists_fc` (or null)
     int bbox_chunks;
+    int dedup;                  // 1: later seeds of an occupancy cell already seen are dropped at the pool refill (exact; see cifcaf.hip)
     int32_t* fc_meta;           // [B, 4] seed kernel -> force-complete kernel: poses stored, dropped, failed, workgroup counter
     long long watchdog_ticks;   // 10-ns ticks after which every wait inside one launch gives up (status -1)
     unsigned* occ;           // occupancy bitmap [B][occ_image_words]: per image [F][occ_h][(occ_w+31)/32] words, zeroed by the kernel
