@@ -142,7 +142,7 @@ struct AssocArgs {
     long long watchdog_ticks;   // 10-ns ticks after which every wait inside one launch gives up (status -1)
     unsigned* occ;           // occupancy bitmap [B][occ_image_words]: per image [F][occ_h][(occ_w+31)/32] words, zeroed by the kernel
     size_t occ_image_words;
-    int32_t* stats;          // [B, 16] statistics of the association (or null), see include/openpifpaf_amd.h
+    int32_t* stats;          // [B, 24] statistics of the association (or null), see include/openpifpaf_amd.h
     int32_t* trace;          // [B, 64, 4] the first commits of each image (or null): commit / hand-out / done tick, seed | grower << 24
     double* anns;            // [B, max_ann, K, 4] doubles (v,x,y,s) scratch
     int64_t* ann_ids;        // [B, max_ann]
