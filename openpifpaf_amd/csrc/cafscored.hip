@@ -27,7 +27,8 @@ __global__ __launch_bounds__(kScoredThreads, 2) void cafscored_kernel(ScoredArgs
 ScoredArgs make_scored_args(const float* caf, int B, int A, int cH, int cW, int cstride,
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
-                            float* lists, int32_t* counts, float* chunk_bbox, int bbox_chunks, int bbox_stride) {
+                            float* lists, int32_t* counts, float* chunk_bbox, int bbox_chunks, int bbox_stride,
+                            const unsigned* tile_touch) {
     if (bbox_chunks <= 0) chunk_bbox = nullptr;
     if (bbox_stride < bbox_chunks) bbox_stride = bbox_chunks;
     ScoredArgs s;
@@ -35,7 +36,16 @@ ScoredArgs make_scored_args(const float* caf, int B, int A, int cH, int cW, int 
     s.hr_pitch = hr_pitch; s.skeleton = skeleton; s.score_th = score_th; s.cif_floor = cif_floor; s.no_rescore = no_rescore;
     s.lists = lists; s.counts = counts; s.chunk_bbox = chunk_bbox; s.nb = chunk_bbox ? bbox_chunks : 0; s.nb_stride = bbox_stride;
     s.planes = B * A;
+    s.tile_touch = tile_touch; s.tiles_x = hr_pitch / kHrTileW;
+    s.touch_words = (s.tiles_x * ((hr_rows + kHrTileH - 1) / kHrTileH) + 31) / 32;
     return s;
+}
+
+hipError_t launch_cafscored(const ScoredArgs& s, hipStream_t st) {
+    const size_t lds = s.chunk_bbox ? sizeof(float) * 2 * s.nb * 4 : 0;
+    cafscored_kernel<<<s.planes, kScoredThreads, lds, st>>>(s);
+    prof_mark(st, "cafscored_kernel");
+    return hipGetLastError();
 }
 
 hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
@@ -43,12 +53,8 @@ hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int 
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
                             float* lists, int32_t* counts, hipStream_t st, float* chunk_bbox, int bbox_chunks,
                             int bbox_stride) {
-    const ScoredArgs s = make_scored_args(caf, B, A, cH, cW, cstride, cifhr, F, hr_rows, hr_cols, hr_pitch, skeleton, score_th,
-                                          cif_floor, no_rescore, lists, counts, chunk_bbox, bbox_chunks, bbox_stride);
-    const size_t lds = s.chunk_bbox ? sizeof(float) * 2 * s.nb * 4 : 0;
-    cafscored_kernel<<<B * A, kScoredThreads, lds, st>>>(s);
-    prof_mark(st, "cafscored_kernel");
-    return hipGetLastError();
+    return launch_cafscored(make_scored_args(caf, B, A, cH, cW, cstride, cifhr, F, hr_rows, hr_cols, hr_pitch, skeleton, score_th,
+                                             cif_floor, no_rescore, lists, counts, chunk_bbox, bbox_chunks, bbox_stride), st);
 }
 
 }  // namespace opa

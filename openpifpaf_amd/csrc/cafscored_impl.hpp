@@ -80,6 +80,7 @@ __device__ __forceinline__ void cafscored_plane(const ScoredArgs& s, int plane_i
     const int lane = tid & 63, w = tid >> 6;
     const float* P = caf + (size_t)plane * 8 * HW;
     const float* hr = cifhr + (size_t)b * F * hr_rows * hr_pitch;
+    const unsigned* touch = s.tile_touch ? s.tile_touch + (size_t)b * F * s.touch_words : nullptr;
     float* Lf = lists + ((size_t)plane * 2 + 0) * 7 * HW;
     float* Lb = lists + ((size_t)plane * 2 + 1) * 7 * HW;
     const long long j1 = skeleton[2 * a + 0], j2 = skeleton[2 * a + 1];
@@ -102,8 +103,8 @@ __device__ __forceinline__ void cafscored_plane(const ScoredArgs& s, int plane_i
                 s1 = r6 * stride_f; s2 = r7 * stride_f;
                 cf = c; cb = c;
                 if (!no_rescore) {                                       // :66-71
-                    const float fhr = cifhr_value(hr, F, hr_rows, hr_cols, hr_pitch, j2, x2, y2, 0.0f);
-                    const float bhr = cifhr_value(hr, F, hr_rows, hr_cols, hr_pitch, j1, x1, y1, 0.0f);
+                    const float fhr = cifhr_value(hr, F, hr_rows, hr_cols, hr_pitch, j2, x2, y2, 0.0f, touch, s.touch_words, s.tiles_x);
+                    const float bhr = cifhr_value(hr, F, hr_rows, hr_cols, hr_pitch, j1, x1, y1, 0.0f, touch, s.touch_words, s.tiles_x);
                     cf = (float)((double)c * (cif_floor + (1.0 - cif_floor) * (double)fhr));
                     cb = (float)((double)c * (cif_floor + (1.0 - cif_floor) * (double)bhr));
                 }

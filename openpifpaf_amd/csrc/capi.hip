@@ -364,19 +364,28 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     // the sort's workgroups -- measured in round 3: 90 us against 42 + 41 us one after the other, 323 against 170 us with
     // the force-complete set: under the sort kernel's 64 KiB of static LDS and 1024-thread workgroups the list building
     // gets two workgroups per compute unit instead of its six, and loses more than the overlap gives.)
+    // this call's touched-tile bitmap of the map (second half of the tile state; cif_active_kernel wrote it): the
+    // force-complete pass looks two map values up for nearly EVERY cell of a field -- a gigabyte of memory lines for a batch
+    // of 32, nine tenths of them in tiles nothing was written to -- and skips those gathers (cafscored 128 -> 92 us)
+    const unsigned* tile_touch = nullptr;
+    if (!p.ablation_cifhr_skip) {
+        const size_t tpp = (size_t)(L.hr_pitch / kHrTileW) * ((L.hr_rows + kHrTileH - 1) / kHrTileH);
+        tile_touch = reinterpret_cast<const unsigned*>(ws + L.off_tile_clean) + (size_t)L.B * L.F * ((tpp + 31) / 32);
+    }
     ScoredArgs scored[2];
     int n_scored = 0;
     scored[n_scored++] = make_scored_args(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols, L.hr_pitch,
                                           dec->dev.skeleton, p.caf_threshold, p.cif_floor, p.ablation_caf_no_rescore,
                                           (float*)(ws + L.off_lists), (int32_t*)(ws + L.off_list_counts),
                                           (float*)(ws + L.off_list_bbox),
-                                          L.bbox_chunks < kListBboxChunks ? L.bbox_chunks : kListBboxChunks, L.bbox_chunks);
+                                          L.bbox_chunks < kListBboxChunks ? L.bbox_chunks : kListBboxChunks, L.bbox_chunks,
+                                          nullptr);   // (cells past caf_th point at joints: touched tiles; the bitmap would only add a dependent load)
     if (p.force_complete)
         scored[n_scored++] = make_scored_args(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols,
                                               L.hr_pitch, dec->dev.skeleton, p.force_complete_caf_th, 0.1,
                                               p.ablation_caf_no_rescore, (float*)(ws + L.off_lists_fc),
                                               (int32_t*)(ws + L.off_list_counts_fc), (float*)(ws + L.off_list_bbox_fc),
-                                              L.bbox_chunks, L.bbox_chunks);
+                                              L.bbox_chunks, L.bbox_chunks, tile_touch);
     const char* fuse_env = std::getenv("OPA_FUSE_SCORED");
     const bool fuse = fuse_env && std::atoi(fuse_env) != 0;
     e = launch_cifseeds(cif_dev, L.B, L.F, L.H, L.W, L.stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
@@ -385,22 +394,11 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
                         (float*)(ws + L.off_seed_vxys), st, false, (int32_t*)(ws + L.off_seed_cell),
                         L.occ_h, L.occ_w, true, fuse ? scored : nullptr, fuse ? n_scored : 0);   // :144-146
     if (e != hipSuccess) return fail_hip(e, "cifseeds");
-    if (!fuse) {
-        e = launch_cafscored(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols, L.hr_pitch,
-                             dec->dev.skeleton, p.caf_threshold, p.cif_floor, p.ablation_caf_no_rescore,
-                             (float*)(ws + L.off_lists), (int32_t*)(ws + L.off_list_counts), st,
-                             (float*)(ws + L.off_list_bbox), L.bbox_chunks < kListBboxChunks ? L.bbox_chunks : kListBboxChunks,
-                             L.bbox_chunks);                                                     // :153-161
-        if (e != hipSuccess) return fail_hip(e, "cafscored");
-        if (p.force_complete) {                                                               // :419-420
-            e = launch_cafscored(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols,
-                                 L.hr_pitch, dec->dev.skeleton, p.force_complete_caf_th, 0.1,
-                                 p.ablation_caf_no_rescore, (float*)(ws + L.off_lists_fc),
-                                 (int32_t*)(ws + L.off_list_counts_fc), st,
-                                 (float*)(ws + L.off_list_bbox_fc), L.bbox_chunks, L.bbox_chunks);
-            if (e != hipSuccess) return fail_hip(e, "cafscored(force complete)");
+    if (!fuse)
+        for (int k = 0; k < n_scored; k++) {
+            e = launch_cafscored(scored[k], st);
+            if (e != hipSuccess) return fail_hip(e, k ? "cafscored(force complete)" : "cafscored");
         }
-    }
     // (the occupancy map of :173 is a bitmap the association kernel clears itself)
     AssocArgs a;
     a.B = L.B; a.K = L.K; a.F = L.F; a.A = L.A; a.max_ann = L.max_ann; a.n_initial = n_initial;

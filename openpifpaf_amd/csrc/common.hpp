@@ -95,6 +95,7 @@ struct ScoredArgs {
     const float* cifhr; int F, hr_rows, hr_cols, hr_pitch;
     const int64_t* skeleton; double score_th, cif_floor; int no_rescore;
     float* lists; int32_t* counts;
+    const unsigned* tile_touch; int touch_words, tiles_x;   // [B][F][touch_words] touched-tile bitmaps of the map (or null)
     float* chunk_bbox; int nb, nb_stride;     // nb: chunks per list that get a box (the first kListBboxChunks for the caf_th
                                               // set; all of them for the force-complete set); nb_stride: boxes per list in memory
     int planes;                               // B * A
@@ -103,8 +104,10 @@ struct ScoredArgs {
 ScoredArgs make_scored_args(const float* caf, int B, int A, int cH, int cW, int cstride,
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
-                            float* lists, int32_t* counts, float* chunk_bbox, int bbox_chunks, int bbox_stride);
+                            float* lists, int32_t* counts, float* chunk_bbox, int bbox_chunks, int bbox_stride,
+                            const unsigned* tile_touch = nullptr);
 
+hipError_t launch_cafscored(const ScoredArgs& s, hipStream_t st);
 hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
@@ -231,13 +234,22 @@ __device__ __forceinline__ int seed_cell_pack(const DevParams& p, int occ_h, int
 
 // Reference cifhr_value (cif_seeds.cpp:17-30 == caf_scored.cpp:15-26) on the raw
 // revision-1 buffer: 0 = untouched (-> default), else 1 + value.
+// `touch` (or null): the image's bitmap of the map's 32x64 tiles that this call's CIF cells reach
+// ([F][touch_words] words, written by cif_active_kernel): a pixel of any other tile is 0.0 in the buffer (never
+// written, or zeroed by the lazy clear), i.e. "untouched", so its value is known without the gather -- most of a
+// map is such tiles, and a random 4-byte gather costs a whole memory line.
 __device__ __forceinline__ float cifhr_value(const float* hr_image, int F, int rows, int cols, int pitch,
-                                             long long f, float x, float y, float default_value) {
+                                             long long f, float x, float y, float default_value,
+                                             const unsigned* touch = nullptr, int touch_words = 0, int tiles_x = 0) {
     const float max_x = (float)((double)(float)cols - 0.51);
     const float max_y = (float)((double)(float)rows - 0.51);
     if (f >= F || (double)x < -0.49 || (double)y < -0.49 || x > max_x || y > max_y) return default_value;
     const long long yi = (long long)((double)y + 0.5);
     const long long xi = (long long)((double)x + 0.5);
+    if (touch) {
+        const int t = (int)(yi / kHrTileH) * tiles_x + (int)(xi / kHrTileW);
+        if (!((touch[(size_t)f * touch_words + (t >> 5)] >> (t & 31)) & 1u)) return default_value;
+    }
     const float raw = hr_image[((size_t)f * rows + yi) * pitch + xi];
     const float value = (float)((double)raw - 1.0);
     if ((double)value < 0.0) return default_value;
