@@ -266,7 +266,7 @@ class CifCaf:
         ``opa_cifcaf_workspace_view`` in the header): growths started / accepted / cancelled / dropped,
         mispredictions, ticks."""
         shape, _ = self._last
-        return self.workspace_view('assoc_stats', torch.int32).view(shape.batch, 24)
+        return self.workspace_view('assoc_stats', torch.int32)[:shape.batch * 24].view(shape.batch, 24)   # (regions are padded to 256 B)
 
     def get_cifhr(self, image=0):
         """module.cpp:37-39 -> (Tensor [F,Hhr,Whr] view of the internal buffer, revision)."""

@@ -220,3 +220,69 @@ def test_workspace_without_force_complete_regions(native, port, coco_skeleton0):
     want, _ = port.decode(cif, 8, caf, 8, coco_skeleton0)
     ok, msg = compare_annotations(out[0, :native.count_rows(int(counts[0]))].cpu().numpy(), want)
     assert ok, msg
+
+
+@pytest.mark.parametrize('case', ['one block', '2048-key blocks', '8192-key blocks'])
+def test_seed_sort_paths_are_bit_exact(native, port, case):
+    """CifSeeds::get (cif_seeds.cpp:93-114) through every path of the round-3 sort: one workgroup in LDS (up to 2048
+    seeds), 2048-key blocks + rank merge (up to 8192), 8192-key blocks + rank merge (wholebody: ~20 000 seeds).  Scores
+    and order bit-equal to the oracle's (float32 fields: no score ties)."""
+    from openpifpaf_amd import constants, synth
+    if case == 'one block':
+        cif, _ = synth.synth_fields(81_001, 2, height=41, width=41)
+        lo, hi = 1, 2048
+    elif case == '2048-key blocks':
+        cif, _ = synth.synth_fields(81_002, 18, height=81, width=81)
+        lo, hi = 2049, 8192
+    else:
+        wb = constants.wholebody()
+        cif, _ = synth.synth_fields(81_003, 8, height=81, width=81, pose=wb['standing_pose'], skeleton=wb['skeleton'])
+        lo, hi = 8193, 8 * 8192
+    ref_hr = port.cifhr_accumulate(cif, 8)
+    ref_f, ref_v = port.cifseeds(cif, 8, ref_hr)
+    assert lo <= len(ref_f) <= hi, 'case %r has %d seeds' % (case, len(ref_f))
+    hr = native.CifHr()
+    hr.accumulate(dev(cif), 8)
+    seeds = native.CifSeeds(hr)
+    seeds.fill(dev(cif), 8)
+    f, v = seeds.get()
+    f, v = f.cpu().numpy(), v.cpu().numpy()
+    assert len(np.unique(ref_v[:, 0])) > 0.99 * len(ref_v)
+    order_free = len(np.unique(ref_v[:, 0])) == len(ref_v)
+    assert len(f) == len(ref_f) and np.all(np.diff(v[:, 0]) <= 0)
+    if order_free:
+        assert np.array_equal(f, ref_f) and np.array_equal(v, ref_v)
+    else:
+        assert sorted(map(tuple, np.column_stack([f, v]).tolist())) == sorted(map(tuple, np.column_stack([ref_f, ref_v]).tolist()))
+
+
+def test_seed_dedupe_by_occupancy_cell_is_exact(native, port, coco_skeleton0, monkeypatch):
+    """Round 3: at the pool refill a later seed of an occupancy cell already seen is dropped -- it is dead for good
+    whatever happens to the first seed of that cell (either that seed's pose is accepted and its joint box covers its own
+    cell, or the box that killed it covers the same cell).  Crowded images: the counter shows seeds being dropped, every
+    image equals the oracle, the result is bit-identical with the dedupe off, and with a reduced minimum occupancy scale
+    below one cell (where the argument does not hold) the kernel switches it off by itself."""
+    from openpifpaf_amd import _lib, synth
+    cases = [(82_001, 20), (82_002, 28), (82_003, 7)]
+    fields = [synth.synth_fields(seed, people, height=81, width=81) for seed, people in cases]
+    cifs, cafs = np.stack([f[0] for f in fields]), np.stack([f[1] for f in fields])
+    got, dec = _decode(native, coco_skeleton0, cifs, cafs)
+    dropped = dec.assoc_stats()[:, 23].cpu().numpy()
+    assert (dropped > 50).all(), dropped
+    for b in range(len(cases)):
+        want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)
+        ok, msg = compare_annotations(got[b], want)
+        assert ok, msg
+    monkeypatch.setenv('OPA_ASSOC_DEDUP', '0')
+    plain, dec0 = _decode(native, coco_skeleton0, cifs, cafs)
+    monkeypatch.delenv('OPA_ASSOC_DEDUP')
+    assert (dec0.assoc_stats()[:, 23].cpu().numpy() == 0).all()
+    for b in range(len(cases)):
+        assert np.array_equal(plain[b], got[b]), 'image %d changes with the seed dedupe' % b
+    kw = dict(occupancy_min_scale=1.0)              # reduced by 2: half a cell -> a joint box may miss the joint's own cell
+    small, dec1 = _decode(native, coco_skeleton0, cifs, cafs, params=_lib.default_params(**kw))
+    assert (dec1.assoc_stats()[:, 23].cpu().numpy() == 0).all()
+    for b in range(len(cases)):
+        want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0, params=port.default_params(**kw))
+        ok, msg = compare_annotations(small[b], want)
+        assert ok, msg
