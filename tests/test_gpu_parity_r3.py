@@ -286,3 +286,30 @@ def test_seed_dedupe_by_occupancy_cell_is_exact(native, port, coco_skeleton0, mo
         want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0, params=port.default_params(**kw))
         ok, msg = compare_annotations(small[b], want)
         assert ok, msg
+
+
+def test_decode_lanes_keep_batches_in_flight_and_equal_the_plain_decode(native, coco_skeleton0):
+    """native.DecodeLanes: two decoders / workspaces / streams taking batches in turn; every ticket's result equals the
+    one-decoder, one-stream decode of the same batch (different batches alternate, so a lane's lazy tile clear sees
+    changing input), and waiting for a ticket does not wait for the ones submitted after it."""
+    from openpifpaf_amd import synth
+    batches = []
+    for s in (90_000, 91_000, 92_000):
+        cifs, cafs = synth.synth_batch(8, seed0=s)
+        batches.append((dev(cifs), dev(cafs)))
+    plain = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    want = []
+    for cif_d, caf_d in batches:
+        out, ids, counts = plain.call_batch(cif_d, 8, caf_d, 8)
+        want.append((out.cpu().numpy(), counts.cpu().numpy()))
+    lanes = native.DecodeLanes(17, torch.from_numpy(coco_skeleton0), lanes=2)
+    tickets = [lanes.submit(*batches[i % 3][:1], 8, batches[i % 3][1], 8) for i in range(9)]
+    for i, t in enumerate(tickets):
+        out, ids, counts = t.synchronize()
+        w_out, w_counts = want[i % 3]
+        native.check_counts(counts.cpu())
+        assert np.array_equal(counts.cpu().numpy(), w_counts)
+        for b in range(8):
+            n = native.count_rows(int(w_counts[b]))
+            assert np.array_equal(out[b, :n].cpu().numpy(), w_out[b, :n]), (i, b)
+    assert len({id(d) for d in lanes.decoders}) == 2 and lanes.streams[0] != lanes.streams[1]
