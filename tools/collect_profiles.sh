@@ -9,6 +9,8 @@ cd "${GRAFT_REPO_ROOT:-.}"
 REPO="$PWD"
 OUT="$REPO/gpurun_out/prof_r3"
 rm -rf "$OUT"; mkdir -p "$OUT"
+STAGES="${STAGES:-1 2 3 4}"        # STAGES=3: only the bench step traces (-> bench_step_summary.md)
+has() { [[ " $STAGES " == *" $1 "* ]]; }
 export TMPDIR=/tmp
 cd /tmp
 summarize() {
@@ -26,14 +28,14 @@ probe_args() {
   esac
 }
 # 1. kernel trace + stats of the decode, per workload
-for w in config2 config4 config2_fc config4_fc; do
+has 1 && for w in config2 config4 config2_fc config4_fc; do
   timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$w/stats" -o stats -- \
       python "$REPO/tools/gpu/r3_probe.py" $(probe_args $w) --reps 12 > "$OUT/${w}_stats_stdout.log" 2> "$OUT/${w}_stats_stderr.log"
   find "$OUT/$w/stats" -name '*kernel_trace.csv' -delete
 done
 summarize
 # 2. HBM traffic counters, separate passes (FETCH_SIZE and WRITE_SIZE cannot share a pass)
-for w in config2 config4 config2_fc config4_fc; do
+has 2 && for w in config2 config4 config2_fc config4_fc; do
   for C in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 240 rocprofv3 --pmc $C --kernel-trace --output-format csv -d "$OUT/$w/pmc_$C" -o pmc -- \
         python "$REPO/tools/gpu/r3_probe.py" $(probe_args $w) --reps 4 > "$OUT/${w}_pmc_${C}_stdout.log" 2> "$OUT/${w}_pmc_${C}_stderr.log"
@@ -42,14 +44,17 @@ for w in config2 config4 config2_fc config4_fc; do
   summarize
 done
 # 3. kernel trace of the default bench command's headline leg (N=1, float32 network), and of the bfloat16 leg
+if has 3; then
 timeout -k 10 420 rocprofv3 --kernel-trace --output-format csv -d "$OUT/bench" -o bench -- \
     python "$REPO/bench.py" --steps 8 --warmup 3 --config 2 --no-cpu-baseline --no-parity --no-bf16-leg > "$OUT/bench_stdout.log" 2> "$OUT/bench_stderr.log"
 summarize
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/bench_bf16" -o bench -- \
     python "$REPO/bench.py" --steps 8 --warmup 3 --config 2 --no-cpu-baseline --no-parity --backbone-dtype bf16 > "$OUT/bench_bf16_stdout.log" 2> "$OUT/bench_bf16_stderr.log"
 summarize
+(cd "$REPO" && python tools/summarize_profiles.py "$OUT" --only-steps > "$OUT/bench_step_summary.md" 2>&1)
+fi
 # 4. cache / LDS / instruction-mix counters of the decode kernels (one small group per pass)
-for w in config2 config4; do
+has 4 && for w in config2 config4; do
   for G in "TCC_HIT_sum TCC_MISS_sum" "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES"; do
     D="$OUT/$w/pmc_$(echo $G | cut -d' ' -f1)"
     timeout -k 10 240 rocprofv3 --pmc $G --kernel-trace --output-format csv -d "$D" -o pmc -- \

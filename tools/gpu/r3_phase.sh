@@ -6,12 +6,14 @@ for cfg in "${@:-wholebody}"; do
   echo "=== $cfg"
   OPA_LIB_PATH=$PWD/openpifpaf_amd/lib/libopenpifpaf_amd_ph.so timeout 300 python tools/gpu/r3_probe.py --config $cfg --reps 2 2>&1 | grep -v amdgpu.ids > gpurun_out/phase_raw.log
   grep -v PHASE gpurun_out/phase_raw.log | grep -v "^ \|^img\|status" | head -6
-  grep PHASE gpurun_out/phase_raw.log | tail -40 | python -c "
-import sys
+  grep -a "PHASE img" gpurun_out/phase_raw.log | tail -40 | python -c "
+import sys, re
 names={0:'pop+entry reads',1:'query+issue loads',2:'wait loads',3:'window test/compact',4:'score (exp)',5:'top-2 reductions',6:'blend finish',7:'connection rest',8:'re-push',9:'assign',10:'publish box',11:'frontier_add_from',12:'task setup+seed publish',13:'(grow end)',14:'pose boxes+score',15:'idle/wait task',16:'(stamp cost)',17:'to scan start'}
 rows={}
 for ln in sys.stdin:
-    p=ln.split(); img,k,cyc,n=int(p[2]),int(p[4]),int(p[6]),int(p[8]); rows.setdefault(img,[]).append((k,cyc,n))
+    m=re.search(r'PHASE img (\\d+) k (\\d+) cycles (\\d+) n (\\d+)', ln)
+    if not m: continue
+    img,k,cyc,n=map(int,m.groups()); rows.setdefault(img,[]).append((k,cyc,n))
 for img,r in rows.items():
     tot=sum(c for k,c,n in r if k not in (15,))
     print('image %d: total grower cycles (excl. idle) %d' % (img,tot))

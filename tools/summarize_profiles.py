@@ -74,10 +74,13 @@ def steady_state_step(sub, title, top=16):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     idx = [i for i, r in enumerate(rows) if 'cifcaf_assoc' in r['Kernel_Name']]
-    if len(idx) < 8:
+    # a timed step = the stretch between two consecutive association launches that holds a whole network forward (the
+    # run ends with decode-only calls: profile steps, tile count, parity stamp); take the last but one such stretch
+    pairs = [(a, b) for a, b in zip(idx, idx[1:]) if b - a > 40]
+    if len(pairs) < 3:
         print('(too few steps in the trace)\n')
         return
-    a, b = idx[-7], idx[-6]
+    a, b = pairs[-2]
     seg = rows[a + 1:b + 1]
     agg = defaultdict(lambda: [0, 0.0])
     for r in seg:
@@ -117,12 +120,15 @@ def pmc_per_decode(sub, counter, last_calls=4):
     return {k: v / last_calls for k, v in acc.items()}
 
 
-print('# rocprofv3 summary (round 3)\n')
+ONLY_STEPS = '--only-steps' in sys.argv
+print('# rocprofv3 summary (round 3)%s\n' % (': one steady-state step of bench.py' if ONLY_STEPS else ''))
 print('Commands: tools/collect_profiles.sh (every pass: `rocprofv3 ... -- python tools/gpu/r3_probe.py --config ... --alternate`,'
       ' i.e. two different field batches decoded in turn; counters in their own passes with --kernel-trace only).\n')
 steady_state_step('bench', 'bench.py headline leg (float32 network + decode): ONE steady-state step, batch 32')
 steady_state_step('bench_bf16', 'bench.py --backbone-dtype bf16 (bfloat16 network + decode): ONE steady-state step, batch 32')
 
+if ONLY_STEPS:
+    sys.exit(0)
 print('## Decode kernels per workload (kernel trace, averages over the run)\n')
 stats = {}
 for key, title, cfg, B, fc in WORKLOADS:
