@@ -785,14 +785,21 @@ def main():
                     'decode_vs_cpu_1thread': round(roof['decode_path']['images_per_s'] / cpu['value'], 1) if cpu else None}
         guarded('force_complete', fc_leg)
 
-        # two batches in flight (stages 1-5 of batch i+1 beside the association of batch i)
+        # several batches in flight (stages 1-5 of batch i+1 beside the association of batch i: an association launch
+        # keeps 32 of the 256 compute units busy)
         def lanes_leg():
-            one = run_leg(wl, None, 'fp32', 40, 4, decode_only=True)
-            two = run_leg(wl, None, 'fp32', 40, 4, decode_only=True, n_streams=2)
-            return {'decode_only_images_per_s': {'one_in_flight': round(wl.B * 40 / one['elapsed'], 1),
-                                                 'two_in_flight': round(wl.B * 40 / two['elapsed'], 1)},
+            alg = algorithmic_bytes(wl.B, wl.K, wl.A, wl.fh, wl.fh, wl.stride, wl.dec.max_annotations)['decode_path']
+            rate, gbps = {}, {}
+            for n, key in ((1, 'one_in_flight'), (2, 'two_in_flight'), (4, 'four_in_flight'), (8, 'eight_in_flight')):
+                leg = run_leg(wl, None, 'fp32', 40, 8, decode_only=True, n_streams=n)
+                rate[key] = round(wl.B * 40 / leg['elapsed'], 1)
+                gbps[key] = round(alg * 40 / leg['elapsed'] / 1e9, 1)
+            best = max(gbps, key=gbps.get)
+            return {'decode_only_images_per_s': rate, 'GBps': gbps,
+                    'best': {'mode': best, 'GBps': gbps[best], 'frac': round(gbps[best] / HBM_PEAK_GBPS, 5)},
                     'what': 'decode only, config 2 fields, alternating batches, annotations copied to the host; '
-                            'native.DecodeLanes(lanes=2): two decoders / workspaces / streams'}
+                            'native.DecodeLanes(lanes=n): n decoders / workspaces / streams; GBps = SURVEY 8d '
+                            'algorithmic bytes of a batch x batches per second (wall clock, whole decode path)'}
         guarded('decode_two_in_flight', lanes_leg)
 
         # the literal configs[1]: batch 1

@@ -26,6 +26,8 @@ ap.add_argument('--alternate', action='store_true')
 ap.add_argument('--trace', type=int, default=None)
 ap.add_argument('--check', action='store_true')
 ap.add_argument('--reps', type=int, default=10)
+ap.add_argument('--param', action='append', default=[], metavar='NAME=VALUE',
+                help='decoder parameter override (sensitivity experiments), e.g. --param reverse_match=0 --param greedy=1')
 args = ap.parse_args()
 
 if args.config == 'wholebody':
@@ -38,7 +40,11 @@ else:
 skel0 = np.asarray(skel1, dtype=np.int64) - 1
 fc_kw = dict(force_complete=1, keypoint_threshold=0.0, keypoint_threshold_rel=0.0,
              nms_instance_threshold=0.0, nms_keypoint_threshold=0.0)
-params = _lib.default_params(**fc_kw) if args.fc else None
+overrides = dict(fc_kw) if args.fc else {}
+for kv in args.param:
+    name, value = kv.split('=', 1)
+    overrides[name] = float(value) if '.' in value else int(value)
+params = _lib.default_params(**overrides) if overrides else None
 
 batches = []
 for s in ((0, 1000) if args.alternate else (0,)):
