@@ -63,7 +63,8 @@ def build_diagnostic(define, suffix, verbose=True, source='cifcaf.hip'):
     hipcc = os.environ.get('HIPCC', 'hipcc')
     obj = os.path.join(OBJ_DIR, '%s_%s.o' % (source[:-4], suffix))
     out = os.path.join(HERE, 'lib', 'libopenpifpaf_amd_%s.so' % suffix)
-    subprocess.check_call([hipcc] + FLAGS + ['-D' + define, '-c', os.path.join(CSRC, source), '-o', obj])
+    defines = [define] if isinstance(define, str) else list(define)
+    subprocess.check_call([hipcc] + FLAGS + ['-D' + d for d in defines] + ['-c', os.path.join(CSRC, source), '-o', obj])
     objs = [os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + '.o') for src in sources() if not src.endswith(os.sep + source)]
     subprocess.check_call([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out, obj] + objs)
     return out

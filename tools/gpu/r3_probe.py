@@ -26,6 +26,7 @@ ap.add_argument('--alternate', action='store_true')
 ap.add_argument('--trace', type=int, default=None)
 ap.add_argument('--check', action='store_true')
 ap.add_argument('--reps', type=int, default=10)
+ap.add_argument('--flush', action='store_true', help='overwrite 1 GB before every timed call: the fields come from HBM, not the 256 MB Infinity Cache')
 ap.add_argument('--param', action='append', default=[], metavar='NAME=VALUE',
                 help='decoder parameter override (sensitivity experiments), e.g. --param reverse_match=0 --param greedy=1')
 args = ap.parse_args()
@@ -59,8 +60,12 @@ print('config %s fc=%s batch %d alternate=%s workspace %.2f GB' % (args.config, 
                                                                   dec._last[1].numel() / 1e9))
 
 acc = {}
+flush = torch.empty(1 << 28, dtype=torch.float32, device='cuda') if args.flush else None
 for i in range(args.reps):
     _, _, cd, fd = batches[i % len(batches)]
+    if flush is not None:
+        flush.fill_(float(i))
+        torch.cuda.synchronize()
     _lib.profile_begin(native._stream())
     out, ids, counts = dec.call_batch(cd, 8, fd, 8, params=params)
     for name, ms in _lib.profile_end():
