@@ -98,6 +98,18 @@ int opa_device_count(void);                  /* number of visible gfx950 devices
 /* ref: module.cpp:19-21  torch.ops.openpifpaf.set_quiet(bool) */
 void opa_set_quiet(int quiet);
 
+/* Order of seeds with EQUAL scores (ref: cif_seeds.cpp:94,118: an unstable std::sort, so the reference's order is
+ * whatever libstdc++'s introsort leaves -- it decides which of two equally scored seeds is grown first).
+ *   1 (default)  libstdc++'s order, reproduced on the device for the images that have such seeds (float32 fields of a
+ *                network practically never do; fields rounded to bfloat16 do).  The workspace view "seed_ties"
+ *                (int32 [B]) says per image: 0 no equal scores, 1 re-ordered, -1 not reproduced (introsort's heapsort
+ *                branch: the image keeps the order below).
+ *   0            cell index ascending (field, row, column) -- one launch less.
+ * Process-global like the reference's statics; the environment variable OPA_SEED_TIES=index selects 0 when this
+ * function was never called. */
+void opa_set_seed_tie_order(int order);
+int opa_get_seed_tie_order(void);
+
 /* The reference keeps its tunables in process-global statics that are set
  * before decoders are built (ref: decoder/factory.py:52-82, decoder/cifcaf.py:175-211).
  * opa_get_params/opa_set_params are that global; every call also accepts an
@@ -175,7 +187,7 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
 /* Locates an intermediate buffer of the last opa_cifcaf_decode inside the workspace
  * (debugging / tests; the reference exposes its intermediates through the utility
  * classes of module.cpp:66-117).  what: "tile_bitmaps" (u32 [2][B*F][words]: tiles of the map written by
- * the previous / by this call), "cifhr", "seed_count", "seed_f", "seed_vxys", "seed_cell",
+ * the previous / by this call), "cifhr", "seed_count", "seed_f", "seed_vxys", "seed_cell", "seed_ties",
  * "lists", "list_counts", "lists_fc", "list_counts_fc", "list_bbox" (f32 [B,A,2,C,4], C = min(ceil(caf_h*caf_w/64),
  * 255): xmin, xmax, ymin, ymax of the (x1, y1) columns of the first min(C, 16) chunks of 64 entries of every "lists"
  * list -- the rest of a list's C boxes is not written; an empty chunk: +inf, -inf, +inf, -inf), "list_bbox_fc" (the

@@ -75,6 +75,8 @@ SYMBOLS = {
     'opa_last_error': (ctypes.c_char_p, []),
     'opa_device_count': (ctypes.c_int, []),
     'opa_set_quiet': (None, [ctypes.c_int]),
+    'opa_set_seed_tie_order': (None, [ctypes.c_int]),
+    'opa_get_seed_tie_order': (ctypes.c_int, []),
     'opa_default_params': (None, [_P(Params)]),
     'opa_get_params': (None, [_P(Params)]),
     'opa_set_params': (ctypes.c_int, [_P(Params)]),

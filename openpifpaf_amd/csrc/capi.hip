@@ -15,6 +15,13 @@ namespace opa {
 static thread_local std::string g_error;
 static std::mutex g_params_mutex;
 static int g_quiet = 0;
+static int g_seed_tie_order = -1;          // -1: not set (OPA_SEED_TIES, else libstdc++'s order)
+
+int seed_tie_order() {
+    if (g_seed_tie_order >= 0) return g_seed_tie_order;
+    const char* e = std::getenv("OPA_SEED_TIES");
+    return e && (std::strcmp(e, "index") == 0 || std::strcmp(e, "0") == 0) ? 0 : 1;
+}
 
 static opa_params default_params() {
     opa_params p;
@@ -137,6 +144,13 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     L->off_status = take(B * sizeof(int32_t));
     L->off_stats = take(B * 24 * sizeof(int32_t));
     L->off_trace = take(B * 64 * 4 * sizeof(int32_t));
+    L->off_tie_state = take(B * sizeof(int32_t));
+    if (L->occ_image_words * sizeof(unsigned) >= tie_small_bytes(L->cif_cells)) {
+        L->off_tie_small = L->off_occ; L->tie_small_stride = L->occ_image_words * sizeof(unsigned);
+    } else {
+        L->tie_small_stride = tie_small_bytes(L->cif_cells);
+        L->off_tie_small = take(B * L->tie_small_stride);
+    }
     L->total_no_fc = off;
     // what only a force-complete decode touches sits behind everything else: a workspace for decodes without it can stop here
     L->off_lists_fc = take(list_bytes);
@@ -171,6 +185,9 @@ int opa_device_count(void) {
 }
 
 void opa_set_quiet(int quiet) { g_quiet = quiet; }
+
+void opa_set_seed_tie_order(int order) { g_seed_tie_order = order ? 1 : 0; }
+int opa_get_seed_tie_order(void) { return opa::seed_tie_order(); }
 
 void opa_default_params(opa_params* out) { if (out) *out = default_params(); }
 void opa_get_params(opa_params* out) {
@@ -302,7 +319,7 @@ int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what, size_t* 
         {"lists", L.off_lists, L.off_list_counts}, {"list_counts", L.off_list_counts, L.off_list_bbox},
         {"list_bbox", L.off_list_bbox, L.off_occ},
         {"occupancy", L.off_occ, L.off_anns}, {"annotation_scratch", L.off_anns, L.off_ann_meta},
-        {"status", L.off_status, L.off_stats}, {"assoc_stats", L.off_stats, L.off_trace}, {"assoc_trace", L.off_trace, L.total_no_fc},
+        {"status", L.off_status, L.off_stats}, {"assoc_stats", L.off_stats, L.off_trace}, {"assoc_trace", L.off_trace, L.off_tie_state}, {"seed_ties", L.off_tie_state, L.off_tie_state + (size_t)L.B * sizeof(int32_t)},
         {"lists_fc", L.off_lists_fc, L.off_list_counts_fc}, {"list_counts_fc", L.off_list_counts_fc, L.off_list_bbox_fc},
         {"list_bbox_fc", L.off_list_bbox_fc, L.off_fc_meta},
     };
@@ -388,11 +405,15 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
                                               L.bbox_chunks, L.bbox_chunks, tile_touch);
     const char* fuse_env = std::getenv("OPA_FUSE_SCORED");
     const bool fuse = fuse_env && std::atoi(fuse_env) != 0;
+    TieScratch ties;
+    ties.big = ws + L.off_act; ties.big_stride = (size_t)L.F * 4 * (L.H * L.W) * sizeof(float);
+    ties.small_ = ws + L.off_tie_small; ties.small_stride = L.tie_small_stride;
+    ties.state = (int32_t*)(ws + L.off_tie_state);
     e = launch_cifseeds(cif_dev, L.B, L.F, L.H, L.W, L.stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
                         (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap,
                         (int32_t*)(ws + L.off_seed_count), (int32_t*)(ws + L.off_seed_f),
                         (float*)(ws + L.off_seed_vxys), st, false, (int32_t*)(ws + L.off_seed_cell),
-                        L.occ_h, L.occ_w, true, fuse ? scored : nullptr, fuse ? n_scored : 0);   // :144-146
+                        L.occ_h, L.occ_w, true, fuse ? scored : nullptr, fuse ? n_scored : 0, &ties);   // :144-146
     if (e != hipSuccess) return fail_hip(e, "cifseeds");
     if (!fuse)
         for (int k = 0; k < n_scored; k++) {
@@ -456,8 +477,20 @@ int opa_cifhr_accumulate(const float* cif_dev, int32_t batch, int32_t n_cif, int
 
 static int sort_cap_for(int cells) { int sc = 2; while (sc < cells) sc <<= 1; return sc < kSortLdsKeys ? kSortLdsKeys : sc; }
 
+// keys, then the scratch of the tie pass (position table + stop lists, bitmap + segment lists, one state word per image)
+static size_t seeds_keys_bytes(int batch, int cells) { return align_up((size_t)batch * sort_cap_for(cells) * sizeof(unsigned long long)); }
 size_t opa_cifseeds_scratch_bytes(int32_t batch, int32_t n_cif, int32_t cif_h, int32_t cif_w) {
-    return align_up((size_t)batch * sort_cap_for(n_cif * cif_h * cif_w) * sizeof(unsigned long long));
+    const int cells = n_cif * cif_h * cif_w;
+    return seeds_keys_bytes(batch, cells) + align_up((size_t)batch * tie_big_bytes(cells)) +
+           align_up((size_t)batch * tie_small_bytes(cells)) + align_up((size_t)batch * sizeof(int32_t));
+}
+static TieScratch stage_ties(void* scratch_dev, int batch, int cells) {
+    unsigned char* sp = (unsigned char*)scratch_dev + seeds_keys_bytes(batch, cells);
+    TieScratch t;
+    t.big = sp; t.big_stride = tie_big_bytes(cells); sp += align_up((size_t)batch * t.big_stride);
+    t.small_ = sp; t.small_stride = tie_small_bytes(cells); sp += align_up((size_t)batch * t.small_stride);
+    t.state = (int32_t*)sp;
+    return t;
 }
 
 int opa_cifseeds_fill(const float* cif_dev, int32_t batch, int32_t n_cif, int32_t cif_h, int32_t cif_w,
@@ -471,10 +504,12 @@ int opa_cifseeds_fill(const float* cif_dev, int32_t batch, int32_t n_cif, int32_
         return fail(OPA_ERR_WORKSPACE, "opa_cifseeds_fill: scratch too small");
     opa_params hp; if (params) hp = *params; else opa_get_params(&hp);
     const DevParams p = to_dev(hp);
+    const TieScratch ties = stage_ties(scratch_dev, batch, n_cif * cif_h * cif_w);
     hipError_t e = launch_cifseeds(cif_dev, batch, n_cif, cif_h, cif_w, stride, cifhr_dev,
                                    (cif_h - 1) * stride + 1, (cif_w - 1) * stride + 1, opa_cifhr_pitch(cif_w, stride),
                                    p, (unsigned long long*)scratch_dev, sort_cap_for(n_cif * cif_h * cif_w),
-                                   seed_count_dev, seed_f_dev, seed_vxys_dev, (hipStream_t)stream);
+                                   seed_count_dev, seed_f_dev, seed_vxys_dev, (hipStream_t)stream, false, nullptr, 0, 0, false,
+                                   nullptr, 0, &ties);
     if (e != hipSuccess) return fail_hip(e, "cifseeds");
     return OPA_OK;
 }
@@ -490,11 +525,12 @@ int opa_cifdetseeds_fill(const float* field_dev, int32_t batch, int32_t n_fields
         return fail(OPA_ERR_WORKSPACE, "opa_cifdetseeds_fill: scratch too small");
     opa_params hp; if (params) hp = *params; else opa_get_params(&hp);
     const DevParams p = to_dev(hp);
+    const TieScratch ties = stage_ties(scratch_dev, batch, n_fields * field_h * field_w);
     hipError_t e = launch_cifseeds(field_dev, batch, n_fields, field_h, field_w, stride, cifhr_dev,
                                    (field_h - 1) * stride + 1, (field_w - 1) * stride + 1,
                                    opa_cifhr_pitch(field_w, stride), p, (unsigned long long*)scratch_dev,
                                    sort_cap_for(n_fields * field_h * field_w), seed_count_dev, seed_f_dev,
-                                   seed_vxywh_dev, (hipStream_t)stream, true);
+                                   seed_vxywh_dev, (hipStream_t)stream, true, nullptr, 0, 0, false, nullptr, 0, &ties);
     if (e != hipSuccess) return fail_hip(e, "cifdetseeds");
     return OPA_OK;
 }
@@ -535,6 +571,7 @@ int opa_grow_connection_blend(const float* rows_dev, int32_t n, double x, double
 struct DetLayout {
     int hr_rows, hr_cols, hr_pitch, occ_h, occ_w, cells, sort_cap;
     size_t off_cifhr, off_act, off_act_count, off_keys, off_seed_count, off_seed_f, off_seed_v, off_occ, total;
+    size_t off_tie_small, tie_small_stride, off_tie_state;    // (see Layout)
 };
 
 static bool make_det_layout(const opa_det_shape& s, DetLayout* L, const char** why) {
@@ -560,6 +597,13 @@ static bool make_det_layout(const opa_det_shape& s, DetLayout* L, const char** w
     L->off_seed_f = take(B * (size_t)L->cells * sizeof(int32_t));
     L->off_seed_v = take(B * (size_t)L->cells * 5 * sizeof(float));
     L->off_occ = take(B * s.n_fields * (size_t)L->occ_h * L->occ_w);
+    L->off_tie_state = take(B * sizeof(int32_t));
+    if (s.n_fields * (size_t)L->occ_h * L->occ_w >= tie_small_bytes(L->cells) && (s.n_fields * (size_t)L->occ_h * L->occ_w) % 16 == 0) {
+        L->off_tie_small = L->off_occ; L->tie_small_stride = s.n_fields * (size_t)L->occ_h * L->occ_w;
+    } else {
+        L->tie_small_stride = tie_small_bytes(L->cells);
+        L->off_tie_small = take(B * L->tie_small_stride);
+    }
     L->total = off;
     return true;
 }
@@ -593,9 +637,14 @@ int opa_cifdet_decode(const opa_det_shape* shape, const opa_params* params, cons
     hipError_t e = launch_cifhr(field_dev, B, F, H, W, shape->stride, 0.0, 1.0, p, cifhr, L.hr_rows, L.hr_pitch,
                                 (float*)(ws + L.off_act), (int32_t*)(ws + L.off_act_count), st, true);   // cifdet.cpp:30-31
     if (e != hipSuccess) return fail_hip(e, "cifdethr");
+    TieScratch ties;
+    ties.big = ws + L.off_act; ties.big_stride = (size_t)F * 4 * (H * W) * sizeof(float);
+    ties.small_ = ws + L.off_tie_small; ties.small_stride = L.tie_small_stride;
+    ties.state = (int32_t*)(ws + L.off_tie_state);
     e = launch_cifseeds(field_dev, B, F, H, W, shape->stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
                         (unsigned long long*)(ws + L.off_keys), L.sort_cap, (int32_t*)(ws + L.off_seed_count),
-                        (int32_t*)(ws + L.off_seed_f), (float*)(ws + L.off_seed_v), st, true);           // :34-36
+                        (int32_t*)(ws + L.off_seed_f), (float*)(ws + L.off_seed_v), st, true, nullptr, 0, 0, false, nullptr, 0,
+                        &ties);                                                                          // :34-36
     if (e != hipSuccess) return fail_hip(e, "cifdetseeds");
     const int occ_h = (int)((double)L.hr_rows / hp.occupancy_reduction) + 1;
     const int occ_w = (int)((double)L.hr_cols / hp.occupancy_reduction) + 1;

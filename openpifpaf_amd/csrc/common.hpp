@@ -35,6 +35,9 @@ struct Layout {
            off_lists_fc, off_list_counts_fc, off_list_bbox, off_list_bbox_fc, off_fc_meta, off_occ, off_anns, off_ann_meta, off_status, off_stats, off_trace,
            total_no_fc, total;           // total_no_fc: everything but the regions only a force-complete decode uses (they come last)
     size_t occ_image_words;               // 32-bit words of one image's occupancy bitmap (capacity)
+    // scratch of the seed tie pass (cifseeds.hip): `big` lies in the active-cell list (dead once the map is built, and
+    // exactly as large), `small` in the occupancy bitmap (cleared by the association kernel afterwards) where it fits
+    size_t off_tie_small, tie_small_stride, off_tie_state;
 };
 
 bool make_layout(const opa_shape& s, Layout* L, const char** why);
@@ -80,12 +83,19 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
 constexpr unsigned long long kWsMagic = 0x6f70615f63696668ull;   // "opa_cifh"
 
 struct ScoredArgs;
+// Scratch of the pass that puts seeds of EQUAL score into libstdc++'s std::sort order (cifseeds.hip); `state` [B]:
+// 0 no equal scores, 1 re-sorted, -1 not reproduced (introsort's heapsort branch).  seed_tie_order(): 1 = libstdc++
+// (the reference, default), 0 = cell index (opa_set_seed_tie_order / OPA_SEED_TIES=index).
+struct TieScratch { unsigned char* big; size_t big_stride; unsigned char* small_; size_t small_stride; int32_t* state; };
+size_t tie_big_bytes(int cells);
+size_t tie_small_bytes(int cells);
+int seed_tie_order();
 hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int stride,
                            const float* cifhr, int hr_rows, int hr_cols, int hr_pitch, const DevParams& p,
                            unsigned long long* keys, int sort_cap, int32_t* seed_count,
                            int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det = false,
                            int32_t* seed_cell = nullptr, int occ_h = 0, int occ_w = 0, bool count_is_zero = false,
-                           const ScoredArgs* scored = nullptr, int n_scored = 0);
+                           const ScoredArgs* scored = nullptr, int n_scored = 0, const TieScratch* ties = nullptr);
 // (`scored`: up to two CafScored list sets built by the SAME launch as the seed sort -- they only share the finished
 // map, and the sort's few workgroups leave the chip to them)
 

@@ -410,6 +410,7 @@ std::vector<double> grow_connection_blend(const torch::Tensor& caf, double x, do
 
 TORCH_LIBRARY(openpifpaf_amd, m) {
     m.def("set_quiet", [](bool quiet) { opa_set_quiet(quiet ? 1 : 0); });                // module.cpp:19-21
+    m.def("set_seed_tie_order", [](bool libstdcxx) { opa_set_seed_tie_order(libstdcxx ? 1 : 0); });   // (no counterpart: cif_seeds.cpp:94 is what it is)
 }
 
 TORCH_LIBRARY(openpifpaf_amd_decoder, m) {

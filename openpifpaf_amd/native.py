@@ -61,6 +61,20 @@ def set_quiet(quiet=True):
     _lib.lib().opa_set_quiet(int(bool(quiet)))
 
 
+SEED_TIE_ORDERS = {'libstdcxx': 1, 'index': 0}
+
+
+def set_seed_tie_order(order='libstdcxx'):
+    """Order of seeds with EQUAL scores: ``'libstdcxx'`` (default) = what the reference's unstable ``std::sort``
+    leaves (cif_seeds.cpp:94), reproduced on the device for the images that have such seeds; ``'index'`` = cell index
+    ascending (one launch less).  Process-global, like the reference's statics."""
+    _lib.lib().opa_set_seed_tie_order(SEED_TIE_ORDERS[order])
+
+
+def get_seed_tie_order():
+    return 'libstdcxx' if _lib.lib().opa_get_seed_tie_order() else 'index'
+
+
 def _device():
     if not torch.cuda.is_available():
         raise _lib.NativeError('openpifpaf_amd: no MI355X/HIP device visible; the decode path has no CPU fallback')

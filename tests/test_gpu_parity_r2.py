@@ -47,7 +47,11 @@ def test_tie_heavy_bf16_fields_equal_the_total_order_oracle(native, port, coco_s
     B = 32
     cifs, cafs = synth.synth_batch(B, seed0=50_000)
     cifs, cafs = to_bf16(cifs), to_bf16(cafs)
-    got, _ = _decode_all(native, coco_skeleton0, cifs, cafs)
+    native.set_seed_tie_order('index')           # (round 3: the default reproduces libstdc++'s order, tests/test_gpu_ties.py)
+    try:
+        got, _ = _decode_all(native, coco_skeleton0, cifs, cafs)
+    finally:
+        native.set_seed_tie_order('libstdcxx')
     tied = differ_ref = 0
     worst = 0.0
     try:
@@ -90,7 +94,18 @@ def test_bf16_network_head_outputs(native, port, coco_skeleton0):
     out, ids, counts = dec.call_batch(cifs, cif_meta.stride, cafs, caf_meta.stride)
     out, counts = out.cpu().numpy(), counts.cpu().numpy()
     assert not native.count_overflowed(counts).any()
+    native.set_seed_tie_order('index')
+    try:
+        out_i, _, counts_i = dec.call_batch(cifs, cif_meta.stride, cafs, caf_meta.stride)
+        out_i, counts_i = out_i.cpu().numpy(), counts_i.cpu().numpy()
+    finally:
+        native.set_seed_tie_order('libstdcxx')
     cifs, cafs = cifs.cpu().numpy(), cafs.cpu().numpy()
+    for b in range(2):                           # default: libstdc++'s order of equal scores (tie rule 0)
+        want, _ = port.decode(cifs[b], cif_meta.stride, cafs[b], caf_meta.stride, coco_skeleton0)
+        ok, msg = compare_annotations(out[b, :counts[b]], want)
+        assert ok, 'image %d (libstdc++ order): %s' % (b, msg)
+    out, counts = out_i, counts_i
     try:
         port.set_seed_tie_rule(1)
         for b in range(2):
