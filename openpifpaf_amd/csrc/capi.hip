@@ -145,10 +145,10 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     L->off_stats = take(B * 24 * sizeof(int32_t));
     L->off_trace = take(B * 64 * 4 * sizeof(int32_t));
     L->off_tie_state = take(B * sizeof(int32_t));
-    if (L->occ_image_words * sizeof(unsigned) >= tie_small_bytes(L->cif_cells)) {
+    if (L->occ_image_words * sizeof(unsigned) >= tie_small_bytes(L->F, L->H * L->W)) {
         L->off_tie_small = L->off_occ; L->tie_small_stride = L->occ_image_words * sizeof(unsigned);
     } else {
-        L->tie_small_stride = tie_small_bytes(L->cif_cells);
+        L->tie_small_stride = tie_small_bytes(L->F, L->H * L->W);
         L->off_tie_small = take(B * L->tie_small_stride);
     }
     L->total_no_fc = off;
@@ -482,13 +482,14 @@ static size_t seeds_keys_bytes(int batch, int cells) { return align_up((size_t)b
 size_t opa_cifseeds_scratch_bytes(int32_t batch, int32_t n_cif, int32_t cif_h, int32_t cif_w) {
     const int cells = n_cif * cif_h * cif_w;
     return seeds_keys_bytes(batch, cells) + align_up((size_t)batch * tie_big_bytes(cells)) +
-           align_up((size_t)batch * tie_small_bytes(cells)) + align_up((size_t)batch * sizeof(int32_t));
+           align_up((size_t)batch * tie_small_bytes(n_cif, cif_h * cif_w)) + align_up((size_t)batch * sizeof(int32_t));
 }
-static TieScratch stage_ties(void* scratch_dev, int batch, int cells) {
+static TieScratch stage_ties(void* scratch_dev, int batch, int F, int HW) {
+    const int cells = F * HW;
     unsigned char* sp = (unsigned char*)scratch_dev + seeds_keys_bytes(batch, cells);
     TieScratch t;
     t.big = sp; t.big_stride = tie_big_bytes(cells); sp += align_up((size_t)batch * t.big_stride);
-    t.small_ = sp; t.small_stride = tie_small_bytes(cells); sp += align_up((size_t)batch * t.small_stride);
+    t.small_ = sp; t.small_stride = tie_small_bytes(F, HW); sp += align_up((size_t)batch * t.small_stride);
     t.state = (int32_t*)sp;
     return t;
 }
@@ -504,7 +505,7 @@ int opa_cifseeds_fill(const float* cif_dev, int32_t batch, int32_t n_cif, int32_
         return fail(OPA_ERR_WORKSPACE, "opa_cifseeds_fill: scratch too small");
     opa_params hp; if (params) hp = *params; else opa_get_params(&hp);
     const DevParams p = to_dev(hp);
-    const TieScratch ties = stage_ties(scratch_dev, batch, n_cif * cif_h * cif_w);
+    const TieScratch ties = stage_ties(scratch_dev, batch, n_cif, cif_h * cif_w);
     hipError_t e = launch_cifseeds(cif_dev, batch, n_cif, cif_h, cif_w, stride, cifhr_dev,
                                    (cif_h - 1) * stride + 1, (cif_w - 1) * stride + 1, opa_cifhr_pitch(cif_w, stride),
                                    p, (unsigned long long*)scratch_dev, sort_cap_for(n_cif * cif_h * cif_w),
@@ -525,7 +526,7 @@ int opa_cifdetseeds_fill(const float* field_dev, int32_t batch, int32_t n_fields
         return fail(OPA_ERR_WORKSPACE, "opa_cifdetseeds_fill: scratch too small");
     opa_params hp; if (params) hp = *params; else opa_get_params(&hp);
     const DevParams p = to_dev(hp);
-    const TieScratch ties = stage_ties(scratch_dev, batch, n_fields * field_h * field_w);
+    const TieScratch ties = stage_ties(scratch_dev, batch, n_fields, field_h * field_w);
     hipError_t e = launch_cifseeds(field_dev, batch, n_fields, field_h, field_w, stride, cifhr_dev,
                                    (field_h - 1) * stride + 1, (field_w - 1) * stride + 1,
                                    opa_cifhr_pitch(field_w, stride), p, (unsigned long long*)scratch_dev,
@@ -598,10 +599,10 @@ static bool make_det_layout(const opa_det_shape& s, DetLayout* L, const char** w
     L->off_seed_v = take(B * (size_t)L->cells * 5 * sizeof(float));
     L->off_occ = take(B * s.n_fields * (size_t)L->occ_h * L->occ_w);
     L->off_tie_state = take(B * sizeof(int32_t));
-    if (s.n_fields * (size_t)L->occ_h * L->occ_w >= tie_small_bytes(L->cells) && (s.n_fields * (size_t)L->occ_h * L->occ_w) % 16 == 0) {
+    if (s.n_fields * (size_t)L->occ_h * L->occ_w >= tie_small_bytes(s.n_fields, s.field_h * s.field_w) && (s.n_fields * (size_t)L->occ_h * L->occ_w) % 16 == 0) {
         L->off_tie_small = L->off_occ; L->tie_small_stride = s.n_fields * (size_t)L->occ_h * L->occ_w;
     } else {
-        L->tie_small_stride = tie_small_bytes(L->cells);
+        L->tie_small_stride = tie_small_bytes(s.n_fields, s.field_h * s.field_w);
         L->off_tie_small = take(B * L->tie_small_stride);
     }
     L->total = off;

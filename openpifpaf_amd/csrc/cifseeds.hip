@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void cifseeds_fill_kernel(
         const float* __restrict__ cif, int F, int NC, int H, int W, int stride,
         const float* __restrict__ cifhr, int hr_rows, int hr_cols, int hr_pitch,
         double threshold, int ablation_nms, int no_rescore,
-        unsigned long long* __restrict__ keys, int sort_cap, int cap, int32_t* __restrict__ seed_count) {
+        unsigned long long* __restrict__ keys, int sort_cap, int cap, int32_t* __restrict__ seed_count,
+        int2* __restrict__ wg_tab, size_t tab_stride, unsigned long long* __restrict__ key_copy, size_t copy_stride) {
     const int HW = H * W;
     const int plane = blockIdx.x;              // b*F + f
     const int b = plane / F, f = plane - b * F;
@@ -77,31 +78,41 @@ __global__ __launch_bounds__(256) void cifseeds_fill_kernel(
     }
     // Survivors are appended to the image's key array.  ONE atomic per workgroup: 15 000 per-wave atomics on the 32
     // per-image counters of a batch serialise at the L2 (~470 per address) and were most of this kernel's time.
-    __shared__ int wave_total[4];
+    // Inside the workgroup's block the keys stand in raster order (r, wave, lane -- the order of the cells), and
+    // `wg_tab` remembers where the block of (field, chunk) begins and how long it is: with that (and a copy of the keys
+    // the sort does not touch) the tie pass lays the image's seeds out in the order the reference pushes them
+    // (cif_seeds.cpp:41-65) without sorting them by cell.
+    __shared__ int wave_total[kFillCells][4];
     __shared__ int wg_base;
     unsigned long long mask[kFillCells];
-    int total = 0;
-#pragma unroll
-    for (int r = 0; r < kFillCells; r++) { mask[r] = __ballot(on[r]); total += __popcll(mask[r]); }
     const int w = threadIdx.x >> 6;
-    if (lane == 0) wave_total[w] = total;
+#pragma unroll
+    for (int r = 0; r < kFillCells; r++) { mask[r] = __ballot(on[r]); if (lane == 0) wave_total[r][w] = __popcll(mask[r]); }
     __syncthreads();
-    const int t0 = wave_total[0], t1 = wave_total[1], t2 = wave_total[2], t3 = wave_total[3];
-    if (t0 + t1 + t2 + t3 == 0) return;              // (uniform over the workgroup)
-    if (threadIdx.x == 0) wg_base = atomicAdd(&seed_count[b], t0 + t1 + t2 + t3);
+    int total = 0, before[kFillCells];
+#pragma unroll
+    for (int r = 0; r < kFillCells; r++) {
+        before[r] = total;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { if (k < w) before[r] += wave_total[r][k]; total += wave_total[r][k]; }
+    }
+    if (threadIdx.x == 0) {
+        wg_base = total ? atomicAdd(&seed_count[b], total) : 0;
+        if (wg_tab) wg_tab[(size_t)b * tab_stride + (size_t)f * gridDim.y + blockIdx.y] = make_int2(wg_base, total);
+    }
+    if (total == 0) return;                          // (uniform over the workgroup)
     __syncthreads();
-    int base = wg_base + (w > 0 ? t0 : 0) + (w > 1 ? t1 : 0) + (w > 2 ? t2 : 0);
 #pragma unroll
     for (int r = 0; r < kFillCells; r++) {
         if (on[r]) {
-            const int slot = base + __popcll(mask[r] & ((1ull << lane) - 1ull));
+            const int slot = wg_base + before[r] + __popcll(mask[r] & ((1ull << lane) - 1ull));
             if (slot < cap) {
                 const unsigned idx = (unsigned)(f * HW + o[r]);
-                keys[(size_t)b * sort_cap + slot] =
-                    ((unsigned long long)sortable_bits(c[r]) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+                const unsigned long long key = ((unsigned long long)sortable_bits(c[r]) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+                keys[(size_t)b * sort_cap + slot] = key;
+                if (key_copy) key_copy[(size_t)b * copy_stride + slot] = key;   // (the sort reorders `keys`; the tie pass wants the blocks)
             }
         }
-        base += __popcll(mask[r]);
     }
 }
 
@@ -130,7 +141,7 @@ __host__ __device__ inline int sort_block_size(int n) { return n <= kSortLdsKeys
 __device__ __forceinline__ void store_seed(unsigned long long key, int t, int b, const float* __restrict__ cif, int F, int NC,
                                            int HW, int stride, int cap, int32_t* __restrict__ seed_f,
                                            float* __restrict__ seed_vxys, int32_t* __restrict__ seed_cell, int occ_h,
-                                           int occ_w, const DevParams& p, unsigned* __restrict__ idx_out = nullptr) {
+                                           int occ_w, const DevParams& p) {
     int32_t* sf = seed_f + (size_t)b * cap;
     const int ncol = NC - 1;                    // (v,x,y,s) for CIF; (v,x,y,w,h) for CifDet, cif_seeds.cpp:124-137
     float* sv = seed_vxys + (size_t)b * cap * ncol;
@@ -139,7 +150,6 @@ __device__ __forceinline__ void store_seed(unsigned long long key, int t, int b,
     const int f = (int)(idx / (unsigned)HW), o = (int)(idx - (unsigned)f * (unsigned)HW);
     const float* P = image + (size_t)f * NC * HW;
     sf[t] = f;
-    if (idx_out) idx_out[t] = idx;              // (the tie pass asks which cell the seed of rank t came from)
     float4 r;
     r.x = from_sortable((unsigned)(key >> 32));
     r.y = P[2 * HW + o] * (float)stride;
@@ -158,7 +168,6 @@ struct SortArgs {
     unsigned long long* keys; int sort_cap, cap; const int32_t* seed_count;
     const float* cif; int F, NC, HW, stride;
     int32_t* seed_f; float* seed_vxys; int32_t* seed_cell; int occ_h, occ_w;
-    unsigned* idx_out; size_t idx_stride;        // [B][idx_stride] cell of every sorted seed, or null
 };
 
 #ifdef OPA_SORT_RADIX
@@ -341,8 +350,7 @@ __device__ __forceinline__ void cifseeds_sort_body(const SortArgs& g, const DevP
 
     // epilogue: decode keys -> sorted seeds (cif_seeds.cpp:100-113)
     for (int t = tid; t < n; t += 1024)
-        store_seed(in_lds ? sk[t] : K[t], t, b, cif, F, NC, HW, stride, cap, seed_f, seed_vxys, seed_cell, occ_h, occ_w, p,
-                   g.idx_out ? g.idx_out + (size_t)b * g.idx_stride : nullptr);
+        store_seed(in_lds ? sk[t] : K[t], t, b, cif, F, NC, HW, stride, cap, seed_f, seed_vxys, seed_cell, occ_h, occ_w, p);
 }
 
 __global__ __launch_bounds__(1024) void cifseeds_sort_kernel(SortArgs g, DevParams p) {
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(256) void cifseeds_rankmerge_kernel(
         const unsigned long long* __restrict__ keys, int sort_cap, int cap, const int32_t* __restrict__ seed_count,
         const float* __restrict__ cif, int F, int NC, int HW, int stride,
         int32_t* __restrict__ seed_f, float* __restrict__ seed_vxys,
-        int32_t* __restrict__ seed_cell, int occ_h, int occ_w, DevParams p, unsigned* __restrict__ idx_out, size_t idx_stride) {
+        int32_t* __restrict__ seed_cell, int occ_h, int occ_w, DevParams p) {
     const int b = blockIdx.y;
     int n = seed_count[b];
     if (n > cap) n = cap;
@@ -398,8 +406,7 @@ __global__ __launch_bounds__(256) void cifseeds_rankmerge_kernel(
         }
         pos += lo;
     }
-    store_seed(key, pos, b, cif, F, NC, HW, stride, cap, seed_f, seed_vxys, seed_cell, occ_h, occ_w, p,
-               idx_out ? idx_out + (size_t)b * idx_stride : nullptr);
+    store_seed(key, pos, b, cif, F, NC, HW, stride, cap, seed_f, seed_vxys, seed_cell, occ_h, occ_w, p);
 }
 
 // ------------------------------------------------------------------ the reference's order of EQUAL scores
@@ -410,7 +417,8 @@ __global__ __launch_bounds__(256) void cifseeds_rankmerge_kernel(
 // have ties, reproduces libstdc++ (bits/stl_algo.h: __introsort_loop, __unguarded_partition_pivot,
 // __move_median_to_first, __unguarded_partition, __final_insertion_sort) on the sequence the reference sorts -- the
 // seeds in raster order (field, row, column: cif_seeds.cpp:33-66):
-//   * raster position of every seed: a bitmap of the seeded cells + a prefix sum of its popcounts;
+//   * raster position of every seed: the fill kernel writes one block of keys per (field, 1024 cells), in cell order, and
+//     notes where each block went; a prefix sum over the blocks' lengths in (field, chunk) order places them;
 //   * the introsort loop, level by level (every partition of a level takes a depth step, like the recursion), one wave per
 //     segment.  A Hoare partition's swaps are fixed by the ORIGINAL segment: scanning from the left it stops at
 //     elements with !(x > pivot), from the right at !(pivot > x), and the k-th stop on the left is swapped with the k-th
@@ -431,18 +439,20 @@ struct TieArgs {
     int cells;                       // F * HW: capacity of the per-image arrays
     unsigned char* big; size_t big_stride;       // per image tie_big_bytes(cells): cells, scores and the two stop lists of an
                                                  // image beyond the LDS arrays
-    unsigned char* small_; size_t small_stride;  // per image tie_small_bytes(cells): cell bitmap + prefix, segment lists
+    unsigned char* small_; size_t small_stride;  // per image tie_small_bytes(F, HW): the fill kernel's block table, its prefix,
+                                                 // segment lists
     int32_t* tie_state;              // [B] or null: 0 no equal scores, 1 re-sorted in libstdc++'s order, -1 not reproduced
 };
 
 __host__ __device__ inline size_t tie_seg_cap(int cells) { return (size_t)cells / 17 + 2; }
+__host__ __device__ inline int tie_blocks(int F, int HW) { return F * ((HW + 256 * kFillCells - 1) / (256 * kFillCells)); }
 size_t tie_big_bytes(int cells) { return 4 * (size_t)cells * sizeof(unsigned); }
-// the first sort leaves the cell of every sorted seed in the LAST of the four arrays (the right-stop list, not yet in use)
-static inline unsigned* tie_idx_out(unsigned char* big, int cells) { return (unsigned*)big + 3 * (size_t)cells; }
-size_t tie_small_bytes(int cells) {
-    const size_t W = ((size_t)cells + 31) / 32;
-    size_t b = (2 * W * sizeof(unsigned) + 15) & ~(size_t)15;
-    b += 2 * tie_seg_cap(cells) * sizeof(int2);
+// the fill kernel's copy of the keys lies in the two stop-list arrays (not in use before the partitions start)
+__host__ __device__ inline unsigned long long* tie_key_copy(unsigned char* big, int cells) { return (unsigned long long*)(big + 2 * (size_t)cells * sizeof(unsigned)); }
+size_t tie_small_bytes(int F, int HW) {       // block table (begin, length), its prefix, two segment lists
+    size_t b = ((size_t)tie_blocks(F, HW) * (sizeof(int2) + sizeof(int)) + 15) & ~(size_t)15;
+    b += 2 * tie_seg_cap(F * HW) * sizeof(int2);
+    b += (((size_t)F * HW + 31) / 32) * sizeof(unsigned);  // cut marks of an image beyond the LDS arrays
     return (b + 255) & ~(size_t)255;
 }
 
@@ -797,73 +807,61 @@ __global__ __launch_bounds__(kTieThreads) void cifseeds_tie_kernel(TieArgs a, So
     if (a.tie_state && tid == 0) a.tie_state[b] = s_flag;
     if (!s_flag) return;
 
+    const int E = tie_blocks(g.F, g.HW);
     unsigned char* sp = a.small_ + (size_t)b * a.small_stride;
-    const bool bm_lds = in_lds && 2 * W <= kTieLdsKeys;        // the cell bitmap and its prefix fit the RPOS array
-    unsigned* BM = bm_lds ? RPOS : (unsigned*)sp;
-    unsigned* PREF = BM + W;
-    sp += (2 * (size_t)W * sizeof(unsigned) + 15) & ~(size_t)15;
+    const int2* TAB = (const int2*)sp;                          // (begin, length) of the key block of (field, chunk)
+    int* PRE = (int*)(sp + (size_t)E * sizeof(int2));           // seeds in the blocks before it
+    sp += ((size_t)E * (sizeof(int2) + sizeof(int)) + 15) & ~(size_t)15;
     int2* seg_a = (int2*)sp; int2* seg_b = seg_a + tie_seg_cap(cells);
-    unsigned long long* K = g.keys + (size_t)b * g.sort_cap;     // the image's keys, in whatever order the first sort left them
-    auto bm_sync = [&]() { if (bm_lds) __syncthreads(); else sync_global(); };
-    auto bm_load = [&](int w) { return BM[w]; };     // (global: behind sync_global's acquire, which drops the L1's stale lines)
+    const unsigned long long* K = tie_key_copy(a.big + (size_t)b * a.big_stride, cells);   // the image's keys, block by block as the fill kernel wrote them
 
-    // ---- raster position of every seed
-    for (int w = tid; w < W; w += kTieThreads) BM[w] = 0u;
-    bm_sync();
-    for (int t0 = tid; t0 < n; t0 += 4 * kTieThreads) {            // (four keys per thread and round trip)
-        unsigned long long key[4];
+    // ---- raster position of every seed: exclusive prefix of the block lengths in (field, chunk) order ...
+    {
+        const int per = (E + kTieThreads - 1) / kTieThreads;
+        const int e0 = min(E, tid * per), e1 = min(E, e0 + per);
+        int mine = 0;
+        for (int e = e0; e < e1; e++) mine += TAB[e].y;
+        int incl = mine;
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const int t = t0 + u * kTieThreads; key[u] = K[t < n ? t : 0]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) asm volatile("" : "+v"(key[u]) :: "memory");
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (t0 + u * kTieThreads < n) {
-                const unsigned idx = 0xFFFFFFFFu - (unsigned)(key[u] & 0xFFFFFFFFull);
-                atomicOr(&BM[idx >> 5], 1u << (idx & 31));
-            }
-    }
-    bm_sync();
-    {   // exclusive prefix of the words' popcounts: every wave takes a contiguous range, 64 words per step
-        constexpr int NW = kTieThreads / 64;
-        const int per = ((W + NW * 64 - 1) / (NW * 64)) * 64;
-        const int w0 = wave * per, w1 = min(W, w0 + per);
-        int sum = 0;
-        for (int c0 = w0; c0 < w1; c0 += 4 * 64) {
-            int v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int w = c0 + u * 64 + lane; v[u] = (int)bm_load(w < w1 ? w : w0); }
-#pragma unroll
-            for (int u = 0; u < 4; u++) asm volatile("" : "+v"(v[u]) :: "memory");
-#pragma unroll
-            for (int u = 0; u < 4; u++) sum += c0 + u * 64 + lane < w1 ? __popc((unsigned)v[u]) : 0;
-        }
-        for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
-        if (lane == 0) s_wave_tot[wave] = sum;
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        if (lane == 63) s_wave_tot[wave] = incl;
         __syncthreads();
-        int run = 0;
+        int run = incl - mine;
         for (int k = 0; k < wave; k++) run += s_wave_tot[k];
-        for (int c0 = w0; c0 < w1; c0 += 4 * 64) {
-            int v[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int w = c0 + u * 64 + lane; v[u] = (int)bm_load(w < w1 ? w : w0); }
-#pragma unroll
-            for (int u = 0; u < 4; u++) asm volatile("" : "+v"(v[u]) :: "memory");
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int w = c0 + u * 64 + lane;
-                v[u] = w < w1 ? __popc((unsigned)v[u]) : 0;
-                int incl = v[u];
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-                if (w < w1) PREF[w] = (unsigned)(run + incl - v[u]);
-                run += __shfl(incl, 63, 64);
-            }
-        }
+        for (int e = e0; e < e1; e++) { PRE[e] = run; run += TAB[e].y; }
     }
-    bm_sync();
+    sync_global();
+    // An image beyond the LDS arrays: the scores that occur twice, in descending order, into the (otherwise unused) LDS
+    // area -- its elements look themselves up there; more than the area holds: every segment is followed.
+    unsigned* TV = (unsigned*)tie_lds;
+    constexpr int kTvCap = 4 * kTieLdsKeys;
+    int n_tv = 0;
+    if (!in_lds) {
+        const int per = (n + kTieThreads - 1) / kTieThreads;
+        const int r0 = min(n, tid * per), r1 = min(n, r0 + per);
+        auto first_of_group = [&](int t) {
+            const float v = sv[(size_t)t * ncol];
+            return t + 1 < n && sv[(size_t)(t + 1) * ncol] == v && (t == 0 || sv[(size_t)(t - 1) * ncol] != v);
+        };
+        int mine = 0;
+        for (int t = r0; t < r1; t++) mine += first_of_group(t) ? 1 : 0;
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        __syncthreads();                                           // (s_wave_tot was read above)
+        if (lane == 63) s_wave_tot[wave] = incl;
+        __syncthreads();
+        int run = incl - mine;
+        for (int k = 0; k < kTieThreads / 64; k++) { if (k < wave) run += s_wave_tot[k]; n_tv += s_wave_tot[k]; }
+        if (n_tv <= kTvCap)
+            for (int t = r0; t < r1; t++)
+                if (first_of_group(t)) TV[run++] = sortable_bits(sv[(size_t)t * ncol]);
+        __syncthreads();
+    }
+    // ... and every key goes to (seeds before its block) + (its offset in the block); its block follows from its cell
+    const int chunks = E / g.F;
     for (int t0 = tid; t0 < n; t0 += 4 * kTieThreads) {
-        unsigned long long key[4]; unsigned pre[4], word[4];
+        unsigned long long key[4]; int pre[4], beg[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) { const int t = t0 + u * kTieThreads; key[u] = K[t < n ? t : 0]; }
 #pragma unroll
@@ -871,36 +869,35 @@ __global__ __launch_bounds__(kTieThreads) void cifseeds_tie_kernel(TieArgs a, So
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const unsigned idx = 0xFFFFFFFFu - (unsigned)(key[u] & 0xFFFFFFFFull);
-            pre[u] = PREF[idx >> 5]; word[u] = bm_load(idx >> 5);
+            const int f = (int)(idx / (unsigned)g.HW), o = (int)(idx - (unsigned)f * (unsigned)g.HW);
+            const int e = f * chunks + o / (256 * kFillCells);
+            pre[u] = PRE[e]; beg[u] = TAB[e].x;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) asm volatile("" : "+v"(pre[u]), "+v"(word[u]) :: "memory");
+        for (int u = 0; u < 4; u++) asm volatile("" : "+v"(pre[u]), "+v"(beg[u]) :: "memory");
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-            if (t0 + u * kTieThreads < n) {
+        for (int u = 0; u < 4; u++) {
+            const int t = t0 + u * kTieThreads;
+            if (t < n) {
                 const unsigned idx = 0xFFFFFFFFu - (unsigned)(key[u] & 0xFFFFFFFFull);
-                const int pos = (int)pre[u] + __popc(word[u] & ((1u << (idx & 31)) - 1u));
-                BITS[pos] = (unsigned)(key[u] >> 32); IDX[pos] = idx;
-            }
-    }
-    tie_group_sync_rt(in_lds);
-    {   // which seeds have a score that occurs twice: neighbours in the sorted order; the first sort left their cells
-        const unsigned* cell_of = g.idx_out + (size_t)b * g.idx_stride;
-        for (int t = tid; t < n; t += kTieThreads) {
-            bool tied;
-            if (in_lds) tied = (t > 0 && SV[t - 1] == SV[t]) || (t + 1 < n && SV[t + 1] == SV[t]);
-            else {
-                const float v = sv[(size_t)t * ncol];
-                tied = (t > 0 && sv[(size_t)(t - 1) * ncol] == v) || (t + 1 < n && sv[(size_t)(t + 1) * ncol] == v);
-            }
-            if (tied) {
-                const unsigned idx = cell_of[t];
-                const int pos = (int)PREF[idx >> 5] + __popc(bm_load(idx >> 5) & ((1u << (idx & 31)) - 1u));
-                IDX[pos] = idx | kTiedBit;
+                const unsigned bits = (unsigned)(key[u] >> 32);
+                // does the score occur twice?  An image in LDS looks it up in its sorted scores, a larger one in the list
+                unsigned tied = kTiedBit;
+                if (in_lds) {
+                    int lo = 0, hi = n;                            // first index with SV[i] <= bits (descending)
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (SV[mid] > bits) lo = mid + 1; else hi = mid; }
+                    tied = (lo + 1 < n && SV[lo + 1] == bits) ? kTiedBit : 0u;
+                } else if (n_tv <= kTvCap) {
+                    int lo = 0, hi = n_tv;
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (TV[mid] > bits) lo = mid + 1; else hi = mid; }
+                    tied = (lo < n_tv && TV[lo] == bits) ? kTiedBit : 0u;
+                }
+                const int pos = pre[u] + (t - beg[u]);
+                BITS[pos] = bits; IDX[pos] = idx | tied;
             }
         }
     }
-    unsigned* mark = in_lds ? s_mark : (unsigned*)(a.small_ + (size_t)b * a.small_stride);   // (the global bitmap has served its purpose)
+    unsigned* mark = in_lds ? s_mark : (unsigned*)(seg_b + tie_seg_cap(cells));   // (behind the segment lists: n / 32 words)
     tie_group_sync_rt(in_lds);
     for (int w = tid; w < (n + 31) / 32; w += kTieThreads) mark[w] = 0u;
     tie_group_sync_rt(in_lds);
@@ -946,7 +943,6 @@ hipError_t launch_cifseeds_ties(unsigned long long* keys, int sort_cap, const in
     SortArgs g;
     g.keys = keys; g.sort_cap = sort_cap; g.cap = F * HW; g.seed_count = seed_count; g.cif = cif; g.F = F; g.NC = NC; g.HW = HW;
     g.stride = stride; g.seed_f = seed_f; g.seed_vxys = seed_vxys; g.seed_cell = seed_cell; g.occ_h = occ_h; g.occ_w = occ_w;
-    g.idx_out = tie_idx_out(big, F * HW); g.idx_stride = big_stride / sizeof(unsigned);
     TieArgs a;
     a.cells = F * HW; a.big = big; a.big_stride = big_stride; a.small_ = small_; a.small_stride = small_stride; a.tie_state = tie_state;
     const int lds = 4 * kTieLdsKeys * (int)sizeof(unsigned);
@@ -974,16 +970,19 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
         if (e != hipSuccess) return e;
         prof_mark(st, "memset_seed_count");
     }
+    const bool tie_pass = ties && ties->big && seed_tie_order() == 1;
     dim3 grid(B * F, (HW + 256 * kFillCells - 1) / (256 * kFillCells));
     cifseeds_fill_kernel<<<grid, 256, 0, st>>>(cif, F, NC, H, W, stride, cifhr, hr_rows, hr_cols, hr_pitch,
                                                p.seed_threshold, det ? 0 : p.ablation_cifseeds_nms,
-                                               det ? 0 : p.ablation_cifseeds_no_rescore, keys, sort_cap, cap, seed_count);
+                                               det ? 0 : p.ablation_cifseeds_no_rescore, keys, sort_cap, cap, seed_count,
+                                               tie_pass ? (int2*)ties->small_ : nullptr,
+                                               tie_pass ? ties->small_stride / sizeof(int2) : 0,
+                                               tie_pass ? tie_key_copy(ties->big, cap) : nullptr,
+                                               tie_pass ? ties->big_stride / sizeof(unsigned long long) : 0);
     prof_mark(st, "cifseeds_fill_kernel");
     SortArgs g;
     g.keys = keys; g.sort_cap = sort_cap; g.cap = cap; g.seed_count = seed_count; g.cif = cif; g.F = F; g.NC = NC; g.HW = HW;
     g.stride = stride; g.seed_f = seed_f; g.seed_vxys = seed_vxys; g.seed_cell = seed_cell; g.occ_h = occ_h; g.occ_w = occ_w;
-    const bool tie_pass = ties && ties->big && seed_tie_order() == 1;
-    g.idx_out = tie_pass ? tie_idx_out(ties->big, cap) : nullptr; g.idx_stride = tie_pass ? ties->big_stride / sizeof(unsigned) : 0;
     const int n_sort = B * kSortBlocksMax;
     if (scored && n_scored > 0) {
         const ScoredArgs& s0 = scored[0];
@@ -998,8 +997,7 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
     if (cap > kSortSmallBlock) {                      // images of more than one block of seeds are possible
         const int most = cap < kSortBlocksMax * kSortLdsKeys ? cap : kSortBlocksMax * kSortLdsKeys;
         cifseeds_rankmerge_kernel<<<dim3((most + 255) / 256, B), 256, 0, st>>>(keys, sort_cap, cap, seed_count, cif, F, NC, HW,
-                                                                                 stride, seed_f, seed_vxys, seed_cell, occ_h, occ_w, p,
-                                                                                 g.idx_out, g.idx_stride);
+                                                                                 stride, seed_f, seed_vxys, seed_cell, occ_h, occ_w, p);
     }
     prof_mark(st, scored && n_scored > 0 ? "sort_cafscored_kernel" : "cifseeds_sort_kernel");
     hipError_t e = hipGetLastError();

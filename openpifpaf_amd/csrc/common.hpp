@@ -88,7 +88,7 @@ struct ScoredArgs;
 // (the reference, default), 0 = cell index (opa_set_seed_tie_order / OPA_SEED_TIES=index).
 struct TieScratch { unsigned char* big; size_t big_stride; unsigned char* small_; size_t small_stride; int32_t* state; };
 size_t tie_big_bytes(int cells);
-size_t tie_small_bytes(int cells);
+size_t tie_small_bytes(int F, int HW);
 int seed_tie_order();
 hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int stride,
                            const float* cifhr, int hr_rows, int hr_cols, int hr_pitch, const DevParams& p,
