@@ -720,12 +720,61 @@ __device__ __forceinline__ int tie_partition_block(unsigned* bits_, unsigned* id
     return cut;
 }
 
+// A segment of at most kTieSubtree elements is finished by ONE wave, all the levels below it (no workgroup barrier per
+// level: most of an image's partitions are down here).  An image in global memory brings the segment into the wave's
+// own LDS area first (scores, cells, two stop lists of kTieSubtree entries) and takes it back afterwards.  `stack`: 3 *
+// kTieStack ints of LDS per wave: (first, last, depth) of the segments still to be partitioned.
+constexpr int kTieSubtree = 512;
+constexpr int kTieSubtreeLds = 0;        // (an image in LDS pays little per level: sharing every level among its waves is faster -- 78 vs 84 us)
+constexpr int kTieStack = kTieSubtree / 17 + 4;
+template <bool LDS>
+__device__ __forceinline__ void tie_subtree(unsigned* BITS, unsigned* IDX, unsigned* LPOS, unsigned* RPOS, int first, int last,
+                                            int depth, unsigned* mark, int* s_fail, int* stack, unsigned* area) {
+    const int lane = threadIdx.x & 63;
+    unsigned *B = BITS, *I = IDX, *L = LPOS, *R = RPOS;
+    int off = 0;                                                   // position in the image = position here + off
+    if constexpr (!LDS) {
+        const TieArr<false> gb = tie_arr<false>(BITS), gi = tie_arr<false>(IDX);
+        B = area; I = area + kTieSubtree; L = I + kTieSubtree; R = L + kTieSubtree;
+        off = first;
+        for (int j = lane; j < last - first; j += 64) { B[j] = gb(first + j); I[j] = gi(first + j); }
+        tie_wave_fence<true>();
+    }
+    int top = 0;
+    if (lane == 0) { stack[0] = first - off; stack[1] = last - off; stack[2] = depth; }
+    top = 1;
+    tie_wave_fence<true>();
+    while (top > 0) {
+        top--;
+        const int f = stack[3 * top], l = stack[3 * top + 1], d = stack[3 * top + 2];
+        tie_wave_fence<true>();                                    // (every lane has read the entry before it is overwritten)
+        if (d == 0) { if (lane == 0) *s_fail = 1; break; }         // the heapsort branch: not reproduced
+        const int cut = tie_partition<true>(B, I, L, R, f, l);
+        if (cut == -2) continue;
+        if (cut < 0) { if (lane == 0) *s_fail = 1; break; }
+        if (lane == 0) {
+            if (cut < l) { const int c = cut + off; atomicOr(&mark[c >> 5], 1u << (c & 31)); }
+            int t = top;
+            if (cut - f > 16) { stack[3 * t] = f; stack[3 * t + 1] = cut; stack[3 * t + 2] = d - 1; t++; }
+            if (l - cut > 16) { stack[3 * t] = cut; stack[3 * t + 1] = l; stack[3 * t + 2] = d - 1; t++; }
+        }
+        top += (cut - f > 16 ? 1 : 0) + (l - cut > 16 ? 1 : 0);
+        tie_wave_fence<true>();
+    }
+    if constexpr (!LDS) {
+        tie_wave_fence<true>();
+        for (int j = lane; j < last - first; j += 64) { BITS[first + j] = B[j]; IDX[first + j] = I[j]; }
+        tie_wave_fence<false>();
+    }
+}
+
 // __introsort_loop(0, n): the segments of one recursion level in `cur`, their children in `nxt`; one wave per segment.
 // `mark`: one bit per position, set where a partition cut its segment (and at 0): the segments of at most 16 elements
 // the loop leaves to the insertion sort lie between two marks.
 template <bool LDS>
 __device__ __forceinline__ void tie_levels(unsigned* BITS, unsigned* IDX, unsigned* LPOS, unsigned* RPOS, int2* cur, int2* nxt,
-                                           int n, int* s_next, int* s_fail, unsigned* mark, int* coop) {
+                                           int n, int* s_next, int* s_fail, unsigned* mark, int* coop, int* stacks,
+                                           unsigned* areas) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int depth = 2 * (31 - __clz(n));                               // std::__lg(n) * 2
     int n_cur = 0;
@@ -753,6 +802,11 @@ __device__ __forceinline__ void tie_levels(unsigned* BITS, unsigned* IDX, unsign
             const int2 sg = cur[s];
             if (sg.y - sg.x > tie_coop_len<LDS>()) continue;
             if ((mine++ % (kTieThreads / 64)) != wave) continue;
+            if (sg.y - sg.x <= (LDS ? kTieSubtreeLds : kTieSubtree)) {   // short enough: this wave finishes it, all levels
+                tie_subtree<LDS>(BITS, IDX, LPOS, RPOS, sg.x, sg.y, depth + 1, mark, s_fail, stacks + wave * 3 * kTieStack,
+                                 areas + (size_t)wave * 4 * kTieSubtree);
+                continue;
+            }
             const int cut = tie_partition<LDS>(BITS, IDX, LPOS, RPOS, sg.x, sg.y);
             if (cut == -2) continue;                               // no tied score in it: nobody asks where its seeds end up
             if (cut < 0) { if (lane == 0) *s_fail = 1; continue; }
@@ -774,6 +828,7 @@ __global__ __launch_bounds__(kTieThreads) void cifseeds_tie_kernel(TieArgs a, So
     __shared__ int2 s_seg[2][kTieLdsKeys / 17 + 2];           // the two segment lists of an image that lives in LDS
     __shared__ unsigned s_mark[kTieLdsKeys / 32];
     __shared__ int s_coop[2 * (kTieThreads / 64) + 2];
+    __shared__ int s_stack[(kTieThreads / 64) * 3 * kTieStack];
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int n = g.seed_count[b];
     if (n > g.cap) n = g.cap;
@@ -903,8 +958,8 @@ __global__ __launch_bounds__(kTieThreads) void cifseeds_tie_kernel(TieArgs a, So
     tie_group_sync_rt(in_lds);
 
     // ---- __introsort_loop, one level of the recursion at a time
-    if (in_lds) tie_levels<true>(BITS, IDX, LPOS, RPOS, s_seg[0], s_seg[1], n, &s_next, &s_fail, mark, s_coop);
-    else tie_levels<false>(BITS, IDX, LPOS, RPOS, seg_a, seg_b, n, &s_next, &s_fail, mark, s_coop);
+    if (in_lds) tie_levels<true>(BITS, IDX, LPOS, RPOS, s_seg[0], s_seg[1], n, &s_next, &s_fail, mark, s_coop, s_stack, nullptr);
+    else tie_levels<false>(BITS, IDX, LPOS, RPOS, seg_a, seg_b, n, &s_next, &s_fail, mark, s_coop, s_stack, (unsigned*)tie_lds);
     __syncthreads();
     if (s_fail) {                                                  // the seeds stay as the first sort left them
         if (tid == 0 && a.tie_state) a.tie_state[b] = -1;
