@@ -358,6 +358,11 @@ def build_model(wl, dtype_name):
     return model
 
 
+def native_tie_order():
+    from openpifpaf_amd import native
+    return native.get_seed_tie_order()
+
+
 def kernel_profile(wl, variants, params, steps):
     """Per-kernel HIP-event times of the decode (events recorded by the library on the stream the kernels are launched
     on), averaged over `steps` launches that alternate the field batches."""
@@ -674,10 +679,12 @@ def main():
                 if 'bf16' in legs:
                     q = parity_stamp(lambda c, f: wl.dec.call_batch(c, wl.stride, f, wl.stride, params=params),
                                      wl.quantised(), wl.skeleton0, wl.K, fc_kw)
+                    q['seed_tie_order'] = native_tie_order()
                     q['note'] = ('decode inputs of the bf16 leg: the fields rounded to bfloat16.  8-bit mantissas make seed '
-                                 'scores tie; the HIP path orders tied seeds by cell index, the reference by whatever its '
-                                 'unstable std::sort leaves (cif_seeds.cpp:94) -- images_beyond_tolerance / images is the '
-                                 'tie mismatch rate (never a pose-count or joint-presence change in the studies)')
+                                 'scores tie, and the reference orders tied seeds by whatever its unstable std::sort leaves '
+                                 '(cif_seeds.cpp:94).  seed_tie_order "libstdcxx": the HIP path reproduces that order '
+                                 '(cifseeds_tie_kernel); "index": it orders them by cell index, and '
+                                 'images_beyond_tolerance / images is the tie mismatch rate (round 2: 5 of 64)')
                     parity['bf16_fields'] = q
         s = leg_summary(wl, legs[primary], steps)
         value = s['value']

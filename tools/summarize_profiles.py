@@ -21,7 +21,7 @@ WORKLOADS = [('config2', 'COCO-17 (configs 2 / 3 fields), batch 32, default flag
              ('config4', 'wholebody 133 keypoints / 160 bones (config 4), batch 16, default flags', 4, 16, False),
              ('config4_fc', 'wholebody, batch 16, force complete', 4, 16, True)]
 DECODE_KERNELS = ('cif_active_kernel', 'cifhr_tile_kernel', 'tile_state_roll_kernel', 'cifseeds_fill_kernel',
-                  'cifseeds_sort_kernel', 'cifseeds_sort_scored_kernel', 'cifseeds_rankmerge_kernel', 'cafscored_kernel', 'cifcaf_assoc_kernel',
+                  'cifseeds_sort_kernel', 'cifseeds_sort_scored_kernel', 'cifseeds_rankmerge_kernel', 'cifseeds_tie_kernel', 'cafscored_kernel', 'cifcaf_assoc_kernel',
                   'cifcaf_fc_kernel')
 
 
