@@ -425,7 +425,13 @@ def decode_roofline(wl, variants, params, steps, force_complete=False):
         'decode_path': {'ms_per_batch': round(decode_ms, 4),
                         'images_per_s': round(wl.B / (decode_ms * 1e-3), 1),
                         'GBps': round(alg['decode_path'] / (decode_ms * 1e-3) / 1e9, 2),
-                        'frac': round(alg['decode_path'] / (decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
+                        'frac': round(alg['decode_path'] / (decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                        'seed_tie_order': native_tie_order(),
+                        'tie_pass_ms': round(avg_ms.get('cifseeds_tie_kernel', 0.0), 4),
+                        'tie_pass_note': 'cifseeds_tie_kernel puts seeds of EQUAL score into the order the reference\'s '
+                                         'unstable std::sort leaves them in; it costs this much only for batches that hold '
+                                         'such seeds (the synthetic blobs are symmetric: about one image in eight has an '
+                                         'equal pair) and a few microseconds otherwise; OPA_SEED_TIES=index removes it'},
         'field_batches_alternating': len(variants),
     }
     return roofline
