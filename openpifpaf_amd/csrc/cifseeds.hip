@@ -834,7 +834,6 @@ __global__ __launch_bounds__(kTieThreads) void cifseeds_tie_kernel(TieArgs a, So
     if (n > g.cap) n = g.cap;
     const bool in_lds = n <= kTieLdsKeys;
     const int cells = a.cells;
-    const int W = (cells + 31) >> 5;
     unsigned *BITS, *IDX, *LPOS, *RPOS;
     if (in_lds) {
         BITS = (unsigned*)tie_lds; IDX = BITS + kTieLdsKeys; LPOS = IDX + kTieLdsKeys; RPOS = LPOS + kTieLdsKeys;
@@ -1001,11 +1000,9 @@ hipError_t launch_cifseeds_ties(unsigned long long* keys, int sort_cap, const in
     TieArgs a;
     a.cells = F * HW; a.big = big; a.big_stride = big_stride; a.small_ = small_; a.small_stride = small_stride; a.tie_state = tie_state;
     const int lds = 4 * kTieLdsKeys * (int)sizeof(unsigned);
-    static bool attr_set = false;
-    if (!attr_set) {
+    {   // (per device, not per process: set on every launch like the association kernel's)
         hipError_t e = hipFuncSetAttribute((const void*)cifseeds_tie_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
     cifseeds_tie_kernel<<<B, kTieThreads, lds, st>>>(a, g, p);
     prof_mark(st, "cifseeds_tie_kernel");
