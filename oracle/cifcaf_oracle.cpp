@@ -454,6 +454,16 @@ typedef Params oracle_params;
 
 void oracle_default_params(oracle_params* p) { *p = Params(); }
 void oracle_set_seed_tie_rule(int rule) { g_seed_tie_rule = rule; }
+
+// The permutation std::sort leaves a sequence of seed scores in (cif_seeds.cpp:94: Seed structs, comparator a.v > b.v):
+// perm[k] = original position of the element that ends up at rank k.  tests/test_tie_order_model.py checks the
+// formulation the HIP tie pass uses (stop pairing, per-segment stable placement) against it without a GPU.
+void oracle_sorted_seed_order(const float* v, int64_t n, int64_t* perm) {
+    std::vector<Seed> seeds((size_t)n);
+    for (int64_t i = 0; i < n; i++) seeds[(size_t)i] = Seed{i, v[i], 0.f, 0.f, 0.f};
+    std::sort(seeds.begin(), seeds.end(), [](const Seed& a, const Seed& b) { return a.v > b.v; });
+    for (int64_t i = 0; i < n; i++) perm[i] = seeds[(size_t)i].f;
+}
 int oracle_get_seed_tie_rule(void) { return g_seed_tie_rule; }
 
 // cifhr [F,Hhr,Whr] must be zero-filled by the caller; on return it holds the

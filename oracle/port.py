@@ -60,6 +60,14 @@ def lib():
     return _lib
 
 
+def sorted_seed_order(scores):
+    """perm[k] = original position of the seed std::sort (cif_seeds.cpp:94) leaves at rank k."""
+    v = _f32(scores).ravel()
+    perm = np.zeros(len(v), dtype=np.int64)
+    lib().oracle_sorted_seed_order(_ptr(v), _i64(len(v)), _ptr(perm))
+    return perm
+
+
 def set_seed_tie_rule(rule):
     """Order of seeds with exactly equal scores in the restatement: 0 = libstdc++'s unstable std::sort
     (the reference, default), 1 = cell index ascending (the HIP path's total order), 2 = descending."""
