@@ -217,8 +217,8 @@ int opa_cifhr_accumulate(const float* cif_dev, int32_t batch, int32_t n_cif, int
                          float* cifhr_dev, void* scratch_dev, size_t scratch_bytes, void* stream);
 
 /* ref: module.cpp:86-94  CifSeeds(cifhr, revision).fill(cif, stride) + get()
- * (cif_seeds.cpp:33-66,93-114).  Output sorted by v descending; ties by cell
- * index ascending (the reference's std::sort leaves tie order unspecified).
+ * (cif_seeds.cpp:33-66,93-114).  Output sorted by v descending; equal scores in
+ * the order the reference's std::sort leaves them in (opa_set_seed_tie_order).
  *  seed_f_dev int32 [B, cap], seed_vxys_dev [B, cap, 4] (v,x,y,s), seed_count_dev int32 [B],
  *  cap = F*H*W;  scratch_dev: opa_cifseeds_scratch_bytes() bytes. */
 size_t opa_cifseeds_scratch_bytes(int32_t batch, int32_t n_cif, int32_t cif_h, int32_t cif_w);
