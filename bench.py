@@ -64,6 +64,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}     # dense matrix peaks, MI355X_MICROARCH.md
 TORCH_DTYPE = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}
+PMC_ROUNDS = ('r4', 'r3')
 VARIANT_SEED = 100_000   # field batch v of rank r is synth_batch(B, seed0 = v * VARIANT_SEED + r * B)
 TOL = 1e-4               # BASELINE.json north_star: keypoint coordinates / scores within 1e-4
 
@@ -147,12 +148,17 @@ def kernel_source_hash():
 def pmc_traffic(config_id, B, force_complete=False):
     """PMC HBM bytes of the WHOLE decode path per launch (rocprofv3 passes cannot run inside bench.py;
     tools/collect_profiles.sh writes them, stamped with the hash of the kernel sources they were measured on)."""
-    try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r3', 'pmc_traffic.json')))
-    except (OSError, ValueError):
-        return None, 'no PMC file (run tools/collect_profiles.sh)'
-    if pmc.get('kernel_source_hash') != kernel_source_hash():
-        return None, 'profiles/r3/pmc_traffic.json was measured on other kernel sources'
+    pmc, where, have = None, None, kernel_source_hash()
+    for rnd in PMC_ROUNDS:                                     # newest first; only a file measured on THESE kernels counts
+        try:
+            cand = json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_traffic.json')))
+        except (OSError, ValueError):
+            continue
+        if cand.get('kernel_source_hash') == have:
+            pmc, where = cand, 'profiles/%s/pmc_traffic.json' % rnd
+            break
+    if pmc is None:
+        return None, 'no pmc_traffic.json measured on these kernel sources (run tools/collect_profiles.sh)'
     key = 'config%d%s_batch%d' % (config_id, '_fc' if force_complete else '', B)
     entry = pmc.get('workloads', {}).get(key)
     same_as = ''
@@ -163,9 +169,128 @@ def pmc_traffic(config_id, B, force_complete=False):
         entry = pmc.get('workloads', {}).get(key)
         same_as = '; config 3 decodes the same field batches with the same launches as config 2'
     if not entry:
-        return None, 'profiles/r3/pmc_traffic.json holds no entry %s' % key
-    return entry, 'profiles/r3/pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 read ' \
-                  'correction; sum over the decode kernels of one launch%s)' % (key, same_as)
+        return None, '%s holds no entry %s' % (where, key)
+    return entry, '%s[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, x2 read ' \
+                  'correction; sum over the decode kernels of one launch%s)' % (where, key, same_as)
+
+
+
+# ----------------------------------------------------------------------------------------------- the printed line
+LINE_LIMIT = 3072        # the driver keeps a stdout tail of a few KB: the final line must stay well inside it
+DETAIL_FILE = 'bench_detail.json'
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_roofline(roof):
+    if not roof:
+        return None
+    out = _pick(roof, ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'avg_launch_ms',
+                       'algorithmic_bytes_per_launch'))
+    path = roof.get('decode_path') or {}
+    out['decode_path_frac'] = path.get('frac')
+    out['decode_path_ms'] = path.get('ms_per_batch')
+    return out
+
+
+def compact_cpu(cpu):
+    if not cpu:
+        return None
+    out = _pick(cpu, ('value', 'cores', 'kind', 'fresh_instance_value', 'all_cores_value', 'all_cores'))
+    out['unit'] = 'images/s (decode only)'
+    out['sample'] = str(cpu.get('sample_short', cpu.get('sample', '')))[:96]
+    return out
+
+
+def compact_parity(par):
+    return _pick(par, ('images', 'poses', 'max_abs_delta', 'discrete_mismatches')) if par else None
+
+
+def parity_ok(par):
+    if not par:
+        return None
+    return bool(par.get('images', 0) > 0 and par.get('discrete_mismatches', 1) == 0
+                and par.get('images_beyond_tolerance', 0) == 0 and par.get('max_abs_delta', 1.0) <= TOL)
+
+
+def compact_leg(leg):
+    """One entry of the line's `configs` digest: {value, ms_per_step, decode_ms, frac, parity_ok}."""
+    if not isinstance(leg, dict):
+        return None
+    if 'error' in leg:
+        return {'error': str(leg['error'])[:80]}
+    roof = leg.get('roofline') or {}
+    path = roof.get('decode_path') or {}
+    value = leg.get('value', leg.get('decode_only_images_per_s'))
+    if isinstance(value, dict):                               # the lanes sweep: its best entry
+        value = max(value.values()) if value else None
+    out = {'value': value,
+           'ms_per_step': leg.get('ms_per_step', leg.get('ms_per_batch_wall', leg.get('eager_ms_per_image'))),
+           'decode_ms': path.get('ms_per_batch', leg.get('decode_ms')),
+           'frac': roof.get('frac', (leg.get('best') or {}).get('frac')),
+           'parity_ok': parity_ok(leg.get('parity'))}
+    return out
+
+
+def compact_line(detail):
+    """The ONE line the driver parses, built from the full result (which goes to bench_detail.json): contract fields,
+    roofline, cpu_baseline, parity and a five-number digest per extra leg -- no prose, always < LINE_LIMIT bytes."""
+    line = _pick(detail, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+                          'scaling', 'vs_baseline', 'dtype', 'data'))
+    cfg = detail.get('config') or {}
+    line['config'] = _pick(cfg, ('workload', 'backbone', 'backbone_dtype', 'decode_dtype', 'global_batch', 'batch_per_gpu',
+                                 'parallelism', 'force_complete_pose'))
+    line['roofline'] = compact_roofline(detail.get('roofline'))
+    line['cpu_baseline'] = compact_cpu(detail.get('cpu_baseline'))
+    line['parity'] = compact_parity(detail.get('parity'))
+    if 'per_rank_ms_per_step' in detail:
+        line['per_rank_ms_per_step'] = detail['per_rank_ms_per_step']
+    bf = detail.get('bf16_backbone')
+    if bf:
+        line['bf16_backbone'] = _pick(bf, ('value', 'ms_per_step'))
+    digest = {k: compact_leg(v) for k, v in (detail.get('configs') or {}).items()}
+    if digest:
+        line['configs'] = digest
+    line['detail'] = DETAIL_FILE
+    line['bench_seconds'] = detail.get('bench_seconds')
+    text = json.dumps(line, separators=(',', ':'))
+    if len(text) >= LINE_LIMIT:                               # never let an extra take the headline with it
+        line.pop('configs', None)
+        line['configs_dropped'] = True
+        text = json.dumps(line, separators=(',', ':'))
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def write_detail(detail):
+    """Everything the line leaves out: next to bench.py, and under gpurun_out/ so that it travels back from a GPU box."""
+    text = json.dumps(detail, indent=1)
+    written = []
+    for path in (os.path.join(ROOT, DETAIL_FILE), os.path.join(ROOT, 'gpurun_out', DETAIL_FILE)):
+        try:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            with open(path, 'w') as f:
+                f.write(text)
+            written.append(path)
+        except OSError as e:                                  # read-only checkout: the line itself still prints
+            print('bench: could not write %s: %r' % (path, e), file=sys.stderr)
+    return written
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (a bare run
+    would silently measure one rank)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('bench: --gpus %d without WORLD_SIZE: re-launching as %s' % (n, ' '.join(cmd)), file=sys.stderr)
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
 
 
 # ----------------------------------------------------------------------------------------------- CPU side
@@ -260,6 +385,8 @@ def cpu_baseline(cifs, cafs, skeleton0, n_keypoints, seconds, fc_kw=None):
         'value': round(reused, 2), 'unit': 'images/s (decode only, 1 thread, decoder instance reused)', 'cores': 1,
         'kind': kind, 'fresh_instance_value': round(fresh, 2),
         'all_cores_value': round(multi, 2) if multi else None, 'all_cores': cores,
+        'sample_short': '%d reused + %d fresh-instance decodes of the rank-0 field batch, then %d forked workers' % (
+            n_reused, n_fresh, cores),
         'sample': '%d decodes of the rank-0 field batch with one reused decoder instance (what the reference\'s '
                   'Decoder does), %d with a fresh instance per image (the parity definition: revision drift), '
                   'then %d forked single-thread workers for a fixed time budget' % (n_reused, n_fresh, cores),
@@ -442,6 +569,10 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        if torch.cuda.device_count() < args.gpus and not args.share_device:
+            sys.exit('bench.py: --gpus %d but %d visible' % (args.gpus, torch.cuda.device_count()))
+        spawn_ranks(args.gpus)
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs'
     # MIOpen "find" mode: benchmark the real solvers once per conv shape during warm-up.  The
     # immediate-mode heuristic occasionally falls back to naive_conv (~300 ms per call).
@@ -456,8 +587,8 @@ def main():
             dist.init_process_group('nccl', device_id=device)  # backend "nccl" is RCCL on ROCm
         else:
             dist.init_process_group('gloo')
-    if args.gpus != world and rank == 0 and world > 1:
-        print('warning: --gpus %d but WORLD_SIZE %d' % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world:
+        sys.exit('bench.py: --gpus %d but WORLD_SIZE %d' % (args.gpus, world))
 
     from openpifpaf_amd import _lib, distributed, native
 
@@ -702,7 +833,7 @@ def main():
                 'workload': wl.workload_text(),
                 'backbone': 'none (decode only)' if decode_only else wl.backbone,
                 'backbone_dtype': primary, 'decode_dtype': 'f32 (+f64 where the reference uses double)',
-                'global_batch': world * wl.B,
+                'global_batch': world * wl.B, 'batch_per_gpu': wl.B,
                 'fields': ('COCO-shaped synthetic fields injected after the heads (people per image cycle %s); %d different '
                            'field batches alternate step by step' % (list(wl.people), len(wl.variants)))
                           if fields == 'synthetic' else
@@ -943,7 +1074,9 @@ def main():
             line['configs'] = others
     if rank == 0:
         line['bench_seconds'] = round(time.perf_counter() - t_program, 1)
-        print(json.dumps(line))
+        write_detail(line)
+        sys.stderr.flush()
+        print(compact_line(line), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
