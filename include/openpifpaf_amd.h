@@ -202,7 +202,10 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
  * 20 ticks of the refills spent waiting for the growers' occupancy marks, 21-22 scan timing of diagnostic builds, 23 seeds
  * dropped at a refill as later seeds of an occupancy cell already seen in the same round; ticks are 10 ns), "assoc_trace" (int32 [B,64,4]: for the first
  * 64 accepted poses of an image the tick of the commit, of the hand-out and of the end of the growth, and
- * seed index | grower << 24). */
+ * seed index | grower << 24).
+ * The three "*_fc" regions lie at the END of the layout: their offsets are only inside a workspace of
+ * opa_cifcaf_workspace_bytes() (or ..._bytes_for() with force_complete set); a workspace sized without the flag
+ * ends before them -- do not dereference them there. */
 int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what,
                               size_t* offset_bytes, size_t* size_bytes);
 

@@ -2366,8 +2366,9 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     AssocArgs a = args;
     if (const char* e = getenv("OPA_ASSOC_BBOX")) { if (atoi(e) == 0) a.list_bbox = a.list_bbox_fc = nullptr; }   // A/B: scan every chunk
     // (the argument needs a joint's box to hold the joint's own cell: true for a reduced minimum scale >= 1 cell --
-    // the reference's is 2 -- not for a box that may shrink to the one cell next to it)
-    a.dedup = p.occupancy_min_scale_reduced >= 1.0 ? 1 : 0;
+    // the reference's is 2 -- not for a box that may shrink to the one cell next to it; and the minimum is only applied
+    // when the map is reduced at all, occupancy.cpp:14-18: with reduction == 1 the box is the raw joint scale)
+    a.dedup = (p.occupancy_reduction != 1.0 && p.occupancy_min_scale_reduced >= 1.0) ? 1 : 0;
     if (const char* e = getenv("OPA_ASSOC_DEDUP")) { if (atoi(e) == 0) a.dedup = 0; }   // A/B and tests: same result without it
     a.watchdog_ticks = kWatchdogTicksDefault;
     if (const char* e = getenv("OPA_ASSOC_WATCHDOG_TICKS")) { const long long v = atoll(e); if (v > 0) a.watchdog_ticks = v; }

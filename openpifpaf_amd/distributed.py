@@ -75,12 +75,12 @@ def broadcast_conv_choices(src=0, group=None):
     picks gemm / pass+gemm / MIOpen per shape by wall clock on first use and the three round differently, so without
     this the ranks of one job could run -- slightly -- different networks.  Call it after the warm-up step in which
     the choices are made and before the first step that counts; a no-op without an initialised process group.
-    -> the table now in force."""
+    ``src`` is a GLOBAL rank (what ``broadcast_object_list`` takes), also for a sub-group.  -> the table now in force."""
     import torch.distributed as dist
     from . import fused
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return fused.choices()
-    box = [fused.choices() if dist.get_rank(group) == src else None]
+    box = [fused.choices() if dist.get_rank() == src else None]    # global rank, like broadcast_object_list's src
     dist.broadcast_object_list(box, src=src, group=group)
     fused.set_choices(box[0], replace=True)
     return fused.choices()

@@ -314,7 +314,11 @@ class DecodeLanes:
 
         def result(self):
             """The decode's ``(annotations, ids, counts)``, safe to use on the current stream."""
-            torch.cuda.current_stream().wait_event(self.event)
+            consumer = torch.cuda.current_stream()
+            consumer.wait_event(self.event)
+            for t in self.tensors:                       # allocated on the lane's stream: the allocator must not hand
+                if t.is_cuda:                            # them to the lane's next submit while the consumer still reads
+                    t.record_stream(consumer)
             return self.tensors
 
         def synchronize(self):

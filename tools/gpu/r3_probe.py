@@ -95,6 +95,12 @@ for b in order:
     print('%3d %5d %5d | %7d %8d %9d %7d %8d %7d %7d | %9.0f %8.0f %6.0f %13.0f %14.0f %5d %7.2f %7d' % (
         b, native.count_rows(int(counts[b])), s[7], s[0], s[1], s[2], s[3], s[4], s[5], s[6],
         s[8] / 100, s[9] / 100, s[15], s[12] / 100, s[10] / 100, s[11], s[10] / 100 / max(1, s[11]), s[13]))
+print('coordinator us per image (wait-iters | head-wait commit refill hand-out other | refill waiting for marks | dup-dropped):')
+for b in order:
+    s = st[b]
+    print('%3d  %5d | %6.0f %6.0f %6.0f %6.0f %6.0f | %6.0f | %6d' % (
+        b, s[16], s[12] / 100, s[17] / 100, s[18] / 100, s[19] / 100, (s[8] - s[12] - s[17] - s[18] - s[19]) / 100,
+        s[20] / 100, s[23]))
 tot_s = st.sum(axis=0)
 print('batch: started %d accepted %d cancelled %d dropped %d; slowest image %.0f us, mean %.0f us; lists: max %d mean %.0f' % (
     tot_s[0], tot_s[1], tot_s[2], tot_s[3], st[:, 9].max() / 100, st[:, 9].mean() / 100,
