@@ -227,6 +227,99 @@ class CifCaf(Decoder):
 
     supports_device_inverse = True       # batch(..., meta_batch=...) undoes pad / rescale / flip on the device
 
+    # ---- several batches in flight (the reference's --decoder-workers, decoder/decoder.py:33-47,130-131) ----------
+    #: decode lanes: decoders / workspaces / HIP streams taking batches in turn.  The reference overlaps the decode of a
+    #: batch with the next batch's network through a fork pool of CPU workers; here a lane's decode (whose longest
+    #: kernel keeps one workgroup per image busy) runs on its own stream beside the next batch's network, and the
+    #: annotations come back through pinned memory without stalling either stream.
+    decoder_workers = 2
+
+    def _decode_lanes(self):
+        lanes = getattr(self, '_lanes', None)
+        n = max(1, int(self.decoder_workers or 1))
+        if lanes is None or len(lanes.decoders) != n:
+            lanes = native.DecodeLanes(len(self.cif_metas[0].keypoints), torch.LongTensor(self.caf_metas[0].skeleton) - 1,
+                                       lanes=n, max_annotations=self.max_annotations)
+            self._lanes, self._lane_host, self._lane_pending = lanes, {}, {}
+        return lanes
+
+    def __getstate__(self):
+        return {k: v for k, v in self.__dict__.items() if k not in ('worker_pool', '_lanes', '_lane_host', '_lane_pending')}
+
+    class Pending:
+        """A batch in flight: ``result()`` waits for ITS decode only (an event on its lane) and builds the annotations."""
+
+        def __init__(self, owner, lane, event, host, n_images, t_submit):
+            self.owner, self.lane, self.event, self.host, self.n_images, self.t_submit = owner, lane, event, host, n_images, t_submit
+            self._result = None
+
+        def done(self):
+            return self._result is not None or self.event.query()
+
+        def result(self):
+            if self._result is None:
+                self.event.synchronize()
+                out, ids, counts = (t.numpy() for t in self.host)
+                self._result = self.owner._annotations_from_host(out, ids, counts[:self.n_images])
+                self.owner.last_decoder_time = time.perf_counter() - self.t_submit
+                if self.owner._lane_pending.get(self.lane) is self:
+                    del self.owner._lane_pending[self.lane]
+            return self._result
+
+    def _annotations_from_host(self, out, ids, counts):
+        native.check_counts(counts)                 # a watchdog failure raises instead of decoding to "no poses"
+        result = []
+        for b in range(len(counts)):
+            n = int(counts[b]) & native.COUNT_ROWS_MASK           # valid rows
+            if int(counts[b]) & native.COUNT_OVERFLOW:
+                LOG.warning('image %d: annotations dropped for lack of capacity (raise --cifcaf-max-annotations)', b)
+            result.append(self._annotations_py(out[b, :n], ids[b, :n]))
+        return result
+
+    def batch_async(self, model, image_batch, *, device=None, meta_batch=None):
+        """Like :meth:`batch`, but returns at once with a :class:`Pending`: the network is queued on the current
+        stream, the decode (+ the inverse transform with ``meta_batch``) on the next lane's stream behind it, the
+        annotations travel to pinned host memory on that stream.  Submit batch *i+1* before asking for batch *i*'s
+        ``result()`` and the two overlap; up to ``decoder_workers`` batches may be in flight (submitting to a lane
+        whose previous batch was not collected yet collects it first: host buffers are per lane)."""
+        t0 = time.perf_counter()
+        lanes = self._decode_lanes()
+        with torch.no_grad():
+            if device is not None:
+                image_batch = image_batch.to(device, non_blocking=True)
+            heads = model(image_batch)
+        cif, caf = heads[self.cif_metas[0].head_index], heads[self.caf_metas[0].head_index]
+        lane = lanes._next
+        stale = self._lane_pending.get(lane)
+        if stale is not None:
+            stale.result()
+        ticket = lanes.submit(cif, self.cif_metas[0].stride, caf, self.caf_metas[0].stride)
+        stream = lanes.streams[lane]
+        B = cif.shape[0]
+        key = (lane, B)
+        host = self._lane_host.get(key)
+        if host is None:
+            K = len(self.cif_metas[0].keypoints)
+            host = (torch.empty((B, self.max_annotations, K, 4), dtype=torch.float32).pin_memory(),
+                    torch.empty((B, self.max_annotations), dtype=torch.int64).pin_memory(),
+                    torch.empty((B,), dtype=torch.int32).pin_memory())
+            self._lane_host = {k: v for k, v in self._lane_host.items() if k[0] != lane}
+            self._lane_host[key] = host
+        with torch.cuda.stream(stream):
+            out, ids, counts = ticket.tensors                     # produced on this stream: no wait needed
+            if meta_batch is not None:
+                from .annotation import inverse_transform_batch
+                out = inverse_transform_batch(out, meta_batch)
+            host[0].copy_(out, non_blocking=True)
+            host[1].copy_(ids, non_blocking=True)
+            host[2].copy_(counts, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(stream)
+        self.last_nn_time = time.perf_counter() - t0               # host time to queue the network (it runs asynchronously)
+        pending = CifCaf.Pending(self, lane, done, host, B, t0)
+        self._lane_pending[lane] = pending
+        return pending
+
     def batch(self, model, image_batch, *, device=None, gt_anns_batch=None, meta_batch=None):
         """Image batch -> annotations batch, fields never leave the device.  With ``meta_batch`` (the metas of the
         preprocessing, no rotation) the annotations come back in ORIGINAL-image coordinates: the inverse transform
@@ -246,13 +339,7 @@ class CifCaf(Decoder):
             from .annotation import inverse_transform_batch
             out = inverse_transform_batch(out, meta_batch)
         out, ids, counts = out.cpu().numpy(), ids.cpu().numpy(), counts.cpu().numpy()   # one small D2H
-        native.check_counts(counts)                 # a watchdog failure raises instead of decoding to "no poses"
-        result = []
-        for b in range(len(counts)):
-            n = int(counts[b]) & native.COUNT_ROWS_MASK           # valid rows
-            if int(counts[b]) & native.COUNT_OVERFLOW:
-                LOG.warning('image %d: annotations dropped for lack of capacity (raise --cifcaf-max-annotations)', b)
-            result.append(self._annotations_py(out[b, :n], ids[b, :n]))
+        result = self._annotations_from_host(out, ids, counts)
         self.last_decoder_time = time.perf_counter() - start_decoder
         LOG.debug('time: nn = %.1fms, dec = %.1fms', self.last_nn_time * 1e3, self.last_decoder_time * 1e3)
         return result
@@ -406,13 +493,28 @@ class Multi(Decoder):
             out += decoder(all_fields)
         return out
 
-    def batch(self, model, image_batch, *, device=None, gt_anns_batch=None):
+    def batch(self, model, image_batch, *, device=None, gt_anns_batch=None, meta_batch=None):
         if len(self.decoders) == 1:
-            res = self.decoders[0].batch(model, image_batch, device=device, gt_anns_batch=gt_anns_batch)
+            kw = {'meta_batch': meta_batch} if meta_batch is not None else {}
+            res = self.decoders[0].batch(model, image_batch, device=device, gt_anns_batch=gt_anns_batch, **kw)
             self.last_nn_time = self.decoders[0].last_nn_time
             self.last_decoder_time = self.decoders[0].last_decoder_time
             return res
         return super().batch(model, image_batch, device=device, gt_anns_batch=gt_anns_batch)
+
+    @property
+    def supports_device_inverse(self):
+        return len(self.decoders) == 1 and getattr(self.decoders[0], 'supports_device_inverse', False)
+
+    @property
+    def pipeline_depth(self):
+        """Batches that may be in flight through :meth:`batch_async` (0: the decoder has no asynchronous path)."""
+        if len(self.decoders) == 1 and hasattr(self.decoders[0], 'batch_async'):
+            return max(1, int(self.decoders[0].decoder_workers or 1))
+        return 0
+
+    def batch_async(self, model, image_batch, *, device=None, meta_batch=None):
+        return self.decoders[0].batch_async(model, image_batch, device=device, meta_batch=meta_batch)
 
 
 DECODERS = {CifCaf, CifCafDense, CifDet}        # + tracking.TrackingPose, which registers itself on import
@@ -436,7 +538,8 @@ def cli(parser, *, workers=None):
                        help='filter instances by score (default is 0.0 with --force-complete-pose '
                             'and {} otherwise)'.format(native.NMSKeypoints.get_instance_threshold()))
     group.add_argument('--decoder-workers', default=workers, type=int,
-                       help='accepted for compatibility; the device decodes whole batches')
+                       help='batches decoded at once: decode lanes (stream + workspace each) beside the next '
+                            'batch\'s network; default {}'.format(CifCaf.decoder_workers))
     group = parser.add_argument_group('CifCaf decoders')
     group.add_argument('--cif-th', default=native.CifHr.get_threshold(), type=float, help='cif threshold')
     group.add_argument('--caf-th', default=native.CafScored.get_default_score_th(), type=float,
@@ -457,6 +560,8 @@ def configure(args):
     native.CafScored.set_default_score_th(args.caf_th)
     native.NMSKeypoints.set_instance_threshold(args.instance_threshold)
     CifDet.instance_threshold = args.instance_threshold
+    if getattr(args, 'decoder_workers', None) is not None:      # reference decoder/factory.py:66-71 sizes its fork pool here
+        CifCaf.decoder_workers = max(1, int(args.decoder_workers))
     for dec in _with_tracking():
         dec.configure(args)
     from . import tracking

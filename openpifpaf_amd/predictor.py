@@ -210,6 +210,7 @@ def preprocess_batch_device(images, *, long_edge, device, fast=True):
 class Predictor:
     """Predict from various inputs with a common configuration."""
     device_preprocess = False      #: batch mode: rescale / pad / normalise on the device instead of with PIL
+    pipelined = True               #: overlap batch i's decode with batch i+1's preprocessing + network (decoder lanes)
     batch_size = 1
     device = torch.device('cuda') if torch.cuda.is_available() else torch.device('cpu')
     fast_rescaling = True          #: reference predictor.py:17 (False = --precise-rescaling, scipy zoom)
@@ -266,23 +267,19 @@ class Predictor:
                 return self.model(image_batch)
         return self.model(image_batch)
 
-    def tensor_batch(self, processed_image_batch, meta_batch=None):
-        """Predict from an already preprocessed ``[B,3,H,W]`` batch -> list (per image) of predictions."""
-        model = _CallModel(self._forward)
-        on_device = (meta_batch is not None and getattr(self.processor, 'supports_device_inverse', False)
-                     and self.device.type == 'cuda'
-                     and all((m.get('rotation') or {}).get('angle', 0.0) == 0.0 and not m.get('horizontal_swap')
-                             for m in meta_batch))
-        if on_device:            # pad / rescale / flip undone on the decoded tensor, before its one D2H copy
-            pred_batch = self.processor.batch(model, processed_image_batch, device=None, meta_batch=meta_batch)
-            meta_batch = [None] * len(pred_batch)
-        else:
-            pred_batch = self.processor.batch(model, processed_image_batch, device=None)
+    def _device_inverse(self, meta_batch):
+        """Can pad / rescale / flip be undone on the decoded tensor, before its one D2H copy?"""
+        return (meta_batch is not None and getattr(self.processor, 'supports_device_inverse', False)
+                and self.device.type == 'cuda'
+                and all((m.get('rotation') or {}).get('angle', 0.0) == 0.0 and not m.get('horizontal_swap')
+                        for m in meta_batch))
+
+    def _finish(self, pred_batch, meta_batch, n_images):
         self.last_decoder_time = self.processor.last_decoder_time
         self.last_nn_time = self.processor.last_nn_time
         self.total_decoder_time += self.last_decoder_time
         self.total_nn_time += self.last_nn_time
-        self.total_images += len(processed_image_batch)
+        self.total_images += n_images
         if meta_batch is None:
             meta_batch = [None] * len(pred_batch)
         out = []
@@ -293,18 +290,58 @@ class Predictor:
             out.append(pred)
         return out
 
-    def _images(self, images):
+    def tensor_batch(self, processed_image_batch, meta_batch=None):
+        """Predict from an already preprocessed ``[B,3,H,W]`` batch -> list (per image) of predictions."""
+        model = _CallModel(self._forward)
+        if self._device_inverse(meta_batch):   # pad / rescale / flip undone on the decoded tensor, before its one D2H copy
+            pred_batch = self.processor.batch(model, processed_image_batch, device=None, meta_batch=meta_batch)
+            meta_batch = [None] * len(pred_batch)
+        else:
+            pred_batch = self.processor.batch(model, processed_image_batch, device=None)
+        return self._finish(pred_batch, meta_batch, len(processed_image_batch))
+
+    def tensor_batch_async(self, processed_image_batch, meta_batch=None):
+        """``tensor_batch`` in two halves: queue network + decode now, collect later -> a callable returning what
+        ``tensor_batch`` returns.  Call it after submitting the NEXT batch and the two overlap (the reference overlaps
+        them with ``--decoder-workers`` CPU processes, decoder/decoder.py:33-47)."""
+        model = _CallModel(self._forward)
+        n = len(processed_image_batch)
+        if self._device_inverse(meta_batch):
+            pending = self.processor.batch_async(model, processed_image_batch, device=None, meta_batch=meta_batch)
+            meta_batch = [None] * n
+        else:
+            pending = self.processor.batch_async(model, processed_image_batch, device=None)
+        return lambda: self._finish(pending.result(), meta_batch, n)
+
+    def _preprocess(self, images):
         batch_mode = self.batch_size > 1
+        if batch_mode and self.device_preprocess and self.device.type == 'cuda':
+            return preprocess_batch_device(images, long_edge=self.long_edge, device=self.device, fast=self.fast_rescaling)
+        items = [preprocess_image(im, long_edge=self.long_edge, batch_mode=batch_mode, fast=self.fast_rescaling)
+                 for im in images]
+        return torch.stack([t for t, _ in items]), [m for _, m in items]
+
+    def _images(self, images):
+        """Batches of ``batch_size`` images -> (pred, gt, meta) per image, in order.  With an asynchronous decoder
+        (``CifCaf.batch_async``) the batches are pipelined: batch i+1 is preprocessed and queued while batch i decodes;
+        at most ``pipeline_depth`` (= ``--decoder-workers``) batches are in flight."""
+        depth = getattr(self.processor, 'pipeline_depth', 0) if self.device.type == 'cuda' and self.pipelined else 0
+        if depth < 1:
+            for i in range(0, len(images), self.batch_size):
+                batch, metas = self._preprocess(images[i:i + self.batch_size])
+                for pred, meta in zip(self.tensor_batch(batch, metas), metas):
+                    yield pred, [], meta
+            return
+        in_flight = []                                  # (collect, metas), oldest first
         for i in range(0, len(images), self.batch_size):
-            if batch_mode and self.device_preprocess and self.device.type == 'cuda':
-                batch, metas = preprocess_batch_device(images[i:i + self.batch_size], long_edge=self.long_edge,
-                                                       device=self.device, fast=self.fast_rescaling)
-            else:
-                items = [preprocess_image(im, long_edge=self.long_edge, batch_mode=batch_mode, fast=self.fast_rescaling)
-                         for im in images[i:i + self.batch_size]]
-                batch = torch.stack([t for t, _ in items])
-                metas = [m for _, m in items]
-            for pred, meta in zip(self.tensor_batch(batch, metas), metas):
+            if len(in_flight) >= depth:                 # every lane is taken: the oldest batch's result first
+                collect, m = in_flight.pop(0)
+                for pred, meta in zip(collect(), m):
+                    yield pred, [], meta
+            batch, metas = self._preprocess(images[i:i + self.batch_size])
+            in_flight.append((self.tensor_batch_async(batch, metas), metas))
+        for collect, m in in_flight:
+            for pred, meta in zip(collect(), m):
                 yield pred, [], meta
 
     def numpy_images(self, numpy_images):

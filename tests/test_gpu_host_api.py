@@ -160,3 +160,91 @@ def test_predictor_with_device_side_preprocessing():
         assert len(pred_d) == len(pred_h)
         for a_d, a_h in zip(pred_d, pred_h):
             assert np.allclose(a_d.data, a_h.data, rtol=0, atol=1e-4) and np.allclose(a_d.joint_scales, a_h.joint_scales, atol=1e-4)
+
+
+def test_pipelined_batches_equal_synchronous_ones_and_the_oracle(coco_skeleton0):
+    """decoder.CifCaf.batch_async / --decoder-workers: several batches in flight over decode lanes
+    (stream + workspace each), annotations through pinned memory.  Every batch must come back as the synchronous
+    ``batch`` returns it and as the oracle decodes the same fields -- whatever the order in which the results are
+    collected, with 1, 2 and 3 lanes, with and without the device-side inverse transform."""
+    from openpifpaf_amd import decoder, headmeta, synth
+    from oracle import port
+    batches = [synth.synth_batch(3, seed0=900 + 10 * i, height=41, width=41, people=(1 + i, 5, 2), size_range=(0.6, 0.95))
+               for i in range(5)]
+
+    class FieldModel:                       # emits the field batch the images name (their first value)
+        def __call__(self, images):
+            i = int(images[0, 0, 0, 0].item())
+            return (torch.from_numpy(batches[i][0]).cuda(), torch.from_numpy(batches[i][1]).cuda())
+
+    def images(i):
+        return torch.full((3, 3, 321, 321), float(i))
+
+    def as_rows(result):
+        return [[(a.data.copy(), a.joint_scales.copy()) for a in anns] for anns in result]
+
+    metas = [{'offset': np.array([3.0, -2.0]), 'scale': np.array([0.5, 0.5]), 'hflip': False, 'width_height': np.array([640, 640])}
+             for _ in range(3)]
+    old = decoder.CifCaf.decoder_workers
+    try:
+        for workers in (1, 2, 3):
+            decoder.CifCaf.decoder_workers = workers
+            dec = decoder.factory(list(headmeta.cocokp_metas()))
+            assert dec.pipeline_depth == workers
+            sync = [as_rows(dec.batch(FieldModel(), images(i), device=torch.device('cuda'))) for i in range(5)]
+            for i in range(5):
+                for b in range(3):
+                    want, _ = port.decode(batches[i][0][b], 8, batches[i][1][b], 8, coco_skeleton0)
+                    assert len(sync[i][b]) == len(want) >= 1
+                    for (data, scales), w in zip(sync[i][b], want):
+                        assert np.allclose(data[:, :2], w[:, 1:3], atol=1e-4) and np.allclose(data[:, 2], w[:, 0], atol=1e-4)
+            # in flight: as many as there are lanes, collected oldest first
+            pend, got = [], {}
+            for i in range(5):
+                if len(pend) >= workers:
+                    j, p = pend.pop(0)
+                    got[j] = as_rows(p.result())
+                pend.append((i, dec.batch_async(FieldModel(), images(i), device=torch.device('cuda'))))
+            for j, p in reversed(pend):      # the rest, newest first
+                got[j] = as_rows(p.result())
+            for i in range(5):
+                assert len(got[i]) == 3
+                for b in range(3):
+                    assert len(got[i][b]) == len(sync[i][b])
+                    for (d0, s0), (d1, s1) in zip(got[i][b], sync[i][b]):
+                        assert np.array_equal(d0, d1) and np.array_equal(s0, s1), (workers, i, b)
+            # a lane that is submitted to again before its batch was collected keeps that batch's result
+            first = dec.batch_async(FieldModel(), images(0), device=torch.device('cuda'))
+            later = [dec.batch_async(FieldModel(), images(1 + k), device=torch.device('cuda')) for k in range(workers)]
+            assert [len(r) for r in first.result()] == [len(r) for r in sync[0]]
+            for k, p in enumerate(later):
+                assert [len(r) for r in p.result()] == [len(r) for r in sync[1 + k]]
+            # with the metas of the preprocessing: the inverse transform runs on the lane as well
+            a = as_rows(dec.batch(FieldModel(), images(2), device=torch.device('cuda'), meta_batch=metas))
+            b_ = as_rows(dec.batch_async(FieldModel(), images(2), device=torch.device('cuda'), meta_batch=metas).result())
+            assert len(a) == len(b_) == 3
+            for x, y in zip(a, b_):
+                for (d0, s0), (d1, s1) in zip(x, y):
+                    assert np.array_equal(d0, d1) and np.array_equal(s0, s1)
+    finally:
+        decoder.CifCaf.decoder_workers = old
+
+
+def test_pipelined_predictor_equals_the_synchronous_one():
+    """Predictor._images pipelines its batches through the decoder's lanes by default; the predictions are the ones the
+    synchronous loop gives (same network, same kernels, other streams)."""
+    from openpifpaf_amd import Predictor
+    Predictor.long_edge, Predictor.batch_size = 193, 2
+    try:
+        pred = Predictor('resnet18', json_data=True)
+        rng = np.random.default_rng(5)
+        images = [(rng.random((150 + 10 * k, 200, 3)) * 255).astype(np.uint8) for k in range(7)]
+        pred.pipelined = False
+        want = list(pred.numpy_images(images))
+        pred.pipelined = True
+        got = list(pred.numpy_images(images))
+        assert len(got) == len(want) == 7 and pred.total_images == 14
+        for (g, _, gm), (w, _, wm) in zip(got, want):
+            assert g == w and np.array_equal(gm['offset'], wm['offset'])
+    finally:
+        Predictor.long_edge, Predictor.batch_size = None, 1

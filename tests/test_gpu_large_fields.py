@@ -1,0 +1,125 @@
+"""Fields larger than the BASELINE's 641 px (missing 3): the reference takes any ``--long-edge``
+(predictor.py:85-102); at 1281 px the fields are 161 x 161.  What changes with the size and is not exercised by the
+COCO shapes: a key array of more than 2^17 entries, more than 256 tiles per CifHr plane (861 here), more than 8192 seeds
+per image (the rank merge over several sort blocks and, with equal scores, the tie pass on arrays in global memory),
+lists of more than 100 chunks, occupancy maps wider than 512 cells.  Every stage bit-exact against the oracle, the decode
+within the north-star tolerance, default flags and the reference benchmark's force-complete setting."""
+import numpy as np
+import pytest
+
+from common import compare_annotations, to_bf16
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip('torch')
+
+FC_KW = dict(force_complete=1, keypoint_threshold=0.0, keypoint_threshold_rel=0.0,
+             nms_instance_threshold=0.0, nms_keypoint_threshold=0.0)       # reference decoder/cifcaf.py:180-185
+
+# (seed, people, H, W, person size range): 1281 x 1281 and 961 x 1281 (H x W) images
+LARGE = [(9001, 40, 161, 161, (0.2, 0.6)), (9002, 25, 121, 161, (0.3, 0.8)), (9004, 45, 161, 161, (0.35, 0.8)),
+         (9005, 90, 161, 161, (0.2, 0.5))]
+
+
+@pytest.fixture(scope='module')
+def native():
+    from openpifpaf_amd import native as n
+    assert torch.cuda.is_available(), 'GPU tests need a HIP device'
+    return n
+
+
+@pytest.fixture(scope='module')
+def port():
+    from oracle import port as p
+    return p
+
+
+_cache = {}
+
+
+def fields(case):
+    from openpifpaf_amd import synth
+    if case not in _cache:
+        seed, people, H, W, sr = case
+        _cache[case] = synth.synth_fields(seed, people, height=H, width=W, size_range=sr)
+    return _cache[case]
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize('case', LARGE[:3])
+def test_large_field_stages_are_bit_exact(native, port, coco_skeleton0, case):
+    cif, caf = fields(case)
+    H, W = cif.shape[-2:]
+    assert ((H - 1) * 8 + 1 + 31) // 32 * (((W - 1) * 8 + 1 + 63) // 64) > 256        # tiles per plane
+    ref_hr = port.cifhr_accumulate(cif, 8)
+    hr = native.CifHr()
+    hr.accumulate(dev(cif), 8)
+    got = hr.get_accumulated()[0].cpu().numpy()
+    assert got.shape == ref_hr.shape and np.array_equal(got, ref_hr), '%d map cells differ' % (got != ref_hr).sum()
+    ref_f, ref_v = port.cifseeds(cif, 8, ref_hr)
+    seeds = native.CifSeeds(hr)
+    seeds.fill(dev(cif), 8)
+    f, v = seeds.get()
+    f, v = f.cpu().numpy(), v.cpu().numpy()
+    assert len(f) == len(ref_f) > 2048                                             # more than one sort block
+    assert np.array_equal(f, ref_f) and np.array_equal(v, ref_v)                   # std::sort's order, ties included
+    ref_fw, ref_bw = port.cafscored(caf, 8, ref_hr, cif.shape, 8, coco_skeleton0)
+    cs = native.CafScored(hr, cif.shape, 8)
+    cs.fill(dev(caf), 8, torch.from_numpy(coco_skeleton0))
+    fwd, bwd = cs.get()
+    for a in range(len(ref_fw)):
+        assert np.array_equal(fwd[a].cpu().numpy(), ref_fw[a]) and np.array_equal(bwd[a].cpu().numpy(), ref_bw[a]), a
+
+
+@pytest.mark.parametrize('fc', [False, True])
+def test_large_field_batch_decodes_like_the_oracle(native, port, coco_skeleton0, fc):
+    """Batches of 161 x 161 and of 121 x 161 fields through the C ABI's batched decode; one decoder per shape, called
+    twice with different images (the lazily cleared map of 861-tile planes carries over)."""
+    params_dev = None
+    params_ref = None
+    if fc:
+        from openpifpaf_amd import _lib
+        params_dev, params_ref = _lib.default_params(**FC_KW), port.default_params(**FC_KW)
+    poses = 0
+    for shape_cases in ([LARGE[0], LARGE[2], LARGE[3]], [LARGE[1]]):
+        dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+        for order in (shape_cases, shape_cases[::-1]):
+            cifs = np.stack([fields(c)[0] for c in order])
+            cafs = np.stack([fields(c)[1] for c in order])
+            out, ids, counts = dec.call_batch(dev(cifs), 8, dev(cafs), 8, params=params_dev)
+            out, counts = out.cpu().numpy(), counts.cpu().numpy()
+            native.check_counts(counts)
+            assert not native.count_overflowed(counts).any()
+            for b, c in enumerate(order):
+                want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0, params=params_ref)
+                ok, msg = compare_annotations(out[b, :native.count_rows(int(counts[b]))], want)
+                assert ok, 'case %s fc=%s: %s' % (c[:4], fc, msg)
+                poses += len(want)
+        n_seeds = dec.workspace_view('seed_count', torch.int32)[:len(order)].cpu().numpy()
+        assert n_seeds.max() > 2048
+    assert poses > 300
+
+
+def test_large_field_ties_in_global_memory(native, port, coco_skeleton0):
+    """bf16-rounded 161 x 161 fields: more than 8192 seeds per image, nearly all with tied scores -- the tie pass works on
+    arrays in global memory (an image beyond its LDS arrays) and must leave the seeds in std::sort's order."""
+    for case in (LARGE[2], LARGE[3]):
+        cif, caf = (to_bf16(a) for a in fields(case))
+        ref_hr = port.cifhr_accumulate(cif, 8)
+        ref_f, ref_v = port.cifseeds(cif, 8, ref_hr)
+        assert len(ref_f) > 8192 and len(np.unique(ref_v[:, 0])) < len(ref_v) // 2
+        hr = native.CifHr()
+        hr.accumulate(dev(cif), 8)
+        seeds = native.CifSeeds(hr)
+        seeds.fill(dev(cif), 8)
+        f, v = seeds.get()
+        assert np.array_equal(f.cpu().numpy(), ref_f) and np.array_equal(v.cpu().numpy(), ref_v)
+        dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+        got, _ = dec.call(dev(cif), 8, dev(caf), 8)
+        assert int(dec.workspace_view('seed_ties', torch.int32)[0]) == 1             # re-sorted in libstdc++'s order
+        want, _ = port.decode(cif, 8, caf, 8, coco_skeleton0)
+        ok, msg = compare_annotations(got.cpu().numpy(), want)
+        assert ok, msg
