@@ -79,6 +79,12 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// set bits of a ballot below this lane: v_mbcnt_lo / v_mbcnt_hi on the scalar mask -- no (1 << lane) - 1 pair held in
+// vector registers through the scans
+__device__ __forceinline__ int prefix_count(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
 // 7 SoA planes: c,x1,y1,x2,y2,s1,s2; `bbox` (LDS, or null): (xmin, xmax, ymin, ymax) of the (x1, y1) columns of the
 // list's first kListBboxChunks chunks of 64 entries (cafscored writes them, common.hpp)
 // `gbbox` (global memory, or null): the boxes of ALL chunks (up to `nb`) where cafscored wrote them
@@ -352,7 +358,6 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
         pos = lane;
     } else {
         float* cx = tgt + 3 * R * kWave; float* cy = cx + kWave; float* cv = cy + kWave; int* ci = (int*)(cv + kWave);   // behind the R chunks' targets
-        const unsigned long long below = (1ull << lane) - 1ull;
         int cnt = 0;
 #pragma unroll
         for (int r = 0; r < R; r++) {
@@ -360,7 +365,7 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
             const bool pass = i < L.n && passes_f(q, x1[r], y1[r]);
             const unsigned long long m = __ballot(pass);
             if (m == 0ull) continue;
-            const int slot = cnt + __popcll(m & below);
+            const int slot = cnt + prefix_count(m);
             // position among the chunks looked at: ascending like the list index, and where the targets landed
             if (pass && slot < kWave) { cx[slot] = x1[r]; cy[slot] = y1[r]; cv[slot] = cc[r]; ci[slot] = r * kWave + lane; }
             cnt += __popcll(m);
@@ -612,7 +617,6 @@ __device__ __forceinline__ BlendResult blend_compacted(const ListView& L, const 
     const int lane = lane_id();
     const gfloat* g = (const gfloat*)L.base;
     float* cx = tgt; float* cy = cx + kCompactCap; float* cv = cy + kCompactCap; int* ci_ = (int*)(cv + kCompactCap);
-    const unsigned long long below = (1ull << lane) - 1ull;
     int cnt = 0;
     {
         ChunkMask k = hit;
@@ -636,7 +640,7 @@ __device__ __forceinline__ BlendResult blend_compacted(const ListView& L, const 
                 const bool pass = ci[r] >= 0 && i < L.n && passes_f(q, x1[r], y1[r]);
                 const unsigned long long m = __ballot(pass);
                 if (m == 0ull) continue;
-                const int slot = cnt + __popcll(m & below);
+                const int slot = cnt + prefix_count(m);
                 if (pass && slot < kCompactCap) { cx[slot] = x1[r]; cy[slot] = y1[r]; cv[slot] = cc[r]; ci_[slot] = i; }
                 cnt += __popcll(m);
             }
@@ -1609,6 +1613,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         task[tid] = t;
     }
     if (tid < 12) sh_ctl[tid] = tid == 9 ? -1 : 0;   // (9: the grower holding the head seed)
+    if (tid < kAssocStats) sh_stats[tid] = 0;
 #ifdef OPA_ASSOC_PHASE_TIMING
     if (tid < kPhases) { g_ph[tid] = 0; g_phn[tid] = 0; }
     if (tid < 16) g_ph_last[tid] = clock64();
@@ -1677,9 +1682,12 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     const int32_t* seed_cell = a.seed_cell + (size_t)b * a.seed_cap;
 
     if (wave == 0) {
-        int st[kAssocStats];
-#pragma unroll
-        for (int k = 0; k < kAssocStats; k++) st[k] = 0;
+        // the always-on statistics live in LDS (lane 0 adds, no return value): two dozen scalar counters carried through this
+        // loop spill scalar registers into vector lanes, and the growers' scans pay for that
+        auto stat = [&](int k, int v) {
+            if (lane == 0) __hip_atomic_fetch_add(&sh_stats[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        int n_commits = 0;
         // ================================================================= coordinator
         // The pool: up to 512 LIVE, undecided seeds, 8 slots per lane in any order (mirrored in LDS for the
         // growers).  Invariant: every seed below scan_pos is either in a slot or dead for good (inside a box of
@@ -1700,19 +1708,11 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         unsigned unver = 0u;
         long long wait_ticks = 0;
         unsigned iter = 0;
-        const unsigned long long lanes_below = (1ull << lane) - 1ull;
         const bool is_grower_lane = lane >= 1 && lane <= S;
         __builtin_amdgcn_s_setprio(3);                   // everything sequential runs here: issue ahead of the growers
 #pragma unroll
         for (int r = 0; r < WR; r++) { s_pack[r] = 0; s_if[r] = kIdxMask; }
 
-        // slot r lies in the box candidate (pk, fo, idx) will occupy with its own seed joint, and comes later
-        auto in_blob = [&](int r, int pk, int fo, int idx) -> bool {
-            const int ccx = pk & 0xfff, ccy = (pk >> 12) & 0xfff, half = (pk >> 24) & 0xff;
-            const int dx = (s_pack[r] & 0xfff) - ccx, dy = ((s_pack[r] >> 12) & 0xfff) - ccy;
-            return (int)((unsigned)s_if[r] >> 24) == fo && (s_if[r] & kIdxMask) > idx &&
-                   dx > -half && dx < half && dy > -half && dy < half;
-        };
         // Seeds enter the pool through two dependent memory round trips (their field and cell, then the bitmap
         // word of that cell).  The first is taken off the refill: the (field, cell) of the next kSeedStage
         // seeds travel HBM/L2 -> LDS directly, in 64-seed blocks, issued after a refill and landed by the next.
@@ -1737,16 +1737,103 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             for (int r = 0; r < WR; r++) n_live += __popcll(__ballot((occupied >> r) & 1u));
         };
 
+        // the head = the smallest-index live seed (everything before it is decided), and the grower that has it
+        unsigned hd = kNone;
+        auto find_head = [&]() {
+            unsigned m = kNone;
+#pragma unroll
+            for (int r = 0; r < WR; r++)
+                if ((occupied >> r) & 1u) m = min(m, (unsigned)(s_if[r] & kIdxMask));
+            hd = ~wave_max_u32(~m);
+        };
+        auto head_grower = [&]() -> int {
+            int mine = -1;
+#pragma unroll
+            for (int r = 0; r < WR; r++)
+                if (((occupied & emitted) >> r) & 1u && (unsigned)(s_if[r] & kIdxMask) == hd) mine = (gmap >> (4 * r)) & 15;
+            const unsigned long long m = __ballot(mine >= 0);
+            return m ? rlane(mine, __builtin_ctzll(m)) : -1;
+        };
+        find_head();
+
         for (;;) {
             const long long t_iter = wall_clock64();
             if (t_iter - t_kernel > kWatchdogTicks) { watchdog = true; break; }
             iter++;
-            // ---- 1. the growers (lane g looks at grower g): state, cancel flag, seed, published boxes
-            int g_state = -1, g_cancel = 0, g_seed = -1, g_pub = 0, g_ack = 0;
+            bool progress = false;                       // this iteration committed, refilled or handed out something
+
+            // ---- 1. commit the head while its growth is done (:213-230): every commit of a run costs the commit alone,
+            //         not a round of the whole loop (a crowded image ends in dozens of poses of one or two joints)
+            int hg = hd == kNone ? -1 : head_grower();
+            while (hg >= 0 && flag_load(&task[hg].state) == kTaskDone) {
+                const long long t_cm = wall_clock64();
+                const PoseView q = pose_of_block(private_base, hg - 1, private_bytes, K);
+                unsigned dead = 0u;                      // pooled seeds inside one of its joint boxes (:211 for them)
+#pragma unroll
+                for (int r0 = 0; r0 < WR; r0 += 4) {     // four boxes per LDS round trip
+                    OccBox bb[4];
+#pragma unroll
+                    for (int r = 0; r < 4; r++) bb[r] = q.box[(occupied >> (r0 + r)) & 1u ? (unsigned)s_if[r0 + r] >> 24 : 0u];
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        if ((occupied >> (r0 + r)) & 1u &&
+                            (box_contains(bb[r], s_pack[r0 + r] & 0xfff, (s_pack[r0 + r] >> 12) & 0xfff) ||
+                             (unsigned)(s_if[r0 + r] & kIdxMask) == hd))
+                            dead |= 1u << (r0 + r);
+                }
+                if (__ballot((dead & emitted) != 0u) != 0ull) {   // growths of seeds that just died: drop finished ones, stop running ones
+                    int n_drop = 0, n_stop = 0;
+#pragma unroll
+                    for (int r = 0; r < WR; r++)
+                        if (((dead & emitted) >> r) & 1u && (unsigned)(s_if[r] & kIdxMask) != hd) {
+                            const int g = (gmap >> (4 * r)) & 15;
+                            if (flag_load(&task[g].state) == kTaskDone) { flag_store(&task[g].state, kTaskIdle); n_drop++; }
+                            else { flag_store(&task[g].cancel, 1); n_stop++; }
+                        }
+                    if (__ballot(n_drop + n_stop > 0) != 0ull) {
+#pragma unroll
+                        for (int k = 0; k < WR; k++) { stat(3, __popcll(__ballot(n_drop > k))); stat(2, __popcll(__ballot(n_stop > k))); }
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < WR; r++)
+                    if ((dead >> r) & 1u) {
+                        occupied &= ~(1u << r); emitted &= ~(1u << r); s_if[r] |= kIdxMask;
+                        pool_if[r * kWave + lane] = s_if[r];
+                    }
+                if (a.trace && n_commits < kAssocTrace && lane == 0) {
+                    int* tr = a.trace + ((size_t)b * kAssocTrace + n_commits) * 4;
+                    tr[0] = (int)(wall_clock64() - t_kernel); tr[1] = task[hg].t_emit; tr[2] = task[hg].t_done;
+                    tr[3] = (int)hd | (hg << 24);
+                }
+                {   // accepted: its grower marks the bitmap and stores the pose (cifcaf.cpp:225-230)
+                    const double score = task[hg].score;
+                    int slot = -1;
+                    if (!(prune && score < p.nms_instance_threshold)) {
+                        if (n_kept >= a.max_ann) n_dropped++;
+                        else slot = n_kept++;
+                    }
+                    if (lane == 0) task[hg].pad0 = slot;
+                    marks_pending = true;
+                }
+                n_commits++;
+                stat(1, 1);
+                wave_sync();                             // every lane has read block hg-1
+                if (lane == 0) flag_store(&task[hg].state, kTaskAccepted);
+                progress = true;
+                find_head();
+                hg = hd == kNone ? -1 : head_grower();
+                stat(17, (int)(wall_clock64() - t_cm));
+            }
+            if (progress) count_live();
+
+            // ---- 2. the growers (lane g looks at grower g): state, cancel flag, seed, published boxes
+            int g_state = -1, g_cancel = 0, g_seed = -1, g_pub = 0, g_ack = 0, g_pk = 0, g_f = -1;
             if (is_grower_lane) {
                 g_state = flag_load(&task[lane].state);
                 g_ack = flag_peek(&task[lane].pad1);
                 g_cancel = flag_peek(&task[lane].cancel); g_seed = task[lane].seed; g_pub = flag_peek(&task[lane].npub);
+                g_pk = task[lane].pk; g_f = task[lane].f;
                 if (g_state == kTaskDone && g_cancel) {  // a growth that finished after its seed died: drop the result
                     flag_store(&task[lane].state, kTaskIdle); g_state = kTaskIdle;
                 }
@@ -1755,7 +1842,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             const unsigned long long live_mask = __ballot(g_live);
             if (__ballot(unver != 0u) != 0ull && __ballot(g_live && g_ack != epoch) == 0ull) unver = 0u;   // everyone has tested the newcomers
 
-            // ---- 2. refill free slots with the next seeds that are still free in the bitmap (:211 for the
+            // ---- 3. refill free slots with the next seeds that are still free in the bitmap (:211 for the
             //         poses accepted so far); slot (r, lane) takes the seed of its rank among the free slots
             if (scan_pos < n_seeds && 2 * n_live < WR * kWave) {
                 const long long t_ph = wall_clock64();
@@ -1764,7 +1851,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                            wall_clock64() - t_kernel <= kWatchdogTicks)
                         __builtin_amdgcn_s_sleep(1);
                     marks_pending = false;
-                    st[20] += (int)(wall_clock64() - t_ph);
+                    stat(20, (int)(wall_clock64() - t_ph));
                 }
                 // this wave's marks (atomics, performed at L2) before its own reads, which bypass the L1 (agent-scope
                 // loads): vmcnt(0) is all it takes -- and the staged seeds have landed in LDS
@@ -1780,7 +1867,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     for (int r = 0; r < WR; r++) {
                         const bool fr = !((occupied >> r) & 1u);
                         const unsigned long long m = __ballot(fr);
-                        nidx[r] = fr ? scan_pos + base + __popcll(m & lanes_below) : n_seeds;
+                        nidx[r] = fr ? scan_pos + base + prefix_count(m) : n_seeds;
                         base += __popcll(m);
                     }
                     if (base == 0) break;
@@ -1850,13 +1937,13 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     }
                     if (__ballot(n_dup > 0) != 0ull) {
 #pragma unroll
-                        for (int k = 0; k < WR; k++) st[23] += __popcll(__ballot(n_dup > k));
+                        for (int k = 0; k < WR; k++) stat(23, __popcll(__ballot(n_dup > k)));
                     }
                     scan_pos = scan_pos + base < n_seeds ? scan_pos + base : n_seeds;
                     count_live();
                     if (2 * n_live >= WR * kWave) break;
                 }
-                st[6]++;
+                stat(6, 1);
                 stage_seeds();
                 // the new occupants: mirror them, forget what the growers said about the slots' former occupants, and
                 // have every candidate in flight test them against the boxes it has published (pool_catch_up)
@@ -1871,34 +1958,29 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 unver |= fresh;
                 wave_sync();
                 if (is_grower_lane) flag_store(&task[lane].epoch, epoch);
-                st[18] += (int)(wall_clock64() - t_ph);
+                stat(18, (int)(wall_clock64() - t_ph));
+                progress = true;
+                if (hd == kNone) { find_head(); hg = -1; }   // (newcomers come after everything pooled)
             }
 
-            // ---- 3. Which pooled seeds lie in a joint box an EARLIER live candidate has published so far?  (The
+            // ---- 4. Which pooled seeds lie in a joint box an EARLIER live candidate has published so far?  (The
             // growers test the mirrored pool against every box they publish.)  Such a seed dies if that candidate
             // is accepted: it is not handed out, and if it is being grown the growth is stopped and the seed waits
             // -- a prediction; should the candidate die instead, the seed is handed out again.
             unsigned shadow = 0u;
             {
-                unsigned w[NW];
+                {
+                    unsigned w[NW];
 #pragma unroll
-                for (int g = 1; g < NW; g++) w[g] = shadow_by[g * kWave + lane];
+                    for (int g = 1; g < NW; g++) w[g] = shadow_by[g * kWave + lane];
 #pragma unroll
-                for (int g = 1; g < NW; g++) shadow |= (live_mask >> g) & 1ull ? w[g] : 0u;
-                unsigned long long fresh_g = __ballot(g_live && g_pub == 0);   // own seed box not published yet: see step 4
-                while (fresh_g) {
-                    const int g = __builtin_ctzll(fresh_g);
-                    fresh_g &= fresh_g - 1;
-                    const int pk = task[g].pk, fo = task[g].f, idx = rlane(g_seed, g);
-#pragma unroll
-                    for (int r = 0; r < WR; r++)
-                        if ((occupied >> r) & 1u && in_blob(r, pk, fo, idx)) shadow |= 1u << r;
+                    for (int g = 1; g < NW; g++) shadow |= (live_mask >> g) & 1ull ? w[g] : 0u;
                 }
                 shadow &= occupied;
                 ever |= shadow;
                 const unsigned pc = shadow & emitted;    // growths of shadowed seeds stop; the seeds stay pooled
                 if (__ballot(pc != 0u) != 0ull) {
-                    int n_pc = 0;
+                    int n_pc = 0, d_sel = 0, h_sel = 0;
 #pragma unroll
                     for (int r = 0; r < WR; r++)
                         if ((pc >> r) & 1u) {
@@ -1907,80 +1989,96 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                                 flag_store(&task[g].cancel, 1);
                                 emitted &= ~(1u << r);
                                 n_pc++;
+                                d_sel = g;               // the stopped growth, and the (first) live candidate whose box holds its seed
+                                for (int h = NW - 1; h >= 1; h--)
+                                    if ((live_mask >> h) & 1ull && (shadow_by[h * kWave + lane] >> r) & 1u) h_sel = h;
                             }
                         }
 #pragma unroll
-                    for (int k = 0; k < WR; k++) st[4] += __popcll(__ballot(n_pc > k));
+                    for (int k = 0; k < WR; k++) stat(4, __popcll(__ballot(n_pc > k)));
+                    // The stopped growth D was growing the person candidate H is growing (its seed lies in a box of H): the
+                    // boxes D has published are, most likely, boxes H will publish.  H inherits D's predictions -- otherwise
+                    // they lapse with D, and the seeds they covered are handed out as the next duplicates of the same person.
+                    // (Advisory like every prediction: H's commit re-tests every seed against H's final boxes.)
+                    if (a.inherit) {
+                        unsigned long long m = __ballot(n_pc > 0 && h_sel > 0 && h_sel != d_sel);
+                        while (m) {
+                            const int l = __builtin_ctzll(m);
+                            m &= m - 1;
+                            const int d = rlane(d_sel, l), h = rlane(h_sel, l);
+                            const unsigned v = shadow_by[d * kWave + lane] & occupied;
+                            if (v) atomicOr(&shadow_by[h * kWave + lane], v);
+                            shadow |= v;
+                        }
+                        ever |= shadow;
+                    }
                 }
             }
 
-            // the head: the smallest-index live seed; everything before it is decided
-            unsigned hd = kNone;
-#pragma unroll
-            for (int r = 0; r < WR; r++)
-                if ((occupied >> r) & 1u) hd = min(hd, (unsigned)(s_if[r] & kIdxMask));
-            hd = ~wave_max_u32(~hd);
-
-            // ---- 4. hand the next candidates, in seed order, to the idle growers (newcomers the candidates in
+            // ---- 5. hand the next candidates, in seed order, to the idle growers (newcomers the candidates in
             //         flight have not tested yet wait for that -- except the head, which nothing can shadow)
             unsigned long long idle = __ballot(g_state == kTaskIdle);
-            const long long t_em = idle ? wall_clock64() : 0;
-            const bool had_idle = idle != 0ull;
-            while (idle) {
-                const unsigned elig = occupied & ~emitted & ~shadow;
-                unsigned mn = kNone;
+            if (idle) {
+                const long long t_em = wall_clock64();
+                // A candidate's own seed box is published by its grower a moment after the hand-out.  Until then (npub == 0)
+                // the coordinator stands in for it, on the side of the NEXT candidate: one test of that seed against the
+                // seed boxes of the unpublished candidates before it (lane g: grower g) instead of a sweep over the pool.
+                bool unp = g_live && g_pub == 0;
+                while (idle) {
+                    const unsigned elig = occupied & ~emitted & ~shadow;
+                    unsigned l_min = kNone; int l_r = 0, l_pk = 0, l_if = 0;
 #pragma unroll
-                for (int r = 0; r < WR; r++)
-                    if ((elig >> r) & 1u && (!((unver >> r) & 1u) || (unsigned)(s_if[r] & kIdxMask) == hd))
-                        mn = min(mn, (unsigned)(s_if[r] & kIdxMask));
-                mn = ~wave_max_u32(~mn);
-                if (mn == kNone) break;
-                const int g = __builtin_ctzll(idle);
-                idle &= idle - 1;
-                int pk = 0, fo = 0; bool own = false, was_shadowed = false;
-#pragma unroll
-                for (int r = 0; r < WR; r++)
-                    if (((elig >> r) & 1u) && (unsigned)(s_if[r] & kIdxMask) == mn) {
-                        pk = s_pack[r]; fo = (int)((unsigned)s_if[r] >> 24); own = true;
-                        was_shadowed = (ever >> r) & 1u; emitted |= 1u << r;
-                        gmap = (gmap & ~(15u << (4 * r))) | ((unsigned)g << (4 * r));
+                    for (int r = 0; r < WR; r++) {
+                        const unsigned idx = (unsigned)(s_if[r] & kIdxMask);
+                        if ((elig >> r) & 1u && (!((unver >> r) & 1u) || idx == hd) && idx < l_min) { l_min = idx; l_r = r; l_pk = s_pack[r]; l_if = s_if[r]; }
                     }
-                const int owner = __builtin_ctzll(__ballot(own));
-                pk = rlane(pk, owner); fo = rlane(fo, owner);
-                shadow_by[g * kWave + lane] = 0u;        // nothing published for this task yet
-                if (lane == 0) {
-                    task[g].seed = (int)mn; task[g].pk = pk; task[g].f = fo; task[g].npub = 0;
-                    task[g].t_emit = (int)(t_iter - t_kernel);
-                    flag_store(&task[g].cancel, 0);
+                    const unsigned mn = ~wave_max_u32(~l_min);
+                    if (mn == kNone) break;
+                    const bool own = l_min == mn;
+                    const int owner = __builtin_ctzll(__ballot(own));
+                    const int pk = rlane(l_pk, owner), fo = (int)((unsigned)rlane(l_if, owner) >> 24);
+                    {   // inside the seed box of an earlier candidate that has not published it yet?
+                        const int ccx = g_pk & 0xfff, ccy = (g_pk >> 12) & 0xfff, half = (g_pk >> 24) & 0xff;
+                        const int dx = (pk & 0xfff) - ccx, dy = ((pk >> 12) & 0xfff) - ccy;
+                        const bool hit = unp && g_f == fo && (unsigned)g_seed < mn && dx > -half && dx < half && dy > -half && dy < half;
+                        if (__ballot(hit) != 0ull) {
+                            if (own) { shadow |= 1u << l_r; ever |= 1u << l_r; }
+                            continue;
+                        }
+                    }
+                    const int g = __builtin_ctzll(idle);
+                    idle &= idle - 1;
+                    bool was_shadowed = false;
+                    if (own) {
+                        was_shadowed = (ever >> l_r) & 1u; emitted |= 1u << l_r;
+                        gmap = (gmap & ~(15u << (4 * l_r))) | ((unsigned)g << (4 * l_r));
+                    }
+                    shadow_by[g * kWave + lane] = 0u;    // nothing published for this task yet
+                    if (lane == 0) {
+                        task[g].seed = (int)mn; task[g].pk = pk; task[g].f = fo; task[g].npub = 0;
+                        task[g].t_emit = (int)(t_iter - t_kernel);
+                        flag_store(&task[g].cancel, 0);
+                    }
+                    wave_sync();
+                    if (lane == 0) flag_store(&task[g].state, kTaskAssigned);
+                    if (lane == g) { g_seed = (int)mn; g_pk = pk; g_f = fo; unp = true; }
+                    stat(0, 1);
+                    if (__ballot(was_shadowed) != 0ull) stat(5, 1);
+                    progress = true;
                 }
-                wave_sync();
-                if (lane == 0) flag_store(&task[g].state, kTaskAssigned);
-#pragma unroll
-                for (int r = 0; r < WR; r++)
-                    if ((occupied >> r) & 1u && in_blob(r, pk, fo, (int)mn)) { shadow |= 1u << r; ever |= 1u << r; }
-                st[0]++;
-                st[5] += __ballot(was_shadowed) != 0ull ? 1 : 0;
+                stat(19, (int)(wall_clock64() - t_em));
             }
-            if (had_idle) st[19] += (int)(wall_clock64() - t_em);
 
-            // ---- 5. commit the head when its growth is done
+            // ---- 6. what the next round waits for
             if (hd == kNone) {
                 if (scan_pos >= n_seeds) break;          // no live seed in the pool, none left to scan
                 continue;                                // pool ran empty: refill
             }
-            int hg = -1;                                 // the grower that has the head
-            {
-                int mine = -1;
-#pragma unroll
-                for (int r = 0; r < WR; r++)
-                    if (((occupied & emitted) >> r) & 1u && (unsigned)(s_if[r] & kIdxMask) == hd) mine = (gmap >> (4 * r)) & 15;
-                const unsigned long long m = __ballot(mine >= 0);
-                if (m) hg = rlane(mine, __builtin_ctzll(m));
-            }
+            if (hg < 0) hg = head_grower();
             if (hg != last_hg) { if (lane == 0) __hip_atomic_store(&sh_ctl[9], hg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); last_hg = hg; }
             if (hg < 0) {
                 // A head that was never handed out, or whose growth was stopped by a prediction that did not
-                // come true.  It is never shadowed (a live candidate shadowing it would be the head), so step 4
+                // come true.  It is never shadowed (a live candidate shadowing it would be the head), so step 5
                 // takes it as soon as a grower is idle.  If every grower holds or grows a LATER seed that
                 // none of the commits to come can free, the latest of them is given up.
                 const int vstate = is_grower_lane ? flag_load(&task[lane].state) : kTaskAssigned;
@@ -1998,70 +2096,14 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
 #pragma unroll
                 for (int r = 0; r < WR; r++)
                     if ((occupied >> r) & 1u && (s_if[r] & kIdxMask) == vseed) emitted &= ~(1u << r);
-                st[4]++;
+                stat(4, 1);
                 continue;
             }
-            if (flag_load(&task[hg].state) != kTaskDone) {
+            if (!progress && flag_load(&task[hg].state) != kTaskDone) {
                 __builtin_amdgcn_s_sleep(2);
                 wait_ticks += wall_clock64() - t_iter;   // an iteration that only waited for the head's growth
-                st[16]++;
-                continue;
+                stat(16, 1);
             }
-            const long long t_cm = wall_clock64();
-
-            // ---- 6. commit: the head's pose is accepted (:213-230)
-            const PoseView q = pose_of_block(private_base, hg - 1, private_bytes, K);
-            unsigned dead = 0u;                          // pooled seeds inside one of its joint boxes (:211 for them)
-            {
-                OccBox bb[WR];
-#pragma unroll
-                for (int r = 0; r < WR; r++) bb[r] = q.box[(occupied >> r) & 1u ? (unsigned)s_if[r] >> 24 : 0u];
-#pragma unroll
-                for (int r = 0; r < WR; r++)
-                    if ((occupied >> r) & 1u &&
-                        (box_contains(bb[r], s_pack[r] & 0xfff, (s_pack[r] >> 12) & 0xfff) || (unsigned)(s_if[r] & kIdxMask) == hd))
-                        dead |= 1u << r;
-            }
-            {   // growths of seeds that just died: drop finished ones, stop running ones
-                int n_drop = 0, n_stop = 0;
-#pragma unroll
-                for (int r = 0; r < WR; r++)
-                    if (((dead & emitted) >> r) & 1u && (unsigned)(s_if[r] & kIdxMask) != hd) {
-                        const int g = (gmap >> (4 * r)) & 15;
-                        if (flag_load(&task[g].state) == kTaskDone) { flag_store(&task[g].state, kTaskIdle); n_drop++; }
-                        else { flag_store(&task[g].cancel, 1); n_stop++; }
-                    }
-                if (__ballot(n_drop + n_stop > 0) != 0ull) {
-#pragma unroll
-                    for (int k = 0; k < WR; k++) { st[3] += __popcll(__ballot(n_drop > k)); st[2] += __popcll(__ballot(n_stop > k)); }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < WR; r++)
-                if ((dead >> r) & 1u) {
-                    occupied &= ~(1u << r); emitted &= ~(1u << r); s_if[r] |= kIdxMask;
-                    pool_if[r * kWave + lane] = s_if[r];
-                }
-            count_live();
-            if (a.trace && st[1] < kAssocTrace && lane == 0) {
-                int* tr = a.trace + ((size_t)b * kAssocTrace + st[1]) * 4;
-                tr[0] = (int)(wall_clock64() - t_kernel); tr[1] = task[hg].t_emit; tr[2] = task[hg].t_done;
-                tr[3] = (int)hd | (hg << 24);
-            }
-            {   // accepted: its grower marks the bitmap and stores the pose (cifcaf.cpp:225-230)
-                const double score = task[hg].score;
-                int slot = -1;
-                if (!(prune && score < p.nms_instance_threshold)) {
-                    if (n_kept >= a.max_ann) n_dropped++;
-                    else slot = n_kept++;
-                }
-                if (lane == 0) task[hg].pad0 = slot;
-                marks_pending = true;
-            }
-            st[1]++;
-            wave_sync();                                 // every lane has read block hg-1
-            if (lane == 0) flag_store(&task[hg].state, kTaskAccepted);
-            st[17] += (int)(wall_clock64() - t_cm);
         }
         // The last commit may still be in its grower's hands (ACCEPTED: marks + pose store).  A grower reads its
         // state once per polling round and then the exit flag: raised inside that window it would leave with the
@@ -2075,13 +2117,10 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             flag_store(&sh_ctl[0], 1);                   // growers leave
         }
         __builtin_amdgcn_s_setprio(0);
-        st[7] = n_seeds;
-        st[8] = (int)(wall_clock64() - t_kernel);
-        st[12] = (int)wait_ticks;
-        st[15] = (int)iter;
-        if (lane == 0)
-#pragma unroll
-            for (int k = 0; k < kAssocStats; k++) sh_stats[k] = st[k];
+        if (lane == 0) {
+            sh_stats[7] = n_seeds; sh_stats[8] = (int)(wall_clock64() - t_kernel);
+            sh_stats[12] = (int)wait_ticks; sh_stats[15] = (int)iter;
+        }
     } else if (wave <= S) {
         // ================================================================= grower
         TaskSlot* my = &task[wave];
@@ -2370,6 +2409,8 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     // when the map is reduced at all, occupancy.cpp:14-18: with reduction == 1 the box is the raw joint scale)
     a.dedup = (p.occupancy_reduction != 1.0 && p.occupancy_min_scale_reduced >= 1.0) ? 1 : 0;
     if (const char* e = getenv("OPA_ASSOC_DEDUP")) { if (atoi(e) == 0) a.dedup = 0; }   // A/B and tests: same result without it
+    a.inherit = 1;
+    if (const char* e = getenv("OPA_ASSOC_INHERIT")) a.inherit = atoi(e) != 0;     // A/B: predictions lapse with the growth that made them
     a.watchdog_ticks = kWatchdogTicksDefault;
     if (const char* e = getenv("OPA_ASSOC_WATCHDOG_TICKS")) { const long long v = atoll(e); if (v > 0) a.watchdog_ticks = v; }
     const int K = a.K, E = 2 * a.A;
