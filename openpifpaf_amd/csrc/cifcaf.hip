@@ -110,6 +110,8 @@ __device__ __forceinline__ void ph_stamp(int k) {
 #define PH(k)
 #endif
 
+extern __shared__ __attribute__((aligned(16))) unsigned char opa_dyn_lds[];   // every kernel's dynamic LDS starts here
+
 struct ImageCtx {
     int K, A, F;                         // F = occupancy fields = n_cif
     int wave;
@@ -754,6 +756,9 @@ __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, dou
 // A joint was assigned (cifcaf.cpp:310): during the seed pipeline the grower publishes the occupancy box the
 // joint WILL occupy if the pose is accepted, so that the coordinator can stop handing out -- and growing --
 // seeds this pose is going to cover (defined behind the occupancy helpers).
+// task slots of the growers (states, see the kernel)
+constexpr int kTaskIdle = 0, kTaskAssigned = 1, kTaskDone = 2, kTaskAccepted = 3;
+struct __attribute__((aligned(16))) TaskSlot { int state, seed, cancel, epoch, npub, pk, f, pad0; double score; int t_emit, t_done, pad1, coll; };
 __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s);
 __device__ __forceinline__ void pool_catch_up(ImageCtx& c, int e);
 // cancel flag and refill epoch of this grower's task slot, one LDS read
@@ -1215,6 +1220,7 @@ __device__ __forceinline__ bool box_contains(const OccBox& b, int xi, int yi) {
 constexpr int kPoolSlots = 8;             // seed-pool slots per coordinator lane
 constexpr int kSeedStage = 1024;          // seeds (field, cell) the coordinator keeps staged in LDS beyond its scan position (ring)
 constexpr int kDedupBits = 10;            // buckets (log2) of the coordinator's first-seed-of-a-cell table
+constexpr int kCommitRun = 4;             // commits per round of the coordinator before it looks at the idle growers again
 constexpr int kPoolIdxMask = 0xFFFFFF;    // seed index bits of a slot word (all ones: empty slot); field above
 
 __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s) {
@@ -1240,6 +1246,31 @@ __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, i
     if (bits) atomicOr(&c.shadow_mine[lane], bits);
     ++c.n_pub;
     if (lane == 0) { c.jbox[k] = b; *c.pub = c.n_pub; }
+    // A joint of mine inside the box an EARLIER live candidate has published for the same joint: the two growths are,
+    // most likely, growing the same person, and the earlier one decides first -- tell the coordinator (it stops this
+    // growth, keeps the seed pooled as predicted dead, and hands my predictions on to that candidate).  Advisory.
+    // (the task slots open the workgroup's dynamic LDS; where the growers' pose blocks lie, how many there are and whether
+    // the test is on: the two control words behind the head grower's, written once by the kernel)
+    const int cfg = c.head_g[2];
+    if (cfg >> 28) {
+        const TaskSlot* tasks = reinterpret_cast<const TaskSlot*>(opa_dyn_lds);
+        const unsigned char* blocks = opa_dyn_lds + c.head_g[1];
+        const int n_growers = (cfg >> 20) & 0xff, block_bytes = cfg & 0xfffff;
+        int cx, cy;
+        occ_xy(c, p, (double)x, (double)y, &cx, &cy);
+        unsigned key = 0xFFFFFFFFu;
+        if (lane >= 1 && lane <= n_growers && lane != c.wave) {
+            const int st = flag_peek(&tasks[lane].state), cn = flag_peek(&tasks[lane].cancel), sd = tasks[lane].seed;
+            if ((st == kTaskAssigned || st == kTaskDone) && !cn && sd < c.my_idx) {
+                const OccBox ob = reinterpret_cast<const OccBox*>(blocks + (size_t)(lane - 1) * block_bytes)[k];
+                if (box_contains(ob, cx, cy)) key = ((unsigned)sd << 6) | (unsigned)lane;
+            }
+        }
+        if (__ballot(key != 0xFFFFFFFFu) != 0ull) {
+            const unsigned first = ~wave_max_u32(~key);      // the earliest of them
+            if (lane == 0) flag_store(const_cast<int*>(&tasks[c.wave].coll), (int)(first & 63u));
+        }
+    }
 }
 
 // Seeds that entered the pool after this growth published a box were not there when publish_joint tested the pool:
@@ -1388,9 +1419,7 @@ __device__ __forceinline__ double pose_score(const double* v, int K) {
 // `cancel` was raised while it grew, IDLE.  Only the coordinator moves a slot out of DONE: to IDLE (result
 // dropped) or to ACCEPTED -- then the grower itself marks the pose's boxes in the bitmap and stores the pose at
 // scratch slot `pad0` (-1: not stored), off the coordinator's critical path, and returns to IDLE.
-constexpr int kTaskIdle = 0, kTaskAssigned = 1, kTaskDone = 2, kTaskAccepted = 3;
 // (`cancel` and `epoch` share an aligned 8 bytes: a grower polls both with one LDS read between frontier pops)
-struct __attribute__((aligned(16))) TaskSlot { int state, seed, cancel, epoch, npub, pk, f, pad0; double score; int t_emit, t_done, pad1, pad2; };
 constexpr int kAssocTrace = 64;           // commits recorded per image in the optional trace ("assoc_trace")
 
 // statistics of one image, int32[kAssocStats] in the workspace ("assoc_stats"): see include/openpifpaf_amd.h
@@ -1609,10 +1638,12 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     }
     if (tid < NW) {
         TaskSlot t; t.state = kTaskIdle; t.cancel = 0; t.epoch = 0; t.seed = -1; t.npub = 0; t.pk = 0; t.f = 0; t.score = 0.0;
-        t.t_emit = t.t_done = t.pad0 = t.pad1 = t.pad2 = 0;
+        t.t_emit = t.t_done = t.pad0 = t.pad1 = t.coll = 0;
         task[tid] = t;
     }
     if (tid < 12) sh_ctl[tid] = tid == 9 ? -1 : 0;   // (9: the grower holding the head seed)
+    if (tid == 10) sh_ctl[10] = (int)(private_base - smem);        // 10, 11: for publish_joint's look at the other growers' boxes
+    if (tid == 11) sh_ctl[11] = (int)private_bytes | (S << 20) | ((a.collide ? 1 : 0) << 28);
     if (tid < kAssocStats) sh_stats[tid] = 0;
 #ifdef OPA_ASSOC_PHASE_TIMING
     if (tid < kPhases) { g_ph[tid] = 0; g_phn[tid] = 0; }
@@ -1765,7 +1796,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             // ---- 1. commit the head while its growth is done (:213-230): every commit of a run costs the commit alone,
             //         not a round of the whole loop (a crowded image ends in dozens of poses of one or two joints)
             int hg = hd == kNone ? -1 : head_grower();
-            while (hg >= 0 && flag_load(&task[hg].state) == kTaskDone) {
+            for (int run = 0; run < kCommitRun && hg >= 0 && flag_load(&task[hg].state) == kTaskDone; run++) {
                 const long long t_cm = wall_clock64();
                 const PoseView q = pose_of_block(private_base, hg - 1, private_bytes, K);
                 unsigned dead = 0u;                      // pooled seeds inside one of its joint boxes (:211 for them)
@@ -1828,12 +1859,12 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             if (progress) count_live();
 
             // ---- 2. the growers (lane g looks at grower g): state, cancel flag, seed, published boxes
-            int g_state = -1, g_cancel = 0, g_seed = -1, g_pub = 0, g_ack = 0, g_pk = 0, g_f = -1;
+            int g_state = -1, g_cancel = 0, g_seed = -1, g_pub = 0, g_ack = 0, g_pk = 0, g_f = -1, g_coll = 0;
             if (is_grower_lane) {
                 g_state = flag_load(&task[lane].state);
                 g_ack = flag_peek(&task[lane].pad1);
                 g_cancel = flag_peek(&task[lane].cancel); g_seed = task[lane].seed; g_pub = flag_peek(&task[lane].npub);
-                g_pk = task[lane].pk; g_f = task[lane].f;
+                g_pk = task[lane].pk; g_f = task[lane].f; g_coll = flag_peek(&task[lane].coll);
                 if (g_state == kTaskDone && g_cancel) {  // a growth that finished after its seed died: drop the result
                     flag_store(&task[lane].state, kTaskIdle); g_state = kTaskIdle;
                 }
@@ -2015,6 +2046,31 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 }
             }
 
+            // ---- 4b. growths that ran into a joint box of an earlier live candidate (their grower says so: publish_joint):
+            //          stopped like the growths of shadowed seeds; the seed stays pooled, predicted dead with that candidate,
+            //          which also inherits what the stopped growth had predicted
+            {
+                unsigned long long cm = __ballot(g_live && g_state == kTaskAssigned && g_coll > 0 && g_coll != lane);
+                while (cm) {
+                    const int d = __builtin_ctzll(cm);
+                    cm &= cm - 1;
+                    const int h = rlane(g_coll, d);
+                    if (!((live_mask >> h) & 1ull) || rlane(g_seed, h) >= rlane(g_seed, d)) continue;   // (that candidate is gone)
+                    unsigned bit = 0u;
+#pragma unroll
+                    for (int r = 0; r < WR; r++)
+                        if (((occupied & emitted) >> r) & 1u && (int)((gmap >> (4 * r)) & 15) == d &&
+                            (s_if[r] & kIdxMask) == rlane(g_seed, d)) bit |= 1u << r;
+                    if (__ballot(bit != 0u) == 0ull) continue;
+                    if (lane == 0) flag_store(&task[d].cancel, 1);
+                    emitted &= ~bit;
+                    const unsigned v = (shadow_by[d * kWave + lane] & occupied) | bit;
+                    if (v) atomicOr(&shadow_by[h * kWave + lane], v);
+                    shadow |= v; ever |= v;
+                    stat(4, 1);
+                }
+            }
+
             // ---- 5. hand the next candidates, in seed order, to the idle growers (newcomers the candidates in
             //         flight have not tested yet wait for that -- except the head, which nothing can shadow)
             unsigned long long idle = __ballot(g_state == kTaskIdle);
@@ -2055,7 +2111,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     }
                     shadow_by[g * kWave + lane] = 0u;    // nothing published for this task yet
                     if (lane == 0) {
-                        task[g].seed = (int)mn; task[g].pk = pk; task[g].f = fo; task[g].npub = 0;
+                        task[g].seed = (int)mn; task[g].pk = pk; task[g].f = fo; task[g].npub = 0; task[g].coll = 0;
                         task[g].t_emit = (int)(t_iter - t_kernel);
                         flag_store(&task[g].cancel, 0);
                     }
@@ -2410,6 +2466,8 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     a.dedup = (p.occupancy_reduction != 1.0 && p.occupancy_min_scale_reduced >= 1.0) ? 1 : 0;
     if (const char* e = getenv("OPA_ASSOC_DEDUP")) { if (atoi(e) == 0) a.dedup = 0; }   // A/B and tests: same result without it
     a.inherit = 1;
+    a.collide = 1;
+    if (const char* e = getenv("OPA_ASSOC_COLLIDE")) a.collide = atoi(e) != 0;     // A/B: growths stop only when their SEED is covered
     if (const char* e = getenv("OPA_ASSOC_INHERIT")) a.inherit = atoi(e) != 0;     // A/B: predictions lapse with the growth that made them
     a.watchdog_ticks = kWatchdogTicksDefault;
     if (const char* e = getenv("OPA_ASSOC_WATCHDOG_TICKS")) { const long long v = atoll(e); if (v > 0) a.watchdog_ticks = v; }

@@ -150,6 +150,7 @@ struct AssocArgs {
     const float* list_bbox;  // [B][A][2][bbox_chunks][4] chunk boxes of `lists` (or null)
     const float* list_bbox_fc;  // ... of `lists_fc` (or null)
     int bbox_chunks;
+    int collide;                // 1: a growth that assigns a joint inside the same joint's box of an earlier live candidate is stopped (advisory)
     int inherit;                // 1: a candidate inherits the predictions of a growth stopped because of it (advisory; see cifcaf.hip)
     int dedup;                  // 1: later seeds of an occupancy cell already seen are dropped at the pool refill (exact; see cifcaf.hip)
     int32_t* fc_meta;           // [B, 4] seed kernel -> force-complete kernel: poses stored, dropped, failed, workgroup counter

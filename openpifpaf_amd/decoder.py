@@ -514,7 +514,16 @@ class Multi(Decoder):
         return 0
 
     def batch_async(self, model, image_batch, *, device=None, meta_batch=None):
-        return self.decoders[0].batch_async(model, image_batch, device=device, meta_batch=meta_batch)
+        inner = self.decoders[0]
+        pending = inner.batch_async(model, image_batch, device=device, meta_batch=meta_batch)
+        collect = pending.result
+
+        def result():                            # the times of the batch that was collected last, like batch()
+            out = collect()
+            self.last_nn_time, self.last_decoder_time = inner.last_nn_time, inner.last_decoder_time
+            return out
+        pending.result = result
+        return pending
 
 
 DECODERS = {CifCaf, CifCafDense, CifDet}        # + tracking.TrackingPose, which registers itself on import

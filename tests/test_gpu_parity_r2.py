@@ -138,21 +138,33 @@ def test_wrong_predictions_are_resolved(native, port, coco_skeleton0):
     cifs = np.stack([c for c, _ in cases]); cafs = np.stack([f for _, f in cases])
     want = [port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)[0] for b in range(len(cases))]
     totals = None
-    for growers in ('', '1', '3'):
-        if growers:
-            os.environ['OPA_ASSOC_GROWERS'] = growers
+    # round 4: a growth is also stopped when it assigns a joint inside an earlier candidate's box of that joint
+    # (OPA_ASSOC_COLLIDE) and a candidate inherits the predictions of the growths stopped because of it
+    # (OPA_ASSOC_INHERIT) -- predictions lapse far less often, so the lapse-and-hand-out-again branch is counted with both
+    # switched off; every setting must give the sequential loop's result
+    settings = [({}, None), ({'OPA_ASSOC_COLLIDE': '0', 'OPA_ASSOC_INHERIT': '0'}, None),
+                ({'OPA_ASSOC_COLLIDE': '0'}, None), ({'OPA_ASSOC_INHERIT': '0'}, None),
+                ({'OPA_ASSOC_GROWERS': '1'}, 1), ({'OPA_ASSOC_GROWERS': '3'}, 3)]
+    started = {}
+    for env, growers in settings:
+        os.environ.update(env)
         try:
             got, dec = _decode_all(native, coco_skeleton0, cifs, cafs)
             stats = dec.assoc_stats().cpu().numpy()
         finally:
-            os.environ.pop('OPA_ASSOC_GROWERS', None)
+            for k in env:
+                os.environ.pop(k, None)
         for b in range(len(cases)):
             ok, msg = compare_annotations(got[b], want[b])
-            assert ok, 'growers=%r image %d: %s' % (growers, b, msg)
-        if not growers:
-            totals = stats.sum(axis=0)
-        else:
-            assert (stats[:, 13] == int(growers)).all()
+            assert ok, 'setting %r image %d: %s' % (env, b, msg)
+        t = stats.sum(axis=0)
+        assert t[0] == t[1] + t[2] + t[3] + t[4], env
+        started[tuple(sorted(env.items()))] = int(t[0])
+        if env == {'OPA_ASSOC_COLLIDE': '0', 'OPA_ASSOC_INHERIT': '0'}:
+            totals = t
+        if growers:
+            assert (stats[:, 13] == growers).all()
+    print('growths started per setting:', started)
     print('growths started %d, accepted %d, stopped (seed died) %d, finished but dropped %d, stopped or given up on '
           'a prediction %d, handed out after a wrong prediction %d' % tuple(totals[:6]))
     assert totals[5] > 0, 'no wrong prediction occurred: the inputs no longer exercise that branch'
