@@ -60,6 +60,9 @@ namespace opa {
 
 constexpr int kAssocWavesDefault = 12;   // waves per workgroup of the association kernel (OPA_ASSOC_WAVES = 8 | 12 | 16)
 constexpr int kBlendChunks = 8;
+constexpr int kPoolSlots = 8;             // seed-pool slots per coordinator lane: skeletons whose growth state lives in register lanes
+constexpr int kPoolSlotsLds = 16;         // ... large skeletons (LDS variant): a person has a thousand seeds, the window must hold several people
+constexpr int kRefillSlots = 8;           // slots per lane one refill round fills (the round's arrays live in registers)
        // list entries per lane held in registers by the single-pass scan
 
 // LDS words shared between the coordinator and the growers: plain loads/stores made atomic at workgroup
@@ -759,9 +762,10 @@ __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, dou
 // task slots of the growers (states, see the kernel)
 constexpr int kTaskIdle = 0, kTaskAssigned = 1, kTaskDone = 2, kTaskAccepted = 3;
 struct __attribute__((aligned(16))) TaskSlot { int state, seed, cancel, epoch, npub, pk, f, pad0; double score; int t_emit, t_done, pad1, coll; };
-__device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s);
-__device__ __forceinline__ void pool_catch_up(ImageCtx& c, int e);
+template <int WR> __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s);
+template <int WR> __device__ __forceinline__ void pool_catch_up(ImageCtx& c, int e);
 // cancel flag and refill epoch of this grower's task slot, one LDS read
+template <int WR>
 __device__ __forceinline__ bool poll_task(ImageCtx& c) {
     if (!c.cancel) return false;
     const unsigned long long ce = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(c.cancel), __ATOMIC_RELAXED,
@@ -774,7 +778,7 @@ __device__ __forceinline__ bool poll_task(ImageCtx& c) {
         c.prio = want;
     }
     if ((int)ce) return true;
-    if (c.epoch && (int)(ce >> 32) != c.my_epoch) pool_catch_up(c, (int)(ce >> 32));
+    if (c.epoch && (int)(ce >> 32) != c.my_epoch) pool_catch_up<WR>(c, (int)(ce >> 32));
     return false;
 }
 
@@ -906,7 +910,7 @@ template <bool LONG>
 __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool reverse_match_, double filter_sigmas) {
     frontier_start(c);
     while (c.heap_n > 0) {
-        if (poll_task(c)) { c.aborted = 1; return; }                     // the seed died while its pose grew
+        if (poll_task<kPoolSlotsLds>(c)) { c.aborted = 1; return; }                     // the seed died while its pose grew
         const int slot = heap_pop(c);
         const int info = c.slot_info[slot];
         const int end = (info >> 8) & 0xff, bn = (info >> 16) & 0xff;
@@ -928,7 +932,7 @@ __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool rever
         }
         c.jv[end] = v; c.jx[end] = x; c.jy[end] = y; c.js[end] = s;     // :310
         PH(9);
-        publish_joint(c, p, end, x, y, s);
+        publish_joint<kPoolSlotsLds>(c, p, end, x, y, s);
         PH(10);
         frontier_add_from(c, end);
         PH(11);
@@ -1121,7 +1125,7 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
     reg_load_pose(c, R);
     reg_frontier_start(R, sk, c.K);
     while (R.heap_n > 0) {
-        if (poll_task(c)) { c.aborted = 1; return; }                         // the seed died while its pose grew
+        if (poll_task<kPoolSlots>(c)) { c.aborted = 1; return; }                         // the seed died while its pose grew
         const int slot = reg_heap_pop(R);
         const int info = rlane(sk.slot_info, slot);
         const int start = info & 0xff, end = (info >> 8) & 0xff;
@@ -1147,7 +1151,7 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
         }
         reg_set_joint(R, end, v, x, y, s);                                   // :310
         PH(9);
-        publish_joint(c, p, end, x, y, s);
+        publish_joint<kPoolSlots>(c, p, end, x, y, s);
         PH(10);
         reg_frontier_add_from(R, sk, end);
         PH(11);
@@ -1217,28 +1221,28 @@ __device__ __forceinline__ bool box_contains(const OccBox& b, int xi, int yi) {
     return xi >= b.minx && xi < b.maxx && yi >= b.miny && yi < b.maxy;
 }
 
-constexpr int kPoolSlots = 8;             // seed-pool slots per coordinator lane
 constexpr int kSeedStage = 1024;          // seeds (field, cell) the coordinator keeps staged in LDS beyond its scan position (ring)
 constexpr int kDedupBits = 10;            // buckets (log2) of the coordinator's first-seed-of-a-cell table
 constexpr int kCommitRun = 4;             // commits per round of the coordinator before it looks at the idle growers again
 constexpr int kPoolIdxMask = 0xFFFFFF;    // seed index bits of a slot word (all ones: empty slot); field above
 
+template <int WR>
 __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s) {
     if (!c.pub || k >= c.F) return;
     const OccBox b = occ_box(c, p, (double)x, (double)y, (double)s);
     const int lane = lane_id();
     // every pooled seed of this field that comes later in seed order and lies in the box is shadowed: it dies
     // if this pose is accepted.  Advisory only (the commit re-tests every seed against the final boxes).
-    int sif[kPoolSlots], spk[kPoolSlots];
+    int sif[WR], spk[WR];
 #pragma unroll
-    for (int r = 0; r < kPoolSlots; r++) { sif[r] = c.pool_if[r * kWave + lane]; spk[r] = c.pool_pack[r * kWave + lane]; }
+    for (int r = 0; r < WR; r++) { sif[r] = c.pool_if[r * kWave + lane]; spk[r] = c.pool_pack[r * kWave + lane]; }
     // field k, a seed index in (my_idx, empty): two unsigned compares on the packed word; inside the box: one unsigned
     // compare per axis (cell - min < extent)
     const unsigned lo = ((unsigned)k << 24) | (unsigned)c.my_idx, hi = ((unsigned)k << 24) | (unsigned)kPoolIdxMask;
     const unsigned ex = (unsigned)(b.maxx - b.minx), ey = (unsigned)(b.maxy - b.miny);
     unsigned bits = 0u;
 #pragma unroll
-    for (int r = 0; r < kPoolSlots; r++) {
+    for (int r = 0; r < WR; r++) {
         const unsigned w = (unsigned)sif[r];
         const unsigned dx = (unsigned)((spk[r] & 0xfff) - b.minx), dy = (unsigned)(((spk[r] >> 12) & 0xfff) - b.miny);
         if (w > lo && w < hi && dx < ex && dy < ey) bits |= 1u << r;
@@ -1276,6 +1280,7 @@ __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, i
 // Seeds that entered the pool after this growth published a box were not there when publish_joint tested the pool:
 // the coordinator bumps an epoch at every refill, and each candidate in flight tests the newcomers against ITS
 // boxes (published so far, or final) -- eleven waves in parallel instead of the coordinator alone -- and acknowledges.
+template <int WR>
 __device__ __forceinline__ void pool_catch_up(ImageCtx& c, int e) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // (the epoch was read relaxed: the pool mirror written before it)
     const int lane = lane_id();
@@ -1283,7 +1288,7 @@ __device__ __forceinline__ void pool_catch_up(ImageCtx& c, int e) {
     // four slots at a time, straight-line: their twelve pool words are ONE LDS round trip, their four boxes a second one
     // (inside the `if`s of a per-slot loop the compiler waited for every load on its own: 24 round trips per call)
 #pragma unroll
-    for (int r0 = 0; r0 < kPoolSlots; r0 += 4) {
+    for (int r0 = 0; r0 < WR; r0 += 4) {
         int ep[4], sif[4], spk[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
@@ -1562,6 +1567,7 @@ template <bool REG, int NW>
 __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a, DevSkeleton sk, DevParams p,
                                                                      int n_growers, int nms_waves, int tgt_floats) {
     constexpr int kThreads = NW * kWave;
+    constexpr int WR = REG ? kPoolSlots : kPoolSlotsLds;     // seed-pool slots per coordinator lane
     const bool use_bbox = REG && a.list_bbox != nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int b = blockIdx.x, tid = threadIdx.x, lane = lane_id();
@@ -1598,9 +1604,9 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     int* sh_ctl = (int*)sp; sp += sizeof(int) * 12;  // 0 exit flag, 1 n_kept, 2 n_dropped, 3 grower ticks, 4 list scans, 5 watchdog,
                                                      // 6-7 scan timing (diagnostic builds), 8 refill epoch, 9 grower of the head seed
     int* sh_stats = (int*)sp; sp += sizeof(int) * kAssocStats;
-    int* pool_if = (int*)sp; sp += sizeof(int) * kPoolSlots * kWave;        // the coordinator's seed pool, mirrored for the growers
-    int* pool_pack = (int*)sp; sp += sizeof(int) * kPoolSlots * kWave;
-    int* pool_ep = (int*)sp; sp += sizeof(int) * kPoolSlots * kWave;
+    int* pool_if = (int*)sp; sp += sizeof(int) * WR * kWave;        // the coordinator's seed pool, mirrored for the growers
+    int* pool_pack = (int*)sp; sp += sizeof(int) * WR * kWave;
+    int* pool_ep = (int*)sp; sp += sizeof(int) * WR * kWave;
     unsigned* shadow_by = (unsigned*)sp; sp += sizeof(unsigned) * NW * kWave; // [grower][lane]: pool slots in its published boxes
     int* stage_f = (int*)sp; sp += sizeof(int) * kSeedStage;                // the next seeds' field and cell, staged ahead of the pool refill
     int* stage_pk = (int*)sp; sp += sizeof(int) * kSeedStage;
@@ -1649,7 +1655,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     if (tid < kPhases) { g_ph[tid] = 0; g_phn[tid] = 0; }
     if (tid < 16) g_ph_last[tid] = clock64();
 #endif
-    for (int k = tid; k < kPoolSlots * kWave; k += kThreads) { pool_if[k] = kPoolIdxMask; pool_pack[k] = 0; pool_ep[k] = 0; }
+    for (int k = tid; k < WR * kWave; k += kThreads) { pool_if[k] = kPoolIdxMask; pool_pack[k] = 0; pool_ep[k] = 0; }
     for (int k = tid; k < NW * kWave; k += kThreads) shadow_by[k] = 0u;
     for (int k = tid; k < (1 << kDedupBits); k += kThreads) dedup[k] = ~0ull;
     const bool dedup_on = a.dedup != 0;
@@ -1724,14 +1730,22 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         // growers).  Invariant: every seed below scan_pos is either in a slot or dead for good (inside a box of
         // an accepted pose), so each seed is fetched and tested against the bitmap exactly once; afterwards it
         // is tested against every newly accepted pose by box containment.
-        constexpr int WR = kPoolSlots;                   // slots per lane
         constexpr int kIdxMask = kPoolIdxMask;
         constexpr unsigned kNone = 0xFFFFFFFFu;
         int s_pack[WR], s_if[WR];                        // cell x | cell y << 12 | box half-width << 24 ;  seed index | field << 24
         unsigned occupied = 0u;                          // bit r: slot r holds a live undecided seed
         unsigned emitted = 0u;                           //        ... handed to a grower (nibble r of gmap says which)
         unsigned ever = 0u;                              //        ... was shadowed at some time (statistics)
-        unsigned gmap = 0u;
+        unsigned gmap[(WR + 7) / 8];                     // nibble r: the grower slot r was handed to
+#pragma unroll
+        for (int k = 0; k < (WR + 7) / 8; k++) gmap[k] = 0u;
+        constexpr int HR = kRefillSlots;
+        auto gm_get = [&](int r) -> int { return (int)((gmap[r >> 3] >> (4 * (r & 7))) & 15u); };
+        auto gm_set = [&](int r, int g) {
+#pragma unroll
+            for (int k = 0; k < (WR + 7) / 8; k++)
+                if ((r >> 3) == k) gmap[k] = (gmap[k] & ~(15u << (4 * (r & 7)))) | ((unsigned)g << (4 * (r & 7)));
+        };
         int scan_pos = 0, n_live = 0;
         bool watchdog = false, marks_pending = false;
         int last_hg = -1;                                // what sh_ctl[9] says
@@ -1781,7 +1795,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             int mine = -1;
 #pragma unroll
             for (int r = 0; r < WR; r++)
-                if (((occupied & emitted) >> r) & 1u && (unsigned)(s_if[r] & kIdxMask) == hd) mine = (gmap >> (4 * r)) & 15;
+                if (((occupied & emitted) >> r) & 1u && (unsigned)(s_if[r] & kIdxMask) == hd) mine = gm_get(r);
             const unsigned long long m = __ballot(mine >= 0);
             return m ? rlane(mine, __builtin_ctzll(m)) : -1;
         };
@@ -1817,7 +1831,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
 #pragma unroll
                     for (int r = 0; r < WR; r++)
                         if (((dead & emitted) >> r) & 1u && (unsigned)(s_if[r] & kIdxMask) != hd) {
-                            const int g = (gmap >> (4 * r)) & 15;
+                            const int g = gm_get(r);
                             if (flag_load(&task[g].state) == kTaskDone) { flag_store(&task[g].state, kTaskIdle); n_drop++; }
                             else { flag_store(&task[g].cancel, 1); n_stop++; }
                         }
@@ -1890,41 +1904,47 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 wave_sync();
                 unsigned fresh = 0u;                     // slots filled by this refill
                 bool first_round = true;
+                int r0 = 0, dry = 0;                     // a round fills slots [r0, r0 + HR) of every lane; rounds without a free slot in a row
                 while (scan_pos < n_seeds) {
                     if (!first_round) __builtin_amdgcn_s_waitcnt(0x0F70);   // the cells marked by the round before are at the L2
                     first_round = false;
-                    int nidx[WR], base = 0;
+                    int nidx[HR], base = 0;
 #pragma unroll
-                    for (int r = 0; r < WR; r++) {
-                        const bool fr = !((occupied >> r) & 1u);
+                    for (int r = 0; r < HR; r++) {
+                        const bool fr = !((occupied >> (r0 + r)) & 1u);
                         const unsigned long long m = __ballot(fr);
                         nidx[r] = fr ? scan_pos + base + prefix_count(m) : n_seeds;
                         base += __popcll(m);
                     }
-                    if (base == 0) break;
+                    if (base == 0) {
+                        if (++dry >= WR / HR) break;
+                        if constexpr (WR > HR) r0 = r0 + HR < WR ? r0 + HR : 0;
+                        continue;
+                    }
+                    dry = 0;
                     // Straight-line code on clamped indices: the eight bitmap words of a lane are ONE memory round
                     // trip (loads inside `if`s are waited for one by one).
-                    int ff[WR], pk[WR]; unsigned ow[WR];
+                    int ff[HR], pk[HR]; unsigned ow[HR];
                     bool beyond = false;                 // a seed beyond the staged window (second round of a refill)
 #pragma unroll
-                    for (int r = 0; r < WR; r++) beyond |= nidx[r] >= pf_end && nidx[r] < n_seeds;
+                    for (int r = 0; r < HR; r++) beyond |= nidx[r] >= pf_end && nidx[r] < n_seeds;
                     if (__ballot(beyond) != 0ull) {
 #pragma unroll
-                        for (int r = 0; r < WR; r++) { const int ii = nidx[r] < n_seeds ? nidx[r] : 0; ff[r] = seed_f[ii]; pk[r] = seed_cell[ii]; }
+                        for (int r = 0; r < HR; r++) { const int ii = nidx[r] < n_seeds ? nidx[r] : 0; ff[r] = seed_f[ii]; pk[r] = seed_cell[ii]; }
 #pragma unroll
-                        for (int r = 0; r < WR; r++) asm volatile("" : "+v"(ff[r]), "+v"(pk[r]) :: "memory");
+                        for (int r = 0; r < HR; r++) asm volatile("" : "+v"(ff[r]), "+v"(pk[r]) :: "memory");
                     } else {
 #pragma unroll
-                        for (int r = 0; r < WR; r++) { ff[r] = stage_f[nidx[r] & (kSeedStage - 1)]; pk[r] = stage_pk[nidx[r] & (kSeedStage - 1)]; }
+                        for (int r = 0; r < HR; r++) { ff[r] = stage_f[nidx[r] & (kSeedStage - 1)]; pk[r] = stage_pk[nidx[r] & (kSeedStage - 1)]; }
                     }
 #pragma unroll
-                    for (int r = 0; r < WR; r++) {
+                    for (int r = 0; r < HR; r++) {
                         const bool valid = nidx[r] < n_seeds;
                         const size_t word = valid ? ((size_t)ff[r] * c.occ_h + ((pk[r] >> 12) & 0xfff)) * c.occ_wpr + ((pk[r] & 0xfff) >> 5) : 0;
                         ow[r] = __hip_atomic_load(&c.occ[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
 #pragma unroll
-                    for (int r = 0; r < WR; r++) asm volatile("" : "+v"(ow[r]) :: "memory");
+                    for (int r = 0; r < HR; r++) asm volatile("" : "+v"(ow[r]) :: "memory");
                     // Of the seeds of ONE occupancy cell of a field only the first can ever be free at its turn: if it is,
                     // its pose is accepted with the seed as joint f and the box of that joint contains the seed's own cell
                     // (occupancy.cpp:13-29: sigma >= 2 cells around it); if it is not, the box that covers its cell covers
@@ -1933,9 +1953,9 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     // same cell.  Each admitted seed therefore marks its own cell in the bitmap (the next refills test
                     // against it), and inside one refill round the first seed of a cell is found through a small LDS
                     // table (64-bit min of cell key << 32 | seed index; a bucket taken by another key just admits).
-                    bool cand[WR]; unsigned key[WR]; int bkt[WR];
+                    bool cand[HR]; unsigned key[HR]; int bkt[HR];
 #pragma unroll
-                    for (int r = 0; r < WR; r++) {
+                    for (int r = 0; r < HR; r++) {
                         cand[r] = nidx[r] < n_seeds && !((ow[r] >> (pk[r] & 31)) & 1u);
                         key[r] = ((unsigned)ff[r] << 24) | ((unsigned)pk[r] & 0xFFFFFFu);
                         bkt[r] = (int)((key[r] * 2654435761u) >> (32 - kDedupBits));
@@ -1944,21 +1964,24 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     wave_sync();
-                    unsigned long long seen[WR];
+                    unsigned long long seen[HR];
 #pragma unroll
-                    for (int r = 0; r < WR; r++) seen[r] = dedup[bkt[r]];
+                    for (int r = 0; r < HR; r++) seen[r] = dedup[bkt[r]];
 #pragma unroll
-                    for (int r = 0; r < WR; r++) asm volatile("" : "+v"(seen[r]) :: "memory");
+                    for (int r = 0; r < HR; r++) asm volatile("" : "+v"(seen[r]) :: "memory");
                     wave_sync();                         // every lane has read its buckets: give them back
 #pragma unroll
-                    for (int r = 0; r < WR; r++) if (cand[r] && dedup_on) dedup[bkt[r]] = ~0ull;
+                    for (int r = 0; r < HR; r++) if (cand[r] && dedup_on) dedup[bkt[r]] = ~0ull;
                     int n_dup = 0;
 #pragma unroll
-                    for (int r = 0; r < WR; r++) {
+                    for (int r = 0; r < HR; r++) {
                         const bool later = dedup_on && (unsigned)(seen[r] >> 32) == key[r] && (unsigned)seen[r] != (unsigned)nidx[r];
                         if (cand[r] && !later) {
-                            s_pack[r] = pk[r]; s_if[r] = nidx[r] | (ff[r] << 24);
-                            occupied |= 1u << r; emitted &= ~(1u << r); ever &= ~(1u << r); fresh |= 1u << r;
+                            const unsigned sb = 1u << (r0 + r);
+#pragma unroll
+                            for (int q = 0; q < WR; q += HR)     // (static register indices: the slot is r0 + r)
+                                if (q == r0) { s_pack[q + r] = pk[r]; s_if[q + r] = nidx[r] | (ff[r] << 24); }
+                            occupied |= sb; emitted &= ~sb; ever &= ~sb; fresh |= sb;
                             if (dedup_on) {
                                 const size_t word = ((size_t)ff[r] * c.occ_h + ((pk[r] >> 12) & 0xfff)) * c.occ_wpr + ((pk[r] & 0xfff) >> 5);
                                 atomicOr(&c.occ[word], 1u << (pk[r] & 31));
@@ -1968,11 +1991,12 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     }
                     if (__ballot(n_dup > 0) != 0ull) {
 #pragma unroll
-                        for (int k = 0; k < WR; k++) stat(23, __popcll(__ballot(n_dup > k)));
+                        for (int k = 0; k < HR; k++) stat(23, __popcll(__ballot(n_dup > k)));
                     }
                     scan_pos = scan_pos + base < n_seeds ? scan_pos + base : n_seeds;
                     count_live();
                     if (2 * n_live >= WR * kWave) break;
+                    if constexpr (WR > HR) r0 = r0 + HR < WR ? r0 + HR : 0;
                 }
                 stat(6, 1);
                 stage_seeds();
@@ -2015,7 +2039,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
 #pragma unroll
                     for (int r = 0; r < WR; r++)
                         if ((pc >> r) & 1u) {
-                            const int g = (gmap >> (4 * r)) & 15;
+                            const int g = gm_get(r);
                             if (flag_load(&task[g].state) == kTaskAssigned) {
                                 flag_store(&task[g].cancel, 1);
                                 emitted &= ~(1u << r);
@@ -2059,7 +2083,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     unsigned bit = 0u;
 #pragma unroll
                     for (int r = 0; r < WR; r++)
-                        if (((occupied & emitted) >> r) & 1u && (int)((gmap >> (4 * r)) & 15) == d &&
+                        if (((occupied & emitted) >> r) & 1u && gm_get(r) == d &&
                             (s_if[r] & kIdxMask) == rlane(g_seed, d)) bit |= 1u << r;
                     if (__ballot(bit != 0u) == 0ull) continue;
                     if (lane == 0) flag_store(&task[d].cancel, 1);
@@ -2107,7 +2131,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     bool was_shadowed = false;
                     if (own) {
                         was_shadowed = (ever >> l_r) & 1u; emitted |= 1u << l_r;
-                        gmap = (gmap & ~(15u << (4 * l_r))) | ((unsigned)g << (4 * l_r));
+                        gm_set(l_r, g);
                     }
                     shadow_by[g * kWave + lane] = 0u;    // nothing published for this task yet
                     if (lane == 0) {
@@ -2187,7 +2211,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             for (;;) {
                 const int state = flag_load(&my->state);
                 if (state == kTaskAssigned) break;
-                if (state == kTaskDone && c.epoch) { const int e = flag_load(c.epoch); if (e != c.my_epoch) pool_catch_up(c, e); }
+                if (state == kTaskDone && c.epoch) { const int e = flag_load(c.epoch); if (e != c.my_epoch) pool_catch_up<WR>(c, e); }
                 else c.epoch = nullptr;
                 if (state == kTaskAccepted) {            // the pose this wave grew was accepted: Occupancy::set + store
                     const PoseView q = pose_of_block(private_base, wave - 1, private_bytes, K);
@@ -2229,7 +2253,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             c.pool_ep = pool_ep; c.epoch = &my->epoch; c.ack = &my->pad1; c.head_g = &sh_ctl[9];
             c.my_epoch = flag_load(c.epoch);             // publish_joint tests the whole pool as of now; later refills: pool_catch_up
             if (lane == 0) flag_store(c.ack, c.my_epoch);
-            publish_joint(c, p, sf, sd.y, sd.z, sd.w);   // the seed joint's own box: the rest of its blob
+            publish_joint<WR>(c, p, sf, sd.y, sd.z, sd.w);   // the seed joint's own box: the rest of its blob
             PH(12);
             grow_pose<REG>(c, p, rs, true, 1.0, false);
             PH(13);
@@ -2404,7 +2428,7 @@ template <bool REG, int NW>
 static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
     const int K = a.K, A = a.A, E = 2 * A;
     size_t shared = sizeof(TaskSlot) * NW + (sizeof(unsigned long long) << kDedupBits) + sizeof(int) * (3 * E + K + 1 + 12 + kAssocStats)
-                  + sizeof(int) * (3 * kPoolSlots + NW) * kWave + sizeof(int) * 2 * kSeedStage;
+                  + sizeof(int) * (3 * (REG ? kPoolSlots : kPoolSlotsLds) + NW) * kWave + sizeof(int) * 2 * kSeedStage;
     shared = (shared + 15) / 16 * 16 + (REG && a.list_bbox ? sizeof(float4) * E * kListBboxChunks : 0);
     // work area behind it: one private block per grower while poses grow, the keypoint-NMS arrays afterwards
 #ifdef OPA_ASSOC_PHASE_TIMING

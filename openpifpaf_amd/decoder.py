@@ -504,7 +504,13 @@ class Multi(Decoder):
 
     @property
     def supports_device_inverse(self):
+        if getattr(self, '_device_inverse_override', None) is not None:
+            return self._device_inverse_override
         return len(self.decoders) == 1 and getattr(self.decoders[0], 'supports_device_inverse', False)
+
+    @supports_device_inverse.setter
+    def supports_device_inverse(self, value):
+        self._device_inverse_override = bool(value)
 
     @property
     def pipeline_depth(self):
