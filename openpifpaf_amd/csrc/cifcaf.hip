@@ -61,7 +61,9 @@ namespace opa {
 constexpr int kAssocWavesDefault = 12;   // waves per workgroup of the association kernel (OPA_ASSOC_WAVES = 8 | 12 | 16)
 constexpr int kBlendChunks = 8;
 constexpr int kPoolSlots = 8;             // seed-pool slots per coordinator lane: skeletons whose growth state lives in register lanes
-constexpr int kPoolSlotsLds = 16;         // ... large skeletons (LDS variant): a person has a thousand seeds, the window must hold several people
+constexpr int kPoolSlotsLds = 8;          // ... large skeletons (LDS variant).  16 (a person has a thousand seeds: a window of several people) was
+                                          // measured in round 4: the image it was meant for gained 15 %, the batch lost 4 % -- every published joint
+                                          // tests twice the slots, and the pool's LDS costs the eleventh grower
 constexpr int kRefillSlots = 8;           // slots per lane one refill round fills (the round's arrays live in registers)
        // list entries per lane held in registers by the single-pass scan
 

@@ -441,7 +441,6 @@ struct TieArgs {
                                                  // image beyond the LDS arrays
     unsigned char* small_; size_t small_stride;  // per image tie_small_bytes(F, HW): the fill kernel's block table, its prefix,
                                                  // segment lists
-    int sub_sort;                    // 1: segments of large images that fit the LDS arrays are finished there (A/B: OPA_TIE_SUBSORT=0)
     int32_t* tie_state;              // [B] or null: 0 no equal scores, 1 re-sorted in libstdc++'s order, -1 not reproduced
 };
 
@@ -769,50 +768,15 @@ __device__ __forceinline__ void tie_subtree(unsigned* BITS, unsigned* IDX, unsig
     }
 }
 
-// LDS arrays and segment lists the global-memory variant lends to tie_sub_sort
-struct TieSub { unsigned *bits, *idx, *lpos, *rpos; int2 *seg0, *seg1; unsigned* mark; int* next; };
-template <bool LDS>
-__device__ __forceinline__ void tie_levels(unsigned* BITS, unsigned* IDX, unsigned* LPOS, unsigned* RPOS, int2* cur, int2* nxt,
-                                           int n, int* s_next, int* s_fail, unsigned* mark, int* coop, int* stacks,
-                                           unsigned* areas, int depth0, TieSub* sub);
-
-// Segment [first, last) of an image in global memory, at most kTieLdsKeys elements, with `depth` levels left: into the
-// LDS arrays, every level below by the in-LDS loop, back, and the cuts it made into the image's marks.
-__device__ __forceinline__ void tie_sub_sort(unsigned* BITS, unsigned* IDX, int first, int last, int depth, unsigned* mark,
-                                             int* s_next_outer, int* s_fail, int* coop, int* stacks, TieSub* sub) {
-    const int tid = threadIdx.x, len = last - first;
-    const TieArr<false> gb = tie_arr<false>(BITS), gi = tie_arr<false>(IDX);
-    bool tied = false;
-    for (int j = tid; j < len; j += kTieThreads) { const unsigned d = gi(first + j); sub->bits[j] = gb(first + j); sub->idx[j] = d; tied |= (d & kTiedBit) != 0u; }
-    for (int w = tid; w < (len + 31) / 32; w += kTieThreads) sub->mark[w] = 0u;
-    if (tid == 0) *sub->next = 0;
-    const int any = __syncthreads_or(tied ? 1 : 0);
-    if (!any) return;                                              // nobody asks where its seeds end up
-    tie_levels<true>(sub->bits, sub->idx, sub->lpos, sub->rpos, sub->seg0, sub->seg1, len, sub->next, s_fail, sub->mark, coop, stacks,
-                     nullptr, depth, nullptr);
-    __syncthreads();
-    for (int j = tid; j < len; j += kTieThreads) { BITS[first + j] = sub->bits[j]; IDX[first + j] = sub->idx[j]; }
-    for (int w = tid; w < (len + 31) / 32; w += kTieThreads) {      // (bit 0 is the segment's own start: marked by its parent)
-        unsigned m = sub->mark[w];
-        while (m) {
-            const int bit = __builtin_ctz(m);
-            m &= m - 1;
-            const int c = first + w * 32 + bit;
-            atomicOr(&mark[c >> 5], 1u << (c & 31));
-        }
-    }
-    tie_group_sync<false>();
-}
-
 // __introsort_loop(0, n): the segments of one recursion level in `cur`, their children in `nxt`; one wave per segment.
 // `mark`: one bit per position, set where a partition cut its segment (and at 0): the segments of at most 16 elements
 // the loop leaves to the insertion sort lie between two marks.
 template <bool LDS>
 __device__ __forceinline__ void tie_levels(unsigned* BITS, unsigned* IDX, unsigned* LPOS, unsigned* RPOS, int2* cur, int2* nxt,
                                            int n, int* s_next, int* s_fail, unsigned* mark, int* coop, int* stacks,
-                                           unsigned* areas, int depth0, TieSub* sub) {
+                                           unsigned* areas) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int depth = depth0 >= 0 ? depth0 : 2 * (31 - __clz(n));        // std::__lg(n) * 2 (or what is left of it for a sub-segment)
+    int depth = 2 * (31 - __clz(n));                               // std::__lg(n) * 2
     int n_cur = 0;
     if (tid == 0) atomicOr(&mark[0], 1u);
     if (n > 16) { if (tid == 0) cur[0] = make_int2(0, n); n_cur = 1; }
@@ -825,20 +789,8 @@ __device__ __forceinline__ void tie_levels(unsigned* BITS, unsigned* IDX, unsign
             if (cut - sg.x > 16) nxt[atomicAdd(s_next, 1)] = make_int2(sg.x, cut);
             if (sg.y - cut > 16) nxt[atomicAdd(s_next, 1)] = make_int2(cut, sg.y);
         };
-        if constexpr (!LDS) {
-            // An image beyond the LDS arrays: once a segment fits them it is brought there and finished by the whole
-            // workgroup, all its levels (in global memory every step of a partition is an L2 round trip of one compute unit)
-            if (sub) {
-                for (int s = 0; s < n_cur; s++) {
-                    const int2 sg = cur[s];
-                    if (sg.y - sg.x > kTieLdsKeys) continue;
-                    tie_sub_sort(BITS, IDX, sg.x, sg.y, depth + 1, mark, s_next, s_fail, coop, stacks, sub);   // (its own depth limit: this level's)
-                }
-            }
-        }
         for (int s = 0; s < n_cur; s++) {                          // the long ones: the whole workgroup on each
             const int2 sg = cur[s];
-            if (!LDS && sub && sg.y - sg.x <= kTieLdsKeys) continue;
             if (sg.y - sg.x <= tie_coop_len<LDS>()) continue;
             const int cut = tie_partition_block<LDS>(BITS, IDX, LPOS, RPOS, sg.x, sg.y, coop);
             if (cut == -2) continue;
@@ -848,7 +800,6 @@ __device__ __forceinline__ void tie_levels(unsigned* BITS, unsigned* IDX, unsign
         int mine = 0;                                              // the others: one wave per segment
         for (int s = 0; s < n_cur; s++) {
             const int2 sg = cur[s];
-            if (!LDS && sub && sg.y - sg.x <= kTieLdsKeys) continue;
             if (sg.y - sg.x > tie_coop_len<LDS>()) continue;
             if ((mine++ % (kTieThreads / 64)) != wave) continue;
             if (sg.y - sg.x <= (LDS ? kTieSubtreeLds : kTieSubtree)) {   // short enough: this wave finishes it, all levels
@@ -872,7 +823,7 @@ __device__ __forceinline__ void tie_levels(unsigned* BITS, unsigned* IDX, unsign
 
 __global__ __launch_bounds__(kTieThreads) void cifseeds_tie_kernel(TieArgs a, SortArgs g, DevParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char tie_lds[];    // 128 KiB: four arrays of 8192 words
-    __shared__ int s_flag, s_next, s_fail, s_next_sub;
+    __shared__ int s_flag, s_next, s_fail;
     __shared__ int s_wave_tot[kTieThreads / 64];
     __shared__ int2 s_seg[2][kTieLdsKeys / 17 + 2];           // the two segment lists of an image that lives in LDS
     __shared__ unsigned s_mark[kTieLdsKeys / 32];
@@ -882,7 +833,6 @@ __global__ __launch_bounds__(kTieThreads) void cifseeds_tie_kernel(TieArgs a, So
     int n = g.seed_count[b];
     if (n > g.cap) n = g.cap;
     const bool in_lds = n <= kTieLdsKeys;
-    const bool tie_sub_enabled = a.sub_sort != 0;
     const int cells = a.cells;
     unsigned *BITS, *IDX, *LPOS, *RPOS;
     if (in_lds) {
@@ -1007,14 +957,8 @@ __global__ __launch_bounds__(kTieThreads) void cifseeds_tie_kernel(TieArgs a, So
     tie_group_sync_rt(in_lds);
 
     // ---- __introsort_loop, one level of the recursion at a time
-    if (in_lds) tie_levels<true>(BITS, IDX, LPOS, RPOS, s_seg[0], s_seg[1], n, &s_next, &s_fail, mark, s_coop, s_stack, nullptr, -1, nullptr);
-    else {
-        TieSub sub;                                                // (the tied-score list in this area has done its job)
-        sub.bits = (unsigned*)tie_lds; sub.idx = sub.bits + kTieLdsKeys; sub.lpos = sub.idx + kTieLdsKeys; sub.rpos = sub.lpos + kTieLdsKeys;
-        sub.seg0 = s_seg[0]; sub.seg1 = s_seg[1]; sub.mark = s_mark; sub.next = &s_next_sub;
-        tie_levels<false>(BITS, IDX, LPOS, RPOS, seg_a, seg_b, n, &s_next, &s_fail, mark, s_coop, s_stack, (unsigned*)tie_lds, -1,
-                          tie_sub_enabled ? &sub : nullptr);
-    }
+    if (in_lds) tie_levels<true>(BITS, IDX, LPOS, RPOS, s_seg[0], s_seg[1], n, &s_next, &s_fail, mark, s_coop, s_stack, nullptr);
+    else tie_levels<false>(BITS, IDX, LPOS, RPOS, seg_a, seg_b, n, &s_next, &s_fail, mark, s_coop, s_stack, (unsigned*)tie_lds);
     __syncthreads();
     if (s_fail) {                                                  // the seeds stay as the first sort left them
         if (tid == 0 && a.tie_state) a.tie_state[b] = -1;
@@ -1055,8 +999,6 @@ hipError_t launch_cifseeds_ties(unsigned long long* keys, int sort_cap, const in
     g.stride = stride; g.seed_f = seed_f; g.seed_vxys = seed_vxys; g.seed_cell = seed_cell; g.occ_h = occ_h; g.occ_w = occ_w;
     TieArgs a;
     a.cells = F * HW; a.big = big; a.big_stride = big_stride; a.small_ = small_; a.small_stride = small_stride; a.tie_state = tie_state;
-    a.sub_sort = 1;
-    if (const char* e = getenv("OPA_TIE_SUBSORT")) a.sub_sort = atoi(e) != 0;
     const int lds = 4 * kTieLdsKeys * (int)sizeof(unsigned);
     {   // (per device, not per process: set on every launch like the association kernel's)
         hipError_t e = hipFuncSetAttribute((const void*)cifseeds_tie_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -110,7 +110,7 @@ def test_large_field_ties_in_global_memory(native, port, coco_skeleton0):
         cif, caf = (to_bf16(a) for a in fields(case))
         ref_hr = port.cifhr_accumulate(cif, 8)
         ref_f, ref_v = port.cifseeds(cif, 8, ref_hr)
-        assert len(ref_f) > 8192 and len(np.unique(ref_v[:, 0])) < len(ref_v) // 2
+        assert len(ref_f) > 8192 and len(np.unique(ref_v[:, 0])) < len(ref_v) - 1000           # thousands of tied seeds
         hr = native.CifHr()
         hr.accumulate(dev(cif), 8)
         seeds = native.CifSeeds(hr)
