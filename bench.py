@@ -957,6 +957,92 @@ def main():
                             'algorithmic bytes of a batch x batches per second (wall clock, whole decode path)'}
         guarded('decode_two_in_flight', lanes_leg)
 
+        # the adversarial case (BASELINE.md 3 ii): structureless all-active fields, what a random-init head
+        # emits -- every cell passes every threshold.  Decode only, reported separately, with its own parity count.
+        def all_active_leg():
+            from openpifpaf_amd import synth
+            pairs = [synth.adversarial_fields(500 + i, height=wl.fh, width=wl.fh) for i in range(wl.B)]
+            cifs = np.stack([c for c, _ in pairs]); cafs = np.stack([f for _, f in pairs])
+            cif_d, caf_d = torch.from_numpy(cifs).to(device), torch.from_numpy(cafs).to(device)
+            variants = [(cifs, cafs, cif_d, caf_d)]
+            with torch.cuda.stream(dec_stream):
+                for _ in range(2):
+                    wl.dec.call_batch(cif_d, wl.stride, caf_d, wl.stride)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    out, ids, counts = wl.dec.call_batch(cif_d, wl.stride, caf_d, wl.stride)
+                torch.cuda.synchronize(device)
+                ms = (time.perf_counter() - t0) / 10 * 1e3
+                kernels = kernel_profile(wl, variants, None, 4)
+                par = None if args.no_parity else parity_stamp(
+                    lambda c, f: wl.dec.call_batch(c, wl.stride, f, wl.stride), variants, wl.skeleton0, wl.K)
+            seeds = wl.dec.workspace_view('seed_count', torch.int32)[:wl.B].cpu().numpy()
+            alg = algorithmic_bytes(wl.B, wl.K, wl.A, wl.fh, wl.fh, wl.stride, wl.dec.max_annotations)['decode_path']
+            return {'what': 'decode only: %d all-active %dx%d field pairs (synth.adversarial_fields: sigmoid(N(0,1)) confidences, '
+                            'every cell above every threshold)' % (wl.B, wl.fh, wl.fh),
+                    'decode_only_images_per_s': round(wl.B / (ms * 1e-3), 1), 'ms_per_batch_wall': round(ms, 3),
+                    'decode_ms': round(sum(kernels.values()), 4),
+                    'kernels_ms': {k: round(v, 4) for k, v in kernels.items()},
+                    'seeds_per_image': {'mean': float(seeds.mean()), 'max': int(seeds.max())},
+                    'roofline': {'frac': round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
+                    'parity': par}
+        guarded('all_active', all_active_leg)
+
+        # the product path: Predictor -> Decoder.batch_async over decode lanes (what a user of openpifpaf.predict gets), fed
+        # uint8 frames that are preprocessed on the device; the network runs for real, the decode sees the headline's
+        # synthetic fields (a random-init head's own output is the all-active case above)
+        def predictor_leg():
+            from openpifpaf_amd import Predictor, predictor as predictor_mod
+            net = build_model(wl, 'fp32')
+
+            class Injected(torch.nn.Module):
+                def __init__(self):
+                    super().__init__()
+                    self.net, self.head_metas, self.n = net, [wl.cif_meta, wl.caf_meta], 0
+
+                def forward(self, x):
+                    self.net(x)
+                    v = wl.variants[self.n % len(wl.variants)]
+                    self.n += 1
+                    return (v[2], v[3])
+            saved = (Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device)
+            Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device = wl.B, None, True, device
+            try:
+                pred = Predictor(model=Injected())
+                rng = np.random.default_rng(3)
+                frames = [rng.integers(0, 255, (args.long_edge, args.long_edge, 3), dtype=np.uint8) for _ in range(wl.B)]
+                n_batches = 8
+                out = {}
+                for mode, pipelined in (('pipelined', True), ('synchronous', False)):
+                    pred.pipelined = pipelined
+                    list(pred.numpy_images(frames * 2))                     # warm-up (lanes, pinned buffers)
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    n_ann = sum(len(p) for p, _, _ in pred.numpy_images(frames * n_batches))
+                    dt = time.perf_counter() - t0
+                    out[mode] = {'images_per_s': round(wl.B * n_batches / dt, 1), 'ms_per_batch': round(dt / n_batches * 1e3, 2),
+                                 'annotations': n_ann}
+                # where a batch's time goes when nothing overlaps
+                t0 = time.perf_counter()
+                batch, metas = pred._preprocess(frames)
+                torch.cuda.synchronize(device)
+                out['preprocess_ms_per_batch'] = round((time.perf_counter() - t0) * 1e3, 2)
+                t0 = time.perf_counter()
+                res = pred.tensor_batch(batch, metas)
+                out['tensor_batch_ms'] = round((time.perf_counter() - t0) * 1e3, 2)
+                out['value'] = out['pipelined']['images_per_s']
+                out['ms_per_step'] = out['pipelined']['ms_per_batch']
+                out['lanes'] = pred.processor.pipeline_depth
+                out['what'] = ('Predictor.numpy_images over %d batches of %d uint8 %dx%d frames: device-side preprocessing, float32 %s, '
+                               'HIP decode of the synthetic fields on decode lanes, inverse transform on the device, annotations '
+                               'through pinned memory, Annotation objects built on the host' % (
+                                   n_batches, wl.B, args.long_edge, args.long_edge, wl.backbone))
+                return out
+            finally:
+                Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device = saved
+        guarded('predictor', predictor_leg)
+
         # the literal configs[1]: batch 1
         def batch1_leg():
             w1 = Workload(2, 1, 0, device, args.long_edge, 2)
@@ -997,6 +1083,28 @@ def main():
                 torch.cuda.synchronize(device)
             out['decode_ms_per_image_eager'] = round((time.perf_counter() - t0) / n * 1e3, 3)
             out['decode_kernels_ms'] = {k: round(v, 4) for k, v in kernel_profile(w1, w1.variants, None, 8).items()}
+            # where an eager step's host time goes: queueing the network (Python + launches, no wait), queueing the decode,
+            # then waiting for the device
+            tq_net = tq_dec = tq_sync = 0.0
+            for i in range(n):
+                _, _, cif_d, caf_d = w1.variants[i % len(w1.variants)]
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                with torch.no_grad():
+                    model(img1)
+                t1 = time.perf_counter()
+                o, ids, counts = w1.dec.call_batch(cif_d, w1.stride, caf_d, w1.stride)
+                w1.host_out.copy_(o, non_blocking=True)
+                w1.host_counts.copy_(counts, non_blocking=True)
+                t2 = time.perf_counter()
+                torch.cuda.synchronize(device)
+                t3 = time.perf_counter()
+                tq_net += t1 - t0; tq_dec += t2 - t1; tq_sync += t3 - t2
+            out['eager_breakdown_ms'] = {'host_queues_network': round(tq_net / n * 1e3, 3),
+                                         'host_queues_decode_and_copies': round(tq_dec / n * 1e3, 3),
+                                         'host_waits_for_device': round(tq_sync / n * 1e3, 3),
+                                         'device_network': out['network_ms_per_image'],
+                                         'device_decode': round(sum(out['decode_kernels_ms'].values()), 3)}
             # the whole step as ONE HIP graph: network + decode captured together, fields refilled in place
             try:
                 st = torch.cuda.Stream()

@@ -57,6 +57,52 @@ int main(void) {
     CHECK_HIP(hipMemcpy(host_counts, counts, sizeof(host_counts), hipMemcpyDeviceToHost));
     printf("annotations per image: %d %d\n", host_counts[0], host_counts[1]);
 
+    /* ---- several batches in flight: one decoder handle, workspace, output block and HIP
+     * stream PER LANE.  A decode allocates nothing and synchronises nothing, so batch i+1 is queued on its lane while
+     * batch i is still decoding on the other one; the annotations travel to pinned host memory on the lane's stream
+     * and an event says when they are there.  (The fields of a lane must stay untouched until its event has fired.) */
+    {
+        enum { LANES = 2, BATCHES = 6 };
+        opa_cifcaf* dec[LANES]; void* ws[LANES]; float* o[LANES]; int64_t* id[LANES]; int32_t* cn[LANES];
+        hipStream_t st[LANES]; hipEvent_t done[LANES]; int32_t* host_cn[LANES]; float* host_o[LANES];
+        const size_t out_bytes = sizeof(float) * 2 * 64 * 17 * 4;
+        int l, i, total = 0;
+        for (l = 0; l < LANES; l++) {
+            CHECK_OPA(opa_cifcaf_create(&dec[l], 17, &SKELETON[0][0], 19));
+            CHECK_HIP(hipMalloc(&ws[l], ws_bytes));
+            CHECK_HIP(hipMemset(ws[l], 0, 256));                 /* workspace contract: the header starts out invalid */
+            CHECK_HIP(hipMalloc((void**)&o[l], out_bytes));
+            CHECK_HIP(hipMalloc((void**)&id[l], sizeof(int64_t) * 2 * 64));
+            CHECK_HIP(hipMalloc((void**)&cn[l], sizeof(int32_t) * 2));
+            CHECK_HIP(hipHostMalloc((void**)&host_cn[l], sizeof(int32_t) * 2, hipHostMallocDefault));
+            CHECK_HIP(hipHostMalloc((void**)&host_o[l], out_bytes, hipHostMallocDefault));
+            CHECK_HIP(hipStreamCreateWithFlags(&st[l], hipStreamNonBlocking));
+            CHECK_HIP(hipEventCreateWithFlags(&done[l], hipEventDisableTiming));
+        }
+        CHECK_HIP(hipDeviceSynchronize());
+        for (i = 0; i < BATCHES + LANES; i++) {
+            l = i % LANES;
+            if (i >= LANES) {                                    /* collect what this lane decoded last time */
+                CHECK_HIP(hipEventSynchronize(done[l]));
+                if ((host_cn[l][0] | host_cn[l][1]) & OPA_COUNT_FAILED) { fprintf(stderr, "decode failed\n"); return 1; }
+                total += OPA_COUNT_ROWS(host_cn[l][0]) + OPA_COUNT_ROWS(host_cn[l][1]);
+            }
+            if (i < BATCHES) {                                   /* ... and queue its next batch */
+                CHECK_OPA(opa_cifcaf_decode(dec[l], &shape, NULL, cif, caf, NULL, NULL, 0, ws[l], ws_bytes,
+                                            o[l], id[l], cn[l], st[l]));
+                CHECK_HIP(hipMemcpyAsync(host_o[l], o[l], out_bytes, hipMemcpyDeviceToHost, st[l]));
+                CHECK_HIP(hipMemcpyAsync(host_cn[l], cn[l], sizeof(int32_t) * 2, hipMemcpyDeviceToHost, st[l]));
+                CHECK_HIP(hipEventRecord(done[l], st[l]));
+            }
+        }
+        printf("%d batches over %d lanes: %d annotations\n", BATCHES, LANES, total);
+        for (l = 0; l < LANES; l++) {
+            opa_cifcaf_destroy(dec[l]);
+            hipFree(ws[l]); hipFree(o[l]); hipFree(id[l]); hipFree(cn[l]); hipHostFree(host_cn[l]); hipHostFree(host_o[l]);
+            hipStreamDestroy(st[l]); hipEventDestroy(done[l]);
+        }
+    }
+
     opa_cifcaf_destroy(decoder);
     hipFree(cif); hipFree(caf); hipFree(workspace); hipFree(out); hipFree(ids); hipFree(counts);
     return 0;

@@ -264,6 +264,7 @@ def test_c_host_example_runs_on_the_gpu(tmp_path):
     proc = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=120)
     assert proc.returncode == 0, proc.stderr
     assert 'annotations per image: 0 0' in proc.stdout
+    assert '6 batches over 2 lanes: 0 annotations' in proc.stdout        # the two-handle / two-stream recipe
 
 
 def test_rescale_restatement_equals_scipy_zoom_pixel_for_pixel():
