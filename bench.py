@@ -1007,7 +1007,7 @@ def main():
                     self.n += 1
                     return (v[2], v[3])
             saved = (Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device)
-            Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device = wl.B, None, True, device
+            Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device = wl.B, args.long_edge, True, device
             try:
                 pred = Predictor(model=Injected())
                 rng = np.random.default_rng(3)

@@ -409,6 +409,10 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     ties.big = ws + L.off_act; ties.big_stride = (size_t)L.F * 4 * (L.H * L.W) * sizeof(float);
     ties.small_ = ws + L.off_tie_small; ties.small_stride = L.tie_small_stride;
     ties.state = (int32_t*)(ws + L.off_tie_state);
+    // inside the decode the tie pass runs in the association kernel (every image its own, before its seeds are read)
+    const char* fuse_ties_env = std::getenv("OPA_FUSE_TIES");
+    const bool fuse_ties = seed_tie_order() == 1 && !(fuse_ties_env && std::atoi(fuse_ties_env) == 0);
+    ties.defer = fuse_ties ? 1 : 0;
     e = launch_cifseeds(cif_dev, L.B, L.F, L.H, L.W, L.stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
                         (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap,
                         (int32_t*)(ws + L.off_seed_count), (int32_t*)(ws + L.off_seed_f),
@@ -441,6 +445,10 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     a.initial = initial_dev; a.initial_ids = initial_ids_dev;
     a.out = out_dev; a.out_ids = out_ids_dev; a.out_count = out_count_dev;
     a.status = (int32_t*)(ws + L.off_status);
+    a.tie_fused = fuse_ties ? 1 : 0;
+    make_tie_args(&a.tie, &a.tie_sort, (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap, (int32_t*)(ws + L.off_seed_count), cif_dev,
+                  L.F, 5, L.H * L.W, L.stride, (int32_t*)(ws + L.off_seed_f), (float*)(ws + L.off_seed_vxys),
+                  (int32_t*)(ws + L.off_seed_cell), L.occ_h, L.occ_w, ties);
     e = launch_assoc(a, dec->dev, p, st);                                                     // :176-261
     if (e != hipSuccess) return fail_hip(e, "association");
     return OPA_OK;
@@ -491,6 +499,7 @@ static TieScratch stage_ties(void* scratch_dev, int batch, int F, int HW) {
     t.big = sp; t.big_stride = tie_big_bytes(cells); sp += align_up((size_t)batch * t.big_stride);
     t.small_ = sp; t.small_stride = tie_small_bytes(F, HW); sp += align_up((size_t)batch * t.small_stride);
     t.state = (int32_t*)sp;
+    t.defer = 0;
     return t;
 }
 
@@ -642,6 +651,7 @@ int opa_cifdet_decode(const opa_det_shape* shape, const opa_params* params, cons
     ties.big = ws + L.off_act; ties.big_stride = (size_t)F * 4 * (H * W) * sizeof(float);
     ties.small_ = ws + L.off_tie_small; ties.small_stride = L.tie_small_stride;
     ties.state = (int32_t*)(ws + L.off_tie_state);
+    ties.defer = 0;
     e = launch_cifseeds(field_dev, B, F, H, W, shape->stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
                         (unsigned long long*)(ws + L.off_keys), L.sort_cap, (int32_t*)(ws + L.off_seed_count),
                         (int32_t*)(ws + L.off_seed_f), (float*)(ws + L.off_seed_v), st, true, nullptr, 0, 0, false, nullptr, 0,

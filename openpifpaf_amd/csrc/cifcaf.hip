@@ -52,7 +52,7 @@
 // Joint confidences are double like the reference's Joint struct; every
 // float/double promotion follows the reference operation by operation and the
 // library is built with -ffp-contract=off.
-#include "common.hpp"
+#include "cifseeds_tie.hpp"
 
 #include <cstdlib>
 
@@ -1579,6 +1579,14 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     const long long t_kernel = wall_clock64();
     const long long kWatchdogTicks = a.watchdog_ticks;
 
+    // ---- seeds of equal score into the order the reference's unstable std::sort leaves them in (cif_seeds.cpp:94), this
+    // image's only: images without equal scores leave after one look at their sorted scores, and nobody waits for
+    // another image's ties.  The pass borrows the whole LDS block; what it stores is read after the sync_global() below.
+    if (a.tie_fused) {
+        cifseeds_tie_body<kThreads>(a.tie, a.tie_sort, p, b, smem);
+        __syncthreads();
+    }
+
     ImageCtx c;
     c.K = K; c.A = A; c.F = a.F; c.wave = wave;
     c.lists = a.lists + (size_t)b * A * 2 * 7 * a.list_cap;
@@ -1727,6 +1735,10 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             if (lane == 0) __hip_atomic_fetch_add(&sh_stats[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
         int n_commits = 0;
+        // the per-phase tick counters (slots 12, 17-20) cost a clock read and a wait each: only when asked for (OPA_ASSOC_TIMING=1,
+        // tools/gpu/r3_probe.py); the event counters are always on
+        const bool timing = a.timing != 0;
+        auto tick = [&]() -> long long { return timing ? wall_clock64() : 0ll; };
         // ================================================================= coordinator
         // The pool: up to 512 LIVE, undecided seeds, 8 slots per lane in any order (mirrored in LDS for the
         // growers).  Invariant: every seed below scan_pos is either in a slot or dead for good (inside a box of
@@ -1813,7 +1825,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             //         not a round of the whole loop (a crowded image ends in dozens of poses of one or two joints)
             int hg = hd == kNone ? -1 : head_grower();
             for (int run = 0; run < kCommitRun && hg >= 0 && flag_load(&task[hg].state) == kTaskDone; run++) {
-                const long long t_cm = wall_clock64();
+                const long long t_cm = tick();
                 const PoseView q = pose_of_block(private_base, hg - 1, private_bytes, K);
                 unsigned dead = 0u;                      // pooled seeds inside one of its joint boxes (:211 for them)
 #pragma unroll
@@ -1870,7 +1882,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 progress = true;
                 find_head();
                 hg = hd == kNone ? -1 : head_grower();
-                stat(17, (int)(wall_clock64() - t_cm));
+                if (timing) stat(17, (int)(wall_clock64() - t_cm));
             }
             if (progress) count_live();
 
@@ -1892,13 +1904,13 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             // ---- 3. refill free slots with the next seeds that are still free in the bitmap (:211 for the
             //         poses accepted so far); slot (r, lane) takes the seed of its rank among the free slots
             if (scan_pos < n_seeds && 2 * n_live < WR * kWave) {
-                const long long t_ph = wall_clock64();
+                const long long t_ph = tick();
                 if (marks_pending) {                     // accepted poses are marked by their growers: all of them are done
                     while (__ballot(is_grower_lane && flag_load(&task[lane].state) == kTaskAccepted) != 0ull &&
                            wall_clock64() - t_kernel <= kWatchdogTicks)
                         __builtin_amdgcn_s_sleep(1);
                     marks_pending = false;
-                    stat(20, (int)(wall_clock64() - t_ph));
+                    if (timing) stat(20, (int)(wall_clock64() - t_ph));
                 }
                 // this wave's marks (atomics, performed at L2) before its own reads, which bypass the L1 (agent-scope
                 // loads): vmcnt(0) is all it takes -- and the staged seeds have landed in LDS
@@ -2015,7 +2027,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 unver |= fresh;
                 wave_sync();
                 if (is_grower_lane) flag_store(&task[lane].epoch, epoch);
-                stat(18, (int)(wall_clock64() - t_ph));
+                if (timing) stat(18, (int)(wall_clock64() - t_ph));
                 progress = true;
                 if (hd == kNone) { find_head(); hg = -1; }   // (newcomers come after everything pooled)
             }
@@ -2101,7 +2113,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             //         flight have not tested yet wait for that -- except the head, which nothing can shadow)
             unsigned long long idle = __ballot(g_state == kTaskIdle);
             if (idle) {
-                const long long t_em = wall_clock64();
+                const long long t_em = tick();
                 // A candidate's own seed box is published by its grower a moment after the hand-out.  Until then (npub == 0)
                 // the coordinator stands in for it, on the side of the NEXT candidate: one test of that seed against the
                 // seed boxes of the unpublished candidates before it (lane g: grower g) instead of a sweep over the pool.
@@ -2148,7 +2160,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     if (__ballot(was_shadowed) != 0ull) stat(5, 1);
                     progress = true;
                 }
-                stat(19, (int)(wall_clock64() - t_em));
+                if (timing) stat(19, (int)(wall_clock64() - t_em));
             }
 
             // ---- 6. what the next round waits for
@@ -2183,7 +2195,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             }
             if (!progress && flag_load(&task[hg].state) != kTaskDone) {
                 __builtin_amdgcn_s_sleep(2);
-                wait_ticks += wall_clock64() - t_iter;   // an iteration that only waited for the head's growth
+                if (timing) wait_ticks += wall_clock64() - t_iter;   // an iteration that only waited for the head's growth
                 stat(16, 1);
             }
         }
@@ -2460,7 +2472,8 @@ static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, con
     const size_t nms = nms_fixed + (size_t)nms_waves * nms_scratch_bytes(a.max_ann);
     if (shared + nms > budget) return hipErrorInvalidValue;
     const size_t grow_bytes = (size_t)growers * priv;
-    const size_t lds = shared + (grow_bytes > nms ? grow_bytes : nms);
+    size_t lds = shared + (grow_bytes > nms ? grow_bytes : nms);
+    if (a.tie_fused && lds < tie_lds_bytes<NW * kWave>()) lds = tie_lds_bytes<NW * kWave>();   // the tie pass borrows the block first
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)cifcaf_assoc_kernel<REG, NW>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2493,6 +2506,8 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     if (const char* e = getenv("OPA_ASSOC_DEDUP")) { if (atoi(e) == 0) a.dedup = 0; }   // A/B and tests: same result without it
     a.inherit = 1;
     a.collide = 1;
+    a.timing = 0;
+    if (const char* e = getenv("OPA_ASSOC_TIMING")) a.timing = atoi(e) != 0;      // phase tick counters of the coordinator (statistics slots 12, 17-20)
     if (const char* e = getenv("OPA_ASSOC_COLLIDE")) a.collide = atoi(e) != 0;     // A/B: growths stop only when their SEED is covered
     if (const char* e = getenv("OPA_ASSOC_INHERIT")) a.inherit = atoi(e) != 0;     // A/B: predictions lapse with the growth that made them
     a.watchdog_ticks = kWatchdogTicksDefault;

@@ -86,7 +86,8 @@ struct ScoredArgs;
 // Scratch of the pass that puts seeds of EQUAL score into libstdc++'s std::sort order (cifseeds.hip); `state` [B]:
 // 0 no equal scores, 1 re-sorted, -1 not reproduced (introsort's heapsort branch).  seed_tie_order(): 1 = libstdc++
 // (the reference, default), 0 = cell index (opa_set_seed_tie_order / OPA_SEED_TIES=index).
-struct TieScratch { unsigned char* big; size_t big_stride; unsigned char* small_; size_t small_stride; int32_t* state; };
+struct TieScratch { unsigned char* big; size_t big_stride; unsigned char* small_; size_t small_stride; int32_t* state;
+                    int defer; };   // defer: launch_cifseeds prepares the pass (block table, key copy) and leaves the pass itself to the caller
 size_t tie_big_bytes(int cells);
 size_t tie_small_bytes(int F, int HW);
 int seed_tie_order();
@@ -138,6 +139,21 @@ constexpr int kListBboxMax = 255;
 // one thing that faulted when the decode was replayed as a captured HIP graph); bytes % 4 == 0
 hipError_t launch_zero(void* dst, size_t bytes, hipStream_t st);
 
+// the seed sort's arrays, and the scratch of the pass that reproduces the reference's order of equal scores (cifseeds_tie.hpp)
+struct SortArgs {
+    unsigned long long* keys; int sort_cap, cap; const int32_t* seed_count;
+    const float* cif; int F, NC, HW, stride;
+    int32_t* seed_f; float* seed_vxys; int32_t* seed_cell; int occ_h, occ_w;
+};
+struct TieArgs {
+    int cells;                       // F * HW: capacity of the per-image arrays
+    unsigned char* big; size_t big_stride;       // per image tie_big_bytes(cells): cells, scores and the two stop lists of an
+                                                 // image beyond the LDS arrays
+    unsigned char* small_; size_t small_stride;  // per image tie_small_bytes(F, HW): the fill kernel's block table, its prefix,
+                                                 // segment lists
+    int32_t* tie_state;              // [B] or null: 0 no equal scores, 1 re-sorted in libstdc++'s order, -1 not reproduced
+};
+
 struct AssocArgs {
     int B, K, F, A, max_ann, n_initial;      // K joints per annotation, F <= K of them with a CIF field
     int hr_rows, hr_cols;
@@ -150,6 +166,9 @@ struct AssocArgs {
     const float* list_bbox;  // [B][A][2][bbox_chunks][4] chunk boxes of `lists` (or null)
     const float* list_bbox_fc;  // ... of `lists_fc` (or null)
     int bbox_chunks;
+    int tie_fused;              // 1: every workgroup first puts its image's seeds of equal score into the reference's order (tie, tie_sort)
+    TieArgs tie; SortArgs tie_sort;
+    int timing;                 // 1: the coordinator also fills the tick counters of its phases (statistics slots 12, 17-20)
     int collide;                // 1: a growth that assigns a joint inside the same joint's box of an earlier live candidate is stopped (advisory)
     int inherit;                // 1: a candidate inherits the predictions of a growth stopped because of it (advisory; see cifcaf.hip)
     int dedup;                  // 1: later seeds of an occupancy cell already seen are dropped at the pool refill (exact; see cifcaf.hip)
@@ -165,6 +184,10 @@ struct AssocArgs {
     float* out; int64_t* out_ids; int32_t* out_count;
     int32_t* status;         // [B] debug/overflow flags
 };
+// TieArgs / SortArgs of the tie pass the way launch_cifseeds builds them (for a caller that runs the pass itself: TieScratch::defer)
+void make_tie_args(TieArgs* a, SortArgs* g, unsigned long long* keys, int sort_cap, const int32_t* seed_count, const float* cif,
+                   int F, int NC, int HW, int stride, int32_t* seed_f, float* seed_vxys, int32_t* seed_cell, int occ_h, int occ_w,
+                   const TieScratch& t);
 hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st);
 
 struct DetArgs {

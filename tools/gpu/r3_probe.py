@@ -9,6 +9,7 @@ BASELINE decode shapes.
 """
 import argparse
 import os
+os.environ.setdefault('OPA_ASSOC_TIMING', '1')     # the coordinator's per-phase tick counters are off by default
 import sys
 import time
 
