@@ -431,7 +431,7 @@ def parity_stamp(decode_device, variants, skeleton0, n_keypoints, fc_kw=None, ma
 class Workload:
     """Field batches, decoder and host buffers of one BASELINE configuration on this rank."""
 
-    def __init__(self, config_id, B, rank, device, long_edge, n_variants, backbone=None, max_annotations=None):
+    def __init__(self, config_id, B, rank, device, long_edge, n_variants, backbone=None, max_annotations=None, full_pool=False):
         from openpifpaf_amd import constants, headmeta, native, synth
         cfg = CONFIGS[config_id]
         self.config_id, self.cfg, self.B, self.device = config_id, cfg, B, device
@@ -456,6 +456,8 @@ class Workload:
             self.variants.append((cifs, cafs, torch.from_numpy(cifs).to(device), torch.from_numpy(cafs).to(device)))
         self._quantised = None
         kw = {} if max_annotations is None else {'max_annotations': max_annotations}
+        if full_pool:
+            kw['cifhr_pool_tiles'] = 'full'
         self.dec = native.CifCaf(self.K, torch.from_numpy(self.skeleton0), **kw)
         self.host_out = torch.empty((B, self.dec.max_annotations, self.K, 4), dtype=torch.float32).pin_memory()
         self.host_counts = torch.empty((B,), dtype=torch.int32).pin_memory()
@@ -508,19 +510,18 @@ def kernel_profile(wl, variants, params, steps):
 
 
 def tiles_written_per_call(wl, variants, params):
-    """32x64 tiles of the CifHr map one call writes when the field batches alternate: touched(this call) | touched(previous
-    call) (lazy clear), counted from the per-call bitmaps the workspace keeps."""
+    """32x64 tiles of the CifHr map one call writes (mean over the alternating field batches): the tiles this call's CIF
+    cells reach -- the map is a pool of tiles, nothing is cleared and nothing carries over -- counted from the touched-tile
+    bitmaps (second half of the workspace's tile state)."""
     rows = (wl.fh - 1) * wl.stride + 1
     words = ((((rows + 63) // 64) * ((rows + 31) // 32)) + 31) // 32
-    maps = []
+    n = wl.B * wl.K * words
+    counts = []
     for _, _, cif_d, caf_d in variants:
         wl.dec.call_batch(cif_d, wl.stride, caf_d, wl.stride, params=params)
         bm = wl.dec.workspace_view('tile_bitmaps', torch.int32).cpu().numpy().view(np.uint32)
-        maps.append(bm[:wl.B * wl.K * words].copy())
-    union = maps[0]
-    for m in maps[1:]:
-        union = union | m
-    return int(np.unpackbits(union.view(np.uint8)).sum())
+        counts.append(int(np.unpackbits(bm[n:2 * n].copy().view(np.uint8)).sum()))
+    return int(round(float(np.mean(counts))))
 
 
 def decode_roofline(wl, variants, params, steps, force_complete=False):
@@ -598,7 +599,7 @@ def main():
               and args.fields == 'synthetic' and not args.force_complete and args.backbone is None and args.batch is None)
     n_variants = 1 if (args.single_batch or args.graph) else 2
     wl = Workload(config_id, args.batch or CONFIGS[config_id]['batch'], rank, device, args.long_edge, n_variants,
-                  backbone=args.backbone)
+                  backbone=args.backbone, full_pool=args.fields == 'network')
     B, K, A, stride = wl.B, wl.K, wl.A, wl.stride
     dec = wl.dec
     dec_params = _lib.default_params(**FC_KW) if args.force_complete else None
@@ -965,6 +966,9 @@ def main():
             cifs = np.stack([c for c, _ in pairs]); cafs = np.stack([f for _, f in pairs])
             cif_d, caf_d = torch.from_numpy(cifs).to(device), torch.from_numpy(cafs).to(device)
             variants = [(cifs, cafs, cif_d, caf_d)]
+            # (every cell active: the CIF map reaches every tile -- a pool that holds the whole map, opa_shape::cifhr_pool_tiles)
+            dec_full = native.CifCaf(wl.K, torch.from_numpy(wl.skeleton0), cifhr_pool_tiles='full')
+            saved_dec, wl.dec = wl.dec, dec_full
             with torch.cuda.stream(dec_stream):
                 for _ in range(2):
                     wl.dec.call_batch(cif_d, wl.stride, caf_d, wl.stride)
@@ -978,6 +982,7 @@ def main():
                 par = None if args.no_parity else parity_stamp(
                     lambda c, f: wl.dec.call_batch(c, wl.stride, f, wl.stride), variants, wl.skeleton0, wl.K)
             seeds = wl.dec.workspace_view('seed_count', torch.int32)[:wl.B].cpu().numpy()
+            wl.dec = saved_dec
             alg = algorithmic_bytes(wl.B, wl.K, wl.A, wl.fh, wl.fh, wl.stride, wl.dec.max_annotations)['decode_path']
             return {'what': 'decode only: %d all-active %dx%d field pairs (synth.adversarial_fields: sigmoid(N(0,1)) confidences, '
                             'every cell above every threshold)' % (wl.B, wl.fh, wl.fh),

@@ -39,9 +39,11 @@ extern "C" {
 #define OPA_ERR_NO_DEVICE 5          /* no gfx950 device visible                    */
 
 /* out_count of opa_cifcaf_decode: number of valid rows, plus OPA_COUNT_OVERFLOW when poses were dropped for lack
- * of capacity (max_annotations too small), plus OPA_COUNT_FAILED when the association kernel gave up on the image
- * (its watchdog fired: a protocol error, never seen outside the test that provokes it; the image has 0 rows and
- * its result must not be used).  Both flags travel with the count, so a caller that reads the counts sees them. */
+ * of capacity (max_annotations too small), plus OPA_COUNT_FAILED when the image could not be decoded: the association
+ * kernel's watchdog fired (a protocol error, never seen outside the test that provokes it; status word -1), or the image's
+ * CIF map reaches more tiles than its pool holds (opa_shape::cifhr_pool_tiles; status word -2: decode again with a
+ * larger pool).  The image then has 0 rows and its result must not be used.  Both flags travel with the count, so a
+ * caller that reads the counts sees them. */
 #define OPA_COUNT_OVERFLOW 0x40000000
 #define OPA_COUNT_FAILED 0x20000000
 #define OPA_COUNT_ROWS(c) ((c) & 0x0FFFFFFF)
@@ -88,6 +90,12 @@ typedef struct opa_shape {
                                * frames, have no CIF field -- no seeds, no rescoring, no occupancy, no reverse
                                * match from them (cifcaf.cpp:173,225-229,397; caf_scored.cpp:15-18) -- and are
                                * reached only through initial annotations and bones                    */
+    int32_t cifhr_pool_tiles; /* capacity, per image, of the high-resolution CIF map, which the decode keeps as a pool
+                               * of 32x64-pixel tiles: only tiles the box of an active CIF cell reaches take a slot
+                               * (a 20-person 641-px COCO image: ~450 of its 3927).  0 = automatic: an eighth of the
+                               * map, at least 1024 tiles; -1 = every tile (the dense map's size: can never run out);
+                               * > 0 = that many.  An image that reaches more tiles than the pool holds is not
+                               * decoded wrongly: its count carries OPA_COUNT_FAILED and its status word is -2.   */
 } opa_shape;
 
 /* ---- library ------------------------------------------------------------ */
@@ -176,11 +184,15 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
                       void* stream);
 
 /* ref: module.cpp:37-39  CifCaf.get_cifhr() -> (Tensor[F,Hhr,Whr], revision).
- * Describes where, inside the workspace of the LAST opa_cifcaf_decode call with
- * this shape, the high-resolution map lives: image b, field f, row y, column x
- * is at  ((float*)workspace)[offset_floats + ((b*F + f)*rows + y)*pitch + x].
- * Cell content is the reference buffer's content at revision 1.0:
- * 0.0 = never touched, otherwise 1.0 + accumulated confidence. */
+ * The decode keeps the high-resolution map as a pool of tiles (opa_shape::cifhr_pool_tiles); this call writes the map of
+ * image `image` of the LAST opa_cifcaf_decode into that workspace as the dense float32 [n_cif, rows, cols] array the
+ * reference returns -- out_dev, device memory of n_cif * rows * cols floats (rows / cols: opa_cifcaf_cifhr_view) --
+ * asynchronously on `stream`.  Cell content is the reference buffer's content at revision 1.0: 0.0 = never touched,
+ * otherwise 1.0 + accumulated confidence. */
+int opa_cifcaf_get_cifhr(const opa_shape* shape, const void* workspace_dev, int32_t image, float* out_dev, void* stream);
+
+/* Geometry of that array: rows = (cif_h - 1) * stride + 1, cols likewise; pitch = cols; revision = 1.0;
+ * offset_floats: where the tile pools begin inside the workspace (debugging; the layout of a pool is not part of the ABI). */
 int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
                           int32_t* rows, int32_t* cols, int32_t* pitch, double* revision);
 
@@ -193,7 +205,8 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
  * list -- the rest of a list's C boxes is not written; an empty chunk: +inf, -inf, +inf, -inf), "list_bbox_fc" (the
  * boxes of ALL C chunks of every "lists_fc" list; written only by a force-complete decode), "occupancy",
  * "annotation_scratch", "status" (int32 [B]: poses dropped for lack of capacity; -1: the kernel's watchdog
- * fired), "assoc_stats" (int32 [B,24] per image: 0 growths started, 1 poses accepted, 2 growths stopped because
+ * fired; -2: the image's CIF map did not fit its tile pool), "cifhr_slots" (int32 [B, n_cif, tiles per plane]: slot of a map
+ * tile in its image's pool, negative: no cell reaches the tile), "cifhr_overflow" (int32 [B]), "assoc_stats" (int32 [B,24] per image: 0 growths started, 1 poses accepted, 2 growths stopped because
  * their seed died, 3 finished growths dropped for the same reason, 4 growths stopped or given up on a prediction
  * (the seed stays pooled), 5 seeds handed out after having been predicted dead, 6 pool refills, 7 seeds,
  * 8 ticks until the growth phase ended, 9 ticks of the kernel, 10 sum of the growers' busy ticks, 11 list

@@ -64,7 +64,7 @@ class Shape(ctypes.Structure):
     """``opa_shape``."""
     _fields_ = [(n, ctypes.c_int32) for n in (
         'batch', 'n_cif', 'n_caf', 'cif_h', 'cif_w', 'caf_h', 'caf_w',
-        'cif_stride', 'caf_stride', 'max_annotations', 'n_keypoints')]
+        'cif_stride', 'caf_stride', 'max_annotations', 'n_keypoints', 'cifhr_pool_tiles')]
 
 
 # every symbol include/openpifpaf_amd.h declares: name -> (restype, argtypes)
@@ -88,6 +88,7 @@ SYMBOLS = {
     'opa_cifcaf_decode': (ctypes.c_int, [_vp, _P(Shape), _P(Params), _vp, _vp, _vp, _vp, _i32,
                                          _vp, _sz, _vp, _vp, _vp, _vp]),
     'opa_cifcaf_cifhr_view': (ctypes.c_int, [_P(Shape), _P(_sz), _P(_i32), _P(_i32), _P(_i32), _P(_dbl)]),
+    'opa_cifcaf_get_cifhr': (ctypes.c_int, [_P(Shape), _vp, _i32, _vp, _vp]),
     'opa_cifcaf_workspace_view': (ctypes.c_int, [_P(Shape), ctypes.c_char_p, _P(_sz), _P(_sz)]),
     'opa_cifhr_pitch': (_i32, [_i32, _i32]),
     'opa_cifhr_scratch_bytes': (_sz, [_i32, _i32, _i32, _i32]),

@@ -113,7 +113,10 @@ def inverse_transform_batch(annotations, metas):
         flip = bool(m.get('hflip'))
         rows.append([float(off[0]), float(off[1]), float(sc[0]), float(sc[1]), 1.0 if flip else 0.0,
                      float(m['width_height'][0]) - 1.0 if flip else 0.0])
-    t = torch.tensor(rows, dtype=annotations.dtype, device=annotations.device).view(B, 1, 1, 6)
+    t = torch.tensor(rows, dtype=annotations.dtype)
+    if annotations.is_cuda:                 # through pinned memory: a pageable upload would make the host wait for the stream
+        t = t.pin_memory().to(annotations.device, non_blocking=True)
+    t = t.view(B, 1, 1, 6)
     out = annotations.clone()
     out[..., 1] = (annotations[..., 1] + t[..., 0]) / t[..., 2]
     out[..., 2] = (annotations[..., 2] + t[..., 1]) / t[..., 3]

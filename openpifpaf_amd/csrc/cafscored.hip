@@ -28,7 +28,7 @@ ScoredArgs make_scored_args(const float* caf, int B, int A, int cH, int cW, int 
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
                             float* lists, int32_t* counts, float* chunk_bbox, int bbox_chunks, int bbox_stride,
-                            const unsigned* tile_touch) {
+                            const unsigned* tile_touch, const HrPool* pool) {
     if (bbox_chunks <= 0) chunk_bbox = nullptr;
     if (bbox_stride < bbox_chunks) bbox_stride = bbox_chunks;
     ScoredArgs s;
@@ -37,6 +37,8 @@ ScoredArgs make_scored_args(const float* caf, int B, int A, int cH, int cW, int 
     s.lists = lists; s.counts = counts; s.chunk_bbox = chunk_bbox; s.nb = chunk_bbox ? bbox_chunks : 0; s.nb_stride = bbox_stride;
     s.planes = B * A;
     s.tile_touch = tile_touch; s.tiles_x = hr_pitch / kHrTileW;
+    s.hr_slot = pool ? pool->slot : nullptr; s.hr_tpp = pool ? pool->tpp : 0;
+    s.hr_image_stride = pool ? (size_t)pool->cap * kHrTileH * kHrTileW : (size_t)F * hr_rows * hr_pitch;
     s.touch_words = (s.tiles_x * ((hr_rows + kHrTileH - 1) / kHrTileH) + 31) / 32;
     return s;
 }

@@ -79,8 +79,9 @@ __device__ __forceinline__ void cafscored_plane(const ScoredArgs& s, int plane_i
     const int b = plane / A, a = plane - b * A;
     const int lane = tid & 63, w = tid >> 6;
     const float* P = caf + (size_t)plane * 8 * HW;
-    const float* hr = cifhr + (size_t)b * F * hr_rows * hr_pitch;
+    const float* hr = cifhr + (size_t)b * s.hr_image_stride;
     const unsigned* touch = s.tile_touch ? s.tile_touch + (size_t)b * F * s.touch_words : nullptr;
+    const int32_t* slot = s.hr_slot ? s.hr_slot + (size_t)b * F * s.hr_tpp : nullptr;   // pooled map: the slot table replaces the bitmap test
     float* Lf = lists + ((size_t)plane * 2 + 0) * 7 * HW;
     float* Lb = lists + ((size_t)plane * 2 + 1) * 7 * HW;
     const long long j1 = skeleton[2 * a + 0], j2 = skeleton[2 * a + 1];
@@ -103,8 +104,8 @@ __device__ __forceinline__ void cafscored_plane(const ScoredArgs& s, int plane_i
                 s1 = r6 * stride_f; s2 = r7 * stride_f;
                 cf = c; cb = c;
                 if (!no_rescore) {                                       // :66-71
-                    const float fhr = cifhr_value(hr, F, hr_rows, hr_cols, hr_pitch, j2, x2, y2, 0.0f, touch, s.touch_words, s.tiles_x);
-                    const float bhr = cifhr_value(hr, F, hr_rows, hr_cols, hr_pitch, j1, x1, y1, 0.0f, touch, s.touch_words, s.tiles_x);
+                    const float fhr = cifhr_value(hr, F, hr_rows, hr_cols, hr_pitch, j2, x2, y2, 0.0f, touch, s.touch_words, s.tiles_x, slot, s.hr_tpp);
+                    const float bhr = cifhr_value(hr, F, hr_rows, hr_cols, hr_pitch, j1, x1, y1, 0.0f, touch, s.touch_words, s.tiles_x, slot, s.hr_tpp);
                     cf = (float)((double)c * (cif_floor + (1.0 - cif_floor) * (double)fhr));
                     cb = (float)((double)c * (cif_floor + (1.0 - cif_floor) * (double)bhr));
                 }

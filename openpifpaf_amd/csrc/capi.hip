@@ -124,7 +124,17 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
         const size_t tpp = (size_t)(L->hr_pitch / kHrTileW) * ((L->hr_rows + kHrTileH - 1) / kHrTileH);
         L->off_tile_clean = take(2 * B * L->F * ((tpp + 31) / 32) * sizeof(unsigned));
     }
-    L->off_cifhr = take(B * L->F * L->hr_rows * (size_t)L->hr_pitch * sizeof(float));
+    {   // the map: a pool of 32x64 tiles per image (cifhr.hip) + the slot table of every plane
+        const size_t tpp = (size_t)(L->hr_pitch / kHrTileW) * ((L->hr_rows + kHrTileH - 1) / kHrTileH);
+        const size_t all = tpp * L->F;
+        size_t cap = s.cifhr_pool_tiles < 0 ? all : s.cifhr_pool_tiles > 0 ? (size_t)s.cifhr_pool_tiles : std::max<size_t>(1024, all / 8);
+        if (cap > all) cap = all;
+        L->hr_tpp = (int)tpp; L->hr_pool_cap = (int)cap;
+        L->off_cifhr = take(B * cap * (size_t)(kHrTileH * kHrTileW) * sizeof(float));
+        L->off_hr_slot = take(B * all * sizeof(int32_t));
+        L->off_hr_plane_count = take(B * L->F * sizeof(int32_t));
+        L->off_hr_overflow = take(B * sizeof(int32_t));
+    }
     L->off_act = take(B * L->F * 4 * (size_t)(L->H * L->W) * sizeof(float));
     L->off_act_count = take(B * L->F * sizeof(int32_t));
     L->off_seed_keys = take(B * (size_t)L->sort_cap * sizeof(unsigned long long));
@@ -304,8 +314,21 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats, int32_t
     if (offset_floats) *offset_floats = L.off_cifhr / sizeof(float);
     if (rows) *rows = L.hr_rows;
     if (cols) *cols = L.hr_cols;
-    if (pitch) *pitch = L.hr_pitch;
+    if (pitch) *pitch = L.hr_cols;
     if (revision) *revision = 1.0;
+    return OPA_OK;
+}
+
+int opa_cifcaf_get_cifhr(const opa_shape* shape, const void* workspace_dev, int32_t image, float* out_dev, void* stream) {
+    Layout L; const char* why = nullptr;
+    if (!shape || !make_layout(*shape, &L, &why)) return fail(OPA_ERR_INVALID_ARGUMENT, why ? why : "null shape");
+    if (!workspace_dev || !out_dev || image < 0 || image >= L.B) return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_get_cifhr: bad argument");
+    const unsigned char* ws = (const unsigned char*)workspace_dev;
+    const float* pool_image = (const float*)(ws + L.off_cifhr) + (size_t)image * L.hr_pool_cap * (kHrTileH * kHrTileW);
+    const int32_t* slot_image = (const int32_t*)(ws + L.off_hr_slot) + (size_t)image * L.F * L.hr_tpp;
+    hipError_t e = launch_cifhr_gather(pool_image, slot_image, L.F, L.hr_rows, L.hr_cols, L.hr_pitch / kHrTileW, L.hr_tpp, out_dev,
+                                       (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "cifhr gather");
     return OPA_OK;
 }
 
@@ -314,7 +337,8 @@ int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what, size_t* 
     if (!shape || !what || !make_layout(*shape, &L, &why)) return fail(OPA_ERR_INVALID_ARGUMENT, why ? why : "null argument");
     struct Entry { const char* name; size_t off, end; };
     const Entry table[] = {
-        {"tile_bitmaps", L.off_tile_clean, L.off_cifhr}, {"cifhr", L.off_cifhr, L.off_act}, {"seed_count", L.off_seed_count, L.off_seed_f},
+        {"tile_bitmaps", L.off_tile_clean, L.off_cifhr}, {"cifhr", L.off_cifhr, L.off_hr_slot}, {"cifhr_slots", L.off_hr_slot, L.off_hr_plane_count},
+        {"cifhr_overflow", L.off_hr_overflow, L.off_act}, {"seed_count", L.off_seed_count, L.off_seed_f},
         {"seed_f", L.off_seed_f, L.off_seed_vxys}, {"seed_vxys", L.off_seed_vxys, L.off_seed_cell}, {"seed_cell", L.off_seed_cell, L.off_lists},
         {"lists", L.off_lists, L.off_list_counts}, {"list_counts", L.off_list_counts, L.off_list_bbox},
         {"list_bbox", L.off_list_bbox, L.off_occ},
@@ -371,10 +395,13 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     for (long long v : {(long long)L.B, (long long)L.F, (long long)L.H, (long long)L.W, (long long)L.stride,
                         (long long)L.A, (long long)L.cH, (long long)L.cW, (long long)L.max_ann, (long long)L.K, (long long)L.total_no_fc})
         layout_hash = (layout_hash ^ (unsigned long long)v) * 1099511628211ull;
+    HrPool pool;                                      // the map is a pool of tiles (cifhr.hip)
+    pool.slot = (int32_t*)(ws + L.off_hr_slot); pool.plane_count = (int32_t*)(ws + L.off_hr_plane_count);
+    pool.overflow = (int32_t*)(ws + L.off_hr_overflow); pool.cap = L.hr_pool_cap; pool.tpp = L.hr_tpp;
     e = launch_cifhr(cif_dev, L.B, L.F, L.H, L.W, L.stride, 0.0, 1.0, p, cifhr, L.hr_rows, L.hr_pitch,
                      (float*)(ws + L.off_act), (int32_t*)(ws + L.off_act_count), st, false,
                      (unsigned long long*)(ws + L.off_hdr), layout_hash, ws + L.off_tile_clean,
-                     (int32_t*)(ws + L.off_seed_count));                                         // cifcaf.cpp:140-141
+                     (int32_t*)(ws + L.off_seed_count), &pool);                                  // cifcaf.cpp:140-141
     if (e != hipSuccess) return fail_hip(e, "cifhr");
     // CafScored::fill (:153-161) of the caf_th list set and, for force complete, of the second one (:419-420): launches of
     // their own.  (OPA_FUSE_SCORED=1 lets them ride in the seed sort's launch, two 512-thread groups per workgroup beside
@@ -396,28 +423,31 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
                                           (float*)(ws + L.off_lists), (int32_t*)(ws + L.off_list_counts),
                                           (float*)(ws + L.off_list_bbox),
                                           L.bbox_chunks < kListBboxChunks ? L.bbox_chunks : kListBboxChunks, L.bbox_chunks,
-                                          nullptr);   // (cells past caf_th point at joints: touched tiles; the bitmap would only add a dependent load)
+                                          nullptr, &pool);   // (pooled map: the slot table says which tiles exist)
     if (p.force_complete)
         scored[n_scored++] = make_scored_args(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols,
                                               L.hr_pitch, dec->dev.skeleton, p.force_complete_caf_th, 0.1,
                                               p.ablation_caf_no_rescore, (float*)(ws + L.off_lists_fc),
                                               (int32_t*)(ws + L.off_list_counts_fc), (float*)(ws + L.off_list_bbox_fc),
-                                              L.bbox_chunks, L.bbox_chunks, tile_touch);
+                                              L.bbox_chunks, L.bbox_chunks, nullptr, &pool);
     const char* fuse_env = std::getenv("OPA_FUSE_SCORED");
     const bool fuse = fuse_env && std::atoi(fuse_env) != 0;
     TieScratch ties;
     ties.big = ws + L.off_act; ties.big_stride = (size_t)L.F * 4 * (L.H * L.W) * sizeof(float);
     ties.small_ = ws + L.off_tie_small; ties.small_stride = L.tie_small_stride;
     ties.state = (int32_t*)(ws + L.off_tie_state);
-    // inside the decode the tie pass runs in the association kernel (every image its own, before its seeds are read)
+    // OPA_FUSE_TIES=1: the tie pass runs in the association kernel instead of a launch of its own (every image its own
+    // ties, before its seeds are read).  Measured in round 4: the decode gets 2 % shorter, not 9 % -- the images with the
+    // most seeds are both the likeliest to hold equal scores and the slowest to associate -- so the separate launch,
+    // whose time shows up under its own name, stays the default.
     const char* fuse_ties_env = std::getenv("OPA_FUSE_TIES");
-    const bool fuse_ties = seed_tie_order() == 1 && !(fuse_ties_env && std::atoi(fuse_ties_env) == 0);
+    const bool fuse_ties = seed_tie_order() == 1 && fuse_ties_env && std::atoi(fuse_ties_env) != 0;
     ties.defer = fuse_ties ? 1 : 0;
     e = launch_cifseeds(cif_dev, L.B, L.F, L.H, L.W, L.stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
                         (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap,
                         (int32_t*)(ws + L.off_seed_count), (int32_t*)(ws + L.off_seed_f),
                         (float*)(ws + L.off_seed_vxys), st, false, (int32_t*)(ws + L.off_seed_cell),
-                        L.occ_h, L.occ_w, true, fuse ? scored : nullptr, fuse ? n_scored : 0, &ties);   // :144-146
+                        L.occ_h, L.occ_w, true, fuse ? scored : nullptr, fuse ? n_scored : 0, &ties, &pool);   // :144-146
     if (e != hipSuccess) return fail_hip(e, "cifseeds");
     if (!fuse)
         for (int k = 0; k < n_scored; k++) {
@@ -445,6 +475,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     a.initial = initial_dev; a.initial_ids = initial_ids_dev;
     a.out = out_dev; a.out_ids = out_ids_dev; a.out_count = out_count_dev;
     a.status = (int32_t*)(ws + L.off_status);
+    a.hr_overflow = pool.overflow;
     a.tie_fused = fuse_ties ? 1 : 0;
     make_tie_args(&a.tie, &a.tie_sort, (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap, (int32_t*)(ws + L.off_seed_count), cif_dev,
                   L.F, 5, L.H * L.W, L.stride, (int32_t*)(ws + L.off_seed_f), (float*)(ws + L.off_seed_vxys),

@@ -1453,7 +1453,7 @@ __device__ __forceinline__ NmsLds nms_carve(unsigned char* work_base, int max_an
 }
 template <int kThreads>
 __device__ __forceinline__ void nms_and_store(const AssocArgs& a, const DevParams& p, const ImageCtx& c, const NmsLds& l, int b,
-                                              int n_kept, int n_dropped, bool failed, double* anns, const int64_t* ann_ids,
+                                              int n_kept, int n_dropped, int failed, double* anns, const int64_t* ann_ids,
                                               int nms_waves) {
     const int tid = threadIdx.x, lane = lane_id(), wave = c.wave, K = a.K;
     const int KC = (K + kWave - 1) / kWave;
@@ -1561,7 +1561,7 @@ __device__ __forceinline__ void nms_and_store(const AssocArgs& a, const DevParam
     if (tid == 0) {
         // rows [0, n_out) are valid; poses dropped for lack of capacity raise the overflow flag
         a.out_count[b] = n_out | (n_dropped > 0 ? OPA_COUNT_OVERFLOW : 0) | (failed ? OPA_COUNT_FAILED : 0);
-        a.status[b] = failed ? -1 : n_dropped;
+        a.status[b] = failed ? -failed : n_dropped;      // (failure codes: see the seed kernel)
     }
 }
 
@@ -2207,7 +2207,10 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             __builtin_amdgcn_s_sleep(1);
         if (wall_clock64() - t_kernel > kWatchdogTicks) watchdog = true;
         if (lane == 0) {
-            sh_ctl[1] = watchdog ? 0 : n_kept; sh_ctl[2] = n_dropped; sh_ctl[5] = watchdog ? 1 : 0;
+            // failure codes (the image then reports no poses and OPA_COUNT_FAILED, its status word is minus the code):
+            // 1 the watchdog fired, 2 the image's CIF map did not fit its tile pool (every lookup into a missing tile was wrong)
+            const int fail_code = watchdog ? 1 : (a.hr_overflow && a.hr_overflow[b] != 0) ? 2 : 0;
+            sh_ctl[1] = fail_code ? 0 : n_kept; sh_ctl[2] = n_dropped; sh_ctl[5] = fail_code;
             flag_store(&sh_ctl[0], 1);                   // growers leave
         }
         __builtin_amdgcn_s_setprio(0);
@@ -2306,7 +2309,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         }
     } else {
         const NmsLds nl = nms_carve(work_base, a.max_ann, K);
-        nms_and_store<kThreads>(a, p, c, nl, b, n_kept, n_dropped, sh_ctl[5] != 0, anns, ann_ids, nms_waves);
+        nms_and_store<kThreads>(a, p, c, nl, b, n_kept, n_dropped, sh_ctl[5], anns, ann_ids, nms_waves);
     }
     if (tid == 0 && a.stats) {
         sh_stats[9] = (int)(wall_clock64() - t_kernel);
@@ -2404,7 +2407,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_fc_kernel(AssocArgs a, D
     if (!sh_last[0]) return;
     __threadfence();
     const NmsLds nl = nms_carve(work_base, a.max_ann, K);
-    nms_and_store<kThreads>(a, p, c, nl, b, failed ? 0 : n_kept, n_dropped, failed != 0, anns, ann_ids, nms_waves);
+    nms_and_store<kThreads>(a, p, c, nl, b, failed ? 0 : n_kept, n_dropped, failed, anns, ann_ids, nms_waves);
 }
 
 template <bool REG, int NW>

@@ -47,10 +47,14 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
         float neighbors_f, double factor, float* __restrict__ act, int32_t* __restrict__ act_count,
         unsigned long long* ws_header, unsigned long long layout_hash,
         unsigned* __restrict__ tile_touch, int touch_words, int rows, int cols, int tiles_x,
-        int32_t* __restrict__ zero_per_image, int F) {
+        int32_t* __restrict__ zero_per_image, int F, HrPool pool) {
     __shared__ int wave_tot[2][kActiveCells][kActiveThreads / 64];
     const int plane = blockIdx.x;
     if (zero_per_image && threadIdx.x == 0 && plane % F == 0) zero_per_image[plane / F] = 0;   // the image's seed counter
+    if (pool.slot) {                                  // pooled map: no tile of this plane has a slot yet
+        for (int k = threadIdx.x; k < pool.tpp; k += kActiveThreads) pool.slot[(size_t)plane * pool.tpp + k] = -1;
+        if (threadIdx.x == 0 && plane % F == 0) pool.overflow[plane / F] = 0;
+    }
     unsigned* touch = tile_touch ? tile_touch + (size_t)plane * touch_words : nullptr;   // one bit per tile of this plane
     if (touch) {
         for (int k = threadIdx.x; k < touch_words; k += kActiveThreads) touch[k] = 0u;
@@ -138,6 +142,22 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
         }
     }
     if (tid == 0) act_count[plane] = base;
+    if (pool.slot) {                                  // how many tiles this plane's cells reach: the tile kernel places the planes' tiles
+        __threadfence();                              // in the image's pool from these counts (this workgroup's atomics are at the L2)
+        __syncthreads();
+        int n = 0;
+        for (int k = tid; k < touch_words; k += kActiveThreads)
+            n += __popc(__hip_atomic_load(&touch[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        for (int d = 32; d > 0; d >>= 1) n += __shfl_xor(n, d, 64);
+        __shared__ int tile_tot[kActiveThreads / 64];
+        if (lane == 0) tile_tot[w] = n;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int k = 0; k < kActiveThreads / 64; k++) t += tile_tot[k];
+            pool.plane_count[plane] = t;
+        }
+    }
 }
 
 // cif_hr.cpp:18-25.  The reference evaluates `1.0 + x / 8.0` and the caller's `-0.5 * d2 / sigma2` in double
@@ -154,16 +174,18 @@ __device__ __forceinline__ float approx_exp(float x) {
 // The four waves of a workgroup build one 32x64 tile in LDS, each its own band of 8 rows (pixels are
 // independent of each other; only the order of the cells applied to ONE pixel matters), and write it out.
 constexpr int kBandH = kHrTileH / 4;
+// `out`: where the tile's pixel (0, 0) goes, `out_pitch` floats per tile row (the dense map: hr_plane + ytile * pitch + x0
+// with the map's pitch; a pool slot: the slot's 32x64 block, pitch 64); `clip_rows`: rows below the map are not written.
 __device__ __forceinline__ void build_tile(const float* __restrict__ A, int n, int HW, float* __restrict__ T,
-                                           float* __restrict__ hr_plane, int rows, int cols, int pitch,
+                                           float* __restrict__ out, int out_pitch, bool clip_rows, int rows, int cols,
                                            int tx, int ty, int band, bool touched) {
     const int lane = threadIdx.x & 63;
     const int lx = lane & 15, ly = lane >> 4;
     const int x0 = tx * kHrTileW, ytile = ty * kHrTileH, y0 = ytile + band * kBandH;
     if (!touched) {                                   // no cell reaches this tile: it only has to be zero
         for (int r = ly; r < kBandH; r += 4)
-            if (y0 + r < rows)
-                *reinterpret_cast<float4*>(hr_plane + (size_t)(y0 + r) * pitch + x0 + lx * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!clip_rows || y0 + r < rows)
+                *reinterpret_cast<float4*>(out + (size_t)(band * kBandH + r) * out_pitch + lx * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
     const int x1 = min(x0 + kHrTileW, cols), y1 = min(y0 + kBandH, rows);
@@ -225,9 +247,9 @@ __device__ __forceinline__ void build_tile(const float* __restrict__ A, int n, i
     // coalesced write-out: 16 lanes x float4 = one 256-B tile row, 4 rows per instruction
     for (int r = ly; r < kBandH; r += 4) {
         const int yy = y0 + r;
-        if (yy < rows) {
+        if (!clip_rows || yy < rows) {
             const float4 val = *reinterpret_cast<const float4*>(T + r * kHrLdsPitch + lx * 4);
-            *reinterpret_cast<float4*>(hr_plane + (size_t)yy * pitch + x0 + lx * 4) = val;
+            *reinterpret_cast<float4*>(out + (size_t)(band * kBandH + r) * out_pitch + lx * 4) = val;
         }
     }
 }
@@ -247,7 +269,7 @@ __global__ __launch_bounds__(256) void cifhr_tile_kernel(
         const float* __restrict__ act, const int32_t* __restrict__ act_count, int HW,
         float* __restrict__ hr, int rows, int cols, int pitch, int tiles_x, int tiles_y,
         const unsigned long long* __restrict__ ws_header, const unsigned* __restrict__ tile_prev,
-        const unsigned* __restrict__ tile_cur, int touch_words) {
+        const unsigned* __restrict__ tile_cur, int touch_words, HrPool pool, int F) {
     __shared__ __attribute__((aligned(16))) float T[kHrTileH * kHrLdsPitch];
     const int band = threadIdx.x >> 6;
     const int g = blockIdx.x % kTileGroups;          // this workgroup's number within the plane
@@ -256,17 +278,30 @@ __global__ __launch_bounds__(256) void cifhr_tile_kernel(
     const int n = act_count[plane];
     const float* A = act + (size_t)plane * 4 * HW;
     float* hr_plane = hr + (size_t)plane * rows * pitch;
+    const bool pooled = pool.slot != nullptr;
     const bool stateful = tile_cur != nullptr;
-    const bool valid = stateful && ws_header[2] == 0ull;
+    const bool valid = stateful && !pooled && ws_header[2] == 0ull;
     int k = 0;                                       // running index of the tiles that need work, dealt round-robin
     const int lane = threadIdx.x & 63;
+    // Pooled map: the touched tiles of the image's planes stand one after the other in its pool, in plane order and, inside
+    // a plane, in bitmap order -- the k-th touched tile of this plane has slot (tiles of the planes before it) + k.
+    int plane_base = 0;
+    float* pool_image = nullptr;
+    if (pooled) {
+        const int b = plane / F, f = plane - b * F;
+        int before = 0;
+        for (int q = lane; q < f; q += 64) before += pool.plane_count[b * F + q];
+        for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
+        plane_base = before;
+        pool_image = hr + (size_t)b * pool.cap * (kHrTileH * kHrTileW);
+    }
     for (int w0 = 0; w0 < touch_words; w0 += 64) {   // 64 bitmap words per step: one load per lane, then readlane
         const int wl = w0 + lane;
         unsigned my_need = 0u, my_cur = 0u;
         if (wl < touch_words) {
             const unsigned in_range = tpp - wl * 32 >= 32 ? 0xFFFFFFFFu : (1u << (tpp - wl * 32)) - 1u;
             my_cur = stateful ? tile_cur[(size_t)plane * touch_words + wl] : in_range;
-            const unsigned prev = valid ? tile_prev[(size_t)plane * touch_words + wl] : in_range;
+            const unsigned prev = pooled ? 0u : valid ? tile_prev[(size_t)plane * touch_words + wl] : in_range;   // (a pool has no stale tiles)
             my_need = (my_cur | prev) & in_range;
         }
         unsigned long long words = __ballot(my_need != 0u);
@@ -281,7 +316,18 @@ __global__ __launch_bounds__(256) void cifhr_tile_kernel(
                 if ((k++ % kTileGroups) != g) continue;
                 const int t = (w0 + wi) * 32 + bit;
                 const int ty = t / tiles_x, tx = t - ty * tiles_x;
-                build_tile(A, n, HW, T, hr_plane, rows, cols, pitch, tx, ty, band, (cur >> bit) & 1u);
+                if (pooled) {
+                    const int sl = plane_base + k - 1;
+                    if (sl >= pool.cap) {             // more tiles than the pool holds: the image is flagged, not decoded wrongly
+                        if (threadIdx.x == 0) { pool.slot[(size_t)plane * tpp + t] = -2; pool.overflow[plane / F] = 1; }
+                        continue;
+                    }
+                    if (threadIdx.x == 0) pool.slot[(size_t)plane * tpp + t] = sl;
+                    build_tile(A, n, HW, T, pool_image + (size_t)sl * (kHrTileH * kHrTileW), kHrTileW, false, rows, cols, tx, ty, band, true);
+                } else {
+                    build_tile(A, n, HW, T, hr_plane + (size_t)ty * kHrTileH * pitch + tx * kHrTileW, pitch, true, rows, cols, tx, ty,
+                               band, (cur >> bit) & 1u);
+                }
             }
         }
     }
@@ -299,19 +345,27 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
                         float* cifhr, int hr_rows, int hr_pitch,
                         float* act, int32_t* act_count, hipStream_t st, bool det,
                         unsigned long long* ws_header, unsigned long long layout_hash, unsigned char* tile_state,
-                        int32_t* zero_per_image) {
+                        int32_t* zero_per_image, const HrPool* pool_in) {
     const int planes = B * F, HW = H * W;
     const int hr_cols = (W - 1) * stride + 1;
     const int tiles_x = hr_pitch / kHrTileW;
     const int tiles_y = (hr_rows + kHrTileH - 1) / kHrTileH;
     // two per-plane tile bitmaps in the workspace region `tile_state`: previous call, this call
     const int touch_words = (tiles_x * tiles_y + 31) / 32;
+    HrPool pool; pool.slot = nullptr; pool.plane_count = nullptr; pool.overflow = nullptr; pool.cap = 0; pool.tpp = tiles_x * tiles_y;
+    if (pool_in) pool = *pool_in;
     unsigned* tile_prev = ws_header ? reinterpret_cast<unsigned*>(tile_state) : nullptr;
     unsigned* tile_touch = ws_header ? tile_prev + (size_t)planes * touch_words : nullptr;
     if (p.ablation_cifhr_skip && !det) {              // cif_hr.cpp:29
         hipError_t e = hipMemsetAsync(act_count, 0, sizeof(int32_t) * planes, st);
         if (e != hipSuccess) return e;
         if (zero_per_image) { e = hipMemsetAsync(zero_per_image, 0, sizeof(int32_t) * B, st); if (e != hipSuccess) return e; }
+        if (pool.slot) {                              // pooled map, no cell: no tile has a slot
+            e = hipMemsetAsync(pool.slot, 0xFF, sizeof(int32_t) * (size_t)planes * pool.tpp, st);
+            if (e != hipSuccess) return e;
+            e = hipMemsetAsync(pool.overflow, 0, sizeof(int32_t) * B, st);
+            if (e != hipSuccess) return e;
+        }
         prof_mark(st, "memset_act_count");
         if (ws_header) {                              // no kernel validates the flags on this path: invalidate them
             e = hipMemsetAsync(ws_header, 0xFF, 32, st);
@@ -324,20 +378,38 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
         if (det)
             cif_active_kernel<true><<<planes, kActiveThreads, 0, st>>>(cif, HW, stride, min_scale_f, p.cif_threshold,
                                                              (float)p.cifhr_neighbors, factor, act, act_count, ws_header, layout_hash,
-                                                             tile_touch, touch_words, hr_rows, hr_cols, tiles_x, zero_per_image, F);
+                                                             tile_touch, touch_words, hr_rows, hr_cols, tiles_x, zero_per_image, F, pool);
         else
             cif_active_kernel<false><<<planes, kActiveThreads, 0, st>>>(cif, HW, stride, min_scale_f, p.cif_threshold,
                                                               (float)p.cifhr_neighbors, factor, act, act_count, ws_header, layout_hash,
-                                                              tile_touch, touch_words, hr_rows, hr_cols, tiles_x, zero_per_image, F);
+                                                              tile_touch, touch_words, hr_rows, hr_cols, tiles_x, zero_per_image, F, pool);
         prof_mark(st, "cif_active_kernel");
     }
     cifhr_tile_kernel<<<planes * kTileGroups, 256, 0, st>>>(act, act_count, HW, cifhr, hr_rows, hr_cols, hr_pitch,
-                                                             tiles_x, tiles_y, ws_header, tile_prev, tile_touch, touch_words);
-    if (ws_header) {                                  // this call's bitmap is the next call's "previous"
+                                                             tiles_x, tiles_y, ws_header, tile_prev, tile_touch, touch_words, pool, F);
+    if (ws_header && !pool.slot) {                    // this call's bitmap is the next call's "previous" (a pooled map keeps no state)
         const int n = touch_words * planes;
         tile_state_roll_kernel<<<(n + 255) / 256, 256, 0, st>>>(tile_prev, tile_touch, n);
     }
     prof_mark(st, "cifhr_tile_kernel");
+    return hipGetLastError();
+}
+
+// get_cifhr of a pooled map: one image's [F][rows][cols] array (0.0 where no tile was built, like the dense buffer)
+__global__ __launch_bounds__(256) void cifhr_gather_kernel(const float* __restrict__ pool_image, const int32_t* __restrict__ slot_image,
+                                                           int F, int rows, int cols, int tiles_x, int tpp, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)F * rows * cols;
+    if (i >= n) return;
+    const int x = (int)(i % cols), y = (int)((i / cols) % rows), f = (int)(i / ((size_t)cols * rows));
+    const int sl = slot_image[(size_t)f * tpp + (y / kHrTileH) * tiles_x + x / kHrTileW];
+    out[i] = sl < 0 ? 0.0f : pool_image[(size_t)sl * (kHrTileH * kHrTileW) + (y % kHrTileH) * kHrTileW + (x % kHrTileW)];
+}
+
+hipError_t launch_cifhr_gather(const float* pool_image, const int32_t* slot_image, int F, int rows, int cols, int tiles_x, int tpp,
+                               float* out, hipStream_t st) {
+    const size_t n = (size_t)F * rows * cols;
+    cifhr_gather_kernel<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(pool_image, slot_image, F, rows, cols, tiles_x, tpp, out);
     return hipGetLastError();
 }
 

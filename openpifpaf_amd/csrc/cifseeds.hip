@@ -28,7 +28,8 @@ __global__ __launch_bounds__(256) void cifseeds_fill_kernel(
         const float* __restrict__ cifhr, int hr_rows, int hr_cols, int hr_pitch,
         double threshold, int ablation_nms, int no_rescore,
         unsigned long long* __restrict__ keys, int sort_cap, int cap, int32_t* __restrict__ seed_count,
-        int2* __restrict__ wg_tab, size_t tab_stride, unsigned long long* __restrict__ key_copy, size_t copy_stride) {
+        int2* __restrict__ wg_tab, size_t tab_stride, unsigned long long* __restrict__ key_copy, size_t copy_stride,
+        const int32_t* __restrict__ hr_slot, int hr_tpp, size_t hr_image_stride) {
     const int HW = H * W;
     const int plane = blockIdx.x;              // b*F + f
     const int b = plane / F, f = plane - b * F;
@@ -61,8 +62,8 @@ __global__ __launch_bounds__(256) void cifseeds_fill_kernel(
                 const float x = xin[r] * (float)stride;              // :53-54
                 const float y = yin[r] * (float)stride;
                 if (!no_rescore) {                                   // :56-58
-                    const float hv = cifhr_value(cifhr + (size_t)b * F * hr_rows * hr_pitch,
-                                                 F, hr_rows, hr_cols, hr_pitch, f, x, y, -1.0f);
+                    const float hv = cifhr_value(cifhr + (size_t)b * hr_image_stride, F, hr_rows, hr_cols, hr_pitch, f, x, y, -1.0f,
+                                                 nullptr, 0, hr_pitch / kHrTileW, hr_slot ? hr_slot + (size_t)b * F * hr_tpp : nullptr, hr_tpp);
                     c[r] = (float)(0.9 * (double)hv + 0.1 * (double)c[r]);
                 }
                 if ((double)c[r] < threshold) on[r] = false;         // :59
@@ -411,7 +412,7 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
                            unsigned long long* keys, int sort_cap, int32_t* seed_count,
                            int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det,
                            int32_t* seed_cell, int occ_h, int occ_w, bool count_is_zero,
-                           const ScoredArgs* scored, int n_scored, const TieScratch* ties) {
+                           const ScoredArgs* scored, int n_scored, const TieScratch* ties, const HrPool* pool) {
     static_assert(kScoredThreads == 512, "the fused launch packs two cafscored groups into a 1024-thread workgroup");
     const int HW = H * W, cap = F * HW, NC = det ? 6 : 5;
     if (!count_is_zero) {                             // (the decode pipeline clears the counters in its first kernel)
@@ -427,7 +428,9 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
                                                tie_pass ? (int2*)ties->small_ : nullptr,
                                                tie_pass ? ties->small_stride / sizeof(int2) : 0,
                                                tie_pass ? tie_key_copy(ties->big, cap) : nullptr,
-                                               tie_pass ? ties->big_stride / sizeof(unsigned long long) : 0);
+                                               tie_pass ? ties->big_stride / sizeof(unsigned long long) : 0,
+                                               pool ? pool->slot : nullptr, pool ? pool->tpp : 0,
+                                               pool ? (size_t)pool->cap * kHrTileH * kHrTileW : (size_t)F * hr_rows * hr_pitch);
     prof_mark(st, "cifseeds_fill_kernel");
     SortArgs g;
     g.keys = keys; g.sort_cap = sort_cap; g.cap = cap; g.seed_count = seed_count; g.cif = cif; g.F = F; g.NC = NC; g.HW = HW;

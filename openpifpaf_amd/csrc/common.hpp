@@ -24,6 +24,7 @@ struct Layout {
     // shapes
     int B, F, K, A, H, W, cH, cW, stride, cstride, max_ann;     // F CIF fields, K >= F joints per annotation
     int hr_rows, hr_cols, hr_pitch;       // high-res map geometry
+    int hr_tpp, hr_pool_cap;              // 32x64 tiles per plane; slots of one image's tile pool (opa_shape::cifhr_pool_tiles)
     int occ_h, occ_w;                     // occupancy geometry
     int cif_cells;                        // F*H*W  (seed capacity)
     int caf_cells;                        // cH*cW  (list capacity per (field, direction))
@@ -38,6 +39,7 @@ struct Layout {
     // scratch of the seed tie pass (cifseeds.hip): `big` lies in the active-cell list (dead once the map is built, and
     // exactly as large), `small` in the occupancy bitmap (cleared by the association kernel afterwards) where it fits
     size_t off_tie_small, tie_small_stride, off_tie_state;
+    size_t off_hr_slot, off_hr_plane_count, off_hr_overflow;   // the pooled map's slot tables [B][F][tpp], plane counts, overflow flags
 };
 
 bool make_layout(const opa_shape& s, Layout* L, const char** why);
@@ -71,12 +73,27 @@ struct DevSkeleton {
 void prof_mark(hipStream_t st, const char* name);
 
 // ---- kernel launchers (one per .hip file) ---------------------------------
+// The CifHr map of the decode path is a POOL of 32x64 tiles per image: only tiles a CIF cell's box reaches get a slot
+// (a few hundred of the 3927 of a 641-px COCO image), nothing is cleared, nothing carries over between calls.
+// `cifhr` then points at the pools ([B][cap] tiles); with `pool == nullptr` the map is the dense [B][F][rows][pitch] array of
+// the stage-level entry points.
+struct HrPool {
+    int32_t* slot;         // [B][F][tpp] tile -> slot in its image's pool; -1: untouched, -2: the pool was full
+    int32_t* plane_count;  // [B][F] touched tiles of a plane (cif_active -> cifhr_tile)
+    int32_t* overflow;     // [B] set when an image reaches more tiles than its pool holds (the decode then flags the image failed)
+    int cap;               // slots per image
+    int tpp;               // tiles per plane
+};
 hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride,
                         double min_scale, double factor, const DevParams& p,
                         float* cifhr, int hr_rows, int hr_pitch,
                         float* act, int32_t* act_count, hipStream_t st, bool det = false,
                         unsigned long long* ws_header = nullptr, unsigned long long layout_hash = 0,
-                        unsigned char* tile_state = nullptr, int32_t* zero_per_image = nullptr);
+                        unsigned char* tile_state = nullptr, int32_t* zero_per_image = nullptr,
+                        const HrPool* pool = nullptr);
+// one image's map as the dense [F][rows][cols] array (get_cifhr of a pooled map)
+hipError_t launch_cifhr_gather(const float* pool_image, const int32_t* slot_image, int F, int rows, int cols, int tiles_x, int tpp,
+                               float* out, hipStream_t st);
 
 // Workspace header (first 256 bytes): [0] magic, [1] hash of the layout the stored tile bitmap describes,
 // [2] 1 = stored bitmap invalid for this call (written by the first kernel of a call).
@@ -96,7 +113,8 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
                            unsigned long long* keys, int sort_cap, int32_t* seed_count,
                            int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det = false,
                            int32_t* seed_cell = nullptr, int occ_h = 0, int occ_w = 0, bool count_is_zero = false,
-                           const ScoredArgs* scored = nullptr, int n_scored = 0, const TieScratch* ties = nullptr);
+                           const ScoredArgs* scored = nullptr, int n_scored = 0, const TieScratch* ties = nullptr,
+                           const HrPool* pool = nullptr);
 // (`scored`: up to two CafScored list sets built by the SAME launch as the seed sort -- they only share the finished
 // map, and the sort's few workgroups leave the chip to them)
 
@@ -107,6 +125,8 @@ struct ScoredArgs {
     const int64_t* skeleton; double score_th, cif_floor; int no_rescore;
     float* lists; int32_t* counts;
     const unsigned* tile_touch; int touch_words, tiles_x;   // [B][F][touch_words] touched-tile bitmaps of the map (or null)
+    const int32_t* hr_slot; int hr_tpp;       // pooled map: [B][F][hr_tpp] slot tables (null: dense map)
+    size_t hr_image_stride;                   // floats between the maps of two images (dense: F * rows * pitch; pooled: cap * tile)
     float* chunk_bbox; int nb, nb_stride;     // nb: chunks per list that get a box (the first kListBboxChunks for the caf_th
                                               // set; all of them for the force-complete set); nb_stride: boxes per list in memory
     int planes;                               // B * A
@@ -116,7 +136,7 @@ ScoredArgs make_scored_args(const float* caf, int B, int A, int cH, int cW, int 
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
                             float* lists, int32_t* counts, float* chunk_bbox, int bbox_chunks, int bbox_stride,
-                            const unsigned* tile_touch = nullptr);
+                            const unsigned* tile_touch = nullptr, const HrPool* pool = nullptr);
 
 hipError_t launch_cafscored(const ScoredArgs& s, hipStream_t st);
 hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
@@ -166,6 +186,7 @@ struct AssocArgs {
     const float* list_bbox;  // [B][A][2][bbox_chunks][4] chunk boxes of `lists` (or null)
     const float* list_bbox_fc;  // ... of `lists_fc` (or null)
     int bbox_chunks;
+    const int32_t* hr_overflow; // [B] (or null): 1 = the image's CIF map did not fit its tile pool -- the image is flagged failed (status -2)
     int tie_fused;              // 1: every workgroup first puts its image's seeds of equal score into the reference's order (tie, tie_sort)
     TieArgs tie; SortArgs tie_sort;
     int timing;                 // 1: the coordinator also fills the tick counters of its phases (statistics slots 12, 17-20)
@@ -273,19 +294,30 @@ __device__ __forceinline__ int seed_cell_pack(const DevParams& p, int occ_h, int
 // ([F][touch_words] words, written by cif_active_kernel): a pixel of any other tile is 0.0 in the buffer (never
 // written, or zeroed by the lazy clear), i.e. "untouched", so its value is known without the gather -- most of a
 // map is such tiles, and a random 4-byte gather costs a whole memory line.
+// `slot` (or null): the map is a POOL of 32x64 tiles (decode path): `hr_image` is the image's pool, `slot` its table
+// [F][tpp] tile -> slot (negative: no cell reached the tile, i.e. untouched) -- one small load instead of the bitmap test.
 __device__ __forceinline__ float cifhr_value(const float* hr_image, int F, int rows, int cols, int pitch,
                                              long long f, float x, float y, float default_value,
-                                             const unsigned* touch = nullptr, int touch_words = 0, int tiles_x = 0) {
+                                             const unsigned* touch = nullptr, int touch_words = 0, int tiles_x = 0,
+                                             const int32_t* slot = nullptr, int tpp = 0) {
     const float max_x = (float)((double)(float)cols - 0.51);
     const float max_y = (float)((double)(float)rows - 0.51);
     if (f >= F || (double)x < -0.49 || (double)y < -0.49 || x > max_x || y > max_y) return default_value;
     const long long yi = (long long)((double)y + 0.5);
     const long long xi = (long long)((double)x + 0.5);
-    if (touch) {
+    float raw;
+    if (slot) {
         const int t = (int)(yi / kHrTileH) * tiles_x + (int)(xi / kHrTileW);
-        if (!((touch[(size_t)f * touch_words + (t >> 5)] >> (t & 31)) & 1u)) return default_value;
+        const int sl = slot[(size_t)f * tpp + t];
+        if (sl < 0) return default_value;
+        raw = hr_image[(size_t)sl * (kHrTileH * kHrTileW) + (size_t)(yi % kHrTileH) * kHrTileW + (size_t)(xi % kHrTileW)];
+    } else {
+        if (touch) {
+            const int t = (int)(yi / kHrTileH) * tiles_x + (int)(xi / kHrTileW);
+            if (!((touch[(size_t)f * touch_words + (t >> 5)] >> (t & 31)) & 1u)) return default_value;
+        }
+        raw = hr_image[((size_t)f * rows + yi) * pitch + xi];
     }
-    const float raw = hr_image[((size_t)f * rows + yi) * pitch + xi];
     const float value = (float)((double)raw - 1.0);
     if ((double)value < 0.0) return default_value;
     return value;

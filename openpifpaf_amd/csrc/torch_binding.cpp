@@ -61,6 +61,7 @@ struct CifCaf : torch::CustomClassHolder {
     opa_cifcaf* handle = nullptr;
     torch::Tensor workspace;         // caller-owned device workspace of the last call
     opa_shape last_shape{};
+    int64_t cifhr_pool_tiles = 0;                    // opa_shape::cifhr_pool_tiles of the next decode
     bool has_last = false;
 
     CifCaf(int64_t n_keypoints_, const torch::Tensor& skeleton_) : n_keypoints(n_keypoints_) {
@@ -87,6 +88,7 @@ struct CifCaf : torch::CustomClassHolder {
         s.cif_stride = (int32_t)cif_stride; s.caf_stride = (int32_t)caf_stride;
         s.max_annotations = (int32_t)max_annotations;
         s.n_keypoints = (int32_t)n_keypoints;        // > n_cif in the tracking setup
+        s.cifhr_pool_tiles = (int32_t)cifhr_pool_tiles;   // 0: automatic (an eighth of the map); -1 after an image did not fit
         // (the decode below runs with the process-global tunables: without force_complete the second list set is left out)
         const size_t need = opa_cifcaf_workspace_bytes_for(&s, nullptr);
         TORCH_CHECK(need > 0, "opa_cifcaf_workspace_bytes_for: ", opa_last_error());
@@ -130,9 +132,16 @@ struct CifCaf : torch::CustomClassHolder {
         if (initial.has_value()) ia = initial->unsqueeze(0);
         if (initial_ids.has_value()) ii = initial_ids->unsqueeze(0);
         auto [out, ids, counts] = call_batch_impl(cif.unsqueeze(0), cif_stride, caf.unsqueeze(0), caf_stride, ia, ii);
-        const int64_t c = counts.cpu().item<int32_t>();
-        TORCH_CHECK(!(c & OPA_COUNT_FAILED), "the association kernel gave up on the image (watchdog, status -1): "
-                    "the decode is invalid");
+        int64_t c = counts.cpu().item<int32_t>();
+        if ((c & OPA_COUNT_FAILED) && cifhr_pool_tiles == 0) {
+            // most likely the image's CIF cells reach more map tiles than the automatic pool holds (structureless
+            // all-active fields do): once more with a pool that holds every tile
+            cifhr_pool_tiles = -1;
+            std::tie(out, ids, counts) = call_batch_impl(cif.unsqueeze(0), cif_stride, caf.unsqueeze(0), caf_stride, ia, ii);
+            c = counts.cpu().item<int32_t>();
+        }
+        TORCH_CHECK(!(c & OPA_COUNT_FAILED), "the decode of the image failed (the association kernel's watchdog, status -1, "
+                    "or a CIF map beyond its tile pool, status -2): the result is invalid");
         TORCH_CHECK(!(c & OPA_COUNT_OVERFLOW), "annotation capacity overflow: poses were dropped; call "
                     "set_max_annotations with a larger value");
         const int64_t n = OPA_COUNT_ROWS(c);
@@ -153,8 +162,11 @@ struct CifCaf : torch::CustomClassHolder {
         size_t off = 0; int32_t rows = 0, cols = 0, pitch = 0; double rev = 0.0;
         check(opa_cifcaf_cifhr_view(&last_shape, &off, &rows, &cols, &pitch, &rev), "opa_cifcaf_cifhr_view");
         const int64_t F = last_shape.n_cif;
-        torch::Tensor flat = workspace.narrow(0, (int64_t)off * 4, F * rows * pitch * 4).view(torch::kFloat32);
-        return std::make_tuple(flat.view({F, rows, pitch}).narrow(2, 0, cols), rev);
+        // the decode keeps the map as a pool of tiles: gathered into the dense array the reference returns
+        torch::Tensor dense = torch::empty({F, rows, cols}, torch::dtype(torch::kFloat32).device(workspace.device()));
+        check(opa_cifcaf_get_cifhr(&last_shape, workspace.data_ptr(), 0, dense.data_ptr<float>(), current_stream(workspace)),
+              "opa_cifcaf_get_cifhr");
+        return std::make_tuple(dense, rev);
     }
 };
 

@@ -249,8 +249,9 @@ class CifCaf(Decoder):
     class Pending:
         """A batch in flight: ``result()`` waits for ITS decode only (an event on its lane) and builds the annotations."""
 
-        def __init__(self, owner, lane, event, host, n_images, t_submit):
+        def __init__(self, owner, lane, event, host, n_images, t_submit, fields=None):
             self.owner, self.lane, self.event, self.host, self.n_images, self.t_submit = owner, lane, event, host, n_images, t_submit
+            self.fields = fields                 # (cif, caf, meta_batch): kept for the one case a decode is repeated (below)
             self._result = None
 
         def done(self):
@@ -260,11 +261,29 @@ class CifCaf(Decoder):
             if self._result is None:
                 self.event.synchronize()
                 out, ids, counts = (t.numpy() for t in self.host)
+                if (counts[:self.n_images] & native.COUNT_FAILED).any() and self.fields is not None and \
+                        self.owner._lanes.decoders[self.lane].pool_overflowed():
+                    # an image's CIF map did not fit the automatic tile pool (structureless, all-active fields): from now
+                    # on every lane uses a pool that holds the whole map, and this batch is decoded again, synchronously
+                    out, ids, counts = self.owner._decode_again_with_full_pool(*self.fields)
+                self.fields = None
                 self._result = self.owner._annotations_from_host(out, ids, counts[:self.n_images])
                 self.owner.last_decoder_time = time.perf_counter() - self.t_submit
                 if self.owner._lane_pending.get(self.lane) is self:
                     del self.owner._lane_pending[self.lane]
             return self._result
+
+    def _decode_again_with_full_pool(self, cif, caf, meta_batch):
+        for dec in [self.cpp_decoder] + (list(self._lanes.decoders) if getattr(self, '_lanes', None) is not None else []):
+            if dec.cifhr_pool_tiles != -1:
+                dec.use_full_pool()
+        LOG.warning('a CIF map reached more tiles than the automatic pool holds: decoding again with a full pool '
+                    '(CifCaf(..., cifhr_pool_tiles=\'full\') avoids the second decode)')
+        out, ids, counts = self.cpp_decoder.call_batch(cif, self.cif_metas[0].stride, caf, self.caf_metas[0].stride)
+        if meta_batch is not None:
+            from .annotation import inverse_transform_batch
+            out = inverse_transform_batch(out, meta_batch)
+        return out.cpu().numpy(), ids.cpu().numpy(), counts.cpu().numpy()
 
     def _annotations_from_host(self, out, ids, counts):
         native.check_counts(counts)                 # a watchdog failure raises instead of decoding to "no poses"
@@ -316,7 +335,7 @@ class CifCaf(Decoder):
             done = torch.cuda.Event()
             done.record(stream)
         self.last_nn_time = time.perf_counter() - t0               # host time to queue the network (it runs asynchronously)
-        pending = CifCaf.Pending(self, lane, done, host, B, t0)
+        pending = CifCaf.Pending(self, lane, done, host, B, t0, fields=(cif, caf, meta_batch))
         self._lane_pending[lane] = pending
         return pending
 
@@ -339,6 +358,9 @@ class CifCaf(Decoder):
             from .annotation import inverse_transform_batch
             out = inverse_transform_batch(out, meta_batch)
         out, ids, counts = out.cpu().numpy(), ids.cpu().numpy(), counts.cpu().numpy()   # one small D2H
+        if (counts & native.COUNT_FAILED).any() and self.cpp_decoder.pool_overflowed():
+            out, ids, counts = self._decode_again_with_full_pool(heads[self.cif_metas[0].head_index],
+                                                                 heads[self.caf_metas[0].head_index], meta_batch)
         result = self._annotations_from_host(out, ids, counts)
         self.last_decoder_time = time.perf_counter() - start_decoder
         LOG.debug('time: nn = %.1fms, dec = %.1fms', self.last_nn_time * 1e3, self.last_decoder_time * 1e3)

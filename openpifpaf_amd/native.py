@@ -53,8 +53,9 @@ def check_counts(counts):
     c = np.asarray(counts.cpu() if hasattr(counts, 'cpu') else counts).reshape(-1)
     bad = np.nonzero(c & COUNT_FAILED)[0]
     if len(bad):
-        raise _lib.NativeError('openpifpaf_amd: the association kernel gave up on image(s) %s of the batch (its '
-                               'watchdog fired, status -1); the decode of these images is invalid' % bad.tolist())
+        raise _lib.NativeError('openpifpaf_amd: the decode of image(s) %s of the batch failed (status -1: the association '
+                               'kernel\'s watchdog fired; status -2: the image\'s CIF map reaches more tiles than its pool holds -- '
+                               'CifCaf(..., cifhr_pool_tiles=\'full\') or use_full_pool()); their result is invalid' % bad.tolist())
 
 
 def set_quiet(quiet=True):
@@ -121,13 +122,20 @@ class CifCaf:
     get_force_complete, set_force_complete = _static_getset('force_complete', bool)
     get_force_complete_caf_th, set_force_complete_caf_th = _static_getset('force_complete_caf_th')
 
-    def __init__(self, n_keypoints, skeleton, *, max_annotations=DEFAULT_MAX_ANNOTATIONS):
+    def __init__(self, n_keypoints, skeleton, *, max_annotations=DEFAULT_MAX_ANNOTATIONS, cifhr_pool_tiles=0):
+        """``cifhr_pool_tiles``: capacity per image of the high-resolution map, which the decode keeps as a pool of 32x64
+        tiles (``opa_shape::cifhr_pool_tiles``): 0 = automatic (an eighth of the map, at least 1024 tiles: 8 MB for a
+        641-px COCO image instead of 31), ``'full'`` / -1 = every tile, n > 0 = n tiles.  An image whose CIF cells reach
+        more tiles than the pool holds is flagged (``OPA_COUNT_FAILED``, status -2) instead of decoded wrongly; the
+        synchronous entry points (``call``, ``call_with_initial_annotations``, ``decoder.CifCaf.batch``) then decode once
+        more with a full pool on their own, ``call_batch`` (asynchronous) leaves that to the caller (:meth:`use_full_pool`)."""
         skeleton = torch.as_tensor(skeleton)
         if skeleton.dtype != torch.int64:
             raise RuntimeError('skeleton must be of type LongTensor')      # cifcaf.hpp:106
         self.n_keypoints = int(n_keypoints)
         self.skeleton = skeleton.detach().cpu().contiguous().reshape(-1, 2)
         self.max_annotations = int(max_annotations)
+        self.cifhr_pool_tiles = -1 if cifhr_pool_tiles in ('full', -1) else int(cifhr_pool_tiles)
         self._handle = ctypes.c_void_p()
         self._workspaces = {}
         self._last = None
@@ -148,10 +156,10 @@ class CifCaf:
 
     # pickle state = (n_keypoints, skeleton), module.cpp:41-53
     def __getstate__(self):
-        return (self.n_keypoints, self.skeleton, self.max_annotations)
+        return (self.n_keypoints, self.skeleton, self.max_annotations, self.cifhr_pool_tiles)
 
     def __setstate__(self, state):
-        self.__init__(state[0], state[1], max_annotations=state[2])
+        self.__init__(state[0], state[1], max_annotations=state[2], cifhr_pool_tiles=state[3] if len(state) > 3 else 0)
 
     def _shape(self, cif, cif_stride, caf, caf_stride):
         B, F, C, H, W = cif.shape
@@ -163,7 +171,7 @@ class CifCaf:
             raise ValueError('the CIF field has %d fields, more than the decoder\'s %d keypoints' % (F, self.n_keypoints))
         # F < n_keypoints: tracking setup, joints F.. have no CIF field (reference tracking_pose.py:47-80)
         return _lib.Shape(B, F, A, H, W, cH, cW, int(cif_stride), int(caf_stride), self.max_annotations,
-                          self.n_keypoints)
+                          self.n_keypoints, self.cifhr_pool_tiles)
 
     def _workspace(self, shape, device, params=None):
         """The decoder's workspace for this shape; the regions only a force-complete decode uses (a second set of CAF
@@ -193,6 +201,19 @@ class CifCaf:
             self._workspaces[key] = ws
             self._workspace_fc = fc
         return ws
+
+    def use_full_pool(self):
+        """From the next decode on the map's tile pool holds every tile (after an image did not fit the automatic one)."""
+        if self._pinned:
+            raise _lib.NativeError('this decoder has a captured HIP graph that replays into its workspace: use another CifCaf instance')
+        self.cifhr_pool_tiles = -1
+
+    def pool_overflowed(self):
+        """Did an image of the last ``call_batch`` reach more map tiles than the pool holds?  (Synchronises.)"""
+        if self._last is None or self.cifhr_pool_tiles == -1:
+            return False
+        shape, _ = self._last
+        return bool(self.workspace_view('cifhr_overflow', torch.int32)[:shape.batch].any().item())
 
     def call_batch(self, cif, cif_stride, caf, caf_stride, initial_annotations=None, initial_ids=None,
                    *, params=None):
@@ -256,6 +277,11 @@ class CifCaf:
         out, ids, counts = self.call_batch(cif_field.unsqueeze(0), cif_stride, caf_field.unsqueeze(0),
                                            caf_stride, ia, ii)
         n = int(counts[0])
+        if n & COUNT_FAILED and self.pool_overflowed():          # the map did not fit the automatic pool: once more, full pool
+            self.use_full_pool()
+            out, ids, counts = self.call_batch(cif_field.unsqueeze(0), cif_stride, caf_field.unsqueeze(0),
+                                               caf_stride, ia, ii)
+            n = int(counts[0])
         check_counts(n)
         if n & COUNT_OVERFLOW:
             raise _lib.NativeError('annotation capacity overflow: %d poses dropped; construct CifCaf with a '
@@ -283,7 +309,8 @@ class CifCaf:
         return self.workspace_view('assoc_stats', torch.int32)[:shape.batch * 24].view(shape.batch, 24)   # (regions are padded to 256 B)
 
     def get_cifhr(self, image=0):
-        """module.cpp:37-39 -> (Tensor [F,Hhr,Whr] view of the internal buffer, revision)."""
+        """module.cpp:37-39 -> (Tensor [F,Hhr,Whr], revision).  The decode keeps the map as a pool of tiles; this gathers the
+        dense array the reference returns (0.0 = untouched, else 1 + value) for one image of the last ``call_batch``."""
         if self._last is None:
             return torch.zeros((1, 1, 1)), 0.0
         shape, ws = self._last
@@ -291,10 +318,10 @@ class CifCaf:
         rev = ctypes.c_double()
         _lib.check(_lib.lib().opa_cifcaf_cifhr_view(ctypes.byref(shape), ctypes.byref(off), ctypes.byref(rows),
                                                     ctypes.byref(cols), ctypes.byref(pitch), ctypes.byref(rev)))
-        F = shape.n_cif
-        n = shape.batch * F * rows.value * pitch.value
-        flat = ws[off.value * 4:(off.value + n) * 4].view(torch.float32)
-        return flat.view(shape.batch, F, rows.value, pitch.value)[image, :, :, :cols.value], rev.value
+        dense = torch.empty((shape.n_cif, rows.value, cols.value), dtype=torch.float32, device=ws.device)
+        _lib.check(_lib.lib().opa_cifcaf_get_cifhr(ctypes.byref(shape), _ptr(ws), int(image), _ptr(dense), _stream()),
+                   'opa_cifcaf_get_cifhr')
+        return dense, rev.value
 
 
 class DecodeLanes:

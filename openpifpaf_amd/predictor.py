@@ -183,16 +183,17 @@ def preprocess_batch_device(images, *, long_edge, device, fast=True):
     ``long_edge x long_edge`` with the reference's fill colour and normalised -- all on ``device``.
     -> (float32 ``[B,3,long_edge,long_edge]`` on ``device``, metas).  The pixels EQUAL the host path's."""
     assert long_edge, '--long-edge must be provided for batch size > 1'
-    mean = torch.tensor(IMAGENET_MEAN, device=device, dtype=torch.float32).view(3, 1, 1)
-    std = torch.tensor(IMAGENET_STD, device=device, dtype=torch.float32).view(3, 1, 1)
-    canvas = torch.tensor((124, 116, 104), dtype=torch.uint8, device=device).view(1, 1, 1, 3)
-    canvas = canvas.expand(len(images), long_edge, long_edge, 3).contiguous()
+    mean, std, fill, d255 = _device_constants(device)
+    canvas = fill.expand(len(images), long_edge, long_edge, 3).contiguous()
     metas = []
     for b, image in enumerate(images):
         frame = torch.from_numpy(np.ascontiguousarray(np.asarray(_to_pil(image), dtype=np.uint8)))
         h0, w0 = frame.shape[:2]
         tw, th = _target_size(w0, h0, long_edge)
-        x = (resize_bilinear_u8 if fast else zoom_linear_u8)(frame.to(device, non_blocking=True), th, tw)
+        # (through pinned memory: an upload from pageable memory makes the host wait for everything queued on the stream)
+        x = frame.pin_memory().to(device, non_blocking=True) if torch.device(device).type == 'cuda' else frame.to(device)
+        if (th, tw) != (h0, w0):
+            x = (resize_bilinear_u8 if fast else zoom_linear_u8)(x, th, tw)
         left, top = max(0, int((long_edge - tw) / 2.0)), max(0, int((long_edge - th) / 2.0))
         canvas[b, top:top + th, left:left + tw] = x
         sx, sy = (tw - 1) / (w0 - 1), (th - 1) / (h0 - 1)
@@ -203,8 +204,23 @@ def preprocess_batch_device(images, *, long_edge, device, fast=True):
     # ToTensor + Normalize exactly as the host path does them: float32(u8) / 255, then (x - mean) / std
     # (a DEVICE tensor as divisor: dividing by a Python scalar is turned into a multiplication by 1/255 on the GPU,
     # which rounds differently from the host's true division)
-    batch = canvas.permute(0, 3, 1, 2).to(torch.float32) / torch.full((1,), 255.0, dtype=torch.float32, device=device)
+    batch = canvas.permute(0, 3, 1, 2).to(torch.float32) / d255
     return ((batch - mean) / std).contiguous(), metas
+
+
+_constants = {}
+
+
+def _device_constants(device):
+    """ImageNet mean / std, the padding colour and 255.0 as tensors on ``device`` (uploaded once: every ``torch.tensor(...,
+    device=...)`` is a blocking copy)."""
+    key = str(device)
+    if key not in _constants:
+        _constants[key] = (torch.tensor(IMAGENET_MEAN, device=device, dtype=torch.float32).view(3, 1, 1),
+                           torch.tensor(IMAGENET_STD, device=device, dtype=torch.float32).view(3, 1, 1),
+                           torch.tensor((124, 116, 104), dtype=torch.uint8, device=device).view(1, 1, 1, 3),
+                           torch.full((1,), 255.0, dtype=torch.float32, device=device))
+    return _constants[key]
 
 
 class Predictor:
@@ -316,7 +332,19 @@ class Predictor:
     def _preprocess(self, images):
         batch_mode = self.batch_size > 1
         if batch_mode and self.device_preprocess and self.device.type == 'cuda':
-            return preprocess_batch_device(images, long_edge=self.long_edge, device=self.device, fast=self.fast_rescaling)
+            # on a stream of its own: uploads and resizes of batch i+1 do not queue behind the network of batch i (nor does
+            # the host behind them); the network's stream waits for the finished batch only
+            if getattr(self, '_pre_stream', None) is None:
+                self._pre_stream = torch.cuda.Stream(device=self.device)
+            main = torch.cuda.current_stream(self.device)
+            with torch.cuda.stream(self._pre_stream):
+                batch, metas = preprocess_batch_device(images, long_edge=self.long_edge, device=self.device,
+                                                       fast=self.fast_rescaling)
+                ready = torch.cuda.Event()
+                ready.record(self._pre_stream)
+            main.wait_event(ready)
+            batch.record_stream(main)
+            return batch, metas
         items = [preprocess_image(im, long_edge=self.long_edge, batch_mode=batch_mode, fast=self.fast_rescaling)
                  for im in images]
         return torch.stack([t for t, _ in items]), [m for _, m in items]

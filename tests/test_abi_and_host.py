@@ -63,7 +63,14 @@ def test_invalid_arguments_fail_loudly_without_gpu():
     assert b'positive' in L.opa_last_error()
     shape = _lib.Shape(32, 17, 19, 81, 81, 81, 81, 8, 8, 128)
     nbytes = L.opa_cifcaf_workspace_bytes(ctypes.byref(shape))
-    assert 1.0e9 < nbytes < 3.0e9                                      # ~50 MB per image
+    assert 0.7e9 < nbytes < 1.1e9                                      # ~29 MB per image: the CIF map is a pool of tiles (r4; the
+    #                                                                    dense map of rounds 1-3: ~51 MB per image)
+    dense = _lib.Shape(32, 17, 19, 81, 81, 81, 81, 8, 8, 128, 0, -1)   # cifhr_pool_tiles = -1: a slot for every tile
+    nbytes_dense = L.opa_cifcaf_workspace_bytes(ctypes.byref(dense))
+    per_image = (nbytes_dense - nbytes) / 32
+    assert 21e6 < per_image < 24e6                                     # 3927 - 1024 tiles of 8 KB
+    small = _lib.Shape(32, 17, 19, 81, 81, 81, 81, 8, 8, 128, 0, 512)
+    assert (nbytes - L.opa_cifcaf_workspace_bytes(ctypes.byref(small))) / 32 == 512 * 8192
     # without force complete the second CAF list set is left out ("weak" 15): ~7 MB per image less
     plain = L.opa_cifcaf_workspace_bytes_for(ctypes.byref(shape), ctypes.byref(_lib.default_params()))
     full = L.opa_cifcaf_workspace_bytes_for(ctypes.byref(shape), ctypes.byref(_lib.default_params(force_complete=1)))

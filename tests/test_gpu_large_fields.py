@@ -91,6 +91,19 @@ def test_large_field_batch_decodes_like_the_oracle(native, port, coco_skeleton0,
             cafs = np.stack([fields(c)[1] for c in order])
             out, ids, counts = dec.call_batch(dev(cifs), 8, dev(cafs), 8, params=params_dev)
             out, counts = out.cpu().numpy(), counts.cpu().numpy()
+            if LARGE[3] in order and dec.cifhr_pool_tiles == 0:
+                # the 90-person image reaches ~2200 map tiles, the automatic pool of a 161 x 161 field holds 1829: that image
+                # -- and only that one -- is flagged, with status -2; with a full pool the same call decodes everything
+                bad = order.index(LARGE[3])
+                assert native.count_failed(counts).tolist() == [i == bad for i in range(len(order))]
+                status = dec.workspace_view('status', torch.int32)[:len(order)].cpu().numpy()
+                assert status[bad] == -2 and dec.pool_overflowed()
+                with pytest.raises(Exception):
+                    native.check_counts(counts)
+                dec.use_full_pool()
+                out, ids, counts = dec.call_batch(dev(cifs), 8, dev(cafs), 8, params=params_dev)
+                out, counts = out.cpu().numpy(), counts.cpu().numpy()
+                assert not dec.pool_overflowed()
             native.check_counts(counts)
             assert not native.count_overflowed(counts).any()
             for b, c in enumerate(order):
@@ -123,3 +136,63 @@ def test_large_field_ties_in_global_memory(native, port, coco_skeleton0):
         want, _ = port.decode(cif, 8, caf, 8, coco_skeleton0)
         ok, msg = compare_annotations(got.cpu().numpy(), want)
         assert ok, msg
+
+
+def test_map_tile_pool_overflow_is_flagged_and_retried(native, port, coco_skeleton0):
+    """The decode keeps the high-resolution CIF map as a pool of 32x64 tiles (opa_shape::cifhr_pool_tiles; automatic: an
+    eighth of the map, 1024 of the 3927 tiles of a 641-px COCO image).  Structureless all-active fields reach every tile:
+    the asynchronous batched call flags such an image (OPA_COUNT_FAILED, status -2) instead of decoding it wrongly; the
+    synchronous entry points and the decoder layer decode again with a pool that holds the whole map; an explicit small
+    pool overflows on an ordinary crowded image, a full pool never does -- and every result equals the oracle's."""
+    from openpifpaf_amd import decoder, headmeta, synth
+    adv_cif, adv_caf = synth.adversarial_fields(11)
+    ok_cif, ok_caf = synth.synth_fields(31, 20, height=81, width=81)
+    cifs, cafs = np.stack([ok_cif, adv_cif]), np.stack([ok_caf, adv_caf])
+    want = [port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)[0] for b in range(2)]
+
+    dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    out, ids, counts = dec.call_batch(dev(cifs), 8, dev(cafs), 8)
+    counts_h = counts.cpu().numpy()
+    assert native.count_failed(counts_h).tolist() == [False, True] and dec.pool_overflowed()
+    assert dec.workspace_view('status', torch.int32)[:2].cpu().numpy().tolist()[1] == -2
+    okk, msg = compare_annotations(out[0, :native.count_rows(int(counts_h[0]))].cpu().numpy(), want[0])
+    assert okk, msg                                                     # the image beside it is not affected
+    bytes_auto = dec._last[1].numel()
+    # synchronous single-image call: retried with a full pool on its own
+    dec1 = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    got, _ = dec1.call(dev(adv_cif), 8, dev(adv_caf), 8)
+    assert dec1.cifhr_pool_tiles == -1
+    okk, msg = compare_annotations(got.cpu().numpy(), want[1])
+    assert okk, msg
+    hr, rev = dec1.get_cifhr()
+    assert rev == 1.0 and np.array_equal(hr.cpu().numpy(), port.cifhr_accumulate(adv_cif, 8))    # the whole map, through the pool
+    # the full pool on request: the dense map's size, never overflows
+    full = native.CifCaf(17, torch.from_numpy(coco_skeleton0), cifhr_pool_tiles='full')
+    out, ids, counts = full.call_batch(dev(cifs), 8, dev(cafs), 8)
+    counts_h = counts.cpu().numpy()
+    native.check_counts(counts_h)
+    for b in range(2):
+        okk, msg = compare_annotations(out[b, :native.count_rows(int(counts_h[b]))].cpu().numpy(), want[b])
+        assert okk, (b, msg)
+    assert (full._last[1].numel() - bytes_auto) // 2 == (3927 - 1024) * 8192
+    # an explicit small pool: the 20-person image alone reaches ~450 tiles
+    small = native.CifCaf(17, torch.from_numpy(coco_skeleton0), cifhr_pool_tiles=256)
+    out, ids, counts = small.call_batch(dev(ok_cif[None]), 8, dev(ok_caf[None]), 8)
+    assert native.count_failed(counts.cpu().numpy()).all() and small.pool_overflowed()
+    # the decoder layer: synchronous and pipelined batches repeat the decode with a full pool
+    old_workers = decoder.CifCaf.decoder_workers
+    try:
+        decoder.CifCaf.decoder_workers = 2
+        class Heads:
+            def __call__(self, images):
+                return (dev(cifs), dev(cafs))
+        d = decoder.factory(list(headmeta.cocokp_metas()))
+        sync = d.batch(Heads(), torch.zeros((2, 3, 641, 641)), device=torch.device('cuda'))
+        assert [len(r) for r in sync] == [len(w) for w in want]
+        d2 = decoder.factory(list(headmeta.cocokp_metas()))
+        pend = [d2.batch_async(Heads(), torch.zeros((2, 3, 641, 641)), device=torch.device('cuda')) for _ in range(3)]
+        for p in pend:
+            assert [len(r) for r in p.result()] == [len(w) for w in want]
+        assert d2.decoders[0].cpp_decoder.cifhr_pool_tiles == -1
+    finally:
+        decoder.CifCaf.decoder_workers = old_workers
