@@ -1017,7 +1017,7 @@ def main():
                 pred = Predictor(model=Injected())
                 rng = np.random.default_rng(3)
                 frames = [rng.integers(0, 255, (args.long_edge, args.long_edge, 3), dtype=np.uint8) for _ in range(wl.B)]
-                n_batches = 8
+                n_batches = 24                             # (a short run is dominated by filling and draining the pipeline)
                 out = {}
                 for mode, pipelined in (('pipelined', True), ('synchronous', False)):
                     pred.pipelined = pipelined

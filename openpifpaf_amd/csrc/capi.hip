@@ -132,7 +132,6 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
         L->hr_tpp = (int)tpp; L->hr_pool_cap = (int)cap;
         L->off_cifhr = take(B * cap * (size_t)(kHrTileH * kHrTileW) * sizeof(float));
         L->off_hr_slot = take(B * all * sizeof(int32_t));
-        L->off_hr_plane_count = take(B * L->F * sizeof(int32_t));
         L->off_hr_overflow = take(B * sizeof(int32_t));
     }
     L->off_act = take(B * L->F * 4 * (size_t)(L->H * L->W) * sizeof(float));
@@ -163,7 +162,7 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     }
     L->total_no_fc = off;
     // what only a force-complete decode touches sits behind everything else: a workspace for decodes without it can stop here
-    L->off_lists_fc = take(list_bytes);
+    L->off_lists_fc = take(B * L->A * 2 * (size_t)L->caf_cells * sizeof(float));   // RAW lists: a score plane per (bone, direction)
     L->off_list_counts_fc = take(B * L->A * 2 * sizeof(int32_t));
     L->off_list_bbox_fc = take(B * L->A * 2 * (size_t)L->bbox_chunks * 4 * sizeof(float));
     L->off_fc_meta = take(B * 4 * sizeof(int32_t));
@@ -337,7 +336,7 @@ int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what, size_t* 
     if (!shape || !what || !make_layout(*shape, &L, &why)) return fail(OPA_ERR_INVALID_ARGUMENT, why ? why : "null argument");
     struct Entry { const char* name; size_t off, end; };
     const Entry table[] = {
-        {"tile_bitmaps", L.off_tile_clean, L.off_cifhr}, {"cifhr", L.off_cifhr, L.off_hr_slot}, {"cifhr_slots", L.off_hr_slot, L.off_hr_plane_count},
+        {"tile_bitmaps", L.off_tile_clean, L.off_cifhr}, {"cifhr", L.off_cifhr, L.off_hr_slot}, {"cifhr_slots", L.off_hr_slot, L.off_hr_overflow},
         {"cifhr_overflow", L.off_hr_overflow, L.off_act}, {"seed_count", L.off_seed_count, L.off_seed_f},
         {"seed_f", L.off_seed_f, L.off_seed_vxys}, {"seed_vxys", L.off_seed_vxys, L.off_seed_cell}, {"seed_cell", L.off_seed_cell, L.off_lists},
         {"lists", L.off_lists, L.off_list_counts}, {"list_counts", L.off_list_counts, L.off_list_bbox},
@@ -396,8 +395,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
                         (long long)L.A, (long long)L.cH, (long long)L.cW, (long long)L.max_ann, (long long)L.K, (long long)L.total_no_fc})
         layout_hash = (layout_hash ^ (unsigned long long)v) * 1099511628211ull;
     HrPool pool;                                      // the map is a pool of tiles (cifhr.hip)
-    pool.slot = (int32_t*)(ws + L.off_hr_slot); pool.plane_count = (int32_t*)(ws + L.off_hr_plane_count);
-    pool.overflow = (int32_t*)(ws + L.off_hr_overflow); pool.cap = L.hr_pool_cap; pool.tpp = L.hr_tpp;
+    pool.slot = (int32_t*)(ws + L.off_hr_slot); pool.overflow = (int32_t*)(ws + L.off_hr_overflow); pool.cap = L.hr_pool_cap; pool.tpp = L.hr_tpp;
     e = launch_cifhr(cif_dev, L.B, L.F, L.H, L.W, L.stride, 0.0, 1.0, p, cifhr, L.hr_rows, L.hr_pitch,
                      (float*)(ws + L.off_act), (int32_t*)(ws + L.off_act_count), st, false,
                      (unsigned long long*)(ws + L.off_hdr), layout_hash, ws + L.off_tile_clean,
@@ -427,9 +425,9 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     if (p.force_complete)
         scored[n_scored++] = make_scored_args(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols,
                                               L.hr_pitch, dec->dev.skeleton, p.force_complete_caf_th, 0.1,
-                                              p.ablation_caf_no_rescore, (float*)(ws + L.off_lists_fc),
+                                              p.ablation_caf_no_rescore, nullptr,
                                               (int32_t*)(ws + L.off_list_counts_fc), (float*)(ws + L.off_list_bbox_fc),
-                                              L.bbox_chunks, L.bbox_chunks, nullptr, &pool);
+                                              L.bbox_chunks, L.bbox_chunks, nullptr, &pool, (float*)(ws + L.off_lists_fc));
     const char* fuse_env = std::getenv("OPA_FUSE_SCORED");
     const bool fuse = fuse_env && std::atoi(fuse_env) != 0;
     TieScratch ties;
@@ -463,7 +461,8 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     a.seed_count = (const int32_t*)(ws + L.off_seed_count);
     a.seed_cell = (const int32_t*)(ws + L.off_seed_cell);
     a.lists = (const float*)(ws + L.off_lists); a.list_counts = (const int32_t*)(ws + L.off_list_counts);
-    a.lists_fc = (const float*)(ws + L.off_lists_fc); a.list_counts_fc = (const int32_t*)(ws + L.off_list_counts_fc);
+    a.scores_fc = (const float*)(ws + L.off_lists_fc); a.list_counts_fc = (const int32_t*)(ws + L.off_list_counts_fc);
+    a.caf_raw = caf_dev; a.caf_stride = L.cstride;
     a.list_bbox = (const float*)(ws + L.off_list_bbox);
     a.list_bbox_fc = (const float*)(ws + L.off_list_bbox_fc);
     a.bbox_chunks = L.bbox_chunks;

@@ -142,22 +142,6 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
         }
     }
     if (tid == 0) act_count[plane] = base;
-    if (pool.slot) {                                  // how many tiles this plane's cells reach: the tile kernel places the planes' tiles
-        __threadfence();                              // in the image's pool from these counts (this workgroup's atomics are at the L2)
-        __syncthreads();
-        int n = 0;
-        for (int k = tid; k < touch_words; k += kActiveThreads)
-            n += __popc(__hip_atomic_load(&touch[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        for (int d = 32; d > 0; d >>= 1) n += __shfl_xor(n, d, 64);
-        __shared__ int tile_tot[kActiveThreads / 64];
-        if (lane == 0) tile_tot[w] = n;
-        __syncthreads();
-        if (tid == 0) {
-            int t = 0;
-            for (int k = 0; k < kActiveThreads / 64; k++) t += tile_tot[k];
-            pool.plane_count[plane] = t;
-        }
-    }
 }
 
 // cif_hr.cpp:18-25.  The reference evaluates `1.0 + x / 8.0` and the caller's `-0.5 * d2 / sigma2` in double
@@ -289,8 +273,9 @@ __global__ __launch_bounds__(256) void cifhr_tile_kernel(
     float* pool_image = nullptr;
     if (pooled) {
         const int b = plane / F, f = plane - b * F;
-        int before = 0;
-        for (int q = lane; q < f; q += 64) before += pool.plane_count[b * F + q];
+        int before = 0;                              // (bitmap words of the planes before this one: a handful of loads per lane)
+        const unsigned* img = tile_cur + (size_t)b * F * touch_words;
+        for (int q = lane; q < f * touch_words; q += 64) before += __popc(img[q]);
         for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
         plane_base = before;
         pool_image = hr + (size_t)b * pool.cap * (kHrTileH * kHrTileW);
@@ -352,7 +337,7 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
     const int tiles_y = (hr_rows + kHrTileH - 1) / kHrTileH;
     // two per-plane tile bitmaps in the workspace region `tile_state`: previous call, this call
     const int touch_words = (tiles_x * tiles_y + 31) / 32;
-    HrPool pool; pool.slot = nullptr; pool.plane_count = nullptr; pool.overflow = nullptr; pool.cap = 0; pool.tpp = tiles_x * tiles_y;
+    HrPool pool; pool.slot = nullptr; pool.overflow = nullptr; pool.cap = 0; pool.tpp = tiles_x * tiles_y;
     if (pool_in) pool = *pool_in;
     unsigned* tile_prev = ws_header ? reinterpret_cast<unsigned*>(tile_state) : nullptr;
     unsigned* tile_touch = ws_header ? tile_prev + (size_t)planes * touch_words : nullptr;

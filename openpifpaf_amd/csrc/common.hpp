@@ -39,7 +39,7 @@ struct Layout {
     // scratch of the seed tie pass (cifseeds.hip): `big` lies in the active-cell list (dead once the map is built, and
     // exactly as large), `small` in the occupancy bitmap (cleared by the association kernel afterwards) where it fits
     size_t off_tie_small, tie_small_stride, off_tie_state;
-    size_t off_hr_slot, off_hr_plane_count, off_hr_overflow;   // the pooled map's slot tables [B][F][tpp], plane counts, overflow flags
+    size_t off_hr_slot, off_hr_overflow;   // the pooled map's slot tables [B][F][tpp], overflow flags
 };
 
 bool make_layout(const opa_shape& s, Layout* L, const char** why);
@@ -79,7 +79,6 @@ void prof_mark(hipStream_t st, const char* name);
 // the stage-level entry points.
 struct HrPool {
     int32_t* slot;         // [B][F][tpp] tile -> slot in its image's pool; -1: untouched, -2: the pool was full
-    int32_t* plane_count;  // [B][F] touched tiles of a plane (cif_active -> cifhr_tile)
     int32_t* overflow;     // [B] set when an image reaches more tiles than its pool holds (the decode then flags the image failed)
     int cap;               // slots per image
     int tpp;               // tiles per plane
@@ -124,6 +123,8 @@ struct ScoredArgs {
     const float* cifhr; int F, hr_rows, hr_cols, hr_pitch;
     const int64_t* skeleton; double score_th, cif_floor; int no_rescore;
     float* lists; int32_t* counts;
+    float* raw_scores;                        // force-complete set: no lists -- [planes][2][HW] rescored confidences (0: not kept),
+                                              // chunk boxes over the field's 64-cell chunks (cifcaf.hip: RAW lists); else null
     const unsigned* tile_touch; int touch_words, tiles_x;   // [B][F][touch_words] touched-tile bitmaps of the map (or null)
     const int32_t* hr_slot; int hr_tpp;       // pooled map: [B][F][hr_tpp] slot tables (null: dense map)
     size_t hr_image_stride;                   // floats between the maps of two images (dense: F * rows * pitch; pooled: cap * tile)
@@ -136,7 +137,7 @@ ScoredArgs make_scored_args(const float* caf, int B, int A, int cH, int cW, int 
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
                             float* lists, int32_t* counts, float* chunk_bbox, int bbox_chunks, int bbox_stride,
-                            const unsigned* tile_touch = nullptr, const HrPool* pool = nullptr);
+                            const unsigned* tile_touch = nullptr, const HrPool* pool = nullptr, float* raw_scores = nullptr);
 
 hipError_t launch_cafscored(const ScoredArgs& s, hipStream_t st);
 hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
@@ -182,7 +183,9 @@ struct AssocArgs {
     const int32_t* seed_f; const float* seed_vxys; const int32_t* seed_count;
     const int32_t* seed_cell;  // occupancy cell of the seed: x | y << 12 | box half-width << 24 (seed_cell_pack)
     const float* lists; const int32_t* list_counts;          // caf_th lists
-    const float* lists_fc; const int32_t* list_counts_fc;    // force-complete lists (or null)
+    const float* scores_fc; const int32_t* list_counts_fc;   // force complete: rescored confidence planes [B][A][2][cells] (0: the cell
+                                                             // did not pass) of the RAW lists (cifcaf.hip), cells kept per list; or null
+    const float* caf_raw; int caf_stride;                    // ... the CAF field tensor itself [B][A][8][cells] and its stride
     const float* list_bbox;  // [B][A][2][bbox_chunks][4] chunk boxes of `lists` (or null)
     const float* list_bbox_fc;  // ... of `lists_fc` (or null)
     int bbox_chunks;

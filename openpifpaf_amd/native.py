@@ -210,9 +210,11 @@ class CifCaf:
 
     def pool_overflowed(self):
         """Did an image of the last ``call_batch`` reach more map tiles than the pool holds?  (Synchronises.)"""
-        if self._last is None or self.cifhr_pool_tiles == -1:
+        if self._last is None:
             return False
         shape, _ = self._last
+        if shape.cifhr_pool_tiles == -1:         # (the pool of THAT call; the setting may have changed since)
+            return False
         return bool(self.workspace_view('cifhr_overflow', torch.int32)[:shape.batch].any().item())
 
     def call_batch(self, cif, cif_stride, caf, caf_stride, initial_annotations=None, initial_ids=None,
