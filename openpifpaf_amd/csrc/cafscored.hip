@@ -28,13 +28,13 @@ ScoredArgs make_scored_args(const float* caf, int B, int A, int cH, int cW, int 
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
                             float* lists, int32_t* counts, float* chunk_bbox, int bbox_chunks, int bbox_stride,
-                            const unsigned* tile_touch, const HrPool* pool, float* raw_scores) {
+                            const unsigned* tile_touch, const HrPool* pool) {
     if (bbox_chunks <= 0) chunk_bbox = nullptr;
     if (bbox_stride < bbox_chunks) bbox_stride = bbox_chunks;
     ScoredArgs s;
     s.caf = caf; s.A = A; s.HW = cH * cW; s.stride = cstride; s.cifhr = cifhr; s.F = F; s.hr_rows = hr_rows; s.hr_cols = hr_cols;
     s.hr_pitch = hr_pitch; s.skeleton = skeleton; s.score_th = score_th; s.cif_floor = cif_floor; s.no_rescore = no_rescore;
-    s.lists = lists; s.counts = counts; s.raw_scores = raw_scores; s.chunk_bbox = chunk_bbox; s.nb = chunk_bbox ? bbox_chunks : 0; s.nb_stride = bbox_stride;
+    s.lists = lists; s.counts = counts; s.chunk_bbox = chunk_bbox; s.nb = chunk_bbox ? bbox_chunks : 0; s.nb_stride = bbox_stride;
     s.planes = B * A;
     s.tile_touch = tile_touch; s.tiles_x = hr_pitch / kHrTileW;
     s.hr_slot = pool ? pool->slot : nullptr; s.hr_tpp = pool ? pool->tpp : 0;

@@ -84,9 +84,6 @@ __device__ __forceinline__ void cafscored_plane(const ScoredArgs& s, int plane_i
     const int32_t* slot = s.hr_slot ? s.hr_slot + (size_t)b * F * s.hr_tpp : nullptr;   // pooled map: the slot table replaces the bitmap test
     float* Lf = lists + ((size_t)plane * 2 + 0) * 7 * HW;
     float* Lb = lists + ((size_t)plane * 2 + 1) * 7 * HW;
-    // RAW list set (force complete: nearly every cell passes, a list would be the field copied twice): no lists -- the
-    // rescored confidence of every cell and direction (0: not kept) and the boxes of the FIELD's 64-cell chunks
-    float* raw = s.raw_scores ? s.raw_scores + (size_t)plane * 2 * HW : nullptr;
     const long long j1 = skeleton[2 * a + 0], j2 = skeleton[2 * a + 1];
     const float stride_f = (float)stride;
     int base_f = 0, base_b = 0, parity = 0;
@@ -128,13 +125,7 @@ __device__ __forceinline__ void cafscored_plane(const ScoredArgs& s, int plane_i
             if (k < w) { off_f += t & 0xffff; off_b += t >> 16; }
             tot_f += t & 0xffff; tot_b += t >> 16;
         }
-        if (raw) {
-            if (o < HW && live) { raw[o] = keep_f ? cf : 0.0f; raw[HW + o] = keep_b ? cb : 0.0f; }
-            if (chunk_bbox) {                        // a wave's 64 cells ARE one chunk of the field
-                widen_boxes(bb, nb, keep_f, o, x1, y1);
-                widen_boxes(bb + nb * 4, nb, keep_b, o, x2, y2);
-            }
-        } else if (chunk_bbox) {
+        if (chunk_bbox) {
             if (nb > kListBboxChunks) {              // long lists: one LDS update per wave and chunk
                 widen_boxes(bb, nb, keep_f, off_f, x1, y1);
                 widen_boxes(bb + nb * 4, nb, keep_b, off_b, x2, y2);
@@ -151,11 +142,11 @@ __device__ __forceinline__ void cafscored_plane(const ScoredArgs& s, int plane_i
                 if (keep_b && off_b < nb * 64) widen(bb + (nb + (off_b >> 6)) * 4, x2, y2);
             }
         }
-        if (keep_f && !raw) {
+        if (keep_f) {
             Lf[0 * HW + off_f] = cf; Lf[1 * HW + off_f] = x1; Lf[2 * HW + off_f] = y1;
             Lf[3 * HW + off_f] = x2; Lf[4 * HW + off_f] = y2; Lf[5 * HW + off_f] = s1; Lf[6 * HW + off_f] = s2;
         }
-        if (keep_b && !raw) {                                            // mirrored tuple, :55-63
+        if (keep_b) {                                                    // mirrored tuple, :55-63
             Lb[0 * HW + off_b] = cb; Lb[1 * HW + off_b] = x2; Lb[2 * HW + off_b] = y2;
             Lb[3 * HW + off_b] = x1; Lb[4 * HW + off_b] = y1; Lb[5 * HW + off_b] = s2; Lb[6 * HW + off_b] = s1;
         }

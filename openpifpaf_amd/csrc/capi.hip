@@ -162,7 +162,7 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     }
     L->total_no_fc = off;
     // what only a force-complete decode touches sits behind everything else: a workspace for decodes without it can stop here
-    L->off_lists_fc = take(B * L->A * 2 * (size_t)L->caf_cells * sizeof(float));   // RAW lists: a score plane per (bone, direction)
+    L->off_lists_fc = take(list_bytes);
     L->off_list_counts_fc = take(B * L->A * 2 * sizeof(int32_t));
     L->off_list_bbox_fc = take(B * L->A * 2 * (size_t)L->bbox_chunks * 4 * sizeof(float));
     L->off_fc_meta = take(B * 4 * sizeof(int32_t));
@@ -425,9 +425,9 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     if (p.force_complete)
         scored[n_scored++] = make_scored_args(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols,
                                               L.hr_pitch, dec->dev.skeleton, p.force_complete_caf_th, 0.1,
-                                              p.ablation_caf_no_rescore, nullptr,
+                                              p.ablation_caf_no_rescore, (float*)(ws + L.off_lists_fc),
                                               (int32_t*)(ws + L.off_list_counts_fc), (float*)(ws + L.off_list_bbox_fc),
-                                              L.bbox_chunks, L.bbox_chunks, nullptr, &pool, (float*)(ws + L.off_lists_fc));
+                                              L.bbox_chunks, L.bbox_chunks, nullptr, &pool);
     const char* fuse_env = std::getenv("OPA_FUSE_SCORED");
     const bool fuse = fuse_env && std::atoi(fuse_env) != 0;
     TieScratch ties;
@@ -461,8 +461,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     a.seed_count = (const int32_t*)(ws + L.off_seed_count);
     a.seed_cell = (const int32_t*)(ws + L.off_seed_cell);
     a.lists = (const float*)(ws + L.off_lists); a.list_counts = (const int32_t*)(ws + L.off_list_counts);
-    a.scores_fc = (const float*)(ws + L.off_lists_fc); a.list_counts_fc = (const int32_t*)(ws + L.off_list_counts_fc);
-    a.caf_raw = caf_dev; a.caf_stride = L.cstride;
+    a.lists_fc = (const float*)(ws + L.off_lists_fc); a.list_counts_fc = (const int32_t*)(ws + L.off_list_counts_fc);
     a.list_bbox = (const float*)(ws + L.off_list_bbox);
     a.list_bbox_fc = (const float*)(ws + L.off_list_bbox_fc);
     a.bbox_chunks = L.bbox_chunks;

@@ -93,28 +93,7 @@ __device__ __forceinline__ int prefix_count(unsigned long long m) {
 // 7 SoA planes: c,x1,y1,x2,y2,s1,s2; `bbox` (LDS, or null): (xmin, xmax, ymin, ymax) of the (x1, y1) columns of the
 // list's first kListBboxChunks chunks of 64 entries (cafscored writes them, common.hpp)
 // `gbbox` (global memory, or null): the boxes of ALL chunks (up to `nb`) where cafscored wrote them
-struct ListView { const float* base; int cap; int n; const float4* bbox; const float4* gbbox; int nb;
-                  const float* sc; float mul; int swap; };   // RAW lists only (below)
-
-// RAW: the "list" is the CAF field itself (force complete: at caf_th 0.001 nearly every cell of a field passes, and a
-// materialised list is the field copied twice).  Entry i = cell i; `base` = the field's 8 component planes of `cap` =
-// H * W cells, `sc` = the rescored confidence of the direction (0: the cell did not pass, caf_scored.cpp:74-80), the
-// coordinate / scale columns are the raw planes times the stride (`mul`; the same float multiplication CafScored::fill
-// makes, :46-54), with the two joints' columns exchanged for the backward direction (`swap`, :55-63).
-template <bool RAW, int K>
-__device__ __forceinline__ const __attribute__((address_space(1))) float* list_col(const ListView& L) {
-    typedef __attribute__((address_space(1))) const float gf;
-    if constexpr (!RAW) return (gf*)L.base + (size_t)K * L.cap;
-    else if constexpr (K == 0) return (gf*)L.sc;
-    else {
-        // columns 1..6 = x1 y1 x2 y2 s1 s2 ; planes 2..7 = x1 y1 x2 y2 s1 s2 of the FORWARD tuple
-        constexpr int fwd = K + 1;
-        constexpr int bwd = K == 1 ? 4 : K == 2 ? 5 : K == 3 ? 2 : K == 4 ? 3 : K == 5 ? 7 : 6;
-        const int plane = L.swap ? bwd : fwd;
-        return (gf*)L.base + (size_t)plane * L.cap;
-    }
-}
-template <bool RAW> __device__ __forceinline__ float list_scale(const ListView& L, float v) { if constexpr (RAW) return v * L.mul; else return v; }
+struct ListView { const float* base; int cap; int n; const float4* bbox; const float4* gbbox; int nb; };
 
 // Diagnostic builds only (-DOPA_ASSOC_PHASE_TIMING, tools/gpu/assoc_probe.py): shader-clock time of the growers
 // by phase of the search, summed over the growers of an image; printed by the kernel for images 0 and 3.
@@ -144,7 +123,6 @@ struct ImageCtx {
     const int32_t *adj_off, *slot_info, *adj_first;   // LDS: adjacency range of a joint; per directed-bone slot: start | other << 8 |
                                                       // bone << 16 | forward << 24; first slot of the same (start, other) pair
     const float* lists; const int32_t* list_counts; int list_cap;
-    const float* raw_caf; const float* raw_sc; float raw_mul;   // force-complete kernel: the image's CAF field, its score planes, the stride
     unsigned* occ; int occ_h, occ_w, occ_wpr;   // occupancy bitmap [F][occ_h][occ_wpr] (one bit per cell)
     const int* cancel;                   // this grower's cancel flag in LDS (polled between frontier pops), or null
     int aborted;                         // set when a growth stopped because of it
@@ -173,24 +151,14 @@ struct ImageCtx {
     int t_blend, t_blend_mem;            // ticks inside the scans, and of those until the loads had returned
 };
 
-template <bool RAW = false>
 __device__ __forceinline__ ListView list_view(const ImageCtx& c, int bone, int dir) {
     ListView v;
-    if constexpr (RAW) {                               // force-complete kernel: the field itself (RAW lists)
-        v.base = c.raw_caf + (size_t)bone * 8 * c.list_cap; v.cap = c.list_cap; v.n = c.list_cap; v.swap = dir;
-        v.sc = c.raw_sc + ((size_t)bone * 2 + dir) * c.list_cap; v.mul = c.raw_mul;
-        v.bbox = nullptr;
-        v.gbbox = c.gbbox ? c.gbbox + (size_t)(bone * 2 + dir) * c.nb : nullptr; v.nb = c.nb;
-        return v;
-    } else {
     v.base = c.lists + ((size_t)bone * 2 + dir) * 7 * c.list_cap;
     v.cap = c.list_cap;
     v.n = c.sh_counts[bone * 2 + dir];
     v.bbox = c.bbox ? c.bbox + (bone * 2 + dir) * kListBboxChunks : nullptr;
     v.gbbox = c.gbbox ? c.gbbox + (size_t)(bone * 2 + dir) * c.nb : nullptr; v.nb = c.nb;
-    v.sc = nullptr; v.mul = 1.0f; v.swap = 0;
     return v;
-    }
 }
 
 // -------------------------------------------------------- grow_connection_blend
@@ -348,20 +316,18 @@ constexpr int kBlendLdsFloats = kTgtFloats + 4 * kWave;  // + the compacted (x1,
 // More than 64 entries pass the window test (rare: a window holding that many cells): blend_cached reports it
 // (ok < 0) and the caller takes one of the streamed scans below.
 __device__ __forceinline__ BlendResult blend_overflow() { BlendResult r; r.v = 0.0; r.x = r.y = r.s = 0.f; r.ok = -1; return r; }
-template <bool RAW = false>
 __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const BlendQuery& q, bool only_max);
 
 // `chunks`: the R chunks of the list to look at, ascending, 8 bits each (0xff: none) -- all of them
 // (kDenseChunks) or, for a list with chunk boxes, those whose box meets the window.
 constexpr unsigned long long kDenseChunks = 0x0706050403020100ull;
-template <int R, bool RAW = false>
+template <int R>
 __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const BlendQuery& q, bool only_max, float* tgt, int* t_mem,
                                                     unsigned long long chunks = kDenseChunks) {
     const int lane = lane_id();
     const long long t_issue = t_mem ? wall_clock64() : 0;
     PH(1);
-    const gfloat *g0 = list_col<RAW, 0>(L), *g1 = list_col<RAW, 1>(L), *g2 = list_col<RAW, 2>(L);
-    const gfloat *g3 = list_col<RAW, 3>(L), *g4 = list_col<RAW, 4>(L), *g6 = list_col<RAW, 6>(L);
+    const gfloat* g = (const gfloat*)L.base;
     // The target columns (x2, y2, s2) are needed for two entries only: they travel HBM/L2 -> LDS
     // directly (global_load_lds, no VGPRs), in flight together with the register loads below; chunk r of
     // column k lands at tgt[(k * R + r) * 64 + lane].
@@ -370,30 +336,26 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
     for (int r = 0; r < R; r++) {
         const int i = (int)((chunks >> (8 * r)) & 0xffull) * kWave + lane;
         const int ii = i < L.n ? i : 0;
-        __builtin_amdgcn_global_load_lds(g3 + ii, t3 + (0 * R + r) * kWave, 4, 0, 0);
-        __builtin_amdgcn_global_load_lds(g4 + ii, t3 + (1 * R + r) * kWave, 4, 0, 0);
-        __builtin_amdgcn_global_load_lds(g6 + ii, t3 + (2 * R + r) * kWave, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(g + 3 * L.cap + ii, t3 + (0 * R + r) * kWave, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(g + 4 * L.cap + ii, t3 + (1 * R + r) * kWave, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(g + 6 * L.cap + ii, t3 + (2 * R + r) * kWave, 4, 0, 0);
     }
     float x1[R], y1[R], cc[R];
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int i = (int)((chunks >> (8 * r)) & 0xffull) * kWave + lane;
         const int ii = i < L.n ? i : 0;
-        x1[r] = g1[ii]; y1[r] = g2[ii]; cc[r] = g0[ii];
+        x1[r] = g[1 * L.cap + ii]; y1[r] = g[2 * L.cap + ii]; cc[r] = g[ii];
     }
 #pragma unroll
     for (int r = 0; r < R; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
-    if constexpr (RAW) {
-#pragma unroll
-        for (int r = 0; r < R; r++) { x1[r] = list_scale<RAW>(L, x1[r]); y1[r] = list_scale<RAW>(L, y1[r]); }
-    }
     if (t_mem) *t_mem += (int)(wall_clock64() - t_issue);
     PH(2);
     bool have; float sc = 0.0f; int pos = 0;
     if constexpr (R == 1) {
         // one chunk: its lanes ARE in list order -- no compaction, the score is evaluated where the entry was loaded
         const int i = (int)(chunks & 0xffull) * kWave + lane;
-        have = i < L.n && (!RAW || cc[0] > 0.0f) && passes_f(q, x1[0], y1[0]);
+        have = i < L.n && passes_f(q, x1[0], y1[0]);
         if (__ballot(have) == 0ull) {                          // :76
             __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): the LDS loads must land before the area is reused
             return blend_none();
@@ -407,7 +369,7 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int i = (int)((chunks >> (8 * r)) & 0xffull) * kWave + lane;
-            const bool pass = i < L.n && (!RAW || cc[r] > 0.0f) && passes_f(q, x1[r], y1[r]);
+            const bool pass = i < L.n && passes_f(q, x1[r], y1[r]);
             const unsigned long long m = __ballot(pass);
             if (m == 0ull) continue;
             const int slot = cnt + prefix_count(m);
@@ -453,10 +415,8 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
     PH(5);
     __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): target columns are in LDS
     wave_sync();
-    const float e1x = list_scale<RAW>(L, tgt[0 * R * kWave + i1]), e1y = list_scale<RAW>(L, tgt[1 * R * kWave + i1]),
-                e1s = list_scale<RAW>(L, tgt[2 * R * kWave + i1]);
-    const float e2x = list_scale<RAW>(L, tgt[0 * R * kWave + i2]), e2y = list_scale<RAW>(L, tgt[1 * R * kWave + i2]),
-                e2s = list_scale<RAW>(L, tgt[2 * R * kWave + i2]);
+    const float e1x = tgt[0 * R * kWave + i1], e1y = tgt[1 * R * kWave + i1], e1s = tgt[2 * R * kWave + i1];
+    const float e2x = tgt[0 * R * kWave + i2], e2y = tgt[1 * R * kWave + i2], e2s = tgt[2 * R * kWave + i2];
     return blend_finish(s1, s2, have2, only_max, e1x, e1y, e1s, e2x, e2y, e2s);
 }
 
@@ -464,12 +424,10 @@ __device__ __forceinline__ BlendResult blend_cached(const ListView& L, const Ble
 // entries): two passes over the list, each in groups of 4 chunks whose loads are issued together
 // and pinned like in blend_cached, so a pass costs one memory round trip per 256 entries instead of
 // one per 64.  Scores are recomputed in pass 2.
-template <bool RAW>
 __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const BlendQuery& q, bool only_max) {
     constexpr int G = 4;
     const int lane = lane_id();
-    const gfloat *g0 = list_col<RAW, 0>(L), *g1 = list_col<RAW, 1>(L), *g2 = list_col<RAW, 2>(L);
-    const gfloat *g3 = list_col<RAW, 3>(L), *g4 = list_col<RAW, 4>(L), *g6 = list_col<RAW, 6>(L);
+    const gfloat* g = (const gfloat*)L.base;
     float s1 = 0.0f; int i1 = -1;
     for (int base = 0; base < L.n; base += G * kWave) {
         float x1[G], y1[G], cc[G];
@@ -477,14 +435,14 @@ __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const B
         for (int r = 0; r < G; r++) {
             const int i = base + r * kWave + lane;
             const int ii = i < L.n ? i : 0;
-            x1[r] = list_scale<RAW>(L, g1[ii]); y1[r] = list_scale<RAW>(L, g2[ii]); cc[r] = g0[ii];
+            x1[r] = g[1 * L.cap + ii]; y1[r] = g[2 * L.cap + ii]; cc[r] = g[ii];
         }
 #pragma unroll
         for (int r = 0; r < G; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
 #pragma unroll
         for (int r = 0; r < G; r++) {
             const int i = base + r * kWave + lane;
-            if (i < L.n && (!RAW || cc[r] > 0.0f) && passes_f(q, x1[r], y1[r])) {
+            if (i < L.n && passes_f(q, x1[r], y1[r])) {
                 const float sc = score_of(q, x1[r], y1[r], cc[r]);
                 if (sc >= s1) { s1 = sc; i1 = i; }
             }
@@ -500,14 +458,14 @@ __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const B
             for (int r = 0; r < G; r++) {
                 const int i = base + r * kWave + lane;
                 const int ii = i < L.n ? i : 0;
-                x1[r] = list_scale<RAW>(L, g1[ii]); y1[r] = list_scale<RAW>(L, g2[ii]); cc[r] = g0[ii];
+                x1[r] = g[1 * L.cap + ii]; y1[r] = g[2 * L.cap + ii]; cc[r] = g[ii];
             }
 #pragma unroll
             for (int r = 0; r < G; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
 #pragma unroll
             for (int r = 0; r < G; r++) {
                 const int i = base + r * kWave + lane;
-                if (i >= L.n || i == i1 || (RAW && !(cc[r] > 0.0f)) || !passes_f(q, x1[r], y1[r])) continue;
+                if (i >= L.n || i == i1 || !passes_f(q, x1[r], y1[r])) continue;
                 const float sc = score_of(q, x1[r], y1[r], cc[r]);
                 if (!(sc > 0.0f)) continue;
                 const int rank = i < i1 ? L.n + i : L.n - i;
@@ -518,8 +476,8 @@ __device__ __forceinline__ BlendResult blend_streamed(const ListView& L, const B
     }
     const bool have2 = r2 >= 0;
     const int i2 = have2 ? (r2 >= L.n ? r2 - L.n : L.n - r2) : i1;
-    const float e1x = list_scale<RAW>(L, g3[i1]), e1y = list_scale<RAW>(L, g4[i1]), e1s = list_scale<RAW>(L, g6[i1]);
-    const float e2x = list_scale<RAW>(L, g3[i2]), e2y = list_scale<RAW>(L, g4[i2]), e2s = list_scale<RAW>(L, g6[i2]);
+    const float e1x = g[3 * L.cap + i1], e1y = g[4 * L.cap + i1], e1s = g[6 * L.cap + i1];
+    const float e2x = g[3 * L.cap + i2], e2y = g[4 * L.cap + i2], e2s = g[6 * L.cap + i2];
     return blend_finish(s1, s2, have2, only_max, e1x, e1y, e1s, e2x, e2y, e2s);
 }
 
@@ -592,12 +550,10 @@ constexpr int kCompactCap = kBlendLdsFloats / 4;              // passing entries
 // blend_streamed over the chunks of `hit` only (ascending, so list positions -- and with them the tie rules --
 // are those of the full scan; no entry of another chunk can pass the window test): the last resort, when more than
 // kCompactCap entries pass.
-template <bool RAW = false>
 __device__ __forceinline__ BlendResult blend_streamed_masked(const ListView& L, const BlendQuery& q, const ChunkMask& hit) {
     constexpr int G = 4;
     const int lane = lane_id();
-    const gfloat *g0 = list_col<RAW, 0>(L), *g1 = list_col<RAW, 1>(L), *g2 = list_col<RAW, 2>(L);
-    const gfloat *g3 = list_col<RAW, 3>(L), *g4 = list_col<RAW, 4>(L), *g6 = list_col<RAW, 6>(L);
+    const gfloat* g = (const gfloat*)L.base;
     float s1 = 0.0f; int i1 = -1;
     {
         ChunkMask k = hit;
@@ -611,14 +567,14 @@ __device__ __forceinline__ BlendResult blend_streamed_masked(const ListView& L, 
             for (int r = 0; r < G; r++) {
                 const int i = ci[r] * kWave + lane;
                 const int ii = ci[r] >= 0 && i < L.n ? i : 0;
-                x1[r] = list_scale<RAW>(L, g1[ii]); y1[r] = list_scale<RAW>(L, g2[ii]); cc[r] = g0[ii];
+                x1[r] = g[1 * L.cap + ii]; y1[r] = g[2 * L.cap + ii]; cc[r] = g[ii];
             }
 #pragma unroll
             for (int r = 0; r < G; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
 #pragma unroll
             for (int r = 0; r < G; r++) {
                 const int i = ci[r] * kWave + lane;
-                if (ci[r] >= 0 && i < L.n && (!RAW || cc[r] > 0.0f) && passes_f(q, x1[r], y1[r])) {
+                if (ci[r] >= 0 && i < L.n && passes_f(q, x1[r], y1[r])) {
                     const float sc = score_of(q, x1[r], y1[r], cc[r]);
                     if (sc >= s1) { s1 = sc; i1 = i; }
                 }
@@ -640,14 +596,14 @@ __device__ __forceinline__ BlendResult blend_streamed_masked(const ListView& L, 
             for (int r = 0; r < G; r++) {
                 const int i = ci[r] * kWave + lane;
                 const int ii = ci[r] >= 0 && i < L.n ? i : 0;
-                x1[r] = list_scale<RAW>(L, g1[ii]); y1[r] = list_scale<RAW>(L, g2[ii]); cc[r] = g0[ii];
+                x1[r] = g[1 * L.cap + ii]; y1[r] = g[2 * L.cap + ii]; cc[r] = g[ii];
             }
 #pragma unroll
             for (int r = 0; r < G; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
 #pragma unroll
             for (int r = 0; r < G; r++) {
                 const int i = ci[r] * kWave + lane;
-                if (ci[r] < 0 || i >= L.n || i == i1 || (RAW && !(cc[r] > 0.0f)) || !passes_f(q, x1[r], y1[r])) continue;
+                if (ci[r] < 0 || i >= L.n || i == i1 || !passes_f(q, x1[r], y1[r])) continue;
                 const float sc = score_of(q, x1[r], y1[r], cc[r]);
                 if (!(sc > 0.0f)) continue;
                 const int rank = i < i1 ? L.n + i : L.n - i;
@@ -658,17 +614,15 @@ __device__ __forceinline__ BlendResult blend_streamed_masked(const ListView& L, 
     reduce_second(s2, r2);
     const bool have2 = r2 >= 0;
     const int i2 = have2 ? (r2 >= L.n ? r2 - L.n : L.n - r2) : i1;
-    const float e1x = list_scale<RAW>(L, g3[i1]), e1y = list_scale<RAW>(L, g4[i1]), e1s = list_scale<RAW>(L, g6[i1]);
-    const float e2x = list_scale<RAW>(L, g3[i2]), e2y = list_scale<RAW>(L, g4[i2]), e2s = list_scale<RAW>(L, g6[i2]);
+    const float e1x = g[3 * L.cap + i1], e1y = g[4 * L.cap + i1], e1s = g[6 * L.cap + i1];
+    const float e2x = g[3 * L.cap + i2], e2y = g[4 * L.cap + i2], e2s = g[6 * L.cap + i2];
     return blend_finish(s1, s2, have2, false, e1x, e1y, e1s, e2x, e2y, e2s);
 }
 
-template <bool RAW = false>
 __device__ __forceinline__ BlendResult blend_compacted(const ListView& L, const BlendQuery& q, const ChunkMask& hit, float* tgt) {
     constexpr int G = 4;
     const int lane = lane_id();
-    const gfloat *g0 = list_col<RAW, 0>(L), *g1 = list_col<RAW, 1>(L), *g2 = list_col<RAW, 2>(L);
-    const gfloat *g3 = list_col<RAW, 3>(L), *g4 = list_col<RAW, 4>(L), *g6 = list_col<RAW, 6>(L);
+    const gfloat* g = (const gfloat*)L.base;
     float* cx = tgt; float* cy = cx + kCompactCap; float* cv = cy + kCompactCap; int* ci_ = (int*)(cv + kCompactCap);
     int cnt = 0;
     {
@@ -683,14 +637,14 @@ __device__ __forceinline__ BlendResult blend_compacted(const ListView& L, const 
             for (int r = 0; r < G; r++) {
                 const int i = ci[r] * kWave + lane;
                 const int ii = ci[r] >= 0 && i < L.n ? i : 0;
-                x1[r] = list_scale<RAW>(L, g1[ii]); y1[r] = list_scale<RAW>(L, g2[ii]); cc[r] = g0[ii];
+                x1[r] = g[1 * L.cap + ii]; y1[r] = g[2 * L.cap + ii]; cc[r] = g[ii];
             }
 #pragma unroll
             for (int r = 0; r < G; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
 #pragma unroll
             for (int r = 0; r < G; r++) {
                 const int i = ci[r] * kWave + lane;
-                const bool pass = ci[r] >= 0 && i < L.n && (!RAW || cc[r] > 0.0f) && passes_f(q, x1[r], y1[r]);
+                const bool pass = ci[r] >= 0 && i < L.n && passes_f(q, x1[r], y1[r]);
                 const unsigned long long m = __ballot(pass);
                 if (m == 0ull) continue;
                 const int slot = cnt + prefix_count(m);
@@ -700,7 +654,7 @@ __device__ __forceinline__ BlendResult blend_compacted(const ListView& L, const 
         }
     }
     if (cnt == 0) return blend_none();                         // :76
-    if (cnt > kCompactCap) return blend_streamed_masked<RAW>(L, q, hit);
+    if (cnt > kCompactCap) return blend_streamed_masked(L, q, hit);
     wave_sync();
     float s1 = 0.0f; int i1 = -1;
     for (int e = lane; e < cnt; e += kWave) {                  // ascending list index per lane: ">=" keeps the last among equals
@@ -722,12 +676,11 @@ __device__ __forceinline__ BlendResult blend_compacted(const ListView& L, const 
     wave_sync();                                               // the area is free for the next scan
     const bool have2 = r2 >= 0;
     const int i2 = have2 ? (r2 >= L.n ? r2 - L.n : L.n - r2) : i1;
-    const float e1x = list_scale<RAW>(L, g3[i1]), e1y = list_scale<RAW>(L, g4[i1]), e1s = list_scale<RAW>(L, g6[i1]);
-    const float e2x = list_scale<RAW>(L, g3[i2]), e2y = list_scale<RAW>(L, g4[i2]), e2s = list_scale<RAW>(L, g6[i2]);
+    const float e1x = g[3 * L.cap + i1], e1y = g[4 * L.cap + i1], e1s = g[6 * L.cap + i1];
+    const float e2x = g[3 * L.cap + i2], e2y = g[4 * L.cap + i2], e2s = g[6 * L.cap + i2];
     return blend_finish(s1, s2, have2, false, e1x, e1y, e1s, e2x, e2y, e2s);
 }
 
-template <bool RAW = false>
 __device__ __forceinline__ BlendResult blend_long(const ListView& L, const BlendQuery& q, float* tgt) {
     const int lane = lane_id();
     const int nch = (L.n + kWave - 1) >> 6;                     // <= L.nb <= kListBboxMax
@@ -759,13 +712,13 @@ __device__ __forceinline__ BlendResult blend_long(const ListView& L, const Blend
             if (ci >= 0) chunks = (chunks & ~(0xffull << (8 * r))) | ((unsigned long long)ci << (8 * r));
         }
         BlendResult r;
-        if (nh == 1) r = blend_cached<1, RAW>(L, q, false, tgt, nullptr, chunks);
-        else if (nh == 2) r = blend_cached<2, RAW>(L, q, false, tgt, nullptr, chunks);
-        else if (nh <= 4) r = blend_cached<4, RAW>(L, q, false, tgt, nullptr, chunks);
-        else r = blend_cached<kBlendChunks, RAW>(L, q, false, tgt, nullptr, chunks);
+        if (nh == 1) r = blend_cached<1>(L, q, false, tgt, nullptr, chunks);
+        else if (nh == 2) r = blend_cached<2>(L, q, false, tgt, nullptr, chunks);
+        else if (nh <= 4) r = blend_cached<4>(L, q, false, tgt, nullptr, chunks);
+        else r = blend_cached<kBlendChunks>(L, q, false, tgt, nullptr, chunks);
         if (r.ok >= 0) return r;
     }
-    return blend_compacted<RAW>(L, q, hit, tgt);
+    return blend_compacted(L, q, hit, tgt);
 }
 
 // LONG: the list set has a box for every chunk in global memory (the force-complete kernel); the seed kernel keeps
@@ -774,11 +727,10 @@ template <bool LONG>
 __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, double x, double y, double xy_scale,
                                              double filter_sigmas) {
     c.n_blend++;
-    if constexpr (LONG) {                                      // the force-complete kernel: RAW lists, a box for every chunk
-        const BlendQuery q = make_query(x, y, xy_scale, filter_sigmas);
-        if (L.gbbox && L.n <= L.nb * kWave) return blend_long<true>(L, q, c.tgt);
-        return blend_streamed<true>(L, q, false);              // (more chunks than the hit mask has bits: every cell of the field)
-    } else {
+    if constexpr (LONG) {
+        if (L.gbbox && L.n > kWave && L.n <= L.nb * kWave)
+            return blend_long(L, make_query(x, y, xy_scale, filter_sigmas), c.tgt);
+    }
     if (L.bbox && L.n > kWave && L.n <= kListBboxChunks * kWave) {
 #ifdef OPA_ASSOC_PHASE_TIMING
         PH(17);
@@ -804,7 +756,6 @@ __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, dou
     return blend_impl(L.base, L.cap, L.n, x, y, xy_scale, filter_sigmas, 0, c.tgt, nullptr, c.max_r);
 #endif
 #endif
-    }
 }
 
 // A joint was assigned (cifcaf.cpp:310): during the seed pipeline the grower publishes the occupancy box the
@@ -896,7 +847,7 @@ __device__ __forceinline__ bool connection_value(ImageCtx& c, const DevParams& p
                                  bool reverse_match_, double filter_sigmas,
                                  double* nv, float* nx, float* ny, float* ns) {
     const int start = info & 0xff, bone = (info >> 16) & 0xff, fwd = (info >> 24) & 1;
-    const ListView caf_f = list_view<LONG>(c, bone, fwd ? 0 : 1);
+    const ListView caf_f = list_view(c, bone, fwd ? 0 : 1);
     const double sv = c.jv[start], sx = (double)c.jx[start], sy = (double)c.jy[start], ss = (double)c.js[start];
     const BlendResult nj = blend<LONG>(c, caf_f, sx, sy, ss, filter_sigmas);
     if (!nj.ok) return false;
@@ -904,7 +855,7 @@ __device__ __forceinline__ bool connection_value(ImageCtx& c, const DevParams& p
     *nv = sqrt(nj.v * sv);                                                      // :386
     if (*nv < p.keypoint_threshold || *nv < sv * p.keypoint_threshold_rel) return false;   // :387-390
     if (p.reverse_match && reverse_match_ && start < c.F) {                     // :397
-        const ListView caf_b = list_view<LONG>(c, bone, fwd ? 1 : 0);
+        const ListView caf_b = list_view(c, bone, fwd ? 1 : 0);
         const BlendResult rj = blend<LONG>(c, caf_b, (double)*nx, (double)*ny, (double)*ns, filter_sigmas);
         if (!rj.ok) return false;
         if (fabs(sx - (double)rj.x) + fabs(sy - (double)rj.y) > ss) return false;   // :404
@@ -1126,17 +1077,13 @@ __device__ __forceinline__ bool reg_connection_value(ImageCtx& c, const DevParam
     const int bone = (info >> 16) & 0xff, fwd = (info >> 24) & 1;
     // (the view of the reverse list is built after the forward scan: nothing of it has to stay live across that scan)
     auto view = [&](int dir) {
-        if constexpr (LONG) return list_view<true>(c, bone, dir);   // force-complete kernel: the field itself (RAW lists)
-        else {
-            ListView v;
-            v.cap = c.list_cap;
-            v.base = c.lists + ((size_t)bone * 2 + dir) * 7 * c.list_cap;
-            v.n = rlane(R.list_n, bone * 2 + dir);
-            v.bbox = c.bbox ? c.bbox + (bone * 2 + dir) * kListBboxChunks : nullptr;
-            v.gbbox = c.gbbox ? c.gbbox + (size_t)(bone * 2 + dir) * c.nb : nullptr; v.nb = c.nb;
-            v.sc = nullptr; v.mul = 1.0f; v.swap = 0;
-            return v;
-        }
+        ListView v;
+        v.cap = c.list_cap;
+        v.base = c.lists + ((size_t)bone * 2 + dir) * 7 * c.list_cap;
+        v.n = rlane(R.list_n, bone * 2 + dir);
+        v.bbox = c.bbox ? c.bbox + (bone * 2 + dir) * kListBboxChunks : nullptr;
+        v.gbbox = c.gbbox ? c.gbbox + (size_t)(bone * 2 + dir) * c.nb : nullptr; v.nb = c.nb;
+        return v;
     };
     const ListView caf_f = view(fwd ? 0 : 1);
     const double sv = reg_jv(R, start);
@@ -1645,7 +1592,6 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     c.lists = a.lists + (size_t)b * A * 2 * 7 * a.list_cap;
     c.list_counts = a.list_counts + (size_t)b * A * 2;
     c.list_cap = a.list_cap;
-    c.raw_caf = nullptr; c.raw_sc = nullptr; c.raw_mul = 1.0f;
     c.occ_h = a.occ_h; c.occ_w = a.occ_w; c.occ_wpr = (a.occ_w + 31) >> 5;
     c.occ = a.occ + (size_t)b * a.occ_image_words;
     c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
@@ -2394,12 +2340,9 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_fc_kernel(AssocArgs a, D
 
     ImageCtx c;
     c.K = K; c.A = A; c.F = a.F; c.wave = wave;
-    c.lists = nullptr;                               // the force-complete "lists" are the CAF field itself (RAW lists, list_view)
+    c.lists = a.lists_fc + (size_t)b * A * 2 * 7 * a.list_cap;
     c.list_counts = a.list_counts_fc + (size_t)b * A * 2;
     c.list_cap = a.list_cap;
-    c.raw_caf = a.caf_raw + (size_t)b * A * 8 * a.list_cap;
-    c.raw_sc = a.scores_fc + (size_t)b * A * 2 * a.list_cap;
-    c.raw_mul = (float)a.caf_stride;
     c.occ_h = a.occ_h; c.occ_w = a.occ_w; c.occ_wpr = (a.occ_w + 31) >> 5;
     c.occ = nullptr;
     c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
@@ -2588,7 +2531,7 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     }
     prof_mark(st, "cifcaf_assoc_kernel");
     if (e == hipSuccess && p.force_complete) {
-        if (!a.fc_meta || !a.scores_fc || !a.caf_raw) return hipErrorInvalidValue;
+        if (!a.fc_meta || !a.lists_fc) return hipErrorInvalidValue;
         e = reg ? launch_fc_nw<true, 12>(a, sk, p, st) : launch_fc_nw<false, 12>(a, sk, p, st);
         prof_mark(st, "cifcaf_fc_kernel");
     }
@@ -2604,7 +2547,7 @@ __global__ __launch_bounds__(64) void blend_rows_kernel(const float* rows, int n
         for (int k = 0; k < 7; k++) soa[(size_t)k * n + i] = rows[(size_t)i * 7 + k];
     __threadfence_block();
     __shared__ float tgt[kBlendLdsFloats];
-    ListView L; L.base = soa; L.cap = n; L.n = n; L.bbox = nullptr; L.gbbox = nullptr; L.nb = 0; L.sc = nullptr; L.mul = 1.0f; L.swap = 0;
+    ListView L; L.base = soa; L.cap = n; L.n = n; L.bbox = nullptr; L.gbbox = nullptr; L.nb = 0;
     const BlendResult r = blend_impl(L.base, L.cap, L.n, x, y, s, filter_sigmas, only_max, tgt);
     if (lane == 0) {
         if (r.ok) { out4[0] = (double)r.x; out4[1] = (double)r.y; out4[2] = (double)r.s; out4[3] = r.v; }

@@ -123,8 +123,6 @@ struct ScoredArgs {
     const float* cifhr; int F, hr_rows, hr_cols, hr_pitch;
     const int64_t* skeleton; double score_th, cif_floor; int no_rescore;
     float* lists; int32_t* counts;
-    float* raw_scores;                        // force-complete set: no lists -- [planes][2][HW] rescored confidences (0: not kept),
-                                              // chunk boxes over the field's 64-cell chunks (cifcaf.hip: RAW lists); else null
     const unsigned* tile_touch; int touch_words, tiles_x;   // [B][F][touch_words] touched-tile bitmaps of the map (or null)
     const int32_t* hr_slot; int hr_tpp;       // pooled map: [B][F][hr_tpp] slot tables (null: dense map)
     size_t hr_image_stride;                   // floats between the maps of two images (dense: F * rows * pitch; pooled: cap * tile)
@@ -137,7 +135,7 @@ ScoredArgs make_scored_args(const float* caf, int B, int A, int cH, int cW, int 
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
                             float* lists, int32_t* counts, float* chunk_bbox, int bbox_chunks, int bbox_stride,
-                            const unsigned* tile_touch = nullptr, const HrPool* pool = nullptr, float* raw_scores = nullptr);
+                            const unsigned* tile_touch = nullptr, const HrPool* pool = nullptr);
 
 hipError_t launch_cafscored(const ScoredArgs& s, hipStream_t st);
 hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
@@ -183,9 +181,7 @@ struct AssocArgs {
     const int32_t* seed_f; const float* seed_vxys; const int32_t* seed_count;
     const int32_t* seed_cell;  // occupancy cell of the seed: x | y << 12 | box half-width << 24 (seed_cell_pack)
     const float* lists; const int32_t* list_counts;          // caf_th lists
-    const float* scores_fc; const int32_t* list_counts_fc;   // force complete: rescored confidence planes [B][A][2][cells] (0: the cell
-                                                             // did not pass) of the RAW lists (cifcaf.hip), cells kept per list; or null
-    const float* caf_raw; int caf_stride;                    // ... the CAF field tensor itself [B][A][8][cells] and its stride
+    const float* lists_fc; const int32_t* list_counts_fc;    // force-complete lists (or null)
     const float* list_bbox;  // [B][A][2][bbox_chunks][4] chunk boxes of `lists` (or null)
     const float* list_bbox_fc;  // ... of `lists_fc` (or null)
     int bbox_chunks;

@@ -68,40 +68,6 @@ def _check_boxes(dec, what_boxes, what_lists, what_counts, B, A, HW, n_boxed=Non
     return counts, checked
 
 
-def _check_raw_set(dec, port, skeleton0, cifs, cafs, B, A, HW):
-    """The force-complete list set is not materialised (round 4): per (image, bone, direction) a plane of rescored
-    confidences -- 0 where the cell did not pass, caf_scored.cpp:74-80 -- and the (x, y) box of the kept cells of every
-    64-cell chunk of the FIELD.  The kept confidences, in raster order, must be the oracle's list column 0, the boxes
-    must be exact."""
-    nb = (HW + 63) // 64
-    scores = dec.workspace_view('lists_fc', torch.float32)[:B * A * 2 * HW].view(B, A, 2, HW).cpu().numpy()
-    counts = dec.workspace_view('list_counts_fc', torch.int32)[:B * A * 2].view(B, A, 2).cpu().numpy()
-    boxes = dec.workspace_view('list_bbox_fc', torch.float32)[:B * A * 2 * nb * 4].view(B, A, 2, nb, 4).cpu().numpy()
-    checked = 0
-    for b in range(B):
-        ref_hr = port.cifhr_accumulate(cifs[b], 8)
-        ref_f, ref_b = port.cafscored(cafs[b], 8, ref_hr, cifs[b].shape, 8, skeleton0, score_th=0.001)
-        for a in range(A):
-            for d, ref in ((0, ref_f[a]), (1, ref_b[a])):
-                kept = scores[b, a, d] > 0
-                assert kept.sum() == counts[b, a, d] == len(ref)
-                assert np.array_equal(scores[b, a, d][kept], np.asarray(ref)[:, 0])
-                xs = cafs[b, a, 2 if d == 0 else 4].reshape(-1) * np.float32(8)
-                ys = cafs[b, a, 3 if d == 0 else 5].reshape(-1) * np.float32(8)
-                pad = nb * 64 - HW
-                k2 = np.pad(kept, (0, pad)).reshape(nb, 64)
-                x2 = np.where(k2, np.pad(xs, (0, pad)).reshape(nb, 64), np.nan)
-                y2 = np.where(k2, np.pad(ys, (0, pad)).reshape(nb, 64), np.nan)
-                with np.errstate(all='ignore'):
-                    want = np.stack([np.nanmin(x2, 1), np.nanmax(x2, 1), np.nanmin(y2, 1), np.nanmax(y2, 1)], 1)
-                full = k2.any(axis=1)
-                got = boxes[b, a, d]
-                assert np.array_equal(got[full], want[full].astype(np.float32)), (b, a, d)
-                assert (got[~full, 0] > got[~full, 1]).all() and (got[~full, 2] > got[~full, 3]).all()
-                checked += int(full.sum())
-    return counts, checked
-
-
 def test_chunk_boxes_of_both_list_sets_and_force_complete_scans(native, port, coco_skeleton0, monkeypatch):
     """cafscored leaves the (x1, y1) bounding box of EVERY 64-entry chunk of every list of the force-complete set
     (and of the first 16 chunks of the caf_th set) in the workspace; the force-complete kernel (cifcaf.cpp:414-427:
@@ -119,8 +85,8 @@ def test_chunk_boxes_of_both_list_sets_and_force_complete_scans(native, port, co
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             _, n1 = _check_boxes(dec, 'list_bbox', 'lists', 'list_counts', B, A, HW, n_boxed=16)
-            counts_fc, n2 = _check_raw_set(dec, port, coco_skeleton0, cifs, cafs, B, A, HW)
-        assert counts_fc.max() > 16 * 64, 'the force-complete set should keep far more cells than 16 chunks'
+            counts_fc, n2 = _check_boxes(dec, 'list_bbox_fc', 'lists_fc', 'list_counts_fc', B, A, HW)
+        assert counts_fc.max() > 16 * 64, 'force-complete lists should span far more than the 16 LDS-resident boxes'
         assert n2 > 20 * n1 > 0
         for b, (seed, people) in enumerate(cases):
             want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0, params=port.default_params(**kw))
