@@ -945,17 +945,29 @@ def main():
         def lanes_leg():
             alg = algorithmic_bytes(wl.B, wl.K, wl.A, wl.fh, wl.fh, wl.stride, wl.dec.max_annotations)['decode_path']
             rate, gbps = {}, {}
-            for n, key in ((1, 'one_in_flight'), (2, 'two_in_flight'), (4, 'four_in_flight'), (8, 'eight_in_flight')):
-                steps = 96                                 # (every lane's first calls allocate its workspace: warm-up per lane)
-                leg = run_leg(wl, None, 'fp32', steps, 4 * n + 4, decode_only=True, n_streams=n)
-                rate[key] = round(wl.B * steps / leg['elapsed'], 1)
-                gbps[key] = round(alg * steps / leg['elapsed'] / 1e9, 1)
+            order0 = native.get_seed_tie_order()
+            try:
+                for mode in ('libstdcxx', 'libstdcxx-fused'):  # the tie pass as a launch of its own / inside the association kernel
+                    native.set_seed_tie_order(mode)
+                    for n, key in ((1, 'one_in_flight'), (2, 'two_in_flight'), (4, 'four_in_flight'), (8, 'eight_in_flight'),
+                                   (12, 'twelve_in_flight')):
+                        if mode == 'libstdcxx-fused' and n in (1, 4):
+                            continue
+                        key = key if mode == 'libstdcxx' else key + '_ties_fused'
+                        steps = 96                             # (every lane's first calls allocate its workspace: warm-up per lane)
+                        leg = run_leg(wl, None, 'fp32', steps, 4 * n + 4, decode_only=True, n_streams=n)
+                        rate[key] = round(wl.B * steps / leg['elapsed'], 1)
+                        gbps[key] = round(alg * steps / leg['elapsed'] / 1e9, 1)
+            finally:
+                native.set_seed_tie_order(order0)
             best = max(gbps, key=gbps.get)
             return {'decode_only_images_per_s': rate, 'GBps': gbps,
                     'best': {'mode': best, 'GBps': gbps[best], 'frac': round(gbps[best] / HBM_PEAK_GBPS, 5)},
+                    'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'default'),
                     'what': 'decode only, config 2 fields, alternating batches, annotations copied to the host; '
                             'native.DecodeLanes(lanes=n): n decoders / workspaces / streams; GBps = SURVEY 8d '
-                            'algorithmic bytes of a batch x batches per second (wall clock, whole decode path)'}
+                            'algorithmic bytes of a batch x batches per second (wall clock, whole decode path); '
+                            '*_ties_fused: seed tie order "libstdcxx-fused" (the tie pass inside the association kernel)'}
         guarded('decode_two_in_flight', lanes_leg)
 
         # the adversarial case (BASELINE.md 3 ii): structureless all-active fields, what a random-init head

@@ -113,8 +113,11 @@ void opa_set_quiet(int quiet);
  *                (int32 [B]) says per image: 0 no equal scores, 1 re-ordered, -1 not reproduced (introsort's heapsort
  *                branch: the image keeps the order below).
  *   0            cell index ascending (field, row, column) -- one launch less.
- * Process-global like the reference's statics; the environment variable OPA_SEED_TIES=index selects 0 when this
- * function was never called. */
+ *   2            like 1, with the pass running inside the association kernel (every image its own ties) instead of as a
+ *                launch of its own: no shorter for one decode, better when several decodes are in flight on streams of
+ *                their own (stage-level entry points: like 1).
+ * Process-global like the reference's statics; the environment variable OPA_SEED_TIES=index / libstdcxx-fused selects 0 / 2
+ * when this function was never called. */
 void opa_set_seed_tie_order(int order);
 int opa_get_seed_tie_order(void);
 

@@ -20,7 +20,9 @@ static int g_seed_tie_order = -1;          // -1: not set (OPA_SEED_TIES, else l
 int seed_tie_order() {
     if (g_seed_tie_order >= 0) return g_seed_tie_order;
     const char* e = std::getenv("OPA_SEED_TIES");
-    return e && (std::strcmp(e, "index") == 0 || std::strcmp(e, "0") == 0) ? 0 : 1;
+    if (e && (std::strcmp(e, "index") == 0 || std::strcmp(e, "0") == 0)) return 0;
+    if (e && (std::strcmp(e, "libstdcxx-fused") == 0 || std::strcmp(e, "2") == 0)) return 2;
+    return 1;
 }
 
 static opa_params default_params() {
@@ -195,7 +197,7 @@ int opa_device_count(void) {
 
 void opa_set_quiet(int quiet) { g_quiet = quiet; }
 
-void opa_set_seed_tie_order(int order) { g_seed_tie_order = order ? 1 : 0; }
+void opa_set_seed_tie_order(int order) { g_seed_tie_order = order == 2 ? 2 : order ? 1 : 0; }
 int opa_get_seed_tie_order(void) { return opa::seed_tie_order(); }
 
 void opa_default_params(opa_params* out) { if (out) *out = default_params(); }
@@ -434,12 +436,13 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     ties.big = ws + L.off_act; ties.big_stride = (size_t)L.F * 4 * (L.H * L.W) * sizeof(float);
     ties.small_ = ws + L.off_tie_small; ties.small_stride = L.tie_small_stride;
     ties.state = (int32_t*)(ws + L.off_tie_state);
-    // OPA_FUSE_TIES=1: the tie pass runs in the association kernel instead of a launch of its own (every image its own
-    // ties, before its seeds are read).  Measured in round 4: the decode gets 2 % shorter, not 9 % -- the images with the
-    // most seeds are both the likeliest to hold equal scores and the slowest to associate -- so the separate launch,
-    // whose time shows up under its own name, stays the default.
+    // Tie order 2 (or OPA_FUSE_TIES=1): the tie pass runs in the association kernel instead of a launch of its own (every
+    // image its own ties, before its seeds are read).  Measured in round 4: ONE decode gets 2 % shorter, not 9 % -- the
+    // images with the most seeds are both the likeliest to hold equal scores and the slowest to associate -- but with
+    // several decodes in flight (DecodeLanes) the pass overlaps like the association does instead of filling the chip
+    // for 80 us per batch.  The separate launch, whose time shows up under its own name, stays the default.
     const char* fuse_ties_env = std::getenv("OPA_FUSE_TIES");
-    const bool fuse_ties = seed_tie_order() == 1 && fuse_ties_env && std::atoi(fuse_ties_env) != 0;
+    const bool fuse_ties = seed_tie_order() >= 1 && (seed_tie_order() == 2 || (fuse_ties_env && std::atoi(fuse_ties_env) != 0));
     ties.defer = fuse_ties ? 1 : 0;
     e = launch_cifseeds(cif_dev, L.B, L.F, L.H, L.W, L.stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
                         (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap,

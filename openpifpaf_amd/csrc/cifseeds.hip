@@ -420,7 +420,7 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
         if (e != hipSuccess) return e;
         prof_mark(st, "memset_seed_count");
     }
-    const bool tie_pass = ties && ties->big && seed_tie_order() == 1;
+    const bool tie_pass = ties && ties->big && seed_tie_order() >= 1;
     dim3 grid(B * F, (HW + 256 * kFillCells - 1) / (256 * kFillCells));
     cifseeds_fill_kernel<<<grid, 256, 0, st>>>(cif, F, NC, H, W, stride, cifhr, hr_rows, hr_cols, hr_pitch,
                                                p.seed_threshold, det ? 0 : p.ablation_cifseeds_nms,

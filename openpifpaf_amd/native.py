@@ -62,18 +62,19 @@ def set_quiet(quiet=True):
     _lib.lib().opa_set_quiet(int(bool(quiet)))
 
 
-SEED_TIE_ORDERS = {'libstdcxx': 1, 'index': 0}
+SEED_TIE_ORDERS = {'libstdcxx': 1, 'index': 0, 'libstdcxx-fused': 2}
 
 
 def set_seed_tie_order(order='libstdcxx'):
     """Order of seeds with EQUAL scores: ``'libstdcxx'`` (default) = what the reference's unstable ``std::sort``
     leaves (cif_seeds.cpp:94), reproduced on the device for the images that have such seeds; ``'index'`` = cell index
-    ascending (one launch less).  Process-global, like the reference's statics."""
+    ascending (one launch less); ``'libstdcxx-fused'`` = the reference's order with the pass inside the association kernel
+    (no launch of its own: what several decodes in flight want).  Process-global, like the reference's statics."""
     _lib.lib().opa_set_seed_tie_order(SEED_TIE_ORDERS[order])
 
 
 def get_seed_tie_order():
-    return 'libstdcxx' if _lib.lib().opa_get_seed_tie_order() else 'index'
+    return {0: 'index', 1: 'libstdcxx', 2: 'libstdcxx-fused'}[_lib.lib().opa_get_seed_tie_order()]
 
 
 def _device():

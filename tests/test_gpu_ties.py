@@ -166,3 +166,53 @@ def test_wholebody_bf16_fields(native, port):
         want = port.decode(cifs[b], 8, cafs[b], 8, skel0)[0]
         ok, msg = compare_annotations(out[b, :native.count_rows(int(counts[b]))], want)
         assert ok, 'image %d: %s' % (b, msg)
+
+
+def test_tie_pass_inside_the_association_kernel_equals_the_separate_launch(native, port, coco_skeleton0):
+    """Seed tie order 'libstdcxx-fused' (round 4): the pass that puts equal scores into std::sort's order runs in the
+    association kernel's prologue, each image its own, instead of as a launch of its own.  Same seeds, same annotations,
+    bit for bit -- on float32 fields with a few ties, on bf16-rounded ones with ties everywhere, and on a wholebody image
+    beyond the LDS arrays (arrays in global memory, 12 waves instead of 16)."""
+    from openpifpaf_amd import constants, synth
+    cifs, cafs = synth.synth_batch(8, seed0=0)
+    cases = [(cifs, cafs, coco_skeleton0), (to_bf16(cifs), to_bf16(cafs), coco_skeleton0)]
+    wb = constants.wholebody()
+    wc, wf = synth.synth_batch(2, seed0=3, people=(6, 10), pose=wb['standing_pose'], skeleton=wb['skeleton'])
+    cases.append((to_bf16(wc), to_bf16(wf), np.asarray(wb['skeleton'], dtype=np.int64) - 1))
+    old = native.get_seed_tie_order()
+    try:
+        for cif, caf, skel0 in cases:
+            res = {}
+            for mode in ('libstdcxx', 'libstdcxx-fused'):
+                native.set_seed_tie_order(mode)
+                assert native.get_seed_tie_order() == mode
+                dec = native.CifCaf(cif.shape[1], torch.from_numpy(skel0))
+                out, ids, counts = dec.call_batch(dev(cif), 8, dev(caf), 8)
+                counts = counts.cpu().numpy()
+                native.check_counts(counts)
+                B = len(counts)
+                n_seeds = dec.workspace_view('seed_count', torch.int32)[:B].cpu().numpy()
+                cap = cif.shape[1] * cif.shape[3] * cif.shape[4]
+                sf = dec.workspace_view('seed_f', torch.int32)[:B * cap].view(B, cap).cpu().numpy()
+                sv = dec.workspace_view('seed_vxys', torch.float32)[:B * cap * 4].view(B, cap, 4).cpu().numpy()
+                ties = dec.workspace_view('seed_ties', torch.int32)[:B].cpu().numpy()
+                res[mode] = (out.cpu().numpy(), counts, [sf[b, :n_seeds[b]].copy() for b in range(B)],
+                             [sv[b, :n_seeds[b]].copy() for b in range(B)], ties)
+            a, b_ = res['libstdcxx'], res['libstdcxx-fused']
+            assert np.array_equal(a[1], b_[1]) and np.array_equal(a[4], b_[4]) and (a[4] != -1).all()
+            for i in range(len(a[1])):
+                assert np.array_equal(a[2][i], b_[2][i]) and np.array_equal(a[3][i], b_[3][i]), 'seed order of image %d' % i
+                n = native.count_rows(int(a[1][i]))
+                assert np.array_equal(a[0][i, :n], b_[0][i, :n])
+            assert (a[4] == 1).any()                                   # the case has images with equal scores
+        # and against the oracle (same std::sort) for the float32 batch
+        native.set_seed_tie_order('libstdcxx-fused')
+        dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+        out, ids, counts = dec.call_batch(dev(cifs), 8, dev(cafs), 8)
+        counts = counts.cpu().numpy()
+        for i in range(8):
+            want, _ = port.decode(cifs[i], 8, cafs[i], 8, coco_skeleton0)
+            ok, msg = compare_annotations(out[i, :native.count_rows(int(counts[i]))].cpu().numpy(), want)
+            assert ok, msg
+    finally:
+        native.set_seed_tie_order(old)
