@@ -95,6 +95,9 @@ class Annotation:
         return ann
 
 
+_meta_staging = {}     # pinned upload buffers of inverse_transform_batch (a small ring per device and batch size)
+
+
 def inverse_transform_batch(annotations, metas):
     """``Annotation.inverse_transform`` (reference ``annotation.py:162-200``) for a whole decoded batch at
     once, on the device the decoder left it on: ``annotations`` ``[B, max, K, 4]`` (v, x, y, s) as returned by
@@ -115,7 +118,15 @@ def inverse_transform_batch(annotations, metas):
                      float(m['width_height'][0]) - 1.0 if flip else 0.0])
     t = torch.tensor(rows, dtype=annotations.dtype)
     if annotations.is_cuda:                 # through pinned memory: a pageable upload would make the host wait for the stream
-        t = t.pin_memory().to(annotations.device, non_blocking=True)
+        ring = _meta_staging.setdefault((str(annotations.device), B, annotations.dtype), {'bufs': [torch.empty((B, 6), dtype=annotations.dtype).pin_memory() for _ in range(4)], 'events': [None] * 4, 'next': 0})
+        k = ring['next']
+        ring['next'] = (k + 1) % 4
+        if ring['events'][k] is not None:
+            ring['events'][k].synchronize()
+        ring['bufs'][k].copy_(t)
+        t = ring['bufs'][k].to(annotations.device, non_blocking=True)
+        ring['events'][k] = torch.cuda.Event()
+        ring['events'][k].record(torch.cuda.current_stream(annotations.device))
     t = t.view(B, 1, 1, 6)
     out = annotations.clone()
     out[..., 1] = (annotations[..., 1] + t[..., 0]) / t[..., 2]

@@ -175,6 +175,36 @@ def preprocess_image(image, *, long_edge=None, batch_mode=False, fast=True):
     return torch.from_numpy(np.ascontiguousarray(x.transpose(2, 0, 1))), meta
 
 
+def _as_u8_rgb(image):
+    """-> contiguous uint8 ``[H, W, 3]`` numpy array (what ``_to_pil(image)`` holds)."""
+    if isinstance(image, np.ndarray) and image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3:
+        return np.ascontiguousarray(image)
+    return np.ascontiguousarray(np.asarray(_to_pil(image), dtype=np.uint8))
+
+
+class _Staging:
+    """Two pinned host buffers per (device, shape) for the frames of a batch: frames are copied in with memcpy and go to the
+    device in ONE asynchronous upload.  (Pinning every frame on its own costs a pinned allocation per frame -- milliseconds
+    each, and the runtime may wait for the device -- and an upload from pageable memory makes the host wait for the stream.)
+    A buffer is reused only after the upload that read it last has finished (its event)."""
+    _slots = {}
+
+    @classmethod
+    def get(cls, device, shape):
+        key = (str(device), tuple(shape))
+        ring = cls._slots.get(key)
+        if ring is None:
+            if len(cls._slots) > 8:                    # a stream of differently sized batches: do not hoard pinned memory
+                cls._slots.clear()
+            ring = cls._slots[key] = {'bufs': [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(2)],
+                                      'events': [None, None], 'next': 0}
+        k = ring['next']
+        ring['next'] = 1 - k
+        if ring['events'][k] is not None:
+            ring['events'][k].synchronize()
+        return ring, k
+
+
 def preprocess_batch_device(images, *, long_edge, device, fast=True):
     """Device-side form of ``preprocess_image`` for batch mode: the uint8 frames are
     uploaded as they are (a quarter of the bytes of normalised float32), rescaled to ``long_edge`` with the
@@ -185,17 +215,31 @@ def preprocess_batch_device(images, *, long_edge, device, fast=True):
     assert long_edge, '--long-edge must be provided for batch size > 1'
     mean, std, fill, d255 = _device_constants(device)
     canvas = fill.expand(len(images), long_edge, long_edge, 3).contiguous()
+    frames = [_as_u8_rgb(image) for image in images]
+    on_gpu = torch.device(device).type == 'cuda'
+    same = on_gpu and len({f.shape for f in frames}) == 1
+    stack = None
+    if same:                                          # the usual case (a video, a batch of one camera): one pinned upload
+        ring, k = _Staging.get(device, (len(frames),) + frames[0].shape)
+        host = ring['bufs'][k].numpy()
+        for b, f in enumerate(frames):
+            host[b] = f
+        stack = ring['bufs'][k].to(device, non_blocking=True)
+        ring['events'][k] = torch.cuda.Event()
+        ring['events'][k].record(torch.cuda.current_stream(device))
     metas = []
-    for b, image in enumerate(images):
-        frame = torch.from_numpy(np.ascontiguousarray(np.asarray(_to_pil(image), dtype=np.uint8)))
+    for b, frame in enumerate(frames):
         h0, w0 = frame.shape[:2]
         tw, th = _target_size(w0, h0, long_edge)
-        # (through pinned memory: an upload from pageable memory makes the host wait for everything queued on the stream)
-        x = frame.pin_memory().to(device, non_blocking=True) if torch.device(device).type == 'cuda' else frame.to(device)
+        x = stack[b] if stack is not None else torch.from_numpy(frame).to(device)
         if (th, tw) != (h0, w0):
             x = (resize_bilinear_u8 if fast else zoom_linear_u8)(x, th, tw)
         left, top = max(0, int((long_edge - tw) / 2.0)), max(0, int((long_edge - th) / 2.0))
-        canvas[b, top:top + th, left:left + tw] = x
+        if stack is not None and (th, tw) == (h0, w0):
+            if b == 0:                                # all frames alike and no rescale: one placement for the batch
+                canvas[:, top:top + th, left:left + tw] = stack
+        else:
+            canvas[b, top:top + th, left:left + tw] = x
         sx, sy = (tw - 1) / (w0 - 1), (th - 1) / (h0 - 1)
         metas.append({'offset': np.array((-float(left), -float(top))), 'scale': np.array((sx, sy)), 'hflip': False,
                       'rotation': {'angle': 0.0, 'width': None, 'height': None},
@@ -300,7 +344,8 @@ class Predictor:
             meta_batch = [None] * len(pred_batch)
         out = []
         for pred, meta in zip(pred_batch, meta_batch):
-            pred = [ann.inverse_transform(meta) for ann in pred]
+            if meta is not None:                      # (None: pad / rescale / flip were undone on the device already)
+                pred = [ann.inverse_transform(meta) for ann in pred]
             if self.json_data:
                 pred = [ann.json_data() for ann in pred]
             out.append(pred)
