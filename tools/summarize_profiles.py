@@ -121,7 +121,7 @@ def pmc_per_decode(sub, counter, last_calls=4):
 
 
 ONLY_STEPS = '--only-steps' in sys.argv
-print('# rocprofv3 summary (round 3)%s\n' % (': one steady-state step of bench.py' if ONLY_STEPS else ''))
+print('# rocprofv3 summary (round %s)%s\n' % (os.environ.get('ROUND', 'r4').lstrip('r'), ': one steady-state step of bench.py' if ONLY_STEPS else ''))
 print('Commands: tools/collect_profiles.sh (every pass: `rocprofv3 ... -- python tools/gpu/r3_probe.py --config ... --alternate`,'
       ' i.e. two different field batches decoded in turn; counters in their own passes with --kernel-trace only).\n')
 steady_state_step('bench', 'bench.py headline leg (float32 network + decode): ONE steady-state step, batch 32')
