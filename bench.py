@@ -921,6 +921,63 @@ def main():
             if isinstance(others[name], dict):
                 others[name]['leg_seconds'] = round(time.perf_counter() - t0, 1)
 
+        # (first among the extra legs: the lane sweeps further down create dozens of HIP streams, and the runtime maps streams
+        # onto 4 hardware queues -- a Predictor whose lanes share a queue with the network's stream overlaps less: 84 instead of
+        # 77 ms per batch in the same process, profiles/r4/README.md)
+        # the product path: Predictor -> Decoder.batch_async over decode lanes (what a user of openpifpaf.predict gets), fed
+        # uint8 frames that are preprocessed on the device; the network runs for real, the decode sees the headline's
+        # synthetic fields (a random-init head's own output is the all-active case above)
+        def predictor_leg():
+            from openpifpaf_amd import Predictor, predictor as predictor_mod
+            net = build_model(wl, 'fp32')
+
+            class Injected(torch.nn.Module):
+                def __init__(self):
+                    super().__init__()
+                    self.net, self.head_metas, self.n = net, [wl.cif_meta, wl.caf_meta], 0
+
+                def forward(self, x):
+                    self.net(x)
+                    v = wl.variants[self.n % len(wl.variants)]
+                    self.n += 1
+                    return (v[2], v[3])
+            saved = (Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device)
+            Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device = wl.B, args.long_edge, True, device
+            try:
+                pred = Predictor(model=Injected())
+                rng = np.random.default_rng(3)
+                frames = [rng.integers(0, 255, (args.long_edge, args.long_edge, 3), dtype=np.uint8) for _ in range(wl.B)]
+                n_batches = 24                             # (a short run is dominated by filling and draining the pipeline)
+                out = {}
+                for mode, pipelined in (('pipelined', True), ('synchronous', False)):
+                    pred.pipelined = pipelined
+                    list(pred.numpy_images(frames * 2))                     # warm-up (lanes, pinned buffers)
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    n_ann = sum(len(p) for p, _, _ in pred.numpy_images(frames * n_batches))
+                    dt = time.perf_counter() - t0
+                    out[mode] = {'images_per_s': round(wl.B * n_batches / dt, 1), 'ms_per_batch': round(dt / n_batches * 1e3, 2),
+                                 'annotations': n_ann}
+                # where a batch's time goes when nothing overlaps
+                t0 = time.perf_counter()
+                batch, metas = pred._preprocess(frames)
+                torch.cuda.synchronize(device)
+                out['preprocess_ms_per_batch'] = round((time.perf_counter() - t0) * 1e3, 2)
+                t0 = time.perf_counter()
+                res = pred.tensor_batch(batch, metas)
+                out['tensor_batch_ms'] = round((time.perf_counter() - t0) * 1e3, 2)
+                out['value'] = out['pipelined']['images_per_s']
+                out['ms_per_step'] = out['pipelined']['ms_per_batch']
+                out['lanes'] = pred.processor.pipeline_depth
+                out['what'] = ('Predictor.numpy_images over %d batches of %d uint8 %dx%d frames: device-side preprocessing, float32 %s, '
+                               'HIP decode of the synthetic fields on decode lanes, inverse transform on the device, annotations '
+                               'through pinned memory, Annotation objects built on the host' % (
+                                   n_batches, wl.B, args.long_edge, args.long_edge, wl.backbone))
+                return out
+            finally:
+                Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device = saved
+        guarded('predictor', predictor_leg)
+
         # the reference benchmark CLI's decoder setting on the headline's fields (decode only: the network is the same)
         def fc_leg():
             fc_params = _lib.default_params(**FC_KW)
@@ -1006,59 +1063,6 @@ def main():
                     'parity': par}
         guarded('all_active', all_active_leg)
 
-        # the product path: Predictor -> Decoder.batch_async over decode lanes (what a user of openpifpaf.predict gets), fed
-        # uint8 frames that are preprocessed on the device; the network runs for real, the decode sees the headline's
-        # synthetic fields (a random-init head's own output is the all-active case above)
-        def predictor_leg():
-            from openpifpaf_amd import Predictor, predictor as predictor_mod
-            net = build_model(wl, 'fp32')
-
-            class Injected(torch.nn.Module):
-                def __init__(self):
-                    super().__init__()
-                    self.net, self.head_metas, self.n = net, [wl.cif_meta, wl.caf_meta], 0
-
-                def forward(self, x):
-                    self.net(x)
-                    v = wl.variants[self.n % len(wl.variants)]
-                    self.n += 1
-                    return (v[2], v[3])
-            saved = (Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device)
-            Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device = wl.B, args.long_edge, True, device
-            try:
-                pred = Predictor(model=Injected())
-                rng = np.random.default_rng(3)
-                frames = [rng.integers(0, 255, (args.long_edge, args.long_edge, 3), dtype=np.uint8) for _ in range(wl.B)]
-                n_batches = 24                             # (a short run is dominated by filling and draining the pipeline)
-                out = {}
-                for mode, pipelined in (('pipelined', True), ('synchronous', False)):
-                    pred.pipelined = pipelined
-                    list(pred.numpy_images(frames * 2))                     # warm-up (lanes, pinned buffers)
-                    torch.cuda.synchronize(device)
-                    t0 = time.perf_counter()
-                    n_ann = sum(len(p) for p, _, _ in pred.numpy_images(frames * n_batches))
-                    dt = time.perf_counter() - t0
-                    out[mode] = {'images_per_s': round(wl.B * n_batches / dt, 1), 'ms_per_batch': round(dt / n_batches * 1e3, 2),
-                                 'annotations': n_ann}
-                # where a batch's time goes when nothing overlaps
-                t0 = time.perf_counter()
-                batch, metas = pred._preprocess(frames)
-                torch.cuda.synchronize(device)
-                out['preprocess_ms_per_batch'] = round((time.perf_counter() - t0) * 1e3, 2)
-                t0 = time.perf_counter()
-                res = pred.tensor_batch(batch, metas)
-                out['tensor_batch_ms'] = round((time.perf_counter() - t0) * 1e3, 2)
-                out['value'] = out['pipelined']['images_per_s']
-                out['ms_per_step'] = out['pipelined']['ms_per_batch']
-                out['lanes'] = pred.processor.pipeline_depth
-                out['what'] = ('Predictor.numpy_images over %d batches of %d uint8 %dx%d frames: device-side preprocessing, float32 %s, '
-                               'HIP decode of the synthetic fields on decode lanes, inverse transform on the device, annotations '
-                               'through pinned memory, Annotation objects built on the host' % (
-                                   n_batches, wl.B, args.long_edge, args.long_edge, wl.backbone))
-                return out
-            finally:
-                Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device = saved
-        guarded('predictor', predictor_leg)
 
         # the literal configs[1]: batch 1
         def batch1_leg():
