@@ -112,6 +112,8 @@ def parse_args():
     p.add_argument('--dist-backend', default='nccl', choices=('nccl', 'gloo'),
                    help='nccl = RCCL over xGMI (default); gloo only to exercise the N>1 control flow on one GPU')
     p.add_argument('--share-device', action='store_true', help='testing: every rank uses cuda:0')
+    p.add_argument('--watchdog-seconds', type=float, default=600.0,
+                   help='print what exists and exit when the run has not finished by then (a default run takes < 3 min)')
     p.add_argument('--dump-annotations', default=None,
                    help='testing: rank 0 writes the gathered annotations of the last step to this .npz')
     return p.parse_args()
@@ -253,6 +255,8 @@ def compact_line(detail):
     digest = {k: compact_leg(v) for k, v in (detail.get('configs') or {}).items()}
     if digest:
         line['configs'] = digest
+    if detail.get('watchdog'):
+        line['watchdog'] = str(detail['watchdog'])[:80]
     line['detail'] = DETAIL_FILE
     line['bench_seconds'] = detail.get('bench_seconds')
     text = json.dumps(line, separators=(',', ':'))
@@ -277,6 +281,37 @@ def write_detail(detail):
         except OSError as e:                                  # read-only checkout: the line itself still prints
             print('bench: could not write %s: %r' % (path, e), file=sys.stderr)
     return written
+
+
+_PARTIAL = {'line': None, 't0': time.perf_counter()}
+
+
+def start_watchdog(soft_seconds):
+    """A default run takes under three minutes.  Should a leg hang (a GPU wait that never returns, a forked worker stuck
+    in a lock), the line must still get out: after `soft_seconds` the tracebacks of all threads go to stderr and, if the
+    headline result exists, it is printed as the final line (marked) and the process exits; without it the exit is 4."""
+    import faulthandler
+    import threading
+
+    def watch():
+        time.sleep(soft_seconds)
+        print('bench: watchdog after %.0f s -- a leg did not return; tracebacks follow' % soft_seconds, file=sys.stderr)
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        sys.stderr.flush()
+        line = _PARTIAL['line']
+        if line is not None:
+            line = dict(line)
+            line['watchdog'] = 'an extra leg did not return within %d s; headline only' % soft_seconds
+            line['bench_seconds'] = round(time.perf_counter() - _PARTIAL['t0'], 1)
+            try:
+                write_detail(line)
+                print(compact_line(line), flush=True)
+            finally:
+                os._exit(0)
+        os._exit(4)
+    t = threading.Thread(target=watch, daemon=True)
+    t.start()
+    return t
 
 
 def spawn_ranks(n):
@@ -372,10 +407,20 @@ def cpu_baseline(cifs, cafs, skeleton0, n_keypoints, seconds, fc_kw=None):
         procs = [ctx.Process(target=work, args=(i, q, t_end)) for i in range(cores)]
         for pr in procs:
             pr.start()
-        results = [q.get() for _ in procs]
+        import queue as queue_mod
+        results = []
+        for _ in procs:                                # (a child forked from a threaded process can deadlock in an allocator lock:
+            try:                                       # it must not take the whole run with it)
+                results.append(q.get(timeout=max(1.0, t_end + 30.0 - time.perf_counter())))
+            except queue_mod.Empty:
+                break
         for pr in procs:
-            pr.join()
-        multi = sum(k for k, _ in results) / (max(t for _, t in results) - t0)
+            pr.join(timeout=0.5)
+            if pr.is_alive():
+                pr.terminate()
+        if len(results) < len(procs):
+            print('cpu_baseline: %d of %d workers did not report' % (len(procs) - len(results), len(procs)), file=sys.stderr)
+        multi = sum(k for k, _ in results) / (max(t for _, t in results) - t0) if results else None
     except Exception as e:   # pragma: no cover
         multi = None
         print('cpu_baseline: multi-process leg failed: %r' % (e,), file=sys.stderr)
@@ -594,6 +639,8 @@ def main():
     from openpifpaf_amd import _lib, distributed, native
 
     t_program = time.perf_counter()
+    if rank == 0:
+        start_watchdog(args.watchdog_seconds)
     config_id = args.config or 2
     extras = (args.config is None and world == 1 and not args.no_extras and not args.decode_only
               and args.fields == 'synthetic' and not args.force_complete and args.backbone is None and args.batch is None)
@@ -904,6 +951,8 @@ def main():
                        'float32 one: see bf16_backbone (reduced precision, reported beside the headline, not as it).'
                        % (primary, nn_ms, ref_ms - nn_ms, ref_ms, nn_ms, ref_ms / nn_ms)}
 
+    if rank == 0:
+        _PARTIAL['line'] = line
     # ------------------------------------------------------------------------------------- the other configurations
     if extras:
         others = {}
@@ -921,62 +970,6 @@ def main():
             if isinstance(others[name], dict):
                 others[name]['leg_seconds'] = round(time.perf_counter() - t0, 1)
 
-        # (first among the extra legs: the lane sweeps further down create dozens of HIP streams, and the runtime maps streams
-        # onto 4 hardware queues -- a Predictor whose lanes share a queue with the network's stream overlaps less: 84 instead of
-        # 77 ms per batch in the same process, profiles/r4/README.md)
-        # the product path: Predictor -> Decoder.batch_async over decode lanes (what a user of openpifpaf.predict gets), fed
-        # uint8 frames that are preprocessed on the device; the network runs for real, the decode sees the headline's
-        # synthetic fields (a random-init head's own output is the all-active case above)
-        def predictor_leg():
-            from openpifpaf_amd import Predictor, predictor as predictor_mod
-            net = build_model(wl, 'fp32')
-
-            class Injected(torch.nn.Module):
-                def __init__(self):
-                    super().__init__()
-                    self.net, self.head_metas, self.n = net, [wl.cif_meta, wl.caf_meta], 0
-
-                def forward(self, x):
-                    self.net(x)
-                    v = wl.variants[self.n % len(wl.variants)]
-                    self.n += 1
-                    return (v[2], v[3])
-            saved = (Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device)
-            Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device = wl.B, args.long_edge, True, device
-            try:
-                pred = Predictor(model=Injected())
-                rng = np.random.default_rng(3)
-                frames = [rng.integers(0, 255, (args.long_edge, args.long_edge, 3), dtype=np.uint8) for _ in range(wl.B)]
-                n_batches = 24                             # (a short run is dominated by filling and draining the pipeline)
-                out = {}
-                for mode, pipelined in (('pipelined', True), ('synchronous', False)):
-                    pred.pipelined = pipelined
-                    list(pred.numpy_images(frames * 2))                     # warm-up (lanes, pinned buffers)
-                    torch.cuda.synchronize(device)
-                    t0 = time.perf_counter()
-                    n_ann = sum(len(p) for p, _, _ in pred.numpy_images(frames * n_batches))
-                    dt = time.perf_counter() - t0
-                    out[mode] = {'images_per_s': round(wl.B * n_batches / dt, 1), 'ms_per_batch': round(dt / n_batches * 1e3, 2),
-                                 'annotations': n_ann}
-                # where a batch's time goes when nothing overlaps
-                t0 = time.perf_counter()
-                batch, metas = pred._preprocess(frames)
-                torch.cuda.synchronize(device)
-                out['preprocess_ms_per_batch'] = round((time.perf_counter() - t0) * 1e3, 2)
-                t0 = time.perf_counter()
-                res = pred.tensor_batch(batch, metas)
-                out['tensor_batch_ms'] = round((time.perf_counter() - t0) * 1e3, 2)
-                out['value'] = out['pipelined']['images_per_s']
-                out['ms_per_step'] = out['pipelined']['ms_per_batch']
-                out['lanes'] = pred.processor.pipeline_depth
-                out['what'] = ('Predictor.numpy_images over %d batches of %d uint8 %dx%d frames: device-side preprocessing, float32 %s, '
-                               'HIP decode of the synthetic fields on decode lanes, inverse transform on the device, annotations '
-                               'through pinned memory, Annotation objects built on the host' % (
-                                   n_batches, wl.B, args.long_edge, args.long_edge, wl.backbone))
-                return out
-            finally:
-                Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device = saved
-        guarded('predictor', predictor_leg)
 
         # the reference benchmark CLI's decoder setting on the headline's fields (decode only: the network is the same)
         def fc_leg():
@@ -1063,6 +1056,62 @@ def main():
                     'parity': par}
         guarded('all_active', all_active_leg)
 
+
+        # (inside this process, behind legs that have created dozens of HIP streams -- the runtime maps streams onto 4 hardware
+        # queues -- the loop takes 78-85 ms per batch; in a process of its own 77.5: tools/gpu/predictor_probe.py, profiles/r4)
+        # the product path: Predictor -> Decoder.batch_async over decode lanes (what a user of openpifpaf.predict gets), fed
+        # uint8 frames that are preprocessed on the device; the network runs for real, the decode sees the headline's
+        # synthetic fields (a random-init head's own output is the all-active case above)
+        def predictor_leg():
+            from openpifpaf_amd import Predictor, predictor as predictor_mod
+            net = build_model(wl, 'fp32')
+
+            class Injected(torch.nn.Module):
+                def __init__(self):
+                    super().__init__()
+                    self.net, self.head_metas, self.n = net, [wl.cif_meta, wl.caf_meta], 0
+
+                def forward(self, x):
+                    self.net(x)
+                    v = wl.variants[self.n % len(wl.variants)]
+                    self.n += 1
+                    return (v[2], v[3])
+            saved = (Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device)
+            Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device = wl.B, args.long_edge, True, device
+            try:
+                pred = Predictor(model=Injected())
+                rng = np.random.default_rng(3)
+                frames = [rng.integers(0, 255, (args.long_edge, args.long_edge, 3), dtype=np.uint8) for _ in range(wl.B)]
+                n_batches = 24                             # (a short run is dominated by filling and draining the pipeline)
+                out = {}
+                for mode, pipelined in (('pipelined', True), ('synchronous', False)):
+                    pred.pipelined = pipelined
+                    list(pred.numpy_images(frames * 2))                     # warm-up (lanes, pinned buffers)
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    n_ann = sum(len(p) for p, _, _ in pred.numpy_images(frames * n_batches))
+                    dt = time.perf_counter() - t0
+                    out[mode] = {'images_per_s': round(wl.B * n_batches / dt, 1), 'ms_per_batch': round(dt / n_batches * 1e3, 2),
+                                 'annotations': n_ann}
+                # where a batch's time goes when nothing overlaps
+                t0 = time.perf_counter()
+                batch, metas = pred._preprocess(frames)
+                torch.cuda.synchronize(device)
+                out['preprocess_ms_per_batch'] = round((time.perf_counter() - t0) * 1e3, 2)
+                t0 = time.perf_counter()
+                res = pred.tensor_batch(batch, metas)
+                out['tensor_batch_ms'] = round((time.perf_counter() - t0) * 1e3, 2)
+                out['value'] = out['pipelined']['images_per_s']
+                out['ms_per_step'] = out['pipelined']['ms_per_batch']
+                out['lanes'] = pred.processor.pipeline_depth
+                out['what'] = ('Predictor.numpy_images over %d batches of %d uint8 %dx%d frames: device-side preprocessing, float32 %s, '
+                               'HIP decode of the synthetic fields on decode lanes, inverse transform on the device, annotations '
+                               'through pinned memory, Annotation objects built on the host' % (
+                                   n_batches, wl.B, args.long_edge, args.long_edge, wl.backbone))
+                return out
+            finally:
+                Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device = saved
+        guarded('predictor', predictor_leg)
 
         # the literal configs[1]: batch 1
         def batch1_leg():

@@ -72,3 +72,30 @@ def test_gpus_without_launcher_respawns(monkeypatch):
     assert argv[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in argv
     assert argv[argv.index('--nproc-per-node') + 1] == '4' and argv[argv.index('--master-addr') + 1] == '127.0.0.1'
     assert argv[-4:] == ['--gpus', '4', '--steps', '3']
+
+
+def test_watchdog_prints_the_headline_when_a_leg_hangs(tmp_path):
+    """A leg that never returns (round 4 lost 25 GPU-minutes to one) must not take the headline with it: after the
+    soft limit the watchdog prints the compact line from what exists and exits 0; with nothing to print it exits 4."""
+    import subprocess
+    code = '''
+import json, sys, time
+sys.path.insert(0, %r)
+import bench
+bench.write_detail = lambda d: []            # (do not touch the checkout from a test)
+if sys.argv[1] == "with":
+    d = json.load(open(%r))
+    d.pop("configs", None)
+    bench._PARTIAL["line"] = d
+bench.start_watchdog(0.3)
+time.sleep(30)
+''' % (ROOT, os.path.join(ROOT, 'profiles', 'r3', 'bench_r3.json'))
+    script = tmp_path / 'hang.py'
+    script.write_text(code)
+    ok = subprocess.run([sys.executable, str(script), 'with'], capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    line = json.loads(ok.stdout.strip().splitlines()[-1])
+    assert line['value'] == canned()['value'] and 'watchdog' in line and line['roofline'] and line['cpu_baseline']
+    assert 'watchdog after' in ok.stderr and 'hang.py' in ok.stderr               # the traceback says where it hung
+    bad = subprocess.run([sys.executable, str(script), 'without'], capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 4 and not bad.stdout.strip()
