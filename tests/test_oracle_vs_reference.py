@@ -258,3 +258,32 @@ def test_composite_field_head_equals_the_reference_package():
             a, b = mine(x), ref(x)
         assert a.shape == b.shape == (2, mine_meta.n_fields, 5 if mine_meta is mine_metas[0] else 8, 13, 17)
         assert torch.allclose(a, b, atol=1e-6), float((a - b).abs().max())
+
+
+@pytest.mark.parametrize('case', [(9001, 40, 161, 161, (0.2, 0.6)), (9002, 25, 121, 161, (0.3, 0.8)),
+                                  (9005, 90, 161, 161, (0.2, 0.5))])
+def test_large_fields_bit_equal(ref, coco_skeleton0, case):
+    """The 1281-px cases of tests/test_gpu_large_fields.py (161 x 161 and 121 x 161 fields, up to 90 people, more than
+    8192 seeds): the restatement the GPU tests compare with is bit-identical to the real reference there too -- default
+    flags, the reference benchmark's force-complete setting, and bf16-rounded fields (tied scores: std::sort's order)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from common import to_bf16
+    from openpifpaf_amd import synth
+    from oracle import port
+    seed, people, H, W, sr = case
+    cif, caf = synth.synth_fields(seed, people, height=H, width=W, size_range=sr)
+    fc = dict(force_complete=1, keypoint_threshold=0.0, keypoint_threshold_rel=0.0, nms_instance_threshold=0.0,
+              nms_keypoint_threshold=0.0)
+    for fields, kw in (((cif, caf), None), ((cif, caf), fc), ((to_bf16(cif), to_bf16(caf)), None)):
+        params = port.default_params(**kw) if kw else None
+        if kw:
+            ref.apply_params(params)
+        try:
+            r_out, r_ids, r_hr = ref.decode(fields[0], 8, fields[1], 8, coco_skeleton0)
+        finally:
+            if kw:
+                ref.reset_statics()
+        o_out, o_ids, o_hr = port.decode(fields[0], 8, fields[1], 8, coco_skeleton0, params=params, return_cifhr=True)
+        assert np.array_equal(r_hr, o_hr)
+        assert r_out.shape == o_out.shape and len(o_out) >= 20 and np.array_equal(r_out, o_out)
