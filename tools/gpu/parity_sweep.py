@@ -30,7 +30,7 @@ OPTIONS = [dict(), dict(), dict(greedy=1), dict(reverse_match=0), dict(keypoint_
                 nms_keypoint_threshold=0.0),
            dict(cif_threshold=0.2, seed_threshold=0.25, caf_threshold=0.2), dict(ablation_cifseeds_no_rescore=1),
            dict(ablation_caf_no_rescore=1), dict(occupancy_reduction=1.0), dict(nms_suppression=0.5)]
-n_images = n_poses = 0
+n_images = n_poses = n_overflows = 0
 worst = 0.0
 t0 = time.time()
 for batch_i in range(n_batches):
@@ -62,6 +62,18 @@ for batch_i in range(n_batches):
         torch.from_numpy(np.stack(inits)).cuda() if n_init else None,
         torch.from_numpy(init_ids).cuda() if n_init else None, params=_lib.default_params(**kw))
     out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
+    if (cnt & native.COUNT_FAILED).any() and dec.pool_overflowed():
+        # an image's CIF map reached more tiles than the automatic pool holds (big people on a small field): flagged, status
+        # -2 -- what the synchronous entry points do on their own: once more with a pool that holds the whole map
+        n_overflows += 1
+        dec.use_full_pool()
+        out, ids, cnt = dec.call_batch(
+            torch.from_numpy(np.stack(cifs)).cuda(), stride, torch.from_numpy(np.stack(cafs)).cuda(), stride,
+            torch.from_numpy(np.stack(inits)).cuda() if n_init else None,
+            torch.from_numpy(init_ids).cuda() if n_init else None, params=_lib.default_params(**kw))
+        out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
+        dec.cifhr_pool_tiles = 0                      # (back to the automatic pool for the next shapes)
+    native.check_counts(cnt)
     for b in range(B):
         want, _ = port.decode(cifs[b], stride, cafs[b], stride, skel0, params=port.default_params(**kw),
                               n_keypoints=K, initial_annotations=inits[b] if n_init else None,
@@ -80,5 +92,5 @@ for batch_i in range(n_batches):
         worst = max(worst, err)
         n_images += 1
         n_poses += n
-print('parity sweep (' + mode + ') ok: %d launches, %d images, %d poses, worst |delta| %.3g, %.1f s' % (
-    n_batches, n_images, n_poses, worst, time.time() - t0))
+print('parity sweep (' + mode + ') ok: %d launches, %d images, %d poses, worst |delta| %.3g, %.1f s; %d launches repeated with a full '
+      'tile pool after a flagged overflow' % (n_batches, n_images, n_poses, worst, time.time() - t0, n_overflows))
