@@ -306,8 +306,9 @@ def start_watchdog(soft_seconds):
             try:
                 write_detail(line)
                 print(compact_line(line), flush=True)
-            finally:
                 os._exit(0)
+            except BaseException as e:                 # (nothing printed: say so with the exit code)
+                print('bench: watchdog could not print the line: %r' % (e,), file=sys.stderr)
         os._exit(4)
     t = threading.Thread(target=watch, daemon=True)
     t.start()
