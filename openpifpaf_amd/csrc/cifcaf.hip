@@ -149,6 +149,13 @@ struct ImageCtx {
     int* sh_counts;                      // [2A] list lengths of the active list set
     int n_blend;                         // list scans of this wave (statistics)
     int t_blend, t_blend_mem;            // ticks inside the scans, and of those until the loads had returned
+    // speculative batched evaluation (spec_phase): per joint `kind | flags | slot << 8`, per bone `state | slot << 8` and the
+    // connection value the bone's scans gave (private LDS, null: off)
+    int *sp_j, *sp_b;
+    double* sp_v; float *sp_x, *sp_y, *sp_s;
+    unsigned char *sp_match, *sp_fromc;  // LDS variant of the growth state: joint assigned with its candidate's values [K]; entry of the bone came from the cache [A]
+    int sp_pcap;                         // passing entries the scan area holds during a batch
+    int n_hit, n_miss;                   // statistics: connection values taken from the cache / evaluated on demand
 };
 
 __device__ __forceinline__ ListView list_view(const ImageCtx& c, int bone, int dir) {
@@ -758,6 +765,152 @@ __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, dou
 #endif
 }
 
+// ------------------------------------------------------------ batched list scans (lane = job)
+// grow_connection_blend (cifcaf.cpp:32-103) for up to 64 (list, query) pairs at once.  _connection_value (:349-411) of a
+// bone depends on nothing but its start joint, so the bones a new joint adds -- and the bones of every joint that became a
+// candidate in the same level of the search -- are scanned TOGETHER: one query setup for all of them (lane = job), the
+// chunk boxes of every job tested side by side, the loads of eight (job, chunk) items in flight at once, the passing
+// entries of all jobs compacted job by job into the wave's scan area, ONE pass of the double-precision exp over them
+// (lane = entry), the top two of every job by the reference's own sequential rule (:65-73, lane = job, each lane walks
+// its job's entries in list order), and one round trip for the target columns of the winners.  A batch costs about what
+// one scan costs (two memory round trips); the results are those of the single scans bit for bit (same score_of, same
+// blend_finish, and the top-2 rule is the reference's loop itself).
+// memo words of the level walk (spec_phase, below)
+constexpr int kSpActual = 1, kSpCand = 2, kSpKind = 3, kSpOpen = 4, kSpNext = 8;     // per joint: kind, "its bones are this level's jobs", "became a candidate in this level"
+constexpr int kSbOk = 1, kSbRejected = 2, kSbUnknown = 3;                            // per bone: connection holds / _connection_value returns the zero joint / not evaluated here
+constexpr int kSpecItems = 128;          // (job, chunk) items of one batch
+constexpr int kSpecGroup = 8;            // items whose loads are in flight together
+struct SpecOut { int ok; double v; float x, y, s; };   // ok: 1 a joint, 0 the all-zero joint (:76), -1 not evaluated (left to the single scans)
+
+__device__ __forceinline__ int rlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float rlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int bperm_i(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
+__device__ __forceinline__ float bperm_f(float v, int src) { return __int_as_float(bperm_i(__float_as_int(v), src)); }
+__device__ __forceinline__ double bperm_d(double v, int src) {
+    return __hiloint2double(bperm_i(__double2hiint(v), src), bperm_i(__double2loint(v), src));
+}
+__device__ __forceinline__ int spec_pcap(int tgt_floats) {   // the scan area: items, a segment per job, then 16 bytes per passing entry
+    return (tgt_floats - kSpecItems - 2 * kWave) / 4;
+}
+
+__device__ __forceinline__ SpecOut spec_scan_batch(ImageCtx& c, bool active, int li, double x, double y, double s, double filter_sigmas) {
+    const int lane = lane_id();
+    int* item = reinterpret_cast<int*>(c.tgt);               // job | chunk << 8 | first item of its job << 16
+    int* seg = item + kSpecItems;                            // [2][64] where a job's passing entries start / end
+    const int pcap = c.sp_pcap;
+    float* cx = reinterpret_cast<float*>(seg + 2 * kWave); float* cy = cx + pcap; float* cv = cy + pcap;
+    int* ci = reinterpret_cast<int*>(cv + pcap);             // list position | job << 16
+    const BlendQuery q = make_query(x, y, s, filter_sigmas);
+    const int n = active ? c.sh_counts[li] : 0;
+    const int nch = (n + kWave - 1) >> 6;
+    int status = !active ? -1 : n <= 0 ? 0 : nch <= kListBboxChunks ? 1 : -1;   // 1: scanned here
+    unsigned mask = 0u;                                      // the chunks of the list whose box meets the window (cifcaf.cpp:54-57)
+    if (c.bbox) {
+        for (int ch = 0; __ballot(status == 1 && ch < nch) != 0ull; ch++)
+            if (status == 1 && ch < nch) {
+                const float4 bb = c.bbox[li * kListBboxChunks + ch];
+                if (bb.x <= q.fxhi && bb.y >= q.fxlo && bb.z <= q.fyhi && bb.w >= q.fylo) mask |= 1u << ch;
+            }
+    } else if (status == 1) {
+        mask = (1u << nch) - 1u;
+    }
+    // where the job's items go: exclusive prefix of the chunk counts (<= 16 each: five ballots)
+    const int cnt = __popc(mask);
+    int base = 0, total = 0;
+#pragma unroll
+    for (int bit = 0; bit < 5; bit++) {
+        const unsigned long long m = __ballot((cnt >> bit) & 1);
+        base += prefix_count(m) << bit; total += __popcll(m) << bit;
+    }
+    int W = total;
+    if (total > kSpecItems) {                                // (the jobs that fit are a prefix of the jobs: the offsets only grow)
+        const bool fits = base + cnt <= kSpecItems;
+        const unsigned long long fm = __ballot(fits && cnt > 0);
+        W = fm ? rlane_i(base + cnt, 63 - __builtin_clzll(fm)) : 0;
+        if (!fits && cnt > 0) { status = -1; mask = 0u; }
+    }
+    {
+        unsigned m = mask; int k = 0;
+        while (__ballot(m != 0u) != 0ull)
+            if (m) { const int ch = __builtin_ctz(m); m &= m - 1u; item[base + k] = lane | (ch << 8) | (k == 0 ? 1 << 16 : 0); k++; }
+    }
+    seg[lane] = 0; seg[kWave + lane] = 0;
+    wave_sync();
+    // ---- the items, kSpecGroup at a time: loads of a group back to back, then window test + ordered compaction
+    const gfloat* g = (const gfloat*)c.lists;
+    const int cap = c.list_cap;
+    const int loff = li * 7 * cap;
+    int np = 0;                                              // passing entries so far (uniform)
+    for (int w0 = 0; w0 < W; w0 += kSpecGroup) {
+        int d[kSpecGroup];
+#pragma unroll
+        for (int r = 0; r < kSpecGroup; r++) d[r] = item[w0 + r < W ? w0 + r : W - 1];
+#pragma unroll
+        for (int r = 0; r < kSpecGroup; r++) asm volatile("" : "+v"(d[r]) :: "memory");
+        float x1[kSpecGroup], y1[kSpecGroup], cc[kSpecGroup];
+#pragma unroll
+        for (int r = 0; r < kSpecGroup; r++) {
+            const int dd = __builtin_amdgcn_readfirstlane(d[r]);
+            const int j = dd & 0xff, ch = (dd >> 8) & 0xff;
+            const int nj = rlane_i(n, j), lo = rlane_i(loff, j);
+            const int i = ch * kWave + lane, ii = i < nj ? i : 0;
+            x1[r] = g[lo + 1 * cap + ii]; y1[r] = g[lo + 2 * cap + ii]; cc[r] = g[lo + ii];
+        }
+#pragma unroll
+        for (int r = 0; r < kSpecGroup; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
+#pragma unroll
+        for (int r = 0; r < kSpecGroup; r++) {
+            if (w0 + r >= W) break;
+            const int dd = __builtin_amdgcn_readfirstlane(d[r]);
+            const int j = dd & 0xff, ch = (dd >> 8) & 0xff;
+            const int i = ch * kWave + lane;
+            const bool pass = i < rlane_i(n, j) && x1[r] >= rlane_f(q.fxlo, j) && x1[r] <= rlane_f(q.fxhi, j) &&
+                              y1[r] >= rlane_f(q.fylo, j) && y1[r] <= rlane_f(q.fyhi, j);
+            const unsigned long long m = __ballot(pass);
+            const int pc = __popcll(m);
+            if (lane == 0) { if (dd >> 16) seg[j] = np; seg[kWave + j] = np + pc; }
+            const int slot = np + prefix_count(m);
+            if (pass && slot < pcap) { cx[slot] = x1[r]; cy[slot] = y1[r]; cv[slot] = cc[r]; ci[slot] = i | (j << 16); }
+            np += pc;
+        }
+    }
+    wave_sync();
+    // ---- scores of the passing entries (:60-63), lane = entry; the entry's query comes from its job's lane
+    const int tot = np < pcap ? np : pcap;
+    for (int e0 = 0; e0 < tot; e0 += kWave) {
+        const int e = e0 + lane;
+        const bool have = e < tot;
+        const int idx = have ? ci[e] : 0;
+        const int j = (idx >> 16) & (kWave - 1);
+        BlendQuery qq;
+        qq.x = bperm_d(q.x, j); qq.y = bperm_d(q.y, j); qq.sigma2 = bperm_f(q.sigma2, j);
+        if (have) cv[e] = score_of(qq, cx[e], cy[e], cv[e]);
+    }
+    wave_sync();
+    // ---- the top two of every job: the reference's loop (:65-73) over the job's entries in list order, lane = job
+    const int lo = seg[lane], hi = seg[kWave + lane];
+    if (status == 1 && hi > pcap) status = -1;               // more passing entries than the area holds: the single scans
+    float s1 = 0.0f, s2 = 0.0f; int i1 = 0, i2 = 0;
+    for (int e = lo; __ballot(status == 1 && e < hi) != 0ull; e++)
+        if (status == 1 && e < hi) {
+            const float sc = cv[e]; const int i = ci[e] & 0xffff;
+            if (sc >= s1) { s2 = s1; i2 = i1; s1 = sc; i1 = i; }
+            else if (sc > s2) { s2 = sc; i2 = i; }
+        }
+    wave_sync();                                             // the area is free for the next batch
+    SpecOut o; o.ok = status; o.v = 0.0; o.x = o.y = o.s = 0.f;
+    if (status == 1) {
+        if (s1 == 0.0f) o.ok = 0;                            // :76
+        else {
+            const float e1x = g[loff + 3 * cap + i1], e1y = g[loff + 4 * cap + i1], e1s = g[loff + 6 * cap + i1];
+            const float e2x = g[loff + 3 * cap + i2], e2y = g[loff + 4 * cap + i2], e2s = g[loff + 6 * cap + i2];
+            const BlendResult r = blend_finish(s1, s2, true, false, e1x, e1y, e1s, e2x, e2y, e2s);
+            o.v = r.v; o.x = r.x; o.y = r.y; o.s = r.s;
+        }
+    }
+    return o;
+}
+
 // A joint was assigned (cifcaf.cpp:310): during the seed pipeline the grower publishes the occupancy box the
 // joint WILL occupy if the pose is accepted, so that the coordinator can stop handing out -- and growing --
 // seeds this pose is going to cover (defined behind the occupancy helpers).
@@ -766,6 +919,7 @@ constexpr int kTaskIdle = 0, kTaskAssigned = 1, kTaskDone = 2, kTaskAccepted = 3
 struct __attribute__((aligned(16))) TaskSlot { int state, seed, cancel, epoch, npub, pk, f, pad0; double score; int t_emit, t_done, pad1, coll; };
 template <int WR> __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s);
 template <int WR> __device__ __forceinline__ void pool_catch_up(ImageCtx& c, int e);
+template <int WR> __device__ __forceinline__ void spec_phase(ImageCtx& c, const DevParams& p, bool reverse_match_, double filter_sigmas);
 // cancel flag and refill epoch of this grower's task slot, one LDS read
 template <int WR>
 __device__ __forceinline__ bool poll_task(ImageCtx& c) {
@@ -910,19 +1064,41 @@ __device__ __forceinline__ void frontier_start(ImageCtx& c) {
 // cifcaf.cpp:265-313 -- one wavefront, no workgroup barriers
 template <bool LONG>
 __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool reverse_match_, double filter_sigmas) {
+    if (c.sp_j) {                                                        // the bones of the pose, level by level, in batches (spec_phase)
+        spec_phase<kPoolSlotsLds>(c, p, reverse_match_, filter_sigmas);
+        if (c.aborted) return;
+        for (int k = lane_id(); k < c.K; k += kWave) c.sp_match[k] = (c.sp_j[k] & kSpKind) == kSpActual ? 1 : 0;
+        for (int a = lane_id(); a < c.A; a += kWave) c.sp_fromc[a] = 0;
+        wave_sync();
+    }
     frontier_start(c);
     while (c.heap_n > 0) {
         if (poll_task<kPoolSlotsLds>(c)) { c.aborted = 1; return; }                     // the seed died while its pose grew
         const int slot = heap_pop(c);
         const int info = c.slot_info[slot];
-        const int end = (info >> 8) & 0xff, bn = (info >> 16) & 0xff;
+        const int start = info & 0xff, end = (info >> 8) & 0xff, bn = (info >> 16) & 0xff;
         if (c.jv[end] > 0.0) { PH(0); continue; }                        // :284
         double v = c.e_v[bn]; float x = c.e_x[bn], y = c.e_y[bn], s = c.e_s[bn];
         PH(0);
         if (v == 0.0) {                                                  // :287: not computed yet
-            if (!connection_value<LONG>(c, p, info, reverse_match_, filter_sigmas, &v, &x, &y, &s)) {
-                PH(7);
-                continue;                                                // :290-296 (block_joints is a no-op)
+            // the memo holds this bone's connection value if it was computed from the very joint the search assigned
+            int memo = 0;
+            if (c.sp_j && c.sp_match[start]) {
+                const int w = c.sp_b[bn];
+                if (((w & 0xff) == kSbOk || (w & 0xff) == kSbRejected) && (w >> 8) == slot) memo = w & 0xff;
+            }
+            if (memo) {
+                c.n_hit++;
+                if (memo == kSbRejected) { PH(7); continue; }            // :290-296
+                v = c.sp_v[bn]; x = c.sp_x[bn]; y = c.sp_y[bn]; s = c.sp_s[bn];
+                c.sp_fromc[bn] = 1;
+            } else {
+                c.n_miss++;
+                if (!connection_value<LONG>(c, p, info, reverse_match_, filter_sigmas, &v, &x, &y, &s)) {
+                    PH(7);
+                    continue;                                            // :290-296 (block_joints is a no-op)
+                }
+                if (c.sp_j) c.sp_fromc[bn] = 0;
             }
             PH(7);
             if (!p.greedy) {                                             // :298-303
@@ -934,7 +1110,12 @@ __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool rever
         }
         c.jv[end] = v; c.jx[end] = x; c.jy[end] = y; c.js[end] = s;     // :310
         PH(9);
-        publish_joint<kPoolSlotsLds>(c, p, end, x, y, s);
+        // assigned exactly the candidate the level walk gave this joint (same bone, entry from the memo): its box is
+        // published already, and the memo of its bones holds
+        bool matched = false;
+        if (c.sp_j && c.sp_fromc[bn]) { const int w = c.sp_j[end]; matched = (w & kSpKind) == kSpCand && (w >> 8) == slot; }
+        if (c.sp_j) c.sp_match[end] = matched ? 1 : 0;
+        if (!matched) publish_joint<kPoolSlotsLds>(c, p, end, x, y, s);
         PH(10);
         frontier_add_from(c, end);
         PH(11);
@@ -1123,6 +1304,13 @@ __device__ __forceinline__ void reg_store_pose(ImageCtx& c, const RegState& R) {
 template <bool LONG>
 __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const RegSkeleton& sk, bool reverse_match_,
                                          double filter_sigmas, bool then_flood_fill) {
+    // joints assigned exactly their candidate's values / directed bones whose entry came from the memo (one bit each)
+    unsigned long long sp_match = 0ull, sp_fromc = 0ull;
+    if (c.sp_j) {                                                            // the bones of the pose, level by level, in batches (spec_phase)
+        spec_phase<kPoolSlots>(c, p, reverse_match_, filter_sigmas);
+        if (c.aborted) return;
+        sp_match = __ballot(lane_id() < c.K && (c.sp_j[lane_id() < c.K ? lane_id() : 0] & kSpKind) == kSpActual);
+    }
     RegState R;
     reg_load_pose(c, R);
     reg_frontier_start(R, sk, c.K);
@@ -1136,9 +1324,25 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
         float x, y, s;
         PH(0);
         if (v == 0.0) {                                                      // :287: not computed yet
-            if (!reg_connection_value<LONG>(c, p, R, start, info, reverse_match_, filter_sigmas, &v, &x, &y, &s)) {
-                PH(7);
-                continue;                                                    // :290-296 (block_joints is a no-op)
+            // the memo holds this bone's connection value if it was computed from the very joint the search assigned
+            int memo = 0;
+            const int bn = (info >> 16) & 0xff;
+            if (c.sp_j && ((sp_match >> start) & 1ull)) {
+                const int w = __builtin_amdgcn_readfirstlane(c.sp_b[bn]);
+                if (((w & 0xff) == kSbOk || (w & 0xff) == kSbRejected) && (w >> 8) == slot) memo = w & 0xff;
+            }
+            if (memo) {
+                c.n_hit++;
+                if (memo == kSbRejected) { PH(7); continue; }                // :290-296
+                v = uniform_f64(c.sp_v[bn]); x = uniform_f32(c.sp_x[bn]); y = uniform_f32(c.sp_y[bn]); s = uniform_f32(c.sp_s[bn]);
+                sp_fromc |= 1ull << slot;
+            } else {
+                c.n_miss++;
+                if (!reg_connection_value<LONG>(c, p, R, start, info, reverse_match_, filter_sigmas, &v, &x, &y, &s)) {
+                    PH(7);
+                    continue;                                                // :290-296 (block_joints is a no-op)
+                }
+                sp_fromc &= ~(1ull << slot);
             }
             PH(7);
             if (!p.greedy) {                                                 // :298-303
@@ -1153,7 +1357,15 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
         }
         reg_set_joint(R, end, v, x, y, s);                                   // :310
         PH(9);
-        publish_joint<kPoolSlots>(c, p, end, x, y, s);
+        // assigned exactly the candidate the level walk gave this joint (same bone, entry from the memo): its box is
+        // published already, and the memo of its bones holds
+        bool matched = false;
+        if (c.sp_j && ((sp_fromc >> slot) & 1ull)) {
+            const int w = __builtin_amdgcn_readfirstlane(c.sp_j[end]);
+            matched = (w & kSpKind) == kSpCand && (w >> 8) == slot;
+        }
+        if (matched) sp_match |= 1ull << end;
+        else publish_joint<kPoolSlots>(c, p, end, x, y, s);
         PH(10);
         reg_frontier_add_from(R, sk, end);
         PH(11);
@@ -1320,6 +1532,196 @@ __device__ __forceinline__ void pool_catch_up(ImageCtx& c, int e) {
     if (lane == 0) flag_store(c.ack, e);
 }
 
+
+// ------------------------------------------------ speculative batched evaluation of a growth (spec_phase)
+// The reference evaluates one bone per pop of its frontier (cifcaf.cpp:287-303), a chain of ~2 list scans per bone -- but
+// _connection_value (:349-411) of a bone depends on its START JOINT alone, and a joint, once assigned, never changes.  So
+// before the search itself runs, the wave walks the skeleton level by level from the joints the pose starts with: all
+// bones leaving the joints of a level are evaluated in ONE batch of forward scans and ONE batch of reverse scans
+// (spec_scan_batch), each result is remembered per bone, and the end joint of every connection that holds becomes a
+// CANDIDATE -- the start joint of the next level's bones.  The search (grow / grow_reg) then runs the reference's heap
+// loop unchanged and takes a bone's connection value from the memo instead of scanning -- but only when the start joint
+// was assigned exactly the candidate the memo was computed from (it was reached through the same bone, whose own entry
+// came from the memo): then the value IS what _connection_value returns, bit for bit.  Anything else -- a joint reached
+// through another bone first, a batch that did not fit -- is evaluated on demand as before.  The sequence of heap
+// operations, and with it every tie, is the reference's.
+// The candidates are also this growth's PREDICTIONS: their occupancy boxes are published level by level (a pose of 17
+// joints is known after ~8 levels, long before the heap loop has assigned it), which is what keeps the other growers off
+// the same person.  Advisory as before: the commit re-tests every seed against the final boxes.
+
+// boxes of the joints that became candidates in this level: published like the boxes of assigned joints (publish_joint)
+template <int WR>
+__device__ __forceinline__ void spec_publish(ImageCtx& c, const DevParams& p) {
+    const int lane = lane_id();
+    bool any_new = false;
+    for (int k0 = 0; k0 < c.F; k0 += kWave) {
+        const int k = k0 + lane;
+        const int w = k < c.F ? c.sp_j[k] : 0;
+        if (w & kSpNext) {
+            const int pb = (c.slot_info[w >> 8] >> 16) & 0xff;
+            c.jbox[k] = occ_box(c, p, (double)c.sp_x[pb], (double)c.sp_y[pb], (double)c.sp_s[pb]);
+            any_new = true;
+        }
+    }
+    if (__ballot(any_new) == 0ull) return;
+    wave_sync();
+    // every pooled seed that comes later in seed order and lies in one of this growth's boxes is shadowed (re-testing the
+    // boxes of earlier levels sets the same bits again)
+    unsigned bits = 0u;
+#pragma unroll
+    for (int r0 = 0; r0 < WR; r0 += 4) {
+        int sif[4], spk[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { sif[r] = c.pool_if[(r0 + r) * kWave + lane]; spk[r] = c.pool_pack[(r0 + r) * kWave + lane]; }
+#pragma unroll
+        for (int r = 0; r < 4; r++) asm volatile("" : "+v"(sif[r]), "+v"(spk[r]) :: "memory");
+        OccBox bx[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int f = (int)((unsigned)sif[r] >> 24);
+            bx[r] = c.jbox[f < c.F ? f : 0];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) asm volatile("" : "+v"(bx[r].minx), "+v"(bx[r].miny), "+v"(bx[r].maxx), "+v"(bx[r].maxy) :: "memory");
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int f = (int)((unsigned)sif[r] >> 24), idx = sif[r] & kPoolIdxMask;
+            if (idx != kPoolIdxMask && idx > c.my_idx && f < c.F &&
+                box_contains(bx[r], spk[r] & 0xfff, (spk[r] >> 12) & 0xfff)) bits |= 1u << (r0 + r);
+        }
+    }
+    if (bits) atomicOr(&c.shadow_mine[lane], bits);
+    ++c.n_pub;
+    if (lane == 0) *c.pub = c.n_pub;
+    // a new candidate inside the box an EARLIER live growth has published for the same joint: most likely the same person
+    // (publish_joint's test, lane = joint, the growers one after the other)
+    const int cfg = c.head_g[2];
+    if (cfg >> 28) {
+        const TaskSlot* tasks = reinterpret_cast<const TaskSlot*>(opa_dyn_lds);
+        const unsigned char* blocks = opa_dyn_lds + c.head_g[1];
+        const int n_growers = (cfg >> 20) & 0xff, block_bytes = cfg & 0xfffff;
+        unsigned key = 0xFFFFFFFFu;
+        for (int k0 = 0; k0 < c.F; k0 += kWave) {
+            const int k = k0 + lane;
+            const int w = k < c.F ? c.sp_j[k] : 0;
+            int cx = 0, cy = 0;
+            if (w & kSpNext) {
+                const int pb = (c.slot_info[w >> 8] >> 16) & 0xff;
+                occ_xy(c, p, (double)c.sp_x[pb], (double)c.sp_y[pb], &cx, &cy);
+            }
+            for (int gw = 1; gw <= n_growers; gw++) {
+                if (gw == c.wave) continue;
+                const int st = flag_peek(&tasks[gw].state), cn = flag_peek(&tasks[gw].cancel), sd = tasks[gw].seed;
+                if (!((st == kTaskAssigned || st == kTaskDone) && !cn && sd < c.my_idx)) continue;
+                if (w & kSpNext) {
+                    const OccBox ob = reinterpret_cast<const OccBox*>(blocks + (size_t)(gw - 1) * block_bytes)[k];
+                    if (box_contains(ob, cx, cy)) key = min(key, ((unsigned)sd << 6) | (unsigned)gw);
+                }
+            }
+        }
+        if (__ballot(key != 0xFFFFFFFFu) != 0ull) {
+            const unsigned first = ~wave_max_u32(~key);      // the earliest of them
+            if (lane == 0) flag_store(const_cast<int*>(&tasks[c.wave].coll), (int)(first & 63u));
+        }
+    }
+}
+
+template <int WR>
+__device__ __forceinline__ void spec_phase(ImageCtx& c, const DevParams& p, bool reverse_match_, double filter_sigmas) {
+    const int lane = lane_id();
+    const int K = c.K, A = c.A, E = 2 * A;
+    int* joblist = reinterpret_cast<int*>(c.tgt);            // (the scan area is free between two batches)
+    for (int k = lane; k < K; k += kWave) c.sp_j[k] = c.jv[k] != 0.0 ? (kSpActual | kSpOpen) : 0;
+    for (int a = lane; a < A; a += kWave) c.sp_b[a] = 0;
+    wave_sync();
+    for (;;) {
+        // ---- this round's jobs: the first slot of every (start, end) pair whose start joint is open, whose end is not filled
+        //      from the start (cifcaf.cpp:327,336) and whose bone has not been evaluated in either direction; of a bone
+        //      between two open joints the direction from the lower joint
+        int nj = 0;
+        for (int t0 = 0; t0 < E; t0 += kWave) {
+            const int t = t0 + lane;
+            bool cand = false;
+            if (t < E) {
+                const int info = c.slot_info[t];
+                const int a = info & 0xff, b = (info >> 8) & 0xff, bn = (info >> 16) & 0xff;
+                const int wa = c.sp_j[a], wb = c.sp_j[b];
+                cand = c.adj_first[t] == t && (wa & kSpOpen) && (wb & kSpKind) != kSpActual && (c.sp_b[bn] & 0xff) == 0 &&
+                       !((wb & kSpOpen) && b < a);
+            }
+            const unsigned long long m = __ballot(cand);
+            const int slot = nj + prefix_count(m);
+            if (cand && slot < kWave) joblist[slot] = t;
+            nj += __popcll(m);
+            if (nj >= kWave) break;                          // (the rest of the level in the next round)
+        }
+        if (nj == 0) {
+            // the level is done: the joints that became candidates in it are the next one
+            bool any = false;
+            for (int k = lane; k < K; k += kWave) {
+                const int w = c.sp_j[k];
+                const int nw = (w & ~(kSpOpen | kSpNext)) | ((w & kSpNext) ? kSpOpen : 0);
+                c.sp_j[k] = nw; any |= (nw & kSpOpen) != 0;
+            }
+            wave_sync();
+            if (__ballot(any) == 0ull) break;
+            continue;
+        }
+        if (nj > kWave) nj = kWave;
+        wave_sync();
+        const bool job = lane < nj;
+        const int t = job ? joblist[lane] : 0;
+        wave_sync();
+        const int info = c.slot_info[t];
+        const int a = info & 0xff, b = (info >> 8) & 0xff, bn = (info >> 16) & 0xff, fwd = (info >> 24) & 1;
+        // the start joint: filled from the start, or the candidate its bone gave it
+        const int wa = c.sp_j[a];
+        double sv; float sxf, syf, ssf;
+        if ((wa & kSpKind) == kSpActual) { sv = c.jv[a]; sxf = c.jx[a]; syf = c.jy[a]; ssf = c.js[a]; }
+        else { const int pb = (c.slot_info[wa >> 8] >> 16) & 0xff; sv = c.sp_v[pb]; sxf = c.sp_x[pb]; syf = c.sp_y[pb]; ssf = c.sp_s[pb]; }
+        const double sx = (double)sxf, sy = (double)syf, ss = (double)ssf;
+        int res = 0;
+        double nv = 0.0; float nx = 0.f, ny = 0.f, ns = 0.f;
+        bool need_rev = false;
+        for (int stage = 0; stage < 2; stage++) {           // cifcaf.cpp:349-411: forward scans of all jobs, then their reverse scans
+            const bool act = stage == 0 ? job : need_rev;
+            const unsigned long long am = __ballot(act);
+            if (am == 0ull) break;
+            c.n_blend += __popcll(am);
+            const int li = bn * 2 + ((stage == 0) == (fwd != 0) ? 0 : 1);
+            const SpecOut o = spec_scan_batch(c, act, li, stage == 0 ? sx : (double)nx, stage == 0 ? sy : (double)ny,
+                                              stage == 0 ? ss : (double)ns, filter_sigmas);
+            if (stage == 0) {
+                if (job) {
+                    if (o.ok < 0) res = kSbUnknown;
+                    else if (o.ok == 0) res = kSbRejected;                                  // :384
+                    else {
+                        nx = o.x; ny = o.y; ns = o.s;
+                        nv = sqrt(o.v * sv);                                                // :386
+                        if (nv < p.keypoint_threshold || nv < sv * p.keypoint_threshold_rel) res = kSbRejected;   // :387-390
+                        else if (p.reverse_match && reverse_match_ && a < c.F) need_rev = true;                  // :397
+                        else res = kSbOk;
+                    }
+                }
+            } else if (need_rev) {
+                if (o.ok < 0) res = kSbUnknown;
+                else if (o.ok == 0) res = kSbRejected;                                      // :400-403
+                else res = fabs(sx - (double)o.x) + fabs(sy - (double)o.y) > ss ? kSbRejected : kSbOk;   // :404
+            }
+        }
+        if (job) {
+            c.sp_b[bn] = res | (t << 8);
+            if (res == kSbOk) { c.sp_v[bn] = nv; c.sp_x[bn] = nx; c.sp_y[bn] = ny; c.sp_s[bn] = ns; }
+        }
+        wave_sync();
+        // the end joint of a connection that holds becomes a candidate, unless it is one already (first come)
+        if (job && res == kSbOk) atomicCAS(&c.sp_j[b], 0, kSpCand | kSpNext | (t << 8));
+        wave_sync();
+        if (c.pub) spec_publish<WR>(c, p);
+        if (poll_task<WR>(c)) { c.aborted = 1; return; }
+    }
+}
+
 // Occupancy::get on the bitmap (one bit per cell, rows of occ_wpr 32-bit words)
 __device__ __forceinline__ bool occ_test(const ImageCtx& c, int f, int xi, int yi) {
     const unsigned w = c.occ[((size_t)f * c.occ_h + yi) * c.occ_wpr + (xi >> 5)];
@@ -1331,16 +1733,23 @@ __device__ __forceinline__ bool occ_test(const ImageCtx& c, int f, int xi, int y
 // area (`tgt_floats`: kBlendLdsFloats, or kSmallTgtFloats when that buys more growers).  16-byte sized.
 constexpr int kSmallTgtChunks = 2;
 constexpr int kSmallTgtFloats = 3 * kSmallTgtChunks * kWave + 4 * kWave;
+constexpr int kSpecTgtFloats = kSpecItems + 2 * kWave + 4 * 192;   // the small scan area when the level walk runs: batches of up to 192 passing entries
 __host__ __device__ inline size_t assoc_pose_bytes(int K) {
     return (16 * (size_t)K + sizeof(double) * K + sizeof(float) * 3 * K + 15) / 16 * 16;
 }
-__host__ __device__ inline size_t assoc_private_bytes(int K, int A, bool reg, int tgt_floats) {
+// the level walk's memo (spec_phase): a word per joint, a word + a connection value per bone; the LDS variant also keeps its two flag sets here
+__host__ __device__ inline size_t assoc_spec_bytes(int K, int A, bool reg) {
+    return (sizeof(double) * A + sizeof(int) * (K + A) + sizeof(float) * 3 * A + (reg ? 0 : K + A) + 15) / 16 * 16;
+}
+__host__ __device__ inline size_t assoc_private_bytes(int K, int A, bool reg, int tgt_floats, bool spec = false) {
     size_t b = assoc_pose_bytes(K);
     if (!reg) b += sizeof(double) * A + sizeof(unsigned long long) * A + sizeof(float) * 3 * A + (A + 15) / 16 * 16 + (A & 1 ? 4 : 0);
-    return (b + 15) / 16 * 16 + sizeof(float) * tgt_floats;
+    b = (b + 15) / 16 * 16;
+    if (spec) b += assoc_spec_bytes(K, A, reg);
+    return b + sizeof(float) * tgt_floats;
 }
 template <bool REG>
-__device__ __forceinline__ void carve_private(ImageCtx& c, unsigned char* sp, int tgt_floats) {
+__device__ __forceinline__ void carve_private(ImageCtx& c, unsigned char* sp, int tgt_floats, bool spec = false) {
     const int K = c.K, A = c.A;
     unsigned char* base = sp;
     c.jbox = (OccBox*)sp; sp += sizeof(OccBox) * K;
@@ -1358,6 +1767,20 @@ __device__ __forceinline__ void carve_private(ImageCtx& c, unsigned char* sp, in
         c.e_s = (float*)sp; sp += sizeof(float) * A;
         c.in_frontier = sp; sp += (A + 15) / 16 * 16 + (A & 1 ? 4 : 0);
         sp = base + (((size_t)(sp - base) + 15) & ~(size_t)15);
+    }
+    c.sp_j = c.sp_b = nullptr; c.sp_v = nullptr; c.sp_x = c.sp_y = c.sp_s = nullptr; c.sp_match = c.sp_fromc = nullptr;
+    c.sp_pcap = 0; c.n_hit = c.n_miss = 0;
+    if (spec) {
+        unsigned char* s0 = sp;
+        c.sp_v = (double*)sp; sp += sizeof(double) * A;
+        c.sp_j = (int*)sp; sp += sizeof(int) * K;
+        c.sp_b = (int*)sp; sp += sizeof(int) * A;
+        c.sp_x = (float*)sp; sp += sizeof(float) * A;
+        c.sp_y = (float*)sp; sp += sizeof(float) * A;
+        c.sp_s = (float*)sp; sp += sizeof(float) * A;
+        if constexpr (!REG) { c.sp_match = sp; sp += K; c.sp_fromc = sp; sp += A; }
+        sp = s0 + assoc_spec_bytes(K, A, REG);
+        c.sp_pcap = spec_pcap(tgt_floats);
     }
     c.tgt = (float*)sp;
     c.max_r = tgt_floats >= kBlendLdsFloats ? kBlendChunks : kSmallTgtChunks;
@@ -1625,8 +2048,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     if (use_bbox) sp += sizeof(float4) * E * kListBboxChunks;
     unsigned char* work_base = sp;                   // growth phase: private blocks; NMS phase: its arrays and scratch
     unsigned char* private_base = sp;
-    const size_t private_bytes = assoc_private_bytes(K, A, REG, tgt_floats);
-    carve_private<REG>(c, private_base + (size_t)(wave >= 1 && wave <= S ? wave - 1 : 0) * private_bytes, tgt_floats);   // other waves never touch theirs
+    const size_t private_bytes = assoc_private_bytes(K, A, REG, tgt_floats, a.spec != 0);
+    carve_private<REG>(c, private_base + (size_t)(wave >= 1 && wave <= S ? wave - 1 : 0) * private_bytes, tgt_floats, a.spec != 0);   // other waves never touch theirs
 
     // the image's occupancy bitmap starts empty (cifcaf.cpp:173); 16-byte stores, region is 256-B aligned
     {
@@ -2291,7 +2714,11 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             busy_ticks += wall_clock64() - t0;
         }
         c.cancel = nullptr;
+#ifdef OPA_ASSOC_SCAN_TIMING
         if (lane == 0) { atomicAdd(&sh_ctl[3], (int)busy_ticks); atomicAdd(&sh_ctl[4], c.n_blend); atomicAdd(&sh_ctl[6], c.t_blend); atomicAdd(&sh_ctl[7], c.t_blend_mem); }
+#else
+        if (lane == 0) { atomicAdd(&sh_ctl[3], (int)busy_ticks); atomicAdd(&sh_ctl[4], c.n_blend); atomicAdd(&sh_ctl[6], c.n_hit); atomicAdd(&sh_ctl[7], c.n_miss); }
+#endif
     }
     sync_global();                        // stored poses visible to every wave; the private blocks are free
 #ifdef OPA_ASSOC_PHASE_TIMING
@@ -2455,13 +2882,15 @@ static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, con
 #endif
     // the scan area of a grower: the full one (lists of up to 8 chunks in one round trip), or the small one when that
     // buys more growers (large skeletons: the frontier lives in LDS too, and their lists are short)
+    const bool spec = a.spec != 0;
     int tgt_floats = kBlendLdsFloats;
-    size_t priv = assoc_private_bytes(K, A, REG, tgt_floats);
+    size_t priv = assoc_private_bytes(K, A, REG, tgt_floats, spec);
     int growers = shared + priv <= budget ? (int)((budget - shared) / priv) : 0;
     if (growers < NW - 1) {
-        const size_t priv_small = assoc_private_bytes(K, A, REG, kSmallTgtFloats);
+        const int small_floats = spec ? kSpecTgtFloats : kSmallTgtFloats;     // (the level walk's batches need more of it than two chunks)
+        const size_t priv_small = assoc_private_bytes(K, A, REG, small_floats, spec);
         const int growers_small = shared + priv_small <= budget ? (int)((budget - shared) / priv_small) : 0;
-        if (growers_small > growers) { growers = growers_small; priv = priv_small; tgt_floats = kSmallTgtFloats; }
+        if (growers_small > growers) { growers = growers_small; priv = priv_small; tgt_floats = small_floats; }
     }
     if (growers < 1) return hipErrorInvalidValue;
     if (growers > NW - 1) growers = NW - 1;
@@ -2490,12 +2919,12 @@ static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, con
 // 16-wave instantiations (OPA_ASSOC_WAVES, interleaving experiments of round 2) double the compile time of this file
 // and are built only with -DOPA_ASSOC_ALL_WAVES.
 static int assoc_waves() {
-#ifdef OPA_ASSOC_ALL_WAVES
     const char* e = getenv("OPA_ASSOC_WAVES");
     const int v = e ? atoi(e) : 0;
+#ifdef OPA_ASSOC_ALL_WAVES
     return v == 8 || v == 12 || v == 16 ? v : kAssocWavesDefault;
 #else
-    return kAssocWavesDefault;
+    return v == 8 || v == 12 ? v : kAssocWavesDefault;
 #endif
 }
 
@@ -2510,6 +2939,8 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     a.inherit = 1;
     a.collide = 1;
     a.timing = 0;
+    a.spec = 1;
+    if (const char* e = getenv("OPA_ASSOC_SPEC")) a.spec = atoi(e) != 0;           // A/B and tests: every bone scanned on demand, one at a time
     if (const char* e = getenv("OPA_ASSOC_TIMING")) a.timing = atoi(e) != 0;      // phase tick counters of the coordinator (statistics slots 12, 17-20)
     if (const char* e = getenv("OPA_ASSOC_COLLIDE")) a.collide = atoi(e) != 0;     // A/B: growths stop only when their SEED is covered
     if (const char* e = getenv("OPA_ASSOC_INHERIT")) a.inherit = atoi(e) != 0;     // A/B: predictions lapse with the growth that made them
@@ -2521,10 +2952,10 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     if (K > 256 || a.A > 256) return hipErrorInvalidValue;      // a slot's joints and bone are packed into 8 bits each
     const bool reg = K <= kWave && E <= kWave;       // pose, frontier and heap fit the lanes of a wave
     hipError_t e;
-    if (!reg) e = launch_assoc_nw<false, 12>(a, sk, p, st);  // LDS-resident growth state: 160 KB hold 8 growers of a 133-joint skeleton
+    if (!reg) e = assoc_waves() == 8 ? launch_assoc_nw<false, 8>(a, sk, p, st) : launch_assoc_nw<false, 12>(a, sk, p, st);  // LDS-resident growth state
     else switch (assoc_waves()) {
-#ifdef OPA_ASSOC_ALL_WAVES
         case 8: e = launch_assoc_nw<true, 8>(a, sk, p, st); break;
+#ifdef OPA_ASSOC_ALL_WAVES
         case 16: e = launch_assoc_nw<true, 16>(a, sk, p, st); break;
 #endif
         default: e = launch_assoc_nw<true, 12>(a, sk, p, st); break;

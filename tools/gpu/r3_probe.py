@@ -107,6 +107,7 @@ print('batch: started %d accepted %d cancelled %d dropped %d; slowest image %.0f
     tot_s[0], tot_s[1], tot_s[2], tot_s[3], st[:, 9].max() / 100, st[:, 9].mean() / 100,
     int(dec.workspace_view('list_counts', torch.int32)[:B * len(skel0) * 2].max()),
     float(dec.workspace_view('list_counts', torch.int32)[:B * len(skel0) * 2].float().mean())))
+print('level walk: connection values from the memo %d, evaluated on demand %d' % (tot_s[21], tot_s[22]))
 if args.fc:
     lc = dec.workspace_view('list_counts_fc', torch.int32)[:B * len(skel0) * 2]
     print('force-complete lists: max %d mean %.0f' % (int(lc.max()), float(lc.float().mean())))
