@@ -98,7 +98,7 @@ struct ListView { const float* base; int cap; int n; const float4* bbox; const f
 // Diagnostic builds only (-DOPA_ASSOC_PHASE_TIMING, tools/gpu/assoc_probe.py): shader-clock time of the growers
 // by phase of the search, summed over the growers of an image; printed by the kernel for images 0 and 3.
 #ifdef OPA_ASSOC_PHASE_TIMING
-constexpr int kPhases = 20;
+constexpr int kPhases = 32;
 __shared__ int g_ph[kPhases], g_phn[kPhases];
 __shared__ long long g_ph_last[16];
 __device__ __forceinline__ void ph_stamp(int k) {
@@ -155,6 +155,7 @@ struct ImageCtx {
     double* sp_v; float *sp_x, *sp_y, *sp_s;
     unsigned char *sp_match, *sp_fromc;  // LDS variant of the growth state: joint assigned with its candidate's values [K]; entry of the bone came from the cache [A]
     int sp_pcap;                         // passing entries the scan area holds during a batch
+    int early;                           // publish a joint's box when its connection is evaluated, not only when it is assigned (advisory)
     int n_hit, n_miss;                   // statistics: connection values taken from the cache / evaluated on demand
 };
 
@@ -775,11 +776,20 @@ __device__ __forceinline__ BlendResult blend(ImageCtx& c, const ListView& L, dou
 // its job's entries in list order), and one round trip for the target columns of the winners.  A batch costs about what
 // one scan costs (two memory round trips); the results are those of the single scans bit for bit (same score_of, same
 // blend_finish, and the top-2 rule is the reference's loop itself).
-// memo words of the level walk (spec_phase, below)
+// The level walk (spec_phase, below) is compiled in only with -DOPA_ASSOC_WALK (build.build_diagnostic('OPA_ASSOC_WALK', 'walk')):
+// measured in round 5 (profiles/r5/rejected_level_walk.log) it is exact and halves the growths started, but a batch of n scans
+// costs what n single scans cost, so the growths get slower, not faster; with the switch off the kernels carry none of it.
+#ifdef OPA_ASSOC_WALK
+constexpr bool kWalk = true;
+#else
+constexpr bool kWalk = false;
+#endif
+// memo words of the level walk
 constexpr int kSpActual = 1, kSpCand = 2, kSpKind = 3, kSpOpen = 4, kSpNext = 8;     // per joint: kind, "its bones are this level's jobs", "became a candidate in this level"
-constexpr int kSbOk = 1, kSbRejected = 2, kSbUnknown = 3;                            // per bone: connection holds / _connection_value returns the zero joint / not evaluated here
+constexpr int kSbOk = 1, kSbRejected = 2, kSbUnknown = 3, kSbPending = 4;            // per bone: connection holds / _connection_value returns the zero joint / not evaluated here / forward scan done, reverse scan outstanding
 constexpr int kSpecItems = 128;          // (job, chunk) items of one batch
-constexpr int kSpecGroup = 8;            // items whose loads are in flight together
+constexpr int kSpecGroup = 6;            // items whose loads are in flight together
+constexpr int kSpecEntryWords = 7;       // a passing entry in the scan area: x1, y1, c -> score, x2, y2, s2, job
 struct SpecOut { int ok; double v; float x, y, s; };   // ok: 1 a joint, 0 the all-zero joint (:76), -1 not evaluated (left to the single scans)
 
 __device__ __forceinline__ int rlane_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
@@ -789,8 +799,8 @@ __device__ __forceinline__ float bperm_f(float v, int src) { return __int_as_flo
 __device__ __forceinline__ double bperm_d(double v, int src) {
     return __hiloint2double(bperm_i(__double2hiint(v), src), bperm_i(__double2loint(v), src));
 }
-__device__ __forceinline__ int spec_pcap(int tgt_floats) {   // the scan area: items, a segment per job, then 16 bytes per passing entry
-    return (tgt_floats - kSpecItems - 2 * kWave) / 4;
+__device__ __forceinline__ int spec_pcap(int tgt_floats) {   // the scan area: items, a segment per job, then seven words per passing entry
+    return (tgt_floats - kSpecItems - 2 * kWave) / kSpecEntryWords;
 }
 
 __device__ __forceinline__ SpecOut spec_scan_batch(ImageCtx& c, bool active, int li, double x, double y, double s, double filter_sigmas) {
@@ -799,21 +809,27 @@ __device__ __forceinline__ SpecOut spec_scan_batch(ImageCtx& c, bool active, int
     int* seg = item + kSpecItems;                            // [2][64] where a job's passing entries start / end
     const int pcap = c.sp_pcap;
     float* cx = reinterpret_cast<float*>(seg + 2 * kWave); float* cy = cx + pcap; float* cv = cy + pcap;
-    int* ci = reinterpret_cast<int*>(cv + pcap);             // list position | job << 16
+    float* tx = cv + pcap; float* ty = tx + pcap; float* ts = ty + pcap;
+    int* cj = reinterpret_cast<int*>(ts + pcap);             // the entry's job
     const BlendQuery q = make_query(x, y, s, filter_sigmas);
     const int n = active ? c.sh_counts[li] : 0;
     const int nch = (n + kWave - 1) >> 6;
     int status = !active ? -1 : n <= 0 ? 0 : nch <= kListBboxChunks ? 1 : -1;   // 1: scanned here
     unsigned mask = 0u;                                      // the chunks of the list whose box meets the window (cifcaf.cpp:54-57)
     if (c.bbox) {
-        for (int ch = 0; __ballot(status == 1 && ch < nch) != 0ull; ch++)
-            if (status == 1 && ch < nch) {
-                const float4 bb = c.bbox[li * kListBboxChunks + ch];
-                if (bb.x <= q.fxhi && bb.y >= q.fxlo && bb.z <= q.fyhi && bb.w >= q.fylo) mask |= 1u << ch;
-            }
+        for (int ch0 = 0; __ballot(status == 1 && ch0 < nch) != 0ull; ch0 += 4) {   // four boxes per LDS round trip
+            float4 bb[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) bb[r] = c.bbox[(status == 1 ? li : 0) * kListBboxChunks + ((ch0 + r) & (kListBboxChunks - 1))];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (status == 1 && ch0 + r < nch && bb[r].x <= q.fxhi && bb[r].y >= q.fxlo && bb[r].z <= q.fyhi && bb[r].w >= q.fylo)
+                    mask |= 1u << (ch0 + r);
+        }
     } else if (status == 1) {
         mask = (1u << nch) - 1u;
     }
+    PH(22);
     // where the job's items go: exclusive prefix of the chunk counts (<= 16 each: five ballots)
     const int cnt = __popc(mask);
     int base = 0, total = 0;
@@ -836,10 +852,12 @@ __device__ __forceinline__ SpecOut spec_scan_batch(ImageCtx& c, bool active, int
     }
     seg[lane] = 0; seg[kWave + lane] = 0;
     wave_sync();
-    // ---- the items, kSpecGroup at a time: loads of a group back to back, then window test + ordered compaction
+    PH(23);
+    // ---- the items, kSpecGroup at a time: all six columns of a group's entries back to back, then window test + ordered
+    //      compaction of what passes (the target columns travel along: no second round trip for the winners)
     const gfloat* g = (const gfloat*)c.lists;
-    const int cap = c.list_cap;
-    const int loff = li * 7 * cap;
+    const unsigned cap = (unsigned)c.list_cap;
+    const unsigned loff = (unsigned)li * 7u * cap;
     int np = 0;                                              // passing entries so far (uniform)
     for (int w0 = 0; w0 < W; w0 += kSpecGroup) {
         int d[kSpecGroup];
@@ -847,17 +865,22 @@ __device__ __forceinline__ SpecOut spec_scan_batch(ImageCtx& c, bool active, int
         for (int r = 0; r < kSpecGroup; r++) d[r] = item[w0 + r < W ? w0 + r : W - 1];
 #pragma unroll
         for (int r = 0; r < kSpecGroup; r++) asm volatile("" : "+v"(d[r]) :: "memory");
-        float x1[kSpecGroup], y1[kSpecGroup], cc[kSpecGroup];
+        float x1[kSpecGroup], y1[kSpecGroup], cc[kSpecGroup], x2[kSpecGroup], y2[kSpecGroup], s2[kSpecGroup];
 #pragma unroll
         for (int r = 0; r < kSpecGroup; r++) {
-            const int dd = __builtin_amdgcn_readfirstlane(d[r]);
-            const int j = dd & 0xff, ch = (dd >> 8) & 0xff;
-            const int nj = rlane_i(n, j), lo = rlane_i(loff, j);
-            const int i = ch * kWave + lane, ii = i < nj ? i : 0;
-            x1[r] = g[lo + 1 * cap + ii]; y1[r] = g[lo + 2 * cap + ii]; cc[r] = g[lo + ii];
+            x1[r] = y1[r] = cc[r] = x2[r] = y2[r] = s2[r] = 0.f;
+            if (w0 + r < W) {                                // (uniform)
+                const int dd = __builtin_amdgcn_readfirstlane(d[r]);
+                const int j = dd & 0xff, ch = (dd >> 8) & 0xff;
+                const unsigned i = (unsigned)(ch * kWave + lane);
+                const unsigned o = (unsigned)rlane_i((int)loff, j) + (i < (unsigned)rlane_i(n, j) ? i : 0u);
+                cc[r] = g[o]; x1[r] = g[o + cap]; y1[r] = g[o + 2u * cap];
+                x2[r] = g[o + 3u * cap]; y2[r] = g[o + 4u * cap]; s2[r] = g[o + 6u * cap];
+            }
         }
 #pragma unroll
-        for (int r = 0; r < kSpecGroup; r++) asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]) :: "memory");
+        for (int r = 0; r < kSpecGroup; r++)
+            asm volatile("" : "+v"(x1[r]), "+v"(y1[r]), "+v"(cc[r]), "+v"(x2[r]), "+v"(y2[r]), "+v"(s2[r]) :: "memory");
 #pragma unroll
         for (int r = 0; r < kSpecGroup; r++) {
             if (w0 + r >= W) break;
@@ -870,44 +893,57 @@ __device__ __forceinline__ SpecOut spec_scan_batch(ImageCtx& c, bool active, int
             const int pc = __popcll(m);
             if (lane == 0) { if (dd >> 16) seg[j] = np; seg[kWave + j] = np + pc; }
             const int slot = np + prefix_count(m);
-            if (pass && slot < pcap) { cx[slot] = x1[r]; cy[slot] = y1[r]; cv[slot] = cc[r]; ci[slot] = i | (j << 16); }
+            if (pass && slot < pcap) {
+                cx[slot] = x1[r]; cy[slot] = y1[r]; cv[slot] = cc[r]; tx[slot] = x2[r]; ty[slot] = y2[r]; ts[slot] = s2[r]; cj[slot] = j;
+            }
             np += pc;
         }
     }
     wave_sync();
+    PH(24);
     // ---- scores of the passing entries (:60-63), lane = entry; the entry's query comes from its job's lane
     const int tot = np < pcap ? np : pcap;
     for (int e0 = 0; e0 < tot; e0 += kWave) {
         const int e = e0 + lane;
         const bool have = e < tot;
-        const int idx = have ? ci[e] : 0;
-        const int j = (idx >> 16) & (kWave - 1);
+        const int j = have ? cj[e] : 0;
         BlendQuery qq;
         qq.x = bperm_d(q.x, j); qq.y = bperm_d(q.y, j); qq.sigma2 = bperm_f(q.sigma2, j);
         if (have) cv[e] = score_of(qq, cx[e], cy[e], cv[e]);
     }
     wave_sync();
+    PH(25);
     // ---- the top two of every job: the reference's loop (:65-73) over the job's entries in list order, lane = job
+    //      (four entries per LDS round trip)
     const int lo = seg[lane], hi = seg[kWave + lane];
     if (status == 1 && hi > pcap) status = -1;               // more passing entries than the area holds: the single scans
-    float s1 = 0.0f, s2 = 0.0f; int i1 = 0, i2 = 0;
-    for (int e = lo; __ballot(status == 1 && e < hi) != 0ull; e++)
-        if (status == 1 && e < hi) {
-            const float sc = cv[e]; const int i = ci[e] & 0xffff;
-            if (sc >= s1) { s2 = s1; i2 = i1; s1 = sc; i1 = i; }
-            else if (sc > s2) { s2 = sc; i2 = i; }
-        }
-    wave_sync();                                             // the area is free for the next batch
+    float s1 = 0.0f, s2 = 0.0f; int e1 = 0, e2 = 0;
+    for (int e0 = lo; __ballot(status == 1 && e0 < hi) != 0ull; e0 += 4) {
+        float sc[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) sc[r] = cv[status == 1 && e0 + r < hi ? e0 + r : 0];
+#pragma unroll
+        for (int r = 0; r < 4; r++) asm volatile("" : "+v"(sc[r]) :: "memory");
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (status == 1 && e0 + r < hi) {
+                if (sc[r] >= s1) { s2 = s1; e2 = e1; s1 = sc[r]; e1 = e0 + r; }
+                else if (sc[r] > s2) { s2 = sc[r]; e2 = e0 + r; }
+            }
+    }
+    PH(26);
     SpecOut o; o.ok = status; o.v = 0.0; o.x = o.y = o.s = 0.f;
     if (status == 1) {
         if (s1 == 0.0f) o.ok = 0;                            // :76
         else {
-            const float e1x = g[loff + 3 * cap + i1], e1y = g[loff + 4 * cap + i1], e1s = g[loff + 6 * cap + i1];
-            const float e2x = g[loff + 3 * cap + i2], e2y = g[loff + 4 * cap + i2], e2s = g[loff + 6 * cap + i2];
+            const float e1x = tx[e1], e1y = ty[e1], e1s = ts[e1];
+            const float e2x = tx[e2], e2y = ty[e2], e2s = ts[e2];     // (s2 == 0: e2 = 0, a valid slot nobody looks at, :84)
             const BlendResult r = blend_finish(s1, s2, true, false, e1x, e1y, e1s, e2x, e2y, e2s);
             o.v = r.v; o.x = r.x; o.y = r.y; o.s = r.s;
         }
     }
+    wave_sync();                                             // the area is free for the next batch
+    PH(27);
     return o;
 }
 
@@ -1064,7 +1100,7 @@ __device__ __forceinline__ void frontier_start(ImageCtx& c) {
 // cifcaf.cpp:265-313 -- one wavefront, no workgroup barriers
 template <bool LONG>
 __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool reverse_match_, double filter_sigmas) {
-    if (c.sp_j) {                                                        // the bones of the pose, level by level, in batches (spec_phase)
+    if (kWalk && c.sp_j) {                                               // the bones of the pose, level by level, in batches (spec_phase)
         spec_phase<kPoolSlotsLds>(c, p, reverse_match_, filter_sigmas);
         if (c.aborted) return;
         for (int k = lane_id(); k < c.K; k += kWave) c.sp_match[k] = (c.sp_j[k] & kSpKind) == kSpActual ? 1 : 0;
@@ -1083,26 +1119,27 @@ __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool rever
         if (v == 0.0) {                                                  // :287: not computed yet
             // the memo holds this bone's connection value if it was computed from the very joint the search assigned
             int memo = 0;
-            if (c.sp_j && c.sp_match[start]) {
+            if (kWalk && c.sp_j && c.sp_match[start]) {
                 const int w = c.sp_b[bn];
                 if (((w & 0xff) == kSbOk || (w & 0xff) == kSbRejected) && (w >> 8) == slot) memo = w & 0xff;
             }
             if (memo) {
-                c.n_hit++;
+                if (kWalk) c.n_hit++;
                 if (memo == kSbRejected) { PH(7); continue; }            // :290-296
                 v = c.sp_v[bn]; x = c.sp_x[bn]; y = c.sp_y[bn]; s = c.sp_s[bn];
                 c.sp_fromc[bn] = 1;
             } else {
-                c.n_miss++;
+                if (kWalk) c.n_miss++;
                 if (!connection_value<LONG>(c, p, info, reverse_match_, filter_sigmas, &v, &x, &y, &s)) {
                     PH(7);
                     continue;                                            // :290-296 (block_joints is a no-op)
                 }
-                if (c.sp_j) c.sp_fromc[bn] = 0;
+                if (kWalk && c.sp_j) c.sp_fromc[bn] = 0;
             }
             PH(7);
             if (!p.greedy) {                                             // :298-303
                 c.e_v[bn] = v; c.e_x[bn] = x; c.e_y[bn] = y; c.e_s[bn] = s;
+                if (c.early) publish_joint<kPoolSlotsLds>(c, p, end, x, y, s);   // where the joint will be if this connection wins: a prediction
                 heap_push(c, (float)v, slot);
                 PH(8);
                 continue;
@@ -1113,8 +1150,8 @@ __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool rever
         // assigned exactly the candidate the level walk gave this joint (same bone, entry from the memo): its box is
         // published already, and the memo of its bones holds
         bool matched = false;
-        if (c.sp_j && c.sp_fromc[bn]) { const int w = c.sp_j[end]; matched = (w & kSpKind) == kSpCand && (w >> 8) == slot; }
-        if (c.sp_j) c.sp_match[end] = matched ? 1 : 0;
+        if (kWalk && c.sp_j && c.sp_fromc[bn]) { const int w = c.sp_j[end]; matched = (w & kSpKind) == kSpCand && (w >> 8) == slot; }
+        if (kWalk && c.sp_j) c.sp_match[end] = matched ? 1 : 0;
         if (!matched) publish_joint<kPoolSlotsLds>(c, p, end, x, y, s);
         PH(10);
         frontier_add_from(c, end);
@@ -1306,7 +1343,7 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
                                          double filter_sigmas, bool then_flood_fill) {
     // joints assigned exactly their candidate's values / directed bones whose entry came from the memo (one bit each)
     unsigned long long sp_match = 0ull, sp_fromc = 0ull;
-    if (c.sp_j) {                                                            // the bones of the pose, level by level, in batches (spec_phase)
+    if (kWalk && c.sp_j) {                                                   // the bones of the pose, level by level, in batches (spec_phase)
         spec_phase<kPoolSlots>(c, p, reverse_match_, filter_sigmas);
         if (c.aborted) return;
         sp_match = __ballot(lane_id() < c.K && (c.sp_j[lane_id() < c.K ? lane_id() : 0] & kSpKind) == kSpActual);
@@ -1327,17 +1364,17 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
             // the memo holds this bone's connection value if it was computed from the very joint the search assigned
             int memo = 0;
             const int bn = (info >> 16) & 0xff;
-            if (c.sp_j && ((sp_match >> start) & 1ull)) {
+            if (kWalk && c.sp_j && ((sp_match >> start) & 1ull)) {
                 const int w = __builtin_amdgcn_readfirstlane(c.sp_b[bn]);
                 if (((w & 0xff) == kSbOk || (w & 0xff) == kSbRejected) && (w >> 8) == slot) memo = w & 0xff;
             }
             if (memo) {
-                c.n_hit++;
+                if (kWalk) c.n_hit++;
                 if (memo == kSbRejected) { PH(7); continue; }                // :290-296
                 v = uniform_f64(c.sp_v[bn]); x = uniform_f32(c.sp_x[bn]); y = uniform_f32(c.sp_y[bn]); s = uniform_f32(c.sp_s[bn]);
                 sp_fromc |= 1ull << slot;
             } else {
-                c.n_miss++;
+                if (kWalk) c.n_miss++;
                 if (!reg_connection_value<LONG>(c, p, R, start, info, reverse_match_, filter_sigmas, &v, &x, &y, &s)) {
                     PH(7);
                     continue;                                                // :290-296 (block_joints is a no-op)
@@ -1348,6 +1385,7 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
             if (!p.greedy) {                                                 // :298-303
                 wlane(R.ev_lo, __double2loint(v), slot); wlane(R.ev_hi, __double2hiint(v), slot);
                 wlanef(R.ex, x, slot); wlanef(R.ey, y, slot); wlanef(R.es, s, slot);
+                if (c.early) publish_joint<kPoolSlots>(c, p, end, x, y, s);      // where the joint will be if this connection wins: a prediction
                 reg_heap_push(R, (float)v, slot);
                 PH(8);
                 continue;
@@ -1360,7 +1398,7 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
         // assigned exactly the candidate the level walk gave this joint (same bone, entry from the memo): its box is
         // published already, and the memo of its bones holds
         bool matched = false;
-        if (c.sp_j && ((sp_fromc >> slot) & 1ull)) {
+        if (kWalk && c.sp_j && ((sp_fromc >> slot) & 1ull)) {
             const int w = __builtin_amdgcn_readfirstlane(c.sp_j[end]);
             matched = (w & kSpKind) == kSpCand && (w >> 8) == slot;
         }
@@ -1444,6 +1482,10 @@ template <int WR>
 __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s) {
     if (!c.pub || k >= c.F) return;
     const OccBox b = occ_box(c, p, (double)x, (double)y, (double)s);
+    if (c.early) {                                   // the box this growth published when it evaluated the connection: nothing new to say
+        const OccBox o = c.jbox[k];
+        if (o.minx == b.minx && o.miny == b.miny && o.maxx == b.maxx && o.maxy == b.maxy) return;
+    }
     const int lane = lane_id();
     // every pooled seed of this field that comes later in seed order and lies in the box is shadowed: it dies
     // if this pose is accepted.  Advisory only (the commit re-tests every seed against the final boxes).
@@ -1470,7 +1512,7 @@ __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, i
     // (the task slots open the workgroup's dynamic LDS; where the growers' pose blocks lie, how many there are and whether
     // the test is on: the two control words behind the head grower's, written once by the kernel)
     const int cfg = c.head_g[2];
-    if (cfg >> 28) {
+    if ((cfg >> 28) & 1) {
         const TaskSlot* tasks = reinterpret_cast<const TaskSlot*>(opa_dyn_lds);
         const unsigned char* blocks = opa_dyn_lds + c.head_g[1];
         const int n_growers = (cfg >> 20) & 0xff, block_bytes = cfg & 0xfffff;
@@ -1549,7 +1591,7 @@ __device__ __forceinline__ void pool_catch_up(ImageCtx& c, int e) {
 // joints is known after ~8 levels, long before the heap loop has assigned it), which is what keeps the other growers off
 // the same person.  Advisory as before: the commit re-tests every seed against the final boxes.
 
-// boxes of the joints that became candidates in this level: published like the boxes of assigned joints (publish_joint)
+// boxes of the joints that became candidates in this round: published like the boxes of assigned joints (publish_joint)
 template <int WR>
 __device__ __forceinline__ void spec_publish(ImageCtx& c, const DevParams& p) {
     const int lane = lane_id();
@@ -1566,7 +1608,7 @@ __device__ __forceinline__ void spec_publish(ImageCtx& c, const DevParams& p) {
     if (__ballot(any_new) == 0ull) return;
     wave_sync();
     // every pooled seed that comes later in seed order and lies in one of this growth's boxes is shadowed (re-testing the
-    // boxes of earlier levels sets the same bits again)
+    // boxes of earlier rounds sets the same bits again)
     unsigned bits = 0u;
 #pragma unroll
     for (int r0 = 0; r0 < WR; r0 += 4) {
@@ -1594,38 +1636,47 @@ __device__ __forceinline__ void spec_publish(ImageCtx& c, const DevParams& p) {
     ++c.n_pub;
     if (lane == 0) *c.pub = c.n_pub;
     // a new candidate inside the box an EARLIER live growth has published for the same joint: most likely the same person
-    // (publish_joint's test, lane = joint, the growers one after the other)
+    // (publish_joint's test: lane = grower, the new joints one after the other)
     const int cfg = c.head_g[2];
-    if (cfg >> 28) {
+    if ((cfg >> 28) & 1) {
         const TaskSlot* tasks = reinterpret_cast<const TaskSlot*>(opa_dyn_lds);
         const unsigned char* blocks = opa_dyn_lds + c.head_g[1];
         const int n_growers = (cfg >> 20) & 0xff, block_bytes = cfg & 0xfffff;
-        unsigned key = 0xFFFFFFFFu;
-        for (int k0 = 0; k0 < c.F; k0 += kWave) {
-            const int k = k0 + lane;
-            const int w = k < c.F ? c.sp_j[k] : 0;
-            int cx = 0, cy = 0;
-            if (w & kSpNext) {
-                const int pb = (c.slot_info[w >> 8] >> 16) & 0xff;
-                occ_xy(c, p, (double)c.sp_x[pb], (double)c.sp_y[pb], &cx, &cy);
-            }
-            for (int gw = 1; gw <= n_growers; gw++) {
-                if (gw == c.wave) continue;
-                const int st = flag_peek(&tasks[gw].state), cn = flag_peek(&tasks[gw].cancel), sd = tasks[gw].seed;
-                if (!((st == kTaskAssigned || st == kTaskDone) && !cn && sd < c.my_idx)) continue;
-                if (w & kSpNext) {
-                    const OccBox ob = reinterpret_cast<const OccBox*>(blocks + (size_t)(gw - 1) * block_bytes)[k];
-                    if (box_contains(ob, cx, cy)) key = min(key, ((unsigned)sd << 6) | (unsigned)gw);
+        bool earlier = false; int sd = 0;
+        if (lane >= 1 && lane <= n_growers && lane != c.wave) {
+            const int st = flag_peek(&tasks[lane].state), cn = flag_peek(&tasks[lane].cancel);
+            sd = tasks[lane].seed;
+            earlier = (st == kTaskAssigned || st == kTaskDone) && !cn && sd < c.my_idx;
+        }
+        if (__ballot(earlier) != 0ull) {
+            unsigned key = 0xFFFFFFFFu;
+            const OccBox* theirs = reinterpret_cast<const OccBox*>(blocks + (size_t)(earlier ? lane - 1 : 0) * block_bytes);
+            for (int k0 = 0; k0 < c.F; k0 += kWave) {
+                const int kk = k0 + lane;
+                unsigned long long nm = __ballot(kk < c.F && (c.sp_j[kk < c.F ? kk : 0] & kSpNext));
+                while (nm) {
+                    const int k = k0 + __builtin_ctzll(nm);
+                    nm &= nm - 1;
+                    const int pb = (c.slot_info[c.sp_j[k] >> 8] >> 16) & 0xff;
+                    int cx, cy;
+                    occ_xy(c, p, (double)c.sp_x[pb], (double)c.sp_y[pb], &cx, &cy);
+                    const OccBox ob = theirs[k];
+                    if (earlier && box_contains(ob, cx, cy)) key = min(key, ((unsigned)sd << 6) | (unsigned)lane);
                 }
             }
-        }
-        if (__ballot(key != 0xFFFFFFFFu) != 0ull) {
-            const unsigned first = ~wave_max_u32(~key);      // the earliest of them
-            if (lane == 0) flag_store(const_cast<int*>(&tasks[c.wave].coll), (int)(first & 63u));
+            if (__ballot(key != 0xFFFFFFFFu) != 0ull) {
+                const unsigned first = ~wave_max_u32(~key);      // the earliest of them
+                if (lane == 0) flag_store(const_cast<int*>(&tasks[c.wave].coll), (int)(first & 63u));
+            }
         }
     }
 }
 
+// One round = ONE batch: the forward scans of the bones leaving the joints that became candidates in the round before
+// TOGETHER with the reverse scans (cifcaf.cpp:397-409) of that round's connections -- a candidate's values are known
+// after its forward scan, the reverse scan only confirms or rejects the connection.  A rejected connection leaves its
+// candidate (and what was computed from it) in the memo, where nothing will ever match it: the search never assigns a
+// joint through a rejected bone.
 template <int WR>
 __device__ __forceinline__ void spec_phase(ImageCtx& c, const DevParams& p, bool reverse_match_, double filter_sigmas) {
     const int lane = lane_id();
@@ -1634,12 +1685,28 @@ __device__ __forceinline__ void spec_phase(ImageCtx& c, const DevParams& p, bool
     for (int k = lane; k < K; k += kWave) c.sp_j[k] = c.jv[k] != 0.0 ? (kSpActual | kSpOpen) : 0;
     for (int a = lane; a < A; a += kWave) c.sp_b[a] = 0;
     wave_sync();
+    bool pending = false;                                    // connections whose reverse scan is outstanding (uniform)
     for (;;) {
-        // ---- this round's jobs: the first slot of every (start, end) pair whose start joint is open, whose end is not filled
+        int nj = 0;
+        // ---- reverse jobs: the connections of the round before
+        if (pending)
+            for (int a0 = 0; a0 < A; a0 += kWave) {
+                const int bn = a0 + lane;
+                const int w = bn < A ? c.sp_b[bn] : 0;
+                const bool cand = (w & 0xff) == kSbPending;
+                const unsigned long long m = __ballot(cand);
+                const int slot = nj + prefix_count(m);
+                if (cand && slot < kWave) joblist[slot] = (w >> 8) | (1 << 16);
+                nj += __popcll(m);
+                if (nj >= kWave) break;
+            }
+        const bool rev_left = nj > kWave;                    // (more than a batch holds: the rest in the next round)
+        if (nj > kWave) nj = kWave;
+        // ---- forward jobs: the first slot of every (start, end) pair whose start joint is open, whose end is not filled
         //      from the start (cifcaf.cpp:327,336) and whose bone has not been evaluated in either direction; of a bone
         //      between two open joints the direction from the lower joint
-        int nj = 0;
-        for (int t0 = 0; t0 < E; t0 += kWave) {
+        bool fwd_left = nj >= kWave;                         // (the batch is full of reverse jobs: the open joints wait)
+        for (int t0 = 0; t0 < E && nj < kWave; t0 += kWave) {
             const int t = t0 + lane;
             bool cand = false;
             if (t < E) {
@@ -1653,25 +1720,17 @@ __device__ __forceinline__ void spec_phase(ImageCtx& c, const DevParams& p, bool
             const int slot = nj + prefix_count(m);
             if (cand && slot < kWave) joblist[slot] = t;
             nj += __popcll(m);
-            if (nj >= kWave) break;                          // (the rest of the level in the next round)
+            if (nj > kWave) { fwd_left = true; nj = kWave; }
+            else if (nj == kWave && t0 + kWave < E) fwd_left = true;       // (possibly: look again next round)
         }
-        if (nj == 0) {
-            // the level is done: the joints that became candidates in it are the next one
-            bool any = false;
-            for (int k = lane; k < K; k += kWave) {
-                const int w = c.sp_j[k];
-                const int nw = (w & ~(kSpOpen | kSpNext)) | ((w & kSpNext) ? kSpOpen : 0);
-                c.sp_j[k] = nw; any |= (nw & kSpOpen) != 0;
-            }
-            wave_sync();
-            if (__ballot(any) == 0ull) break;
-            continue;
-        }
-        if (nj > kWave) nj = kWave;
+        if (nj == 0) break;
         wave_sync();
+        PH(20);
         const bool job = lane < nj;
-        const int t = job ? joblist[lane] : 0;
+        const int jw = job ? joblist[lane] : 0;
         wave_sync();
+        const int t = jw & 0xffff;
+        const bool is_rev = (jw >> 16) != 0;
         const int info = c.slot_info[t];
         const int a = info & 0xff, b = (info >> 8) & 0xff, bn = (info >> 16) & 0xff, fwd = (info >> 24) & 1;
         // the start joint: filled from the start, or the candidate its bone gave it
@@ -1680,45 +1739,44 @@ __device__ __forceinline__ void spec_phase(ImageCtx& c, const DevParams& p, bool
         if ((wa & kSpKind) == kSpActual) { sv = c.jv[a]; sxf = c.jx[a]; syf = c.jy[a]; ssf = c.js[a]; }
         else { const int pb = (c.slot_info[wa >> 8] >> 16) & 0xff; sv = c.sp_v[pb]; sxf = c.sp_x[pb]; syf = c.sp_y[pb]; ssf = c.sp_s[pb]; }
         const double sx = (double)sxf, sy = (double)syf, ss = (double)ssf;
+        // forward: the start joint against the bone's list in its direction; reverse: the new joint against the other list
+        double qx = sx, qy = sy, qs = ss;
+        if (is_rev) { qx = (double)c.sp_x[bn]; qy = (double)c.sp_y[bn]; qs = (double)c.sp_s[bn]; }
+        const int li = bn * 2 + ((fwd != 0) != is_rev ? 0 : 1);
+        PH(21);
+        c.n_blend += nj;
+        const SpecOut o = spec_scan_batch(c, job, li, qx, qy, qs, filter_sigmas);
         int res = 0;
-        double nv = 0.0; float nx = 0.f, ny = 0.f, ns = 0.f;
-        bool need_rev = false;
-        for (int stage = 0; stage < 2; stage++) {           // cifcaf.cpp:349-411: forward scans of all jobs, then their reverse scans
-            const bool act = stage == 0 ? job : need_rev;
-            const unsigned long long am = __ballot(act);
-            if (am == 0ull) break;
-            c.n_blend += __popcll(am);
-            const int li = bn * 2 + ((stage == 0) == (fwd != 0) ? 0 : 1);
-            const SpecOut o = spec_scan_batch(c, act, li, stage == 0 ? sx : (double)nx, stage == 0 ? sy : (double)ny,
-                                              stage == 0 ? ss : (double)ns, filter_sigmas);
-            if (stage == 0) {
-                if (job) {
-                    if (o.ok < 0) res = kSbUnknown;
-                    else if (o.ok == 0) res = kSbRejected;                                  // :384
-                    else {
-                        nx = o.x; ny = o.y; ns = o.s;
-                        nv = sqrt(o.v * sv);                                                // :386
-                        if (nv < p.keypoint_threshold || nv < sv * p.keypoint_threshold_rel) res = kSbRejected;   // :387-390
-                        else if (p.reverse_match && reverse_match_ && a < c.F) need_rev = true;                  // :397
-                        else res = kSbOk;
-                    }
-                }
-            } else if (need_rev) {
-                if (o.ok < 0) res = kSbUnknown;
-                else if (o.ok == 0) res = kSbRejected;                                      // :400-403
-                else res = fabs(sx - (double)o.x) + fabs(sy - (double)o.y) > ss ? kSbRejected : kSbOk;   // :404
-            }
-        }
         if (job) {
+            if (o.ok < 0) res = kSbUnknown;
+            else if (o.ok == 0) res = kSbRejected;                                          // :384, :400-403
+            else if (is_rev) res = fabs(sx - (double)o.x) + fabs(sy - (double)o.y) > ss ? kSbRejected : kSbOk;   // :404
+            else {
+                const double nv = sqrt(o.v * sv);                                           // :386
+                if (nv < p.keypoint_threshold || nv < sv * p.keypoint_threshold_rel) res = kSbRejected;          // :387-390
+                else {
+                    res = p.reverse_match && reverse_match_ && a < c.F ? kSbPending : kSbOk;                     // :397
+                    c.sp_v[bn] = nv; c.sp_x[bn] = o.x; c.sp_y[bn] = o.y; c.sp_s[bn] = o.s;
+                }
+            }
             c.sp_b[bn] = res | (t << 8);
-            if (res == kSbOk) { c.sp_v[bn] = nv; c.sp_x[bn] = nx; c.sp_y[bn] = ny; c.sp_s[bn] = ns; }
         }
+        pending = __ballot(job && res == kSbPending) != 0ull || rev_left;
         wave_sync();
-        // the end joint of a connection that holds becomes a candidate, unless it is one already (first come)
-        if (job && res == kSbOk) atomicCAS(&c.sp_j[b], 0, kSpCand | kSpNext | (t << 8));
+        // the level is done (unless jobs were left over): the joints that became candidates in the round before are closed,
+        // the end joint of every new connection becomes a candidate -- unless it is one already (first come) -- and open
+        if (!fwd_left)
+            for (int k = lane; k < K; k += kWave) { const int w = c.sp_j[k]; if (w & kSpOpen) c.sp_j[k] = w & ~kSpOpen; }
         wave_sync();
+        if (job && !is_rev && (res == kSbOk || res == kSbPending)) atomicCAS(&c.sp_j[b], 0, kSpCand | kSpNext | kSpOpen | (t << 8));
+        wave_sync();
+        PH(28);
         if (c.pub) spec_publish<WR>(c, p);
+        for (int k = lane; k < K; k += kWave) { const int w = c.sp_j[k]; if (w & kSpNext) c.sp_j[k] = w & ~kSpNext; }
+        wave_sync();
+        PH(29);
         if (poll_task<WR>(c)) { c.aborted = 1; return; }
+        PH(30);
     }
 }
 
@@ -1733,7 +1791,7 @@ __device__ __forceinline__ bool occ_test(const ImageCtx& c, int f, int xi, int y
 // area (`tgt_floats`: kBlendLdsFloats, or kSmallTgtFloats when that buys more growers).  16-byte sized.
 constexpr int kSmallTgtChunks = 2;
 constexpr int kSmallTgtFloats = 3 * kSmallTgtChunks * kWave + 4 * kWave;
-constexpr int kSpecTgtFloats = kSpecItems + 2 * kWave + 4 * 192;   // the small scan area when the level walk runs: batches of up to 192 passing entries
+constexpr int kSpecTgtFloats = kSpecItems + 2 * kWave + kSpecEntryWords * 160;   // the small scan area when the level walk runs: batches of up to 160 passing entries
 __host__ __device__ inline size_t assoc_pose_bytes(int K) {
     return (16 * (size_t)K + sizeof(double) * K + sizeof(float) * 3 * K + 15) / 16 * 16;
 }
@@ -1770,7 +1828,7 @@ __device__ __forceinline__ void carve_private(ImageCtx& c, unsigned char* sp, in
     }
     c.sp_j = c.sp_b = nullptr; c.sp_v = nullptr; c.sp_x = c.sp_y = c.sp_s = nullptr; c.sp_match = c.sp_fromc = nullptr;
     c.sp_pcap = 0; c.n_hit = c.n_miss = 0;
-    if (spec) {
+    if (kWalk && spec) {
         unsigned char* s0 = sp;
         c.sp_v = (double*)sp; sp += sizeof(double) * A;
         c.sp_j = (int*)sp; sp += sizeof(int) * K;
@@ -2020,7 +2078,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
     c.pool_if = nullptr; c.pool_pack = nullptr; c.shadow_mine = nullptr; c.my_idx = 0;
     c.pool_ep = nullptr; c.epoch = nullptr; c.ack = nullptr; c.my_epoch = 0;
-    c.head_g = nullptr; c.prio = 0;
+    c.head_g = nullptr; c.prio = 0; c.early = 0;
     c.bbox = nullptr;
     c.nb = a.bbox_chunks;
     c.gbbox = a.list_bbox ? reinterpret_cast<const float4*>(a.list_bbox) + (size_t)b * 2 * a.A * a.bbox_chunks : nullptr;
@@ -2082,7 +2140,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     }
     if (tid < 12) sh_ctl[tid] = tid == 9 ? -1 : 0;   // (9: the grower holding the head seed)
     if (tid == 10) sh_ctl[10] = (int)(private_base - smem);        // 10, 11: for publish_joint's look at the other growers' boxes
-    if (tid == 11) sh_ctl[11] = (int)private_bytes | (S << 20) | ((a.collide ? 1 : 0) << 28);
+    if (tid == 11) sh_ctl[11] = (int)private_bytes | (S << 20) | ((a.collide ? 1 : 0) << 28) | ((a.early ? 1 : 0) << 29);
     if (tid < kAssocStats) sh_stats[tid] = 0;
 #ifdef OPA_ASSOC_PHASE_TIMING
     if (tid < kPhases) { g_ph[tid] = 0; g_phn[tid] = 0; }
@@ -2247,7 +2305,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             // ---- 1. commit the head while its growth is done (:213-230): every commit of a run costs the commit alone,
             //         not a round of the whole loop (a crowded image ends in dozens of poses of one or two joints)
             int hg = hd == kNone ? -1 : head_grower();
-            for (int run = 0; run < kCommitRun && hg >= 0 && flag_load(&task[hg].state) == kTaskDone; run++) {
+            for (int run = 0; run < a.commit_run && hg >= 0 && flag_load(&task[hg].state) == kTaskDone; run++) {
                 const long long t_cm = tick();
                 const PoseView q = pose_of_block(private_base, hg - 1, private_bytes, K);
                 unsigned dead = 0u;                      // pooled seeds inside one of its joint boxes (:211 for them)
@@ -2690,7 +2748,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             c.aborted = 0;
             c.pub = &my->npub; c.n_pub = 0; c.my_idx = mine;
             c.pool_if = pool_if; c.pool_pack = pool_pack; c.shadow_mine = shadow_by + wave * kWave;
-            c.pool_ep = pool_ep; c.epoch = &my->epoch; c.ack = &my->pad1; c.head_g = &sh_ctl[9];
+            c.pool_ep = pool_ep; c.epoch = &my->epoch; c.ack = &my->pad1; c.head_g = &sh_ctl[9]; c.early = a.early;
             c.my_epoch = flag_load(c.epoch);             // publish_joint tests the whole pool as of now; later refills: pool_catch_up
             if (lane == 0) flag_store(c.ack, c.my_epoch);
             publish_joint<WR>(c, p, sf, sd.y, sd.z, sd.w);   // the seed joint's own box: the rest of its blob
@@ -2775,7 +2833,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_fc_kernel(AssocArgs a, D
     c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
     c.pool_if = nullptr; c.pool_pack = nullptr; c.shadow_mine = nullptr; c.my_idx = 0;
     c.pool_ep = nullptr; c.epoch = nullptr; c.ack = nullptr; c.my_epoch = 0;
-    c.head_g = nullptr; c.prio = 0;
+    c.head_g = nullptr; c.prio = 0; c.early = 0;
     c.bbox = nullptr;
     c.nb = a.bbox_chunks;
     c.gbbox = a.list_bbox_fc ? reinterpret_cast<const float4*>(a.list_bbox_fc) + (size_t)b * E * a.bbox_chunks : nullptr;
@@ -2939,8 +2997,12 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     a.inherit = 1;
     a.collide = 1;
     a.timing = 0;
-    a.spec = 1;
-    if (const char* e = getenv("OPA_ASSOC_SPEC")) a.spec = atoi(e) != 0;           // A/B and tests: every bone scanned on demand, one at a time
+    a.early = 0;                                                                    // (round 5: COCO 558 -> 562 us, wholebody 3.12 -> 3.30 ms: more predictions, more of them wrong)
+    if (const char* e = getenv("OPA_ASSOC_EARLY")) a.early = atoi(e) != 0;         // A/B: boxes are published when a joint is assigned only
+    a.commit_run = kCommitRun;
+    if (const char* e = getenv("OPA_ASSOC_COMMIT_RUN")) { const int v = atoi(e); if (v >= 1 && v <= 64) a.commit_run = v; }
+    a.spec = kWalk ? 1 : 0;
+    if (const char* e = getenv("OPA_ASSOC_SPEC")) a.spec = kWalk && atoi(e) != 0;  // (walk builds) A/B: every bone scanned on demand, one at a time
     if (const char* e = getenv("OPA_ASSOC_TIMING")) a.timing = atoi(e) != 0;      // phase tick counters of the coordinator (statistics slots 12, 17-20)
     if (const char* e = getenv("OPA_ASSOC_COLLIDE")) a.collide = atoi(e) != 0;     // A/B: growths stop only when their SEED is covered
     if (const char* e = getenv("OPA_ASSOC_INHERIT")) a.inherit = atoi(e) != 0;     // A/B: predictions lapse with the growth that made them

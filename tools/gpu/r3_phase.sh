@@ -6,9 +6,9 @@ for cfg in "${@:-wholebody}"; do
   echo "=== $cfg"
   OPA_LIB_PATH=$PWD/openpifpaf_amd/lib/libopenpifpaf_amd_ph.so timeout 300 python tools/gpu/r3_probe.py --config $cfg --reps 2 2>&1 | grep -v amdgpu.ids > gpurun_out/phase_raw.log
   grep -v PHASE gpurun_out/phase_raw.log | grep -v "^ \|^img\|status" | head -6
-  grep -a "PHASE img" gpurun_out/phase_raw.log | tail -40 | python -c "
+  grep -a "PHASE img" gpurun_out/phase_raw.log | tail -64 | python -c "
 import sys, re
-names={0:'pop+entry reads',1:'query+issue loads',2:'wait loads',3:'window test/compact',4:'score (exp)',5:'top-2 reductions',6:'blend finish',7:'connection rest',8:'re-push',9:'assign',10:'publish box',11:'frontier_add_from',12:'task setup+seed publish',13:'(grow end)',14:'pose boxes+score',15:'idle/wait task',16:'(stamp cost)',17:'to scan start'}
+names={0:'pop+entry reads',1:'query+issue loads',2:'wait loads',3:'window test/compact',4:'score (exp)',5:'top-2 reductions',6:'blend finish',7:'connection rest',8:'re-push',9:'assign',10:'publish box',11:'frontier_add_from',12:'task setup+seed publish',13:'(grow end)',14:'pose boxes+score',15:'idle/wait task',16:'(stamp cost)',17:'to scan start',20:'walk: gather jobs',21:'walk: start values',22:'batch: query+chunk boxes',23:'batch: items',24:'batch: loads+window+compact',25:'batch: scores (exp)',26:'batch: top-2',27:'batch: targets+finish',28:'walk: results+candidates',29:'walk: publish',30:'walk: poll'}
 rows={}
 for ln in sys.stdin:
     m=re.search(r'PHASE img (\\d+) k (\\d+) cycles (\\d+) n (\\d+)', ln)
