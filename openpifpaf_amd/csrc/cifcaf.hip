@@ -155,7 +155,10 @@ struct ImageCtx {
     double* sp_v; float *sp_x, *sp_y, *sp_s;
     unsigned char *sp_match, *sp_fromc;  // LDS variant of the growth state: joint assigned with its candidate's values [K]; entry of the bone came from the cache [A]
     int sp_pcap;                         // passing entries the scan area holds during a batch
-    int early;                           // publish a joint's box when its connection is evaluated, not only when it is assigned (advisory)
+    // scan helpers (help_*): requests of this growth [kHelpRing], a word per bone [A], the slot each joint was assigned through [K],
+    // control words (0 epoch, 1 closed, 2-3 mask of assigned joints for the register variant); null: off
+    int *hq, *rq, *jsrc, *hctl;
+    int hq_n, h_epoch;                   // requests posted so far, this growth's epoch
     int n_hit, n_miss;                   // statistics: connection values taken from the cache / evaluated on demand
 };
 
@@ -784,6 +787,28 @@ constexpr bool kWalk = true;
 #else
 constexpr bool kWalk = false;
 #endif
+// ---- scan helpers.  _connection_value (cifcaf.cpp:349-411) of a bone depends on its start joint alone, so it can be computed
+// by ANOTHER wave as soon as that joint's values are known -- i.e. as soon as the connection that leads to the joint has
+// been evaluated, usually long before the search assigns the joint and pops the bone.  The grower posts "joint b, reached
+// through slot u, has these values" (help_post); idle growers look at the requests of the growth that holds the HEAD seed --
+// the one the commit waits for -- claim the bones leaving b one at a time (a word per bone, compare-and-swap) and leave
+// the connection value in the master's entry array; the master's heap loop, unchanged, takes it from there when it pops
+// the bone, provided b was indeed assigned through u (then the values are the ones _connection_value would compute, bit
+// for bit: same code, same inputs); anything else it evaluates itself, as before.  The head's growth becomes a chain of
+// heap operations with the list scans done beside it.
+// Compiled in only with -DOPA_ASSOC_HELPERS: measured in round 5 (profiles/r5/rejected_scan_helpers.log) it is exact (153 GPU
+// tests) and changes nothing -- while the head's pose grows, the other growers are busy with growths of their own (the idle
+// half of the growers' time lies in the tail of one- and two-joint poses), and the second copy of the scan code costs the
+// 12-wave kernel 18 spilled registers (COCO 597 -> 625 us with it on, 558 without it in the build).
+#ifdef OPA_ASSOC_HELPERS
+constexpr bool kHelp = true;
+#else
+constexpr bool kHelp = false;
+#endif
+constexpr int kHelpRing = 16;
+constexpr int kRqFree = 0, kRqTaken = 1, kRqOk = 2, kRqRej = 3, kRqMaster = 4;   // word of a bone: state | slot << 3 | source slot << 12 | epoch << 21
+constexpr int kSrcStart = 511;           // "source slot" of a joint the pose started with
+__device__ __forceinline__ int rq_word(int state, int slot, int src, int ep) { return state | (slot << 3) | (src << 12) | (ep << 21); }
 // memo words of the level walk
 constexpr int kSpActual = 1, kSpCand = 2, kSpKind = 3, kSpOpen = 4, kSpNext = 8;     // per joint: kind, "its bones are this level's jobs", "became a candidate in this level"
 constexpr int kSbOk = 1, kSbRejected = 2, kSbUnknown = 3, kSbPending = 4;            // per bone: connection holds / _connection_value returns the zero joint / not evaluated here / forward scan done, reverse scan outstanding
@@ -1031,14 +1056,14 @@ __device__ __forceinline__ int heap_pop(ImageCtx& c) {          // returns the t
 // in_frontier flags suffice (round 2 appended entries to a pool of 4A and searched the adjacency for the slot at
 // every evaluation).  A heap node carries the directed slot (start, end, list), the entry is found through its bone.
 
-// cifcaf.cpp:349-411 for the directed bone `info` (its first slot: the bone _connection_value's scan finds, :361-374)
+// cifcaf.cpp:349-411 for the directed bone `info` (its first slot: the bone _connection_value's scan finds, :361-374) leaving a
+// joint with the values (sv, sx, sy, ss) -- the growing wave's own joint, or (scan helpers) a joint of another wave's growth
 template <bool LONG>
-__device__ __forceinline__ bool connection_value(ImageCtx& c, const DevParams& p, int info,
-                                 bool reverse_match_, double filter_sigmas,
-                                 double* nv, float* nx, float* ny, float* ns) {
+__device__ __forceinline__ bool connection_value_at(ImageCtx& c, const DevParams& p, int info, double sv, double sx, double sy, double ss,
+                                                    bool reverse_match_, double filter_sigmas,
+                                                    double* nv, float* nx, float* ny, float* ns) {
     const int start = info & 0xff, bone = (info >> 16) & 0xff, fwd = (info >> 24) & 1;
     const ListView caf_f = list_view(c, bone, fwd ? 0 : 1);
-    const double sv = c.jv[start], sx = (double)c.jx[start], sy = (double)c.jy[start], ss = (double)c.js[start];
     const BlendResult nj = blend<LONG>(c, caf_f, sx, sy, ss, filter_sigmas);
     if (!nj.ok) return false;
     *nx = nj.x; *ny = nj.y; *ns = nj.s;
@@ -1051,6 +1076,70 @@ __device__ __forceinline__ bool connection_value(ImageCtx& c, const DevParams& p
         if (fabs(sx - (double)rj.x) + fabs(sy - (double)rj.y) > ss) return false;   // :404
     }
     return true;
+}
+template <bool LONG>
+__device__ __forceinline__ bool connection_value(ImageCtx& c, const DevParams& p, int info,
+                                 bool reverse_match_, double filter_sigmas,
+                                 double* nv, float* nx, float* ny, float* ns) {
+    const int start = info & 0xff;
+    return connection_value_at<LONG>(c, p, info, c.jv[start], (double)c.jx[start], (double)c.jy[start], (double)c.js[start],
+                                     reverse_match_, filter_sigmas, nv, nx, ny, ns);
+}
+
+// ---- scan helpers, the growing wave's side
+// "joint b, reached through slot u (kSrcStart: filled from the start), has its values": the bones leaving it can be evaluated
+__device__ __forceinline__ void help_post(ImageCtx& c, int b, int u) {
+    if (lane_id() == 0) flag_store(&c.hq[c.hq_n & (kHelpRing - 1)], 1 | (b << 1) | (u << 10) | (c.h_epoch << 19));
+    c.hq_n++;
+}
+// a growth begins: new epoch (words of the last growth mean nothing any more), every bone free, the block open for helpers
+__device__ __forceinline__ void help_begin(ImageCtx& c) {
+    const int lane = lane_id();
+    c.h_epoch = (c.h_epoch + 1) & 0x3ff;
+    for (int a = lane; a < c.A; a += kWave) c.rq[a] = rq_word(kRqFree, 0, 0, c.h_epoch);
+    if (lane < kHelpRing) c.hq[lane] = 0;
+    unsigned long long filled0 = 0ull;
+    for (int k0 = 0; k0 < c.K; k0 += kWave) {
+        const int k = k0 + lane;
+        const bool f = k < c.K && c.jv[k < c.K ? k : 0] != 0.0;
+        if (k < c.K) c.jsrc[k] = f ? kSrcStart : -1;
+        if (k0 == 0) filled0 = __ballot(f);
+    }
+    if (lane == 0) { c.hctl[0] = c.h_epoch; c.hctl[2] = (int)(unsigned)filled0; c.hctl[3] = (int)(unsigned)(filled0 >> 32); }
+    c.hq_n = 0;
+    wave_sync();
+    if (lane == 0) flag_store(&c.hctl[1], 0);
+    for (int k0 = 0; k0 < c.K; k0 += kWave) {
+        unsigned long long filled = __ballot(k0 + lane < c.K && c.jsrc[k0 + lane < c.K ? k0 + lane : 0] == kSrcStart);
+        while (filled) { const int j = k0 + __builtin_ctzll(filled); filled &= filled - 1; help_post(c, j, kSrcStart); }
+    }
+}
+// the growth is over (finished or stopped): no new claims, and nobody writes into this block once this returns
+__device__ __forceinline__ void help_end(ImageCtx& c) {
+    const int lane = lane_id();
+    if (lane == 0) flag_store(&c.hctl[1], 1);
+    for (int spin = 0; spin < (1 << 20); spin++) {
+        bool taken = false;
+        for (int a = lane; a < c.A; a += kWave) taken |= (flag_load(&c.rq[a]) & 7) == kRqTaken;
+        if (__ballot(taken) == 0ull) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// The search pops bone `bn` (slot `slot`) for the first time; its start joint was assigned through slot `src`.
+// 1: a helper left the connection value in the entry array, 2: a helper found that the connection does not hold,
+// 0: the wave evaluates it itself (the word is claimed: no helper will write the entry)
+__device__ __forceinline__ int help_claim(ImageCtx& c, int bn, int slot, int src) {
+    for (int spin = 0; spin < (1 << 20); spin++) {
+        const int w = __builtin_amdgcn_readfirstlane(flag_load(&c.rq[bn]));
+        const int st = w & 7;
+        if (st == kRqTaken) { __builtin_amdgcn_s_sleep(1); continue; }        // a helper is at it (3-4 us at most)
+        if ((st == kRqOk || st == kRqRej) && w == rq_word(st, slot, src, c.h_epoch)) return st == kRqOk ? 1 : 2;
+        int old = w;
+        if (lane_id() == 0) old = atomicCAS(&c.rq[bn], w, rq_word(kRqMaster, slot, src & 0x1ff, c.h_epoch));
+        old = __builtin_amdgcn_readfirstlane(old);
+        if (old == w) return 0;                                              // (else a helper was faster: look again)
+    }
+    return 0;
 }
 
 // cifcaf.cpp:316-346: the bones leaving `start` whose other end is still empty and that are not in the frontier yet
@@ -1075,9 +1164,8 @@ __device__ __forceinline__ void frontier_add_from(ImageCtx& c, int start) {
             const int l = __builtin_ctzll(m);
             m &= m - 1;
             const int bn = __builtin_amdgcn_readlane(bone, l);
-            c.e_v[bn] = 0.0;
             heap_push(c, max_score, base + l);
-            c.in_frontier[bn] = 1;
+            c.in_frontier[bn] = 1;                                       // (bit 1: its entry has been computed)
         }
     }
 }
@@ -1107,23 +1195,32 @@ __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool rever
         for (int a = lane_id(); a < c.A; a += kWave) c.sp_fromc[a] = 0;
         wave_sync();
     }
+    const bool help = kHelp && c.hq != nullptr;
+    if (help) help_begin(c);
     frontier_start(c);
     while (c.heap_n > 0) {
-        if (poll_task<kPoolSlotsLds>(c)) { c.aborted = 1; return; }                     // the seed died while its pose grew
+        if (poll_task<kPoolSlotsLds>(c)) { c.aborted = 1; break; }                      // the seed died while its pose grew
         const int slot = heap_pop(c);
         const int info = c.slot_info[slot];
         const int start = info & 0xff, end = (info >> 8) & 0xff, bn = (info >> 16) & 0xff;
         if (c.jv[end] > 0.0) { PH(0); continue; }                        // :284
-        double v = c.e_v[bn]; float x = c.e_x[bn], y = c.e_y[bn], s = c.e_s[bn];
+        double v = 0.0; float x = 0.f, y = 0.f, s = 0.f;
+        const bool computed = (c.in_frontier[bn] & 2) != 0;
+        if (computed) { v = c.e_v[bn]; x = c.e_x[bn]; y = c.e_y[bn]; s = c.e_s[bn]; }
         PH(0);
-        if (v == 0.0) {                                                  // :287: not computed yet
-            // the memo holds this bone's connection value if it was computed from the very joint the search assigned
+        if (!computed) {                                                 // :287: not computed yet
+            // a helper may have evaluated the connection already (from the very joint the search assigned: then it is
+            // what _connection_value returns); the level walk's memo likewise (walk builds)
             int memo = 0;
+            const int got = help ? help_claim(c, bn, slot, c.jsrc[start]) : 0;
+            if (got == 2) { PH(7); continue; }                           // :290-296
             if (kWalk && c.sp_j && c.sp_match[start]) {
                 const int w = c.sp_b[bn];
                 if (((w & 0xff) == kSbOk || (w & 0xff) == kSbRejected) && (w >> 8) == slot) memo = w & 0xff;
             }
-            if (memo) {
+            if (got == 1) {
+                v = c.e_v[bn]; x = c.e_x[bn]; y = c.e_y[bn]; s = c.e_s[bn];
+            } else if (memo) {
                 if (kWalk) c.n_hit++;
                 if (memo == kSbRejected) { PH(7); continue; }            // :290-296
                 v = c.sp_v[bn]; x = c.sp_x[bn]; y = c.sp_y[bn]; s = c.sp_s[bn];
@@ -1138,14 +1235,16 @@ __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool rever
             }
             PH(7);
             if (!p.greedy) {                                             // :298-303
-                c.e_v[bn] = v; c.e_x[bn] = x; c.e_y[bn] = y; c.e_s[bn] = s;
-                if (c.early) publish_joint<kPoolSlotsLds>(c, p, end, x, y, s);   // where the joint will be if this connection wins: a prediction
+                if (got != 1) { c.e_v[bn] = v; c.e_x[bn] = x; c.e_y[bn] = y; c.e_s[bn] = s; }
+                c.in_frontier[bn] = 3;
+                if (help) { wave_sync(); help_post(c, end, slot); }      // the joint this connection leads to: its bones can be evaluated
                 heap_push(c, (float)v, slot);
                 PH(8);
                 continue;
             }
         }
         c.jv[end] = v; c.jx[end] = x; c.jy[end] = y; c.js[end] = s;     // :310
+        if (help) c.jsrc[end] = slot;
         PH(9);
         // assigned exactly the candidate the level walk gave this joint (same bone, entry from the memo): its box is
         // published already, and the memo of its bones holds
@@ -1157,6 +1256,7 @@ __device__ __forceinline__ void grow(ImageCtx& c, const DevParams& p, bool rever
         frontier_add_from(c, end);
         PH(11);
     }
+    if (help) help_end(c);
 }
 
 // cifcaf.cpp:429-449
@@ -1348,11 +1448,14 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
         if (c.aborted) return;
         sp_match = __ballot(lane_id() < c.K && (c.sp_j[lane_id() < c.K ? lane_id() : 0] & kSpKind) == kSpActual);
     }
+    const bool help = kHelp && c.hq != nullptr;
+    if (help) help_begin(c);
+    unsigned long long amask = help ? ((unsigned long long)(unsigned)c.hctl[3] << 32) | (unsigned)c.hctl[2] : 0ull;   // joints assigned so far (for the helpers)
     RegState R;
     reg_load_pose(c, R);
     reg_frontier_start(R, sk, c.K);
     while (R.heap_n > 0) {
-        if (poll_task<kPoolSlots>(c)) { c.aborted = 1; return; }                         // the seed died while its pose grew
+        if (poll_task<kPoolSlots>(c)) { c.aborted = 1; if (help) help_end(c); return; }   // the seed died while its pose grew
         const int slot = reg_heap_pop(R);
         const int info = rlane(sk.slot_info, slot);
         const int start = info & 0xff, end = (info >> 8) & 0xff;
@@ -1361,31 +1464,40 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
         float x, y, s;
         PH(0);
         if (v == 0.0) {                                                      // :287: not computed yet
-            // the memo holds this bone's connection value if it was computed from the very joint the search assigned
+            // a helper may have evaluated the connection already (from the very joint the search assigned: then it is
+            // what _connection_value returns); the level walk's memo likewise (walk builds)
             int memo = 0;
             const int bn = (info >> 16) & 0xff;
+            const int got = help ? help_claim(c, bn, slot, __builtin_amdgcn_readfirstlane(c.jsrc[start])) : 0;
+            if (got == 2) { PH(7); continue; }                               // :290-296
             if (kWalk && c.sp_j && ((sp_match >> start) & 1ull)) {
                 const int w = __builtin_amdgcn_readfirstlane(c.sp_b[bn]);
                 if (((w & 0xff) == kSbOk || (w & 0xff) == kSbRejected) && (w >> 8) == slot) memo = w & 0xff;
             }
-            if (memo) {
+            if (got == 1) {
+                v = uniform_f64(c.e_v[bn]); x = uniform_f32(c.e_x[bn]); y = uniform_f32(c.e_y[bn]); s = uniform_f32(c.e_s[bn]);
+            } else if (memo) {
                 if (kWalk) c.n_hit++;
                 if (memo == kSbRejected) { PH(7); continue; }                // :290-296
                 v = uniform_f64(c.sp_v[bn]); x = uniform_f32(c.sp_x[bn]); y = uniform_f32(c.sp_y[bn]); s = uniform_f32(c.sp_s[bn]);
-                sp_fromc |= 1ull << slot;
+                if (kWalk) sp_fromc |= 1ull << slot;
             } else {
                 if (kWalk) c.n_miss++;
                 if (!reg_connection_value<LONG>(c, p, R, start, info, reverse_match_, filter_sigmas, &v, &x, &y, &s)) {
                     PH(7);
                     continue;                                                // :290-296 (block_joints is a no-op)
                 }
-                sp_fromc &= ~(1ull << slot);
+                if (kWalk) sp_fromc &= ~(1ull << slot);
             }
             PH(7);
             if (!p.greedy) {                                                 // :298-303
                 wlane(R.ev_lo, __double2loint(v), slot); wlane(R.ev_hi, __double2hiint(v), slot);
                 wlanef(R.ex, x, slot); wlanef(R.ey, y, slot); wlanef(R.es, s, slot);
-                if (c.early) publish_joint<kPoolSlots>(c, p, end, x, y, s);      // where the joint will be if this connection wins: a prediction
+                if (help) {                                                  // the joint this connection leads to: its bones can be evaluated
+                    if (got != 1 && lane_id() == 0) { c.e_v[bn] = v; c.e_x[bn] = x; c.e_y[bn] = y; c.e_s[bn] = s; }
+                    wave_sync();
+                    help_post(c, end, slot);
+                }
                 reg_heap_push(R, (float)v, slot);
                 PH(8);
                 continue;
@@ -1394,6 +1506,10 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
             x = rlanef(R.ex, slot); y = rlanef(R.ey, slot); s = rlanef(R.es, slot);
         }
         reg_set_joint(R, end, v, x, y, s);                                   // :310
+        if (help) {
+            amask |= 1ull << end;
+            if (lane_id() == 0) { c.jsrc[end] = slot; c.hctl[2] = (int)(unsigned)amask; c.hctl[3] = (int)(unsigned)(amask >> 32); }
+        }
         PH(9);
         // assigned exactly the candidate the level walk gave this joint (same bone, entry from the memo): its box is
         // published already, and the memo of its bones holds
@@ -1402,12 +1518,13 @@ __device__ __forceinline__ void grow_reg(ImageCtx& c, const DevParams& p, const 
             const int w = __builtin_amdgcn_readfirstlane(c.sp_j[end]);
             matched = (w & kSpKind) == kSpCand && (w >> 8) == slot;
         }
-        if (matched) sp_match |= 1ull << end;
+        if (kWalk && matched) sp_match |= 1ull << end;
         else publish_joint<kPoolSlots>(c, p, end, x, y, s);
         PH(10);
         reg_frontier_add_from(R, sk, end);
         PH(11);
     }
+    if (help) help_end(c);
     if (then_flood_fill) {                                                   // cifcaf.cpp:429-449
         reg_frontier_start(R, sk, c.K);
         while (R.heap_n > 0) {
@@ -1482,10 +1599,6 @@ template <int WR>
 __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s) {
     if (!c.pub || k >= c.F) return;
     const OccBox b = occ_box(c, p, (double)x, (double)y, (double)s);
-    if (c.early) {                                   // the box this growth published when it evaluated the connection: nothing new to say
-        const OccBox o = c.jbox[k];
-        if (o.minx == b.minx && o.miny == b.miny && o.maxx == b.maxx && o.maxy == b.maxy) return;
-    }
     const int lane = lane_id();
     // every pooled seed of this field that comes later in seed order and lies in the box is shadowed: it dies
     // if this pose is accepted.  Advisory only (the commit re-tests every seed against the final boxes).
@@ -1799,15 +1912,21 @@ __host__ __device__ inline size_t assoc_pose_bytes(int K) {
 __host__ __device__ inline size_t assoc_spec_bytes(int K, int A, bool reg) {
     return (sizeof(double) * A + sizeof(int) * (K + A) + sizeof(float) * 3 * A + (reg ? 0 : K + A) + 15) / 16 * 16;
 }
-__host__ __device__ inline size_t assoc_private_bytes(int K, int A, bool reg, int tgt_floats, bool spec = false) {
+// the scan helpers' words (requests, a word per bone, the slot each joint was assigned through, control words); the
+// register variant also keeps an LDS copy of its computed entries here (what the helpers read and write)
+__host__ __device__ inline size_t assoc_help_bytes(int K, int A, bool reg) {
+    return (sizeof(int) * (kHelpRing + A + K + 4) + (reg ? (sizeof(double) + 3 * sizeof(float)) * A + 8 : 0) + 15) / 16 * 16;
+}
+__host__ __device__ inline size_t assoc_private_bytes(int K, int A, bool reg, int tgt_floats, bool spec = false, bool help = false) {
     size_t b = assoc_pose_bytes(K);
     if (!reg) b += sizeof(double) * A + sizeof(unsigned long long) * A + sizeof(float) * 3 * A + (A + 15) / 16 * 16 + (A & 1 ? 4 : 0);
     b = (b + 15) / 16 * 16;
     if (spec) b += assoc_spec_bytes(K, A, reg);
+    if (help) b += assoc_help_bytes(K, A, reg);
     return b + sizeof(float) * tgt_floats;
 }
 template <bool REG>
-__device__ __forceinline__ void carve_private(ImageCtx& c, unsigned char* sp, int tgt_floats, bool spec = false) {
+__device__ __forceinline__ void carve_private(ImageCtx& c, unsigned char* sp, int tgt_floats, bool spec = false, bool help = false) {
     const int K = c.K, A = c.A;
     unsigned char* base = sp;
     c.jbox = (OccBox*)sp; sp += sizeof(OccBox) * K;
@@ -1840,9 +1959,84 @@ __device__ __forceinline__ void carve_private(ImageCtx& c, unsigned char* sp, in
         sp = s0 + assoc_spec_bytes(K, A, REG);
         c.sp_pcap = spec_pcap(tgt_floats);
     }
+    c.hq = c.rq = c.jsrc = c.hctl = nullptr;
+    if (kHelp && help) {
+        unsigned char* s0 = sp;
+        if constexpr (REG) {                                 // (the LDS variant's entry arrays are the ones above)
+            c.e_v = (double*)sp; sp += sizeof(double) * A + (A & 1 ? 8 : 0);
+            c.e_x = (float*)sp; sp += sizeof(float) * A;
+            c.e_y = (float*)sp; sp += sizeof(float) * A;
+            c.e_s = (float*)sp; sp += sizeof(float) * A;
+        }
+        c.hq = (int*)sp; sp += sizeof(int) * kHelpRing;
+        c.rq = (int*)sp; sp += sizeof(int) * A;
+        c.jsrc = (int*)sp; sp += sizeof(int) * K;
+        c.hctl = (int*)sp; sp += sizeof(int) * 4;
+        sp = s0 + assoc_help_bytes(K, A, REG);
+    }
     c.tgt = (float*)sp;
     c.max_r = tgt_floats >= kBlendLdsFloats ? kBlendChunks : kSmallTgtChunks;
     c.heap_n = 0;
+}
+
+// ---- scan helpers, the helping wave's side: ONE connection of the growth in block `mblock` (the one that holds the head
+// seed), if any is waiting.  The bones leaving a posted joint are claimed one at a time (compare-and-swap on the bone's
+// word), evaluated with this wave's own scan area, and left in the master's entry array.
+template <bool REG>
+__device__ __forceinline__ void help_once(ImageCtx& c, const DevParams& p, unsigned char* mblock, int tgt_floats, bool spec) {
+    ImageCtx m;
+    m.K = c.K; m.A = c.A;
+    carve_private<REG>(m, mblock, tgt_floats, spec, true);
+    const int lane = lane_id();
+    if (flag_load(&m.hctl[1])) return;                       // not growing
+    const int ep = flag_load(&m.hctl[0]);
+    const int free_w = rq_word(kRqFree, 0, 0, ep);
+    const int hw = lane < kHelpRing ? flag_peek(&m.hq[lane]) : 0;
+    unsigned long long vm = __ballot(hw != 0 && ((hw >> 19) & 0x3ff) == ep);
+    while (vm) {
+        const int i = __builtin_ctzll(vm); vm &= vm - 1;
+        const int w = rlane_i(hw, i);
+        const int b = (w >> 1) & 0x1ff, u = (w >> 10) & 0x1ff;
+        const int parent = u == kSrcStart ? -1 : (c.slot_info[u] & 0xff);
+        const int t1 = c.adj_off[b + 1];
+        for (int t0 = c.adj_off[b]; t0 < t1; t0 += kWave) {
+            const int t = t0 + lane;
+            bool cand = false; int bn = 0;
+            if (t < t1) {
+                const int info = c.slot_info[t];
+                const int other = (info >> 8) & 0xff; bn = (info >> 16) & 0xff;
+                bool assigned;
+                if constexpr (REG) assigned = (((((unsigned long long)(unsigned)m.hctl[3]) << 32) | (unsigned)m.hctl[2]) >> other) & 1ull;
+                else assigned = m.jv[other] > 0.0;
+                cand = c.adj_first[t] == t && other != parent && !assigned && flag_peek(&m.rq[bn]) == free_w;
+            }
+            unsigned long long cm = __ballot(cand);
+            while (cm) {
+                const int l = __builtin_ctzll(cm); cm &= cm - 1;
+                const int ts = t0 + l, bs = rlane_i(bn, l);
+                const int mine = rq_word(kRqTaken, ts, u, ep);
+                int old = 0;
+                if (lane == 0) old = atomicCAS(&m.rq[bs], free_w, mine);
+                if (__builtin_amdgcn_readfirstlane(old) != free_w) continue;   // somebody else has it
+                // the block closed, or went on to its next growth, in between: hand the bone back untouched
+                if (flag_load(&m.hctl[1]) || flag_load(&m.hctl[0]) != ep) {
+                    if (lane == 0) atomicCAS(&m.rq[bs], mine, free_w);
+                    return;
+                }
+                double sv; float sx, sy, ss;
+                if (u == kSrcStart) { sv = m.jv[b]; sx = m.jx[b]; sy = m.jy[b]; ss = m.js[b]; }
+                else { const int bu = (c.slot_info[u] >> 16) & 0xff; sv = m.e_v[bu]; sx = m.e_x[bu]; sy = m.e_y[bu]; ss = m.e_s[bu]; }
+                double nv = 0.0; float nx = 0.f, ny = 0.f, ns = 0.f;
+                const bool ok = connection_value_at<false>(c, p, c.slot_info[ts], sv, (double)sx, (double)sy, (double)ss, true, 1.0,
+                                                           &nv, &nx, &ny, &ns);
+                if (ok && lane == 0) { m.e_v[bs] = nv; m.e_x[bs] = nx; m.e_y[bs] = ny; m.e_s[bs] = ns; }
+                wave_sync();
+                if (lane == 0) flag_store(&m.rq[bs], rq_word(ok ? kRqOk : kRqRej, ts, u, ep));
+                return;                                      // one connection at a time: back to the own task slot
+            }
+        }
+        if (lane == 0) atomicCAS(&m.hq[i], w, 0);            // nothing left of this request
+    }
 }
 
 // LDS scratch of one wave during keypoint NMS (aliases the growth state): a box and a cell per pose
@@ -2078,7 +2272,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
     c.pool_if = nullptr; c.pool_pack = nullptr; c.shadow_mine = nullptr; c.my_idx = 0;
     c.pool_ep = nullptr; c.epoch = nullptr; c.ack = nullptr; c.my_epoch = 0;
-    c.head_g = nullptr; c.prio = 0; c.early = 0;
+    c.head_g = nullptr; c.prio = 0;
     c.bbox = nullptr;
     c.nb = a.bbox_chunks;
     c.gbbox = a.list_bbox ? reinterpret_cast<const float4*>(a.list_bbox) + (size_t)b * 2 * a.A * a.bbox_chunks : nullptr;
@@ -2106,8 +2300,11 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     if (use_bbox) sp += sizeof(float4) * E * kListBboxChunks;
     unsigned char* work_base = sp;                   // growth phase: private blocks; NMS phase: its arrays and scratch
     unsigned char* private_base = sp;
-    const size_t private_bytes = assoc_private_bytes(K, A, REG, tgt_floats, a.spec != 0);
-    carve_private<REG>(c, private_base + (size_t)(wave >= 1 && wave <= S ? wave - 1 : 0) * private_bytes, tgt_floats, a.spec != 0);   // other waves never touch theirs
+    const bool help_on = kHelp && a.help != 0;
+    const size_t private_bytes = assoc_private_bytes(K, A, REG, tgt_floats, a.spec != 0, help_on);
+    carve_private<REG>(c, private_base + (size_t)(wave >= 1 && wave <= S ? wave - 1 : 0) * private_bytes, tgt_floats, a.spec != 0, help_on);   // other waves never touch theirs
+    c.hq_n = 0; c.h_epoch = 0;
+    if (help_on && wave >= 1 && wave <= S && lane == 0) { c.hctl[0] = 0; c.hctl[1] = 1; }     // (no growth yet: closed to helpers)
 
     // the image's occupancy bitmap starts empty (cifcaf.cpp:173); 16-byte stores, region is 256-B aligned
     {
@@ -2140,7 +2337,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     }
     if (tid < 12) sh_ctl[tid] = tid == 9 ? -1 : 0;   // (9: the grower holding the head seed)
     if (tid == 10) sh_ctl[10] = (int)(private_base - smem);        // 10, 11: for publish_joint's look at the other growers' boxes
-    if (tid == 11) sh_ctl[11] = (int)private_bytes | (S << 20) | ((a.collide ? 1 : 0) << 28) | ((a.early ? 1 : 0) << 29);
+    if (tid == 11) sh_ctl[11] = (int)private_bytes | (S << 20) | ((a.collide ? 1 : 0) << 28);
     if (tid < kAssocStats) sh_stats[tid] = 0;
 #ifdef OPA_ASSOC_PHASE_TIMING
     if (tid < kPhases) { g_ph[tid] = 0; g_phn[tid] = 0; }
@@ -2305,7 +2502,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             // ---- 1. commit the head while its growth is done (:213-230): every commit of a run costs the commit alone,
             //         not a round of the whole loop (a crowded image ends in dozens of poses of one or two joints)
             int hg = hd == kNone ? -1 : head_grower();
-            for (int run = 0; run < a.commit_run && hg >= 0 && flag_load(&task[hg].state) == kTaskDone; run++) {
+            for (int run = 0; run < kCommitRun && hg >= 0 && flag_load(&task[hg].state) == kTaskDone; run++) {
                 const long long t_cm = tick();
                 const PoseView q = pose_of_block(private_base, hg - 1, private_bytes, K);
                 unsigned dead = 0u;                      // pooled seeds inside one of its joint boxes (:211 for them)
@@ -2729,6 +2926,13 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     continue;
                 }
                 if (flag_load(&sh_ctl[0]) || wall_clock64() - t_kernel > 2 * kWatchdogTicks) { leave = true; break; }
+                if (help_on) {                           // nothing of its own to do: a connection of the growth the commit waits for
+                    const int hgw = flag_peek(&sh_ctl[9]);
+                    if (hgw >= 1 && hgw <= S && hgw != wave) {
+                        help_once<REG>(c, p, private_base + (size_t)(hgw - 1) * private_bytes, tgt_floats, a.spec != 0);
+                        continue;
+                    }
+                }
                 __builtin_amdgcn_s_sleep(2);
             }
             if (leave) break;
@@ -2748,7 +2952,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             c.aborted = 0;
             c.pub = &my->npub; c.n_pub = 0; c.my_idx = mine;
             c.pool_if = pool_if; c.pool_pack = pool_pack; c.shadow_mine = shadow_by + wave * kWave;
-            c.pool_ep = pool_ep; c.epoch = &my->epoch; c.ack = &my->pad1; c.head_g = &sh_ctl[9]; c.early = a.early;
+            c.pool_ep = pool_ep; c.epoch = &my->epoch; c.ack = &my->pad1; c.head_g = &sh_ctl[9];
             c.my_epoch = flag_load(c.epoch);             // publish_joint tests the whole pool as of now; later refills: pool_catch_up
             if (lane == 0) flag_store(c.ack, c.my_epoch);
             publish_joint<WR>(c, p, sf, sd.y, sd.z, sd.w);   // the seed joint's own box: the rest of its blob
@@ -2833,7 +3037,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_fc_kernel(AssocArgs a, D
     c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
     c.pool_if = nullptr; c.pool_pack = nullptr; c.shadow_mine = nullptr; c.my_idx = 0;
     c.pool_ep = nullptr; c.epoch = nullptr; c.ack = nullptr; c.my_epoch = 0;
-    c.head_g = nullptr; c.prio = 0; c.early = 0;
+    c.head_g = nullptr; c.prio = 0;
     c.bbox = nullptr;
     c.nb = a.bbox_chunks;
     c.gbbox = a.list_bbox_fc ? reinterpret_cast<const float4*>(a.list_bbox_fc) + (size_t)b * E * a.bbox_chunks : nullptr;
@@ -2942,11 +3146,12 @@ static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, con
     // buys more growers (large skeletons: the frontier lives in LDS too, and their lists are short)
     const bool spec = a.spec != 0;
     int tgt_floats = kBlendLdsFloats;
-    size_t priv = assoc_private_bytes(K, A, REG, tgt_floats, spec);
+    const bool help = kHelp && a.help != 0;
+    size_t priv = assoc_private_bytes(K, A, REG, tgt_floats, spec, help);
     int growers = shared + priv <= budget ? (int)((budget - shared) / priv) : 0;
     if (growers < NW - 1) {
         const int small_floats = spec ? kSpecTgtFloats : kSmallTgtFloats;     // (the level walk's batches need more of it than two chunks)
-        const size_t priv_small = assoc_private_bytes(K, A, REG, small_floats, spec);
+        const size_t priv_small = assoc_private_bytes(K, A, REG, small_floats, spec, help);
         const int growers_small = shared + priv_small <= budget ? (int)((budget - shared) / priv_small) : 0;
         if (growers_small > growers) { growers = growers_small; priv = priv_small; tgt_floats = small_floats; }
     }
@@ -2997,10 +3202,8 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     a.inherit = 1;
     a.collide = 1;
     a.timing = 0;
-    a.early = 0;                                                                    // (round 5: COCO 558 -> 562 us, wholebody 3.12 -> 3.30 ms: more predictions, more of them wrong)
-    if (const char* e = getenv("OPA_ASSOC_EARLY")) a.early = atoi(e) != 0;         // A/B: boxes are published when a joint is assigned only
-    a.commit_run = kCommitRun;
-    if (const char* e = getenv("OPA_ASSOC_COMMIT_RUN")) { const int v = atoi(e); if (v >= 1 && v <= 64) a.commit_run = v; }
+    a.help = kHelp ? 1 : 0;
+    if (const char* e = getenv("OPA_ASSOC_HELP")) a.help = kHelp && atoi(e) != 0;  // A/B and tests: every growth scans its own lists
     a.spec = kWalk ? 1 : 0;
     if (const char* e = getenv("OPA_ASSOC_SPEC")) a.spec = kWalk && atoi(e) != 0;  // (walk builds) A/B: every bone scanned on demand, one at a time
     if (const char* e = getenv("OPA_ASSOC_TIMING")) a.timing = atoi(e) != 0;      // phase tick counters of the coordinator (statistics slots 12, 17-20)

@@ -191,8 +191,7 @@ struct AssocArgs {
     int timing;                 // 1: the coordinator also fills the tick counters of its phases (statistics slots 12, 17-20)
     int collide;                // 1: a growth that assigns a joint inside the same joint's box of an earlier live candidate is stopped (advisory)
     int inherit;                // 1: a candidate inherits the predictions of a growth stopped because of it (advisory; see cifcaf.hip)
-    int early;                  // 1: a growth publishes a joint's box when it EVALUATES the connection to it, not only when it assigns it (advisory)
-    int commit_run;             // commits per round of the coordinator before it looks at the idle growers again
+    int help;                   // 1: idle growers evaluate connections of the growth that holds the head seed (scan helpers; exact, see cifcaf.hip)
     int spec;                   // 1: the growers walk the skeleton level by level in batched scans first and the search takes connection values from that memo (exact; see cifcaf.hip)
     int dedup;                  // 1: later seeds of an occupancy cell already seen are dropped at the pool refill (exact; see cifcaf.hip)
     int32_t* fc_meta;           // [B, 4] seed kernel -> force-complete kernel: poses stored, dropped, failed, workgroup counter
