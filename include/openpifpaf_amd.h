@@ -92,13 +92,23 @@ typedef struct opa_shape {
                                * reached only through initial annotations and bones                    */
     int32_t cifhr_pool_tiles; /* capacity, per image, of the high-resolution CIF map, which the decode keeps as a pool
                                * of 32x64-pixel tiles: only tiles the box of an active CIF cell reaches take a slot
-                               * (a 20-person 641-px COCO image: ~450 of its 3927).  0 = automatic: an eighth of the
-                               * map, at least 1024 tiles; -1 = every tile (the dense map's size: can never run out);
-                               * > 0 = that many.  An image that reaches more tiles than the pool holds is not
-                               * decoded wrongly: its count carries OPA_COUNT_FAILED and its status word is -2.   */
+                               * (a 20-person 641-px COCO image: ~450 of its 3927).  0 = automatic: every tile where
+                               * the whole map is at most 32 MB per image (nothing can run out), else an eighth of the
+                               * map and at least 1024 tiles, plus ONE spill region shared by the batch that holds what
+                               * a single image's pool cannot (the rest of a whole map); -1 = every tile (the dense
+                               * map's size: can never run out); > 0 = exactly that many, no spill region.  An image
+                               * that reaches more tiles than pool + spill region hold is not decoded wrongly: its
+                               * count carries OPA_COUNT_FAILED and its status word is -2 (decode it again with -1).  */
 } opa_shape;
 
 /* ---- library ------------------------------------------------------------ */
+/* The structs above are passed by pointer and have grown over time (opa_shape::cifhr_pool_tiles is the latest field): a
+ * caller built against another header would make the library read past its struct.  Check once at start-up that
+ * opa_abi_version() == OPA_ABI_VERSION and opa_shape_bytes() == sizeof(opa_shape), opa_params_bytes() == sizeof(opa_params). */
+#define OPA_ABI_VERSION 5
+int opa_abi_version(void);
+size_t opa_shape_bytes(void);
+size_t opa_params_bytes(void);
 const char* opa_version(void);
 const char* opa_last_error(void);            /* thread-local, never NULL            */
 int opa_device_count(void);                  /* number of visible gfx950 devices    */
@@ -194,8 +204,9 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
  * otherwise 1.0 + accumulated confidence. */
 int opa_cifcaf_get_cifhr(const opa_shape* shape, const void* workspace_dev, int32_t image, float* out_dev, void* stream);
 
-/* Geometry of that array: rows = (cif_h - 1) * stride + 1, cols likewise; pitch = cols; revision = 1.0;
- * offset_floats: where the tile pools begin inside the workspace (debugging; the layout of a pool is not part of the ABI). */
+/* Geometry of that array: rows = (cif_h - 1) * stride + 1, cols likewise; pitch = cols; revision = 1.0.
+ * offset_floats: SIZE_MAX -- the map is NOT a dense array inside the workspace any more (rounds 1-3 returned its offset;
+ * a caller that still indexes the workspace with it fails loudly instead of reading tile pools): use opa_cifcaf_get_cifhr. */
 int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
                           int32_t* rows, int32_t* cols, int32_t* pitch, double* revision);
 

@@ -55,6 +55,9 @@ class Params(ctypes.Structure):
         return other
 
 
+ABI_VERSION = 5                      # OPA_ABI_VERSION of include/openpifpaf_amd.h
+
+
 class DetShape(ctypes.Structure):
     """``opa_det_shape``."""
     _fields_ = [(n, ctypes.c_int32) for n in ('batch', 'n_fields', 'field_h', 'field_w', 'stride', 'max_detections')]
@@ -71,6 +74,9 @@ class Shape(ctypes.Structure):
 _vp, _i32, _i64, _dbl, _sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_size_t
 _P = ctypes.POINTER
 SYMBOLS = {
+    'opa_abi_version': (ctypes.c_int, []),
+    'opa_shape_bytes': (_sz, []),
+    'opa_params_bytes': (_sz, []),
     'opa_version': (ctypes.c_char_p, []),
     'opa_last_error': (ctypes.c_char_p, []),
     'opa_device_count': (ctypes.c_int, []),
@@ -135,6 +141,13 @@ def lib():
             fn = getattr(handle, name)     # AttributeError = ABI mismatch, fail loudly
             fn.restype = restype
             fn.argtypes = argtypes
+        # the structs are passed by pointer: a library built from another header would read past (or short of) them
+        if handle.opa_abi_version() != ABI_VERSION or handle.opa_shape_bytes() != ctypes.sizeof(Shape) or \
+                handle.opa_params_bytes() != ctypes.sizeof(Params):
+            raise NativeError('openpifpaf_amd: %s was built from another include/openpifpaf_amd.h (ABI %d, opa_shape %d bytes, '
+                              'opa_params %d bytes; this package: ABI %d, %d, %d): rebuild it' % (
+                                  LIB_PATH, handle.opa_abi_version(), handle.opa_shape_bytes(), handle.opa_params_bytes(),
+                                  ABI_VERSION, ctypes.sizeof(Shape), ctypes.sizeof(Params)))
         _lib = handle
     return _lib
 

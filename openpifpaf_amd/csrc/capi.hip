@@ -129,12 +129,18 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     {   // the map: a pool of 32x64 tiles per image (cifhr.hip) + the slot table of every plane
         const size_t tpp = (size_t)(L->hr_pitch / kHrTileW) * ((L->hr_rows + kHrTileH - 1) / kHrTileH);
         const size_t all = tpp * L->F;
-        size_t cap = s.cifhr_pool_tiles < 0 ? all : s.cifhr_pool_tiles > 0 ? (size_t)s.cifhr_pool_tiles : std::max<size_t>(1024, all / 8);
+        // automatic: the whole map where that is small (<= 32 MB per image: nothing can run out), else an eighth of it and at
+        // least 1024 tiles, plus a spill region for the whole batch that holds what ONE image's pool cannot (a single
+        // structureless image in a batch decodes; several of them are flagged and decoded again by the host paths)
+        const size_t tile_bytes = (size_t)(kHrTileH * kHrTileW) * sizeof(float);
+        size_t cap = s.cifhr_pool_tiles < 0 ? all : s.cifhr_pool_tiles > 0 ? (size_t)s.cifhr_pool_tiles
+                   : all * tile_bytes <= (size_t)32000000 ? all : std::max<size_t>(1024, all / 8);   // (32 MB: a 641-px COCO map, 32.2 MB, is pooled)
         if (cap > all) cap = all;
-        L->hr_tpp = (int)tpp; L->hr_pool_cap = (int)cap;
-        L->off_cifhr = take(B * cap * (size_t)(kHrTileH * kHrTileW) * sizeof(float));
+        const size_t spill = s.cifhr_pool_tiles == 0 ? all - cap : 0;
+        L->hr_tpp = (int)tpp; L->hr_pool_cap = (int)cap; L->hr_spill_cap = (int)spill;
+        L->off_cifhr = take((B * cap + spill) * tile_bytes);
         L->off_hr_slot = take(B * all * sizeof(int32_t));
-        L->off_hr_overflow = take(B * sizeof(int32_t));
+        L->off_hr_overflow = take((B + 1) * sizeof(int32_t));
     }
     L->off_act = take(B * L->F * 4 * (size_t)(L->H * L->W) * sizeof(float));
     L->off_act_count = take(B * L->F * sizeof(int32_t));
@@ -187,6 +193,9 @@ struct opa_cifcaf {
 extern "C" {
 
 const char* opa_version(void) { return "openpifpaf_amd 0.1 (gfx950)"; }
+int opa_abi_version(void) { return OPA_ABI_VERSION; }
+size_t opa_shape_bytes(void) { return sizeof(opa_shape); }
+size_t opa_params_bytes(void) { return sizeof(opa_params); }
 const char* opa_last_error(void) { return g_error.c_str(); }
 
 int opa_device_count(void) {
@@ -312,7 +321,7 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats, int32_t
                           int32_t* pitch, double* revision) {
     Layout L; const char* why = nullptr;
     if (!shape || !make_layout(*shape, &L, &why)) return fail(OPA_ERR_INVALID_ARGUMENT, why ? why : "null shape");
-    if (offset_floats) *offset_floats = L.off_cifhr / sizeof(float);
+    if (offset_floats) *offset_floats = SIZE_MAX;            // (not a dense array in the workspace: opa_cifcaf_get_cifhr)
     if (rows) *rows = L.hr_rows;
     if (cols) *cols = L.hr_cols;
     if (pitch) *pitch = L.hr_cols;
@@ -398,6 +407,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
         layout_hash = (layout_hash ^ (unsigned long long)v) * 1099511628211ull;
     HrPool pool;                                      // the map is a pool of tiles (cifhr.hip)
     pool.slot = (int32_t*)(ws + L.off_hr_slot); pool.overflow = (int32_t*)(ws + L.off_hr_overflow); pool.cap = L.hr_pool_cap; pool.tpp = L.hr_tpp;
+    pool.spill_cap = L.hr_spill_cap; pool.images = L.B; pool.spill_count = pool.overflow + L.B;
     e = launch_cifhr(cif_dev, L.B, L.F, L.H, L.W, L.stride, 0.0, 1.0, p, cifhr, L.hr_rows, L.hr_pitch,
                      (float*)(ws + L.off_act), (int32_t*)(ws + L.off_act_count), st, false,
                      (unsigned long long*)(ws + L.off_hdr), layout_hash, ws + L.off_tile_clean,

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
     if (pool.slot) {                                  // pooled map: no tile of this plane has a slot yet
         for (int k = threadIdx.x; k < pool.tpp; k += kActiveThreads) pool.slot[(size_t)plane * pool.tpp + k] = -1;
         if (threadIdx.x == 0 && plane % F == 0) pool.overflow[plane / F] = 0;
+        if (threadIdx.x == 0 && plane == 0 && pool.spill_count) *pool.spill_count = 0;
     }
     unsigned* touch = tile_touch ? tile_touch + (size_t)plane * touch_words : nullptr;   // one bit per tile of this plane
     if (touch) {
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256) void cifhr_tile_kernel(
         const unsigned long long* __restrict__ ws_header, const unsigned* __restrict__ tile_prev,
         const unsigned* __restrict__ tile_cur, int touch_words, HrPool pool, int F) {
     __shared__ __attribute__((aligned(16))) float T[kHrTileH * kHrLdsPitch];
+    __shared__ int spill_slot;
     const int band = threadIdx.x >> 6;
     const int g = blockIdx.x % kTileGroups;          // this workgroup's number within the plane
     const int plane = blockIdx.x / kTileGroups;
@@ -302,10 +304,17 @@ __global__ __launch_bounds__(256) void cifhr_tile_kernel(
                 const int t = (w0 + wi) * 32 + bit;
                 const int ty = t / tiles_x, tx = t - ty * tiles_x;
                 if (pooled) {
-                    const int sl = plane_base + k - 1;
-                    if (sl >= pool.cap) {             // more tiles than the pool holds: the image is flagged, not decoded wrongly
-                        if (threadIdx.x == 0) { pool.slot[(size_t)plane * tpp + t] = -2; pool.overflow[plane / F] = 1; }
-                        continue;
+                    int sl = plane_base + k - 1;
+                    if (sl >= pool.cap) {             // more tiles than the image's pool holds: a slot of the batch's spill region
+                        if (threadIdx.x == 0) spill_slot = pool.spill_cap > 0 ? atomicAdd(pool.spill_count, 1) : pool.spill_cap;
+                        __syncthreads();              // (every thread of the workgroup walks the same tiles)
+                        const int i = spill_slot;
+                        __syncthreads();
+                        if (i >= pool.spill_cap) {    // that ran out too: the image is flagged, not decoded wrongly
+                            if (threadIdx.x == 0) { pool.slot[(size_t)plane * tpp + t] = -2; pool.overflow[plane / F] = 1; }
+                            continue;
+                        }
+                        sl = (pool.images - plane / F) * pool.cap + i;
                     }
                     if (threadIdx.x == 0) pool.slot[(size_t)plane * tpp + t] = sl;
                     build_tile(A, n, HW, T, pool_image + (size_t)sl * (kHrTileH * kHrTileW), kHrTileW, false, rows, cols, tx, ty, band, true);
@@ -338,6 +347,7 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
     // two per-plane tile bitmaps in the workspace region `tile_state`: previous call, this call
     const int touch_words = (tiles_x * tiles_y + 31) / 32;
     HrPool pool; pool.slot = nullptr; pool.overflow = nullptr; pool.cap = 0; pool.tpp = tiles_x * tiles_y;
+    pool.spill_cap = 0; pool.images = B; pool.spill_count = nullptr;
     if (pool_in) pool = *pool_in;
     unsigned* tile_prev = ws_header ? reinterpret_cast<unsigned*>(tile_state) : nullptr;
     unsigned* tile_touch = ws_header ? tile_prev + (size_t)planes * touch_words : nullptr;
@@ -348,7 +358,7 @@ hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride
         if (pool.slot) {                              // pooled map, no cell: no tile has a slot
             e = hipMemsetAsync(pool.slot, 0xFF, sizeof(int32_t) * (size_t)planes * pool.tpp, st);
             if (e != hipSuccess) return e;
-            e = hipMemsetAsync(pool.overflow, 0, sizeof(int32_t) * B, st);
+            e = hipMemsetAsync(pool.overflow, 0, sizeof(int32_t) * (B + (pool.spill_count ? 1 : 0)), st);   // (+ the spill counter behind the flags)
             if (e != hipSuccess) return e;
         }
         prof_mark(st, "memset_act_count");

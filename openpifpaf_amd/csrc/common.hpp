@@ -25,6 +25,7 @@ struct Layout {
     int B, F, K, A, H, W, cH, cW, stride, cstride, max_ann;     // F CIF fields, K >= F joints per annotation
     int hr_rows, hr_cols, hr_pitch;       // high-res map geometry
     int hr_tpp, hr_pool_cap;              // 32x64 tiles per plane; slots of one image's tile pool (opa_shape::cifhr_pool_tiles)
+    int hr_spill_cap;                     // slots of the batch's shared spill region behind the pools (automatic sizing only)
     int occ_h, occ_w;                     // occupancy geometry
     int cif_cells;                        // F*H*W  (seed capacity)
     int caf_cells;                        // cH*cW  (list capacity per (field, direction))
@@ -39,7 +40,7 @@ struct Layout {
     // scratch of the seed tie pass (cifseeds.hip): `big` lies in the active-cell list (dead once the map is built, and
     // exactly as large), `small` in the occupancy bitmap (cleared by the association kernel afterwards) where it fits
     size_t off_tie_small, tie_small_stride, off_tie_state;
-    size_t off_hr_slot, off_hr_overflow;   // the pooled map's slot tables [B][F][tpp], overflow flags
+    size_t off_hr_slot, off_hr_overflow;   // the pooled map's slot tables [B][F][tpp], overflow flags [B] + the spill region's counter
 };
 
 bool make_layout(const opa_shape& s, Layout* L, const char** why);
@@ -82,6 +83,11 @@ struct HrPool {
     int32_t* overflow;     // [B] set when an image reaches more tiles than its pool holds (the decode then flags the image failed)
     int cap;               // slots per image
     int tpp;               // tiles per plane
+    // An image that reaches more tiles than its pool holds takes slots of a region all images of the batch share, right
+    // behind the B pools (slot numbers stay relative to the image's own pool: (B - b) * cap + i), handed out by a counter;
+    // only when that runs out too is the image flagged.  `spill_cap` 0: no such region.
+    int spill_cap, images;
+    int32_t* spill_count;  // [1]
 };
 hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride,
                         double min_scale, double factor, const DevParams& p,

@@ -73,6 +73,10 @@ struct CifCaf : torch::CustomClassHolder {
     ~CifCaf() override { opa_cifcaf_destroy(handle); }
 
     void set_max_annotations(int64_t n) { max_annotations = n; }
+    // opa_shape::cifhr_pool_tiles of the next decodes: 0 automatic, -1 every tile (can never run out), n tiles per image
+    void set_cifhr_pool_tiles(int64_t n) { cifhr_pool_tiles = n < 0 ? -1 : n; }
+    int64_t get_cifhr_pool_tiles() { return cifhr_pool_tiles; }
+    void use_full_pool() { cifhr_pool_tiles = -1; }
 
     // batched extension: cif [B,F,5,H,W], caf [B,A,8,H,W] -> (ann [B,max,K,4], ids [B,max], counts [B])
     std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> call_batch_impl(
@@ -88,7 +92,7 @@ struct CifCaf : torch::CustomClassHolder {
         s.cif_stride = (int32_t)cif_stride; s.caf_stride = (int32_t)caf_stride;
         s.max_annotations = (int32_t)max_annotations;
         s.n_keypoints = (int32_t)n_keypoints;        // > n_cif in the tracking setup
-        s.cifhr_pool_tiles = (int32_t)cifhr_pool_tiles;   // 0: automatic (an eighth of the map); -1 after an image did not fit
+        s.cifhr_pool_tiles = (int32_t)cifhr_pool_tiles;   // 0: automatic (+ the batch's spill region); -1 after an image did not fit, or on request
         // (the decode below runs with the process-global tunables: without force_complete the second list set is left out)
         const size_t need = opa_cifcaf_workspace_bytes_for(&s, nullptr);
         TORCH_CHECK(need > 0, "opa_cifcaf_workspace_bytes_for: ", opa_last_error());
@@ -121,7 +125,19 @@ struct CifCaf : torch::CustomClassHolder {
 
     std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> call_batch(
             const torch::Tensor& cif, int64_t cif_stride, const torch::Tensor& caf, int64_t caf_stride) {
-        return call_batch_impl(cif, cif_stride, caf, caf_stride, torch::nullopt, torch::nullopt);
+        auto result = call_batch_impl(cif, cif_stride, caf, caf_stride, torch::nullopt, torch::nullopt);
+        if (cifhr_pool_tiles == 0) {
+            // Scripted and batched callers have no other place to recover: an image whose CIF map ran out of the automatic
+            // pool AND the batch's spill region (several structureless, all-active fields in one batch) comes back flagged
+            // with no rows.  One look at the counts (they are what a caller reads first anyway), and if need be the batch is
+            // decoded again with a pool that holds every tile -- from then on this decoder keeps that pool.
+            const torch::Tensor c = std::get<2>(result).cpu();
+            if (c.bitwise_and(OPA_COUNT_FAILED).any().item<bool>()) {
+                cifhr_pool_tiles = -1;
+                result = call_batch_impl(cif, cif_stride, caf, caf_stride, torch::nullopt, torch::nullopt);
+            }
+        }
+        return result;
     }
 
     // module.cpp:36 -- single image, results on the device the fields came from
@@ -439,13 +455,20 @@ TORCH_LIBRARY(openpifpaf_amd_decoder, m) {
         .def("call_with_initial_annotations", &CifCaf::call_with_initial_annotations)    // :36
         .def("call_batch", &CifCaf::call_batch)
         .def("set_max_annotations", &CifCaf::set_max_annotations)
+        .def("set_cifhr_pool_tiles", &CifCaf::set_cifhr_pool_tiles)
+        .def("get_cifhr_pool_tiles", &CifCaf::get_cifhr_pool_tiles)
+        .def("use_full_pool", &CifCaf::use_full_pool)
         .def("get_cifhr", &CifCaf::get_cifhr)                                            // :37-39
-        .def_pickle(                                                                      // :41-53
-            [](const c10::intrusive_ptr<CifCaf>& self) -> std::tuple<int64_t, torch::Tensor> {
-                return std::make_tuple(self->n_keypoints, self->skeleton);
+        // :41-53 (n_keypoints, skeleton) -- plus this build's two capacities, so that a saved module decodes like the live one
+        .def_pickle(
+            [](const c10::intrusive_ptr<CifCaf>& self) -> std::tuple<int64_t, torch::Tensor, int64_t, int64_t> {
+                return std::make_tuple(self->n_keypoints, self->skeleton, self->max_annotations, self->cifhr_pool_tiles);
             },
-            [](std::tuple<int64_t, torch::Tensor> state) -> c10::intrusive_ptr<CifCaf> {
-                return c10::make_intrusive<CifCaf>(std::get<0>(state), std::get<1>(state));
+            [](std::tuple<int64_t, torch::Tensor, int64_t, int64_t> state) -> c10::intrusive_ptr<CifCaf> {
+                auto obj = c10::make_intrusive<CifCaf>(std::get<0>(state), std::get<1>(state));
+                obj->max_annotations = std::get<2>(state);
+                obj->cifhr_pool_tiles = std::get<3>(state);
+                return obj;
             });
     m.def("grow_connection_blend", grow_connection_blend);                               // :55
     m.class_<CifDet>("CifDet")                                                           // :57-62

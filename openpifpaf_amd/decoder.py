@@ -90,6 +90,9 @@ class CifCaf(Decoder):
     nms_before_force_complete = False
     reverse_match = True
     max_annotations = native.DEFAULT_MAX_ANNOTATIONS
+    #: per-image capacity of the high-resolution map's tile pool (``opa_shape::cifhr_pool_tiles``): 0 = automatic,
+    #: ``'full'`` / -1 = every tile (can never run out), n = n tiles; ``--cifcaf-cifhr-pool-tiles``
+    cifhr_pool_tiles = 0
 
     def __init__(self, cif_metas: List[headmeta.Cif], caf_metas: List[headmeta.Caf]):
         super().__init__()
@@ -101,6 +104,7 @@ class CifCaf(Decoder):
             len(cif_metas[0].keypoints),
             torch.LongTensor(caf_metas[0].skeleton) - 1,          # reference cifcaf.py:119-122
             max_annotations=self.max_annotations,
+            cifhr_pool_tiles=self.cifhr_pool_tiles,
         )
         # prefer decoders with more keypoints and associations (reference cifcaf.py:123-125)
         self.priority += sum(m.n_fields for m in cif_metas) / 1000.0
@@ -131,6 +135,9 @@ class CifCaf(Decoder):
         group.add_argument('--ablation-independent-kp', default=False, action='store_true')
         group.add_argument('--cifcaf-max-annotations', default=cls.max_annotations, type=int,
                            help='per-image capacity of the device-side annotation buffer')
+        group.add_argument('--cifcaf-cifhr-pool-tiles', default=cls.cifhr_pool_tiles,
+                           type=lambda v: -1 if v == 'full' else int(v),
+                           help='32x64 tiles per image of the high-resolution map\'s pool: 0 = automatic, full = every tile')
 
     @classmethod
     def configure(cls, args: argparse.Namespace):
@@ -164,6 +171,7 @@ class CifCaf(Decoder):
         if args.ablation_cifseeds_no_rescore and args.ablation_caf_no_rescore:
             native.CifHr.set_ablation_skip(True)
         cls.max_annotations = getattr(args, 'cifcaf_max_annotations', cls.max_annotations)
+        cls.cifhr_pool_tiles = getattr(args, 'cifcaf_cifhr_pool_tiles', cls.cifhr_pool_tiles)
 
     @classmethod
     def factory(cls, head_metas):
@@ -237,14 +245,19 @@ class CifCaf(Decoder):
     def _decode_lanes(self):
         lanes = getattr(self, '_lanes', None)
         n = max(1, int(self.decoder_workers or 1))
-        if lanes is None or len(lanes.decoders) != n:
+        key = (n, int(self.max_annotations), self.cifhr_pool_tiles)
+        if lanes is None or getattr(self, '_lanes_key', None) != key:
+            # (the lanes, their workspaces and the pinned host buffers are sized by these: rebuilt when one of them changes;
+            # batches still in flight on the old lanes are collected first)
+            for pending in list(getattr(self, '_lane_pending', {}).values()):
+                pending.result()
             lanes = native.DecodeLanes(len(self.cif_metas[0].keypoints), torch.LongTensor(self.caf_metas[0].skeleton) - 1,
-                                       lanes=n, max_annotations=self.max_annotations)
-            self._lanes, self._lane_host, self._lane_pending = lanes, {}, {}
+                                       lanes=n, max_annotations=self.max_annotations, cifhr_pool_tiles=self.cifhr_pool_tiles)
+            self._lanes, self._lane_host, self._lane_pending, self._lanes_key = lanes, {}, {}, key
         return lanes
 
     def __getstate__(self):
-        return {k: v for k, v in self.__dict__.items() if k not in ('worker_pool', '_lanes', '_lane_host', '_lane_pending')}
+        return {k: v for k, v in self.__dict__.items() if k not in ('worker_pool', '_lanes', '_lane_host', '_lane_pending', '_lanes_key')}
 
     class Pending:
         """A batch in flight: ``result()`` waits for ITS decode only (an event on its lane) and builds the annotations."""
@@ -253,24 +266,35 @@ class CifCaf(Decoder):
             self.owner, self.lane, self.event, self.host, self.n_images, self.t_submit = owner, lane, event, host, n_images, t_submit
             self.fields = fields                 # (cif, caf, meta_batch): kept for the one case a decode is repeated (below)
             self._result = None
+            self._error = None
 
         def done(self):
             return self._result is not None or self.event.query()
 
         def result(self):
+            if self._error is not None:
+                raise self._error                # (the decode failed: every call says so, the lane itself is free again)
             if self._result is None:
-                self.event.synchronize()
-                out, ids, counts = (t.numpy() for t in self.host)
-                if (counts[:self.n_images] & native.COUNT_FAILED).any() and self.fields is not None and \
-                        self.owner._lanes.decoders[self.lane].pool_overflowed():
-                    # an image's CIF map did not fit the automatic tile pool (structureless, all-active fields): from now
-                    # on every lane uses a pool that holds the whole map, and this batch is decoded again, synchronously
-                    out, ids, counts = self.owner._decode_again_with_full_pool(*self.fields)
-                self.fields = None
-                self._result = self.owner._annotations_from_host(out, ids, counts[:self.n_images])
-                self.owner.last_decoder_time = time.perf_counter() - self.t_submit
-                if self.owner._lane_pending.get(self.lane) is self:
-                    del self.owner._lane_pending[self.lane]
+                try:
+                    self.event.synchronize()
+                    out, ids, counts = (t.numpy() for t in self.host)
+                    if (counts[:self.n_images] & native.COUNT_FAILED).any() and self.fields is not None and \
+                            self.owner._lanes.decoders[self.lane].pool_overflowed():
+                        # an image's CIF map did not fit the tile pool and the batch's spill region (several structureless,
+                        # all-active fields in one batch): from now on every lane uses a pool that holds the whole map, and
+                        # this batch is decoded again, synchronously
+                        out, ids, counts = self.owner._decode_again_with_full_pool(*self.fields)
+                    self._result = self.owner._annotations_from_host(out, ids, counts[:self.n_images])
+                    self.owner.last_decoder_time = time.perf_counter() - self.t_submit
+                except Exception as e:           # noqa: BLE001 -- remembered for later calls, raised below
+                    self._error = e
+                    raise
+                finally:
+                    # whatever happened, the ticket is spent: a failed batch must not be collected again before every
+                    # later submit to this lane (and fail every later, unrelated batch)
+                    self.fields = None
+                    if self.owner._lane_pending.get(self.lane) is self:
+                        del self.owner._lane_pending[self.lane]
             return self._result
 
     def _decode_again_with_full_pool(self, cif, caf, meta_batch):
@@ -278,7 +302,7 @@ class CifCaf(Decoder):
             if dec.cifhr_pool_tiles != -1:
                 dec.use_full_pool()
         LOG.warning('a CIF map reached more tiles than the automatic pool holds: decoding again with a full pool '
-                    '(CifCaf(..., cifhr_pool_tiles=\'full\') avoids the second decode)')
+                    '(--cifcaf-cifhr-pool-tiles full, or decoder.CifCaf.cifhr_pool_tiles = -1, avoids the second decode)')
         out, ids, counts = self.cpp_decoder.call_batch(cif, self.cif_metas[0].stride, caf, self.caf_metas[0].stride)
         if meta_batch is not None:
             from .annotation import inverse_transform_batch

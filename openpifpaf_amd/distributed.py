@@ -60,12 +60,18 @@ def gather_annotations(annotations, ids, counts, group=None):
 
 
 def unpack(annotations, ids, counts, max_annotations=None):
-    """Device/host blocks -> per-image list of ``(ann [n,K,4] numpy, ids [n] numpy)``."""
+    """Device/host blocks -> per-image list of ``(ann [n,K,4] numpy, ids [n] numpy)``.
+
+    Raises ``NativeError`` when an image of the (gathered) batch carries ``OPA_COUNT_FAILED`` -- on whatever rank it was
+    decoded: a failed decode reports no rows, and handing that on as "nobody in the picture" would be a silent wrong answer
+    (the same check ``native.CifCaf.call*`` and ``decoder.CifCaf.batch`` make on their own results)."""
+    from . import native
     annotations, ids, counts = annotations.cpu().numpy(), ids.cpu().numpy(), counts.cpu().numpy()
+    native.check_counts(counts)
     cap = annotations.shape[1] if max_annotations is None else max_annotations
     out = []
     for b in range(len(counts)):
-        n = min(int(counts[b]) & 0x0FFFFFFF, cap)           # OPA_COUNT_ROWS: the valid rows
+        n = min(int(counts[b]) & native.COUNT_ROWS_MASK, cap)           # OPA_COUNT_ROWS: the valid rows
         out.append((annotations[b, :n], ids[b, :n]))
     return out
 

@@ -125,7 +125,8 @@ class CifCaf:
 
     def __init__(self, n_keypoints, skeleton, *, max_annotations=DEFAULT_MAX_ANNOTATIONS, cifhr_pool_tiles=0):
         """``cifhr_pool_tiles``: capacity per image of the high-resolution map, which the decode keeps as a pool of 32x64
-        tiles (``opa_shape::cifhr_pool_tiles``): 0 = automatic (an eighth of the map, at least 1024 tiles: 8 MB for a
+        tiles (``opa_shape::cifhr_pool_tiles``): 0 = automatic (the whole map where that is at most 32 MB per image; else an
+        eighth of it, at least 1024 tiles, plus one spill region for the batch that holds the rest of ONE whole map: 8 MB for a
         641-px COCO image instead of 31), ``'full'`` / -1 = every tile, n > 0 = n tiles.  An image whose CIF cells reach
         more tiles than the pool holds is flagged (``OPA_COUNT_FAILED``, status -2) instead of decoded wrongly; the
         synchronous entry points (``call``, ``call_with_initial_annotations``, ``decoder.CifCaf.batch``) then decode once
@@ -355,8 +356,9 @@ class DecodeLanes:
             self.event.synchronize()
             return self.tensors
 
-    def __init__(self, n_keypoints, skeleton, *, lanes=2, max_annotations=DEFAULT_MAX_ANNOTATIONS):
-        self.decoders = [CifCaf(n_keypoints, skeleton, max_annotations=max_annotations) for _ in range(max(1, lanes))]
+    def __init__(self, n_keypoints, skeleton, *, lanes=2, max_annotations=DEFAULT_MAX_ANNOTATIONS, cifhr_pool_tiles=0):
+        self.decoders = [CifCaf(n_keypoints, skeleton, max_annotations=max_annotations, cifhr_pool_tiles=cifhr_pool_tiles)
+                         for _ in range(max(1, lanes))]
         self.streams = [torch.cuda.Stream(priority=-1) for _ in self.decoders]
         self._next = 0
 

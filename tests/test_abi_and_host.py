@@ -69,8 +69,17 @@ def test_invalid_arguments_fail_loudly_without_gpu():
     nbytes_dense = L.opa_cifcaf_workspace_bytes(ctypes.byref(dense))
     per_image = (nbytes_dense - nbytes) / 32
     assert 21e6 < per_image < 24e6                                     # 3927 - 1024 tiles of 8 KB
+    # (the automatic size is 1024 tiles per image + ONE spill region for the batch that holds the rest of a whole map;
+    # an explicit capacity has no spill region)
     small = _lib.Shape(32, 17, 19, 81, 81, 81, 81, 8, 8, 128, 0, 512)
-    assert (nbytes - L.opa_cifcaf_workspace_bytes(ctypes.byref(small))) / 32 == 512 * 8192
+    assert (nbytes - (3927 - 1024) * 8192 - L.opa_cifcaf_workspace_bytes(ctypes.byref(small))) / 32 == 512 * 8192
+    # a map of at most 32 MB per image is kept whole (nothing can run out): the 47 x 16 fields of the round-4 sweeps
+    whole = _lib.Shape(16, 133, 160, 16, 47, 16, 47, 8, 8, 128, 0, 0)
+    whole_full = _lib.Shape(16, 133, 160, 16, 47, 16, 47, 8, 8, 128, 0, -1)
+    assert L.opa_cifcaf_workspace_bytes(ctypes.byref(whole)) == L.opa_cifcaf_workspace_bytes(ctypes.byref(whole_full))
+    # the structs are passed by pointer: the library says which header it was built from (checked at load, _lib.lib())
+    assert L.opa_abi_version() == _lib.ABI_VERSION and L.opa_shape_bytes() == ctypes.sizeof(_lib.Shape)
+    assert L.opa_params_bytes() == ctypes.sizeof(_lib.Params)
     # without force complete the second CAF list set is left out ("weak" 15): ~7 MB per image less
     plain = L.opa_cifcaf_workspace_bytes_for(ctypes.byref(shape), ctypes.byref(_lib.default_params()))
     full = L.opa_cifcaf_workspace_bytes_for(ctypes.byref(shape), ctypes.byref(_lib.default_params(force_complete=1)))

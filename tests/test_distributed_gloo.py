@@ -40,6 +40,19 @@ WORKER = textwrap.dedent('''
     for g, (pa, pi) in enumerate(per_image):
         assert len(pa) == g %% (max_ann + 1)
         assert (pa == g + 1).all() and (pi == g).all()
+    # an image whose decode FAILED on one rank (OPA_COUNT_FAILED travels with its count) must not come out of the gather as
+    # "nobody in the picture": unpack raises on every rank that looks at the gathered batch
+    from openpifpaf_amd import native, _lib
+    bad_counts = counts.clone()
+    if rank == 1:
+        bad_counts[0] = native.COUNT_FAILED
+    a2, i2, c2 = D.gather_annotations(ann, ids, bad_counts)
+    assert native.count_failed(c2.numpy()).tolist() == [g == 3 for g in range(n_images)]
+    try:
+        D.unpack(a2, i2, c2)
+        raise SystemExit('rank %%d: a failed image passed for an empty one' %% rank)
+    except _lib.NativeError as e:
+        assert '[3]' in str(e), str(e)
     # every rank adopts rank 0's table of 1x1-convolution kernel choices (the paths round differently)
     from openpifpaf_amd import fused
     key = ('torch.float32', 32 * 81 * 81, 64, 256, True, False)

@@ -91,19 +91,21 @@ def test_large_field_batch_decodes_like_the_oracle(native, port, coco_skeleton0,
             cafs = np.stack([fields(c)[1] for c in order])
             out, ids, counts = dec.call_batch(dev(cifs), 8, dev(cafs), 8, params=params_dev)
             out, counts = out.cpu().numpy(), counts.cpu().numpy()
-            if LARGE[3] in order and dec.cifhr_pool_tiles == 0:
-                # the 90-person image reaches ~2200 map tiles, the automatic pool of a 161 x 161 field holds 1829: that image
-                # -- and only that one -- is flagged, with status -2; with a full pool the same call decodes everything
-                bad = order.index(LARGE[3])
-                assert native.count_failed(counts).tolist() == [i == bad for i in range(len(order))]
-                status = dec.workspace_view('status', torch.int32)[:len(order)].cpu().numpy()
-                assert status[bad] == -2 and dec.pool_overflowed()
-                with pytest.raises(Exception):
-                    native.check_counts(counts)
-                dec.use_full_pool()
-                out, ids, counts = dec.call_batch(dev(cifs), 8, dev(cafs), 8, params=params_dev)
-                out, counts = out.cpu().numpy(), counts.cpu().numpy()
+            if LARGE[3] in order and fc is False and order is shape_cases:
+                # the 90-person image reaches ~2200 map tiles, the automatic pool of a 161 x 161 field holds 1829: the rest sits
+                # in the batch's spill region, and the image decodes in the same call (round 4: flagged and decoded again).
+                # A pool of exactly that size WITHOUT a spill region flags the image -- and only that one --, status -2
                 assert not dec.pool_overflowed()
+                tight = native.CifCaf(17, torch.from_numpy(coco_skeleton0), cifhr_pool_tiles=1829)
+                _, _, tc = tight.call_batch(dev(cifs), 8, dev(cafs), 8, params=params_dev)
+                tc = tc.cpu().numpy()
+                bad = order.index(LARGE[3])
+                assert native.count_failed(tc).tolist() == [i == bad for i in range(len(order))]
+                status = tight.workspace_view('status', torch.int32)[:len(order)].cpu().numpy()
+                assert status[bad] == -2 and tight.pool_overflowed()
+                with pytest.raises(Exception):
+                    native.check_counts(tc)
+                del tight
             native.check_counts(counts)
             assert not native.count_overflowed(counts).any()
             for b, c in enumerate(order):
@@ -139,43 +141,64 @@ def test_large_field_ties_in_global_memory(native, port, coco_skeleton0):
 
 
 def test_map_tile_pool_overflow_is_flagged_and_retried(native, port, coco_skeleton0):
-    """The decode keeps the high-resolution CIF map as a pool of 32x64 tiles (opa_shape::cifhr_pool_tiles; automatic: an
-    eighth of the map, 1024 of the 3927 tiles of a 641-px COCO image).  Structureless all-active fields reach every tile:
-    the asynchronous batched call flags such an image (OPA_COUNT_FAILED, status -2) instead of decoding it wrongly; the
-    synchronous entry points and the decoder layer decode again with a pool that holds the whole map; an explicit small
-    pool overflows on an ordinary crowded image, a full pool never does -- and every result equals the oracle's."""
+    """The decode keeps the high-resolution CIF map as a pool of 32x64 tiles (opa_shape::cifhr_pool_tiles; automatic: 1024 of
+    the 3927 tiles of a 641-px COCO image, plus one spill region for the batch that holds the rest of a whole map).
+    Structureless all-active fields reach every tile: ONE such image in a batch decodes through the spill region (the
+    reference never fails, cif_hr.cpp:97-121); with two of them the region runs out: the asynchronous batched call flags
+    what did not fit (OPA_COUNT_FAILED, status -2) instead of decoding it wrongly, the synchronous entry points and the
+    decoder layer decode again with a pool that holds the whole map; an explicit small pool (no spill region) overflows on
+    an ordinary crowded image, a full pool never does -- and every result equals the oracle's."""
     from openpifpaf_amd import decoder, headmeta, synth
     adv_cif, adv_caf = synth.adversarial_fields(11)
+    adv2_cif, adv2_caf = synth.adversarial_fields(12)
     ok_cif, ok_caf = synth.synth_fields(31, 20, height=81, width=81)
     cifs, cafs = np.stack([ok_cif, adv_cif]), np.stack([ok_caf, adv_caf])
     want = [port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)[0] for b in range(2)]
+    cifs2, cafs2 = np.stack([adv_cif, adv2_cif]), np.stack([adv_caf, adv2_caf])
+    want2 = [want[1], port.decode(adv2_cif, 8, adv2_caf, 8, coco_skeleton0)[0]]
 
+    # one structureless image beside an ordinary one: its own pool + the spill region hold its whole map
     dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
     out, ids, counts = dec.call_batch(dev(cifs), 8, dev(cafs), 8)
     counts_h = counts.cpu().numpy()
-    assert native.count_failed(counts_h).tolist() == [False, True] and dec.pool_overflowed()
-    assert dec.workspace_view('status', torch.int32)[:2].cpu().numpy().tolist()[1] == -2
-    okk, msg = compare_annotations(out[0, :native.count_rows(int(counts_h[0]))].cpu().numpy(), want[0])
-    assert okk, msg                                                     # the image beside it is not affected
-    bytes_auto = dec._last[1].numel()
-    # synchronous single-image call: retried with a full pool on its own
-    dec1 = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
-    got, _ = dec1.call(dev(adv_cif), 8, dev(adv_caf), 8)
-    assert dec1.cifhr_pool_tiles == -1
-    okk, msg = compare_annotations(got.cpu().numpy(), want[1])
-    assert okk, msg
-    hr, rev = dec1.get_cifhr()
-    assert rev == 1.0 and np.array_equal(hr.cpu().numpy(), port.cifhr_accumulate(adv_cif, 8))    # the whole map, through the pool
-    # the full pool on request: the dense map's size, never overflows
-    full = native.CifCaf(17, torch.from_numpy(coco_skeleton0), cifhr_pool_tiles='full')
-    out, ids, counts = full.call_batch(dev(cifs), 8, dev(cafs), 8)
-    counts_h = counts.cpu().numpy()
     native.check_counts(counts_h)
+    assert not dec.pool_overflowed()
     for b in range(2):
         okk, msg = compare_annotations(out[b, :native.count_rows(int(counts_h[b]))].cpu().numpy(), want[b])
         assert okk, (b, msg)
-    assert (full._last[1].numel() - bytes_auto) // 2 == (3927 - 1024) * 8192
-    # an explicit small pool: the 20-person image alone reaches ~450 tiles
+    hr, rev = dec.get_cifhr(1)
+    assert rev == 1.0 and np.array_equal(hr.cpu().numpy(), port.cifhr_accumulate(adv_cif, 8))    # the whole map, through pool + spill slots
+    bytes_auto = dec._last[1].numel()
+    # two of them: what the spill region cannot hold is flagged, never decoded wrongly
+    out, ids, counts = dec.call_batch(dev(cifs2), 8, dev(cafs2), 8)
+    counts_h = counts.cpu().numpy()
+    failed = native.count_failed(counts_h)
+    assert failed.any() and dec.pool_overflowed()
+    status = dec.workspace_view('status', torch.int32)[:2].cpu().numpy()
+    for b in range(2):
+        if failed[b]:
+            assert status[b] == -2 and native.count_rows(int(counts_h[b])) == 0
+        else:
+            okk, msg = compare_annotations(out[b, :native.count_rows(int(counts_h[b]))].cpu().numpy(), want2[b])
+            assert okk, (b, msg)
+    with pytest.raises(Exception):
+        native.check_counts(counts_h)
+    # synchronous single-image call: B = 1, the spill region is the image's own
+    dec1 = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    got, _ = dec1.call(dev(adv_cif), 8, dev(adv_caf), 8)
+    assert dec1.cifhr_pool_tiles == 0
+    okk, msg = compare_annotations(got.cpu().numpy(), want[1])
+    assert okk, msg
+    # the full pool on request: the dense map's size, never overflows
+    full = native.CifCaf(17, torch.from_numpy(coco_skeleton0), cifhr_pool_tiles='full')
+    out, ids, counts = full.call_batch(dev(cifs2), 8, dev(cafs2), 8)
+    counts_h = counts.cpu().numpy()
+    native.check_counts(counts_h)
+    for b in range(2):
+        okk, msg = compare_annotations(out[b, :native.count_rows(int(counts_h[b]))].cpu().numpy(), want2[b])
+        assert okk, (b, msg)
+    assert full._last[1].numel() - bytes_auto == (3927 - 1024) * 8192
+    # an explicit small pool (no spill region): the 20-person image alone reaches ~450 tiles
     small = native.CifCaf(17, torch.from_numpy(coco_skeleton0), cifhr_pool_tiles=256)
     out, ids, counts = small.call_batch(dev(ok_cif[None]), 8, dev(ok_caf[None]), 8)
     assert native.count_failed(counts.cpu().numpy()).all() and small.pool_overflowed()
@@ -185,14 +208,14 @@ def test_map_tile_pool_overflow_is_flagged_and_retried(native, port, coco_skelet
         decoder.CifCaf.decoder_workers = 2
         class Heads:
             def __call__(self, images):
-                return (dev(cifs), dev(cafs))
+                return (dev(cifs2), dev(cafs2))
         d = decoder.factory(list(headmeta.cocokp_metas()))
         sync = d.batch(Heads(), torch.zeros((2, 3, 641, 641)), device=torch.device('cuda'))
-        assert [len(r) for r in sync] == [len(w) for w in want]
+        assert [len(r) for r in sync] == [len(w) for w in want2]
         d2 = decoder.factory(list(headmeta.cocokp_metas()))
         pend = [d2.batch_async(Heads(), torch.zeros((2, 3, 641, 641)), device=torch.device('cuda')) for _ in range(3)]
         for p in pend:
-            assert [len(r) for r in p.result()] == [len(w) for w in want]
+            assert [len(r) for r in p.result()] == [len(w) for w in want2]
         assert d2.decoders[0].cpp_decoder.cifhr_pool_tiles == -1
     finally:
         decoder.CifCaf.decoder_workers = old_workers
