@@ -233,6 +233,13 @@ def compact_leg(leg):
            'decode_ms': path.get('ms_per_batch', leg.get('decode_ms')),
            'frac': roof.get('frac', (leg.get('best') or {}).get('frac')),
            'parity_ok': parity_ok(leg.get('parity'))}
+    if isinstance(leg.get('synchronous'), dict):              # the product path: pipelined (= value) and synchronous
+        out['sync_value'] = leg['synchronous'].get('images_per_s')
+    if 'vs_reference_cpu' in leg:                             # configs[0]: the reference's CPU-only predict beside it
+        out['vs_ref_cpu'] = leg['vs_reference_cpu']
+        out['ref_cpu_ms'] = (leg.get('reference_cpu') or {}).get('ms_per_image')
+    if 'decode_vs_cpu_1thread' in leg and leg.get('cpu_baseline'):
+        out['cpu_1thread'] = leg['cpu_baseline'].get('value')
     return out
 
 
@@ -667,13 +674,16 @@ def main():
             torch.cuda.synchronize(device)
 
     def run_leg(wl, images32, dtype_name, steps, warmup, *, params=None, decode_only=False, fields='synthetic',
-                quantised=False, n_streams=1, graph=False, dump=None):
+                quantised=False, n_streams=1, graph=False, dump=None, tie_inside=None):
         """W warm-up steps, then EXACTLY `steps` timed steps between barrier + synchronize.  -> dict(elapsed = max over
         ranks, per-rank times, model, images, annotations of the last step)."""
         model = None if decode_only else build_model(wl, dtype_name)
         images = images32 if dtype_name == 'fp32' else images32.to(TORCH_DTYPE[dtype_name])
         variants = wl.quantised() if quantised else wl.variants
         lanes = native.DecodeLanes(wl.K, torch.from_numpy(wl.skeleton0), lanes=n_streams) if n_streams > 1 else None
+        if lanes is not None and tie_inside is not None:        # (DecodeLanes puts the tie pass inside the association kernel for lanes > 1)
+            for d_ in lanes.decoders:
+                d_.set_tie_placement(tie_inside)
         graphs = None
         if graph:                                          # one captured decode per (decoder, stream), one field batch
             decs = [wl.dec] + [native.CifCaf(wl.K, torch.from_numpy(wl.skeleton0)) for _ in range(n_streams - 1)]
@@ -972,94 +982,8 @@ def main():
                 others[name]['leg_seconds'] = round(time.perf_counter() - t0, 1)
 
 
-        # the reference benchmark CLI's decoder setting on the headline's fields (decode only: the network is the same)
-        def fc_leg():
-            fc_params = _lib.default_params(**FC_KW)
-            leg = run_leg(wl, None, 'fp32', 10, 2, params=fc_params, decode_only=True)
-            with torch.cuda.stream(dec_stream):
-                roof = decode_roofline(wl, wl.variants, fc_params, args.profile_steps, force_complete=True)
-                par = None if args.no_parity else parity_stamp(
-                    lambda c, f: wl.dec.call_batch(c, wl.stride, f, wl.stride, params=fc_params), wl.variants,
-                    wl.skeleton0, wl.K, FC_KW)
-            cpu = None if args.no_cpu_baseline else cpu_baseline(wl.variants[0][0], wl.variants[0][1], wl.skeleton0,
-                                                                 wl.K, 6.0, FC_KW)
-            return {'setting': 'reference benchmark.py:77-79: --force-complete-pose and zero keypoint / instance thresholds '
-                               '(decoder/cifcaf.py:180-185); decode only, config 2 fields',
-                    'decode_only_images_per_s': round(wl.B * 10 / leg['elapsed'], 1),
-                    'ms_per_batch_wall': round(leg['elapsed'] / 10 * 1e3, 3), 'annotations_per_batch': leg['n_ann'],
-                    'roofline': roof, 'cpu_baseline': cpu, 'parity': par,
-                    'decode_vs_cpu_1thread': round(roof['decode_path']['images_per_s'] / cpu['value'], 1) if cpu else None}
-        guarded('force_complete', fc_leg)
-
-        # several batches in flight (stages 1-5 of batch i+1 beside the association of batch i: an association launch
-        # keeps 32 of the 256 compute units busy)
-        def lanes_leg():
-            alg = algorithmic_bytes(wl.B, wl.K, wl.A, wl.fh, wl.fh, wl.stride, wl.dec.max_annotations)['decode_path']
-            rate, gbps = {}, {}
-            order0 = native.get_seed_tie_order()
-            try:
-                for mode in ('libstdcxx', 'libstdcxx-fused'):  # the tie pass as a launch of its own / inside the association kernel
-                    native.set_seed_tie_order(mode)
-                    for n, key in ((1, 'one_in_flight'), (2, 'two_in_flight'), (4, 'four_in_flight'), (8, 'eight_in_flight'),
-                                   (12, 'twelve_in_flight')):
-                        if mode == 'libstdcxx-fused' and n in (1, 4):
-                            continue
-                        key = key if mode == 'libstdcxx' else key + '_ties_fused'
-                        steps = 96                             # (every lane's first calls allocate its workspace: warm-up per lane)
-                        leg = run_leg(wl, None, 'fp32', steps, 4 * n + 4, decode_only=True, n_streams=n)
-                        rate[key] = round(wl.B * steps / leg['elapsed'], 1)
-                        gbps[key] = round(alg * steps / leg['elapsed'] / 1e9, 1)
-            finally:
-                native.set_seed_tie_order(order0)
-            best = max(gbps, key=gbps.get)
-            return {'decode_only_images_per_s': rate, 'GBps': gbps,
-                    'best': {'mode': best, 'GBps': gbps[best], 'frac': round(gbps[best] / HBM_PEAK_GBPS, 5)},
-                    'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'default'),
-                    'what': 'decode only, config 2 fields, alternating batches, annotations copied to the host; '
-                            'native.DecodeLanes(lanes=n): n decoders / workspaces / streams; GBps = SURVEY 8d '
-                            'algorithmic bytes of a batch x batches per second (wall clock, whole decode path); '
-                            '*_ties_fused: seed tie order "libstdcxx-fused" (the tie pass inside the association kernel)'}
-        guarded('decode_two_in_flight', lanes_leg)
-
-        # the adversarial case (BASELINE.md 3 ii, SURVEY 8d): structureless all-active fields, what a random-init head
-        # emits -- every cell passes every threshold.  Decode only, reported separately, with its own parity count.
-        def all_active_leg():
-            from openpifpaf_amd import synth
-            pairs = [synth.adversarial_fields(500 + i, height=wl.fh, width=wl.fh) for i in range(wl.B)]
-            cifs = np.stack([c for c, _ in pairs]); cafs = np.stack([f for _, f in pairs])
-            cif_d, caf_d = torch.from_numpy(cifs).to(device), torch.from_numpy(cafs).to(device)
-            variants = [(cifs, cafs, cif_d, caf_d)]
-            # (every cell active: the CIF map reaches every tile -- a pool that holds the whole map, opa_shape::cifhr_pool_tiles)
-            dec_full = native.CifCaf(wl.K, torch.from_numpy(wl.skeleton0), cifhr_pool_tiles='full')
-            saved_dec, wl.dec = wl.dec, dec_full
-            with torch.cuda.stream(dec_stream):
-                for _ in range(2):
-                    wl.dec.call_batch(cif_d, wl.stride, caf_d, wl.stride)
-                torch.cuda.synchronize(device)
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    out, ids, counts = wl.dec.call_batch(cif_d, wl.stride, caf_d, wl.stride)
-                torch.cuda.synchronize(device)
-                ms = (time.perf_counter() - t0) / 10 * 1e3
-                kernels = kernel_profile(wl, variants, None, 4)
-                par = None if args.no_parity else parity_stamp(
-                    lambda c, f: wl.dec.call_batch(c, wl.stride, f, wl.stride), variants, wl.skeleton0, wl.K)
-            seeds = wl.dec.workspace_view('seed_count', torch.int32)[:wl.B].cpu().numpy()
-            wl.dec = saved_dec
-            alg = algorithmic_bytes(wl.B, wl.K, wl.A, wl.fh, wl.fh, wl.stride, wl.dec.max_annotations)['decode_path']
-            return {'what': 'decode only: %d all-active %dx%d field pairs (synth.adversarial_fields: sigmoid(N(0,1)) confidences, '
-                            'every cell above every threshold)' % (wl.B, wl.fh, wl.fh),
-                    'decode_only_images_per_s': round(wl.B / (ms * 1e-3), 1), 'ms_per_batch_wall': round(ms, 3),
-                    'decode_ms': round(sum(kernels.values()), 4),
-                    'kernels_ms': {k: round(v, 4) for k, v in kernels.items()},
-                    'seeds_per_image': {'mean': float(seeds.mean()), 'max': int(seeds.max())},
-                    'roofline': {'frac': round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
-                    'parity': par}
-        guarded('all_active', all_active_leg)
-
-
-        # (inside this process, behind legs that have created dozens of HIP streams -- the runtime maps streams onto 4 hardware
-        # queues -- the loop takes 78-85 ms per batch; in a process of its own 77.5: tools/gpu/predictor_probe.py, profiles/r4)
+        # FIRST of the extra legs: behind the lane sweeps, which leave dozens of HIP streams behind, the same loop measured
+        # 8 % slower (round 4: the driver's record carried that figure)
         # the product path: Predictor -> Decoder.batch_async over decode lanes (what a user of openpifpaf.predict gets), fed
         # uint8 frames that are preprocessed on the device; the network runs for real, the decode sees the headline's
         # synthetic fields (a random-init head's own output is the all-active case above)
@@ -1113,6 +1037,154 @@ def main():
             finally:
                 Predictor.batch_size, Predictor.long_edge, Predictor.device_preprocess, Predictor.device = saved
         guarded('predictor', predictor_leg)
+
+        # the reference benchmark CLI's decoder setting on the headline's fields (decode only: the network is the same)
+        def fc_leg():
+            fc_params = _lib.default_params(**FC_KW)
+            leg = run_leg(wl, None, 'fp32', 10, 2, params=fc_params, decode_only=True)
+            with torch.cuda.stream(dec_stream):
+                roof = decode_roofline(wl, wl.variants, fc_params, args.profile_steps, force_complete=True)
+                par = None if args.no_parity else parity_stamp(
+                    lambda c, f: wl.dec.call_batch(c, wl.stride, f, wl.stride, params=fc_params), wl.variants,
+                    wl.skeleton0, wl.K, FC_KW)
+            cpu = None if args.no_cpu_baseline else cpu_baseline(wl.variants[0][0], wl.variants[0][1], wl.skeleton0,
+                                                                 wl.K, 6.0, FC_KW)
+            return {'setting': 'reference benchmark.py:77-79: --force-complete-pose and zero keypoint / instance thresholds '
+                               '(decoder/cifcaf.py:180-185); decode only, config 2 fields',
+                    'decode_only_images_per_s': round(wl.B * 10 / leg['elapsed'], 1),
+                    'ms_per_batch_wall': round(leg['elapsed'] / 10 * 1e3, 3), 'annotations_per_batch': leg['n_ann'],
+                    'roofline': roof, 'cpu_baseline': cpu, 'parity': par,
+                    'decode_vs_cpu_1thread': round(roof['decode_path']['images_per_s'] / cpu['value'], 1) if cpu else None}
+        guarded('force_complete', fc_leg)
+
+        # several batches in flight (stages 1-5 of batch i+1 beside the association of batch i: an association launch
+        # keeps 32 of the 256 compute units busy)
+        def lanes_leg():
+            alg = algorithmic_bytes(wl.B, wl.K, wl.A, wl.fh, wl.fh, wl.stride, wl.dec.max_annotations)['decode_path']
+            rate, gbps = {}, {}
+            for inside in (None, False):          # default (DecodeLanes: the tie pass inside the association kernel) / a launch of its own
+                for n, key in ((1, 'one_in_flight'), (2, 'two_in_flight'), (4, 'four_in_flight'), (8, 'eight_in_flight'),
+                               (12, 'twelve_in_flight')):
+                    if inside is False and n in (1, 4):
+                        continue
+                    key = key if inside is None else key + '_ties_launch'
+                    steps = 96                             # (every lane's first calls allocate its workspace: warm-up per lane)
+                    leg = run_leg(wl, None, 'fp32', steps, 4 * n + 4, decode_only=True, n_streams=n, tie_inside=inside)
+                    rate[key] = round(wl.B * steps / leg['elapsed'], 1)
+                    gbps[key] = round(alg * steps / leg['elapsed'] / 1e9, 1)
+            best = max(gbps, key=gbps.get)
+            return {'decode_only_images_per_s': rate, 'GBps': gbps,
+                    'best': {'mode': best, 'GBps': gbps[best], 'frac': round(gbps[best] / HBM_PEAK_GBPS, 5)},
+                    'hw_queues': os.environ.get('GPU_MAX_HW_QUEUES', 'default'),
+                    'what': 'decode only, config 2 fields, alternating batches, annotations copied to the host; '
+                            'native.DecodeLanes(lanes=n): n decoders / workspaces / streams; GBps = SURVEY 8d '
+                            'algorithmic bytes of a batch x batches per second (wall clock, whole decode path); '
+                            'two or more lanes run the tie pass inside the association kernel (opa_cifcaf_set_tie_placement, the '
+                            'DecodeLanes default); *_ties_launch: the same lanes with the pass as a launch of its own'}
+        guarded('decode_two_in_flight', lanes_leg)
+
+        # the adversarial case (BASELINE.md 3 ii, SURVEY 8d): structureless all-active fields, what a random-init head
+        # emits -- every cell passes every threshold.  Decode only, reported separately, with its own parity count.
+        def all_active_leg():
+            from openpifpaf_amd import synth
+            pairs = [synth.adversarial_fields(500 + i, height=wl.fh, width=wl.fh, people=(3, 6, 1, 10)[i % 4] if wl.K == 17 else 0)
+                     for i in range(wl.B)]
+            cifs = np.stack([c for c, _ in pairs]); cafs = np.stack([f for _, f in pairs])
+            cif_d, caf_d = torch.from_numpy(cifs).to(device), torch.from_numpy(cafs).to(device)
+            variants = [(cifs, cafs, cif_d, caf_d)]
+            # (every cell active: the CIF map reaches every tile -- a pool that holds the whole map, opa_shape::cifhr_pool_tiles)
+            dec_full = native.CifCaf(wl.K, torch.from_numpy(wl.skeleton0), cifhr_pool_tiles='full')
+            saved_dec, wl.dec = wl.dec, dec_full
+            with torch.cuda.stream(dec_stream):
+                for _ in range(2):
+                    wl.dec.call_batch(cif_d, wl.stride, caf_d, wl.stride)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    out, ids, counts = wl.dec.call_batch(cif_d, wl.stride, caf_d, wl.stride)
+                torch.cuda.synchronize(device)
+                ms = (time.perf_counter() - t0) / 10 * 1e3
+                kernels = kernel_profile(wl, variants, None, 4)
+                par = None if args.no_parity else parity_stamp(
+                    lambda c, f: wl.dec.call_batch(c, wl.stride, f, wl.stride), variants, wl.skeleton0, wl.K)
+            seeds = wl.dec.workspace_view('seed_count', torch.int32)[:wl.B].cpu().numpy()
+            wl.dec = saved_dec
+            cpu = None if args.no_cpu_baseline else cpu_baseline(cifs, cafs, wl.skeleton0, wl.K, 6.0)
+            alg = algorithmic_bytes(wl.B, wl.K, wl.A, wl.fh, wl.fh, wl.stride, wl.dec.max_annotations)['decode_path']
+            return {'what': 'decode only: %d all-active %dx%d field pairs (synth.adversarial_fields: sigmoid(N(0,1)) confidences, '
+                            'every cell above every threshold) with 3 / 6 / 1 / 10 people planted into the noise, so that the '
+                            'parity stamp compares poses, not a count of zero' % (wl.B, wl.fh, wl.fh),
+                    'cpu_baseline': cpu,
+                    'decode_vs_cpu_1thread': round(wl.B / (ms * 1e-3) / cpu['value'], 1) if cpu else None,
+                    'decode_only_images_per_s': round(wl.B / (ms * 1e-3), 1), 'ms_per_batch_wall': round(ms, 3),
+                    'decode_ms': round(sum(kernels.values()), 4),
+                    'kernels_ms': {k: round(v, 4) for k, v in kernels.items()},
+                    'seeds_per_image': {'mean': float(seeds.mean()), 'max': int(seeds.max())},
+                    'roofline': {'frac': round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
+                    'parity': par}
+        guarded('all_active', all_active_leg)
+
+
+        # BASELINE.json configs[0], the plumbing baseline: resnet18, ONE 321x321 image, the reference's CPU-only predict
+        # (network on the host cores in float32 -> its C++ CifCaf decoder on one thread) next to this path (network on the
+        # MI355X -> HIP decode -> annotations on the host), on the same 41x41 synthetic fields
+        def r0_leg():
+            from openpifpaf_amd import synth
+            edge = 321
+            w0 = Workload(2, 1, 0, device, edge, 2, backbone='resnet18')
+            fh = (edge - 1) // w0.stride + 1
+            pairs = [synth.synth_fields(900 + i, (2, 5)[i % 2], height=fh, width=fh) for i in range(4)]
+            w0.variants = [(c[None], f[None], torch.from_numpy(c[None]).to(device), torch.from_numpy(f[None]).to(device)) for c, f in pairs]
+            img = torch.randn((1, 3, edge, edge), generator=torch.Generator().manual_seed(11))
+            model = build_model(w0, 'fp32')
+            img_d = img.to(device).contiguous(memory_format=torch.channels_last)
+            n = 30
+            def ours(i):
+                _, _, cd, fd = w0.variants[i % 4]
+                with torch.no_grad():
+                    model(img_d)
+                out, ids, counts = w0.dec.call_batch(cd, w0.stride, fd, w0.stride)
+                return out.cpu(), counts.cpu()
+            for i in range(5):
+                ours(i)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for i in range(n):
+                ours(i)
+            ours_ms = (time.perf_counter() - t0) / n * 1e3
+            out = {'what': 'BASELINE configs[0]: resnet18, one %dx%d image (fields %dx%d); ours = network on the MI355X + HIP decode + '
+                           'D2H of the annotations, eager; reference = the same float32 network on the HOST cores + the reference C++ '
+                           'decoder on one thread (its CPU-only predict)' % (edge, edge, fh, fh),
+                   'value': round(1e3 / ours_ms, 1), 'ms_per_step': round(ours_ms, 3), 'eager_ms_per_image': round(ours_ms, 3)}
+            if not args.no_cpu_baseline:
+                kind, make, torch_ = reference_decoder(w0.skeleton0, w0.K, None)
+                decode = make(True)
+                from openpifpaf_amd import network
+                cpu_model = network.factory(w0.backbone, [w0.cif_meta, w0.caf_meta]).eval()   # plain PyTorch modules, float32, host cores
+                threads0 = torch.get_num_threads()
+                with torch.no_grad():
+                    cpu_model(img)                                       # warm-up
+                    t0 = time.perf_counter()
+                    k = 0
+                    while time.perf_counter() - t0 < 4.0 or k < 3:
+                        cpu_model(img)
+                        k += 1
+                    nn_ms = (time.perf_counter() - t0) / k * 1e3
+                t0 = time.perf_counter()
+                k = 0
+                while time.perf_counter() - t0 < 2.0 or k < 3:
+                    decode(pairs[k % 4][0], pairs[k % 4][1])
+                    k += 1
+                dec_ms = (time.perf_counter() - t0) / k * 1e3
+                out['reference_cpu'] = {'kind': kind, 'network_ms': round(nn_ms, 2), 'network_threads': threads0,
+                                        'decode_ms_1thread': round(dec_ms, 3), 'ms_per_image': round(nn_ms + dec_ms, 2),
+                                        'images_per_s': round(1e3 / (nn_ms + dec_ms), 2)}
+                out['vs_reference_cpu'] = round((nn_ms + dec_ms) / ours_ms, 2)
+            with torch.cuda.stream(dec_stream):
+                out['parity'] = None if args.no_parity else parity_stamp(
+                    lambda c, f: w0.dec.call_batch(c, w0.stride, f, w0.stride), w0.variants, w0.skeleton0, w0.K)
+            return out
+        guarded('config1_resnet18_321', r0_leg)
 
         # the literal configs[1]: batch 1
         def batch1_leg():

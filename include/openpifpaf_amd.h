@@ -153,6 +153,14 @@ void opa_cifcaf_destroy(opa_cifcaf* dec);
 int opa_cifcaf_get_state(const opa_cifcaf* dec, int32_t* n_keypoints,
                          int64_t* skeleton_host /* [n_bones,2] or NULL */, int32_t* n_bones);
 
+/* Where the pass that puts seeds of EQUAL score into the reference's order runs for THIS decoder's decodes (seed tie
+ * order 1, see opa_set_seed_tie_order): 0 = a launch of its own (default for one decode at a time: the association
+ * kernel's time stays what it is), 1 = inside the association kernel, every image its own ties (what several decodes in
+ * flight want: the pass overlaps like the association does instead of filling the chip; native.DecodeLanes sets it for
+ * two or more lanes), -1 = the process-wide choice (opa_set_seed_tie_order / OPA_SEED_TIES / OPA_FUSE_TIES).  The
+ * results are the same bit for bit. */
+int opa_cifcaf_set_tie_placement(opa_cifcaf* dec, int32_t inside_association);
+
 /* Bytes of device workspace opa_cifcaf_decode needs for `shape`
  * (0 and an error text if the shape is invalid).
  *

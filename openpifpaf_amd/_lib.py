@@ -89,6 +89,7 @@ SYMBOLS = {
     'opa_cifcaf_create': (ctypes.c_int, [_P(_vp), _i32, _vp, _i32]),
     'opa_cifcaf_destroy': (None, [_vp]),
     'opa_cifcaf_get_state': (ctypes.c_int, [_vp, _P(_i32), _vp, _P(_i32)]),
+    'opa_cifcaf_set_tie_placement': (ctypes.c_int, [_vp, _i32]),
     'opa_cifcaf_workspace_bytes': (_sz, [_P(Shape)]),
     'opa_cifcaf_workspace_bytes_for': (_sz, [_P(Shape), _P(Params)]),
     'opa_cifcaf_decode': (ctypes.c_int, [_vp, _P(Shape), _P(Params), _vp, _vp, _vp, _vp, _i32,

@@ -188,6 +188,7 @@ struct opa_cifcaf {
     void* dev_block;                   // one allocation holding everything below
     DevSkeleton dev;
     int device;
+    int tie_inside;                    // opa_cifcaf_set_tie_placement: -1 process-wide choice, 0 own launch, 1 inside the association kernel
 };
 
 extern "C" {
@@ -285,6 +286,7 @@ int opa_cifcaf_create(opa_cifcaf** out, int32_t n_keypoints, const int64_t* skel
     d->dev.adj_fwd = (const int32_t*)(base + skel_bytes + off_bytes + 2 * e_bytes);
     d->dev.adj_first = (const int32_t*)(base + skel_bytes + off_bytes + 3 * e_bytes);
     (void)hipGetDevice(&d->device);
+    d->tie_inside = -1;
     *out = d;
     return OPA_OK;
 }
@@ -293,6 +295,12 @@ void opa_cifcaf_destroy(opa_cifcaf* dec) {
     if (!dec) return;
     if (dec->dev_block) (void)hipFree(dec->dev_block);
     delete dec;
+}
+
+int opa_cifcaf_set_tie_placement(opa_cifcaf* dec, int32_t inside_association) {
+    if (!dec) return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_set_tie_placement: null handle");
+    dec->tie_inside = inside_association < 0 ? -1 : inside_association ? 1 : 0;
+    return OPA_OK;
 }
 
 int opa_cifcaf_get_state(const opa_cifcaf* dec, int32_t* n_keypoints, int64_t* skeleton_host, int32_t* n_bones) {
@@ -452,7 +460,8 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     // several decodes in flight (DecodeLanes) the pass overlaps like the association does instead of filling the chip
     // for 80 us per batch.  The separate launch, whose time shows up under its own name, stays the default.
     const char* fuse_ties_env = std::getenv("OPA_FUSE_TIES");
-    const bool fuse_ties = seed_tie_order() >= 1 && (seed_tie_order() == 2 || (fuse_ties_env && std::atoi(fuse_ties_env) != 0));
+    const bool fuse_ties = seed_tie_order() >= 1 && (dec->tie_inside >= 0 ? dec->tie_inside == 1
+                                                       : seed_tie_order() == 2 || (fuse_ties_env && std::atoi(fuse_ties_env) != 0));
     ties.defer = fuse_ties ? 1 : 0;
     e = launch_cifseeds(cif_dev, L.B, L.F, L.H, L.W, L.stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
                         (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap,

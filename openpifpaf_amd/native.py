@@ -157,6 +157,14 @@ class CifCaf:
             pass
 
     # pickle state = (n_keypoints, skeleton), module.cpp:41-53
+    def set_tie_placement(self, inside_association):
+        """Where the pass that puts seeds of equal score into the reference's order runs for this decoder: ``True`` inside the
+        association kernel (what several decodes in flight want -- :class:`DecodeLanes` sets it for two or more lanes),
+        ``False`` a launch of its own (default for one decode at a time), ``None`` the process-wide choice
+        (:func:`set_seed_tie_order`).  Same results bit for bit (``opa_cifcaf_set_tie_placement``)."""
+        _lib.check(_lib.lib().opa_cifcaf_set_tie_placement(
+            self._handle, -1 if inside_association is None else int(bool(inside_association))), 'opa_cifcaf_set_tie_placement')
+
     def __getstate__(self):
         return (self.n_keypoints, self.skeleton, self.max_annotations, self.cifhr_pool_tiles)
 
@@ -359,6 +367,9 @@ class DecodeLanes:
     def __init__(self, n_keypoints, skeleton, *, lanes=2, max_annotations=DEFAULT_MAX_ANNOTATIONS, cifhr_pool_tiles=0):
         self.decoders = [CifCaf(n_keypoints, skeleton, max_annotations=max_annotations, cifhr_pool_tiles=cifhr_pool_tiles)
                          for _ in range(max(1, lanes))]
+        if len(self.decoders) > 1:                       # the tie pass inside the association kernel: +11 % with twelve lanes (round 4)
+            for d in self.decoders:
+                d.set_tie_placement(True)
         self.streams = [torch.cuda.Stream(priority=-1) for _ in self.decoders]
         self._next = 0
 

@@ -232,9 +232,16 @@ def synth_batch(batch, *, seed0=0, height=81, width=81, people=None,
     return np.stack(cifs), np.stack(cafs)
 
 
-def adversarial_fields(seed, *, n_keypoints=17, n_bones=19, height=81, width=81):
+def adversarial_fields(seed, *, n_keypoints=17, n_bones=19, height=81, width=81, people=0):
     """The structureless all-active case a random-initialised head produces
-    (sigmoid ~ 0.5 everywhere): every cell passes every threshold."""
+    (sigmoid ~ 0.5 everywhere): every cell passes every threshold.  ``people`` > 0 plants that many
+    :func:`synth_fields` people into the noise (their blobs replace the background cells they cover), so that
+    the decode of an all-active field has poses to return (COCO-17 fields only)."""
+    if people:
+        cif, caf = adversarial_fields(seed, n_keypoints=n_keypoints, n_bones=n_bones, height=height, width=width)
+        pcif, pcaf = synth_fields(seed + 7919, people, height=height, width=width)
+        return (np.where(pcif[:, 1:2] > 0.3, pcif, cif).astype(np.float32),
+                np.where(pcaf[:, 1:2] > 0.3, pcaf, caf).astype(np.float32))
     rng = np.random.default_rng(seed)
     H, W = height, width
     jj, ii = np.meshgrid(np.arange(H, dtype=np.float64),
