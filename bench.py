@@ -1028,6 +1028,24 @@ def main():
                 out['tensor_batch_ms'] = round((time.perf_counter() - t0) * 1e3, 2)
                 out['value'] = out['pipelined']['images_per_s']
                 out['ms_per_step'] = out['pipelined']['ms_per_batch']
+                # The same pipelined loop in a process of its own (tools/gpu/predictor_probe.py: what a user's process looks
+                # like -- no other model, no other legs' streams and allocations): inside this process the loop has measured
+                # 8 % slower in two rounds running, wherever in the run it sits.  That figure is the leg's value; the
+                # in-process ones stay beside it.
+                try:
+                    import re
+                    import subprocess
+                    probe = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'gpu', 'predictor_probe.py'), '--batches', '24'],
+                                           capture_output=True, text=True, timeout=300)
+                    m = re.search(r'wall ([0-9.]+) ms per batch \(([0-9.]+) images/s\)', probe.stdout)
+                    if m:
+                        out['fresh_process'] = {'ms_per_batch': float(m.group(1)), 'images_per_s': float(m.group(2)),
+                                                'log': [ln for ln in probe.stdout.splitlines() if ln.strip()][-3:]}
+                        out['value'], out['ms_per_step'] = float(m.group(2)), float(m.group(1))
+                    else:
+                        out['fresh_process'] = {'error': (probe.stderr or probe.stdout)[-300:]}
+                except Exception as e:                     # noqa: BLE001 -- the in-process figures stand
+                    out['fresh_process'] = {'error': repr(e)}
                 out['lanes'] = pred.processor.pipeline_depth
                 out['what'] = ('Predictor.numpy_images over %d batches of %d uint8 %dx%d frames: device-side preprocessing, float32 %s, '
                                'HIP decode of the synthetic fields on decode lanes, inverse transform on the device, annotations '

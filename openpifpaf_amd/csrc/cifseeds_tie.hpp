@@ -65,8 +65,9 @@ __device__ __forceinline__ void store_seed(unsigned long long key, int t, int b,
 //   * __final_insertion_sort only moves an element past strictly smaller scores, and the loop leaves segments of at most
 //     16 elements in their final places relative to each other: it is a stable sort INSIDE every such segment -- one
 //     thread per tied seed counts the larger (and the equal, earlier) elements of its segment and stores the seed there.
-// Heapsort (the depth limit, 2 log2 n levels) is not reproduced: such an image keeps the cell-index order and says so
-// in `tie_state` (-1).  Images without ties leave after one look at their sorted scores.
+// Heapsort (the depth limit, 2 log2 n levels) is not reproduced: an image in which a segment that HOLDS EQUAL SCORES
+// reaches the limit keeps the cell-index order and says so in `tie_state` (-1); segments without equal scores that reach it
+// do not matter (whatever sorts them leaves them as the first sort did).  Images without ties leave after one look at their sorted scores.
 constexpr int kTieLdsKeys = 8192;
 constexpr int kTieThreads = 1024;          // of the stand-alone kernel; the pass itself is a template on the workgroup size
 constexpr unsigned kTiedBit = 0x80000000u;      // in a cell index: the seed's score occurs more than once
@@ -369,7 +370,15 @@ __device__ __forceinline__ void tie_subtree(unsigned* BITS, unsigned* IDX, unsig
         top--;
         const int f = stack[3 * top], l = stack[3 * top + 1], d = stack[3 * top + 2];
         tie_wave_fence<true>();                                    // (every lane has read the entry before it is overwritten)
-        if (d == 0) { if (lane == 0) *s_fail = 1; break; }         // the heapsort branch: not reproduced
+        if (d == 0) {
+            // the heapsort branch (std::__partial_sort): not reproduced -- but it only matters where it would have to order
+            // equal scores: a segment without a tied score ends up sorted whatever sorts it, i.e. as the first sort left it
+            bool tied = false;
+            for (int j = f + lane; j < l; j += 64) tied |= (I[j] & kTiedBit) != 0u;
+            if (__ballot(tied) == 0ull) continue;
+            if (lane == 0) *s_fail = 1;
+            break;
+        }
         const int cut = tie_partition<true>(B, I, L, R, f, l);
         if (cut == -2) continue;
         if (cut < 0) { if (lane == 0) *s_fail = 1; break; }
@@ -403,7 +412,18 @@ __device__ __forceinline__ void tie_levels(unsigned* BITS, unsigned* IDX, unsign
     if (n > 16) { if (tid == 0) cur[0] = make_int2(0, n); n_cur = 1; }
     tie_group_sync<LDS>();
     while (n_cur > 0) {
-        if (depth == 0) { if (tid == 0) *s_fail = 1; break; }      // the heapsort branch: not reproduced
+        if (depth == 0) {
+            // the heapsort branch (std::__partial_sort): not reproduced -- but it only matters where it would have to order
+            // equal scores: fail only if one of the segments that are left holds a tied score
+            const TieArr<LDS> IDXA = tie_arr<LDS>(IDX);
+            bool tied = false;
+            for (int s = 0; s < n_cur && !tied; s++) {
+                const int2 sg = cur[s];
+                for (int j = sg.x + tid; j < sg.y; j += NT) tied |= (IDXA(j) & kTiedBit) != 0u;
+            }
+            if (tied) *s_fail = 1;                                 // (any thread: the same value)
+            break;
+        }
         depth--;
         auto children = [&](const int2 sg, int cut) {               // (one thread)
             if (cut < sg.y) atomicOr(&mark[cut >> 5], 1u << (cut & 31));
