@@ -65,16 +65,24 @@ __global__ __launch_bounds__(256, BN == 128 ? OPA_F32_WGS : 3) void gemm_f32_bia
     // staging map: a 32-float row is 8 x 16 B; 256 threads cover 32 rows per pass
     const int s_row = tid >> 3, s_col = (tid & 7) * 4;
     f32x4_t ra[kF32BM / 32], rb[BN / 32];
-    auto fetch = [&](int k0) {                 // global -> registers for K-step k0 (with the operand prologue)
+    // Row pointers once, outside the K loop.  Rows past M read row M - 1 (valid memory; the epilogue never stores them): no
+    // zero fill, no branch around a load -- with both in the loop the compiler put `s_waitcnt vmcnt(0)` BETWEEN the A and the
+    // B loads of a K-step (destination registers doubled as address temporaries), i.e. the A operand's memory latency sat in
+    // front of every K-step's multiplications instead of behind the previous step's (round 5: found in the ISA).
+    const float* pa[kF32BM / 32]; const float* pb[BN / 32];
 #pragma unroll
-        for (int p = 0; p < kF32BM / 32; p++) {
-            const int m = m0 + p * 32 + s_row;
-            ra[p] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            if (m < M) ra[p] = *reinterpret_cast<const f32x4_t*>(A + (size_t)m * K + k0 + s_col);
-        }
+    for (int p = 0; p < kF32BM / 32; p++) {
+        int m = m0 + p * 32 + s_row;
+        if (m > M - 1) m = M - 1;
+        pa[p] = A + (size_t)m * K + s_col;
+    }
 #pragma unroll
-        for (int p = 0; p < BN / 32; p++)
-            rb[p] = *reinterpret_cast<const f32x4_t*>(W + (size_t)(n0 + p * 32 + s_row) * K + k0 + s_col);
+    for (int p = 0; p < BN / 32; p++) pb[p] = W + (size_t)(n0 + p * 32 + s_row) * K + s_col;
+    auto fetch = [&](int k0) {                 // global -> registers for K-step k0 (with the operand prologue): all loads back to back
+#pragma unroll
+        for (int p = 0; p < kF32BM / 32; p++) ra[p] = *reinterpret_cast<const f32x4_t*>(pa[p] + k0);
+#pragma unroll
+        for (int p = 0; p < BN / 32; p++) rb[p] = *reinterpret_cast<const f32x4_t*>(pb[p] + k0);
         if (PRO) {                             // the preceding convolution's bias + ReLU, applied to the raw operand
             const f32x4_t ab = *reinterpret_cast<const f32x4_t*>(a_bias + k0 + s_col);
 #pragma unroll
