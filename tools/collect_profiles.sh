@@ -3,11 +3,11 @@
 # Every profiler run sits under `timeout` (a rocprofv3 that does not exit must not eat the GPU budget), the most
 # important outputs come first and the summary is rewritten after every stage, so a run that is cut short still
 # leaves what it finished.  Counters are collected in passes of their own with --kernel-trace only.
-# Run on the GPU box:  bash tools/collect_profiles.sh   (outputs under gpurun_out/prof_${ROUND:-r4}; the summaries that are
+# Run on the GPU box:  bash tools/collect_profiles.sh   (outputs under gpurun_out/prof_${ROUND:-r5}; the summaries that are
 # judged are copied to profiles/r3/ by hand: rocprofv3_summary.md, *_kernel_stats.csv, pmc_traffic.json).
 cd "${GRAFT_REPO_ROOT:-.}"
 REPO="$PWD"
-OUT="$REPO/gpurun_out/prof_${ROUND:-r4}"
+OUT="$REPO/gpurun_out/prof_${ROUND:-r5}"
 rm -rf "$OUT"; mkdir -p "$OUT"
 STAGES="${STAGES:-1 2 3 4}"        # STAGES=3: only the bench step traces (-> bench_step_summary.md)
 has() { [[ " $STAGES " == *" $1 "* ]]; }
