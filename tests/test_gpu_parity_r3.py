@@ -185,7 +185,20 @@ def test_watchdog_failure_is_flagged_and_raises_on_every_host_path(native, coco_
     ts = torch.classes.openpifpaf_amd_decoder.CifCaf(17, torch.from_numpy(coco_skeleton0))
     with pytest.raises(RuntimeError, match='watchdog'):
         ts.call(dev(cif), 8, dev(caf), 8)
+    # a pipelined batch that fails: its ticket raises -- every time it is asked -- and is SPENT: the lane takes the next
+    # batches as if nothing had happened (round 4: the stale ticket was collected again before every later submit and
+    # failed every later, unrelated batch of that lane)
+    heads = lambda x: (dev(cif)[None], dev(caf)[None])
+    bad = [host.batch_async(heads, torch.zeros((1, 3, 8, 8))) for _ in range(2)]      # one per lane
+    for t in bad:
+        with pytest.raises(_lib.NativeError, match='watchdog'):
+            t.result()
+        with pytest.raises(_lib.NativeError, match='watchdog'):
+            t.result()
+    assert not host._lane_pending
     monkeypatch.delenv('OPA_ASSOC_WATCHDOG_TICKS')
+    good = [host.batch_async(heads, torch.zeros((1, 3, 8, 8))) for _ in range(3)]
+    assert [len(t.result()[0]) for t in good] == [4, 4, 4]
     out, ids, counts = dec.call_batch(dev(cif)[None], 8, dev(caf)[None], 8)      # and the decoder is fine afterwards
     assert native.count_rows(int(counts[0])) == 4 and not native.count_failed(counts).any()
     assert len(ts.call(dev(cif), 8, dev(caf), 8)[0]) == 4

@@ -216,3 +216,35 @@ def test_tie_pass_inside_the_association_kernel_equals_the_separate_launch(nativ
             assert ok, msg
     finally:
         native.set_seed_tie_order(old)
+
+
+def test_tie_placement_per_decoder_is_bit_identical(native, port, coco_skeleton0):
+    """``opa_cifcaf_set_tie_placement`` (round 5): the pass that orders equal scores runs as a launch of its own or inside
+    that decoder's association kernel -- a property of the decoder handle, whatever the process-wide tie order says; two or
+    more ``DecodeLanes`` choose "inside".  Same seeds, same poses, bit for bit, on fields full of equal scores."""
+    from openpifpaf_amd import synth
+    cifs, cafs = synth.synth_batch(6, seed0=77_000)
+    cifs, cafs = to_bf16(cifs), to_bf16(cafs)
+    res = {}
+    for inside in (False, True, None):
+        dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
+        dec.set_tie_placement(inside)
+        out, ids, counts = dec.call_batch(dev(cifs), 8, dev(cafs), 8)
+        state = dec.workspace_view('seed_ties', torch.int32)[:6].cpu().numpy()
+        assert (state == 1).all(), (inside, state)
+        res[inside] = (out.cpu().numpy(), counts.cpu().numpy(),
+                       dec.workspace_view('seed_vxys', torch.float32)[:64].cpu().numpy())
+    for k in (True, None):
+        assert np.array_equal(res[False][1], res[k][1]) and np.array_equal(res[False][2], res[k][2])
+        for b in range(6):
+            n = native.count_rows(int(res[False][1][b]))
+            assert np.array_equal(res[False][0][b, :n], res[k][0][b, :n])
+    lanes = native.DecodeLanes(17, torch.from_numpy(coco_skeleton0), lanes=2)
+    t = [lanes.submit(dev(cifs), 8, dev(cafs), 8) for _ in range(2)]
+    for ticket in t:
+        out, ids, counts = ticket.result()
+        assert np.array_equal(counts.cpu().numpy(), res[False][1])
+    for b in range(6):
+        want = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)[0]
+        ok, msg = compare_annotations(res[True][0][b, :native.count_rows(int(res[True][1][b]))], want)
+        assert ok, (b, msg)

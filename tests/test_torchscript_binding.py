@@ -147,6 +147,49 @@ def test_binding_batch_cifhr_initial_annotations_and_blend(coco_skeleton0):
 
 
 @pytest.mark.gpu
+def test_binding_pool_setting_survives_pickle_and_call_batch_recovers(coco_skeleton0, tmp_path):
+    """scripted and batched users had no way to choose the CIF map's tile pool, and ``call_batch`` could
+    not recover from an overflow.  The class now has ``set_cifhr_pool_tiles`` / ``get_cifhr_pool_tiles`` / ``use_full_pool``,
+    the setting (and ``max_annotations``) is part of the pickle state, and ``call_batch`` decodes again with a full pool when
+    an image comes back flagged -- here: TWO structureless all-active images in one batch, more than pool + spill region hold."""
+    from openpifpaf_amd import native, synth, torchscript
+    from oracle import port
+    C = torchscript.load().CifCaf
+    dec = C(17, torch.from_numpy(coco_skeleton0))
+    assert dec.get_cifhr_pool_tiles() == 0
+    dec.set_cifhr_pool_tiles(2048)
+    dec.set_max_annotations(96)
+
+    class Holder(torch.nn.Module):
+        def __init__(self, d):
+            super().__init__()
+            self.d = d
+
+        def forward(self, cif, caf):
+            return self.d.call_batch(cif, 8, caf, 8)
+    path = str(tmp_path / 'holder.pt')
+    torch.jit.script(Holder(dec)).save(path)
+    loaded = torch.jit.load(path)
+    assert loaded.d.get_cifhr_pool_tiles() == 2048
+    cifs, cafs = synth.synth_batch(2, seed0=70, height=41, width=41, people=(2, 3))
+    out, ids, counts = loaded(torch.from_numpy(cifs).cuda(), torch.from_numpy(cafs).cuda())
+    assert out.shape[1] == 96 and not native.count_failed(counts.cpu().numpy()).any()
+    # the automatic pool: two all-active images overflow pool + spill region, call_batch notices and repeats the decode
+    auto = C(17, torch.from_numpy(coco_skeleton0))
+    pairs = [synth.adversarial_fields(21 + i) for i in range(2)]
+    cif_t = torch.from_numpy(np.stack([c for c, _ in pairs])).cuda()
+    caf_t = torch.from_numpy(np.stack([f for _, f in pairs])).cuda()
+    out, ids, counts = auto.call_batch(cif_t, 8, caf_t, 8)
+    counts = counts.cpu().numpy()
+    assert not native.count_failed(counts).any() and auto.get_cifhr_pool_tiles() == -1
+    for b in range(2):
+        want, _ = port.decode(pairs[b][0], 8, pairs[b][1], 8, coco_skeleton0)
+        assert native.count_rows(int(counts[b])) == len(want)
+    auto.use_full_pool()
+    assert auto.get_cifhr_pool_tiles() == -1
+
+
+@pytest.mark.gpu
 def test_binding_stage_objects_and_cifdet_equal_the_ctypes_mirror(coco_skeleton0):
     """openpifpaf_amd_decoder_utils.{CifHr,CifSeeds,CafScored} and openpifpaf_amd_decoder.CifDet used the way
     the reference's tests/tools use theirs (module.cpp:57-111)."""
