@@ -205,9 +205,9 @@ __device__ __forceinline__ BlendQuery make_query(double x, double y, double xy_s
     return q;
 }
 
-// (One deviation, for garbage input only: a NaN x1 / y1 fails these compares and is skipped, while the reference's
-// early-out form `if (x1 < lo) continue; ...` lets a NaN through to the score, where it poisons the top-2.  Fields
-// that come out of a network's sigmoid / offset arithmetic on finite activations hold no NaN.)
+// (A NaN x1 / y1 fails these compares and is skipped.  The reference's early-out form `if (x1 < lo) continue; ...` lets it
+// through to the score -- but the score is then NaN, and a NaN never satisfies `score >= score_1` or `score > score_2`
+// (cifcaf.cpp:65-73): the entry is ignored there too.  Same result; tests/test_gpu_parity.py::test_grow_connection_blend_nan.)
 __device__ __forceinline__ bool passes_f(const BlendQuery& q, float x1, float y1) {
     return x1 >= q.fxlo && x1 <= q.fxhi && y1 >= q.fylo && y1 <= q.fyhi;
 }

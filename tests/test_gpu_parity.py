@@ -135,6 +135,31 @@ def test_grow_connection_blend(native, port, coco_skeleton0):
     assert native.grow_connection_blend(dev(ref_f[0]), -1e4, -1e4, 1.0) == [0.0, 0.0, 0.0, 0.0]
 
 
+def test_grow_connection_blend_nan(native, port):
+    """Garbage input: list entries with a NaN coordinate or confidence.  The reference lets a NaN coordinate through its
+    window test (cifcaf.cpp:54-57: `if (x1 < lo) continue` is false for a NaN), but the entry's score is then NaN and never
+    satisfies `>=` / `>` (:65-73): it is ignored.  The kernel skips it at the window test.  Same joint, for every mix."""
+    rng = np.random.default_rng(3)
+    for trial in range(60):
+        n = int(rng.integers(3, 200))
+        rows = np.zeros((n, 7), dtype=np.float32)
+        rows[:, 0] = rng.uniform(0.3, 1.0, n)
+        rows[:, 1] = 100.0 + rng.normal(0, 2.5, n)
+        rows[:, 2] = 100.0 + rng.normal(0, 2.5, n)
+        rows[:, 3], rows[:, 4] = rng.uniform(0, 600, n), rng.uniform(0, 600, n)
+        rows[:, 5], rows[:, 6] = 4.0, rng.uniform(1, 8, n)
+        bad = rows.copy()
+        k = rng.integers(0, n, size=max(1, n // 4))
+        bad[k, rng.integers(0, 3, size=len(k))] = np.nan             # confidence, x1 or y1
+        for only_max in (False, True):
+            want = port.grow_connection_blend(bad, 100.0, 100.0, 6.0, 1.0, only_max)
+            got = np.asarray(native.grow_connection_blend(dev(bad), 100.0, 100.0, 6.0, 1.0, only_max))
+            assert np.allclose(got, want, rtol=1e-6, atol=1e-6), (trial, got, want)
+            keep = np.ones(n, dtype=bool)
+            keep[k] = False
+            assert np.array_equal(want, port.grow_connection_blend(rows[keep], 100.0, 100.0, 6.0, 1.0, only_max))
+
+
 def test_grow_connection_blend_window_edges(native, port):
     """Entries exactly on, one float below and one float above the four edges of the filter window
     (cifcaf.cpp:54-57 compares the float entry with double bounds): the kernel tests floats against directed-rounded
