@@ -70,6 +70,18 @@ def build_diagnostic(define, suffix, verbose=True, source='cifcaf.hip'):
     return out
 
 
+def build_variants(verbose=True):
+    """The measured-and-compiled-out designs that the GPU tests still decode through (each a second library, loaded with
+    ``OPA_LIB_PATH`` in a process of its own): the self-serve hand-out of the association kernel
+    (``-DOPA_ASSOC_SELFSERVE=1`` -> ``lib/libopenpifpaf_amd_selfserve.so``, ``tests/test_gpu_selfserve.py``).  Rebuilt only
+    when a source is newer."""
+    out = os.path.join(HERE, 'lib', 'libopenpifpaf_amd_selfserve.so')
+    deps = sources() + glob.glob(os.path.join(CSRC, '*.hpp')) + [os.path.join(HERE, '..', 'include', 'openpifpaf_amd.h')]
+    if os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return [out]
+    return [build_diagnostic('OPA_ASSOC_SELFSERVE=1', 'selfserve', verbose=verbose)]
+
+
 TORCH_SRC = os.path.join(CSRC, 'torch_binding.cpp')
 TORCH_OUT = os.path.join(HERE, 'lib', 'libopenpifpaf_amd_torch.so')
 

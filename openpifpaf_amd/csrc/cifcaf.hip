@@ -11,9 +11,9 @@
 // (cifcaf.cpp:265-411).  So poses are grown SPECULATIVELY by several wavefronts at once and only the
 // accept/reject decision stays sequential.  The workgroup is a small in-order-commit machine:
 //
-//   wave 0, the coordinator, owns everything sequential: the pool of up to 512 live, undecided seeds
-//       (8 slots per lane; a seed is fetched and tested against the occupancy bitmap ONCE, when it enters
-//       the pool), the hand-out of candidates to idle growers, and the commits;
+//   wave 0, the coordinator, owns everything sequential: the pool of up to 256 / 512 live, undecided seeds
+//       (4 or 8 slots per lane, kPoolSlots; a seed is fetched and tested against the occupancy bitmap ONCE, when
+//       it enters the pool), the hand-out of candidates to idle growers, and the commits;
 //   waves 1.., the growers, poll a task slot in LDS, grow the pose of the seed they are handed (best-first
 //       search with the reference's lazy frontier, no barriers), leave pose + occupancy boxes in their
 //       private LDS block and report DONE.  There is no round barrier: a grower that finishes is handed
@@ -60,11 +60,37 @@ namespace opa {
 
 constexpr int kAssocWavesDefault = 12;   // waves per workgroup of the association kernel (OPA_ASSOC_WAVES = 8 | 12 | 16)
 constexpr int kBlendChunks = 8;
-constexpr int kPoolSlots = 8;             // seed-pool slots per coordinator lane: skeletons whose growth state lives in register lanes
-constexpr int kPoolSlotsLds = 8;          // ... large skeletons (LDS variant).  16 (a person has a thousand seeds: a window of several people) was
-                                          // measured in round 4: the image it was meant for gained 15 %, the batch lost 4 % -- every published joint
-                                          // tests twice the slots, and the pool's LDS costs the eleventh grower
-constexpr int kRefillSlots = 8;           // slots per lane one refill round fills (the round's arrays live in registers)
+// Seed-pool slots per coordinator lane.  Every serial step of the coordinator (commit test, head search, hand-out) and every
+// published joint of a grower walks ALL slots, so the pool is as small as the window of live seeds needs to be:
+//   skeletons whose growth state lives in register lanes (COCO): 4 slots = 256 seeds.  Round 5: with the seed list reduced to the
+//     first seed of every cell before the coordinator starts (below), 256 DISTINCT cells reach as far into a crowded image as 512
+//     undeduped seeds did; measured 8 / 4 / 2 / 1 slots: 533 / 503 / 518 / 556 us (COCO batch 32, profiles/r5/assoc_pool_slots.log);
+//   large skeletons (LDS variant, wholebody): 8.  16 (a person has a thousand seeds: a window of several people) was measured in
+//     round 4: the image it was meant for gained 15 %, the batch lost 4 % -- every published joint tests twice the slots, and the
+//     pool's LDS costs the eleventh grower.
+#ifndef OPA_POOL_SLOTS
+#define OPA_POOL_SLOTS 4
+#endif
+#ifndef OPA_POOL_SLOTS_LDS
+#define OPA_POOL_SLOTS_LDS 8
+#endif
+constexpr int kPoolSlots = OPA_POOL_SLOTS;
+// Who hands a candidate to an idle grower (-DOPA_ASSOC_SELFSERVE=1 builds the second variant; build.py builds it as
+// lib/libopenpifpaf_amd_selfserve.so and tests/test_gpu_selfserve.py decodes through it).  0, the default: the coordinator (one
+// more serial step of the one wave everything waits for, 0.7 us per hand-out, a fifth of its time on a crowded image).  1 (round
+// 5): the idle grower itself -- it looks at the mirrored pool the way the coordinator did (smallest eligible seed index, not
+// predicted dead, tested by every candidate in flight, not inside the seed box of a candidate that has not published yet) and
+// CLAIMS the slot with a compare-and-swap on the slot's owner word; the coordinator learns who grows what from those words.
+// Which seeds are grown when is advisory either way: the commit decides, in seed order, from final boxes.  Measured (COCO batch
+// 32, profiles/r5/assoc_selfserve.log): the coordinator then waits for the head's growth 60 % of its time (305 of 513 us on the
+// crowded image, hand-out 88 -> 0, other 127 -> 95) -- and the launch lasts as long as before (508 against 505 us): what is left
+// is the chain of growths itself, not the wave that serialises them.  As a run-time switch the second path costs the default one
+// 1.3 % (eight spilled registers in the growers): compiled out by default; statistics slot 5 is not counted in that variant.
+#ifndef OPA_ASSOC_SELFSERVE
+#define OPA_ASSOC_SELFSERVE 0
+#endif
+constexpr bool kSelfServe = OPA_ASSOC_SELFSERVE != 0;
+constexpr int kPoolSlotsLds = OPA_POOL_SLOTS_LDS;
        // list entries per lane held in registers by the single-pass scan
 
 // LDS words shared between the coordinator and the growers: plain loads/stores made atomic at workgroup
@@ -1592,8 +1618,16 @@ __device__ __forceinline__ bool box_contains(const OccBox& b, int xi, int yi) {
 
 constexpr int kSeedStage = 1024;          // seeds (field, cell) the coordinator keeps staged in LDS beyond its scan position (ring)
 constexpr int kDedupBits = 10;            // buckets (log2) of the coordinator's first-seed-of-a-cell table
-constexpr int kCommitRun = 4;             // commits per round of the coordinator before it looks at the idle growers again
+#ifndef OPA_COMMIT_RUN
+#define OPA_COMMIT_RUN 4
+#endif
+#ifndef OPA_REFILL_NUM
+#define OPA_REFILL_NUM 2
+#endif
+constexpr int kRefillNum = OPA_REFILL_NUM, kRefillDen = 4;   // the pool is refilled when fewer than kRefillNum / kRefillDen of its slots are live
+constexpr int kCommitRun = OPA_COMMIT_RUN;             // commits per round of the coordinator before it looks at the idle growers again
 constexpr int kPoolIdxMask = 0xFFFFFF;    // seed index bits of a slot word (all ones: empty slot); field above
+constexpr int kPreDedupMin = 1024;        // images with fewer seeds go through the pool refill as they are (two refill rounds)
 
 template <int WR>
 __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s) {
@@ -1656,26 +1690,27 @@ __device__ __forceinline__ void pool_catch_up(ImageCtx& c, int e) {
     unsigned bits = 0u;
     // four slots at a time, straight-line: their twelve pool words are ONE LDS round trip, their four boxes a second one
     // (inside the `if`s of a per-slot loop the compiler waited for every load on its own: 24 round trips per call)
+    constexpr int G = WR < 4 ? WR : 4;
 #pragma unroll
-    for (int r0 = 0; r0 < WR; r0 += 4) {
-        int ep[4], sif[4], spk[4];
+    for (int r0 = 0; r0 < WR; r0 += G) {
+        int ep[G], sif[G], spk[G];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < G; r++) {
             ep[r] = c.pool_ep[(r0 + r) * kWave + lane]; sif[r] = c.pool_if[(r0 + r) * kWave + lane];
             spk[r] = c.pool_pack[(r0 + r) * kWave + lane];
         }
 #pragma unroll
-        for (int r = 0; r < 4; r++) asm volatile("" : "+v"(ep[r]), "+v"(sif[r]), "+v"(spk[r]) :: "memory");
-        OccBox bx[4];
+        for (int r = 0; r < G; r++) asm volatile("" : "+v"(ep[r]), "+v"(sif[r]), "+v"(spk[r]) :: "memory");
+        OccBox bx[G];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < G; r++) {
             const int f = (int)((unsigned)sif[r] >> 24);
             bx[r] = c.jbox[f < c.F ? f : 0];
         }
 #pragma unroll
-        for (int r = 0; r < 4; r++) asm volatile("" : "+v"(bx[r].minx), "+v"(bx[r].miny), "+v"(bx[r].maxx), "+v"(bx[r].maxy) :: "memory");
+        for (int r = 0; r < G; r++) asm volatile("" : "+v"(bx[r].minx), "+v"(bx[r].miny), "+v"(bx[r].maxx), "+v"(bx[r].maxy) :: "memory");
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
+        for (int r = 0; r < G; r++) {
             const int f = (int)((unsigned)sif[r] >> 24), idx = sif[r] & kPoolIdxMask;
             if (ep[r] - c.my_epoch > 0 && idx != kPoolIdxMask && idx > c.my_idx && f < c.F &&
                 box_contains(bx[r], spk[r] & 0xfff, (spk[r] >> 12) & 0xfff)) bits |= 1u << (r0 + r);
@@ -2259,7 +2294,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     // another image's ties.  The pass borrows the whole LDS block; what it stores is read after the sync_global() below.
     if (a.tie_fused) {
         cifseeds_tie_body<kThreads>(a.tie, a.tie_sort, p, b, smem);
-        __syncthreads();
+        sync_global();                               // (the seed list it re-ordered is read by every wave below)
     }
 
     ImageCtx c;
@@ -2286,12 +2321,14 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     int* l_off = (int*)sp; sp += sizeof(int) * (K + 1);
     int* l_info = (int*)sp; sp += sizeof(int) * E;
     int* l_first = (int*)sp; sp += sizeof(int) * E;
-    int* sh_ctl = (int*)sp; sp += sizeof(int) * 12;  // 0 exit flag, 1 n_kept, 2 n_dropped, 3 grower ticks, 4 list scans, 5 watchdog,
-                                                     // 6-7 scan timing (diagnostic builds), 8 refill epoch, 9 grower of the head seed
+    int* sh_ctl = (int*)sp; sp += sizeof(int) * 16;  // 0 exit flag, 1 n_kept, 2 n_dropped, 3 grower ticks, 4 list scans, 5 watchdog,
+                                                     // 6-7 scan timing (diagnostic builds), 8 refill epoch, 9 grower of the head seed,
+                                                     // 10-11 see below, 12 the head seed's index (self-serve hand-out)
     int* sh_stats = (int*)sp; sp += sizeof(int) * kAssocStats;
     int* pool_if = (int*)sp; sp += sizeof(int) * WR * kWave;        // the coordinator's seed pool, mirrored for the growers
     int* pool_pack = (int*)sp; sp += sizeof(int) * WR * kWave;
     int* pool_ep = (int*)sp; sp += sizeof(int) * WR * kWave;
+    int* pool_own = (int*)sp; sp += sizeof(int) * WR * kWave;       // 0, or the grower that claimed the slot's seed (self-serve hand-out)
     unsigned* shadow_by = (unsigned*)sp; sp += sizeof(unsigned) * NW * kWave; // [grower][lane]: pool slots in its published boxes
     int* stage_f = (int*)sp; sp += sizeof(int) * kSeedStage;                // the next seeds' field and cell, staged ahead of the pool refill
     int* stage_pk = (int*)sp; sp += sizeof(int) * kSeedStage;
@@ -2335,7 +2372,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         t.t_emit = t.t_done = t.pad0 = t.pad1 = t.coll = 0;
         task[tid] = t;
     }
-    if (tid < 12) sh_ctl[tid] = tid == 9 ? -1 : 0;   // (9: the grower holding the head seed)
+    if (tid < 16) sh_ctl[tid] = tid == 9 || tid == 12 ? -1 : 0;   // (9: the grower holding the head seed, 12: the head seed)
     if (tid == 10) sh_ctl[10] = (int)(private_base - smem);        // 10, 11: for publish_joint's look at the other growers' boxes
     if (tid == 11) sh_ctl[11] = (int)private_bytes | (S << 20) | ((a.collide ? 1 : 0) << 28);
     if (tid < kAssocStats) sh_stats[tid] = 0;
@@ -2343,12 +2380,92 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     if (tid < kPhases) { g_ph[tid] = 0; g_phn[tid] = 0; }
     if (tid < 16) g_ph_last[tid] = clock64();
 #endif
-    for (int k = tid; k < WR * kWave; k += kThreads) { pool_if[k] = kPoolIdxMask; pool_pack[k] = 0; pool_ep[k] = 0; }
+    for (int k = tid; k < WR * kWave; k += kThreads) { pool_if[k] = kPoolIdxMask; pool_pack[k] = 0; pool_ep[k] = 0; pool_own[k] = 0; }
     for (int k = tid; k < NW * kWave; k += kThreads) shadow_by[k] = 0u;
     for (int k = tid; k < (1 << kDedupBits); k += kThreads) dedup[k] = ~0ull;
     const bool dedup_on = a.dedup != 0;
+    constexpr bool self = kSelfServe;                // idle growers take their next candidate themselves (see kPoolSlots' neighbour above)
     c.adj_off = l_off; c.slot_info = l_info; c.adj_first = l_first;
-    sync_global();                                   // bitmap zeros are in memory before anyone marks or tests
+
+    // ---- seeds in score order, cifcaf.cpp:206-231
+    int n_seeds = a.seed_count[b];
+    if (n_seeds > a.seed_cap) n_seeds = a.seed_cap;
+    const int n_seeds_all = n_seeds;
+    const int32_t* seed_f = a.seed_f + (size_t)b * a.seed_cap;
+    const float4* seed_vxys = reinterpret_cast<const float4*>(a.seed_vxys) + (size_t)b * a.seed_cap;
+    const int32_t* seed_cell = a.seed_cell + (size_t)b * a.seed_cap;
+
+    // ---- [r5] the first seed of every occupancy cell, found by the whole workgroup before the coordinator sees any of them.
+    // The refill's dedupe argument (below: of the seeds of ONE cell of a field only the first can ever be free at its turn)
+    // does not need the pool: it is a property of the seed list.  The coordinator walked all ~5 000 seeds of a crowded COCO
+    // image through its refill (two dependent memory round trips per round of 512, eight or nine refills, 60-70 us of the ONE
+    // wave everything waits for) to admit the ~900 that are the first of their cell; here twelve waves do that walk once, in a
+    // few microseconds, while the LDS work area is still free: a table of (cell key << 32 | seed index) minima in it, an ordered
+    // compaction of the survivors (original index | field << 24, cell) into the image's sort-key array -- the sort and the tie
+    // pass are done with it -- and the coordinator scans that list instead.  A bucket shared by two cells keeps the smaller key's
+    // seeds exact and admits the other's (the refill's own test against the bitmap, which stays, sees those).  Seed order is
+    // preserved, the dropped seeds are dead for good: the accepted seeds and their poses are the sequential loop's.
+    const int32_t* scan_f = seed_f;                  // what the coordinator's refill reads at scan position i: the seed's field ...
+    const int32_t* scan_pk = seed_cell;              // ... and its cell word
+    bool pre = false;
+    {
+        const int n_it = (n_seeds + kThreads - 1) / kThreads;
+        pre = dedup_on && a.prededup && a.tie_sort.keys != nullptr && n_seeds > kPreDedupMin && n_it * NW < 2 * kSeedStage;
+        if (pre) {
+            int32_t* kept_if = reinterpret_cast<int32_t*>(a.tie_sort.keys + (size_t)b * a.tie_sort.sort_cap);
+            int32_t* kept_pk = kept_if + a.tie_sort.sort_cap;
+            const size_t area = (size_t)S * private_bytes;
+            int tb = 31 - __clz((int)(area >> 3));
+            if (tb > 14) tb = 14;
+            unsigned long long* tbl = reinterpret_cast<unsigned long long*>(work_base);
+            int* cnt = stage_f;                      // (stage_f and stage_pk: 2 * kSeedStage words, empty until the coordinator starts)
+            for (int k = tid; k < (1 << tb); k += kThreads) tbl[k] = ~0ull;
+            __syncthreads();
+            for (int i = tid; i < n_seeds; i += kThreads) {
+                const unsigned key = ((unsigned)seed_f[i] << 24) | ((unsigned)seed_cell[i] & 0xFFFFFFu);
+                __hip_atomic_fetch_min(&tbl[(key * 2654435761u) >> (32 - tb)], ((unsigned long long)key << 32) | (unsigned)i,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __syncthreads();
+            auto first_of_cell = [&](int i, int* f, int* pk) -> bool {
+                if (i >= n_seeds) return false;
+                *f = seed_f[i]; *pk = seed_cell[i];
+                const unsigned key = ((unsigned)*f << 24) | ((unsigned)*pk & 0xFFFFFFu);
+                const unsigned long long v = tbl[(key * 2654435761u) >> (32 - tb)];
+                return !((unsigned)(v >> 32) == key && (unsigned)v != (unsigned)i);
+            };
+            for (int it = 0; it < n_it; it++) {
+                int f, pk;
+                const unsigned long long m = __ballot(first_of_cell(it * kThreads + tid, &f, &pk));
+                if (lane == 0) cnt[it * NW + wave] = __popcll(m);
+            }
+            __syncthreads();
+            if (wave == 0) {                         // exclusive prefix over the (iteration, wave) counts, in seed order
+                const int n_e = n_it * NW, per = (n_e + kWave - 1) / kWave;
+                int sum = 0;
+                for (int k = 0; k < per; k++) { const int e = lane * per + k; if (e < n_e) sum += cnt[e]; }
+                int incl = sum;
+                for (int d = 1; d < kWave; d <<= 1) { const int t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+                int run = incl - sum;
+                for (int k = 0; k < per; k++) { const int e = lane * per + k; if (e < n_e) { const int t = cnt[e]; cnt[e] = run; run += t; } }
+                if (lane == kWave - 1) cnt[2 * kSeedStage - 1] = incl;
+            }
+            __syncthreads();
+            for (int it = 0; it < n_it; it++) {
+                int f = 0, pk = 0;
+                const int i = it * kThreads + tid;
+                const bool keep = first_of_cell(i, &f, &pk);
+                const unsigned long long m = __ballot(keep);
+                if (keep) {
+                    const int pos = cnt[it * NW + wave] + prefix_count(m);
+                    kept_if[pos] = i | (f << 24); kept_pk[pos] = pk;
+                }
+            }
+            n_seeds = cnt[2 * kSeedStage - 1];
+            scan_f = kept_if; scan_pk = kept_pk;
+        }
+    }
+    sync_global();                                   // bitmap zeros are in memory before anyone marks or tests (and the compacted seed list)
     RegSkeleton rs; rs.slot_info = 0; rs.slot_first = 0; rs.off = 0; rs.off1 = 0;
     if constexpr (REG) {                             // lane t: directed bone t; lane j: adjacency range of joint j
         if (lane < E) { rs.slot_info = l_info[lane]; rs.slot_first = l_first[lane]; }
@@ -2399,13 +2516,6 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         __syncthreads();
     }
 
-    // ---- seeds in score order, cifcaf.cpp:206-231
-    int n_seeds = a.seed_count[b];
-    if (n_seeds > a.seed_cap) n_seeds = a.seed_cap;
-    const int32_t* seed_f = a.seed_f + (size_t)b * a.seed_cap;
-    const float4* seed_vxys = reinterpret_cast<const float4*>(a.seed_vxys) + (size_t)b * a.seed_cap;
-    const int32_t* seed_cell = a.seed_cell + (size_t)b * a.seed_cap;
-
     if (wave == 0) {
         // the always-on statistics live in LDS (lane 0 adds, no return value): two dozen scalar counters carried through this
         // loop spill scalar registers into vector lanes, and the growers' scans pay for that
@@ -2413,12 +2523,13 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             if (lane == 0) __hip_atomic_fetch_add(&sh_stats[k], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
         int n_commits = 0;
+        if (pre) stat(23, n_seeds_all - n_seeds);        // later seeds of a cell, dropped before the pool saw them
         // the per-phase tick counters (slots 12, 17-20) cost a clock read and a wait each: only when asked for (OPA_ASSOC_TIMING=1,
         // tools/gpu/r3_probe.py); the event counters are always on
         const bool timing = a.timing != 0;
         auto tick = [&]() -> long long { return timing ? wall_clock64() : 0ll; };
         // ================================================================= coordinator
-        // The pool: up to 512 LIVE, undecided seeds, 8 slots per lane in any order (mirrored in LDS for the
+        // The pool: up to WR * 64 LIVE, undecided seeds, WR slots per lane in any order (mirrored in LDS for the
         // growers).  Invariant: every seed below scan_pos is either in a slot or dead for good (inside a box of
         // an accepted pose), so each seed is fetched and tested against the bitmap exactly once; afterwards it
         // is tested against every newly accepted pose by box containment.
@@ -2431,7 +2542,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         unsigned gmap[(WR + 7) / 8];                     // nibble r: the grower slot r was handed to
 #pragma unroll
         for (int k = 0; k < (WR + 7) / 8; k++) gmap[k] = 0u;
-        constexpr int HR = kRefillSlots;
+        constexpr int HR = WR < 8 ? WR : 8;      // slots per lane one refill round fills (the round's arrays live in registers)
         auto gm_get = [&](int r) -> int { return (int)((gmap[r >> 3] >> (4 * (r & 7))) & 15u); };
         auto gm_set = [&](int r, int g) {
 #pragma unroll
@@ -2462,8 +2573,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             for (int r = 0; r < 8; r++)
                 if (pf_end < limit) {
                     const int idx = pf_end + lane, ii = idx < n_seeds ? idx : 0;
-                    __builtin_amdgcn_global_load_lds((gint*)seed_f + ii, (lint*)stage_f + (pf_end & (kSeedStage - 1)), 4, 0, 0);
-                    __builtin_amdgcn_global_load_lds((gint*)seed_cell + ii, (lint*)stage_pk + (pf_end & (kSeedStage - 1)), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gint*)scan_f + ii, (lint*)stage_f + (pf_end & (kSeedStage - 1)), 4, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gint*)scan_pk + ii, (lint*)stage_pk + (pf_end & (kSeedStage - 1)), 4, 0, 0);
                     pf_end += kWave;
                 }
         };
@@ -2481,7 +2592,20 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
 #pragma unroll
             for (int r = 0; r < WR; r++)
                 if ((occupied >> r) & 1u) m = min(m, (unsigned)(s_if[r] & kIdxMask));
+            const unsigned was = hd;
             hd = ~wave_max_u32(~m);
+            if (self && hd != was && lane == 0) __hip_atomic_store(&sh_ctl[12], (int)hd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        // self-serve: who grows what is read from the slots' owner words (the growers claim them), once per round
+        auto read_owners = [&]() {
+            emitted = 0u;
+#pragma unroll
+            for (int k = 0; k < (WR + 7) / 8; k++) gmap[k] = 0u;
+#pragma unroll
+            for (int r = 0; r < WR; r++) {
+                const int o = flag_peek(&pool_own[r * kWave + lane]);
+                if (o != 0 && (occupied >> r) & 1u) { emitted |= 1u << r; gm_set(r, o); }
+            }
         };
         auto head_grower = [&]() -> int {
             int mine = -1;
@@ -2501,23 +2625,27 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
 
             // ---- 1. commit the head while its growth is done (:213-230): every commit of a run costs the commit alone,
             //         not a round of the whole loop (a crowded image ends in dozens of poses of one or two joints)
+            if (self) read_owners();
             int hg = hd == kNone ? -1 : head_grower();
-            for (int run = 0; run < kCommitRun && hg >= 0 && flag_load(&task[hg].state) == kTaskDone; run++) {
+            for (int run = 0; run < kCommitRun && hg >= 0 && flag_load(&task[hg].state) == kTaskDone &&
+                              (!self || task[hg].seed == (int)hd); run++) {
                 const long long t_cm = tick();
                 const PoseView q = pose_of_block(private_base, hg - 1, private_bytes, K);
                 unsigned dead = 0u;                      // pooled seeds inside one of its joint boxes (:211 for them)
+                constexpr int CG = WR < 4 ? WR : 4;
 #pragma unroll
-                for (int r0 = 0; r0 < WR; r0 += 4) {     // four boxes per LDS round trip
-                    OccBox bb[4];
+                for (int r0 = 0; r0 < WR; r0 += CG) {    // four boxes per LDS round trip
+                    OccBox bb[CG];
 #pragma unroll
-                    for (int r = 0; r < 4; r++) bb[r] = q.box[(occupied >> (r0 + r)) & 1u ? (unsigned)s_if[r0 + r] >> 24 : 0u];
+                    for (int r = 0; r < CG; r++) bb[r] = q.box[(occupied >> (r0 + r)) & 1u ? (unsigned)s_if[r0 + r] >> 24 : 0u];
 #pragma unroll
-                    for (int r = 0; r < 4; r++)
+                    for (int r = 0; r < CG; r++)
                         if ((occupied >> (r0 + r)) & 1u &&
                             (box_contains(bb[r], s_pack[r0 + r] & 0xfff, (s_pack[r0 + r] >> 12) & 0xfff) ||
                              (unsigned)(s_if[r0 + r] & kIdxMask) == hd))
                             dead |= 1u << (r0 + r);
                 }
+                if (!self) {
                 if (__ballot((dead & emitted) != 0u) != 0ull) {   // growths of seeds that just died: drop finished ones, stop running ones
                     int n_drop = 0, n_stop = 0;
 #pragma unroll
@@ -2538,6 +2666,28 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                         occupied &= ~(1u << r); emitted &= ~(1u << r); s_if[r] |= kIdxMask;
                         pool_if[r * kWave + lane] = s_if[r];
                     }
+                } else {
+                    // the slot is emptied FIRST, then its owner word is taken: a grower that claims the slot in between finds it
+                    // empty when it looks again (try_claim), one that claimed it before is found here and stopped
+                    int n_drop = 0, n_stop = 0;
+#pragma unroll
+                    for (int r = 0; r < WR; r++)
+                        if ((dead >> r) & 1u) {
+                            const int idx = s_if[r] & kIdxMask;
+                            occupied &= ~(1u << r); emitted &= ~(1u << r); s_if[r] |= kIdxMask;
+                            __hip_atomic_store(&pool_if[r * kWave + lane], s_if[r], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            const int g = __hip_atomic_exchange(&pool_own[r * kWave + lane], 0, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (g != 0 && (unsigned)idx != hd) {
+                                // (a claim whose task is not set up yet -- the seed word is still the last task's -- finds the flag when it starts)
+                                if (flag_load(&task[g].state) == kTaskDone && task[g].seed == idx) { flag_store(&task[g].state, kTaskIdle); n_drop++; }
+                                else { flag_store(&task[g].cancel, 1); n_stop++; }
+                            }
+                        }
+                    if (__ballot(n_drop + n_stop > 0) != 0ull) {
+#pragma unroll
+                        for (int k = 0; k < WR; k++) { stat(3, __popcll(__ballot(n_drop > k))); stat(2, __popcll(__ballot(n_stop > k))); }
+                    }
+                }
                 if (a.trace && n_commits < kAssocTrace && lane == 0) {
                     int* tr = a.trace + ((size_t)b * kAssocTrace + n_commits) * 4;
                     tr[0] = (int)(wall_clock64() - t_kernel); tr[1] = task[hg].t_emit; tr[2] = task[hg].t_done;
@@ -2577,11 +2727,11 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             }
             const bool g_live = (g_state == kTaskAssigned || g_state == kTaskDone) && !g_cancel;
             const unsigned long long live_mask = __ballot(g_live);
-            if (__ballot(unver != 0u) != 0ull && __ballot(g_live && g_ack != epoch) == 0ull) unver = 0u;   // everyone has tested the newcomers
+            if (!self && __ballot(unver != 0u) != 0ull && __ballot(g_live && g_ack != epoch) == 0ull) unver = 0u;   // everyone has tested the newcomers
 
             // ---- 3. refill free slots with the next seeds that are still free in the bitmap (:211 for the
             //         poses accepted so far); slot (r, lane) takes the seed of its rank among the free slots
-            if (scan_pos < n_seeds && 2 * n_live < WR * kWave) {
+            if (scan_pos < n_seeds && kRefillDen * n_live < kRefillNum * WR * kWave) {
                 const long long t_ph = tick();
                 if (marks_pending) {                     // accepted poses are marked by their growers: all of them are done
                     while (__ballot(is_grower_lane && flag_load(&task[lane].state) == kTaskAccepted) != 0ull &&
@@ -2622,12 +2772,19 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     for (int r = 0; r < HR; r++) beyond |= nidx[r] >= pf_end && nidx[r] < n_seeds;
                     if (__ballot(beyond) != 0ull) {
 #pragma unroll
-                        for (int r = 0; r < HR; r++) { const int ii = nidx[r] < n_seeds ? nidx[r] : 0; ff[r] = seed_f[ii]; pk[r] = seed_cell[ii]; }
+                        for (int r = 0; r < HR; r++) { const int ii = nidx[r] < n_seeds ? nidx[r] : 0; ff[r] = scan_f[ii]; pk[r] = scan_pk[ii]; }
 #pragma unroll
                         for (int r = 0; r < HR; r++) asm volatile("" : "+v"(ff[r]), "+v"(pk[r]) :: "memory");
                     } else {
 #pragma unroll
                         for (int r = 0; r < HR; r++) { ff[r] = stage_f[nidx[r] & (kSeedStage - 1)]; pk[r] = stage_pk[nidx[r] & (kSeedStage - 1)]; }
+                    }
+                    // sw: the slot word of the seed (its index in the image's seed list | field << 24) -- what the compacted list holds
+                    int sw[HR];
+#pragma unroll
+                    for (int r = 0; r < HR; r++) {
+                        sw[r] = pre ? ff[r] : (nidx[r] | (ff[r] << 24));
+                        ff[r] = (int)((unsigned)sw[r] >> 24);
                     }
 #pragma unroll
                     for (int r = 0; r < HR; r++) {
@@ -2672,7 +2829,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                             const unsigned sb = 1u << (r0 + r);
 #pragma unroll
                             for (int q = 0; q < WR; q += HR)     // (static register indices: the slot is r0 + r)
-                                if (q == r0) { s_pack[q + r] = pk[r]; s_if[q + r] = nidx[r] | (ff[r] << 24); }
+                                if (q == r0) { s_pack[q + r] = pk[r]; s_if[q + r] = sw[r]; }
                             occupied |= sb; emitted &= ~sb; ever &= ~sb; fresh |= sb;
                             if (dedup_on) {
                                 const size_t word = ((size_t)ff[r] * c.occ_h + ((pk[r] >> 12) & 0xfff)) * c.occ_wpr + ((pk[r] & 0xfff) >> 5);
@@ -2687,7 +2844,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     }
                     scan_pos = scan_pos + base < n_seeds ? scan_pos + base : n_seeds;
                     count_live();
-                    if (2 * n_live >= WR * kWave) break;
+                    if (kRefillDen * n_live >= kRefillNum * WR * kWave) break;
                     if constexpr (WR > HR) r0 = r0 + HR < WR ? r0 + HR : 0;
                 }
                 stat(6, 1);
@@ -2698,7 +2855,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
 #pragma unroll
                 for (int r = 0; r < WR; r++)
                     if ((fresh >> r) & 1u) {
-                        pool_if[r * kWave + lane] = s_if[r]; pool_pack[r * kWave + lane] = s_pack[r]; pool_ep[r * kWave + lane] = epoch;
+                        pool_pack[r * kWave + lane] = s_pack[r]; pool_ep[r * kWave + lane] = epoch;
+                        __hip_atomic_store(&pool_if[r * kWave + lane], s_if[r], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (the claimers read this word first)
                     }
                 if (fresh)
                     for (int g = 1; g <= S; g++) atomicAnd(&shadow_by[g * kWave + lane], ~fresh);
@@ -2732,9 +2890,10 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     for (int r = 0; r < WR; r++)
                         if ((pc >> r) & 1u) {
                             const int g = gm_get(r);
-                            if (flag_load(&task[g].state) == kTaskAssigned) {
+                            if (flag_load(&task[g].state) == kTaskAssigned &&
+                                (!self || (task[g].seed == (s_if[r] & kIdxMask) && !flag_peek(&task[g].cancel)))) {
                                 flag_store(&task[g].cancel, 1);
-                                emitted &= ~(1u << r);
+                                if (!self) emitted &= ~(1u << r);   // (self-serve: the grower gives the slot back when it has stopped)
                                 n_pc++;
                                 d_sel = g;               // the stopped growth, and the (first) live candidate whose box holds its seed
                                 for (int h = NW - 1; h >= 1; h--)
@@ -2778,8 +2937,9 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                         if (((occupied & emitted) >> r) & 1u && gm_get(r) == d &&
                             (s_if[r] & kIdxMask) == rlane(g_seed, d)) bit |= 1u << r;
                     if (__ballot(bit != 0u) == 0ull) continue;
+                    if (self && rlane(g_cancel, d)) continue;   // (told already)
                     if (lane == 0) flag_store(&task[d].cancel, 1);
-                    emitted &= ~bit;
+                    if (!self) emitted &= ~bit;
                     const unsigned v = (shadow_by[d * kWave + lane] & occupied) | bit;
                     if (v) atomicOr(&shadow_by[h * kWave + lane], v);
                     shadow |= v; ever |= v;
@@ -2789,7 +2949,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
 
             // ---- 5. hand the next candidates, in seed order, to the idle growers (newcomers the candidates in
             //         flight have not tested yet wait for that -- except the head, which nothing can shadow)
-            unsigned long long idle = __ballot(g_state == kTaskIdle);
+            unsigned long long idle = self ? 0ull : __ballot(g_state == kTaskIdle);
             if (idle) {
                 const long long t_em = tick();
                 // A candidate's own seed box is published by its grower a moment after the hand-out.  Until then (npub == 0)
@@ -2847,6 +3007,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 continue;                                // pool ran empty: refill
             }
             if (hg < 0) hg = head_grower();
+            if (self && hg < 0) { read_owners(); hg = head_grower(); }   // (claimed since the round's look at the owner words?)
             if (hg != last_hg) { if (lane == 0) __hip_atomic_store(&sh_ctl[9], hg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); last_hg = hg; }
             if (hg < 0) {
                 // A head that was never handed out, or whose growth was stopped by a prediction that did not
@@ -2858,10 +3019,16 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     __builtin_amdgcn_s_sleep(1);         // a grower is idle or about to be
                     continue;
                 }
+                // (self-serve: a grower may have claimed the head a moment ago -- its slot says so before the owner word is read here)
+                if (self && __ballot(is_grower_lane && vstate == kTaskAssigned && task[lane].seed == (int)hd) != 0ull) continue;
                 const unsigned key = is_grower_lane ? ((unsigned)task[lane].seed << 6) | (unsigned)lane : 0u;
                 const int victim = (int)(wave_max_u32(key) & 63u);
                 const int vseed = task[victim].seed;
                 if (lane == 0) flag_store(&task[victim].cancel, 1);
+                if (self) {                              // (it stops or its result is dropped by step 2, gives its slot back and takes the head)
+                    stat(4, 1);
+                    continue;
+                }
                 while (flag_load(&task[victim].state) == kTaskAssigned && wall_clock64() - t_kernel <= kWatchdogTicks)
                     __builtin_amdgcn_s_sleep(2);
                 if (lane == 0) flag_store(&task[victim].state, kTaskIdle);
@@ -2884,6 +3051,23 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                wall_clock64() - t_kernel <= kWatchdogTicks)
             __builtin_amdgcn_s_sleep(1);
         if (wall_clock64() - t_kernel > kWatchdogTicks) watchdog = true;
+#ifdef OPA_ASSOC_WATCHDOG_DUMP
+        if (watchdog && a.trace) {                       // diagnostic builds: what everybody was doing when the watchdog fired
+            int* tr = a.trace + (size_t)b * kAssocTrace * 4;
+            if (lane < NW) { int* t4 = tr + (40 + lane) * 4; t4[0] = task[lane].state; t4[1] = task[lane].seed; t4[2] = task[lane].cancel; t4[3] = task[lane].npub | (task[lane].pad1 << 16); }
+            if (lane == 0) { int* t4 = tr + 60 * 4; t4[0] = (int)hd; t4[1] = scan_pos; t4[2] = n_live; t4[3] = epoch; }
+            unsigned best = kNone; int bo = 0, be = 0, bs = 0;
+#pragma unroll
+            for (int r = 0; r < WR; r++) {
+                const unsigned idx = (unsigned)(s_if[r] & kIdxMask);
+                if ((occupied >> r) & 1u && idx < best) { best = idx; bo = pool_own[r * kWave + lane]; be = pool_ep[r * kWave + lane]; bs = 0;
+                    for (int g = 1; g < NW; g++) bs |= ((shadow_by[g * kWave + lane] >> r) & 1u) << g; }
+            }
+            const unsigned mn = ~wave_max_u32(~best);
+            if (best == mn && mn != kNone) { int* t4 = tr + 61 * 4; t4[0] = (int)mn; t4[1] = bo; t4[2] = be; t4[3] = bs; }
+            if (lane == 0) { int* t4 = tr + 62 * 4; t4[0] = sh_ctl[12]; t4[1] = sh_ctl[9]; t4[2] = (int)iter; t4[3] = n_commits; }
+        }
+#endif
         if (lane == 0) {
             // failure codes (the image then reports no poses and OPA_COUNT_FAILED, its status word is minus the code):
             // 1 the watchdog fired, 2 the image's CIF map did not fit its tile pool (every lookup into a missing tile was wrong)
@@ -2893,7 +3077,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         }
         __builtin_amdgcn_s_setprio(0);
         if (lane == 0) {
-            sh_stats[7] = n_seeds; sh_stats[8] = (int)(wall_clock64() - t_kernel);
+            sh_stats[7] = n_seeds_all; sh_stats[8] = (int)(wall_clock64() - t_kernel);
             sh_stats[12] = (int)wait_ticks; sh_stats[15] = (int)iter;
         }
     } else if (wave <= S) {
@@ -2901,6 +3085,85 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
         TaskSlot* my = &task[wave];
         c.cancel = &my->cancel;
         long long busy_ticks = 0;
+        int my_pos = -1;                                 // self-serve: the pool slot (slot * 64 + lane) this wave claimed last
+        // Self-serve hand-out: take the next candidate -- the smallest-index pooled seed that is nobody's, is not predicted dead by
+        // a candidate in flight, has been tested by every candidate in flight (or is the head, which nothing can shadow), and does
+        // not lie in the seed box of an earlier candidate that has not published that box yet -- by a compare-and-swap on the
+        // slot's owner word.  What the coordinator's hand-out loop did (step 5), done by the wave that would otherwise wait for it.
+        auto try_claim = [&]() -> bool {
+            constexpr unsigned kNone = 0xFFFFFFFFu;
+            int st = kTaskIdle, cn = 0, sd = -1, npub = 0, gpk = 0, gf = -1, ack = 0;
+            const bool gl = lane >= 1 && lane <= S && lane != wave;
+            if (gl) {
+                st = flag_load(&task[lane].state); cn = flag_peek(&task[lane].cancel); sd = task[lane].seed;
+                npub = flag_peek(&task[lane].npub); gpk = task[lane].pk; gf = task[lane].f; ack = flag_peek(&task[lane].pad1);
+            }
+            const bool live = gl && (st == kTaskAssigned || st == kTaskDone) && !cn;
+            const unsigned long long live_mask = __ballot(live);
+            const unsigned min_ack = ~wave_max_u32(~(live ? (unsigned)ack : kNone));   // (all ones: no candidate in flight)
+            const unsigned hd_now = (unsigned)flag_peek(&sh_ctl[12]);
+            int sif[WR], spk[WR];
+            unsigned elig = 0u;
+            {
+                int sep[WR], own[WR];
+#pragma unroll
+                for (int r = 0; r < WR; r++) {
+                    sif[r] = flag_peek(&pool_if[r * kWave + lane]); spk[r] = pool_pack[r * kWave + lane];
+                    sep[r] = pool_ep[r * kWave + lane]; own[r] = flag_peek(&pool_own[r * kWave + lane]);
+                }
+                unsigned sh = 0u;
+                for (int g = 1; g <= S; g++)
+                    if ((live_mask >> g) & 1ull) sh |= shadow_by[g * kWave + lane];
+#pragma unroll
+                for (int r = 0; r < WR; r++) {
+                    const unsigned idx = (unsigned)(sif[r] & kPoolIdxMask);
+                    const bool tested = min_ack == kNone || sep[r] - (int)min_ack <= 0 || idx == hd_now;
+                    if (idx != (unsigned)kPoolIdxMask && own[r] == 0 && !((sh >> r) & 1u) && tested) elig |= 1u << r;
+                }
+            }
+            const bool unp = live && npub == 0;
+            for (;;) {
+                unsigned l_min = kNone; int l_r = 0, l_pk = 0, l_if = 0;
+#pragma unroll
+                for (int r = 0; r < WR; r++) {
+                    const unsigned idx = (unsigned)(sif[r] & kPoolIdxMask);
+                    if ((elig >> r) & 1u && idx < l_min) { l_min = idx; l_r = r; l_pk = spk[r]; l_if = sif[r]; }
+                }
+                const unsigned mn = ~wave_max_u32(~l_min);
+                if (mn == kNone) return false;
+                const bool own_lane = l_min == mn;
+                const int owner = __builtin_ctzll(__ballot(own_lane));
+                const int pk = rlane(l_pk, owner), fo = (int)((unsigned)rlane(l_if, owner) >> 24), slot = rlane(l_r, owner);
+                {   // inside the seed box of an earlier candidate that has not published it yet?
+                    const int ccx = gpk & 0xfff, ccy = (gpk >> 12) & 0xfff, half = (gpk >> 24) & 0xff;
+                    const int dx = (pk & 0xfff) - ccx, dy = ((pk >> 12) & 0xfff) - ccy;
+                    const bool hit = unp && gf == fo && (unsigned)sd < mn && dx > -half && dx < half && dy > -half && dy < half;
+                    if (__ballot(hit) != 0ull) { if (own_lane) elig &= ~(1u << l_r); continue; }
+                }
+                int won = 0;
+                if (lane == owner) {
+                    flag_store(&my->cancel, 0);          // (before the claim: a cancel that follows it is meant for it)
+                    int* ow = &pool_own[slot * kWave + lane];
+                    int expected = 0;
+                    if (__hip_atomic_compare_exchange_strong(ow, &expected, wave, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        // the slot may have changed hands between the look at it and the claim: the occupant has to be the same
+                        if (flag_load(&pool_if[slot * kWave + lane]) == l_if) won = 1;
+                        else { expected = wave; __hip_atomic_compare_exchange_strong(ow, &expected, 0, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                    }
+                }
+                if (__ballot(won) == 0ull) return false; // (somebody else's: look again at everything -- the winner's seed box is among the unpublished ones then)
+                my_pos = slot * kWave + owner;
+                shadow_by[wave * kWave + lane] = 0u;     // nothing published for this task yet
+                if (lane == 0) {
+                    my->seed = (int)mn; my->pk = pk; my->f = fo; my->npub = 0; my->coll = 0;
+                    my->t_emit = (int)(wall_clock64() - t_kernel);
+                    __hip_atomic_fetch_add(&sh_stats[0], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                wave_sync();
+                if (lane == 0) flag_store(&my->state, kTaskAssigned);
+                return true;
+            }
+        };
         for (;;) {
             bool leave = false;
             for (;;) {
@@ -2926,6 +3189,16 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     continue;
                 }
                 if (flag_load(&sh_ctl[0]) || wall_clock64() - t_kernel > 2 * kWatchdogTicks) { leave = true; break; }
+                if (self && state == kTaskIdle) {
+                    if (my_pos >= 0) {                   // a growth that was stopped, or a result that was dropped: the seed is somebody's again
+                        if (lane == 0) {
+                            int expected = wave;
+                            __hip_atomic_compare_exchange_strong(&pool_own[my_pos], &expected, 0, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        my_pos = -1;
+                    }
+                    if (try_claim()) break;
+                }
                 if (help_on) {                           // nothing of its own to do: a connection of the growth the commit waits for
                     const int hgw = flag_peek(&sh_ctl[9]);
                     if (hgw >= 1 && hgw <= S && hgw != wave) {
@@ -3133,8 +3406,8 @@ static hipError_t launch_fc_nw(const AssocArgs& a, const DevSkeleton& sk, const 
 template <bool REG, int NW>
 static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
     const int K = a.K, A = a.A, E = 2 * A;
-    size_t shared = sizeof(TaskSlot) * NW + (sizeof(unsigned long long) << kDedupBits) + sizeof(int) * (3 * E + K + 1 + 12 + kAssocStats)
-                  + sizeof(int) * (3 * (REG ? kPoolSlots : kPoolSlotsLds) + NW) * kWave + sizeof(int) * 2 * kSeedStage;
+    size_t shared = sizeof(TaskSlot) * NW + (sizeof(unsigned long long) << kDedupBits) + sizeof(int) * (3 * E + K + 1 + 16 + kAssocStats)
+                  + sizeof(int) * (4 * (REG ? kPoolSlots : kPoolSlotsLds) + NW) * kWave + sizeof(int) * 2 * kSeedStage;
     shared = (shared + 15) / 16 * 16 + (REG && a.list_bbox ? sizeof(float4) * E * kListBboxChunks : 0);
     // work area behind it: one private block per grower while poses grow, the keypoint-NMS arrays afterwards
 #ifdef OPA_ASSOC_PHASE_TIMING
@@ -3199,6 +3472,8 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     // when the map is reduced at all, occupancy.cpp:14-18: with reduction == 1 the box is the raw joint scale)
     a.dedup = (p.occupancy_reduction != 1.0 && p.occupancy_min_scale_reduced >= 1.0) ? 1 : 0;
     if (const char* e = getenv("OPA_ASSOC_DEDUP")) { if (atoi(e) == 0) a.dedup = 0; }   // A/B and tests: same result without it
+    a.prededup = 1;
+    if (const char* e = getenv("OPA_ASSOC_PREDEDUP")) a.prededup = atoi(e) != 0;         // A/B and tests: the coordinator's refill walks every seed
     a.inherit = 1;
     a.collide = 1;
     a.timing = 0;

@@ -200,6 +200,7 @@ struct AssocArgs {
     int help;                   // 1: idle growers evaluate connections of the growth that holds the head seed (scan helpers; exact, see cifcaf.hip)
     int spec;                   // 1: the growers walk the skeleton level by level in batched scans first and the search takes connection values from that memo (exact; see cifcaf.hip)
     int dedup;                  // 1: later seeds of an occupancy cell already seen are dropped at the pool refill (exact; see cifcaf.hip)
+    int prededup;               // 1: ... and by the whole workgroup before the coordinator starts (needs dedup; exact; see cifcaf.hip)
     int32_t* fc_meta;           // [B, 4] seed kernel -> force-complete kernel: poses stored, dropped, failed, workgroup counter
     long long watchdog_ticks;   // 10-ns ticks after which every wait inside one launch gives up (status -1)
     unsigned* occ;           // occupancy bitmap [B][occ_image_words]: per image [F][occ_h][(occ_w+31)/32] words, zeroed by the kernel

@@ -144,7 +144,8 @@ def test_wrong_predictions_are_resolved(native, port, coco_skeleton0):
     # switched off; every setting must give the sequential loop's result
     settings = [({}, None), ({'OPA_ASSOC_COLLIDE': '0', 'OPA_ASSOC_INHERIT': '0'}, None),
                 ({'OPA_ASSOC_COLLIDE': '0'}, None), ({'OPA_ASSOC_INHERIT': '0'}, None),
-                ({'OPA_ASSOC_GROWERS': '1'}, 1), ({'OPA_ASSOC_GROWERS': '3'}, 3)]
+                ({'OPA_ASSOC_GROWERS': '1'}, 1), ({'OPA_ASSOC_GROWERS': '3'}, 3),
+                ({'OPA_ASSOC_PREDEDUP': '0'}, None)]      # round 5: every seed through the coordinator's refill
     started = {}
     for env, growers in settings:
         os.environ.update(env)

@@ -286,6 +286,13 @@ def test_seed_dedupe_by_occupancy_cell_is_exact(native, port, coco_skeleton0, mo
         want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)
         ok, msg = compare_annotations(got[b], want)
         assert ok, msg
+    # round 5: the whole workgroup drops them before the coordinator starts; without that pass the refill drops them one by one
+    monkeypatch.setenv('OPA_ASSOC_PREDEDUP', '0')
+    refill, dec_r = _decode(native, coco_skeleton0, cifs, cafs)
+    monkeypatch.delenv('OPA_ASSOC_PREDEDUP')
+    assert (dec_r.assoc_stats()[:, 23].cpu().numpy() > 50).all()
+    for b in range(len(cases)):
+        assert np.array_equal(refill[b], got[b]), 'image %d changes with the dedupe pass ahead of the pool' % b
     monkeypatch.setenv('OPA_ASSOC_DEDUP', '0')
     plain, dec0 = _decode(native, coco_skeleton0, cifs, cafs)
     monkeypatch.delenv('OPA_ASSOC_DEDUP')

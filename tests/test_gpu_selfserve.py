@@ -1,0 +1,54 @@
+"""Round 5: the self-serve hand-out of the association kernel (idle growers claim their next candidate with a compare-and-swap
+on the pool slot's owner word; cifcaf.hip, -DOPA_ASSOC_SELFSERVE=1) is measured, not faster, and compiled out of the default
+library -- but it is a complete second coordinator / grower protocol, and it has to stay exact.  ``build.build_variants``
+builds it as ``lib/libopenpifpaf_amd_selfserve.so``; this test decodes crowded and noisy images through it in a process of
+its own (the library is chosen at import) with all, one and three growers, against the oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, 'openpifpaf_amd', 'lib', 'libopenpifpaf_amd_selfserve.so')
+
+SCRIPT = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, 'tests'))
+from common import compare_annotations
+from openpifpaf_amd import _lib, constants, native, synth
+from oracle import port
+assert _lib.LIB_PATH.endswith('_selfserve.so'), _lib.LIB_PATH
+skel0 = np.asarray(constants.COCO_PERSON_SKELETON, dtype=np.int64) - 1
+rng = np.random.default_rng(11)
+cases = [synth.synth_fields(7000 + i, int(rng.integers(2, 12)), height=57, width=65,
+                            cif_noise=float(rng.choice([0.2, 0.4, 0.7])), size_range=(0.3, 0.8)) for i in range(8)]
+cases += [synth.synth_fields(7100 + i, int(rng.integers(8, 22)), height=57, width=65) for i in range(8)]
+cifs = np.stack([c for c, _ in cases]); cafs = np.stack([f for _, f in cases])
+want = [port.decode(cifs[b], 8, cafs[b], 8, skel0)[0] for b in range(len(cases))]
+n = 0
+for growers in (None, '1', '3'):
+    if growers: os.environ['OPA_ASSOC_GROWERS'] = growers
+    dec = native.CifCaf(17, torch.from_numpy(skel0))
+    for rep in range(3):
+        out, ids, counts = dec.call_batch(torch.from_numpy(cifs).cuda(), 8, torch.from_numpy(cafs).cuda(), 8)
+        out, counts = out.cpu().numpy(), counts.cpu().numpy()
+        native.check_counts(counts)
+        for b in range(len(cases)):
+            ok, msg = compare_annotations(out[b, :native.count_rows(int(counts[b]))], want[b])
+            assert ok, 'growers %%s image %%d: %%s' %% (growers, b, msg)
+            n += len(want[b])
+    os.environ.pop('OPA_ASSOC_GROWERS', None)
+print('SELFSERVE_OK', n)
+'''
+
+
+def test_selfserve_variant_equals_the_oracle():
+    if not os.path.exists(LIB):
+        pytest.fail('lib/libopenpifpaf_amd_selfserve.so is missing: run __graft_entry__.build() (build.build_variants)')
+    env = dict(os.environ, OPA_LIB_PATH=LIB)
+    r = subprocess.run([sys.executable, '-c', SCRIPT % {'root': ROOT}], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'SELFSERVE_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
