@@ -656,6 +656,11 @@ __device__ __forceinline__ BlendResult blend_streamed_masked(const ListView& L, 
     return blend_finish(s1, s2, have2, false, e1x, e1y, e1s, e2x, e2y, e2s);
 }
 
+#ifdef OPA_FC_TIMING
+// diagnostic builds (tools/gpu/fc_timing.py): scans of the force-complete kernel by the number of chunks their window meets
+// (0..31, 32+ in [32]); [33] scans that were compacted, [34] entries compacted -- rows 40.. of image 0's trace
+__device__ int* g_fc_hist;
+#endif
 __device__ __forceinline__ BlendResult blend_compacted(const ListView& L, const BlendQuery& q, const ChunkMask& hit, float* tgt) {
     constexpr int G = 4;
     const int lane = lane_id();
@@ -690,6 +695,9 @@ __device__ __forceinline__ BlendResult blend_compacted(const ListView& L, const 
             }
         }
     }
+#ifdef OPA_FC_TIMING
+    if (lane == 0) { atomicAdd(&g_fc_hist[33], 1); atomicAdd(&g_fc_hist[34], cnt); }
+#endif
     if (cnt == 0) return blend_none();                         // :76
     if (cnt > kCompactCap) return blend_streamed_masked(L, q, hit);
     wave_sync();
@@ -739,6 +747,9 @@ __device__ __forceinline__ BlendResult blend_long(const ListView& L, const Blend
             nh += __popcll(hit.m[g]);
         }
     }
+#ifdef OPA_FC_TIMING
+    if (lane == 0) atomicAdd(&g_fc_hist[nh < 32 ? nh : 32], 1);
+#endif
     if (nh == 0) return blend_none();                          // :76
     if (nh <= kBlendChunks) {
         unsigned long long chunks = ~0ull;                     // 0xff: no chunk
@@ -3344,9 +3355,22 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_fc_kernel(AssocArgs a, D
 
     double* anns = a.anns + (size_t)b * a.max_ann * K * 4;
     const int64_t* ann_ids = a.ann_ids + (size_t)b * a.max_ann;
+#ifdef OPA_FC_TIMING
+    // diagnostic builds: per image, in 10-ns ticks -- trace row 56: longest growth phase of a workgroup [0], longest single pose [1],
+    // the keypoint NMS of the last workgroup [2], poses [3]; row 57 [0]: (ticks << 10 | list scans) of the longest pose
+    if (tid == 0) g_fc_hist = a.trace + 40 * 4;
+    if (a.trace && tid < 8 && part == 0) a.trace[((size_t)b * kAssocTrace + 56) * 4 + tid] = 0;   // (racy against fast workgroups: diagnostic only)
+    __syncthreads();
+    const long long t_fc0 = wall_clock64();
+    int t_pose_max = 0;
+#endif
     if (wave < n_growers && !failed) {
         // pose n belongs to workgroup n % S, and there to wave (n / S) % n_growers
         for (int n = part + S * wave; n < n_kept; n += S * n_growers) {
+#ifdef OPA_FC_TIMING
+            const long long t_p0 = wall_clock64();
+            const int nb0 = c.n_blend;
+#endif
             double* src = anns + (size_t)n * K * 4;
             for (int k = lane; k < K; k += kWave) {
                 c.jv[k] = src[4 * k + 0]; c.jx[k] = (float)src[4 * k + 1];
@@ -3359,8 +3383,23 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_fc_kernel(AssocArgs a, D
                 src[4 * k + 2] = (double)c.jy[k]; src[4 * k + 3] = (double)c.js[k];
             }
             wave_sync();
+#ifdef OPA_FC_TIMING
+            {
+                const int dt = (int)(wall_clock64() - t_p0);
+                t_pose_max = max(t_pose_max, dt);
+                if (a.trace && lane == 0) atomicMax(a.trace + ((size_t)b * kAssocTrace + 57) * 4, (dt << 10) | min(c.n_blend - nb0, 1023));
+            }
+#endif
         }
     }
+#ifdef OPA_FC_TIMING
+    if (a.trace && lane == 0) {
+        int* t4 = a.trace + ((size_t)b * kAssocTrace + 56) * 4;
+        atomicMax(&t4[0], (int)(wall_clock64() - t_fc0));
+        atomicMax(&t4[1], t_pose_max);
+        t4[3] = n_kept;
+    }
+#endif
     // the last workgroup of the image to get here sees every pose (agent-scope release / acquire around the counter)
     __threadfence();
     __syncthreads();
@@ -3369,7 +3408,13 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_fc_kernel(AssocArgs a, D
     if (!sh_last[0]) return;
     __threadfence();
     const NmsLds nl = nms_carve(work_base, a.max_ann, K);
+#ifdef OPA_FC_TIMING
+    const long long t_nms0 = wall_clock64();
+#endif
     nms_and_store<kThreads>(a, p, c, nl, b, failed ? 0 : n_kept, n_dropped, failed, anns, ann_ids, nms_waves);
+#ifdef OPA_FC_TIMING
+    if (a.trace && tid == 0) a.trace[((size_t)b * kAssocTrace + 56) * 4 + 2] = (int)(wall_clock64() - t_nms0);
+#endif
 }
 
 template <bool REG, int NW>
