@@ -50,7 +50,13 @@ def register():
     except ImportError:
         return
     from . import tracking
-    ours = {decoder.CifCaf, decoder.CifCafDense, decoder.CifDet, tracking.TrackingPose, tracking.PoseSimilarity}
+    # the tracking decoders of a host that has the reference package are ITS classes with the HIP pose generator
+    # (tracking.host_classes); this package's own restatement of their bookkeeping is for hosts without it
+    try:
+        host_tracking = set(tracking.host_classes(openpifpaf))
+    except (ImportError, AttributeError):
+        host_tracking = {tracking.TrackingPose, tracking.PoseSimilarity}
+    ours = {decoder.CifCaf, decoder.CifCafDense, decoder.CifDet} | host_tracking
     names = {d.__name__ for d in ours}
     # mutate the set in place: the reference's factory iterates the very same object
     # (decoder/factory.py:17, re-exported by openpifpaf/__init__.py:28)

@@ -90,6 +90,9 @@ class CifCaf(Decoder):
     nms_before_force_complete = False
     reverse_match = True
     max_annotations = native.DEFAULT_MAX_ANNOTATIONS
+    #: the reference's class carries its occupancy visualizer here (``decoder/cifcaf.py:87``) and its TrackingPose looks at it
+    #: after the soft NMS (``tracking_pose.py:160``); the occupancy of this decode is a bitmap on the device: none
+    occupancy_visualizer = None
     #: per-image capacity of the high-resolution map's tile pool (``opa_shape::cifhr_pool_tiles``): 0 = automatic,
     #: ``'full'`` / -1 = every tile (can never run out), n = n tiles; ``--cifcaf-cifhr-pool-tiles``
     cifhr_pool_tiles = 0

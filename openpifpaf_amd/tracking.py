@@ -547,3 +547,50 @@ class PoseSimilarity(TrackBase):
 
 _decoder.DECODERS.add(TrackingPose)
 _decoder.DECODERS.add(PoseSimilarity)
+
+
+# ---------------------------------------------------------------- a host that has the reference package itself
+_HOST_CLASSES = {}
+
+
+def host_classes(openpifpaf):
+    """-> ``(TrackingPose, PoseSimilarity)`` for a host process that HAS the reference package (``openpifpaf_amd.register()``
+    running as its plugin): the reference's OWN classes -- track bookkeeping, soft NMS between tracks, pruning rules,
+    the pose-similarity matching are its code, not this module's restatement of it -- subclassed for one thing only: the
+    pose generator they decode with is the HIP ``CifCaf`` (reference ``decoder/tracking_pose.py:26-83``,
+    ``decoder/pose_similarity.py:23-42`` take it as ``pose_generator=``).  The classes above stay what the package uses
+    where the reference is not importable (the GPU box, a stand-alone installation); both are checked against the same
+    golden videos (``tests/test_tracking_pose.py``)."""
+    key = id(openpifpaf)
+    if key in _HOST_CLASSES:
+        return _HOST_CLASSES[key]
+    from openpifpaf.decoder import pose_similarity as ref_ps, tracking_pose as ref_tp
+
+    class _NoPoseGenerator:                       # (keeps the reference constructor from building ITS CifCaf, which needs its extension)
+        occupancy_visualizer = None
+
+    class HostTrackingPose(ref_tp.TrackingPose):
+        """The reference's ``TrackingPose`` decoding through ``openpifpaf_amd.decoder.CifCaf``."""
+
+        def __init__(self, cif_meta, caf_meta, tcaf_meta, *, pose_generator=None):
+            super().__init__(cif_meta, caf_meta, tcaf_meta, pose_generator=pose_generator or _NoPoseGenerator())
+            if pose_generator is None:
+                self.pose_generator = CifCaf([self.tracking_cif_meta], [self.tracking_caf_meta])
+
+        def __call__(self, fields, *, initial_annotations=None):
+            CifCaf.nms = None                     # (what the reference does to its own class: tracking_pose.py:203-205)
+            return super().__call__(fields, initial_annotations=initial_annotations)
+
+    class HostPoseSimilarity(ref_ps.PoseSimilarity):
+        """The reference's ``PoseSimilarity`` decoding through ``openpifpaf_amd.decoder.CifCaf``."""
+
+        def __init__(self, cif_meta, caf_meta, *, pose_generator=None):
+            super().__init__(cif_meta, caf_meta, pose_generator=pose_generator or _NoPoseGenerator())
+            if pose_generator is None:
+                self.pose_generator = CifCaf([cif_meta], [caf_meta])
+
+    HostTrackingPose.__name__ = HostTrackingPose.__qualname__ = 'TrackingPose'
+    HostPoseSimilarity.__name__ = HostPoseSimilarity.__qualname__ = 'PoseSimilarity'
+    _HOST_CLASSES[key] = (HostTrackingPose, HostPoseSimilarity)
+    return _HOST_CLASSES[key]
+

@@ -191,8 +191,13 @@ def test_register_swaps_decoders_inside_the_real_reference_package():
     try:
         openpifpaf_amd.register()
         assert ref_factory.DECODERS is opp.DECODERS
-        assert {decoder.CifCaf, decoder.CifCafDense, decoder.CifDet, tracking.TrackingPose,
-                tracking.PoseSimilarity} <= ref_factory.DECODERS
+        assert {decoder.CifCaf, decoder.CifCafDense, decoder.CifDet} <= ref_factory.DECODERS
+        # the tracking decoders of a host that has the reference package: ITS classes (bookkeeping, soft NMS, pruning are the
+        # reference's own code), subclassed so that they decode through the HIP CifCaf
+        host_tp, host_ps = tracking.host_classes(opp)
+        assert {host_tp, host_ps} <= ref_factory.DECODERS
+        assert issubclass(host_tp, sys.modules['openpifpaf.decoder.tracking_pose'].TrackingPose)
+        assert issubclass(host_ps, sys.modules['openpifpaf.decoder.pose_similarity'].PoseSimilarity)
         assert not [d for d in ref_factory.DECODERS if d.__module__.startswith('openpifpaf.')]
     finally:
         opp.DECODERS.clear()
@@ -287,3 +292,55 @@ def test_large_fields_bit_equal(ref, coco_skeleton0, case):
         o_out, o_ids, o_hr = port.decode(fields[0], 8, fields[1], 8, coco_skeleton0, params=params, return_cifhr=True)
         assert np.array_equal(r_hr, o_hr)
         assert r_out.shape == o_out.shape and len(o_out) >= 20 and np.array_equal(r_out, o_out)
+
+
+def test_host_tracking_classes_run_the_reference_bookkeeping_on_our_annotations(monkeypatch):
+    """``tracking.host_classes``: the reference's own TrackingPose / PoseSimilarity with a pose generator that returns THIS
+    package's Annotation objects (here the oracle's decode, as in tests/test_tracking_pose.py) -- over the golden videos the
+    reference's tracker produced with its own decoder; and their default pose generator is the HIP CifCaf."""
+    from oracle import reference_python
+    import os
+    if not os.path.isdir(reference_python.REF_SRC):
+        pytest.skip('reference sources not present')
+    opp = reference_python.load()
+    import sys
+    import torch
+    from common import TRACKING_VIDEOS
+    from openpifpaf_amd import decoder, synth, tracking
+    import test_tracking_pose as ttp
+    host_tp, host_ps = tracking.host_classes(opp)
+    assert tracking.host_classes(opp) == (host_tp, host_ps)                # (one pair of classes per package object)
+    golden = np.load(ttp.GOLDEN)
+    ref_track_annotation = sys.modules['openpifpaf.decoder.track_annotation'].TrackAnnotation
+    for v, video in enumerate(TRACKING_VIDEOS):
+        cif, caf, tcaf = ttp.metas()
+        keypoints = list(cif.keypoints) * 2
+        skeleton = list(caf.skeleton) + [(k + 1, k + 18) for k in range(17)]
+        ref_track_annotation.track_id_counter = 0
+        generator = ttp.OraclePoseGenerator(keypoints, skeleton)
+        generator.occupancy_visualizer = None                               # (decoder.CifCaf has the attribute, see below)
+        tracker = host_tp(cif, caf, tcaf, pose_generator=generator)
+        seed, people, n_frames, appear = video
+        for t, fields in enumerate(synth.synth_tracking_sequence(seed, people, n_frames, appear=appear)):
+            anns = tracker([torch.from_numpy(f) for f in fields])
+            assert [a.id_ for a in anns] == golden['video%d_frame%d_ids' % (v, t)].tolist(), 'video %d frame %d' % (v, t)
+            got = np.asarray([a.data for a in anns], dtype=np.float32).reshape(-1, 17, 3)
+            want = golden['video%d_frame%d_data' % (v, t)]
+            assert got.shape == want.shape and np.abs(got - want).max() <= 1e-4, 'video %d frame %d' % (v, t)
+    # the default pose generator is this package's CifCaf, built on the TRACKING metas (34 keypoints, 19 + 17 bones); the class
+    # itself needs a device, so a stand-in records what it is constructed with
+    built = []
+
+    class Recorder:
+        occupancy_visualizer = None
+
+        def __init__(self, cif_metas, caf_metas):
+            built.append((len(cif_metas[0].keypoints), len(caf_metas[0].skeleton)))
+
+    monkeypatch.setattr(tracking, 'CifCaf', Recorder)
+    cif, caf, tcaf = ttp.metas()
+    tp = host_tp(cif, caf, tcaf)
+    ps = host_ps(cif, caf)
+    assert type(tp.pose_generator) is Recorder and type(ps.pose_generator) is Recorder
+    assert built == [(34, 19 + 17), (17, 19)]
+    assert decoder.CifCaf.occupancy_visualizer is None                      # tracking_pose.py:160 reads it after the soft NMS
