@@ -235,7 +235,8 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
  * scans, 12 coordinator ticks spent in iterations that only waited for the head's growth, 13 growers,
  * 14 poses stored, 15 coordinator iterations, 16 of them waiting, 17/18/19 ticks in commits / refills / hand-outs,
  * 20 ticks of the refills spent waiting for the growers' occupancy marks, 21-22 scan timing of diagnostic builds, 23 seeds
- * dropped at a refill as later seeds of an occupancy cell already seen in the same round; ticks are 10 ns; the tick
+ * dropped as later seeds of an occupancy cell already seen -- by the workgroup's pass over the seed list before the pool sees it
+ * (round 5) and, for what that pass admits, at the refills; ticks are 10 ns; the tick
  * counters 12 and 17-20 are filled only with OPA_ASSOC_TIMING=1 in the environment: each costs clock reads in the coordinator's loop), "assoc_trace" (int32 [B,64,4]: for the first
  * 64 accepted poses of an image the tick of the commit, of the hand-out and of the end of the growth, and
  * seed index | grower << 24).
