@@ -484,6 +484,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     a.seed_cell = (const int32_t*)(ws + L.off_seed_cell);
     a.lists = (const float*)(ws + L.off_lists); a.list_counts = (const int32_t*)(ws + L.off_list_counts);
     a.lists_fc = (const float*)(ws + L.off_lists_fc); a.list_counts_fc = (const int32_t*)(ws + L.off_list_counts_fc);
+    a.caf_raw = caf_dev; a.caf_w = L.cW; a.caf_stride = (float)L.cstride;
     a.list_bbox = (const float*)(ws + L.off_list_bbox);
     a.list_bbox_fc = (const float*)(ws + L.off_list_bbox_fc);
     a.bbox_chunks = L.bbox_chunks;

@@ -149,6 +149,8 @@ struct ImageCtx {
     const int32_t *adj_off, *slot_info, *adj_first;   // LDS: adjacency range of a joint; per directed-bone slot: start | other << 8 |
                                                       // bone << 16 | forward << 24; first slot of the same (start, other) pair
     const float* lists; const int32_t* list_counts; int list_cap;
+    int* n_predicted;                    // LDS counter: joint boxes published from predictions (statistics)
+    const float* raw_caf; int raw_w; float raw_stride, predict_th;   // the image's CAF field itself [A][8][H*W] (predict_pose), or null
     unsigned* occ; int occ_h, occ_w, occ_wpr;   // occupancy bitmap [F][occ_h][occ_wpr] (one bit per cell)
     const int* cancel;                   // this grower's cancel flag in LDS (polled between frontier pops), or null
     int aborted;                         // set when a growth stopped because of it
@@ -1734,6 +1736,89 @@ __device__ __forceinline__ void pool_catch_up(ImageCtx& c, int e) {
 }
 
 
+// [r5] Where the pose is going to be, before it is grown: a walk over the skeleton from the seed joint that reads, for every
+// bone leaving a joint it has reached, ONE cell of the raw CAF field -- the cell the joint lies in -- and takes the far end
+// the field regresses there (no list scan, no blend, no reverse match: a level of the walk is one memory round trip for all its
+// bones, lane = directed bone), then publishes the occupancy boxes of all joints it reached in one pass over the pool.  The
+// exact search that follows assigns these joints one every ~6 us; until it has, the other seeds of the same person are
+// handed out and grown as duplicates -- on a crowded image two growths in three, and the people whose first seed comes
+// after them in seed order start 50-140 us late.  Predicted boxes are what published boxes are: advisory --
+// pooled seeds inside them are not handed out while this candidate lives, growths that run into them are stopped, the commit
+// decides from the final boxes (pose_boxes rewrites every box when the growth ends).
+// (A real call, once per growth, with everything it needs passed by value: inlined into the grower's loop it cost the scans
+// fourteen spilled registers; handed the context by reference it would have put the whole context into scratch memory.)
+struct PredictArgs {
+    const float* raw; int HW, W; float stride, th;
+    int E, K, F, occ_w, occ_h, my_idx;
+    OccBox* jbox; const int* pool_if; const int* pool_pack; unsigned* shadow; int* n_predicted;
+};
+#ifndef OPA_PREDICT_INLINE
+#define OPA_PREDICT_INLINE 1
+#endif
+#if OPA_PREDICT_INLINE
+#define OPA_PREDICT_ATTR __forceinline__
+#else
+#define OPA_PREDICT_ATTR __attribute__((noinline))
+#endif
+template <int WR>
+__device__ OPA_PREDICT_ATTR void predict_pose_call(PredictArgs q, const DevParams* pp, int info, int first, int seed_joint,
+                                                   float sx, float sy, float ss) {
+    const DevParams& p = *pp;
+    const int lane = lane_id();
+    const int HW = q.HW, W = q.W, H = HW / W;
+    const int start = info & 0xff, other = (info >> 8) & 0xff, bone = (info >> 16) & 0xff, fwd = (info >> 24) & 1;
+    const float inv = 1.0f / q.stride;
+    float qx = lane == seed_joint ? sx : 0.f, qy = lane == seed_joint ? sy : 0.f, qs = lane == seed_joint ? ss : 0.f;   // lane j: joint j
+    unsigned long long known = 1ull << seed_joint;
+    for (int level = 0; level < q.K; level++) {
+        const bool act = lane < q.E && first == lane && ((known >> start) & 1ull) && !((known >> other) & 1ull);
+        if (__ballot(act) == 0ull) break;
+        const float x = bperm_f(qx, start), y = bperm_f(qy, start);
+        int cx = (int)(x * inv + 0.5f), cy = (int)(y * inv + 0.5f);
+        cx = min(max(cx, 0), W - 1); cy = min(max(cy, 0), H - 1);
+        const float* P = q.raw + ((size_t)bone * 8) * HW + (size_t)cy * W + cx;
+        float cc = 0.f, tx = 0.f, ty = 0.f, ts = 0.f;
+        if (act) { cc = P[1 * HW]; tx = P[(fwd ? 4 : 2) * HW]; ty = P[(fwd ? 5 : 3) * HW]; ts = P[(fwd ? 7 : 6) * HW]; }
+        const bool ok = act && cc > q.th && tx == tx && ty == ty && ts == ts;
+        unsigned long long m = __ballot(ok);
+        if (m == 0ull) break;
+        while (m) {                                  // (two bones into one joint: the first slot's answer)
+            const int l = __builtin_ctzll(m);
+            const int o = rlane(other, l);
+            const float nx = rlanef(tx, l) * q.stride, ny = rlanef(ty, l) * q.stride, ns = rlanef(ts, l) * q.stride;
+            if (lane == o) { qx = nx; qy = ny; qs = ns; }
+            known |= 1ull << o;
+            m &= ~__ballot(ok && other == o);
+        }
+    }
+    known &= ~(1ull << seed_joint);                  // (its box is out already)
+    if (q.F < 64) known &= (1ull << q.F) - 1ull;     // joints without a CIF field have no seeds to keep away
+    if (known == 0ull) return;
+    ImageCtx dims; dims.occ_w = q.occ_w; dims.occ_h = q.occ_h;     // (occ_box reads the map's size from the context)
+    if ((known >> lane) & 1ull) q.jbox[lane] = occ_box(dims, p, (double)qx, (double)qy, (double)qs);
+    wave_sync();
+    unsigned bits = 0u;
+#pragma unroll
+    for (int r = 0; r < WR; r++) {
+        const int sif = q.pool_if[r * kWave + lane], spk = q.pool_pack[r * kWave + lane];
+        const int f = (int)((unsigned)sif >> 24), idx = sif & kPoolIdxMask;
+        if (idx != kPoolIdxMask && idx > q.my_idx && f < q.F && ((known >> f) & 1ull) &&
+            box_contains(q.jbox[f], spk & 0xfff, (spk >> 12) & 0xfff)) bits |= 1u << r;
+    }
+    if (bits) atomicOr(&q.shadow[lane], bits);
+    if (lane == 0) __hip_atomic_fetch_add(q.n_predicted, __popcll(known), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+template <int WR>
+__device__ __forceinline__ void predict_pose(ImageCtx& c, const DevParams& p, const RegSkeleton& sk, int seed_joint,
+                                             float sx, float sy, float ss) {
+    if (!c.raw_caf || !c.pub) return;
+    PredictArgs q;
+    q.raw = c.raw_caf; q.HW = c.list_cap; q.W = c.raw_w; q.stride = c.raw_stride; q.th = c.predict_th;
+    q.E = 2 * c.A; q.K = c.K; q.F = c.F; q.occ_w = c.occ_w; q.occ_h = c.occ_h; q.my_idx = c.my_idx;
+    q.jbox = c.jbox; q.pool_if = c.pool_if; q.pool_pack = c.pool_pack; q.shadow = c.shadow_mine; q.n_predicted = c.n_predicted;
+    predict_pose_call<WR>(q, &p, sk.slot_info, sk.slot_first, seed_joint, sx, sy, ss);
+}
+
 // ------------------------------------------------ speculative batched evaluation of a growth (spec_phase)
 // The reference evaluates one bone per pop of its frontier (cifcaf.cpp:287-303), a chain of ~2 list scans per bone -- but
 // _connection_value (:349-411) of a bone depends on its START JOINT alone, and a joint, once assigned, never changes.  So
@@ -2313,6 +2398,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     c.lists = a.lists + (size_t)b * A * 2 * 7 * a.list_cap;
     c.list_counts = a.list_counts + (size_t)b * A * 2;
     c.list_cap = a.list_cap;
+    c.raw_caf = a.predict && a.caf_raw ? a.caf_raw + (size_t)b * A * 8 * a.list_cap : nullptr;
+    c.raw_w = a.caf_w; c.raw_stride = a.caf_stride; c.predict_th = a.predict_th; c.n_predicted = nullptr;
     c.occ_h = a.occ_h; c.occ_w = a.occ_w; c.occ_wpr = (a.occ_w + 31) >> 5;
     c.occ = a.occ + (size_t)b * a.occ_image_words;
     c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
@@ -2397,6 +2484,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     const bool dedup_on = a.dedup != 0;
     constexpr bool self = kSelfServe;                // idle growers take their next candidate themselves (see kPoolSlots' neighbour above)
     c.adj_off = l_off; c.slot_info = l_info; c.adj_first = l_first;
+    c.n_predicted = &sh_ctl[6];                      // (statistics slot 21: joint boxes published from predictions)
 
     // ---- seeds in score order, cifcaf.cpp:206-231
     int n_seeds = a.seed_count[b];
@@ -3240,6 +3328,9 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             c.my_epoch = flag_load(c.epoch);             // publish_joint tests the whole pool as of now; later refills: pool_catch_up
             if (lane == 0) flag_store(c.ack, c.my_epoch);
             publish_joint<WR>(c, p, sf, sd.y, sd.z, sd.w);   // the seed joint's own box: the rest of its blob
+            if constexpr (REG)                           // ... and where its other joints will be (advisory; strong seeds only:
+                if (__builtin_expect(sd.x >= a.predict_min_v, 0))   // the one- and two-joint poses of weak seeds predict joints their search rejects)
+                    predict_pose<WR>(c, p, rs, sf, sd.y, sd.z, sd.w);
             PH(12);
             grow_pose<REG>(c, p, rs, true, 1.0, false);
             PH(13);
@@ -3316,6 +3407,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_fc_kernel(AssocArgs a, D
     c.lists = a.lists_fc + (size_t)b * A * 2 * 7 * a.list_cap;
     c.list_counts = a.list_counts_fc + (size_t)b * A * 2;
     c.list_cap = a.list_cap;
+    c.raw_caf = nullptr; c.raw_w = 0; c.raw_stride = 1.f; c.predict_th = 0.f; c.n_predicted = nullptr;
     c.occ_h = a.occ_h; c.occ_w = a.occ_w; c.occ_wpr = (a.occ_w + 31) >> 5;
     c.occ = nullptr;
     c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
@@ -3517,6 +3609,10 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     // when the map is reduced at all, occupancy.cpp:14-18: with reduction == 1 the box is the raw joint scale)
     a.dedup = (p.occupancy_reduction != 1.0 && p.occupancy_min_scale_reduced >= 1.0) ? 1 : 0;
     if (const char* e = getenv("OPA_ASSOC_DEDUP")) { if (atoi(e) == 0) a.dedup = 0; }   // A/B and tests: same result without it
+    a.predict = 1; a.predict_th = 0.3f; a.predict_min_v = 0.5f;
+    if (const char* e = getenv("OPA_ASSOC_PREDICT_MINV")) a.predict_min_v = (float)atof(e);   // seeds below this confidence grow without the walk
+    if (const char* e = getenv("OPA_ASSOC_PREDICT")) a.predict = atoi(e) != 0;          // A/B and tests: boxes are published only for assigned joints
+    if (const char* e = getenv("OPA_ASSOC_PREDICT_TH")) a.predict_th = (float)atof(e);  // raw CAF confidence a predicted bone needs
     a.prededup = 1;
     if (const char* e = getenv("OPA_ASSOC_PREDEDUP")) a.prededup = atoi(e) != 0;         // A/B and tests: the coordinator's refill walks every seed
     a.inherit = 1;

@@ -200,6 +200,9 @@ struct AssocArgs {
     int help;                   // 1: idle growers evaluate connections of the growth that holds the head seed (scan helpers; exact, see cifcaf.hip)
     int spec;                   // 1: the growers walk the skeleton level by level in batched scans first and the search takes connection values from that memo (exact; see cifcaf.hip)
     int dedup;                  // 1: later seeds of an occupancy cell already seen are dropped at the pool refill (exact; see cifcaf.hip)
+    const float* caf_raw; int caf_w; float caf_stride;   // the CAF field tensor itself [B][A][8][list_cap] (predict_pose reads single cells of it)
+    float predict_min_v;
+    int predict; float predict_th;   // 1: a growth first walks the skeleton through single cells of the raw field and publishes the boxes of the joints it expects (advisory; see cifcaf.hip)
     int prededup;               // 1: ... and by the whole workgroup before the coordinator starts (needs dedup; exact; see cifcaf.hip)
     int32_t* fc_meta;           // [B, 4] seed kernel -> force-complete kernel: poses stored, dropped, failed, workgroup counter
     long long watchdog_ticks;   // 10-ns ticks after which every wait inside one launch gives up (status -1)
