@@ -234,7 +234,9 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
  * 8 ticks until the growth phase ended, 9 ticks of the kernel, 10 sum of the growers' busy ticks, 11 list
  * scans, 12 coordinator ticks spent in iterations that only waited for the head's growth, 13 growers,
  * 14 poses stored, 15 coordinator iterations, 16 of them waiting, 17/18/19 ticks in commits / refills / hand-outs,
- * 20 ticks of the refills spent waiting for the growers' occupancy marks, 21-22 scan timing of diagnostic builds, 23 seeds
+ * 20 ticks of the refills spent waiting for the growers' occupancy marks, 21 joint boxes published from PREDICTIONS (a growth's walk over
+ * single cells of the raw CAF field before its search; round 5) and 22 seeds that entered the pool ahead of the scan (large skeletons' lookahead;
+ * round 5) -- in diagnostic builds both also carry scan timing --, 23 seeds
  * dropped as later seeds of an occupancy cell already seen -- by the workgroup's pass over the seed list before the pool sees it
  * (round 5) and, for what that pass admits, at the refills; ticks are 10 ns; the tick
  * counters 12 and 17-20 are filled only with OPA_ASSOC_TIMING=1 in the environment: each costs clock reads in the coordinator's loop), "assoc_trace" (int32 [B,64,4]: for the first

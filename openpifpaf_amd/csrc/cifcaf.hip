@@ -149,6 +149,7 @@ struct ImageCtx {
     const int32_t *adj_off, *slot_info, *adj_first;   // LDS: adjacency range of a joint; per directed-bone slot: start | other << 8 |
                                                       // bone << 16 | forward << 24; first slot of the same (start, other) pair
     const float* lists; const int32_t* list_counts; int list_cap;
+    int coll_shift;                      // collision test: within (box extent >> shift) / 2 cells of the box centre (0: anywhere in the box)
     int* n_predicted;                    // LDS counter: joint boxes published from predictions (statistics)
     const float* raw_caf; int raw_w; float raw_stride, predict_th;   // the image's CAF field itself [A][8][H*W] (predict_pose), or null
     unsigned* occ; int occ_h, occ_w, occ_wpr;   // occupancy bitmap [F][occ_h][occ_wpr] (one bit per cell)
@@ -1683,7 +1684,13 @@ __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, i
             const int st = flag_peek(&tasks[lane].state), cn = flag_peek(&tasks[lane].cancel), sd = tasks[lane].seed;
             if ((st == kTaskAssigned || st == kTaskDone) && !cn && sd < c.my_idx) {
                 const OccBox ob = reinterpret_cast<const OccBox*>(blocks + (size_t)(lane - 1) * block_bytes)[k];
-                if (box_contains(ob, cx, cy)) key = ((unsigned)sd << 6) | (unsigned)lane;
+                // the SAME joint, not a neighbour's: in the middle of the box (two growths of one person put a joint within a cell
+                // of each other; the hands of two people standing side by side lie inside each other's boxes -- stopping THOSE growths
+                // made every second person of the wholebody batches wait for the one before, round 5)
+                const int ex = ob.maxx - ob.minx, ey = ob.maxy - ob.miny;
+                const int ddx = 2 * cx - (ob.minx + ob.maxx - 1), ddy = 2 * cy - (ob.miny + ob.maxy - 1);   // twice the offset from the centre
+                const int tx = max(2, ex >> c.coll_shift), ty = max(2, ey >> c.coll_shift);
+                if (ex > 0 && ddx >= -tx && ddx <= tx && ddy >= -ty && ddy <= ty) key = ((unsigned)sd << 6) | (unsigned)lane;
             }
         }
         if (__ballot(key != 0xFFFFFFFFu) != 0ull) {
@@ -1773,13 +1780,19 @@ __device__ OPA_PREDICT_ATTR void predict_pose_call(PredictArgs q, const DevParam
     for (int level = 0; level < q.K; level++) {
         const bool act = lane < q.E && first == lane && ((known >> start) & 1ull) && !((known >> other) & 1ull);
         if (__ballot(act) == 0ull) break;
-        const float x = bperm_f(qx, start), y = bperm_f(qy, start);
+        const float x = bperm_f(qx, start), y = bperm_f(qy, start), s0 = bperm_f(qs, start);   // (all lanes: a permute reads nothing from a masked lane)
         int cx = (int)(x * inv + 0.5f), cy = (int)(y * inv + 0.5f);
         cx = min(max(cx, 0), W - 1); cy = min(max(cy, 0), H - 1);
         const float* P = q.raw + ((size_t)bone * 8) * HW + (size_t)cy * W + cx;
-        float cc = 0.f, tx = 0.f, ty = 0.f, ts = 0.f;
-        if (act) { cc = P[1 * HW]; tx = P[(fwd ? 4 : 2) * HW]; ty = P[(fwd ? 5 : 3) * HW]; ts = P[(fwd ? 7 : 6) * HW]; }
-        const bool ok = act && cc > q.th && tx == tx && ty == ty && ts == ts;
+        float cc = 0.f, tx = 0.f, ty = 0.f, ts = 0.f, ox = 0.f, oy = 0.f;
+        if (act) {
+            cc = P[1 * HW]; tx = P[(fwd ? 4 : 2) * HW]; ty = P[(fwd ? 5 : 3) * HW]; ts = P[(fwd ? 7 : 6) * HW];
+            ox = P[(fwd ? 2 : 4) * HW]; oy = P[(fwd ? 3 : 5) * HW];    // where the cell says THIS end of the bone lies
+        }
+        // (a bone of somebody else that passes through the joint's cell starts somewhere else: the search's reverse match, :404,
+        // rejects it; here the cell's own regression of the near end has to agree with the joint -- same loads, no second trip)
+        const bool ok = act && cc > q.th && tx == tx && ty == ty && ts == ts &&
+                        fabsf(ox * q.stride - x) + fabsf(oy * q.stride - y) <= s0;
         unsigned long long m = __ballot(ok);
         if (m == 0ull) break;
         while (m) {                                  // (two bones into one joint: the first slot's answer)
@@ -1817,6 +1830,73 @@ __device__ __forceinline__ void predict_pose(ImageCtx& c, const DevParams& p, co
     q.E = 2 * c.A; q.K = c.K; q.F = c.F; q.occ_w = c.occ_w; q.occ_h = c.occ_h; q.my_idx = c.my_idx;
     q.jbox = c.jbox; q.pool_if = c.pool_if; q.pool_pack = c.pool_pack; q.shadow = c.shadow_mine; q.n_predicted = c.n_predicted;
     predict_pose_call<WR>(q, &p, sk.slot_info, sk.slot_first, seed_joint, sx, sy, ss);
+}
+
+// The same walk for skeletons that do not fit the lanes of a wave (LDS-resident growth state: wholebody, dense connections,
+// tracking): the reached joints live in the wave's scan area, which is free until the search starts; directed bones 64 at a time.
+template <int WR>
+__device__ __forceinline__ void predict_pose_lds(ImageCtx& c, const DevParams& p, int seed_joint, float sx, float sy, float ss,
+                                                 int tgt_floats) {
+    if (!c.raw_caf || !c.pub || 4 * c.K > tgt_floats) return;
+    const int lane = lane_id(), K = c.K, E = 2 * c.A, HW = c.list_cap, W = c.raw_w, H = HW / W;
+    float* px = c.tgt; float* py = px + K; float* ps = py + K; int* kn = reinterpret_cast<int*>(ps + K);   // kn: 0 unknown, 1 reached, 2 reached in this level
+    for (int k = lane; k < K; k += kWave) kn[k] = 0;
+    wave_sync();
+    if (lane == 0) { kn[seed_joint] = 1; px[seed_joint] = sx; py[seed_joint] = sy; ps[seed_joint] = ss; }
+    wave_sync();
+    const float inv = 1.0f / c.raw_stride;
+    int n_reached = 0;
+    for (int level = 0; level < K; level++) {
+        bool any = false;
+        for (int t0 = 0; t0 < E; t0 += kWave) {
+            const int t = t0 + lane;
+            bool act = false; int start = 0, other = 0, bone = 0, fwd = 0;
+            if (t < E) {
+                const int info = c.slot_info[t];
+                start = info & 0xff; other = (info >> 8) & 0xff; bone = (info >> 16) & 0xff; fwd = (info >> 24) & 1;
+                act = c.adj_first[t] == t && kn[start] == 1 && kn[other] == 0;
+            }
+            if (__ballot(act) == 0ull) continue;
+            float cc = 0.f, tx = 0.f, ty = 0.f, ts = 0.f, ox = 0.f, oy = 0.f, jx0 = 0.f, jy0 = 0.f, js0 = 0.f;
+            if (act) {
+                jx0 = px[start]; jy0 = py[start]; js0 = ps[start];
+                int cx = (int)(jx0 * inv + 0.5f), cy = (int)(jy0 * inv + 0.5f);
+                cx = min(max(cx, 0), W - 1); cy = min(max(cy, 0), H - 1);
+                const float* P = c.raw_caf + ((size_t)bone * 8) * HW + (size_t)cy * W + cx;
+                cc = P[1 * HW]; tx = P[(fwd ? 4 : 2) * HW]; ty = P[(fwd ? 5 : 3) * HW]; ts = P[(fwd ? 7 : 6) * HW];
+                ox = P[(fwd ? 2 : 4) * HW]; oy = P[(fwd ? 3 : 5) * HW];    // where the cell says THIS end of the bone lies
+            }
+            // (the cell's own regression of the near end has to agree with the joint: see predict_pose_call)
+            const bool ok = act && cc > c.predict_th && tx == tx && ty == ty && ts == ts &&
+                            fabsf(ox * c.raw_stride - jx0) + fabsf(oy * c.raw_stride - jy0) <= js0;
+            if (ok && atomicCAS(&kn[other], 0, 2) == 0) {     // (two bones into one joint: whichever gets there first)
+                px[other] = tx * c.raw_stride; py[other] = ty * c.raw_stride; ps[other] = ts * c.raw_stride;
+            }
+            any |= __ballot(ok) != 0ull;
+        }
+        if (!any) break;
+        wave_sync();
+        for (int k = lane; k < K; k += kWave) if (kn[k] == 2) { kn[k] = 1; }
+        wave_sync();
+    }
+    for (int k = lane; k < K; k += kWave) {
+        const bool have = k < c.F && k != seed_joint && kn[k] == 1;
+        if (have) c.jbox[k] = occ_box(c, p, (double)px[k], (double)py[k], (double)ps[k]);
+        n_reached += __popcll(__ballot(have));
+    }
+    if (n_reached == 0) return;
+    wave_sync();
+    unsigned bits = 0u;
+#pragma unroll
+    for (int r = 0; r < WR; r++) {
+        const int sif = c.pool_if[r * kWave + lane], spk = c.pool_pack[r * kWave + lane];
+        const int f = (int)((unsigned)sif >> 24), idx = sif & kPoolIdxMask;
+        if (idx != kPoolIdxMask && idx > c.my_idx && f < c.F && f != seed_joint && kn[f] == 1 &&
+            box_contains(c.jbox[f], spk & 0xfff, (spk >> 12) & 0xfff)) bits |= 1u << r;
+    }
+    if (bits) atomicOr(&c.shadow_mine[lane], bits);
+    if (lane == 0) __hip_atomic_fetch_add(c.n_predicted, n_reached, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    wave_sync();                                     // (the scan area is the search's from here on)
 }
 
 // ------------------------------------------------ speculative batched evaluation of a growth (spec_phase)
@@ -2399,7 +2479,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     c.list_counts = a.list_counts + (size_t)b * A * 2;
     c.list_cap = a.list_cap;
     c.raw_caf = a.predict && a.caf_raw ? a.caf_raw + (size_t)b * A * 8 * a.list_cap : nullptr;
-    c.raw_w = a.caf_w; c.raw_stride = a.caf_stride; c.predict_th = a.predict_th; c.n_predicted = nullptr;
+    c.raw_w = a.caf_w; c.raw_stride = a.caf_stride; c.predict_th = a.predict_th; c.n_predicted = nullptr; c.coll_shift = a.coll_shift;
     c.occ_h = a.occ_h; c.occ_w = a.occ_w; c.occ_wpr = (a.occ_w + 31) >> 5;
     c.occ = a.occ + (size_t)b * a.occ_image_words;
     c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
@@ -2426,7 +2506,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     int* pool_if = (int*)sp; sp += sizeof(int) * WR * kWave;        // the coordinator's seed pool, mirrored for the growers
     int* pool_pack = (int*)sp; sp += sizeof(int) * WR * kWave;
     int* pool_ep = (int*)sp; sp += sizeof(int) * WR * kWave;
-    int* pool_own = (int*)sp; sp += sizeof(int) * WR * kWave;       // 0, or the grower that claimed the slot's seed (self-serve hand-out)
+    int* pool_own = (int*)sp; if (kSelfServe) sp += sizeof(int) * WR * kWave;   // 0, or the grower that claimed the slot's seed (self-serve variant only)
     unsigned* shadow_by = (unsigned*)sp; sp += sizeof(unsigned) * NW * kWave; // [grower][lane]: pool slots in its published boxes
     int* stage_f = (int*)sp; sp += sizeof(int) * kSeedStage;                // the next seeds' field and cell, staged ahead of the pool refill
     int* stage_pk = (int*)sp; sp += sizeof(int) * kSeedStage;
@@ -2478,7 +2558,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     if (tid < kPhases) { g_ph[tid] = 0; g_phn[tid] = 0; }
     if (tid < 16) g_ph_last[tid] = clock64();
 #endif
-    for (int k = tid; k < WR * kWave; k += kThreads) { pool_if[k] = kPoolIdxMask; pool_pack[k] = 0; pool_ep[k] = 0; pool_own[k] = 0; }
+    for (int k = tid; k < WR * kWave; k += kThreads) { pool_if[k] = kPoolIdxMask; pool_pack[k] = 0; pool_ep[k] = 0; if (kSelfServe) pool_own[k] = 0; }
     for (int k = tid; k < NW * kWave; k += kThreads) shadow_by[k] = 0u;
     for (int k = tid; k < (1 << kDedupBits); k += kThreads) dedup[k] = ~0ull;
     const bool dedup_on = a.dedup != 0;
@@ -2649,6 +2729,19 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                 if ((r >> 3) == k) gmap[k] = (gmap[k] & ~(15u << (4 * (r & 7)))) | ((unsigned)g << (4 * (r & 7)));
         };
         int scan_pos = 0, n_live = 0;
+        // Lookahead (large skeletons, with the compacted seed list): when growers are idle and every pooled seed is somebody's,
+        // predicted dead or handed out, the list is searched AHEAD of the scan position for the next seed that is free in the
+        // bitmap and outside every box the candidates in flight have published or predicted -- the first seed of the next
+        // person, whose thousand seeds otherwise reach the window only when the people before are committed -- and that ONE
+        // seed enters the pool early (its list entry is marked: the scan skips it when it gets there).  It is grown like any
+        // other candidate and committed at its turn: `bound`, the index of the first seed the scan has not reached, stops a
+        // commit of anything beyond it.
+        const bool la_on = !REG && pre && a.lookahead != 0 && a.F < 255;
+        int la_pos = 0;                                  // lookahead cursor (>= scan_pos)
+        bool want_la = false;
+        int la_snap = -1, la_restarts = 0;               // lane g: the seed grower g's candidate had while the current pass over the list ran (-1: none)
+        unsigned bound = 0u;                             // seed index of list position scan_pos (all ones: the scan is through); set by the refill
+        int32_t* list_w = const_cast<int32_t*>(scan_f);  // (the compacted list is this kernel's own: lookahead marks entries in it)
         bool watchdog = false, marks_pending = false;
         int last_hg = -1;                                // what sh_ctl[9] says
         int epoch = 0;                                   // refills so far; `unver`: slots filled by refills not every candidate in flight has tested yet
@@ -2715,6 +2808,22 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             return m ? rlane(mine, __builtin_ctzll(m)) : -1;
         };
         find_head();
+        // the new occupants of pool slots: mirror them, forget what the growers said about the slots' former occupants, and
+        // have every candidate in flight test them against the boxes it has published (pool_catch_up)
+        auto publish_fresh = [&](unsigned fresh) {
+            epoch++;
+#pragma unroll
+            for (int r = 0; r < WR; r++)
+                if ((fresh >> r) & 1u) {
+                    pool_pack[r * kWave + lane] = s_pack[r]; pool_ep[r * kWave + lane] = epoch;
+                    __hip_atomic_store(&pool_if[r * kWave + lane], s_if[r], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (the claimers read this word first)
+                }
+            if (fresh)
+                for (int g = 1; g <= S; g++) atomicAnd(&shadow_by[g * kWave + lane], ~fresh);
+            unver |= fresh;
+            wave_sync();
+            if (is_grower_lane) flag_store(&task[lane].epoch, epoch);
+        };
 
         for (;;) {
             const long long t_iter = wall_clock64();
@@ -2727,7 +2836,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             if (self) read_owners();
             int hg = hd == kNone ? -1 : head_grower();
             for (int run = 0; run < kCommitRun && hg >= 0 && flag_load(&task[hg].state) == kTaskDone &&
-                              (!self || task[hg].seed == (int)hd); run++) {
+                              (!self || task[hg].seed == (int)hd) && (!la_on || hd < bound); run++) {
                 const long long t_cm = tick();
                 const PoseView q = pose_of_block(private_base, hg - 1, private_bytes, K);
                 unsigned dead = 0u;                      // pooled seeds inside one of its joint boxes (:211 for them)
@@ -2830,7 +2939,8 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
 
             // ---- 3. refill free slots with the next seeds that are still free in the bitmap (:211 for the
             //         poses accepted so far); slot (r, lane) takes the seed of its rank among the free slots
-            if (scan_pos < n_seeds && kRefillDen * n_live < kRefillNum * WR * kWave) {
+            const bool head_early = la_on && hd != kNone && hd >= bound;     // the scan has to reach the head before it can be committed
+            if (scan_pos < n_seeds && (kRefillDen * n_live < kRefillNum * WR * kWave || head_early)) {
                 const long long t_ph = tick();
                 if (marks_pending) {                     // accepted poses are marked by their growers: all of them are done
                     while (__ballot(is_grower_lane && flag_load(&task[lane].state) == kTaskAccepted) != 0ull &&
@@ -2871,7 +2981,10 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     for (int r = 0; r < HR; r++) beyond |= nidx[r] >= pf_end && nidx[r] < n_seeds;
                     if (__ballot(beyond) != 0ull) {
 #pragma unroll
-                        for (int r = 0; r < HR; r++) { const int ii = nidx[r] < n_seeds ? nidx[r] : 0; ff[r] = scan_f[ii]; pk[r] = scan_pk[ii]; }
+                        for (int r = 0; r < HR; r++) {
+                            const int ii = nidx[r] < n_seeds ? nidx[r] : 0;
+                            ff[r] = __hip_atomic_load(&scan_f[ii], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pk[r] = scan_pk[ii];
+                        }
 #pragma unroll
                         for (int r = 0; r < HR; r++) asm volatile("" : "+v"(ff[r]), "+v"(pk[r]) :: "memory");
                     } else {
@@ -2887,7 +3000,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     }
 #pragma unroll
                     for (int r = 0; r < HR; r++) {
-                        const bool valid = nidx[r] < n_seeds;
+                        const bool valid = nidx[r] < n_seeds && ff[r] != 0xff;     // (field 255: an entry the lookahead took)
                         const size_t word = valid ? ((size_t)ff[r] * c.occ_h + ((pk[r] >> 12) & 0xfff)) * c.occ_wpr + ((pk[r] & 0xfff) >> 5) : 0;
                         ow[r] = __hip_atomic_load(&c.occ[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
@@ -2904,7 +3017,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     bool cand[HR]; unsigned key[HR]; int bkt[HR];
 #pragma unroll
                     for (int r = 0; r < HR; r++) {
-                        cand[r] = nidx[r] < n_seeds && !((ow[r] >> (pk[r] & 31)) & 1u);
+                        cand[r] = nidx[r] < n_seeds && !((ow[r] >> (pk[r] & 31)) & 1u) && (!la_on || ff[r] != 0xff);   // (field 255: taken early by the lookahead)
                         key[r] = ((unsigned)ff[r] << 24) | ((unsigned)pk[r] & 0xFFFFFFu);
                         bkt[r] = (int)((key[r] * 2654435761u) >> (32 - kDedupBits));
                         if (cand[r] && dedup_on)
@@ -2930,7 +3043,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                             for (int q = 0; q < WR; q += HR)     // (static register indices: the slot is r0 + r)
                                 if (q == r0) { s_pack[q + r] = pk[r]; s_if[q + r] = sw[r]; }
                             occupied |= sb; emitted &= ~sb; ever &= ~sb; fresh |= sb;
-                            if (dedup_on) {
+                            if (dedup_on && !la_on) {       // (with the lookahead a seed may enter before earlier ones of its cell: no admission marks)
                                 const size_t word = ((size_t)ff[r] * c.occ_h + ((pk[r] >> 12) & 0xfff)) * c.occ_wpr + ((pk[r] & 0xfff) >> 5);
                                 atomicOr(&c.occ[word], 1u << (pk[r] & 31));
                             }
@@ -2943,28 +3056,122 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     }
                     scan_pos = scan_pos + base < n_seeds ? scan_pos + base : n_seeds;
                     count_live();
-                    if (kRefillDen * n_live >= kRefillNum * WR * kWave) break;
+                    bool need_more = false;              // the smallest pooled seed still lies beyond the scan (it entered early): go on
+                    if (la_on) {
+                        find_head();                     // (what this round admitted comes BEFORE an early seed)
+                        bound = scan_pos < n_seeds ? (unsigned)__hip_atomic_load(&scan_f[scan_pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (unsigned)kIdxMask : kNone;
+                        need_more = hd != kNone && hd >= bound;
+                    }
+                    if (kRefillDen * n_live >= kRefillNum * WR * kWave && !need_more) break;
                     if constexpr (WR > HR) r0 = r0 + HR < WR ? r0 + HR : 0;
+                }
+                if (la_on) {
+                    find_head();
+                    bound = scan_pos < n_seeds ? (unsigned)__hip_atomic_load(&scan_f[scan_pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & (unsigned)kIdxMask : kNone;
+                    if (la_pos < scan_pos) la_pos = scan_pos;
+                    hg = -1;
                 }
                 stat(6, 1);
                 stage_seeds();
-                // the new occupants: mirror them, forget what the growers said about the slots' former occupants, and
-                // have every candidate in flight test them against the boxes it has published (pool_catch_up)
-                epoch++;
-#pragma unroll
-                for (int r = 0; r < WR; r++)
-                    if ((fresh >> r) & 1u) {
-                        pool_pack[r * kWave + lane] = s_pack[r]; pool_ep[r * kWave + lane] = epoch;
-                        __hip_atomic_store(&pool_if[r * kWave + lane], s_if[r], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // (the claimers read this word first)
-                    }
-                if (fresh)
-                    for (int g = 1; g <= S; g++) atomicAnd(&shadow_by[g * kWave + lane], ~fresh);
-                unver |= fresh;
-                wave_sync();
-                if (is_grower_lane) flag_store(&task[lane].epoch, epoch);
+                publish_fresh(fresh);
                 if (timing) stat(18, (int)(wall_clock64() - t_ph));
                 progress = true;
                 if (hd == kNone) { find_head(); hg = -1; }   // (newcomers come after everything pooled)
+            }
+
+            // ---- 3b. lookahead (see la_on): ONE seed ahead of the scan, the first that is free and outside every box in flight
+            if (la_on && want_la) {
+                want_la = false;
+                if (la_pos < scan_pos) la_pos = scan_pos;
+                // A pass skips what lies in a box of a candidate in flight.  When such a candidate is gone -- stopped as a duplicate,
+                // committed -- what only IT covered is free: the pass starts again behind the scan (entries taken early are marked).
+                if (la_pos >= n_seeds && la_restarts < 256 &&
+                    __ballot(la_snap >= 0 && !(g_live && g_seed == la_snap)) != 0ull) {
+                    la_pos = scan_pos; la_snap = -1; la_restarts++;
+                }
+                if (g_live && la_snap < 0) la_snap = g_seed;
+                // (every candidate in flight has said where it expects its joints: count 2, or it is done)
+                // ... and what entered the pool last has been looked at by everybody (it is handed out first: its candidate's
+                // boxes are what the next step must see -- else the step takes the same person's next seed, and the next ...)
+                const bool settled = __ballot(g_live && g_state == kTaskAssigned && g_pub < 2) == 0ull && __ballot(unver != 0u) == 0ull;
+                if (la_pos < n_seeds && settled) {
+                    if (marks_pending) {
+                        while (__ballot(is_grower_lane && flag_load(&task[lane].state) == kTaskAccepted) != 0ull &&
+                               wall_clock64() - t_kernel <= kWatchdogTicks)
+                            __builtin_amdgcn_s_sleep(1);
+                        marks_pending = false;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                    constexpr int LR = 8;                // 512 list positions per step
+                    int q[LR], sifq[LR], pkq[LR]; unsigned owq[LR];
+#pragma unroll
+                    for (int r = 0; r < LR; r++) {
+                        q[r] = la_pos + r * kWave + lane;
+                        const int ii = q[r] < n_seeds ? q[r] : 0;
+                        sifq[r] = __hip_atomic_load(&scan_f[ii], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pkq[r] = scan_pk[ii];
+                    }
+#pragma unroll
+                    for (int r = 0; r < LR; r++) asm volatile("" : "+v"(sifq[r]), "+v"(pkq[r]) :: "memory");
+                    bool candq[LR];
+#pragma unroll
+                    for (int r = 0; r < LR; r++) {
+                        const int f = (int)((unsigned)sifq[r] >> 24);
+                        candq[r] = q[r] < n_seeds && f < c.F;                        // (255: taken early before)
+                        const size_t word = candq[r] ? ((size_t)f * c.occ_h + ((pkq[r] >> 12) & 0xfff)) * c.occ_wpr + ((pkq[r] & 0xfff) >> 5) : 0;
+                        owq[r] = __hip_atomic_load(&c.occ[word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int r = 0; r < LR; r++) asm volatile("" : "+v"(owq[r]) :: "memory");
+#pragma unroll
+                    for (int r = 0; r < LR; r++) candq[r] = candq[r] && !((owq[r] >> (pkq[r] & 31)) & 1u);
+                    for (int g = 1; g <= S; g++)
+                        if ((live_mask >> g) & 1ull) {
+                            const OccBox* jb = pose_of_block(private_base, g - 1, private_bytes, K).box;
+#pragma unroll
+                            for (int r = 0; r < LR; r++)
+                                if (candq[r] && box_contains(jb[(unsigned)sifq[r] >> 24], pkq[r] & 0xfff, (pkq[r] >> 12) & 0xfff)) candq[r] = false;
+                        }
+                    unsigned lmin = kNone; int vs = 0, vp = 0;
+#pragma unroll
+                    for (int r = LR - 1; r >= 0; r--)
+                        if (candq[r]) { lmin = (unsigned)q[r]; vs = sifq[r]; vp = pkq[r]; }   // (descending r: the smallest position of the lane stays)
+                    const unsigned pstar = ~wave_max_u32(~lmin);
+                    if (pstar == kNone) {
+                        la_pos = la_pos + LR * kWave < n_seeds ? la_pos + LR * kWave : n_seeds;
+                        want_la = true;                  // (nothing in these 512: go on with the next step at once)
+                        progress = true;
+                    } else {
+                        const int owner = __builtin_ctzll(__ballot(lmin == pstar));
+                        const int sif_star = rlane(vs, owner), pk_star = rlane(vp, owner);
+                        int fr_r = -1, fr_lane = 0;
+#pragma unroll
+                        for (int r = 0; r < WR; r++) {
+                            const unsigned long long m = __ballot(!((occupied >> r) & 1u));
+                            if (fr_r < 0 && m) { fr_r = r; fr_lane = __builtin_ctzll(m); }
+                        }
+                        if (fr_r >= 0) {
+                            unsigned fresh = 0u;
+#pragma unroll
+                            for (int r = 0; r < WR; r++)
+                                if (r == fr_r && lane == fr_lane) {
+                                    s_if[r] = sif_star; s_pack[r] = pk_star;
+                                    occupied |= 1u << r; emitted &= ~(1u << r); ever &= ~(1u << r); fresh |= 1u << r;
+                                }
+                            // the list entry says so (field 255, the index stays: `bound` reads it): the scan skips it when it gets there
+                            if (lane == 0) {
+                                const int marked = (sif_star & kIdxMask) | (0xff << 24);
+                                __hip_atomic_store(&list_w[pstar], marked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if ((int)pstar < pf_end && (int)pstar >= pf_end - kSeedStage) stage_f[pstar & (kSeedStage - 1)] = marked;
+                                __hip_atomic_fetch_add(&sh_ctl[7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (statistics slot 22)
+                            }
+                            la_pos = (int)pstar + 1;
+                            count_live();
+                            publish_fresh(fresh);
+                            find_head(); hg = -1;
+                            progress = true;
+                        }
+                    }
+                }
             }
 
             // ---- 4. Which pooled seeds lie in a joint box an EARLIER live candidate has published so far?  (The
@@ -3098,6 +3305,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
                     progress = true;
                 }
                 if (timing) stat(19, (int)(wall_clock64() - t_em));
+                if (la_on && idle != 0ull) want_la = true;   // growers left idle, nothing to hand out: look ahead in the next round
             }
 
             // ---- 6. what the next round waits for
@@ -3328,9 +3536,13 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
             c.my_epoch = flag_load(c.epoch);             // publish_joint tests the whole pool as of now; later refills: pool_catch_up
             if (lane == 0) flag_store(c.ack, c.my_epoch);
             publish_joint<WR>(c, p, sf, sd.y, sd.z, sd.w);   // the seed joint's own box: the rest of its blob
-            if constexpr (REG)                           // ... and where its other joints will be (advisory; strong seeds only:
-                if (__builtin_expect(sd.x >= a.predict_min_v, 0))   // the one- and two-joint poses of weak seeds predict joints their search rejects)
-                    predict_pose<WR>(c, p, rs, sf, sd.y, sd.z, sd.w);
+            if (__builtin_expect(sd.x >= a.predict_min_v, 0)) {   // ... and where its other joints will be (advisory; strong seeds only:
+                // the one- and two-joint poses of weak seeds predict joints their search rejects)
+                if constexpr (REG) predict_pose<WR>(c, p, rs, sf, sd.y, sd.z, sd.w);
+                else predict_pose_lds<WR>(c, p, sf, sd.y, sd.z, sd.w, tgt_floats);
+            }
+            ++c.n_pub;                                   // (count 2: whatever this growth predicts is out -- the lookahead waits for that)
+            if (lane == 0) flag_store(&my->npub, c.n_pub);
             PH(12);
             grow_pose<REG>(c, p, rs, true, 1.0, false);
             PH(13);
@@ -3407,7 +3619,7 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_fc_kernel(AssocArgs a, D
     c.lists = a.lists_fc + (size_t)b * A * 2 * 7 * a.list_cap;
     c.list_counts = a.list_counts_fc + (size_t)b * A * 2;
     c.list_cap = a.list_cap;
-    c.raw_caf = nullptr; c.raw_w = 0; c.raw_stride = 1.f; c.predict_th = 0.f; c.n_predicted = nullptr;
+    c.raw_caf = nullptr; c.raw_w = 0; c.raw_stride = 1.f; c.predict_th = 0.f; c.n_predicted = nullptr; c.coll_shift = 0;
     c.occ_h = a.occ_h; c.occ_w = a.occ_w; c.occ_wpr = (a.occ_w + 31) >> 5;
     c.occ = nullptr;
     c.cancel = nullptr; c.aborted = 0; c.n_blend = 0; c.t_blend = 0; c.t_blend_mem = 0; c.pub = nullptr; c.n_pub = 0;
@@ -3544,7 +3756,7 @@ template <bool REG, int NW>
 static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
     const int K = a.K, A = a.A, E = 2 * A;
     size_t shared = sizeof(TaskSlot) * NW + (sizeof(unsigned long long) << kDedupBits) + sizeof(int) * (3 * E + K + 1 + 16 + kAssocStats)
-                  + sizeof(int) * (4 * (REG ? kPoolSlots : kPoolSlotsLds) + NW) * kWave + sizeof(int) * 2 * kSeedStage;
+                  + sizeof(int) * ((kSelfServe ? 4 : 3) * (REG ? kPoolSlots : kPoolSlotsLds) + NW) * kWave + sizeof(int) * 2 * kSeedStage;
     shared = (shared + 15) / 16 * 16 + (REG && a.list_bbox ? sizeof(float4) * E * kListBboxChunks : 0);
     // work area behind it: one private block per grower while poses grow, the keypoint-NMS arrays afterwards
 #ifdef OPA_ASSOC_PHASE_TIMING
@@ -3613,6 +3825,10 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     if (const char* e = getenv("OPA_ASSOC_PREDICT_MINV")) a.predict_min_v = (float)atof(e);   // seeds below this confidence grow without the walk
     if (const char* e = getenv("OPA_ASSOC_PREDICT")) a.predict = atoi(e) != 0;          // A/B and tests: boxes are published only for assigned joints
     if (const char* e = getenv("OPA_ASSOC_PREDICT_TH")) a.predict_th = (float)atof(e);  // raw CAF confidence a predicted bone needs
+    a.coll_shift = 1;
+    if (const char* e = getenv("OPA_ASSOC_COLLIDE_SHIFT")) a.coll_shift = atoi(e);       // 0: anywhere inside the earlier candidate's box (round 4)
+    a.lookahead = 1;
+    if (const char* e = getenv("OPA_ASSOC_LOOKAHEAD")) a.lookahead = atoi(e) != 0;      // A/B and tests: seeds enter the pool in list order only
     a.prededup = 1;
     if (const char* e = getenv("OPA_ASSOC_PREDEDUP")) a.prededup = atoi(e) != 0;         // A/B and tests: the coordinator's refill walks every seed
     a.inherit = 1;

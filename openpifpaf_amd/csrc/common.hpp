@@ -201,6 +201,8 @@ struct AssocArgs {
     int spec;                   // 1: the growers walk the skeleton level by level in batched scans first and the search takes connection values from that memo (exact; see cifcaf.hip)
     int dedup;                  // 1: later seeds of an occupancy cell already seen are dropped at the pool refill (exact; see cifcaf.hip)
     const float* caf_raw; int caf_w; float caf_stride;   // the CAF field tensor itself [B][A][8][list_cap] (predict_pose reads single cells of it)
+    int coll_shift;             // collision stops: how close to the centre of the earlier candidate's joint box (extent >> shift; 0 = anywhere inside)
+    int lookahead;              // 1: (large skeletons) the first free seed outside every box in flight enters the pool ahead of the scan (see cifcaf.hip)
     float predict_min_v;
     int predict; float predict_th;   // 1: a growth first walks the skeleton through single cells of the raw field and publishes the boxes of the joints it expects (advisory; see cifcaf.hip)
     int prededup;               // 1: ... and by the whole workgroup before the coordinator starts (needs dedup; exact; see cifcaf.hip)

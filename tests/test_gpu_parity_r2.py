@@ -145,7 +145,12 @@ def test_wrong_predictions_are_resolved(native, port, coco_skeleton0):
     settings = [({}, None), ({'OPA_ASSOC_COLLIDE': '0', 'OPA_ASSOC_INHERIT': '0'}, None),
                 ({'OPA_ASSOC_COLLIDE': '0'}, None), ({'OPA_ASSOC_INHERIT': '0'}, None),
                 ({'OPA_ASSOC_GROWERS': '1'}, 1), ({'OPA_ASSOC_GROWERS': '3'}, 3),
-                ({'OPA_ASSOC_PREDEDUP': '0'}, None)]      # round 5: every seed through the coordinator's refill
+                ({'OPA_ASSOC_PREDEDUP': '0'}, None),      # round 5: every seed through the coordinator's refill
+                # round 5: boxes are predicted from single cells of the raw CAF field before the search runs -- off, for every
+                # seed however weak (wrong predictions by the dozen: the lapse-and-hand-out-again branch again), and with the
+                # collision test of round 4 (anywhere inside the earlier candidate's box)
+                ({'OPA_ASSOC_PREDICT': '0'}, None), ({'OPA_ASSOC_PREDICT_MINV': '0'}, None),
+                ({'OPA_ASSOC_PREDICT_MINV': '0', 'OPA_ASSOC_GROWERS': '3'}, 3), ({'OPA_ASSOC_COLLIDE_SHIFT': '0'}, None)]
     started = {}
     for env, growers in settings:
         os.environ.update(env)
@@ -191,6 +196,21 @@ def test_wholebody_batch16(native, port):
         assert ok, 'image %d: %s' % (b, msg)
         n_poses += len(want)
     assert n_poses >= 4 * (1 + 3 + 6 + 10) * 0.8
+    # round 5 (large skeletons): predicted boxes, the lookahead that lets the first seed of the NEXT person into the pool ahead of
+    # the scan, the tighter collision test -- each switched off, and predictions from every seed: the same annotations, bit for bit
+    import os
+    st = dec.assoc_stats().cpu().numpy()
+    assert st[:, 21].sum() > 0 and st[:, 22].sum() > 0, 'no box was predicted / no seed entered early: the inputs no longer exercise this'
+    for env in ({'OPA_ASSOC_LOOKAHEAD': '0'}, {'OPA_ASSOC_PREDICT': '0'}, {'OPA_ASSOC_COLLIDE_SHIFT': '0'},
+                {'OPA_ASSOC_PREDICT_MINV': '0'}, {'OPA_ASSOC_LOOKAHEAD': '1', 'OPA_ASSOC_GROWERS': '3'}):
+        os.environ.update(env)
+        try:
+            other, _ = _decode_all(native, skel0, cifs[8:], cafs[8:])
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        for b in range(8):
+            assert np.array_equal(other[b], got[8 + b]), 'image %d changes with %r' % (8 + b, env)
 
 
 def test_list_chunk_boxes_bound_their_chunks_and_do_not_change_the_decode(native, port, coco_skeleton0, monkeypatch):
