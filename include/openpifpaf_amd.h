@@ -184,7 +184,9 @@ size_t opa_cifcaf_workspace_bytes_for(const opa_shape* shape, const opa_params* 
  * tensors where the network wrote them (device memory; the reference
  * hard-requires CPU tensors, cifcaf.cpp:137-138).
  *
- *  cif_dev  [B,F,5,H,W], caf_dev [B,A,8,H,W]
+ *  cif_dev  [B,F,5,H,W], caf_dev [B,A,8,H,W]: read by the kernels the call queues on `stream` -- the CAF tensor by the LAST of
+ *                   them too (the association kernel reads single cells of it, round 5): both have to stay as they are until
+ *                   the work queued by this call has run (the call itself returns at once)
  *  initial_dev      optional [B, n_initial, K, 4] (v,x,y,s) or NULL
  *  initial_ids_dev  optional int64 [B, n_initial] or NULL
  *  out_dev          [B, max_annotations, K, 4] (v,x,y,s)   (ref: cifcaf.cpp:246-258), K = the decoder's n_keypoints
