@@ -54,6 +54,8 @@ import numpy as np
 
 # MIOpen's find step otherwise also benchmarks its naive reference solver (~0.3 s per call)
 os.environ.setdefault('MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_FWD', '0')
+# decode lanes want a hardware queue each (the runtime's default is four for all streams of the process)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 import torch  # noqa: E402  (after the MIOpen environment is set)
 

@@ -105,10 +105,11 @@ typedef struct opa_shape {
 /* The structs above are passed by pointer and have grown over time (opa_shape::cifhr_pool_tiles is the latest field): a
  * caller built against another header would make the library read past its struct.  Check once at start-up that
  * opa_abi_version() == OPA_ABI_VERSION and opa_shape_bytes() == sizeof(opa_shape), opa_params_bytes() == sizeof(opa_params). */
-#define OPA_ABI_VERSION 5
+#define OPA_ABI_VERSION 6
 int opa_abi_version(void);
 size_t opa_shape_bytes(void);
 size_t opa_params_bytes(void);
+size_t opa_debug_bytes(void);
 const char* opa_version(void);
 const char* opa_last_error(void);            /* thread-local, never NULL            */
 int opa_device_count(void);                  /* number of visible gfx950 devices    */
@@ -127,7 +128,7 @@ void opa_set_quiet(int quiet);
  *                launch of its own: no shorter for one decode, better when several decodes are in flight on streams of
  *                their own (stage-level entry points: like 1).
  * Process-global like the reference's statics; the environment variable OPA_SEED_TIES=index / libstdcxx-fused selects 0 / 2
- * when this function was never called. */
+ * when this function was never called (read once, when the library is loaded). */
 void opa_set_seed_tie_order(int order);
 int opa_get_seed_tie_order(void);
 
@@ -157,9 +158,46 @@ int opa_cifcaf_get_state(const opa_cifcaf* dec, int32_t* n_keypoints,
  * order 1, see opa_set_seed_tie_order): 0 = a launch of its own (default for one decode at a time: the association
  * kernel's time stays what it is), 1 = inside the association kernel, every image its own ties (what several decodes in
  * flight want: the pass overlaps like the association does instead of filling the chip; native.DecodeLanes sets it for
- * two or more lanes), -1 = the process-wide choice (opa_set_seed_tie_order / OPA_SEED_TIES / OPA_FUSE_TIES).  The
+ * two or more lanes), -1 = the process-wide choice (opa_set_seed_tie_order / OPA_SEED_TIES / OPA_FUSE_TIES at load time).  The
  * results are the same bit for bit. */
 int opa_cifcaf_set_tie_placement(opa_cifcaf* dec, int32_t inside_association);
+
+/* A/B and test switches of ONE decoder handle (no reference counterpart; the reference's tunables are opa_params).  None of
+ * them changes a result: they select between exact variants of the kernels, shorten the watchdog, or switch measurements on.
+ * opa_default_debug() = the library's defaults with the environment variables named below applied -- the environment is read
+ * ONCE, when the library is loaded, never during a decode (rounds 2-5 looked 20 variables up at every launch, and tests
+ * flipped them mid-process next to running decode lanes).  opa_cifcaf_set_debug() copies the struct into the handle; a decode
+ * reads only that copy. */
+typedef struct opa_debug {
+    int32_t stage_worklist;        /* 1: tiles of the CIF map through a work list, seeds from candidate lists (round 6); 0: round 5's
+                                    *    per-plane tile kernel and a seed fill that streams the field      OPA_STAGE_WORKLIST      */
+    int32_t fuse_scored;           /* 0; 1: CafScored::fill rides in the seed sort's launch (round 3, slower) OPA_FUSE_SCORED       */
+    int32_t scored_one_pass;       /* 1: a force-complete decode builds both CAF list sets from ONE read of the field (round 6);
+                                    *    0: two passes                                                       OPA_SCORED_ONE_PASS   */
+    int32_t assoc_waves;           /* 0 = 12 waves per association workgroup; 8 (and 16 in -DOPA_ASSOC_ALL_WAVES builds) OPA_ASSOC_WAVES */
+    int32_t assoc_growers;         /* 0 = as many growing waves as fit; n: at most n (other interleavings) OPA_ASSOC_GROWERS      */
+    int32_t assoc_bbox;            /* 1: list scans skip chunks whose box misses the window                  OPA_ASSOC_BBOX         */
+    int32_t assoc_dedup;           /* 1: later seeds of an occupancy cell already seen are dropped           OPA_ASSOC_DEDUP        */
+    int32_t assoc_prededup;        /* 1: ... by the whole workgroup before the coordinator starts            OPA_ASSOC_PREDEDUP     */
+    int32_t assoc_predict;         /* 1: joint boxes predicted from single cells of the raw CAF field        OPA_ASSOC_PREDICT      */
+    float assoc_predict_min_v;     /* 0.5: seeds below this confidence grow without that walk                OPA_ASSOC_PREDICT_MINV */
+    float assoc_predict_th;        /* 0.3: raw CAF confidence a predicted bone needs                         OPA_ASSOC_PREDICT_TH   */
+    int32_t assoc_collide;         /* 1: a growth that runs into an earlier candidate's joint box is stopped OPA_ASSOC_COLLIDE      */
+    int32_t assoc_collide_shift;   /* 1: ... only near the centre of that box (0: anywhere inside, round 4)  OPA_ASSOC_COLLIDE_SHIFT */
+    int32_t assoc_inherit;         /* 1: a candidate inherits the predictions of growths stopped for it      OPA_ASSOC_INHERIT      */
+    int32_t assoc_lookahead;       /* 1: large skeletons: the next person's first seed enters the pool early OPA_ASSOC_LOOKAHEAD    */
+    int32_t assoc_help;            /* compiled-in variants only (-DOPA_ASSOC_HELPERS)                        OPA_ASSOC_HELP         */
+    int32_t assoc_spec;            /* compiled-in variants only (-DOPA_ASSOC_WALK)                           OPA_ASSOC_SPEC         */
+    int32_t assoc_timing;          /* 0; 1: the coordinator fills its per-phase tick counters                OPA_ASSOC_TIMING       */
+    int32_t assoc_persistent;      /* 0 = automatic: more images than compute units are taken from a queue, longest first, by
+                                    *    one workgroup per compute unit (round 6); 1: always; -1: never      OPA_ASSOC_PERSISTENT   */
+    int32_t fc_split;              /* 0 = automatic; n: force-complete workgroups per image                  OPA_FC_SPLIT           */
+    int64_t assoc_watchdog_ticks;  /* 1e8 (one second): 10-ns ticks after which a wait inside the association kernel gives up
+                                    *    and the image is flagged OPA_COUNT_FAILED                           OPA_ASSOC_WATCHDOG_TICKS */
+} opa_debug;
+void opa_default_debug(opa_debug* out);
+int opa_cifcaf_set_debug(opa_cifcaf* dec, const opa_debug* in);
+int opa_cifcaf_get_debug(const opa_cifcaf* dec, opa_debug* out);
 
 /* Bytes of device workspace opa_cifcaf_decode needs for `shape`
  * (0 and an error text if the shape is invalid).
@@ -196,7 +234,7 @@ size_t opa_cifcaf_workspace_bytes_for(const opa_shape* shape, const opa_params* 
  *                   OPA_COUNT_OVERFLOW bit is set when the annotation capacity was too small: the poses the
  *                   seed loop produced after the first max_annotations (in seed order, cifcaf.cpp:206-231) were
  *                   dropped before keypoint NMS, and the workspace's "status" buffer holds how many.
- *                   OPA_COUNT_FAILED: see above (environment OPA_ASSOC_WATCHDOG_TICKS = the watchdog in 10-ns
+ *                   OPA_COUNT_FAILED: see above (opa_debug::assoc_watchdog_ticks = the watchdog in 10-ns
  *                   ticks, default 1e8 = one second; tests shorten it to provoke the failure).
  */
 int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_params* params,
@@ -241,7 +279,7 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
  * round 5) -- in diagnostic builds both also carry scan timing --, 23 seeds
  * dropped as later seeds of an occupancy cell already seen -- by the workgroup's pass over the seed list before the pool sees it
  * (round 5) and, for what that pass admits, at the refills; ticks are 10 ns; the tick
- * counters 12 and 17-20 are filled only with OPA_ASSOC_TIMING=1 in the environment: each costs clock reads in the coordinator's loop), "assoc_trace" (int32 [B,64,4]: for the first
+ * counters 12 and 17-20 are filled only with opa_debug::assoc_timing: each costs clock reads in the coordinator's loop), "assoc_trace" (int32 [B,64,4]: for the first
  * 64 accepted poses of an image the tick of the commit, of the hand-out and of the end of the growth, and
  * seed index | grower << 24).
  * The three "*_fc" regions lie at the END of the layout: their offsets are only inside a workspace of

@@ -6,16 +6,7 @@ HIP for gfx950, C ABI in ``include/openpifpaf_amd.h``); this package is the
 host-side mirror of the reference's decoder interface.  There is no CPU
 fallback: using the decode path without the built library / without a GPU raises.
 """
-import os
-
-# Decode lanes (native.DecodeLanes, decoder.CifCaf.decoder_workers, one HIP stream each) only run side by side while every
-# stream has a hardware queue of its own; the HIP runtime maps all streams of a process onto FOUR by default, and four
-# lanes then share queues with the network's stream (measured in round 4: 54 k images/s with four lanes against 66 k with
-# two; with eight queues 86 k).  The runtime reads the variable when it initialises, i.e. at the first GPU call of the
-# process: import this package (or set the variable yourself) before that.  An explicit setting wins.
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
-
-from . import constants, headmeta, synth                      # noqa: F401,E402  (light, no torch)
+from . import constants, headmeta, synth                      # noqa: F401  (light, no torch)
 
 __version__ = '0.1.0'
 

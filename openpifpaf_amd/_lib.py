@@ -55,7 +55,22 @@ class Params(ctypes.Structure):
         return other
 
 
-ABI_VERSION = 5                      # OPA_ABI_VERSION of include/openpifpaf_amd.h
+ABI_VERSION = 6                      # OPA_ABI_VERSION of include/openpifpaf_amd.h
+
+
+class Debug(ctypes.Structure):
+    """``opa_debug``: A/B and test switches of one decoder handle (none changes a result).  The library reads the ``OPA_*``
+    environment variables once, when it is loaded, into the defaults; a decode reads only its handle's copy."""
+    _fields_ = [
+        ('stage_worklist', ctypes.c_int32), ('fuse_scored', ctypes.c_int32), ('scored_one_pass', ctypes.c_int32),
+        ('assoc_waves', ctypes.c_int32), ('assoc_growers', ctypes.c_int32), ('assoc_bbox', ctypes.c_int32),
+        ('assoc_dedup', ctypes.c_int32), ('assoc_prededup', ctypes.c_int32), ('assoc_predict', ctypes.c_int32),
+        ('assoc_predict_min_v', ctypes.c_float), ('assoc_predict_th', ctypes.c_float),
+        ('assoc_collide', ctypes.c_int32), ('assoc_collide_shift', ctypes.c_int32), ('assoc_inherit', ctypes.c_int32),
+        ('assoc_lookahead', ctypes.c_int32), ('assoc_help', ctypes.c_int32), ('assoc_spec', ctypes.c_int32),
+        ('assoc_timing', ctypes.c_int32), ('assoc_persistent', ctypes.c_int32), ('fc_split', ctypes.c_int32),
+        ('assoc_watchdog_ticks', ctypes.c_int64),
+    ]
 
 
 class DetShape(ctypes.Structure):
@@ -77,6 +92,10 @@ SYMBOLS = {
     'opa_abi_version': (ctypes.c_int, []),
     'opa_shape_bytes': (_sz, []),
     'opa_params_bytes': (_sz, []),
+    'opa_debug_bytes': (_sz, []),
+    'opa_default_debug': (None, [_P(Debug)]),
+    'opa_cifcaf_set_debug': (ctypes.c_int, [_vp, _P(Debug)]),
+    'opa_cifcaf_get_debug': (ctypes.c_int, [_vp, _P(Debug)]),
     'opa_version': (ctypes.c_char_p, []),
     'opa_last_error': (ctypes.c_char_p, []),
     'opa_device_count': (ctypes.c_int, []),
@@ -144,7 +163,7 @@ def lib():
             fn.argtypes = argtypes
         # the structs are passed by pointer: a library built from another header would read past (or short of) them
         if handle.opa_abi_version() != ABI_VERSION or handle.opa_shape_bytes() != ctypes.sizeof(Shape) or \
-                handle.opa_params_bytes() != ctypes.sizeof(Params):
+                handle.opa_params_bytes() != ctypes.sizeof(Params) or handle.opa_debug_bytes() != ctypes.sizeof(Debug):
             raise NativeError('openpifpaf_amd: %s was built from another include/openpifpaf_amd.h (ABI %d, opa_shape %d bytes, '
                               'opa_params %d bytes; this package: ABI %d, %d, %d): rebuild it' % (
                                   LIB_PATH, handle.opa_abi_version(), handle.opa_shape_bytes(), handle.opa_params_bytes(),
@@ -167,6 +186,16 @@ def default_params(**overrides):
             raise AttributeError('opa_params has no field %r' % k)
         setattr(p, k, v)
     return p
+
+
+def default_debug(**overrides):
+    d = Debug()
+    lib().opa_default_debug(ctypes.byref(d))
+    for k, v in overrides.items():
+        if not hasattr(d, k):
+            raise AttributeError('opa_debug has no field %r' % k)
+        setattr(d, k, v)
+    return d
 
 
 def get_params():

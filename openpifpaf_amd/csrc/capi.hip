@@ -15,15 +15,47 @@ namespace opa {
 static thread_local std::string g_error;
 static std::mutex g_params_mutex;
 static int g_quiet = 0;
-static int g_seed_tie_order = -1;          // -1: not set (OPA_SEED_TIES, else libstdc++'s order)
+static int g_seed_tie_order = -1;          // -1: not set (OPA_SEED_TIES at load time, else libstdc++'s order)
 
-int seed_tie_order() {
-    if (g_seed_tie_order >= 0) return g_seed_tie_order;
+// The environment is read ONCE, when the library is loaded (static initialisation): no decode looks a variable up.
+static int env_int(const char* name, int dflt) { const char* e = std::getenv(name); return e && *e ? std::atoi(e) : dflt; }
+static float env_float(const char* name, float dflt) { const char* e = std::getenv(name); return e && *e ? (float)std::atof(e) : dflt; }
+static opa_debug debug_from_environment() {
+    opa_debug d;
+    d.stage_worklist = env_int("OPA_STAGE_WORKLIST", 1) != 0;
+    d.fuse_scored = env_int("OPA_FUSE_SCORED", 0) != 0;
+    d.scored_one_pass = env_int("OPA_SCORED_ONE_PASS", 1) != 0;
+    d.assoc_waves = env_int("OPA_ASSOC_WAVES", 0);
+    d.assoc_growers = env_int("OPA_ASSOC_GROWERS", 0);
+    d.assoc_bbox = env_int("OPA_ASSOC_BBOX", 1) != 0;
+    d.assoc_dedup = env_int("OPA_ASSOC_DEDUP", 1) != 0;
+    d.assoc_prededup = env_int("OPA_ASSOC_PREDEDUP", 1) != 0;
+    d.assoc_predict = env_int("OPA_ASSOC_PREDICT", 1) != 0;
+    d.assoc_predict_min_v = env_float("OPA_ASSOC_PREDICT_MINV", 0.5f);
+    d.assoc_predict_th = env_float("OPA_ASSOC_PREDICT_TH", 0.3f);
+    d.assoc_collide = env_int("OPA_ASSOC_COLLIDE", 1) != 0;
+    d.assoc_collide_shift = env_int("OPA_ASSOC_COLLIDE_SHIFT", 1);
+    d.assoc_inherit = env_int("OPA_ASSOC_INHERIT", 1) != 0;
+    d.assoc_lookahead = env_int("OPA_ASSOC_LOOKAHEAD", 1) != 0;
+    d.assoc_help = env_int("OPA_ASSOC_HELP", 1) != 0;
+    d.assoc_spec = env_int("OPA_ASSOC_SPEC", 1) != 0;
+    d.assoc_timing = env_int("OPA_ASSOC_TIMING", 0) != 0;
+    d.assoc_persistent = env_int("OPA_ASSOC_PERSISTENT", 0);
+    d.fc_split = env_int("OPA_FC_SPLIT", 0);
+    d.assoc_watchdog_ticks = 100000000ll;
+    if (const char* e = std::getenv("OPA_ASSOC_WATCHDOG_TICKS")) { const long long v = std::atoll(e); if (v > 0) d.assoc_watchdog_ticks = v; }
+    return d;
+}
+static const opa_debug g_debug_default = debug_from_environment();
+static int tie_order_from_environment() {
     const char* e = std::getenv("OPA_SEED_TIES");
     if (e && (std::strcmp(e, "index") == 0 || std::strcmp(e, "0") == 0)) return 0;
     if (e && (std::strcmp(e, "libstdcxx-fused") == 0 || std::strcmp(e, "2") == 0)) return 2;
-    return 1;
+    return env_int("OPA_FUSE_TIES", 0) != 0 ? 2 : 1;
 }
+static const int g_tie_order_default = tie_order_from_environment();
+
+int seed_tie_order() { return g_seed_tie_order >= 0 ? g_seed_tie_order : g_tie_order_default; }
 
 static opa_params default_params() {
     opa_params p;
@@ -140,7 +172,10 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
         L->hr_tpp = (int)tpp; L->hr_pool_cap = (int)cap; L->hr_spill_cap = (int)spill;
         L->off_cifhr = take((B * cap + spill) * tile_bytes);
         L->off_hr_slot = take(B * all * sizeof(int32_t));
-        L->off_hr_overflow = take((B + 1) * sizeof(int32_t));
+        L->off_hr_overflow = take((2 * B + 2) * sizeof(int32_t));     // overflow flags [B], spill counter, work counter, slot counters [B]
+        L->off_hr_work = take(B * all * sizeof(int2));                // the tile kernel's work list
+        L->cand_chunks = (L->H * L->W + 256 * kFillCells - 1) / (256 * kFillCells);
+        L->off_cand_start = take(B * L->F * (size_t)(L->cand_chunks + 1) * sizeof(int32_t));   // seed candidates: chunk starts, then counts
     }
     L->off_act = take(B * L->F * 4 * (size_t)(L->H * L->W) * sizeof(float));
     L->off_act_count = take(B * L->F * sizeof(int32_t));
@@ -189,6 +224,7 @@ struct opa_cifcaf {
     DevSkeleton dev;
     int device;
     int tie_inside;                    // opa_cifcaf_set_tie_placement: -1 process-wide choice, 0 own launch, 1 inside the association kernel
+    opa_debug debug;                   // opa_cifcaf_set_debug
 };
 
 extern "C" {
@@ -197,6 +233,8 @@ const char* opa_version(void) { return "openpifpaf_amd 0.1 (gfx950)"; }
 int opa_abi_version(void) { return OPA_ABI_VERSION; }
 size_t opa_shape_bytes(void) { return sizeof(opa_shape); }
 size_t opa_params_bytes(void) { return sizeof(opa_params); }
+size_t opa_debug_bytes(void) { return sizeof(opa_debug); }
+void opa_default_debug(opa_debug* out) { if (out) *out = g_debug_default; }
 const char* opa_last_error(void) { return g_error.c_str(); }
 
 int opa_device_count(void) {
@@ -287,6 +325,7 @@ int opa_cifcaf_create(opa_cifcaf** out, int32_t n_keypoints, const int64_t* skel
     d->dev.adj_first = (const int32_t*)(base + skel_bytes + off_bytes + 3 * e_bytes);
     (void)hipGetDevice(&d->device);
     d->tie_inside = -1;
+    d->debug = g_debug_default;
     *out = d;
     return OPA_OK;
 }
@@ -300,6 +339,19 @@ void opa_cifcaf_destroy(opa_cifcaf* dec) {
 int opa_cifcaf_set_tie_placement(opa_cifcaf* dec, int32_t inside_association) {
     if (!dec) return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_set_tie_placement: null handle");
     dec->tie_inside = inside_association < 0 ? -1 : inside_association ? 1 : 0;
+    return OPA_OK;
+}
+
+int opa_cifcaf_set_debug(opa_cifcaf* dec, const opa_debug* in) {
+    if (!dec || !in) return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_set_debug: null argument");
+    if (in->assoc_watchdog_ticks <= 0 || in->assoc_growers < 0 || in->fc_split < 0 || in->fc_split > 64)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_set_debug: value out of range");
+    dec->debug = *in;
+    return OPA_OK;
+}
+int opa_cifcaf_get_debug(const opa_cifcaf* dec, opa_debug* out) {
+    if (!dec || !out) return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_get_debug: null argument");
+    *out = dec->debug;
     return OPA_OK;
 }
 
@@ -356,7 +408,7 @@ int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what, size_t* 
     struct Entry { const char* name; size_t off, end; };
     const Entry table[] = {
         {"tile_bitmaps", L.off_tile_clean, L.off_cifhr}, {"cifhr", L.off_cifhr, L.off_hr_slot}, {"cifhr_slots", L.off_hr_slot, L.off_hr_overflow},
-        {"cifhr_overflow", L.off_hr_overflow, L.off_act}, {"seed_count", L.off_seed_count, L.off_seed_f},
+        {"cifhr_overflow", L.off_hr_overflow, L.off_hr_overflow + (size_t)L.B * sizeof(int32_t)}, {"cifhr_work", L.off_hr_work, L.off_cand_start}, {"seed_count", L.off_seed_count, L.off_seed_f},
         {"seed_f", L.off_seed_f, L.off_seed_vxys}, {"seed_vxys", L.off_seed_vxys, L.off_seed_cell}, {"seed_cell", L.off_seed_cell, L.off_lists},
         {"lists", L.off_lists, L.off_list_counts}, {"list_counts", L.off_list_counts, L.off_list_bbox},
         {"list_bbox", L.off_list_bbox, L.off_occ},
@@ -416,10 +468,15 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     HrPool pool;                                      // the map is a pool of tiles (cifhr.hip)
     pool.slot = (int32_t*)(ws + L.off_hr_slot); pool.overflow = (int32_t*)(ws + L.off_hr_overflow); pool.cap = L.hr_pool_cap; pool.tpp = L.hr_tpp;
     pool.spill_cap = L.hr_spill_cap; pool.images = L.B; pool.spill_count = pool.overflow + L.B;
+    pool.work_count = pool.overflow + L.B + 1; pool.img_tiles = pool.overflow + L.B + 2; pool.work = (int2*)(ws + L.off_hr_work);
+    // the seed candidates lie where the sorted seeds will: the fill kernel is done with them before the sort writes those
+    SeedCandidates cand;
+    cand.cand = (float4*)(ws + L.off_seed_vxys); cand.start = (int32_t*)(ws + L.off_cand_start);
+    cand.count = cand.start + (size_t)L.B * L.F * L.cand_chunks; cand.chunks = L.cand_chunks; cand.produced = false;
     e = launch_cifhr(cif_dev, L.B, L.F, L.H, L.W, L.stride, 0.0, 1.0, p, cifhr, L.hr_rows, L.hr_pitch,
                      (float*)(ws + L.off_act), (int32_t*)(ws + L.off_act_count), st, false,
                      (unsigned long long*)(ws + L.off_hdr), layout_hash, ws + L.off_tile_clean,
-                     (int32_t*)(ws + L.off_seed_count), &pool);                                  // cifcaf.cpp:140-141
+                     (int32_t*)(ws + L.off_seed_count), &pool, dec->debug.stage_worklist ? &cand : nullptr);   // cifcaf.cpp:140-141
     if (e != hipSuccess) return fail_hip(e, "cifhr");
     // CafScored::fill (:153-161) of the caf_th list set and, for force complete, of the second one (:419-420): launches of
     // their own.  (OPA_FUSE_SCORED=1 lets them ride in the seed sort's launch, two 512-thread groups per workgroup beside
@@ -448,8 +505,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
                                               p.ablation_caf_no_rescore, (float*)(ws + L.off_lists_fc),
                                               (int32_t*)(ws + L.off_list_counts_fc), (float*)(ws + L.off_list_bbox_fc),
                                               L.bbox_chunks, L.bbox_chunks, nullptr, &pool);
-    const char* fuse_env = std::getenv("OPA_FUSE_SCORED");
-    const bool fuse = fuse_env && std::atoi(fuse_env) != 0;
+    const bool fuse = dec->debug.fuse_scored != 0;
     TieScratch ties;
     ties.big = ws + L.off_act; ties.big_stride = (size_t)L.F * 4 * (L.H * L.W) * sizeof(float);
     ties.small_ = ws + L.off_tie_small; ties.small_stride = L.tie_small_stride;
@@ -459,15 +515,13 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     // images with the most seeds are both the likeliest to hold equal scores and the slowest to associate -- but with
     // several decodes in flight (DecodeLanes) the pass overlaps like the association does instead of filling the chip
     // for 80 us per batch.  The separate launch, whose time shows up under its own name, stays the default.
-    const char* fuse_ties_env = std::getenv("OPA_FUSE_TIES");
-    const bool fuse_ties = seed_tie_order() >= 1 && (dec->tie_inside >= 0 ? dec->tie_inside == 1
-                                                       : seed_tie_order() == 2 || (fuse_ties_env && std::atoi(fuse_ties_env) != 0));
+    const bool fuse_ties = seed_tie_order() >= 1 && (dec->tie_inside >= 0 ? dec->tie_inside == 1 : seed_tie_order() == 2);
     ties.defer = fuse_ties ? 1 : 0;
     e = launch_cifseeds(cif_dev, L.B, L.F, L.H, L.W, L.stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
                         (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap,
                         (int32_t*)(ws + L.off_seed_count), (int32_t*)(ws + L.off_seed_f),
                         (float*)(ws + L.off_seed_vxys), st, false, (int32_t*)(ws + L.off_seed_cell),
-                        L.occ_h, L.occ_w, true, fuse ? scored : nullptr, fuse ? n_scored : 0, &ties, &pool);   // :144-146
+                        L.occ_h, L.occ_w, true, fuse ? scored : nullptr, fuse ? n_scored : 0, &ties, &pool, &cand);   // :144-146
     if (e != hipSuccess) return fail_hip(e, "cifseeds");
     if (!fuse)
         for (int k = 0; k < n_scored; k++) {
@@ -501,7 +555,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     make_tie_args(&a.tie, &a.tie_sort, (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap, (int32_t*)(ws + L.off_seed_count), cif_dev,
                   L.F, 5, L.H * L.W, L.stride, (int32_t*)(ws + L.off_seed_f), (float*)(ws + L.off_seed_vxys),
                   (int32_t*)(ws + L.off_seed_cell), L.occ_h, L.occ_w, ties);
-    e = launch_assoc(a, dec->dev, p, st);                                                     // :176-261
+    e = launch_assoc(a, dec->dev, p, st, dec->debug);                                         // :176-261
     if (e != hipSuccess) return fail_hip(e, "association");
     return OPA_OK;
 }

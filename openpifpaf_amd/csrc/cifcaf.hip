@@ -3747,7 +3747,7 @@ static hipError_t launch_fc_nw(const AssocArgs& a, const DevSkeleton& sk, const 
     const int fill = (256 + a.B - 1) / a.B;
     if (S > fill) S = fill;
     if (S < 1) S = 1;
-    if (const char* e = getenv("OPA_FC_SPLIT")) { const int v = atoi(e); if (v >= 1 && v <= 64) S = v; }   // tests: other splits
+    if (a.fc_split >= 1 && a.fc_split <= 64) S = a.fc_split;   // tests: other splits
     cifcaf_fc_kernel<REG, NW><<<a.B * S, NW * kWave, lds, st>>>(a, sk, p, growers, nms_waves, S);
     return hipGetLastError();
 }
@@ -3779,10 +3779,7 @@ static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, con
     }
     if (growers < 1) return hipErrorInvalidValue;
     if (growers > NW - 1) growers = NW - 1;
-    if (const char* e = getenv("OPA_ASSOC_GROWERS")) {   // tests: other interleavings of the same result
-        const int v = atoi(e);
-        if (v >= 1 && v < growers) growers = v;
-    }
+    if (a.max_growers >= 1 && a.max_growers < growers) growers = a.max_growers;   // tests: other interleavings of the same result
     int nms_waves = NW;                              // large annotation capacities: fewer waves share the NMS pass
     const size_t nms_fixed = nms_shared_bytes(a.max_ann, K);
     while (nms_waves > 1 && shared + nms_fixed + (size_t)nms_waves * nms_scratch_bytes(a.max_ann) > budget) nms_waves--;
@@ -3803,9 +3800,7 @@ static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, con
 // waves per workgroup of the association kernel: 1 coordinator + up to NW-1 growers.  12 is what ships; the 8- and
 // 16-wave instantiations (OPA_ASSOC_WAVES, interleaving experiments of round 2) double the compile time of this file
 // and are built only with -DOPA_ASSOC_ALL_WAVES.
-static int assoc_waves() {
-    const char* e = getenv("OPA_ASSOC_WAVES");
-    const int v = e ? atoi(e) : 0;
+static int assoc_waves(int v) {
 #ifdef OPA_ASSOC_ALL_WAVES
     return v == 8 || v == 12 || v == 16 ? v : kAssocWavesDefault;
 #else
@@ -3813,44 +3808,39 @@ static int assoc_waves() {
 #endif
 }
 
-hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
+hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevParams& p, hipStream_t st, const opa_debug& dbg) {
     AssocArgs a = args;
-    if (const char* e = getenv("OPA_ASSOC_BBOX")) { if (atoi(e) == 0) a.list_bbox = a.list_bbox_fc = nullptr; }   // A/B: scan every chunk
+    // (every switch comes from the decoder's opa_debug -- opa_cifcaf_set_debug; its defaults took the OPA_* environment variables
+    // in when the library was loaded -- no launch reads the environment)
+    if (!dbg.assoc_bbox) a.list_bbox = a.list_bbox_fc = nullptr;                          // A/B: scan every chunk
     // (the argument needs a joint's box to hold the joint's own cell: true for a reduced minimum scale >= 1 cell --
     // the reference's is 2 -- not for a box that may shrink to the one cell next to it; and the minimum is only applied
     // when the map is reduced at all, occupancy.cpp:14-18: with reduction == 1 the box is the raw joint scale)
     a.dedup = (p.occupancy_reduction != 1.0 && p.occupancy_min_scale_reduced >= 1.0) ? 1 : 0;
-    if (const char* e = getenv("OPA_ASSOC_DEDUP")) { if (atoi(e) == 0) a.dedup = 0; }   // A/B and tests: same result without it
-    a.predict = 1; a.predict_th = 0.3f; a.predict_min_v = 0.5f;
-    if (const char* e = getenv("OPA_ASSOC_PREDICT_MINV")) a.predict_min_v = (float)atof(e);   // seeds below this confidence grow without the walk
-    if (const char* e = getenv("OPA_ASSOC_PREDICT")) a.predict = atoi(e) != 0;          // A/B and tests: boxes are published only for assigned joints
-    if (const char* e = getenv("OPA_ASSOC_PREDICT_TH")) a.predict_th = (float)atof(e);  // raw CAF confidence a predicted bone needs
-    a.coll_shift = 1;
-    if (const char* e = getenv("OPA_ASSOC_COLLIDE_SHIFT")) a.coll_shift = atoi(e);       // 0: anywhere inside the earlier candidate's box (round 4)
-    a.lookahead = 1;
-    if (const char* e = getenv("OPA_ASSOC_LOOKAHEAD")) a.lookahead = atoi(e) != 0;      // A/B and tests: seeds enter the pool in list order only
-    a.prededup = 1;
-    if (const char* e = getenv("OPA_ASSOC_PREDEDUP")) a.prededup = atoi(e) != 0;         // A/B and tests: the coordinator's refill walks every seed
-    a.inherit = 1;
-    a.collide = 1;
-    a.timing = 0;
-    a.help = kHelp ? 1 : 0;
-    if (const char* e = getenv("OPA_ASSOC_HELP")) a.help = kHelp && atoi(e) != 0;  // A/B and tests: every growth scans its own lists
-    a.spec = kWalk ? 1 : 0;
-    if (const char* e = getenv("OPA_ASSOC_SPEC")) a.spec = kWalk && atoi(e) != 0;  // (walk builds) A/B: every bone scanned on demand, one at a time
-    if (const char* e = getenv("OPA_ASSOC_TIMING")) a.timing = atoi(e) != 0;      // phase tick counters of the coordinator (statistics slots 12, 17-20)
-    if (const char* e = getenv("OPA_ASSOC_COLLIDE")) a.collide = atoi(e) != 0;     // A/B: growths stop only when their SEED is covered
-    if (const char* e = getenv("OPA_ASSOC_INHERIT")) a.inherit = atoi(e) != 0;     // A/B: predictions lapse with the growth that made them
-    a.watchdog_ticks = kWatchdogTicksDefault;
-    if (const char* e = getenv("OPA_ASSOC_WATCHDOG_TICKS")) { const long long v = atoll(e); if (v > 0) a.watchdog_ticks = v; }
+    if (!dbg.assoc_dedup) a.dedup = 0;                                                    // A/B and tests: same result without it
+    a.predict = dbg.assoc_predict != 0;           // 0: boxes are published only for assigned joints
+    a.predict_th = dbg.assoc_predict_th;          // raw CAF confidence a predicted bone needs
+    a.predict_min_v = dbg.assoc_predict_min_v;    // seeds below this confidence grow without the walk
+    a.coll_shift = dbg.assoc_collide_shift;       // 0: anywhere inside the earlier candidate's box (round 4)
+    a.lookahead = dbg.assoc_lookahead != 0;       // 0: seeds enter the pool in list order only
+    a.prededup = dbg.assoc_prededup != 0;         // 0: the coordinator's refill walks every seed
+    a.inherit = dbg.assoc_inherit != 0;           // 0: predictions lapse with the growth that made them
+    a.collide = dbg.assoc_collide != 0;           // 0: growths stop only when their SEED is covered
+    a.timing = dbg.assoc_timing != 0;             // phase tick counters of the coordinator (statistics slots 12, 17-20)
+    a.help = kHelp && dbg.assoc_help != 0;        // (helper builds) 0: every growth scans its own lists
+    a.spec = kWalk && dbg.assoc_spec != 0;        // (walk builds) 0: every bone scanned on demand, one at a time
+    a.watchdog_ticks = dbg.assoc_watchdog_ticks > 0 ? dbg.assoc_watchdog_ticks : kWatchdogTicksDefault;
+    a.max_growers = dbg.assoc_growers;
+    a.fc_split = dbg.fc_split;
+    const int waves = assoc_waves(dbg.assoc_waves);
     const int K = a.K, E = 2 * a.A;
     // the seed pool packs cell coordinates into 12 bits, the field into 8 and the seed index into 24
     if (a.occ_w > 4096 || a.occ_h > 4096 || a.F > 256 || a.seed_cap > 0xFFFFFF) return hipErrorInvalidValue;
     if (K > 256 || a.A > 256) return hipErrorInvalidValue;      // a slot's joints and bone are packed into 8 bits each
     const bool reg = K <= kWave && E <= kWave;       // pose, frontier and heap fit the lanes of a wave
     hipError_t e;
-    if (!reg) e = assoc_waves() == 8 ? launch_assoc_nw<false, 8>(a, sk, p, st) : launch_assoc_nw<false, 12>(a, sk, p, st);  // LDS-resident growth state
-    else switch (assoc_waves()) {
+    if (!reg) e = waves == 8 ? launch_assoc_nw<false, 8>(a, sk, p, st) : launch_assoc_nw<false, 12>(a, sk, p, st);  // LDS-resident growth state
+    else switch (waves) {
         case 8: e = launch_assoc_nw<true, 8>(a, sk, p, st); break;
 #ifdef OPA_ASSOC_ALL_WAVES
         case 16: e = launch_assoc_nw<true, 16>(a, sk, p, st); break;

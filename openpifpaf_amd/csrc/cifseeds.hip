@@ -110,6 +110,98 @@ __global__ __launch_bounds__(256) void cifseeds_fill_kernel(
     }
 }
 
+// The decode path's form: the candidates cif_active_kernel left (common.hpp: SeedCandidates) instead of the field.  Same grid,
+// same blocks -- workgroup (plane, chunk) holds the candidates among cells [1024 chunk, 1024 chunk + 1024) of its plane, in
+// cell order -- so the block table the tie pass reads (a key's block follows from its cell index) means what it meant; what
+// changes is that a batch of 32 COCO images reads ~150 000 candidates of 16 bytes instead of three planes of 71 MB.
+__global__ __launch_bounds__(256) void cifseeds_fill_cand_kernel(
+        const float* __restrict__ cif, const float4* __restrict__ cand, const int32_t* __restrict__ cand_start,
+        const int32_t* __restrict__ cand_count, int F, int NC, int H, int W, int stride,
+        const float* __restrict__ cifhr, int hr_rows, int hr_cols, int hr_pitch,
+        double threshold, int ablation_nms, int no_rescore,
+        unsigned long long* __restrict__ keys, int sort_cap, int cap, int32_t* __restrict__ seed_count,
+        int2* __restrict__ wg_tab, size_t tab_stride, unsigned long long* __restrict__ key_copy, size_t copy_stride,
+        const int32_t* __restrict__ hr_slot, int hr_tpp, size_t hr_image_stride) {
+    const int HW = H * W;
+    const int plane = blockIdx.x;              // b*F + f
+    const int b = plane / F, f = plane - b * F;
+    const int lane = threadIdx.x & 63;
+    const int chunks = gridDim.y;
+    const int first = cand_start[(size_t)plane * chunks + blockIdx.y];
+    const int last = blockIdx.y + 1 < chunks ? cand_start[(size_t)plane * chunks + blockIdx.y + 1] : cand_count[plane];
+    if (first >= last) {                       // (uniform) nothing in this chunk -- most chunks of most planes
+        if (threadIdx.x == 0 && wg_tab) wg_tab[(size_t)b * tab_stride + (size_t)f * chunks + blockIdx.y] = make_int2(0, 0);
+        return;
+    }
+    const float* P = cif + (size_t)plane * NC * HW;
+    const float4* C = cand + (size_t)plane * HW;
+    int o[kFillCells]; float c[kFillCells], xin[kFillCells], yin[kFillCells]; bool on[kFillCells];
+#pragma unroll
+    for (int r = 0; r < kFillCells; r++) {
+        const int i = first + r * 256 + threadIdx.x;
+        const float4 q = C[i < last ? i : first];
+        on[r] = i < last;                                            // (a candidate passed cif_seeds.cpp:47 already)
+        o[r] = __float_as_int(q.x); c[r] = q.y; xin[r] = q.z; yin[r] = q.w;
+    }
+#pragma unroll
+    for (int r = 0; r < kFillCells; r++) {
+        if (on[r]) {
+            if (ablation_nms) {                                      // :35-40,49-51: 3x3 max-pool gate
+                const int j = o[r] / W, i = o[r] - j * W;
+                float m = c[r];
+                for (int dj = -1; dj <= 1; dj++) for (int di = -1; di <= 1; di++) {
+                    const int jj = j + dj, ii = i + di;
+                    if (jj < 0 || jj >= H || ii < 0 || ii >= W) continue;
+                    m = fmaxf(m, P[HW + jj * W + ii]);
+                }
+                if (c[r] < m) on[r] = false;
+            }
+            if (on[r]) {
+                const float x = xin[r] * (float)stride;              // :53-54
+                const float y = yin[r] * (float)stride;
+                if (!no_rescore) {                                   // :56-58
+                    const float hv = cifhr_value(cifhr + (size_t)b * hr_image_stride, F, hr_rows, hr_cols, hr_pitch, f, x, y, -1.0f,
+                                                 nullptr, 0, hr_pitch / kHrTileW, hr_slot ? hr_slot + (size_t)b * F * hr_tpp : nullptr, hr_tpp);
+                    c[r] = (float)(0.9 * (double)hv + 0.1 * (double)c[r]);
+                }
+                if ((double)c[r] < threshold) on[r] = false;         // :59
+            }
+        }
+    }
+    __shared__ int wave_total[kFillCells][4];
+    __shared__ int wg_base;
+    unsigned long long mask[kFillCells];
+    const int w = threadIdx.x >> 6;
+#pragma unroll
+    for (int r = 0; r < kFillCells; r++) { mask[r] = __ballot(on[r]); if (lane == 0) wave_total[r][w] = __popcll(mask[r]); }
+    __syncthreads();
+    int total = 0, before[kFillCells];
+#pragma unroll
+    for (int r = 0; r < kFillCells; r++) {
+        before[r] = total;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { if (k < w) before[r] += wave_total[r][k]; total += wave_total[r][k]; }
+    }
+    if (threadIdx.x == 0) {
+        wg_base = total ? atomicAdd(&seed_count[b], total) : 0;
+        if (wg_tab) wg_tab[(size_t)b * tab_stride + (size_t)f * chunks + blockIdx.y] = make_int2(wg_base, total);
+    }
+    if (total == 0) return;                          // (uniform over the workgroup)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kFillCells; r++) {
+        if (on[r]) {
+            const int slot = wg_base + before[r] + __popcll(mask[r] & ((1ull << lane) - 1ull));
+            if (slot < cap) {
+                const unsigned idx = (unsigned)(f * HW + o[r]);
+                const unsigned long long key = ((unsigned long long)sortable_bits(c[r]) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+                keys[(size_t)b * sort_cap + slot] = key;
+                if (key_copy) key_copy[(size_t)b * copy_stride + slot] = key;
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ void compare_exchange_desc(unsigned long long& a, unsigned long long& b, bool desc) {
     if ((a < b) == desc) { const unsigned long long t = a; a = b; b = t; }
 }
@@ -412,7 +504,7 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
                            unsigned long long* keys, int sort_cap, int32_t* seed_count,
                            int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det,
                            int32_t* seed_cell, int occ_h, int occ_w, bool count_is_zero,
-                           const ScoredArgs* scored, int n_scored, const TieScratch* ties, const HrPool* pool) {
+                           const ScoredArgs* scored, int n_scored, const TieScratch* ties, const HrPool* pool, const SeedCandidates* cand) {
     static_assert(kScoredThreads == 512, "the fused launch packs two cafscored groups into a 1024-thread workgroup");
     const int HW = H * W, cap = F * HW, NC = det ? 6 : 5;
     if (!count_is_zero) {                             // (the decode pipeline clears the counters in its first kernel)
@@ -422,7 +514,18 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
     }
     const bool tie_pass = ties && ties->big && seed_tie_order() >= 1;
     dim3 grid(B * F, (HW + 256 * kFillCells - 1) / (256 * kFillCells));
-    cifseeds_fill_kernel<<<grid, 256, 0, st>>>(cif, F, NC, H, W, stride, cifhr, hr_rows, hr_cols, hr_pitch,
+    if (cand && cand->produced && !det && cand->chunks == (int)grid.y)
+        cifseeds_fill_cand_kernel<<<grid, 256, 0, st>>>(cif, cand->cand, cand->start, cand->count, F, NC, H, W, stride, cifhr, hr_rows,
+                                                        hr_cols, hr_pitch, p.seed_threshold, p.ablation_cifseeds_nms,
+                                                        p.ablation_cifseeds_no_rescore, keys, sort_cap, cap, seed_count,
+                                                        tie_pass ? (int2*)ties->small_ : nullptr,
+                                                        tie_pass ? ties->small_stride / sizeof(int2) : 0,
+                                                        tie_pass ? tie_key_copy(ties->big, cap) : nullptr,
+                                                        tie_pass ? ties->big_stride / sizeof(unsigned long long) : 0,
+                                                        pool ? pool->slot : nullptr, pool ? pool->tpp : 0,
+                                                        pool ? (size_t)pool->cap * kHrTileH * kHrTileW : (size_t)F * hr_rows * hr_pitch);
+    else
+        cifseeds_fill_kernel<<<grid, 256, 0, st>>>(cif, F, NC, H, W, stride, cifhr, hr_rows, hr_cols, hr_pitch,
                                                p.seed_threshold, det ? 0 : p.ablation_cifseeds_nms,
                                                det ? 0 : p.ablation_cifseeds_no_rescore, keys, sort_cap, cap, seed_count,
                                                tie_pass ? (int2*)ties->small_ : nullptr,

@@ -15,7 +15,6 @@ __device__ __forceinline__ float from_sortable(unsigned s) {
     return __uint_as_float((s & 0x80000000u) ? (s & 0x7fffffffu) : ~s);
 }
 
-constexpr int kFillCells = 4;            // CIF cells per thread: their confidence loads are in flight together
 
 // keys -> sorted seeds (cif_seeds.cpp:100-113): the seed of rank t
 __device__ __forceinline__ void store_seed(unsigned long long key, int t, int b, const float* __restrict__ cif, int F, int NC,

@@ -40,7 +40,9 @@ struct Layout {
     // scratch of the seed tie pass (cifseeds.hip): `big` lies in the active-cell list (dead once the map is built, and
     // exactly as large), `small` in the occupancy bitmap (cleared by the association kernel afterwards) where it fits
     size_t off_tie_small, tie_small_stride, off_tie_state;
-    size_t off_hr_slot, off_hr_overflow;   // the pooled map's slot tables [B][F][tpp], overflow flags [B] + the spill region's counter
+    size_t off_hr_slot, off_hr_overflow;   // the pooled map's slot tables [B][F][tpp]; overflow flags [B], spill counter, work counter, slot counters [B]
+    size_t off_hr_work, off_cand_start;    // the tile kernel's work list [B*F*tpp] int2; seed candidates: chunk starts [B*F][chunks] + counts [B*F]
+    int cand_chunks;                       // 1024-cell chunks of a CIF plane
 };
 
 bool make_layout(const opa_shape& s, Layout* L, const char** why);
@@ -88,14 +90,25 @@ struct HrPool {
     // only when that runs out too is the image flagged.  `spill_cap` 0: no such region.
     int spill_cap, images;
     int32_t* spill_count;  // [1]
+    // Work-list form of the tile kernel (cifhr.hip): cif_active_kernel gives every reached tile its slot -- `img_tiles` [B]: slots
+    // taken per image -- and appends (plane * tpp + tile, slot) to `work`, `work_count` [1] entries so far.  overflow [B],
+    // spill_count, work_count and img_tiles [B] are ONE region of 2B + 2 words, zeroed by a launch before that kernel.
+    int2* work;            // [B * F * tpp]
+    int32_t* work_count;
+    int32_t* img_tiles;
 };
+// The cells CifSeeds::fill looks at (cif_seeds.cpp:47: !(c < seed_threshold)), written by cif_active_kernel on its one pass
+// over the CIF field: per (image, field) plane (cell index as float bits, c, x, y) in raster order, where the candidates of
+// every chunk of 1024 cells begin (`start` [planes][chunks]) and how many there are (`count` [planes]).
+constexpr int kFillCells = 4;             // cells (or candidates) per thread of the seed fill: 1024 per workgroup
+struct SeedCandidates { float4* cand; int32_t* start; int32_t* count; int chunks; bool produced; };
 hipError_t launch_cifhr(const float* cif, int B, int F, int H, int W, int stride,
                         double min_scale, double factor, const DevParams& p,
                         float* cifhr, int hr_rows, int hr_pitch,
                         float* act, int32_t* act_count, hipStream_t st, bool det = false,
                         unsigned long long* ws_header = nullptr, unsigned long long layout_hash = 0,
                         unsigned char* tile_state = nullptr, int32_t* zero_per_image = nullptr,
-                        const HrPool* pool = nullptr);
+                        const HrPool* pool = nullptr, SeedCandidates* cand = nullptr);
 // one image's map as the dense [F][rows][cols] array (get_cifhr of a pooled map)
 hipError_t launch_cifhr_gather(const float* pool_image, const int32_t* slot_image, int F, int rows, int cols, int tiles_x, int tpp,
                                float* out, hipStream_t st);
@@ -119,7 +132,7 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
                            int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det = false,
                            int32_t* seed_cell = nullptr, int occ_h = 0, int occ_w = 0, bool count_is_zero = false,
                            const ScoredArgs* scored = nullptr, int n_scored = 0, const TieScratch* ties = nullptr,
-                           const HrPool* pool = nullptr);
+                           const HrPool* pool = nullptr, const SeedCandidates* cand = nullptr);
 // (`scored`: up to two CafScored list sets built by the SAME launch as the seed sort -- they only share the finished
 // map, and the sort's few workgroups leave the chip to them)
 
@@ -208,6 +221,7 @@ struct AssocArgs {
     int prededup;               // 1: ... and by the whole workgroup before the coordinator starts (needs dedup; exact; see cifcaf.hip)
     int32_t* fc_meta;           // [B, 4] seed kernel -> force-complete kernel: poses stored, dropped, failed, workgroup counter
     long long watchdog_ticks;   // 10-ns ticks after which every wait inside one launch gives up (status -1)
+    int max_growers, fc_split;  // opa_debug: at most this many growing waves (0: as many as fit); force-complete workgroups per image (0: automatic)
     unsigned* occ;           // occupancy bitmap [B][occ_image_words]: per image [F][occ_h][(occ_w+31)/32] words, zeroed by the kernel
     size_t occ_image_words;
     int32_t* stats;          // [B, 24] statistics of the association (or null), see include/openpifpaf_amd.h
@@ -222,7 +236,7 @@ struct AssocArgs {
 void make_tie_args(TieArgs* a, SortArgs* g, unsigned long long* keys, int sort_cap, const int32_t* seed_count, const float* cif,
                    int F, int NC, int HW, int stride, int32_t* seed_f, float* seed_vxys, int32_t* seed_cell, int occ_h, int occ_w,
                    const TieScratch& t);
-hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st);
+hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st, const opa_debug& dbg);
 
 struct DetArgs {
     int B, F, max_det, occ_h, occ_w, seed_cap;

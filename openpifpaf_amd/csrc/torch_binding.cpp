@@ -77,6 +77,30 @@ struct CifCaf : torch::CustomClassHolder {
     void set_cifhr_pool_tiles(int64_t n) { cifhr_pool_tiles = n < 0 ? -1 : n; }
     int64_t get_cifhr_pool_tiles() { return cifhr_pool_tiles; }
     void use_full_pool() { cifhr_pool_tiles = -1; }
+    // opa_debug of this decoder's handle by field name (A/B and test switches: exact kernel variants, the watchdog; none changes
+    // a result): set_debug("assoc_growers", 3); an unknown name raises
+    void set_debug(const std::string& name, double value) {
+        opa_debug d;
+        check(opa_cifcaf_get_debug(handle, &d), "opa_cifcaf_get_debug");
+#define OPA_DBG_FIELD(F, T) if (name == #F) { d.F = (T)value; check(opa_cifcaf_set_debug(handle, &d), "opa_cifcaf_set_debug"); return; }
+        OPA_DBG_FIELD(stage_worklist, int32_t) OPA_DBG_FIELD(fuse_scored, int32_t) OPA_DBG_FIELD(scored_one_pass, int32_t)
+        OPA_DBG_FIELD(assoc_waves, int32_t) OPA_DBG_FIELD(assoc_growers, int32_t) OPA_DBG_FIELD(assoc_bbox, int32_t)
+        OPA_DBG_FIELD(assoc_dedup, int32_t) OPA_DBG_FIELD(assoc_prededup, int32_t) OPA_DBG_FIELD(assoc_predict, int32_t)
+        OPA_DBG_FIELD(assoc_predict_min_v, float) OPA_DBG_FIELD(assoc_predict_th, float) OPA_DBG_FIELD(assoc_collide, int32_t)
+        OPA_DBG_FIELD(assoc_collide_shift, int32_t) OPA_DBG_FIELD(assoc_inherit, int32_t) OPA_DBG_FIELD(assoc_lookahead, int32_t)
+        OPA_DBG_FIELD(assoc_help, int32_t) OPA_DBG_FIELD(assoc_spec, int32_t) OPA_DBG_FIELD(assoc_timing, int32_t)
+        OPA_DBG_FIELD(assoc_persistent, int32_t) OPA_DBG_FIELD(fc_split, int32_t) OPA_DBG_FIELD(assoc_watchdog_ticks, int64_t)
+#undef OPA_DBG_FIELD
+        TORCH_CHECK(false, "opa_debug has no field ", name);
+    }
+    // did an image of the last decode run out of its tile pool (status -2)?  The only failure a larger pool cures.
+    bool pool_overflowed() {
+        if (!has_last) return false;
+        size_t off = 0, bytes = 0;
+        check(opa_cifcaf_workspace_view(&last_shape, "cifhr_overflow", &off, &bytes), "opa_cifcaf_workspace_view");
+        const torch::Tensor flags = workspace.narrow(0, (int64_t)off, (int64_t)last_shape.batch * 4).view(torch::kInt32);
+        return flags.ne(0).any().item<bool>();
+    }
 
     // batched extension: cif [B,F,5,H,W], caf [B,A,8,H,W] -> (ann [B,max,K,4], ids [B,max], counts [B])
     std::tuple<torch::Tensor, torch::Tensor, torch::Tensor> call_batch_impl(
@@ -131,8 +155,11 @@ struct CifCaf : torch::CustomClassHolder {
             // pool AND the batch's spill region (several structureless, all-active fields in one batch) comes back flagged
             // with no rows.  One look at the counts (they are what a caller reads first anyway), and if need be the batch is
             // decoded again with a pool that holds every tile -- from then on this decoder keeps that pool.
+            // (a failure of another kind -- the watchdog, status -1 -- is not cured by a larger pool: the flagged counts go back as
+            // they are and the pool setting stays; this look at the counts synchronises with the stream, so a caller that wants
+            // call_batch asynchronous chooses the pool up front: set_cifhr_pool_tiles(n) or use_full_pool())
             const torch::Tensor c = std::get<2>(result).cpu();
-            if (c.bitwise_and(OPA_COUNT_FAILED).any().item<bool>()) {
+            if (c.bitwise_and(OPA_COUNT_FAILED).any().item<bool>() && pool_overflowed()) {
                 cifhr_pool_tiles = -1;
                 result = call_batch_impl(cif, cif_stride, caf, caf_stride, torch::nullopt, torch::nullopt);
             }
@@ -149,8 +176,8 @@ struct CifCaf : torch::CustomClassHolder {
         if (initial_ids.has_value()) ii = initial_ids->unsqueeze(0);
         auto [out, ids, counts] = call_batch_impl(cif.unsqueeze(0), cif_stride, caf.unsqueeze(0), caf_stride, ia, ii);
         int64_t c = counts.cpu().item<int32_t>();
-        if ((c & OPA_COUNT_FAILED) && cifhr_pool_tiles == 0) {
-            // most likely the image's CIF cells reach more map tiles than the automatic pool holds (structureless
+        if ((c & OPA_COUNT_FAILED) && cifhr_pool_tiles == 0 && pool_overflowed()) {
+            //  the image's CIF cells reach more map tiles than the automatic pool holds (structureless
             // all-active fields do): once more with a pool that holds every tile
             cifhr_pool_tiles = -1;
             std::tie(out, ids, counts) = call_batch_impl(cif.unsqueeze(0), cif_stride, caf.unsqueeze(0), caf_stride, ia, ii);
@@ -458,16 +485,28 @@ TORCH_LIBRARY(openpifpaf_amd_decoder, m) {
         .def("set_cifhr_pool_tiles", &CifCaf::set_cifhr_pool_tiles)
         .def("get_cifhr_pool_tiles", &CifCaf::get_cifhr_pool_tiles)
         .def("use_full_pool", &CifCaf::use_full_pool)
+        .def("set_debug", &CifCaf::set_debug)
         .def("get_cifhr", &CifCaf::get_cifhr)                                            // :37-39
-        // :41-53 (n_keypoints, skeleton) -- plus this build's two capacities, so that a saved module decodes like the live one
+        // :41-53: the state is the reference's (n_keypoints, skeleton) pair.  This build's two capacities travel INSIDE the skeleton
+        // tensor, as one extra row (-1 - max_annotations, cifhr_pool_tiles) -- no joint index is negative -- so that a saved module
+        // decodes like the live one while modules saved by a build (or a reference) that knows only the pair still load.
         .def_pickle(
-            [](const c10::intrusive_ptr<CifCaf>& self) -> std::tuple<int64_t, torch::Tensor, int64_t, int64_t> {
-                return std::make_tuple(self->n_keypoints, self->skeleton, self->max_annotations, self->cifhr_pool_tiles);
+            [](const c10::intrusive_ptr<CifCaf>& self) -> std::tuple<int64_t, torch::Tensor> {
+                torch::Tensor extra = torch::empty({1, 2}, torch::kInt64);
+                extra[0][0] = -1 - self->max_annotations; extra[0][1] = self->cifhr_pool_tiles;
+                return std::make_tuple(self->n_keypoints, torch::cat({self->skeleton, extra}, 0));
             },
-            [](std::tuple<int64_t, torch::Tensor, int64_t, int64_t> state) -> c10::intrusive_ptr<CifCaf> {
-                auto obj = c10::make_intrusive<CifCaf>(std::get<0>(state), std::get<1>(state));
-                obj->max_annotations = std::get<2>(state);
-                obj->cifhr_pool_tiles = std::get<3>(state);
+            [](std::tuple<int64_t, torch::Tensor> state) -> c10::intrusive_ptr<CifCaf> {
+                torch::Tensor sk = std::get<1>(state).detach().cpu().contiguous().view({-1, 2});
+                int64_t max_ann = -1, pool = 0;
+                const int64_t n = sk.size(0);
+                if (n > 0 && sk[n - 1][0].item<int64_t>() < 0) {
+                    max_ann = -1 - sk[n - 1][0].item<int64_t>(); pool = sk[n - 1][1].item<int64_t>();
+                    sk = sk.narrow(0, 0, n - 1).contiguous();
+                }
+                auto obj = c10::make_intrusive<CifCaf>(std::get<0>(state), sk);
+                if (max_ann > 0) obj->max_annotations = max_ann;
+                obj->cifhr_pool_tiles = pool;
                 return obj;
             });
     m.def("grow_connection_blend", grow_connection_blend);                               // :55

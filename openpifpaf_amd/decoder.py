@@ -245,6 +245,14 @@ class CifCaf(Decoder):
     #: annotations come back through pinned memory without stalling either stream.
     decoder_workers = 2
 
+    def set_debug(self, **switches):
+        """A/B and test switches (``opa_debug``: exact kernel variants, the watchdog, measurements; none changes a result) of
+        this decoder's native handles -- the synchronous one and every decode lane's.  ``set_debug()`` restores the defaults."""
+        self._debug = dict(switches)
+        self.cpp_decoder.set_debug(**switches)
+        if getattr(self, '_lanes', None) is not None:
+            self._lanes.set_debug(**switches)
+
     def _decode_lanes(self):
         lanes = getattr(self, '_lanes', None)
         n = max(1, int(self.decoder_workers or 1))
@@ -256,6 +264,8 @@ class CifCaf(Decoder):
                 pending.result()
             lanes = native.DecodeLanes(len(self.cif_metas[0].keypoints), torch.LongTensor(self.caf_metas[0].skeleton) - 1,
                                        lanes=n, max_annotations=self.max_annotations, cifhr_pool_tiles=self.cifhr_pool_tiles)
+            if getattr(self, '_debug', None):
+                lanes.set_debug(**self._debug)
             self._lanes, self._lane_host, self._lane_pending, self._lanes_key = lanes, {}, {}, key
         return lanes
 

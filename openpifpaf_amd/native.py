@@ -19,6 +19,7 @@ reference only accepts CPU tensors, ``cifcaf.cpp:137-138``); results come back
 on the device the inputs were on.
 """
 import ctypes
+import os
 
 import torch
 
@@ -164,6 +165,26 @@ class CifCaf:
         (:func:`set_seed_tie_order`).  Same results bit for bit (``opa_cifcaf_set_tie_placement``)."""
         _lib.check(_lib.lib().opa_cifcaf_set_tie_placement(
             self._handle, -1 if inside_association is None else int(bool(inside_association))), 'opa_cifcaf_set_tie_placement')
+
+    def set_debug(self, **switches):
+        """A/B and test switches of THIS decoder (``opa_debug``, ``include/openpifpaf_amd.h``): exact variants of the kernels,
+        the watchdog, measurements -- none changes a result.  ``set_debug(assoc_growers=3)``; ``set_debug()`` with no
+        argument restores the defaults (the library's, with the ``OPA_*`` environment variables it read when it was loaded).
+        Nothing reads the environment during a decode."""
+        if switches:
+            d = self.get_debug()
+            for k, v in switches.items():
+                if not hasattr(d, k):
+                    raise AttributeError('opa_debug has no field %r' % k)
+                setattr(d, k, v)
+        else:
+            d = _lib.default_debug()
+        _lib.check(_lib.lib().opa_cifcaf_set_debug(self._handle, ctypes.byref(d)), 'opa_cifcaf_set_debug')
+
+    def get_debug(self):
+        d = _lib.Debug()
+        _lib.check(_lib.lib().opa_cifcaf_get_debug(self._handle, ctypes.byref(d)), 'opa_cifcaf_get_debug')
+        return d
 
     def __getstate__(self):
         return (self.n_keypoints, self.skeleton, self.max_annotations, self.cifhr_pool_tiles)
@@ -336,6 +357,28 @@ class CifCaf:
         return dense, rev.value
 
 
+_hw_queues_checked = False
+
+
+def ensure_hw_queues(lanes):
+    """Decode lanes (one HIP stream each) only run side by side while every stream has a hardware queue of its own; the HIP
+    runtime maps all streams of a process onto FOUR by default, and four lanes then share queues with the network's stream
+    (round 4: 54 k images/s with four lanes against 66 k with two; with eight queues 86 k).  The runtime reads
+    ``GPU_MAX_HW_QUEUES`` when it initialises, i.e. at the first GPU call of the process.  Called where lanes are set up
+    (:class:`DecodeLanes`, ``Predictor``): sets the variable to 8 when that is still possible and nothing was chosen -- an
+    explicit setting wins, importing the package changes nothing -- and says so, once, when it is too late."""
+    global _hw_queues_checked
+    if lanes <= 2 or _hw_queues_checked or os.environ.get('GPU_MAX_HW_QUEUES'):
+        return
+    _hw_queues_checked = True
+    if torch.cuda.is_initialized():
+        import warnings
+        warnings.warn('openpifpaf_amd: %d decode lanes on the HIP runtime\'s default of 4 hardware queues -- they will share '
+                      'queues; export GPU_MAX_HW_QUEUES=8 before the first GPU call of the process' % lanes, RuntimeWarning)
+    else:
+        os.environ['GPU_MAX_HW_QUEUES'] = '8'
+
+
 class DecodeLanes:
     """Several batched decodes in flight at once.  One decode is six kernels in a row whose longest, the
     association, keeps one workgroup per image busy (32 of 256 compute units for a batch of 32) -- the stages of the
@@ -365,6 +408,7 @@ class DecodeLanes:
             return self.tensors
 
     def __init__(self, n_keypoints, skeleton, *, lanes=2, max_annotations=DEFAULT_MAX_ANNOTATIONS, cifhr_pool_tiles=0):
+        ensure_hw_queues(lanes)
         self.decoders = [CifCaf(n_keypoints, skeleton, max_annotations=max_annotations, cifhr_pool_tiles=cifhr_pool_tiles)
                          for _ in range(max(1, lanes))]
         if len(self.decoders) > 1:                       # the tie pass inside the association kernel: +11 % with twelve lanes (round 4)
@@ -372,6 +416,11 @@ class DecodeLanes:
                 d.set_tie_placement(True)
         self.streams = [torch.cuda.Stream(priority=-1) for _ in self.decoders]
         self._next = 0
+
+    def set_debug(self, **switches):
+        """``CifCaf.set_debug`` on every lane's decoder."""
+        for d in self.decoders:
+            d.set_debug(**switches)
 
     def submit(self, cif, cif_stride, caf, caf_stride, *, params=None):
         lane = self._next

@@ -28,8 +28,10 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def _decode_all(native, skeleton0, cifs, cafs, **kw):
+def _decode_all(native, skeleton0, cifs, cafs, debug=None, **kw):
     dec = native.CifCaf(cifs.shape[1], torch.from_numpy(skeleton0), **kw)
+    if debug:
+        dec.set_debug(**debug)                    # opa_debug: exact variants of the kernels, per decoder
     out, ids, counts = dec.call_batch(dev(cifs), 8, dev(cafs), 8)
     out, counts = out.cpu().numpy(), counts.cpu().numpy()
     assert not native.count_overflowed(counts).any()
@@ -125,8 +127,7 @@ def test_wrong_predictions_are_resolved(native, port, coco_skeleton0):
     stopped.  When the candidate dies instead -- covered by an earlier pose -- the seeds it shadowed are free
     again and must be handed out after all (statistics slot 5), and the result must still be the sequential
     loop's.  Crowded images make that happen; noisy CIF regressions add blobs spread over several boxes.  Every
-    image is also decoded with 1 and 3 growers only (OPA_ASSOC_GROWERS): other interleavings, same result."""
-    import os
+    image is also decoded with 1 and 3 growers only (opa_debug::assoc_growers): other interleavings, same result."""
     from openpifpaf_amd import synth
     rng = np.random.default_rng(11)
     cases = []
@@ -139,34 +140,29 @@ def test_wrong_predictions_are_resolved(native, port, coco_skeleton0):
     want = [port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)[0] for b in range(len(cases))]
     totals = None
     # round 4: a growth is also stopped when it assigns a joint inside an earlier candidate's box of that joint
-    # (OPA_ASSOC_COLLIDE) and a candidate inherits the predictions of the growths stopped because of it
-    # (OPA_ASSOC_INHERIT) -- predictions lapse far less often, so the lapse-and-hand-out-again branch is counted with both
+    # (assoc_collide) and a candidate inherits the predictions of the growths stopped because of it
+    # (assoc_inherit) -- predictions lapse far less often, so the lapse-and-hand-out-again branch is counted with both
     # switched off; every setting must give the sequential loop's result
-    settings = [({}, None), ({'OPA_ASSOC_COLLIDE': '0', 'OPA_ASSOC_INHERIT': '0'}, None),
-                ({'OPA_ASSOC_COLLIDE': '0'}, None), ({'OPA_ASSOC_INHERIT': '0'}, None),
-                ({'OPA_ASSOC_GROWERS': '1'}, 1), ({'OPA_ASSOC_GROWERS': '3'}, 3),
-                ({'OPA_ASSOC_PREDEDUP': '0'}, None),      # round 5: every seed through the coordinator's refill
+    settings = [({}, None), ({'assoc_collide': 0, 'assoc_inherit': 0}, None),
+                ({'assoc_collide': 0}, None), ({'assoc_inherit': 0}, None),
+                ({'assoc_growers': 1}, 1), ({'assoc_growers': 3}, 3),
+                ({'assoc_prededup': 0}, None),      # round 5: every seed through the coordinator's refill
                 # round 5: boxes are predicted from single cells of the raw CAF field before the search runs -- off, for every
                 # seed however weak (wrong predictions by the dozen: the lapse-and-hand-out-again branch again), and with the
                 # collision test of round 4 (anywhere inside the earlier candidate's box)
-                ({'OPA_ASSOC_PREDICT': '0'}, None), ({'OPA_ASSOC_PREDICT_MINV': '0'}, None),
-                ({'OPA_ASSOC_PREDICT_MINV': '0', 'OPA_ASSOC_GROWERS': '3'}, 3), ({'OPA_ASSOC_COLLIDE_SHIFT': '0'}, None)]
+                ({'assoc_predict': 0}, None), ({'assoc_predict_min_v': 0.0}, None),
+                ({'assoc_predict_min_v': 0.0, 'assoc_growers': 3}, 3), ({'assoc_collide_shift': 0}, None)]
     started = {}
     for env, growers in settings:
-        os.environ.update(env)
-        try:
-            got, dec = _decode_all(native, coco_skeleton0, cifs, cafs)
-            stats = dec.assoc_stats().cpu().numpy()
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
+        got, dec = _decode_all(native, coco_skeleton0, cifs, cafs, debug=env)
+        stats = dec.assoc_stats().cpu().numpy()
         for b in range(len(cases)):
             ok, msg = compare_annotations(got[b], want[b])
             assert ok, 'setting %r image %d: %s' % (env, b, msg)
         t = stats.sum(axis=0)
         assert t[0] == t[1] + t[2] + t[3] + t[4], env
         started[tuple(sorted(env.items()))] = int(t[0])
-        if env == {'OPA_ASSOC_COLLIDE': '0', 'OPA_ASSOC_INHERIT': '0'}:
+        if env == {'assoc_collide': 0, 'assoc_inherit': 0}:
             totals = t
         if growers:
             assert (stats[:, 13] == growers).all()
@@ -198,17 +194,11 @@ def test_wholebody_batch16(native, port):
     assert n_poses >= 4 * (1 + 3 + 6 + 10) * 0.8
     # round 5 (large skeletons): predicted boxes, the lookahead that lets the first seed of the NEXT person into the pool ahead of
     # the scan, the tighter collision test -- each switched off, and predictions from every seed: the same annotations, bit for bit
-    import os
     st = dec.assoc_stats().cpu().numpy()
     assert st[:, 21].sum() > 0 and st[:, 22].sum() > 0, 'no box was predicted / no seed entered early: the inputs no longer exercise this'
-    for env in ({'OPA_ASSOC_LOOKAHEAD': '0'}, {'OPA_ASSOC_PREDICT': '0'}, {'OPA_ASSOC_COLLIDE_SHIFT': '0'},
-                {'OPA_ASSOC_PREDICT_MINV': '0'}, {'OPA_ASSOC_LOOKAHEAD': '1', 'OPA_ASSOC_GROWERS': '3'}):
-        os.environ.update(env)
-        try:
-            other, _ = _decode_all(native, skel0, cifs[8:], cafs[8:])
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
+    for env in ({'assoc_lookahead': 0}, {'assoc_predict': 0}, {'assoc_collide_shift': 0},
+                {'assoc_predict_min_v': 0.0}, {'assoc_lookahead': 1, 'assoc_growers': 3}):
+        other, _ = _decode_all(native, skel0, cifs[8:], cafs[8:], debug=env)
         for b in range(8):
             assert np.array_equal(other[b], got[8 + b]), 'image %d changes with %r' % (8 + b, env)
 
@@ -246,8 +236,7 @@ def test_list_chunk_boxes_bound_their_chunks_and_do_not_change_the_decode(native
         want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0)
         ok, msg = compare_annotations(got[b], want)
         assert ok, 'seed %d: %s' % (seed, msg)
-    monkeypatch.setenv('OPA_ASSOC_BBOX', '0')
-    plain, _ = _decode_all(native, coco_skeleton0, cifs, cafs, max_annotations=128)
+    plain, _ = _decode_all(native, coco_skeleton0, cifs, cafs, max_annotations=128, debug={'assoc_bbox': 0})
     for b in range(B):
         assert plain[b].shape == got[b].shape and np.array_equal(plain[b], got[b]), 'image %d changes with the chunk boxes' % b
 

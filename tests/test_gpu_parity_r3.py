@@ -33,8 +33,10 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def _decode(native, skeleton0, cifs, cafs, params=None, **kw):
+def _decode(native, skeleton0, cifs, cafs, params=None, debug=None, **kw):
     dec = native.CifCaf(cifs.shape[1], torch.from_numpy(skeleton0), **kw)
+    if debug:
+        dec.set_debug(**debug)                    # opa_debug: exact variants of the kernels, per decoder
     out, ids, counts = dec.call_batch(dev(cifs), 8, dev(cafs), 8, params=params)
     out, counts = out.cpu().numpy(), counts.cpu().numpy()
     native.check_counts(counts)
@@ -92,10 +94,8 @@ def test_chunk_boxes_of_both_list_sets_and_force_complete_scans(native, port, co
             want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0, params=port.default_params(**kw))
             ok, msg = compare_annotations(got[b], want)
             assert ok, 'seed %d %s: %s' % (seed, sorted(kw), msg)
-        for env, value in (('OPA_ASSOC_BBOX', '0'), ('OPA_FC_SPLIT', '1'), ('OPA_FC_SPLIT', '3')):
-            monkeypatch.setenv(env, value)
-            plain, _ = _decode(native, coco_skeleton0, cifs, cafs, params=_lib.default_params(**kw))
-            monkeypatch.delenv(env)
+        for env, value in (('assoc_bbox', 0), ('fc_split', 1), ('fc_split', 3), ('scored_one_pass', 0)):
+            plain, _ = _decode(native, coco_skeleton0, cifs, cafs, params=_lib.default_params(**kw), debug={env: value})
             for b in range(B):
                 assert plain[b].shape == got[b].shape and np.array_equal(plain[b], got[b]), \
                     'image %d changes with %s=%s (%s)' % (b, env, value, sorted(kw))
@@ -117,8 +117,7 @@ def test_long_default_lists(native, port, coco_skeleton0, monkeypatch):
         want, _ = port.decode(cifs[b], 8, cafs[b], 8, coco_skeleton0, params=port.default_params(**kw))
         ok, msg = compare_annotations(got[b], want)
         assert ok, msg
-    monkeypatch.setenv('OPA_ASSOC_BBOX', '0')
-    plain, _ = _decode(native, coco_skeleton0, cifs, cafs, params=_lib.default_params(**kw))
+    plain, _ = _decode(native, coco_skeleton0, cifs, cafs, params=_lib.default_params(**kw), debug={'assoc_bbox': 0})
     for b in range(len(cases)):
         assert np.array_equal(plain[b], got[b])
 
@@ -159,13 +158,13 @@ def test_watchdog_failure_is_flagged_and_raises_on_every_host_path(native, coco_
     """VERDICT r2 "weak" 13: when the association kernel's watchdog fires the image reports status -1 and zero poses.
     That must not pass for "nobody in the picture": the failure travels with the counts (OPA_COUNT_FAILED) and
     every host entry point that brings the counts to the host raises.  The watchdog is shortened to one tick
-    (OPA_ASSOC_WATCHDOG_TICKS) so that the coordinator gives up in its first iteration."""
+    (opa_debug::assoc_watchdog_ticks, per decoder) so that the coordinator gives up in its first iteration."""
     from openpifpaf_amd import _lib, decoder, headmeta, synth
     cif, caf = synth.synth_fields(3, 4, height=41, width=41)
     dec = native.CifCaf(17, torch.from_numpy(coco_skeleton0))
     out, ids, counts = dec.call_batch(dev(cif)[None], 8, dev(caf)[None], 8)
     assert native.count_rows(int(counts[0])) == 4 and not native.count_failed(counts).any()
-    monkeypatch.setenv('OPA_ASSOC_WATCHDOG_TICKS', '1')
+    dec.set_debug(assoc_watchdog_ticks=1)
     out, ids, counts = dec.call_batch(dev(cif)[None], 8, dev(caf)[None], 8)
     c = int(counts[0])
     assert c & native.COUNT_FAILED and native.count_rows(c) == 0
@@ -176,6 +175,7 @@ def test_watchdog_failure_is_flagged_and_raises_on_every_host_path(native, coco_
         dec.call(dev(cif), 8, dev(caf), 8)
     cif_meta, caf_meta = headmeta.cocokp_metas()
     host = decoder.CifCaf([cif_meta], [caf_meta])
+    host.set_debug(assoc_watchdog_ticks=1)
     with pytest.raises(_lib.NativeError, match='watchdog'):
         host([dev(cif), dev(caf)])
     with pytest.raises(_lib.NativeError, match='watchdog'):
@@ -183,8 +183,10 @@ def test_watchdog_failure_is_flagged_and_raises_on_every_host_path(native, coco_
     from openpifpaf_amd import torchscript
     torchscript.load()
     ts = torch.classes.openpifpaf_amd_decoder.CifCaf(17, torch.from_numpy(coco_skeleton0))
+    ts.set_debug('assoc_watchdog_ticks', 1)
     with pytest.raises(RuntimeError, match='watchdog'):
         ts.call(dev(cif), 8, dev(caf), 8)
+    assert ts.get_cifhr_pool_tiles() == 0, 'a watchdog failure must not switch the decoder to the full tile pool'
     # a pipelined batch that fails: its ticket raises -- every time it is asked -- and is SPENT: the lane takes the next
     # batches as if nothing had happened (round 4: the stale ticket was collected again before every later submit and
     # failed every later, unrelated batch of that lane)
@@ -196,7 +198,7 @@ def test_watchdog_failure_is_flagged_and_raises_on_every_host_path(native, coco_
         with pytest.raises(_lib.NativeError, match='watchdog'):
             t.result()
     assert not host._lane_pending
-    monkeypatch.delenv('OPA_ASSOC_WATCHDOG_TICKS')
+    host.set_debug(); dec.set_debug(); ts.set_debug('assoc_watchdog_ticks', 100000000)
     good = [host.batch_async(heads, torch.zeros((1, 3, 8, 8))) for _ in range(3)]
     assert [len(t.result()[0]) for t in good] == [4, 4, 4]
     out, ids, counts = dec.call_batch(dev(cif)[None], 8, dev(caf)[None], 8)      # and the decoder is fine afterwards
@@ -287,15 +289,11 @@ def test_seed_dedupe_by_occupancy_cell_is_exact(native, port, coco_skeleton0, mo
         ok, msg = compare_annotations(got[b], want)
         assert ok, msg
     # round 5: the whole workgroup drops them before the coordinator starts; without that pass the refill drops them one by one
-    monkeypatch.setenv('OPA_ASSOC_PREDEDUP', '0')
-    refill, dec_r = _decode(native, coco_skeleton0, cifs, cafs)
-    monkeypatch.delenv('OPA_ASSOC_PREDEDUP')
+    refill, dec_r = _decode(native, coco_skeleton0, cifs, cafs, debug={'assoc_prededup': 0})
     assert (dec_r.assoc_stats()[:, 23].cpu().numpy() > 50).all()
     for b in range(len(cases)):
         assert np.array_equal(refill[b], got[b]), 'image %d changes with the dedupe pass ahead of the pool' % b
-    monkeypatch.setenv('OPA_ASSOC_DEDUP', '0')
-    plain, dec0 = _decode(native, coco_skeleton0, cifs, cafs)
-    monkeypatch.delenv('OPA_ASSOC_DEDUP')
+    plain, dec0 = _decode(native, coco_skeleton0, cifs, cafs, debug={'assoc_dedup': 0})
     assert (dec0.assoc_stats()[:, 23].cpu().numpy() == 0).all()
     for b in range(len(cases)):
         assert np.array_equal(plain[b], got[b]), 'image %d changes with the seed dedupe' % b
