@@ -18,10 +18,20 @@
 
 namespace opa {
 
-__global__ __launch_bounds__(kScoredThreads, 2) void cafscored_kernel(ScoredArgs s) {
+#ifndef OPA_SCORED_MIN_WAVES
+#define OPA_SCORED_MIN_WAVES 2
+#endif
+__global__ __launch_bounds__(kScoredThreads, OPA_SCORED_MIN_WAVES) void cafscored_kernel(ScoredArgs s) {
     __shared__ int wave_tot[2][kScoredThreads / 64];
     extern __shared__ float bb[];
     cafscored_plane(s, blockIdx.x, threadIdx.x, wave_tot, bb);
+}
+
+// both list sets of a force-complete decode from ONE read of the field (cafscored_impl.hpp)
+__global__ __launch_bounds__(kScoredThreads, OPA_SCORED_MIN_WAVES) void cafscored2_kernel(ScoredArgs s, ScoredArgs s2) {
+    __shared__ int wave_tot[4][kScoredCells][kScoredThreads / 64];
+    extern __shared__ float bb[];
+    cafscored_plane2<true>(s, s2, blockIdx.x, threadIdx.x, wave_tot, bb);
 }
 
 ScoredArgs make_scored_args(const float* caf, int B, int A, int cH, int cW, int cstride,
@@ -46,6 +56,16 @@ ScoredArgs make_scored_args(const float* caf, int B, int A, int cH, int cW, int 
 hipError_t launch_cafscored(const ScoredArgs& s, hipStream_t st) {
     const size_t lds = s.chunk_bbox ? sizeof(float) * 2 * s.nb * 4 : 0;
     cafscored_kernel<<<s.planes, kScoredThreads, lds, st>>>(s);
+    prof_mark(st, "cafscored_kernel");
+    return hipGetLastError();
+}
+
+hipError_t launch_cafscored2(const ScoredArgs& s, const ScoredArgs& s2, hipStream_t st) {
+    const size_t lds = sizeof(float) * 2 * 4 * ((s.chunk_bbox ? s.nb : 0) + (s2.chunk_bbox ? s2.nb : 0));
+    ScoredArgs a = s, b = s2;
+    if (!a.chunk_bbox) a.nb = 0;                      // (the second set's boxes sit behind 2 * nb * 4 floats of the first's)
+    if (!b.chunk_bbox) b.nb = 0;
+    cafscored2_kernel<<<s.planes, kScoredThreads, lds, st>>>(a, b);
     prof_mark(st, "cafscored_kernel");
     return hipGetLastError();
 }

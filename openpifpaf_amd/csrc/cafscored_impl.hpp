@@ -8,7 +8,10 @@ namespace opa {
 
 // One workgroup walks a field.  8 waves at 76 VGPRs: three workgroups per CU, so the 608 planes of a bench batch are
 // all resident at once; with 1024 threads a CU held one workgroup and the batch took three rounds (50 -> 37 us).
-constexpr int kScoredThreads = 512;
+#ifndef OPA_SCORED_THREADS
+#define OPA_SCORED_THREADS 512
+#endif
+constexpr int kScoredThreads = OPA_SCORED_THREADS;
 
 // Wave-wide min / max of a float with DPP row operations (register only; result broadcast from lane 63).
 // (A NaN coordinate never passes the window test and must not poison a box: callers feed the identity for it.)
@@ -159,6 +162,218 @@ __device__ __forceinline__ void cafscored_plane(const ScoredArgs& s, int plane_i
             const int dir = k / (nb * 4), rest = k - dir * nb * 4;
             chunk_bbox[((size_t)plane * 2 + dir) * nb_stride * 4 + rest] = bb[k];
         }
+    }
+}
+
+
+// `tid`: thread index inside the group; `wave_tot` [2][kScoredCells][kScoredThreads / 64] (TWO: [4][...], the second set's behind
+// the first's) and `bb` [2][nb][4] ((xmin, xmax, ymin, ymax) of the (x1, y1) columns per list chunk; TWO: the second set's
+// [2][nb2][4] behind it): the group's LDS.  Every barrier is a WORKGROUP barrier: all groups of a workgroup walk planes of the
+// same size in lockstep.
+//
+// TWO (round 6): a force-complete decode needs the lists twice -- at caf_th for the seed loop (cifcaf.cpp:153-161) and at
+// force_complete_caf_th for _force_complete (:419-420).  Rounds 3-5 ran the pass twice: the 128 MB CAF tensor of a batch read
+// twice, the two map values of every cell gathered twice.  Here one read of the field feeds both sets (`s2` = the second set's
+// thresholds and outputs; everything that describes the field and the map is taken from `s`).
+//
+// kScoredCells cells per thread and step, the planes of the next step requested before this step's cells are looked at: both
+// are compile-time experiments of round 6 (-DOPA_SCORED_CELLS=n, the prefetch unless -DOPA_SCORED_NO_PREFETCH).  A read-only
+// stream of this shape reaches 6.2 TB/s on this chip (tools/gpu/micro/readbw.hip: 144 us for the field of 256 images) where the
+// single-set kernel takes 250 us -- 190 of them with a threshold nothing passes, i.e. no gather and no store: the price of a
+// barrier per step.  Measured at 256 images (profiles/r6/cafscored_variants.log): 1 / 2 / 4 cells per thread 269 / 267 / 314 us
+// with the prefetch, 273 / 271 without; 256-thread groups 271; none beats round 5's loop (252), which therefore stays for
+// the single set (cafscored_plane above) -- this routine serves the two-set pass, with one cell per thread.  Cell order
+// (r, wave, lane) is raster order, and the lists keep it.
+#ifndef OPA_SCORED_CELLS
+#define OPA_SCORED_CELLS 1
+#endif
+constexpr int kScoredCells = OPA_SCORED_CELLS;
+
+template <bool TWO>
+__device__ __forceinline__ void cafscored_plane2(const ScoredArgs& s, const ScoredArgs& s2, int plane_in, int tid,
+                                                int (*wave_tot)[kScoredCells][kScoredThreads / 64], float* bb) {
+    const float* __restrict__ caf = s.caf; const float* __restrict__ cifhr = s.cifhr;
+    const int A = s.A, HW = s.HW, stride = s.stride, F = s.F, hr_rows = s.hr_rows, hr_cols = s.hr_cols, hr_pitch = s.hr_pitch;
+    const int64_t* __restrict__ skeleton = s.skeleton;
+    const double score_th = s.score_th, cif_floor = s.cif_floor;
+    const double score_th2 = TWO ? s2.score_th : 0.0, cif_floor2 = TWO ? s2.cif_floor : 0.0;
+    const int no_rescore = s.no_rescore, nb = s.nb, nb_stride = s.nb_stride;
+    const int nb2 = TWO ? s2.nb : 0;
+    float* bb2 = bb + 2 * nb * 4;
+    float* __restrict__ lists = s.lists; int32_t* __restrict__ counts = s.counts; float* __restrict__ chunk_bbox = s.chunk_bbox;
+    const bool live = plane_in < s.planes;           // an idle group only keeps the barriers company
+    const int plane = live ? plane_in : 0;
+    if (chunk_bbox)
+        for (int k = tid; k < 2 * nb * 4; k += kScoredThreads) bb[k] = (k & 1) ? -__builtin_inff() : __builtin_inff();
+    if (TWO && s2.chunk_bbox)
+        for (int k = tid; k < 2 * nb2 * 4; k += kScoredThreads) bb2[k] = (k & 1) ? -__builtin_inff() : __builtin_inff();
+    __syncthreads();
+    const int b = plane / A, a = plane - b * A;
+    const int lane = tid & 63, w = tid >> 6;
+    const float* P = caf + (size_t)plane * 8 * HW;
+    const float* hr = cifhr + (size_t)b * s.hr_image_stride;
+    const unsigned* touch = s.tile_touch ? s.tile_touch + (size_t)b * F * s.touch_words : nullptr;
+    const int32_t* slot = s.hr_slot ? s.hr_slot + (size_t)b * F * s.hr_tpp : nullptr;   // pooled map: the slot table replaces the bitmap test
+    float* Lf = lists + ((size_t)plane * 2 + 0) * 7 * HW;
+    float* Lb = lists + ((size_t)plane * 2 + 1) * 7 * HW;
+    float* Lf2 = TWO ? s2.lists + ((size_t)plane * 2 + 0) * 7 * HW : nullptr;
+    float* Lb2 = TWO ? s2.lists + ((size_t)plane * 2 + 1) * 7 * HW : nullptr;
+    const long long j1 = skeleton[2 * a + 0], j2 = skeleton[2 * a + 1];
+    const float stride_f = (float)stride;
+    // the lower of the two thresholds decides whether a cell is looked at all (caf_scored.cpp:44)
+    const double th_low = TWO && score_th2 < score_th ? score_th2 : score_th;
+    int base_f = 0, base_b = 0, base_f2 = 0, base_b2 = 0, parity = 0;
+    constexpr int kStep = kScoredThreads * kScoredCells;
+
+    // all seven planes of a cell are requested at once (the stage's compulsory bytes), one step ahead
+    float pc[kScoredCells], p2[kScoredCells], p3[kScoredCells], p4[kScoredCells], p5[kScoredCells], p6[kScoredCells], p7[kScoredCells];
+    auto request = [&](int c0) {
+#pragma unroll
+        for (int r = 0; r < kScoredCells; r++) {
+            const int o = c0 + r * kScoredThreads + tid;
+            const int oo = o < HW ? o : 0;
+            pc[r] = o < HW && live ? P[1 * HW + oo] : -1.0f;
+            p2[r] = P[2 * HW + oo]; p3[r] = P[3 * HW + oo]; p4[r] = P[4 * HW + oo];
+            p5[r] = P[5 * HW + oo]; p6[r] = P[6 * HW + oo]; p7[r] = P[7 * HW + oo];
+        }
+    };
+    request(0);
+    for (int c0 = 0; c0 < HW; c0 += kStep, parity ^= 1) {
+#ifdef OPA_SCORED_NO_PREFETCH
+        if (c0) request(c0);
+#endif
+        bool keep_f[kScoredCells], keep_b[kScoredCells], keep_f2[kScoredCells], keep_b2[kScoredCells];
+        float cf[kScoredCells], cb[kScoredCells], cf2[kScoredCells], cb2[kScoredCells];
+        float x1[kScoredCells], y1[kScoredCells], x2[kScoredCells], y2[kScoredCells], s1[kScoredCells], s2v[kScoredCells];
+        float c[kScoredCells];
+        bool look[kScoredCells];
+#pragma unroll
+        for (int r = 0; r < kScoredCells; r++) {
+            const int o = c0 + r * kScoredThreads + tid;
+            c[r] = pc[r];
+            look[r] = o < HW && live && !((double)c[r] < th_low);        // caf_scored.cpp:44
+            x1[r] = p2[r] * stride_f; y1[r] = p3[r] * stride_f;          // :46-54
+            x2[r] = p4[r] * stride_f; y2[r] = p5[r] * stride_f;
+            s1[r] = p6[r] * stride_f; s2v[r] = p7[r] * stride_f;
+        }
+#ifndef OPA_SCORED_NO_PREFETCH
+        if (c0 + kStep < HW) request(c0 + kStep);
+#endif
+        // the map values of the step's cells: all slot-table loads first, then all tile loads (cifhr_value is two dependent loads)
+        float fhr[kScoredCells], bhr[kScoredCells];
+#pragma unroll
+        for (int r = 0; r < kScoredCells; r++) {
+            fhr[r] = 0.f; bhr[r] = 0.f;
+            if (look[r] && !no_rescore) {                                // :66-71
+                fhr[r] = cifhr_value(hr, F, hr_rows, hr_cols, hr_pitch, j2, x2[r], y2[r], 0.0f, touch, s.touch_words, s.tiles_x, slot, s.hr_tpp);
+                bhr[r] = cifhr_value(hr, F, hr_rows, hr_cols, hr_pitch, j1, x1[r], y1[r], 0.0f, touch, s.touch_words, s.tiles_x, slot, s.hr_tpp);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < kScoredCells; r++) {
+            keep_f[r] = keep_b[r] = keep_f2[r] = keep_b2[r] = false;
+            cf[r] = cb[r] = cf2[r] = cb2[r] = c[r];
+            if (look[r]) {
+                if (!no_rescore) {
+                    cf[r] = (float)((double)c[r] * (cif_floor + (1.0 - cif_floor) * (double)fhr[r]));
+                    cb[r] = (float)((double)c[r] * (cif_floor + (1.0 - cif_floor) * (double)bhr[r]));
+                    if (TWO) {
+                        cf2[r] = (float)((double)c[r] * (cif_floor2 + (1.0 - cif_floor2) * (double)fhr[r]));
+                        cb2[r] = (float)((double)c[r] * (cif_floor2 + (1.0 - cif_floor2) * (double)bhr[r]));
+                    }
+                }
+                const bool in1 = !((double)c[r] < score_th);             // :44 for this set
+                keep_f[r] = in1 && (double)cf[r] > score_th;             // :74
+                keep_b[r] = in1 && (double)cb[r] > score_th;             // :77
+                if (TWO) {
+                    const bool in2 = !((double)c[r] < score_th2);
+                    keep_f2[r] = in2 && (double)cf2[r] > score_th2;
+                    keep_b2[r] = in2 && (double)cb2[r] > score_th2;
+                }
+            }
+        }
+        unsigned long long mf[kScoredCells], mb[kScoredCells], mf2[kScoredCells], mb2[kScoredCells];
+#pragma unroll
+        for (int r = 0; r < kScoredCells; r++) {
+            mf[r] = __ballot(keep_f[r]); mb[r] = __ballot(keep_b[r]);
+            mf2[r] = TWO ? __ballot(keep_f2[r]) : 0ull; mb2[r] = TWO ? __ballot(keep_b2[r]) : 0ull;
+            if (lane == 0) {
+                wave_tot[parity][r][w] = __popcll(mf[r]) | (__popcll(mb[r]) << 16);
+                if (TWO) wave_tot[2 + parity][r][w] = __popcll(mf2[r]) | (__popcll(mb2[r]) << 16);
+            }
+        }
+        __syncthreads();                              // double-buffered totals: one barrier per step
+        const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+        for (int r = 0; r < kScoredCells; r++) {
+            int off_f = base_f + __popcll(mf[r] & lt), off_b = base_b + __popcll(mb[r] & lt);
+            int off_f2 = base_f2 + __popcll(mf2[r] & lt), off_b2 = base_b2 + __popcll(mb2[r] & lt);
+            int tot_f = 0, tot_b = 0, tot_f2 = 0, tot_b2 = 0;
+#pragma unroll
+            for (int k = 0; k < kScoredThreads / 64; k++) {
+                const int t = wave_tot[parity][r][k];
+                if (k < w) { off_f += t & 0xffff; off_b += t >> 16; }
+                tot_f += t & 0xffff; tot_b += t >> 16;
+                if (TWO) {
+                    const int u = wave_tot[2 + parity][r][k];
+                    if (k < w) { off_f2 += u & 0xffff; off_b2 += u >> 16; }
+                    tot_f2 += u & 0xffff; tot_b2 += u >> 16;
+                }
+            }
+            auto boxes = [&](float* q, int n_boxes, bool kf, int of, bool kb, int ob) {
+                if (n_boxes > kListBboxChunks) {         // long lists: one LDS update per wave and chunk
+                    widen_boxes(q, n_boxes, kf, of, x1[r], y1[r]);
+                    widen_boxes(q + n_boxes * 4, n_boxes, kb, ob, x2[r], y2[r]);
+                } else {
+                    // short lists, few kept entries per step: LDS float min/max per entry (ds_min_f32 / ds_max_f32); a NaN
+                    // coordinate never passes the window test and must not poison the box
+                    auto widen = [](float* e, float x, float y) {
+                        if (x == x) { __hip_atomic_fetch_min(e + 0, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                      __hip_atomic_fetch_max(e + 1, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                        if (y == y) { __hip_atomic_fetch_min(e + 2, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                      __hip_atomic_fetch_max(e + 3, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                    };
+                    if (kf && of < n_boxes * 64) widen(q + (of >> 6) * 4, x1[r], y1[r]);
+                    if (kb && ob < n_boxes * 64) widen(q + (n_boxes + (ob >> 6)) * 4, x2[r], y2[r]);
+                }
+            };
+            if (chunk_bbox) boxes(bb, nb, keep_f[r], off_f, keep_b[r], off_b);
+            if (TWO && s2.chunk_bbox) boxes(bb2, nb2, keep_f2[r], off_f2, keep_b2[r], off_b2);
+            if (keep_f[r]) {
+                Lf[0 * HW + off_f] = cf[r]; Lf[1 * HW + off_f] = x1[r]; Lf[2 * HW + off_f] = y1[r];
+                Lf[3 * HW + off_f] = x2[r]; Lf[4 * HW + off_f] = y2[r]; Lf[5 * HW + off_f] = s1[r]; Lf[6 * HW + off_f] = s2v[r];
+            }
+            if (keep_b[r]) {                                                 // mirrored tuple, :55-63
+                Lb[0 * HW + off_b] = cb[r]; Lb[1 * HW + off_b] = x2[r]; Lb[2 * HW + off_b] = y2[r];
+                Lb[3 * HW + off_b] = x1[r]; Lb[4 * HW + off_b] = y1[r]; Lb[5 * HW + off_b] = s2v[r]; Lb[6 * HW + off_b] = s1[r];
+            }
+            if (TWO && keep_f2[r]) {
+                Lf2[0 * HW + off_f2] = cf2[r]; Lf2[1 * HW + off_f2] = x1[r]; Lf2[2 * HW + off_f2] = y1[r];
+                Lf2[3 * HW + off_f2] = x2[r]; Lf2[4 * HW + off_f2] = y2[r]; Lf2[5 * HW + off_f2] = s1[r]; Lf2[6 * HW + off_f2] = s2v[r];
+            }
+            if (TWO && keep_b2[r]) {
+                Lb2[0 * HW + off_b2] = cb2[r]; Lb2[1 * HW + off_b2] = x2[r]; Lb2[2 * HW + off_b2] = y2[r];
+                Lb2[3 * HW + off_b2] = x1[r]; Lb2[4 * HW + off_b2] = y1[r]; Lb2[5 * HW + off_b2] = s2v[r]; Lb2[6 * HW + off_b2] = s1[r];
+            }
+            base_f += tot_f; base_b += tot_b; base_f2 += tot_f2; base_b2 += tot_b2;
+        }
+    }
+    if (tid == 0 && live) {
+        counts[plane * 2 + 0] = base_f; counts[plane * 2 + 1] = base_b;
+        if (TWO) { s2.counts[plane * 2 + 0] = base_f2; s2.counts[plane * 2 + 1] = base_b2; }
+    }
+    if (chunk_bbox || (TWO && s2.chunk_bbox)) {       // the chunk boxes (common.hpp), gathered in LDS while the lists were built
+        __syncthreads();
+        if (chunk_bbox)
+            for (int k = tid; k < 2 * nb * 4 && live; k += kScoredThreads) {
+                const int dir = k / (nb * 4), rest = k - dir * nb * 4;
+                chunk_bbox[((size_t)plane * 2 + dir) * nb_stride * 4 + rest] = bb[k];
+            }
+        if (TWO && s2.chunk_bbox)
+            for (int k = tid; k < 2 * nb2 * 4 && live; k += kScoredThreads) {
+                const int dir = k / (nb2 * 4), rest = k - dir * nb2 * 4;
+                s2.chunk_bbox[((size_t)plane * 2 + dir) * s2.nb_stride * 4 + rest] = bb2[k];
+            }
     }
 }
 

@@ -483,14 +483,6 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     // the sort's workgroups -- measured in round 3: 90 us against 42 + 41 us one after the other, 323 against 170 us with
     // the force-complete set: under the sort kernel's 64 KiB of static LDS and 1024-thread workgroups the list building
     // gets two workgroups per compute unit instead of its six, and loses more than the overlap gives.)
-    // this call's touched-tile bitmap of the map (second half of the tile state; cif_active_kernel wrote it): the
-    // force-complete pass looks two map values up for nearly EVERY cell of a field -- a gigabyte of memory lines for a batch
-    // of 32, nine tenths of them in tiles nothing was written to -- and skips those gathers (cafscored 128 -> 92 us)
-    const unsigned* tile_touch = nullptr;
-    if (!p.ablation_cifhr_skip) {
-        const size_t tpp = (size_t)(L.hr_pitch / kHrTileW) * ((L.hr_rows + kHrTileH - 1) / kHrTileH);
-        tile_touch = reinterpret_cast<const unsigned*>(ws + L.off_tile_clean) + (size_t)L.B * L.F * ((tpp + 31) / 32);
-    }
     ScoredArgs scored[2];
     int n_scored = 0;
     scored[n_scored++] = make_scored_args(caf_dev, L.B, L.A, L.cH, L.cW, L.cstride, cifhr, L.F, L.hr_rows, L.hr_cols, L.hr_pitch,
@@ -523,11 +515,16 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
                         (float*)(ws + L.off_seed_vxys), st, false, (int32_t*)(ws + L.off_seed_cell),
                         L.occ_h, L.occ_w, true, fuse ? scored : nullptr, fuse ? n_scored : 0, &ties, &pool, &cand);   // :144-146
     if (e != hipSuccess) return fail_hip(e, "cifseeds");
-    if (!fuse)
-        for (int k = 0; k < n_scored; k++) {
-            e = launch_cafscored(scored[k], st);
-            if (e != hipSuccess) return fail_hip(e, k ? "cafscored(force complete)" : "cafscored");
-        }
+    if (!fuse) {
+        if (n_scored == 2 && dec->debug.scored_one_pass) {     // both list sets from one read of the field (round 6)
+            e = launch_cafscored2(scored[0], scored[1], st);
+            if (e != hipSuccess) return fail_hip(e, "cafscored(both list sets)");
+        } else
+            for (int k = 0; k < n_scored; k++) {
+                e = launch_cafscored(scored[k], st);
+                if (e != hipSuccess) return fail_hip(e, k ? "cafscored(force complete)" : "cafscored");
+            }
+    }
     // (the occupancy map of :173 is a bitmap the association kernel clears itself)
     AssocArgs a;
     a.B = L.B; a.K = L.K; a.F = L.F; a.A = L.A; a.max_ann = L.max_ann; a.n_initial = n_initial;

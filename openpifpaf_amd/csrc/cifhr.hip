@@ -184,14 +184,13 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
     if (!WL) return;
     if (tid == 0) cand_count[plane] = cbase;
     // ---- slots and work items of the tiles this plane's cells reach
-    __shared__ int sh_n, sh_slot0, sh_work0;
+    __shared__ int sh_slot0, sh_work0;
     __syncthreads();                                  // (the LDS bitmap is complete)
     if (w == 0) {
         int n = 0;
         for (int k = lane; k < touch_words; k += 64) n += __popc(sh_touch[k]);
         for (int d = 32; d > 0; d >>= 1) n += __shfl_xor(n, d, 64);
         if (lane == 0) {
-            sh_n = n;
             sh_slot0 = n ? atomicAdd(&pool.img_tiles[plane / F], n) : 0;
             sh_work0 = n ? atomicAdd(pool.work_count, n) : 0;
         }

@@ -157,6 +157,7 @@ ScoredArgs make_scored_args(const float* caf, int B, int A, int cH, int cW, int 
                             const unsigned* tile_touch = nullptr, const HrPool* pool = nullptr);
 
 hipError_t launch_cafscored(const ScoredArgs& s, hipStream_t st);
+hipError_t launch_cafscored2(const ScoredArgs& s, const ScoredArgs& s2, hipStream_t st);   // two list sets, one read of the field
 hipError_t launch_cafscored(const float* caf, int B, int A, int cH, int cW, int cstride,
                             const float* cifhr, int F, int hr_rows, int hr_cols, int hr_pitch,
                             const int64_t* skeleton, double score_th, double cif_floor, int no_rescore,
