@@ -120,13 +120,13 @@ void opa_set_quiet(int quiet);
 /* Order of seeds with EQUAL scores (ref: cif_seeds.cpp:94,118: an unstable std::sort, so the reference's order is
  * whatever libstdc++'s introsort leaves -- it decides which of two equally scored seeds is grown first).
  *   1 (default)  libstdc++'s order, reproduced on the device for the images that have such seeds (float32 fields of a
- *                network practically never do; fields rounded to bfloat16 do).  The workspace view "seed_ties"
- *                (int32 [B]) says per image: 0 no equal scores, 1 re-ordered, -1 not reproduced (introsort's heapsort
- *                branch: the image keeps the order below).
+ *                network practically never do; fields rounded to bfloat16 do) -- introsort's partitions and, since round 6,
+ *                its heapsort branch (std::__partial_sort for a segment at the depth limit).  The workspace view "seed_ties"
+ *                (int32 [B]) says per image: 0 no equal scores, 1 re-ordered (-1: a protocol failure of the pass, never seen:
+ *                the image keeps the order below).
  *   0            cell index ascending (field, row, column) -- one launch less.
- *   2            like 1, with the pass running inside the association kernel (every image its own ties) instead of as a
- *                launch of its own: no shorter for one decode, better when several decodes are in flight on streams of
- *                their own (stage-level entry points: like 1).
+ *   2            like 1 (rounds 4-5: "with the pass inside the association kernel" -- that is a decoder's own choice now,
+ *                opa_cifcaf_set_tie_placement, and the default).
  * Process-global like the reference's statics; the environment variable OPA_SEED_TIES=index / libstdcxx-fused selects 0 / 2
  * when this function was never called (read once, when the library is loaded). */
 void opa_set_seed_tie_order(int order);
@@ -144,8 +144,9 @@ int opa_set_params(const opa_params* in);
 /* ref: module.cpp:25,34  torch.classes.openpifpaf_decoder.CifCaf(n_keypoints, skeleton)
  * skeleton_host: int64 [n_bones, 2], 0-based joint indices, CAF field order
  * (ref: decoder/cifcaf.py:119-122).  The handle owns a small device copy of
- * the skeleton and its adjacency; it holds no per-call state, so one handle
- * may be used from several streams. */
+ * the skeleton and its adjacency -- and, per caller stream it has decoded on, one side stream and two events (opa_debug::
+ * side_stream), created at the first decode on that stream; it holds no per-call state, so one handle may be used from
+ * several streams. */
 typedef struct opa_cifcaf opa_cifcaf;
 int opa_cifcaf_create(opa_cifcaf** out, int32_t n_keypoints,
                       const int64_t* skeleton_host, int32_t n_bones);
@@ -155,11 +156,9 @@ int opa_cifcaf_get_state(const opa_cifcaf* dec, int32_t* n_keypoints,
                          int64_t* skeleton_host /* [n_bones,2] or NULL */, int32_t* n_bones);
 
 /* Where the pass that puts seeds of EQUAL score into the reference's order runs for THIS decoder's decodes (seed tie
- * order 1, see opa_set_seed_tie_order): 0 = a launch of its own (default for one decode at a time: the association
- * kernel's time stays what it is), 1 = inside the association kernel, every image its own ties (what several decodes in
- * flight want: the pass overlaps like the association does instead of filling the chip; native.DecodeLanes sets it for
- * two or more lanes), -1 = the process-wide choice (opa_set_seed_tie_order / OPA_SEED_TIES / OPA_FUSE_TIES at load time).  The
- * results are the same bit for bit. */
+ * order 1, see opa_set_seed_tie_order): 1 = inside the association kernel, every image its own ties; 0 = a launch of its own
+ * (its time then shows up under its own name); -1 (default) = automatic, which since round 6 means inside the kernel -- measured
+ * shorter for one decode at a time as well as for several in flight.  The results are the same bit for bit. */
 int opa_cifcaf_set_tie_placement(opa_cifcaf* dec, int32_t inside_association);
 
 /* A/B and test switches of ONE decoder handle (no reference counterpart; the reference's tunables are opa_params).  None of
@@ -192,6 +191,10 @@ typedef struct opa_debug {
     int32_t assoc_persistent;      /* 0 = automatic: more images than compute units are taken from a queue, longest first, by
                                     *    one workgroup per compute unit (round 6); 1: always; -1: never      OPA_ASSOC_PERSISTENT   */
     int32_t fc_split;              /* 0 = automatic; n: force-complete workgroups per image                  OPA_FC_SPLIT           */
+    int32_t side_stream;           /* 0; 1: the CAF lists are built on a stream of the handle's own beside the seed chain (fill, sort,
+                                    *    tie pass) and joined before the association kernel (round 6: the two branches do not overlap
+                                    *    -- the list building fills the chip and the sort's fat workgroups find no room beside it --
+                                    *    one lane is slower with it, two lanes are faster)                   OPA_SIDE_STREAM        */
     int64_t assoc_watchdog_ticks;  /* 1e8 (one second): 10-ns ticks after which a wait inside the association kernel gives up
                                     *    and the image is flagged OPA_COUNT_FAILED                           OPA_ASSOC_WATCHDOG_TICKS */
 } opa_debug;

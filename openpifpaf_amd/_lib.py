@@ -69,6 +69,7 @@ class Debug(ctypes.Structure):
         ('assoc_collide', ctypes.c_int32), ('assoc_collide_shift', ctypes.c_int32), ('assoc_inherit', ctypes.c_int32),
         ('assoc_lookahead', ctypes.c_int32), ('assoc_help', ctypes.c_int32), ('assoc_spec', ctypes.c_int32),
         ('assoc_timing', ctypes.c_int32), ('assoc_persistent', ctypes.c_int32), ('fc_split', ctypes.c_int32),
+        ('side_stream', ctypes.c_int32),
         ('assoc_watchdog_ticks', ctypes.c_int64),
     ]
 

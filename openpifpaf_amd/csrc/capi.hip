@@ -41,6 +41,7 @@ static opa_debug debug_from_environment() {
     d.assoc_spec = env_int("OPA_ASSOC_SPEC", 1) != 0;
     d.assoc_timing = env_int("OPA_ASSOC_TIMING", 0) != 0;
     d.assoc_persistent = env_int("OPA_ASSOC_PERSISTENT", 0);
+    d.side_stream = env_int("OPA_SIDE_STREAM", 0) != 0;
     d.fc_split = env_int("OPA_FC_SPLIT", 0);
     d.assoc_watchdog_ticks = 100000000ll;
     if (const char* e = std::getenv("OPA_ASSOC_WATCHDOG_TICKS")) { const long long v = std::atoll(e); if (v > 0) d.assoc_watchdog_ticks = v; }
@@ -225,7 +226,36 @@ struct opa_cifcaf {
     int device;
     int tie_inside;                    // opa_cifcaf_set_tie_placement: -1 process-wide choice, 0 own launch, 1 inside the association kernel
     opa_debug debug;                   // opa_cifcaf_set_debug
+    // Side streams (round 6): CafScored::fill only needs the finished map, the seed chain (fill, sort, rank merge, tie pass) only
+    // needs the finished map -- two branches that meet at the association kernel.  The list building runs on a stream of the
+    // library's own beside the seed chain: one per caller stream, created at the first decode on that stream, joined back before
+    // the association kernel is queued (event fork / join: capturable into a HIP graph like everything else).
+    struct Side { hipStream_t main, side; hipEvent_t fork, join; };
+    std::vector<Side> sides;
+    std::mutex sides_mutex;
 };
+
+static bool side_for(opa_cifcaf* dec, hipStream_t main, opa_cifcaf::Side* out) {
+    std::lock_guard<std::mutex> lock(dec->sides_mutex);
+    for (const auto& s : dec->sides)
+        if (s.main == main) { *out = s; return true; }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(main, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return false;                                 // (no stream is created in the middle of a capture: this decode runs on one stream)
+    }
+    opa_cifcaf::Side s; s.main = main;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    // LOWEST priority: the list building fills every compute unit it is given; the seed chain's few, fat workgroups (1024 threads,
+    // 64-128 KB of LDS) only find room beside it when the dispatcher prefers them
+    if (hipStreamCreateWithPriority(&s.side, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+    dec->sides.push_back(s);
+    *out = s;
+    return true;
+}
 
 extern "C" {
 
@@ -333,6 +363,7 @@ int opa_cifcaf_create(opa_cifcaf** out, int32_t n_keypoints, const int64_t* skel
 void opa_cifcaf_destroy(opa_cifcaf* dec) {
     if (!dec) return;
     if (dec->dev_block) (void)hipFree(dec->dev_block);
+    for (auto& s : dec->sides) { (void)hipStreamDestroy(s.side); (void)hipEventDestroy(s.fork); (void)hipEventDestroy(s.join); }
     delete dec;
 }
 
@@ -426,11 +457,12 @@ int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what, size_t* 
     return fail(OPA_ERR_INVALID_ARGUMENT, std::string("opa_cifcaf_workspace_view: unknown buffer ") + what);
 }
 
-int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_params* params,
+int opa_cifcaf_decode(const opa_cifcaf* dec_in, const opa_shape* shape, const opa_params* params,
                       const float* cif_dev, const float* caf_dev,
                       const float* initial_dev, const int64_t* initial_ids_dev, int32_t n_initial,
                       void* workspace_dev, size_t workspace_bytes,
                       float* out_dev, int64_t* out_ids_dev, int32_t* out_count_dev, void* stream) {
+    opa_cifcaf* dec = const_cast<opa_cifcaf*>(dec_in);   // (the handle's side streams are created on first use, under its mutex)
     if (!dec || !shape || !cif_dev || !caf_dev || !workspace_dev || !out_dev || !out_ids_dev || !out_count_dev)
         return fail(OPA_ERR_INVALID_ARGUMENT, "opa_cifcaf_decode: null argument");
     if (n_initial < 0 || (n_initial > 0 && !initial_dev))
@@ -502,28 +534,51 @@ int opa_cifcaf_decode(const opa_cifcaf* dec, const opa_shape* shape, const opa_p
     ties.big = ws + L.off_act; ties.big_stride = (size_t)L.F * 4 * (L.H * L.W) * sizeof(float);
     ties.small_ = ws + L.off_tie_small; ties.small_stride = L.tie_small_stride;
     ties.state = (int32_t*)(ws + L.off_tie_state);
-    // Tie order 2 (or OPA_FUSE_TIES=1): the tie pass runs in the association kernel instead of a launch of its own (every
-    // image its own ties, before its seeds are read).  Measured in round 4: ONE decode gets 2 % shorter, not 9 % -- the
-    // images with the most seeds are both the likeliest to hold equal scores and the slowest to associate -- but with
-    // several decodes in flight (DecodeLanes) the pass overlaps like the association does instead of filling the chip
-    // for 80 us per batch.  The separate launch, whose time shows up under its own name, stays the default.
-    const bool fuse_ties = seed_tie_order() >= 1 && (dec->tie_inside >= 0 ? dec->tie_inside == 1 : seed_tie_order() == 2);
+    // Where the tie pass runs: in the association kernel (every image its own ties, before its seeds are read) or as a launch of its
+    // own.  Round 4 measured ONE decode 2 % shorter with the pass inside -- the images with the most seeds are both the likeliest
+    // to hold equal scores and the slowest to associate -- and twelve lanes 11 % faster; round 6 measured it again on the new stage
+    // kernels (wall per decode: 32 COCO images 0.730 -> 0.713 ms, 256 images 1.563 -> 1.502 ms, 16 wholebody images 3.42 -> 3.36 ms).
+    // (round 6: inside the association kernel unless the decoder asks for the launch of its own -- measured shorter for one decode
+    // of 32 or 256 COCO images and of 16 wholebody images alike, profiles/r6/tie_placement.log)
+    const bool fuse_ties = seed_tie_order() >= 1 && (dec->tie_inside >= 0 ? dec->tie_inside == 1 : true);
     ties.defer = fuse_ties ? 1 : 0;
+    // The two branches behind the finished map: the CAF lists on the handle's side stream, the seed chain on the caller's
+    // (opa_debug::side_stream; not while this thread profiles the stream with events -- their times are per kernel in a row --
+    // and not when the side stream cannot be had, e.g. the first decode of a handle inside a graph capture).
+    opa_cifcaf::Side side;
+    const bool forked = !fuse && dec->debug.side_stream != 0 && !(g_prof.on && g_prof.st == st) && side_for(dec, st, &side);
+    auto lists = [&](hipStream_t ls) -> int {
+        if (n_scored == 2 && dec->debug.scored_one_pass) {     // both list sets from one read of the field (round 6)
+            const hipError_t le = launch_cafscored2(scored[0], scored[1], ls);
+            if (le != hipSuccess) return fail_hip(le, "cafscored(both list sets)");
+        } else
+            for (int k = 0; k < n_scored; k++) {
+                const hipError_t le = launch_cafscored(scored[k], ls);
+                if (le != hipSuccess) return fail_hip(le, k ? "cafscored(force complete)" : "cafscored");
+            }
+        return OPA_OK;
+    };
+    if (forked) {
+        e = hipEventRecord(side.fork, st);
+        if (e == hipSuccess) e = hipStreamWaitEvent(side.side, side.fork, 0);
+        if (e != hipSuccess) return fail_hip(e, "fork to the side stream");
+        const int rc = lists(side.side);
+        if (rc != OPA_OK) return rc;
+        e = hipEventRecord(side.join, side.side);
+        if (e != hipSuccess) return fail_hip(e, "side stream");
+    }
     e = launch_cifseeds(cif_dev, L.B, L.F, L.H, L.W, L.stride, cifhr, L.hr_rows, L.hr_cols, L.hr_pitch, p,
                         (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap,
                         (int32_t*)(ws + L.off_seed_count), (int32_t*)(ws + L.off_seed_f),
                         (float*)(ws + L.off_seed_vxys), st, false, (int32_t*)(ws + L.off_seed_cell),
                         L.occ_h, L.occ_w, true, fuse ? scored : nullptr, fuse ? n_scored : 0, &ties, &pool, &cand);   // :144-146
     if (e != hipSuccess) return fail_hip(e, "cifseeds");
-    if (!fuse) {
-        if (n_scored == 2 && dec->debug.scored_one_pass) {     // both list sets from one read of the field (round 6)
-            e = launch_cafscored2(scored[0], scored[1], st);
-            if (e != hipSuccess) return fail_hip(e, "cafscored(both list sets)");
-        } else
-            for (int k = 0; k < n_scored; k++) {
-                e = launch_cafscored(scored[k], st);
-                if (e != hipSuccess) return fail_hip(e, k ? "cafscored(force complete)" : "cafscored");
-            }
+    if (forked) {
+        e = hipStreamWaitEvent(st, side.join, 0);
+        if (e != hipSuccess) return fail_hip(e, "join of the side stream");
+    } else if (!fuse) {
+        const int rc = lists(st);
+        if (rc != OPA_OK) return rc;
     }
     // (the occupancy map of :173 is a bitmap the association kernel clears itself)
     AssocArgs a;

@@ -64,9 +64,10 @@ __device__ __forceinline__ void store_seed(unsigned long long key, int t, int b,
 //   * __final_insertion_sort only moves an element past strictly smaller scores, and the loop leaves segments of at most
 //     16 elements in their final places relative to each other: it is a stable sort INSIDE every such segment -- one
 //     thread per tied seed counts the larger (and the equal, earlier) elements of its segment and stores the seed there.
-// Heapsort (the depth limit, 2 log2 n levels) is not reproduced: an image in which a segment that HOLDS EQUAL SCORES
-// reaches the limit keeps the cell-index order and says so in `tie_state` (-1); segments without equal scores that reach it
-// do not matter (whatever sorts them leaves them as the first sort did).  Images without ties leave after one look at their sorted scores.
+// Heapsort (the depth limit, 2 log2 n levels; round 6): a segment that HOLDS EQUAL SCORES and reaches the limit is heap-sorted
+// like std::__partial_sort does it (tie_heapsort: one lane, serially); segments without equal scores that reach it do not matter
+// (whatever sorts them leaves them as the first sort did).  `tie_state` -1 is left for a protocol failure (a partition without a
+// stop on one side: cannot happen after the median step).  Images without ties leave after one look at their sorted scores.
 constexpr int kTieLdsKeys = 8192;
 constexpr int kTieThreads = 1024;          // of the stand-alone kernel; the pass itself is a template on the workgroup size
 constexpr unsigned kTiedBit = 0x80000000u;      // in a cell index: the seed's score occurs more than once
@@ -341,6 +342,61 @@ __device__ __forceinline__ int tie_partition_block(unsigned* bits_, unsigned* id
     return cut;
 }
 
+// std::__partial_sort(first, last, last, comp) -- what __introsort_loop does with a segment that is still longer than 16
+// elements at its depth limit (bits/stl_algo.h:1944-1948): __make_heap + __sort_heap (bits/stl_heap.h: __adjust_heap, __push_heap,
+// __pop_heap), comp(a, b) = a.v > b.v, on the (score, cell) pairs of [first, last).  ONE lane, serially, exactness over speed:
+// only a sequence built against libstdc++'s pivot rule gets here (tests/test_tie_depth_limit.py: McIlroy's adversary), and only
+// segments that hold equal scores are sorted at all.  The caller marks every position of the segment afterwards: it is sorted,
+// so __final_insertion_sort moves nothing in it.  (Arrays in global memory: relaxed agent-scope atomics both ways, which keeps
+// the lane's own loads behind its own stores.)
+template <bool LDS>
+__device__ __noinline__ void tie_heapsort(unsigned* bits_, unsigned* idx_, int first, int last) {
+    auto ld = [](unsigned* p, int i) -> unsigned {
+        if constexpr (LDS) return p[i];
+        else return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    auto st = [](unsigned* p, int i, unsigned v) {
+        if constexpr (LDS) p[i] = v;
+        else __hip_atomic_store(p + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    unsigned* B = bits_ + first; unsigned* I = idx_ + first;
+    const int len0 = last - first;
+    // __adjust_heap(first, hole, len, value) with __push_heap at its end; comp(x, y) = x > y on the scores
+    auto adjust = [&](int hole, int len, unsigned vb, unsigned vi) {
+        const int top = hole;
+        int child = hole;
+        while (child < (len - 1) / 2) {
+            child = 2 * (child + 1);
+            if (ld(B, child) > ld(B, child - 1)) child--;
+            st(B, hole, ld(B, child)); st(I, hole, ld(I, child));
+            hole = child;
+        }
+        if ((len & 1) == 0 && child == (len - 2) / 2) {
+            child = 2 * (child + 1);
+            st(B, hole, ld(B, child - 1)); st(I, hole, ld(I, child - 1));
+            hole = child - 1;
+        }
+        int parent = (hole - 1) / 2;                  // __push_heap(first, hole, top, value)
+        while (hole > top && ld(B, parent) > vb) {
+            st(B, hole, ld(B, parent)); st(I, hole, ld(I, parent));
+            hole = parent;
+            parent = (hole - 1) / 2;
+        }
+        st(B, hole, vb); st(I, hole, vi);
+    };
+    if (len0 >= 2)                                    // __make_heap
+        for (int parent = (len0 - 2) / 2; ; parent--) {
+            adjust(parent, len0, ld(B, parent), ld(I, parent));
+            if (parent == 0) break;
+        }
+    for (int end = len0; end > 1; ) {                 // __sort_heap: __pop_heap(first, end - 1, end - 1)
+        end--;
+        const unsigned vb = ld(B, end), vi = ld(I, end);
+        st(B, end, ld(B, 0)); st(I, end, ld(I, 0));
+        adjust(0, end, vb, vi);
+    }
+}
+
 // A segment of at most kTieSubtree elements is finished by ONE wave, all the levels below it (no workgroup barrier per
 // level: most of an image's partitions are down here).  An image in global memory brings the segment into the wave's
 // own LDS area first (scores, cells, two stop lists of kTieSubtree entries) and takes it back afterwards.  `stack`: 3 *
@@ -370,13 +426,15 @@ __device__ __forceinline__ void tie_subtree(unsigned* BITS, unsigned* IDX, unsig
         const int f = stack[3 * top], l = stack[3 * top + 1], d = stack[3 * top + 2];
         tie_wave_fence<true>();                                    // (every lane has read the entry before it is overwritten)
         if (d == 0) {
-            // the heapsort branch (std::__partial_sort): not reproduced -- but it only matters where it would have to order
-            // equal scores: a segment without a tied score ends up sorted whatever sorts it, i.e. as the first sort left it
+            // the heapsort branch (std::__partial_sort) -- it only matters where it has to order equal scores: a segment without
+            // a tied score ends up sorted whatever sorts it, i.e. as the first sort left it
             bool tied = false;
             for (int j = f + lane; j < l; j += 64) tied |= (I[j] & kTiedBit) != 0u;
             if (__ballot(tied) == 0ull) continue;
-            if (lane == 0) *s_fail = 1;
-            break;
+            if (lane == 0) tie_heapsort<true>(B, I, f, l);
+            tie_wave_fence<true>();
+            for (int j = f + lane; j < l; j += 64) { const int c = j + off; atomicOr(&mark[c >> 5], 1u << (c & 31)); }   // sorted: every element a segment of its own
+            continue;
         }
         const int cut = tie_partition<true>(B, I, L, R, f, l);
         if (cut == -2) continue;
@@ -412,15 +470,19 @@ __device__ __forceinline__ void tie_levels(unsigned* BITS, unsigned* IDX, unsign
     tie_group_sync<LDS>();
     while (n_cur > 0) {
         if (depth == 0) {
-            // the heapsort branch (std::__partial_sort): not reproduced -- but it only matters where it would have to order
-            // equal scores: fail only if one of the segments that are left holds a tied score
+            // the heapsort branch (std::__partial_sort) for the segments that are left and hold a tied score (the others end up
+            // sorted whatever sorts them): one wave per segment, its first lane sorts
             const TieArr<LDS> IDXA = tie_arr<LDS>(IDX);
-            bool tied = false;
-            for (int s = 0; s < n_cur && !tied; s++) {
+            for (int s = wave; s < n_cur; s += NT / 64) {
                 const int2 sg = cur[s];
-                for (int j = sg.x + tid; j < sg.y; j += NT) tied |= (IDXA(j) & kTiedBit) != 0u;
+                bool tied = false;
+                for (int j = sg.x + lane; j < sg.y; j += 64) tied |= (IDXA(j) & kTiedBit) != 0u;
+                if (__ballot(tied) == 0ull) continue;
+                if (lane == 0) tie_heapsort<LDS>(BITS, IDX, sg.x, sg.y);
+                tie_wave_fence<LDS>();
+                for (int j = sg.x + lane; j < sg.y; j += 64) atomicOr(&mark[j >> 5], 1u << (j & 31));   // sorted: every element a segment of its own
             }
-            if (tied) *s_fail = 1;                                 // (any thread: the same value)
+            tie_group_sync<LDS>();
             break;
         }
         depth--;

@@ -89,7 +89,7 @@ struct CifCaf : torch::CustomClassHolder {
         OPA_DBG_FIELD(assoc_predict_min_v, float) OPA_DBG_FIELD(assoc_predict_th, float) OPA_DBG_FIELD(assoc_collide, int32_t)
         OPA_DBG_FIELD(assoc_collide_shift, int32_t) OPA_DBG_FIELD(assoc_inherit, int32_t) OPA_DBG_FIELD(assoc_lookahead, int32_t)
         OPA_DBG_FIELD(assoc_help, int32_t) OPA_DBG_FIELD(assoc_spec, int32_t) OPA_DBG_FIELD(assoc_timing, int32_t)
-        OPA_DBG_FIELD(assoc_persistent, int32_t) OPA_DBG_FIELD(fc_split, int32_t) OPA_DBG_FIELD(assoc_watchdog_ticks, int64_t)
+        OPA_DBG_FIELD(assoc_persistent, int32_t) OPA_DBG_FIELD(fc_split, int32_t) OPA_DBG_FIELD(side_stream, int32_t) OPA_DBG_FIELD(assoc_watchdog_ticks, int64_t)
 #undef OPA_DBG_FIELD
         TORCH_CHECK(false, "opa_debug has no field ", name);
     }

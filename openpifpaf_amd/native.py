@@ -69,8 +69,9 @@ SEED_TIE_ORDERS = {'libstdcxx': 1, 'index': 0, 'libstdcxx-fused': 2}
 def set_seed_tie_order(order='libstdcxx'):
     """Order of seeds with EQUAL scores: ``'libstdcxx'`` (default) = what the reference's unstable ``std::sort``
     leaves (cif_seeds.cpp:94), reproduced on the device for the images that have such seeds; ``'index'`` = cell index
-    ascending (one launch less); ``'libstdcxx-fused'`` = the reference's order with the pass inside the association kernel
-    (no launch of its own: what several decodes in flight want).  Process-global, like the reference's statics."""
+    ascending (no such pass); ``'libstdcxx-fused'`` = the same as ``'libstdcxx'`` since round 6 (WHERE the pass runs -- inside
+    the association kernel by default, or as a launch of its own -- is a decoder's choice: :meth:`CifCaf.set_tie_placement`).
+    Process-global, like the reference's statics."""
     _lib.lib().opa_set_seed_tie_order(SEED_TIE_ORDERS[order])
 
 
@@ -160,9 +161,9 @@ class CifCaf:
     # pickle state = (n_keypoints, skeleton), module.cpp:41-53
     def set_tie_placement(self, inside_association):
         """Where the pass that puts seeds of equal score into the reference's order runs for this decoder: ``True`` inside the
-        association kernel (what several decodes in flight want -- :class:`DecodeLanes` sets it for two or more lanes),
-        ``False`` a launch of its own (default for one decode at a time), ``None`` the process-wide choice
-        (:func:`set_seed_tie_order`).  Same results bit for bit (``opa_cifcaf_set_tie_placement``)."""
+        association kernel (every image its own ties), ``False`` a launch of its own (its time then shows up under its own
+        name), ``None`` (default) automatic = inside the kernel: measured shorter for one decode at a time and for several in
+        flight (round 6).  Same results bit for bit (``opa_cifcaf_set_tie_placement``)."""
         _lib.check(_lib.lib().opa_cifcaf_set_tie_placement(
             self._handle, -1 if inside_association is None else int(bool(inside_association))), 'opa_cifcaf_set_tie_placement')
 

@@ -187,6 +187,7 @@ def test_tie_pass_inside_the_association_kernel_equals_the_separate_launch(nativ
                 native.set_seed_tie_order(mode)
                 assert native.get_seed_tie_order() == mode
                 dec = native.CifCaf(cif.shape[1], torch.from_numpy(skel0))
+                dec.set_tie_placement(mode == 'libstdcxx-fused')     # (round 6: a decoder's own choice; automatic = inside)
                 out, ids, counts = dec.call_batch(dev(cif), 8, dev(caf), 8)
                 counts = counts.cpu().numpy()
                 native.check_counts(counts)

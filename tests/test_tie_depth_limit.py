@@ -132,6 +132,22 @@ def killer_scores(n, tie):
     return v, (i, j)
 
 
+def killer_scores_many(n, groups=6):
+    """Like ``killer_scores(n, 'deep')`` with ``groups`` more pairs and triples of equal scores spread over the segment that
+    reaches the limit (spread evenly: a handful of changed scores leaves the adversary's pivots what they were)."""
+    v, _ = killer_scores(n, 'deep')
+    a = list(range(n))
+    hit = quicksort_loop(a, lambda x, y: v[x] > v[y], 0, n, 2 * (int(n).bit_length() - 1))
+    deep = sorted(set(e for f, l in hit for e in a[f:l]))
+    L = len(deep)
+    for g in range(groups):
+        i, j, k = (deep[(3 * g + t) * L // (3 * groups + 2)] for t in (1, 2, 3))
+        v[j] = v[i]
+        if g % 2:
+            v[k] = v[i]
+    return v
+
+
 def test_the_scalar_restatement_sorts_like_std_sort(port):
     rng = np.random.default_rng(5)
     for n in (17, 100, 1000, 3000):
@@ -156,9 +172,19 @@ def test_killer_reaches_the_depth_limit_and_the_model_says_what_matters(port):
         assert got is not None and np.array_equal(got, port.sorted_seed_order(v))
         v, (i, j) = killer_scores(n, 'deep')
         assert introsort_model(v, follow_only_tied=True) is None
-        # std::sort itself still sorts, of course: descending, both orders of the equal pair are "sorted"
+        # round 6: the segment at the limit is heap-sorted like std::__partial_sort does it (__make_heap + __sort_heap):
+        # std::sort's order, the equal pair included -- with every segment followed, and with only the tied ones
         perm = port.sorted_seed_order(v)
         assert (np.diff(v[perm]) <= 0).all()
+        for only_tied in (False, True):
+            got = introsort_model(v, follow_only_tied=only_tied, heapsort=True)
+            assert got is not None and np.array_equal(got, perm), (n, only_tied)
+    # heapsort with SEVERAL groups of equal scores inside the segment at the limit
+    for n in (1500, 5000):
+        v = killer_scores_many(n)
+        assert introsort_model(v, follow_only_tied=True) is None, 'the sequence no longer reaches the limit with its ties'
+        got = introsort_model(v, follow_only_tied=True, heapsort=True)
+        assert got is not None and np.array_equal(got, port.sorted_seed_order(v)), n
 
 
 def _field_from_scores(v, H=None):
@@ -185,9 +211,10 @@ def test_kernel_flags_only_a_tied_segment_at_the_depth_limit(port):
     native.CifSeeds.set_ablation_no_rescore(True)
     port_params = port.default_params(ablation_cifseeds_no_rescore=1)
     try:
-        for n in (1500, 5000):                      # one LDS block / the split first sort; both inside the LDS arrays of the pass
-            for tie, want_state in (('shallow', 1), ('deep', -1)):
-                v, (i, j) = killer_scores(n, tie)
+        # one LDS block / the split first sort, both inside the LDS arrays of the pass; 9000: the arrays in global memory
+        for n in (1500, 5000, 9000):
+            for tie, want_state in ((('shallow', 1), ('deep', 1), ('many', 1)) if n < 9000 else (('many', 1),)):      # round 6: the heapsort branch is reproduced
+                v, (i, j) = killer_scores(n, tie) if tie != 'many' else (killer_scores_many(n), (0, 0))
                 cif = _field_from_scores(v)
                 caf = np.zeros((1, 8, cif.shape[2], cif.shape[3]), dtype=np.float32)
                 dec = native.CifCaf(2, torch.from_numpy(skel0))

@@ -15,8 +15,54 @@ def port():
     return p
 
 
-def introsort_model(v, follow_only_tied=True):
-    """-> perm (original positions in final order), or None where std::sort would switch to heapsort."""
+def heapsort_segment(a, v, first, last):
+    """``std::__partial_sort(first, last, last, comp)`` -- what ``__introsort_loop`` does with a segment that reaches its depth
+    limit: ``__make_heap`` + ``__sort_heap`` (bits/stl_heap.h: ``__adjust_heap``, ``__push_heap``, ``__pop_heap``), comp(x, y) =
+    x.v > y.v.  In place on a[first:last] (original positions); scores v."""
+    comp = lambda x, y: v[x] > v[y]
+
+    def push_heap(hole, top, value):
+        parent = (hole - 1) // 2
+        while hole > top and comp(a[first + parent], value):
+            a[first + hole] = a[first + parent]
+            hole = parent
+            parent = (hole - 1) // 2
+        a[first + hole] = value
+
+    def adjust_heap(hole, length, value):
+        top = hole
+        child = hole
+        while child < (length - 1) // 2:
+            child = 2 * (child + 1)
+            if comp(a[first + child], a[first + child - 1]):
+                child -= 1
+            a[first + hole] = a[first + child]
+            hole = child
+        if (length & 1) == 0 and child == (length - 2) // 2:
+            child = 2 * (child + 1)
+            a[first + hole] = a[first + child - 1]
+            hole = child - 1
+        push_heap(hole, top, value)
+
+    length = last - first
+    if length >= 2:                                       # __make_heap
+        parent = (length - 2) // 2
+        while True:
+            adjust_heap(parent, length, a[first + parent])
+            if parent == 0:
+                break
+            parent -= 1
+    end = last                                            # __sort_heap
+    while end - first > 1:
+        end -= 1
+        value = a[end]
+        a[end] = a[first]
+        adjust_heap(0, end - first, value)
+
+
+def introsort_model(v, follow_only_tied=True, heapsort=False):
+    """-> perm (original positions in final order); where std::sort switches to heapsort (a segment at the depth limit): None,
+    or with ``heapsort`` the segment is heap-sorted like ``std::__partial_sort`` does it (round 6: the kernel does)."""
     v = np.asarray(v, dtype=np.float32)
     n = len(v)
     a = np.arange(n)                                      # a[k]: original position of the element at k
@@ -32,7 +78,11 @@ def introsort_model(v, follow_only_tied=True):
         if follow_only_tied and not tied[a[first:last]].any():
             continue                                      # nobody asks where these end up: each has a rank of its own
         if depth == 0:
-            return None
+            if not heapsort:
+                return None
+            heapsort_segment(a, v, first, last)           # sorted now: every element of it is a segment of its own
+            marks.update(range(first, last + 1))
+            continue
         x = lambda k: v[a[k]]
         A, B, C = first + 1, first + (last - first) // 2, last - 1     # __move_median_to_first
         if x(A) > x(B):
@@ -67,7 +117,7 @@ def introsort_model(v, follow_only_tied=True):
     # final insertion sort: a tied element goes behind the larger and the equal-and-earlier elements of the segment
     # between the mark at or before it and the next mark; everything else sits at its rank, wherever the loop left it
     out = np.full(n, -1, dtype=np.int64)
-    bounds = sorted(marks) + [n]
+    bounds = sorted(marks | {n})
     order = np.argsort(-v, kind='stable')
     rank_of = np.empty(n, dtype=np.int64)
     rank_of[order] = np.arange(n)
@@ -76,8 +126,9 @@ def introsort_model(v, follow_only_tied=True):
         if not tied[e]:
             out[rank_of[e]] = e                           # a score of its own: its rank is its place
             continue
-        ls = max(b for b in bounds if b <= k)
-        le = min(b for b in bounds if b > k)
+        import bisect
+        at = bisect.bisect_right(bounds, k)
+        ls, le = bounds[at - 1], bounds[at]
         assert le - ls <= 16, (ls, le)
         seg = v[a[ls:le]]
         pos = ls + int((seg > v[e]).sum()) + int((seg[:k - ls] == v[e]).sum())
