@@ -188,8 +188,9 @@ typedef struct opa_debug {
     int32_t assoc_help;            /* compiled-in variants only (-DOPA_ASSOC_HELPERS)                        OPA_ASSOC_HELP         */
     int32_t assoc_spec;            /* compiled-in variants only (-DOPA_ASSOC_WALK)                           OPA_ASSOC_SPEC         */
     int32_t assoc_timing;          /* 0; 1: the coordinator fills its per-phase tick counters                OPA_ASSOC_TIMING       */
-    int32_t assoc_persistent;      /* 0 = automatic: more images than compute units are taken from a queue, longest first, by
-                                    *    one workgroup per compute unit (round 6); 1: always; -1: never      OPA_ASSOC_PERSISTENT   */
+    int32_t assoc_persistent;      /* 0 = automatic: in a batch of more images than the chip has compute units the association
+                                    *    workgroups take their images from a queue, most seeds first (round 6); 1: always;
+                                    *    -1: never (workgroup b = image b)                                   OPA_ASSOC_PERSISTENT   */
     int32_t fc_split;              /* 0 = automatic; n: force-complete workgroups per image                  OPA_FC_SPLIT           */
     int32_t side_stream;           /* 0; 1: the CAF lists are built on a stream of the handle's own beside the seed chain (fill, sort,
                                     *    tie pass) and joined before the association kernel (round 6: the two branches do not overlap
@@ -284,7 +285,8 @@ int opa_cifcaf_cifhr_view(const opa_shape* shape, size_t* offset_floats,
  * (round 5) and, for what that pass admits, at the refills; ticks are 10 ns; the tick
  * counters 12 and 17-20 are filled only with opa_debug::assoc_timing: each costs clock reads in the coordinator's loop), "assoc_trace" (int32 [B,64,4]: for the first
  * 64 accepted poses of an image the tick of the commit, of the hand-out and of the end of the growth, and
- * seed index | grower << 24).
+ * seed index | grower << 24), "assoc_queue" (int32 [B + 1]: batches of more images than compute units -- the images by seed count,
+ * most first, then the queue's head; round 6), "cifhr_work" (int2 [..]: the tile kernel's work list, round 6).
  * The three "*_fc" regions lie at the END of the layout: their offsets are only inside a workspace of
  * opa_cifcaf_workspace_bytes() (or ..._bytes_for() with force_complete set); a workspace sized without the flag
  * ends before them -- do not dereference them there. */

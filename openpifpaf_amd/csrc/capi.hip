@@ -197,6 +197,7 @@ bool make_layout(const opa_shape& s, Layout* L, const char** why) {
     L->off_status = take(B * sizeof(int32_t));
     L->off_stats = take(B * 24 * sizeof(int32_t));
     L->off_trace = take(B * 64 * 4 * sizeof(int32_t));
+    L->off_assoc_queue = take((B + 1) * sizeof(int32_t));             // the association kernel's image queue (batches beyond one workgroup per compute unit)
     L->off_tie_state = take(B * sizeof(int32_t));
     if (L->occ_image_words * sizeof(unsigned) >= tie_small_bytes(L->F, L->H * L->W)) {
         L->off_tie_small = L->off_occ; L->tie_small_stride = L->occ_image_words * sizeof(unsigned);
@@ -444,7 +445,7 @@ int opa_cifcaf_workspace_view(const opa_shape* shape, const char* what, size_t* 
         {"lists", L.off_lists, L.off_list_counts}, {"list_counts", L.off_list_counts, L.off_list_bbox},
         {"list_bbox", L.off_list_bbox, L.off_occ},
         {"occupancy", L.off_occ, L.off_anns}, {"annotation_scratch", L.off_anns, L.off_ann_meta},
-        {"status", L.off_status, L.off_stats}, {"assoc_stats", L.off_stats, L.off_trace}, {"assoc_trace", L.off_trace, L.off_tie_state}, {"seed_ties", L.off_tie_state, L.off_tie_state + (size_t)L.B * sizeof(int32_t)},
+        {"status", L.off_status, L.off_stats}, {"assoc_stats", L.off_stats, L.off_trace}, {"assoc_trace", L.off_trace, L.off_assoc_queue}, {"assoc_queue", L.off_assoc_queue, L.off_tie_state}, {"seed_ties", L.off_tie_state, L.off_tie_state + (size_t)L.B * sizeof(int32_t)},
         {"lists_fc", L.off_lists_fc, L.off_list_counts_fc}, {"list_counts_fc", L.off_list_counts_fc, L.off_list_bbox_fc},
         {"list_bbox_fc", L.off_list_bbox_fc, L.off_fc_meta},
     };
@@ -603,6 +604,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec_in, const opa_shape* shape, const op
     a.out = out_dev; a.out_ids = out_ids_dev; a.out_count = out_count_dev;
     a.status = (int32_t*)(ws + L.off_status);
     a.hr_overflow = pool.overflow;
+    a.queue_order = (int32_t*)(ws + L.off_assoc_queue); a.queue_head = a.queue_order + L.B;
     a.tie_fused = fuse_ties ? 1 : 0;
     make_tie_args(&a.tie, &a.tie_sort, (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap, (int32_t*)(ws + L.off_seed_count), cif_dev,
                   L.F, 5, L.H * L.W, L.stride, (int32_t*)(ws + L.off_seed_f), (float*)(ws + L.off_seed_vxys),

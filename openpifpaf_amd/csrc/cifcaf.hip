@@ -2451,14 +2451,16 @@ __device__ __forceinline__ void nms_and_store(const AssocArgs& a, const DevParam
     }
 }
 
+// One image, by the NW waves of a workgroup (the kernel below calls it once -- one workgroup per image -- or, as a persistent
+// workgroup, for one image after the other).  `smem`: the workgroup's dynamic LDS; every word of it that is read is written here first.
 template <bool REG, int NW>
-__global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a, DevSkeleton sk, DevParams p,
-                                                                     int n_growers, int nms_waves, int tgt_floats) {
+__device__ __forceinline__ void assoc_image(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p,
+                                            const int n_growers, const int nms_waves, const int tgt_floats, const int b,
+                                            unsigned char* smem) {
     constexpr int kThreads = NW * kWave;
     constexpr int WR = REG ? kPoolSlots : kPoolSlotsLds;     // seed-pool slots per coordinator lane
     const bool use_bbox = REG && a.list_bbox != nullptr;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int b = blockIdx.x, tid = threadIdx.x, lane = lane_id();
+    const int tid = threadIdx.x, lane = lane_id();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = a.K, A = a.A, E = 2 * A;
     const int S = n_growers;                         // growers = waves 1..S, each with a private LDS block
@@ -3595,6 +3597,47 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a
     }
 }
 
+// One workgroup per image.  Which image: its block index -- or, round 6, for batches of more images than the chip has compute
+// units, the next entry of a QUEUE: `queue_order` [B] lists the images by seed count, most seeds first (assoc_order_kernel),
+// `queue_head` is the next entry, taken with one atomic when the workgroup starts.  The hardware's dispatcher is the pool of
+// persistent workers (a workgroup starts when a compute unit is free); what the queue adds is the ORDER: a launch lasts as long
+// as its most crowded image while the mean image takes half of that, so the long ones go first and the tail is the short ones.
+// (A loop over images inside the kernel -- one resident workgroup per compute unit pulling from the same queue -- was built first:
+// the loop costs the kernel 170 spilled vector registers, with the image's code inlined once or twice alike.)
+// Replaces the reference's per-image loop over a fork pool (decoder/decoder.py:33-47,130-131).
+template <bool REG, int NW>
+__global__ __launch_bounds__(NW * kWave, 1) void cifcaf_assoc_kernel(AssocArgs a, DevSkeleton sk, DevParams p,
+                                                                     int n_growers, int nms_waves, int tgt_floats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int b = blockIdx.x;
+    if (a.queue_order) {
+        int* entry = reinterpret_cast<int*>(smem);
+        if (threadIdx.x == 0) *entry = atomicAdd(a.queue_head, 1);
+        __syncthreads();
+        b = __builtin_amdgcn_readfirstlane(a.queue_order[__builtin_amdgcn_readfirstlane(*entry)]);   // (uniform: keep it scalar)
+        __syncthreads();                              // (read by everybody before the image's code lays the LDS out)
+    }
+    assoc_image<REG, NW>(a, sk, p, n_growers, nms_waves, tgt_floats, b, smem);
+}
+
+// images by seed count, most first (ties by index): rank by counting, one thread per image
+__global__ __launch_bounds__(1024) void assoc_order_kernel(const int32_t* __restrict__ seed_count, int B, int32_t* __restrict__ order,
+                                                           int32_t* __restrict__ head) {
+    __shared__ int tile[1024];
+    if (threadIdx.x == 0 && blockIdx.x == 0) *head = 0;
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int mine = i < B ? seed_count[i] : 0;
+    int rank = 0;
+    for (int j0 = 0; j0 < B; j0 += 1024) {
+        __syncthreads();
+        tile[threadIdx.x] = j0 + threadIdx.x < B ? seed_count[j0 + threadIdx.x] : -1;
+        __syncthreads();
+        const int m = min(1024, B - j0);
+        for (int k = 0; k < m; k++) { const int c = tile[k]; rank += (c > mine || (c == mine && j0 + k < i)) ? 1 : 0; }
+    }
+    if (i < B) order[rank] = i;
+}
+
 // ------------------------------------------------------------ force complete
 // cifcaf.cpp:233-236,414-449 + the keypoint NMS behind it, as a kernel of its own.  The stored poses of an image
 // are independent here (each is grown on with the caf_th 0.001 lists, no reverse match, a 4 sigma window, then flood
@@ -3721,6 +3764,17 @@ __global__ __launch_bounds__(NW * kWave, 1) void cifcaf_fc_kernel(AssocArgs a, D
 #endif
 }
 
+static int assoc_compute_units() {                    // of the current device (asked once per device)
+    static int n_cu[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (n_cu[dev] == 0) {
+        int v = 0;
+        n_cu[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0 ? v : 256;
+    }
+    return n_cu[dev];
+}
+
 template <bool REG, int NW>
 static hipError_t launch_fc_nw(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st) {
     const int K = a.K, A = a.A, E = 2 * A;
@@ -3793,6 +3847,8 @@ static hipError_t launch_assoc_nw(const AssocArgs& a, const DevSkeleton& sk, con
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    if (a.queue_order)                                // more images than compute units: longest first
+        assoc_order_kernel<<<(a.B + 1023) / 1024, 1024, 0, st>>>(a.seed_count, a.B, a.queue_order, a.queue_head);
     cifcaf_assoc_kernel<REG, NW><<<a.B, NW * kWave, lds, st>>>(a, sk, p, growers, nms_waves, tgt_floats);
     return hipGetLastError();
 }
@@ -3831,6 +3887,7 @@ hipError_t launch_assoc(const AssocArgs& args, const DevSkeleton& sk, const DevP
     a.spec = kWalk && dbg.assoc_spec != 0;        // (walk builds) 0: every bone scanned on demand, one at a time
     a.watchdog_ticks = dbg.assoc_watchdog_ticks > 0 ? dbg.assoc_watchdog_ticks : kWatchdogTicksDefault;
     a.max_growers = dbg.assoc_growers;
+    if (dbg.assoc_persistent < 0 || (dbg.assoc_persistent == 0 && a.B <= assoc_compute_units())) a.queue_order = a.queue_head = nullptr;
     a.fc_split = dbg.fc_split;
     const int waves = assoc_waves(dbg.assoc_waves);
     const int K = a.K, E = 2 * a.A;

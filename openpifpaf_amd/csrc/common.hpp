@@ -34,7 +34,7 @@ struct Layout {
     // byte offsets into the workspace (all 256-B aligned)
     size_t off_hdr, off_tile_clean, off_cifhr, off_act, off_act_count, off_seed_keys, off_seed_count,
            off_seed_f, off_seed_vxys, off_seed_cell, off_lists, off_list_counts,
-           off_lists_fc, off_list_counts_fc, off_list_bbox, off_list_bbox_fc, off_fc_meta, off_occ, off_anns, off_ann_meta, off_status, off_stats, off_trace,
+           off_lists_fc, off_list_counts_fc, off_list_bbox, off_list_bbox_fc, off_fc_meta, off_occ, off_anns, off_ann_meta, off_status, off_stats, off_trace, off_assoc_queue,
            total_no_fc, total;           // total_no_fc: everything but the regions only a force-complete decode uses (they come last)
     size_t occ_image_words;               // 32-bit words of one image's occupancy bitmap (capacity)
     // scratch of the seed tie pass (cifseeds.hip): `big` lies in the active-cell list (dead once the map is built, and
@@ -222,6 +222,7 @@ struct AssocArgs {
     int prededup;               // 1: ... and by the whole workgroup before the coordinator starts (needs dedup; exact; see cifcaf.hip)
     int32_t* fc_meta;           // [B, 4] seed kernel -> force-complete kernel: poses stored, dropped, failed, workgroup counter
     long long watchdog_ticks;   // 10-ns ticks after which every wait inside one launch gives up (status -1)
+    int32_t* queue_order; int32_t* queue_head;   // [B] images by seed count, most first + the queue's head (or null: one workgroup per image)
     int max_growers, fc_split;  // opa_debug: at most this many growing waves (0: as many as fit); force-complete workgroups per image (0: automatic)
     unsigned* occ;           // occupancy bitmap [B][occ_image_words]: per image [F][occ_h][(occ_w+31)/32] words, zeroed by the kernel
     size_t occ_image_words;
