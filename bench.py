@@ -532,6 +532,19 @@ class Workload:
                    self.fh, self.B, self.A, self.fh, self.fh))
 
 
+def _synth_part(seed0, n, fh):
+    from openpifpaf_amd import synth
+    return synth.synth_batch(n, seed0=seed0, height=fh, width=fh)
+
+
+def Workload_view(wl, B, variants):
+    """The same decoder and shapes with another batch size / field batches (kernel_profile only reads these)."""
+    v = Workload.__new__(Workload)
+    v.__dict__.update(wl.__dict__)
+    v.B, v.variants = B, variants
+    return v
+
+
 def build_model(wl, dtype_name):
     from openpifpaf_amd import network
     model = network.factory(wl.backbone, [wl.cif_meta, wl.caf_meta]).to(wl.device)
@@ -745,12 +758,8 @@ def main():
         for _ in range(warmup):
             step()
         sync_all()
-        if world > 1 and model is not None:
-            # each process picked its 1x1-convolution kernels by wall clock during the warm-up and the paths round
-            # differently: from here on every rank runs rank 0's choices
-            distributed.broadcast_conv_choices()
-            step()
-            sync_all()
+        # (round 6: no broadcast of 1x1-convolution kernel choices any more -- the package ships the table for these shapes,
+        # fused.load_pinned, and a multi-rank job takes the same default for a shape the table does not know)
         if rank == 0:
             print('bench: config %d %s leg warm-up (incl. MIOpen find) %.1f s' % (wl.config_id, dtype_name,
                                                                                   time.perf_counter() - t_setup), file=sys.stderr)
@@ -1102,6 +1111,71 @@ def main():
                             'two or more lanes run the tie pass inside the association kernel (opa_cifcaf_set_tie_placement, the '
                             'DecodeLanes default); *_ties_launch: the same lanes with the pass as a launch of its own'}
         guarded('decode_two_in_flight', lanes_leg)
+
+        # ONE call_batch of 256 images (eight of the headline's field batches: BASELINE configs[4]'s global batch on one GPU): the
+        # launch that fills the chip -- the association kernel's 256 workgroups on 256 compute units -- per kernel, its roofline,
+        # every image against the reference; the same with two and four decode lanes, and 512 images in one call (the
+        # association kernel's image queue: more images than compute units, most seeds first)
+        def b256_leg():
+            from openpifpaf_amd import synth
+            Bb = 256
+            import multiprocessing as mp
+            ctx = mp.get_context('fork')
+            seeds = [k * 32 + 2 * VARIANT_SEED for k in range(Bb // 32)]
+            with ctx.Pool(min(8, os.cpu_count() or 1)) as pool:            # (numpy only in the children)
+                parts = pool.starmap(_synth_part, [(s0, 32, wl.fh) for s0 in seeds])
+            cifs = np.concatenate([c for c, _ in parts]); cafs = np.concatenate([f for _, f in parts])
+            cif_d, caf_d = torch.from_numpy(cifs).to(device), torch.from_numpy(cafs).to(device)
+            variants = [(cifs, cafs, cif_d, caf_d)]
+            wb = Workload.__new__(Workload)
+            wb.__dict__.update(wl.__dict__)
+            wb.B, wb.variants = Bb, variants
+            wb.dec = native.CifCaf(wl.K, torch.from_numpy(wl.skeleton0))
+            wb.host_out = torch.empty((Bb, wb.dec.max_annotations, wl.K, 4), dtype=torch.float32).pin_memory()
+            wb.host_counts = torch.empty((Bb,), dtype=torch.int32).pin_memory()
+            out = {'what': 'decode only: ONE call_batch of %d COCO-shaped images (%d synth batches of 32, seeds %d..), annotations copied '
+                           'to the host; roofline: SURVEY 8d bytes of the 256-image launch over the dominant kernel\'s HIP-event time; '
+                           'lanes: native.DecodeLanes with 256 images per call; b512: 512 images in one call (image queue)' % (Bb, Bb // 32, seeds[0])}
+            rate = {}
+            for n in (1, 2, 4):
+                steps = 24
+                leg = run_leg(wb, None, 'fp32', steps, 2 * n + 3, decode_only=True, n_streams=n)
+                rate[n] = round(Bb * steps / leg['elapsed'], 1)
+                if n == 1:
+                    out['ms_per_batch_wall'] = round(leg['elapsed'] / steps * 1e3, 3)
+                    out['annotations_per_batch'] = leg['n_ann']
+            out['value'] = rate[1]
+            out['lanes_images_per_s'] = {'one': rate[1], 'two': rate[2], 'four': rate[4]}
+            alg = algorithmic_bytes(Bb, wl.K, wl.A, wl.fh, wl.fh, wl.stride, wb.dec.max_annotations)['decode_path']
+            best = max(rate.values())
+            out['best'] = {'images_per_s': best, 'GBps': round(alg * best / Bb / 1e9, 1), 'frac': round(alg * best / Bb / 1e9 / HBM_PEAK_GBPS, 5)}
+            with torch.cuda.stream(dec_stream):
+                out['roofline'] = decode_roofline(wb, variants, None, 6)
+                out['parity'] = None if args.no_parity else parity_stamp(
+                    lambda c, f: wb.dec.call_batch(c, wl.stride, f, wl.stride), variants, wl.skeleton0, wl.K)
+                # 512 images in one call: the 256 twice
+                c2, f2 = torch.cat([cif_d, cif_d]), torch.cat([caf_d, caf_d])
+                for _ in range(2):
+                    wb.dec.call_batch(c2, wl.stride, f2, wl.stride)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(8):
+                    o2, i2, n2 = wb.dec.call_batch(c2, wl.stride, f2, wl.stride)
+                torch.cuda.synchronize(device)
+                ms = (time.perf_counter() - t0) / 8 * 1e3
+                native.check_counts(n2)
+                k512 = kernel_profile(Workload_view(wb, 2 * Bb, [(None, None, c2, f2)]), [(None, None, c2, f2)], None, 4)
+                same = bool(torch.equal(n2[:Bb], n2[Bb:]))
+                out['b512_one_call'] = {'images_per_s': round(2 * Bb / (ms * 1e-3), 1), 'ms_per_batch_wall': round(ms, 3),
+                                        'kernels_ms': {k: round(v, 4) for k, v in k512.items()},
+                                        'frac_dominant_kernel': round(2 * alg / (max(k512.values()) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                                        'frac_decode_path_wall': round(2 * alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
+                                        'both_halves_same_counts': same}
+                del c2, f2, o2
+            wb.dec = None
+            torch.cuda.empty_cache()
+            return out
+        guarded('decode_b256', b256_leg)
 
         # the adversarial case (BASELINE.md 3 ii): structureless all-active fields, what a random-init head
         # emits -- every cell passes every threshold.  Decode only, reported separately, with its own parity count.

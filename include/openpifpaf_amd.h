@@ -192,10 +192,10 @@ typedef struct opa_debug {
                                     *    workgroups take their images from a queue, most seeds first (round 6); 1: always;
                                     *    -1: never (workgroup b = image b)                                   OPA_ASSOC_PERSISTENT   */
     int32_t fc_split;              /* 0 = automatic; n: force-complete workgroups per image                  OPA_FC_SPLIT           */
-    int32_t side_stream;           /* 0; 1: the CAF lists are built on a stream of the handle's own beside the seed chain (fill, sort,
-                                    *    tie pass) and joined before the association kernel (round 6: the two branches do not overlap
-                                    *    -- the list building fills the chip and the sort's fat workgroups find no room beside it --
-                                    *    one lane is slower with it, two lanes are faster)                   OPA_SIDE_STREAM        */
+    int32_t side_stream;           /* one branch of the decode on a stream of the handle's own, joined before the association kernel
+                                    *    (round 6): 0 none; 1 the CAF lists beside the seed chain (measured: the two do not overlap, the
+                                    *    list building fills the chip); 2 the tie pass (as a launch of its own) beside the list building
+                                    *                                                                        OPA_SIDE_STREAM        */
     int64_t assoc_watchdog_ticks;  /* 1e8 (one second): 10-ns ticks after which a wait inside the association kernel gives up
                                     *    and the image is flagged OPA_COUNT_FAILED                           OPA_ASSOC_WATCHDOG_TICKS */
 } opa_debug;

@@ -41,7 +41,7 @@ static opa_debug debug_from_environment() {
     d.assoc_spec = env_int("OPA_ASSOC_SPEC", 1) != 0;
     d.assoc_timing = env_int("OPA_ASSOC_TIMING", 0) != 0;
     d.assoc_persistent = env_int("OPA_ASSOC_PERSISTENT", 0);
-    d.side_stream = env_int("OPA_SIDE_STREAM", 0) != 0;
+    d.side_stream = env_int("OPA_SIDE_STREAM", 0);
     d.fc_split = env_int("OPA_FC_SPLIT", 0);
     d.assoc_watchdog_ticks = 100000000ll;
     if (const char* e = std::getenv("OPA_ASSOC_WATCHDOG_TICKS")) { const long long v = std::atoll(e); if (v > 0) d.assoc_watchdog_ticks = v; }
@@ -248,9 +248,9 @@ static bool side_for(opa_cifcaf* dec, hipStream_t main, opa_cifcaf::Side* out) {
     opa_cifcaf::Side s; s.main = main;
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    // LOWEST priority: the list building fills every compute unit it is given; the seed chain's few, fat workgroups (1024 threads,
-    // 64-128 KB of LDS) only find room beside it when the dispatcher prefers them
-    if (hipStreamCreateWithPriority(&s.side, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); return false; }
+    // (mode 1 -- the lists on the side stream -- wants the LOWEST priority there, mode 2 -- the tie pass -- the highest: its fat
+    // workgroups only find room beside the list building when the dispatcher prefers them)
+    if (hipStreamCreateWithPriority(&s.side, hipStreamNonBlocking, dec->debug.side_stream == 2 ? hi : lo) != hipSuccess) { (void)hipGetLastError(); return false; }
     if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&s.join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
     dec->sides.push_back(s);
@@ -541,13 +541,18 @@ int opa_cifcaf_decode(const opa_cifcaf* dec_in, const opa_shape* shape, const op
     // kernels (wall per decode: 32 COCO images 0.730 -> 0.713 ms, 256 images 1.563 -> 1.502 ms, 16 wholebody images 3.42 -> 3.36 ms).
     // (round 6: inside the association kernel unless the decoder asks for the launch of its own -- measured shorter for one decode
     // of 32 or 256 COCO images and of 16 wholebody images alike, profiles/r6/tie_placement.log)
-    const bool fuse_ties = seed_tie_order() >= 1 && (dec->tie_inside >= 0 ? dec->tie_inside == 1 : true);
-    ties.defer = fuse_ties ? 1 : 0;
-    // The two branches behind the finished map: the CAF lists on the handle's side stream, the seed chain on the caller's
-    // (opa_debug::side_stream; not while this thread profiles the stream with events -- their times are per kernel in a row --
-    // and not when the side stream cannot be had, e.g. the first decode of a handle inside a graph capture).
+    // The branches behind the finished map -- the CAF lists, the seed chain (fill, sort, rank merge), the tie pass -- meet at the
+    // association kernel.  opa_debug::side_stream puts one of them on the handle's side stream (not while this thread profiles the
+    // stream with events -- their times are per kernel in a row -- and not when the side stream cannot be had, e.g. the first
+    // decode of a handle inside a graph capture): 1 = the lists beside the whole seed chain (measured: no overlap, the list
+    // building fills the chip and the sort's fat workgroups find no room beside it); 2 = the TIE PASS, a launch of its own, beside
+    // the list building -- one workgroup per image that needs most of a compute unit's LDS but few of its wave slots.
     opa_cifcaf::Side side;
     const bool forked = !fuse && dec->debug.side_stream != 0 && !(g_prof.on && g_prof.st == st) && side_for(dec, st, &side);
+    const bool tie_on_side = forked && dec->debug.side_stream == 2 && seed_tie_order() >= 1 && dec->tie_inside != 1;
+    const bool lists_on_side = forked && dec->debug.side_stream == 1;
+    const bool fuse_ties = seed_tie_order() >= 1 && !tie_on_side && (dec->tie_inside >= 0 ? dec->tie_inside == 1 : true);
+    ties.defer = fuse_ties || tie_on_side ? 1 : 0;
     auto lists = [&](hipStream_t ls) -> int {
         if (n_scored == 2 && dec->debug.scored_one_pass) {     // both list sets from one read of the field (round 6)
             const hipError_t le = launch_cafscored2(scored[0], scored[1], ls);
@@ -559,7 +564,7 @@ int opa_cifcaf_decode(const opa_cifcaf* dec_in, const opa_shape* shape, const op
             }
         return OPA_OK;
     };
-    if (forked) {
+    if (lists_on_side) {
         e = hipEventRecord(side.fork, st);
         if (e == hipSuccess) e = hipStreamWaitEvent(side.side, side.fork, 0);
         if (e != hipSuccess) return fail_hip(e, "fork to the side stream");
@@ -574,12 +579,27 @@ int opa_cifcaf_decode(const opa_cifcaf* dec_in, const opa_shape* shape, const op
                         (float*)(ws + L.off_seed_vxys), st, false, (int32_t*)(ws + L.off_seed_cell),
                         L.occ_h, L.occ_w, true, fuse ? scored : nullptr, fuse ? n_scored : 0, &ties, &pool, &cand);   // :144-146
     if (e != hipSuccess) return fail_hip(e, "cifseeds");
-    if (forked) {
+    if (lists_on_side) {
         e = hipStreamWaitEvent(st, side.join, 0);
         if (e != hipSuccess) return fail_hip(e, "join of the side stream");
     } else if (!fuse) {
+        if (tie_on_side) {                            // the seeds are sorted: the tie pass beside the list building
+            TieArgs ta; SortArgs tg;
+            make_tie_args(&ta, &tg, (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap, (int32_t*)(ws + L.off_seed_count), cif_dev,
+                          L.F, 5, L.H * L.W, L.stride, (int32_t*)(ws + L.off_seed_f), (float*)(ws + L.off_seed_vxys),
+                          (int32_t*)(ws + L.off_seed_cell), L.occ_h, L.occ_w, ties);
+            e = hipEventRecord(side.fork, st);
+            if (e == hipSuccess) e = hipStreamWaitEvent(side.side, side.fork, 0);
+            if (e == hipSuccess) e = launch_cifseeds_ties(ta, tg, L.B, p, side.side);
+            if (e == hipSuccess) e = hipEventRecord(side.join, side.side);
+            if (e != hipSuccess) return fail_hip(e, "tie pass on the side stream");
+        }
         const int rc = lists(st);
         if (rc != OPA_OK) return rc;
+        if (tie_on_side) {
+            e = hipStreamWaitEvent(st, side.join, 0);
+            if (e != hipSuccess) return fail_hip(e, "join of the side stream");
+        }
     }
     // (the occupancy map of :173 is a bitmap the association kernel clears itself)
     AssocArgs a;

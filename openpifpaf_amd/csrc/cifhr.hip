@@ -430,6 +430,9 @@ __global__ __launch_bounds__(256) void cifhr_tile_kernel(
 //    [-0.5 sigma^2, -0.125], sigma^2 >= 1).  tests/test_exact_division_model.py checks the identity on 10^7 operand pairs of this
 //    kernel's domain, the bit-exact map tests and the randomised sweeps check the kernel;
 //  * approx_exp's range test is gone: d^2 <= sigma^2 inside the circle, so its argument lies in [-0.5, 0].
+// (Measured and dropped: HALF a tile per wave for small batches -- twice the work items at half the LDS each, eight waves per
+// workgroup -- 45.8 us against 42.8 us for 32 images: the launch is bound by its most crowded tiles' chains of cells, which a
+// split by rows does not shorten, not by the number of tiles in flight.)
 // the rare cell whose sigma^2 has an all-ones significand (Markstein's exception): the compiler's division, the plain loop
 __device__ __noinline__ void apply_cell_tile_slow(float* __restrict__ T, float bv, float bx, float by, float sigma2, int bx0, int bx1,
                                                   int by0, int by1, int x0, int y0, int lane) {

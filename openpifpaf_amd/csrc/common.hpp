@@ -238,6 +238,7 @@ struct AssocArgs {
 void make_tie_args(TieArgs* a, SortArgs* g, unsigned long long* keys, int sort_cap, const int32_t* seed_count, const float* cif,
                    int F, int NC, int HW, int stride, int32_t* seed_f, float* seed_vxys, int32_t* seed_cell, int occ_h, int occ_w,
                    const TieScratch& t);
+hipError_t launch_cifseeds_ties(const TieArgs& a, const SortArgs& g, int B, const DevParams& p, hipStream_t st);
 hipError_t launch_assoc(const AssocArgs& a, const DevSkeleton& sk, const DevParams& p, hipStream_t st, const opa_debug& dbg);
 
 struct DetArgs {

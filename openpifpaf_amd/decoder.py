@@ -376,10 +376,64 @@ class CifCaf(Decoder):
         self._lane_pending[lane] = pending
         return pending
 
+    #: multi-GPU (reference ``predictor.py:33-37`` wraps the model in ``nn.DataParallel``: one process, the field
+    #: tensors of all GPUs gathered to GPU 0 and copied to the host).  Here: one process per GPU under ``torch.distributed``
+    #: (backend ``nccl`` = RCCL over xGMI); every rank is handed the SAME batch, runs network + decode on its shard of the
+    #: images and ONE ``all_gather`` of the packed annotation blocks gives every rank the whole batch's annotations -- what
+    #: ``batch`` returns on every rank.  ``None`` = automatic (an initialised process group of more than one rank), ``False`` =
+    #: never (every rank decodes whole batches on its own), a ``ProcessGroup`` = that group.
+    distributed = None
+
+    def _dist(self):
+        if self.distributed is False:
+            return None
+        from . import distributed as dist_mod
+        group = None if self.distributed in (None, True) else self.distributed
+        act = dist_mod.active(group)
+        return None if act is None else (act[0], act[1], group)
+
+    def _batch_sharded(self, model, image_batch, device, meta_batch, rank, world, group):
+        """``batch`` under ``torch.distributed``: this rank's shard through network + decode, one collective, the whole batch back."""
+        from . import distributed as dist_mod
+        from .annotation import inverse_transform_batch
+        n = len(image_batch)
+        lo, hi, per = dist_mod.shard_batch(n, rank, world)
+        pick = list(range(lo, hi)) + [min(lo, n - 1)] * (per - (hi - lo))      # (a short shard is padded with a repeated image)
+        start_nn = time.perf_counter()
+        local = image_batch[torch.as_tensor(pick, dtype=torch.long, device=image_batch.device)]
+        with torch.no_grad():
+            if device is not None:
+                local = local.to(device, non_blocking=True)
+            heads = model(local)
+        if local.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        self.last_nn_time = time.perf_counter() - start_nn
+        start_decoder = time.perf_counter()
+        out, ids, counts = self.decode_heads(heads)
+        if (counts.cpu().numpy() & native.COUNT_FAILED).any() and self.cpp_decoder.pool_overflowed():
+            # an image of THIS shard ran out of its tile pool: decoded again here, before the collective (the other ranks wait in it)
+            for dec in [self.cpp_decoder]:
+                dec.use_full_pool()
+            out, ids, counts = self.decode_heads(heads)
+        if meta_batch is not None:
+            out = inverse_transform_batch(out, [meta_batch[i] for i in pick])
+        import torch.distributed as tdist
+        if tdist.get_backend(group) != 'nccl':       # (gloo: the CPU tests) host tensors through the collective
+            out, ids, counts = out.cpu(), ids.cpu(), counts.cpu()
+        out, ids, counts = dist_mod.gather_annotations(out, ids, counts, group=group)      # the ONE collective of the batch
+        out, ids, counts = dist_mod.merge_shards(out, ids, counts, n, world)
+        result = self._annotations_from_host(out.cpu().numpy(), ids.cpu().numpy(), counts.cpu().numpy())   # raises for a failed image of ANY rank
+        self.last_decoder_time = time.perf_counter() - start_decoder
+        return result
+
     def batch(self, model, image_batch, *, device=None, gt_anns_batch=None, meta_batch=None):
         """Image batch -> annotations batch, fields never leave the device.  With ``meta_batch`` (the metas of the
         preprocessing, no rotation) the annotations come back in ORIGINAL-image coordinates: the inverse transform
-        (reference ``annotation.py:162-200``) runs on the decoded tensor before its one small D2H copy."""
+        (reference ``annotation.py:162-200``) runs on the decoded tensor before its one small D2H copy.
+        Under ``torch.distributed`` (see :attr:`distributed`) the batch is sharded over the ranks."""
+        d = self._dist()
+        if d is not None:
+            return self._batch_sharded(model, image_batch, device, meta_batch, *d)
         start_nn = time.perf_counter()
         with torch.no_grad():
             if device is not None:
@@ -573,7 +627,11 @@ class Multi(Decoder):
 
     @property
     def pipeline_depth(self):
-        """Batches that may be in flight through :meth:`batch_async` (0: the decoder has no asynchronous path)."""
+        """Batches that may be in flight through :meth:`batch_async` (0: the decoder has no asynchronous path -- or the batch is
+        sharded over the ranks of a ``torch.distributed`` job: ``batch`` then ends in the job's one collective per batch, which every
+        rank has to enter in the same order)."""
+        if len(self.decoders) == 1 and getattr(self.decoders[0], '_dist', lambda: None)() is not None:
+            return 0
         if len(self.decoders) == 1 and hasattr(self.decoders[0], 'batch_async'):
             return max(1, int(self.decoders[0].decoder_workers or 1))
         return 0

@@ -37,9 +37,19 @@ def unpack_block(block, max_ann, n_keypoints):
     return annotations, ids, counts
 
 
-def gather_annotations(annotations, ids, counts, group=None):
+def active(group=None):
+    """-> (rank, world size) of an initialised process group with more than one rank, else None."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    world = dist.get_world_size(group)
+    return (dist.get_rank(group), world) if world > 1 else None
+
+
+def gather_annotations(annotations, ids, counts, group=None, force=False):
     """All-gather per-rank decode results in rank order with ONE collective per batch: counts,
-    annotations and ids are packed into one fixed-size int32 block per image.
+    annotations and ids are packed into one fixed-size int32 block per image.  ``force``: run the collective even in a
+    group of one rank (the GPU suite drives the RCCL branch that way on a single-GPU box).
 
     :param annotations: ``[B_local, max_ann, K, 4]`` float32
     :param ids: ``[B_local, max_ann]`` int64, :param counts: ``[B_local]`` int32
@@ -47,7 +57,7 @@ def gather_annotations(annotations, ids, counts, group=None):
               (every rank must contribute the same ``B_local``; pad the last shard).
     """
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return annotations, ids, counts
     world = dist.get_world_size(group)
     block = pack(annotations, ids, counts)
@@ -57,6 +67,25 @@ def gather_annotations(annotations, ids, counts, group=None):
     else:
         dist.all_gather(list(buf.unbind(0)), block, group=group)      # gloo (CPU tests)
     return unpack_block(buf.reshape(world * block.shape[0], block.shape[1]), annotations.shape[1], annotations.shape[2])
+
+
+def shard_batch(n_items, rank, world_size):
+    """The product path's split of a batch of ``n_items`` images (``decoder.CifCaf.batch`` under ``torch.distributed``):
+    -> (lo, hi, per): this rank decodes images [lo, hi), every rank contributes ``per`` = ceil(n / world) rows to the gather
+    (a shorter shard is padded: the collective wants equal blocks)."""
+    lo, hi = shard_bounds(n_items, rank, world_size)
+    return lo, hi, -(-n_items // world_size)
+
+
+def merge_shards(annotations, ids, counts, n_items, world_size):
+    """Gathered ``[world * per, ...]`` blocks -> the ``n_items`` rows of the global batch in image order (padding rows dropped)."""
+    per = -(-n_items // world_size)
+    keep = []
+    for r in range(world_size):
+        lo, hi = shard_bounds(n_items, r, world_size)
+        keep.extend(range(r * per, r * per + (hi - lo)))
+    idx = torch.as_tensor(keep, dtype=torch.long, device=annotations.device)
+    return annotations.index_select(0, idx), ids.index_select(0, idx), counts.index_select(0, idx)
 
 
 def unpack(annotations, ids, counts, max_annotations=None):

@@ -107,6 +107,31 @@ def conv1x1_bias_act(x, weight2d, bias, residual=None, relu=True, a_bias=None):
 # run use the same kernel), can be pinned with OPA_CONV1X1=gemm|conv, and can be exported / imported
 # (choices / set_choices; distributed.broadcast_conv_choices) so that every rank of a job runs the same kernels.
 _CHOICE = {}
+PINNED_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'conv1x1_pinned.json')
+
+
+def load_pinned(path=None):
+    """The table the package ships (``conv1x1_pinned.json``: measured on an MI355X by ``tools/gpu/dump_conv_choices.py`` for the
+    shapes of the BASELINE configurations, float32 and bfloat16): the same choice on every rank of a multi-GPU job WITHOUT a
+    collective (round 5 broadcast rank 0's wall-clock choices, ``distributed.broadcast_conv_choices``).  Loaded when this module
+    is imported; entries made later (``set_choices``, timing) go on top.  -> number of entries adopted."""
+    import json
+    try:
+        with open(path or PINNED_FILE) as f:
+            table = json.load(f)['table']
+    except (OSError, ValueError, KeyError):
+        return 0
+    for dtype, m, k, n, res, a_bias, choice in table:
+        _CHOICE.setdefault((dtype, int(m), int(k), int(n), bool(res), bool(a_bias)), choice)
+    return len(table)
+
+
+def _in_multi_rank_job():
+    try:
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    except Exception:              # noqa: BLE001
+        return False
 
 
 def choices():
@@ -154,6 +179,10 @@ def conv_bias_act(conv, x, bias, residual=None, relu=True, a_bias=None):
                 choice = _CHOICE[key] = forced
             elif torch.cuda.is_current_stream_capturing():
                 choice = _CHOICE[key] = 'gemm'   # no timing inside a capture; remembered, so eager runs agree with the graph
+            elif _in_multi_rank_job():
+                # a shape the shipped table does not know, in a job of several ranks: every rank takes the SAME default instead of
+                # timing (wall clocks differ from rank to rank, and the three paths round differently) -- no collective needed
+                choice = _CHOICE[key] = 'gemm'
         if choice is None:
             times = {'gemm': _time_ms(lambda: conv1x1_bias_act(x, w2d, bias, residual, relu, a_bias))}
             if a_bias is None:
@@ -254,3 +283,6 @@ def channel_interleave(a, b):
         B * H * W, half, _DTYPES[a.dtype], ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
         'opa_channel_interleave')
     return out
+
+
+load_pinned()

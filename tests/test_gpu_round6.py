@@ -154,3 +154,52 @@ def test_side_stream_and_list_set_passes_are_bit_identical(native, port, coco_sk
                 native.check_counts(counts)
                 for b in range(6):
                     assert np.array_equal(out[b, :native.count_rows(int(counts[b]))].cpu().numpy(), want[b]), (kw, debug, rep, b)
+
+
+def test_rccl_gather_branch_runs_on_one_gpu(coco_skeleton0, tmp_path):
+    """The job's one collective, ``dist.all_gather_into_tensor`` on DEVICE tensors through backend "nccl" (= RCCL), had never
+    run: no multi-GPU box, and a group of one rank returns early.  Here a process group of ONE rank is initialised with nccl and
+    the collective is forced (``gather_annotations(force=True)``): packed annotation blocks of a real decode go through RCCL and
+    come back bit for bit.  (In a process of its own: a process group is process-wide state.)"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'rccl_one_rank.py'
+    script.write_text(textwrap.dedent('''
+        import os, sys
+        sys.path.insert(0, %r)
+        import numpy as np, torch, torch.distributed as dist
+        from openpifpaf_amd import constants, distributed as D, native, synth
+        torch.cuda.set_device(0)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+        assert dist.get_world_size() == 1 and dist.get_backend() == 'nccl'
+        skel0 = np.asarray(constants.COCO_PERSON_SKELETON, dtype=np.int64) - 1
+        cifs, cafs = synth.synth_batch(5, seed0=63_000, height=41, width=49)
+        dec = native.CifCaf(17, torch.from_numpy(skel0))
+        out, ids, counts = dec.call_batch(torch.from_numpy(cifs).cuda(), 8, torch.from_numpy(cafs).cuda(), 8)
+        native.check_counts(counts)
+        calls = []
+        real = dist.all_gather_into_tensor
+        dist.all_gather_into_tensor = lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1]
+        a, i, c = D.gather_annotations(out, ids, counts, force=True)
+        dist.all_gather_into_tensor = real
+        torch.cuda.synchronize()
+        assert len(calls) == 1 and a.is_cuda
+        assert torch.equal(c, counts) and torch.equal(i, ids)
+        n = int(native.count_rows(int(counts.max())))
+        assert n > 0 and torch.equal(a[:, :n].view(torch.int32), out[:, :n].view(torch.int32))
+        a0, i0, c0 = D.gather_annotations(out, ids, counts)          # without force: a group of one rank is the identity
+        assert a0 is out and len(calls) == 1
+        per_image = D.unpack(a, i, c)
+        assert sum(len(p) for p, _ in per_image) == int(sum(native.count_rows(int(x)) for x in counts.cpu()))
+        dist.destroy_process_group()
+        print('RCCL_OK')
+    ''' % root))
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'RCCL_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
