@@ -577,7 +577,8 @@ int opa_cifcaf_decode(const opa_cifcaf* dec_in, const opa_shape* shape, const op
                         (unsigned long long*)(ws + L.off_seed_keys), L.sort_cap,
                         (int32_t*)(ws + L.off_seed_count), (int32_t*)(ws + L.off_seed_f),
                         (float*)(ws + L.off_seed_vxys), st, false, (int32_t*)(ws + L.off_seed_cell),
-                        L.occ_h, L.occ_w, true, fuse ? scored : nullptr, fuse ? n_scored : 0, &ties, &pool, &cand);   // :144-146
+                        L.occ_h, L.occ_w, true, fuse ? scored : nullptr, fuse ? n_scored : 0, &ties, &pool, &cand,
+                        dec->debug.stage_worklist != 0);                                              // :144-146
     if (e != hipSuccess) return fail_hip(e, "cifseeds");
     if (lists_on_side) {
         e = hipStreamWaitEvent(st, side.join, 0);

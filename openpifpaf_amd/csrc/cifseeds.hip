@@ -407,8 +407,91 @@ __device__ __forceinline__ void cifseeds_sort_body(const SortArgs& g, const DevP
         store_seed(in_lds ? sk[t] : K[t], t, b, cif, F, NC, HW, stride, cap, seed_f, seed_vxys, seed_cell, occ_h, occ_w, p);
 }
 
-__global__ __launch_bounds__(1024) void cifseeds_sort_kernel(SortArgs g, DevParams p) {
+// ---- round 6: the 2048-key blocks in REGISTERS.  Round 3's network keeps the keys in LDS: 66 passes of one compare-exchange per
+// thread, every pass an LDS round trip (four 8-byte accesses per lane, bank conflicts measured at 89 % of the LDS cycles) and a
+// barrier or wave fence -- 25 us for a block that holds 16 KB.  Here a block is 256 threads x 8 keys: position p = 8 t + r, so
+//   strides 1, 2, 4          exchange two registers of one thread            (30 of the 66 passes)
+//   strides 8 ... 256        exchange with lane ^ (stride / 8): ds_bpermute  (33 passes; no memory, no bank conflicts)
+//   strides 512, 1024        exchange with another wave: through LDS, SoA [r][t] (3 passes, 2 barriers each)
+// The order is the same total order (score descending, then cell index ascending), so the result does not depend on the network.
+// Blocks of images with more than 8192 seeds (wholebody) stay with the kernel below (8192-key blocks).
+constexpr int kSort2kThreads = 256, kSort2kKeys = 8;
+static_assert(kSort2kThreads * kSort2kKeys == kSortSmallBlock, "one block = 256 threads x 8 keys");
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int mask) {
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, mask, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), mask, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(kSort2kThreads) void cifseeds_sort2k_kernel(SortArgs g, DevParams p) {
+    __shared__ unsigned long long xs[kSort2kKeys][kSort2kThreads];   // 16 KB: the cross-wave exchanges
+    const int b = blockIdx.x / 4, part = blockIdx.x & 3, t = threadIdx.x;
+    int n = g.seed_count[b];
+    if (n > g.cap) n = g.cap;
+    if (n > 4 * kSortSmallBlock || part * kSortSmallBlock >= n) return;   // (more than 8192 seeds: the 8192-key blocks of the kernel below)
+    const bool single = n <= kSortSmallBlock;         // one block: sorted and decoded here; else the rank merge kernel places the keys
+    unsigned long long* K = g.keys + (size_t)b * g.sort_cap;
+    const int blk = part * kSortSmallBlock;
+    unsigned long long key[kSort2kKeys];
+#pragma unroll
+    for (int r = 0; r < kSort2kKeys; r++) { const int i = blk + t * kSort2kKeys + r; key[r] = i < n ? K[i] : 0ull; }
+    auto cx = [](unsigned long long& lo, unsigned long long& hi, bool desc) {     // positions lo < hi: descending = the larger key first
+        const bool swap = (lo < hi) == desc;          // (one 64-bit compare per exchange; equal keys are padding: either way)
+        const unsigned long long a = lo, c = hi;
+        lo = swap ? c : a; hi = swap ? a : c;
+    };
+#pragma unroll
+    for (int k = 2; k <= kSortSmallBlock; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 512) {                           // another wave's keys: through LDS
+#pragma unroll
+                for (int r = 0; r < kSort2kKeys; r++) xs[r][t] = key[r];
+                __syncthreads();
+                const int pt = t ^ (j >> 3);
+                const bool lower = (t & (j >> 3)) == 0, desc = ((t * kSort2kKeys) & k) == 0;
+                const bool take_max = lower == desc;
+#pragma unroll
+                for (int r = 0; r < kSort2kKeys; r++) {
+                    const unsigned long long o = xs[r][pt];
+                    key[r] = ((o > key[r]) == take_max) ? o : key[r];
+                }
+                __syncthreads();
+            } else if (j >= kSort2kKeys) {            // another lane's keys
+                const int m = j >> 3;
+                const bool lower = (t & m) == 0, desc = ((t * kSort2kKeys) & k) == 0;
+                const bool take_max = lower == desc;
+                unsigned long long o[kSort2kKeys];
+#pragma unroll
+                for (int r = 0; r < kSort2kKeys; r++) o[r] = shfl_xor_u64(key[r], m);      // sixteen ds_bpermute in flight
+#pragma unroll
+                for (int r = 0; r < kSort2kKeys; r++) key[r] = ((o[r] > key[r]) == take_max) ? o[r] : key[r];
+            } else {                                  // two registers of this thread
+#pragma unroll
+                for (int r = 0; r < kSort2kKeys; r++)
+                    if ((r & j) == 0) cx(key[r], key[r | j], ((t * kSort2kKeys + r) & k) == 0);
+            }
+        }
+    }
+    if (single) {                                     // epilogue: decode keys -> sorted seeds (cif_seeds.cpp:100-113)
+#pragma unroll
+        for (int r = 0; r < kSort2kKeys; r++) {
+            const int pos = t * kSort2kKeys + r;
+            if (pos < n) store_seed(key[r], pos, b, g.cif, g.F, g.NC, g.HW, g.stride, g.cap, g.seed_f, g.seed_vxys, g.seed_cell, g.occ_h, g.occ_w, p);
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < kSort2kKeys; r++) K[blk + t * kSort2kKeys + r] = key[r];
+    }
+}
+
+__global__ __launch_bounds__(1024) void cifseeds_sort_kernel(SortArgs g, DevParams p, int only_large) {
     __shared__ unsigned long long sk[kSortLdsKeys];
+    if (only_large) {                                 // (images of up to 8192 seeds were sorted by cifseeds_sort2k_kernel)
+        int n = g.seed_count[blockIdx.x / kSortBlocksMax];
+        if (n > g.cap) n = g.cap;
+        if (n <= 4 * kSortSmallBlock) return;
+    }
     cifseeds_sort_body(g, p, blockIdx.x, sk);
 }
 
@@ -463,6 +546,10 @@ __global__ __launch_bounds__(256) void cifseeds_rankmerge_kernel(
     store_seed(key, pos, b, cif, F, NC, HW, stride, cap, seed_f, seed_vxys, seed_cell, occ_h, occ_w, p);
 }
 
+// (Round 6 also built the rank merge with the other blocks in LDS -- one workgroup per block, eight keys per thread searched in
+// lockstep, branch-free: 71 us for 256 images against this kernel's 47.5, 15.5 against 14 for 32: one key per thread and thousands of
+// threads hide the L2 round trips better than 48 KB of LDS per workgroup allow; removed.)
+
 // ------------------------------------------------------------------ the reference's order of EQUAL scores: cifseeds_tie.hpp
 size_t tie_big_bytes(int cells) { return 4 * (size_t)cells * sizeof(unsigned); }
 
@@ -504,7 +591,8 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
                            unsigned long long* keys, int sort_cap, int32_t* seed_count,
                            int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det,
                            int32_t* seed_cell, int occ_h, int occ_w, bool count_is_zero,
-                           const ScoredArgs* scored, int n_scored, const TieScratch* ties, const HrPool* pool, const SeedCandidates* cand) {
+                           const ScoredArgs* scored, int n_scored, const TieScratch* ties, const HrPool* pool, const SeedCandidates* cand,
+                           bool sort_registers) {
     static_assert(kScoredThreads == 512, "the fused launch packs two cafscored groups into a 1024-thread workgroup");
     const int HW = H * W, cap = F * HW, NC = det ? 6 : 5;
     if (!count_is_zero) {                             // (the decode pipeline clears the counters in its first kernel)
@@ -546,8 +634,11 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
         const int nb_max = s0.nb > s1.nb || n_scored < 2 ? s0.nb : s1.nb;
         const size_t lds = sizeof(float) * 2 * 2 * nb_max * 4;
         cifseeds_sort_scored_kernel<<<n_sort + wgs0 + wgs1, 1024, lds, st>>>(g, p, n_sort, s0, s1, wgs0);
+    } else if (sort_registers) {
+        cifseeds_sort2k_kernel<<<B * 4, kSort2kThreads, 0, st>>>(g, p);
+        if (cap > 4 * kSortSmallBlock) cifseeds_sort_kernel<<<n_sort, 1024, 0, st>>>(g, p, 1);
     } else {
-        cifseeds_sort_kernel<<<n_sort, 1024, 0, st>>>(g, p);
+        cifseeds_sort_kernel<<<n_sort, 1024, 0, st>>>(g, p, 0);
     }
     if (cap > kSortSmallBlock) {                      // images of more than one block of seeds are possible
         const int most = cap < kSortBlocksMax * kSortLdsKeys ? cap : kSortBlocksMax * kSortLdsKeys;

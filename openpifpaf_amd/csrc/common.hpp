@@ -132,7 +132,7 @@ hipError_t launch_cifseeds(const float* cif, int B, int F, int H, int W, int str
                            int32_t* seed_f, float* seed_vxys, hipStream_t st, bool det = false,
                            int32_t* seed_cell = nullptr, int occ_h = 0, int occ_w = 0, bool count_is_zero = false,
                            const ScoredArgs* scored = nullptr, int n_scored = 0, const TieScratch* ties = nullptr,
-                           const HrPool* pool = nullptr, const SeedCandidates* cand = nullptr);
+                           const HrPool* pool = nullptr, const SeedCandidates* cand = nullptr, bool sort_registers = true);
 // (`scored`: up to two CafScored list sets built by the SAME launch as the seed sort -- they only share the finished
 // map, and the sort's few workgroups leave the chip to them)
 
