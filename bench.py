@@ -66,7 +66,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 achievable
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}     # dense matrix peaks, MI355X_MICROARCH.md
 TORCH_DTYPE = {'bf16': torch.bfloat16, 'fp16': torch.float16, 'fp32': torch.float32}
-PMC_ROUNDS = ('r5', 'r4', 'r3')
+PMC_ROUNDS = ('r6', 'r5', 'r4', 'r3')
 VARIANT_SEED = 100_000   # field batch v of rank r is synth_batch(B, seed0 = v * VARIANT_SEED + r * B)
 TOL = 1e-4               # BASELINE.json north_star: keypoint coordinates / scores within 1e-4
 

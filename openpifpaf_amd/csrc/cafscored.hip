@@ -22,9 +22,15 @@ namespace opa {
 #define OPA_SCORED_MIN_WAVES 2
 #endif
 __global__ __launch_bounds__(kScoredThreads, OPA_SCORED_MIN_WAVES) void cafscored_kernel(ScoredArgs s) {
+#ifdef OPA_SCORED_SINGLE_TEMPLATE                     // experiment: the two-set routine (cells per thread, prefetch) for the single set too
+    __shared__ int wave_tot[2][kScoredCells][kScoredThreads / 64];
+    extern __shared__ float bb[];
+    cafscored_plane2<false>(s, s, blockIdx.x, threadIdx.x, wave_tot, bb);
+#else
     __shared__ int wave_tot[2][kScoredThreads / 64];
     extern __shared__ float bb[];
     cafscored_plane(s, blockIdx.x, threadIdx.x, wave_tot, bb);
+#endif
 }
 
 // both list sets of a force-complete decode from ONE read of the field (cafscored_impl.hpp)

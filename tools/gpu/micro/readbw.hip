@@ -4,6 +4,7 @@
 // hipcc --offload-arch=gfx950 -O3 -o readbw readbw.hip && ./readbw
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
@@ -55,9 +56,11 @@ __global__ __launch_bounds__(512) void read_planes(const float* __restrict__ p, 
     if (acc == 123.456f) out[0] = acc;
 }
 
-int main() {
-    const size_t planes = 256 * 19, HW = 6561;
-    const size_t n = planes * 8 * HW;                 // the CAF tensor of 256 COCO images: 1.02 GB
+int main(int argc, char** argv) {
+    const size_t images = argc > 1 ? (size_t)atoi(argv[1]) : 256;      // 32: the field of one bench batch (112 MB: inside the Infinity Cache)
+    const size_t planes = images * 19, HW = 6561;
+    const size_t n = planes * 8 * HW;                 // the CAF tensor of `images` COCO images (256: 1.02 GB)
+    printf("buffer %.1f MB (%zu images)\n", n * 4 / 1e6, images);
     float *p, *out;
     CK(hipMalloc(&p, n * sizeof(float))); CK(hipMalloc(&out, 256));
     CK(hipMemset(p, 0, n * sizeof(float)));

@@ -13,7 +13,20 @@ import numpy as np
 import torch
 
 from openpifpaf_amd import _lib, constants, native, synth
-from oracle import port
+from oracle import port, reference
+
+# round 6: against the REAL reference (oracle/_ref, the reference's own csrc compiled by oracle/build_ref.py: it travels to the GPU
+# box with the snapshot) wherever the option set can be pushed into its statics; the restatement (pinned bit-equal to it on the
+# CPU, tests/test_oracle_vs_reference.py) for the options that are constructor constants there
+USE_REF = reference.available()
+REF_FIELDS = {'greedy', 'reverse_match', 'keypoint_threshold', 'keypoint_threshold_rel', 'force_complete', 'force_complete_caf_th',
+              'cif_threshold', 'seed_threshold', 'caf_threshold', 'ablation_cifseeds_no_rescore', 'ablation_caf_no_rescore',
+              'ablation_cifseeds_nms', 'ablation_cifhr_skip', 'nms_suppression', 'nms_instance_threshold', 'nms_keypoint_threshold',
+              'cifhr_neighbors', 'block_joints'}
+if USE_REF:
+    reference.load().set_num_threads(1)
+    reference.reset_statics()
+n_ref = n_port = 0
 
 n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -74,10 +87,20 @@ for batch_i in range(n_batches):
         out, cnt = out.cpu().numpy(), cnt.cpu().numpy()
         dec.cifhr_pool_tiles = 0                      # (back to the automatic pool for the next shapes)
     native.check_counts(cnt)
+    by_ref = USE_REF and set(kw) <= REF_FIELDS
+    if by_ref:
+        reference.apply_params(port.default_params(**kw))
     for b in range(B):
-        want, _ = port.decode(cifs[b], stride, cafs[b], stride, skel0, params=port.default_params(**kw),
-                              n_keypoints=K, initial_annotations=inits[b] if n_init else None,
-                              initial_ids=init_ids[b] if n_init else None)
+        if by_ref:
+            want = reference.decode(cifs[b], stride, cafs[b], stride, skel0, n_keypoints=K,
+                                    initial_annotations=inits[b] if n_init else None,
+                                    initial_ids=init_ids[b] if n_init else None)[0]
+            n_ref += 1
+        else:
+            want, _ = port.decode(cifs[b], stride, cafs[b], stride, skel0, params=port.default_params(**kw),
+                                  n_keypoints=K, initial_annotations=inits[b] if n_init else None,
+                                  initial_ids=init_ids[b] if n_init else None)
+            n_port += 1
         n = int(cnt[b])
         if n & native.COUNT_OVERFLOW:          # capacity overflow is flagged, not compared
             assert len(want) > native.count_rows(n)
@@ -92,5 +115,8 @@ for batch_i in range(n_batches):
         worst = max(worst, err)
         n_images += 1
         n_poses += n
+    if by_ref:
+        reference.reset_statics()
 print('parity sweep (' + mode + ') ok: %d launches, %d images, %d poses, worst |delta| %.3g, %.1f s; %d launches repeated with a full '
-      'tile pool after a flagged overflow' % (n_batches, n_images, n_poses, worst, time.time() - t0, n_overflows))
+      'tile pool after a flagged overflow; %d images against the reference itself (oracle/_ref), %d against the restatement' % (
+          n_batches, n_images, n_poses, worst, time.time() - t0, n_overflows, n_ref, n_port))

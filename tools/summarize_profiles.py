@@ -19,10 +19,12 @@ root = sys.argv[1]
 WORKLOADS = [('config2', 'COCO-17 (configs 2 / 3 fields), batch 32, default flags', 2, 32, False),
              ('config2_fc', 'COCO-17, batch 32, the reference benchmark\'s force-complete setting', 2, 32, True),
              ('config4', 'wholebody 133 keypoints / 160 bones (config 4), batch 16, default flags', 4, 16, False),
-             ('config4_fc', 'wholebody, batch 16, force complete', 4, 16, True)]
-DECODE_KERNELS = ('cif_active_kernel', 'cifhr_tile_kernel', 'tile_state_roll_kernel', 'cifseeds_fill_kernel',
-                  'cifseeds_sort_kernel', 'cifseeds_sort_scored_kernel', 'cifseeds_rankmerge_kernel', 'cifseeds_tie_kernel', 'cafscored_kernel', 'cifcaf_assoc_kernel',
-                  'cifcaf_fc_kernel')
+             ('config4_fc', 'wholebody, batch 16, force complete', 4, 16, True),
+             ('config2_b256', 'COCO-17, 256 images in ONE call_batch (round 6)', 2, 256, False)]
+DECODE_KERNELS = ('zero_kernel', 'cif_active_kernel', 'cifhr_tile_kernel', 'cifhr_worktile_kernel', 'tile_state_roll_kernel',
+                  'cifseeds_fill_kernel', 'cifseeds_fill_cand_kernel', 'cifseeds_sort2k_kernel', 'cifseeds_sort_kernel',
+                  'cifseeds_sort_scored_kernel', 'cifseeds_rankmerge_kernel', 'cifseeds_tie_kernel', 'cafscored_kernel',
+                  'cafscored2_kernel', 'assoc_order_kernel', 'cifcaf_assoc_kernel', 'cifcaf_fc_kernel')
 
 
 def find(sub, pattern):
@@ -121,7 +123,7 @@ def pmc_per_decode(sub, counter, last_calls=4):
 
 
 ONLY_STEPS = '--only-steps' in sys.argv
-print('# rocprofv3 summary (round %s)%s\n' % (os.environ.get('ROUND', 'r4').lstrip('r'), ': one steady-state step of bench.py' if ONLY_STEPS else ''))
+print('# rocprofv3 summary (round %s)%s\n' % (os.environ.get('ROUND', 'r6').lstrip('r'), ': one steady-state step of bench.py' if ONLY_STEPS else ''))
 print('Commands: tools/collect_profiles.sh (every pass: `rocprofv3 ... -- python tools/gpu/r3_probe.py --config ... --alternate`,'
       ' i.e. two different field batches decoded in turn; counters in their own passes with --kernel-trace only).\n')
 steady_state_step('bench', 'bench.py headline leg (float32 network + decode): ONE steady-state step, batch 32')
