@@ -392,7 +392,11 @@ def test_seed_tie_order_setting_and_workspace_view():
         assert off.value + size.value <= total
         end_trace = ctypes.c_size_t()
         assert L.opa_cifcaf_workspace_view(ctypes.byref(shape), b'assoc_trace', ctypes.byref(end_trace), ctypes.byref(size)) == 0
-        assert off.value == end_trace.value + size.value                       # right behind the trace: nothing else was added
+        queue, qsize = ctypes.c_size_t(), ctypes.c_size_t()                    # [r6] the association kernel's image queue: B + 1 words
+        assert L.opa_cifcaf_workspace_view(ctypes.byref(shape), b'assoc_queue', ctypes.byref(queue), ctypes.byref(qsize)) == 0
+        assert queue.value == end_trace.value + size.value                     # right behind the trace ...
+        assert 4 * (shape.batch + 1) <= qsize.value < 4 * (shape.batch + 1) + 256
+        assert off.value == queue.value + qsize.value                          # ... and the per-image state words right behind the queue
         assert total - (off.value + 4 * shape.batch) < 512                      # (alignment only)
     # the stage-level entry point asks for its scratch: keys + the tie pass's arrays
     cells = 17 * 81 * 81
