@@ -389,6 +389,18 @@ int opa_gemm_bias_act_f32(const float* a_dev, const float* a_bias_dev, const flo
                           const float* residual_dev, float* out_dev, int64_t m, int32_t n, int32_t k,
                           int32_t relu, void* stream);
 
+/* 3x3 convolution, stride 1, padding 1, of an NHWC float32 activation as Winograd F(2x2, 3x3) in ONE kernel (input
+ * transform -> sixteen float32 MFMA GEMMs -> output transform; csrc/winograd.hip): the bottleneck convolutions of the
+ * ResNet trunk (reference network/basenetworks.py:71-150 runs them through torch.nn.Conv2d), 2.25x fewer multiplications
+ * than the direct form, float32 arithmetic throughout.
+ *  x_dev [B, h, w, c_in], u_dev = the filter transformed and laid out by openpifpaf_amd.winograd.transform_filter for
+ *  `variant` (0: 64 output channels per workgroup, c_in % 16 == 0, c_out % 64 == 0; 1: 32 channels, c_in % 8 == 0,
+ *  c_out % 32 == 0), out_dev [B, h, w, c_out]; bias_dev [c_out] or NULL; relu 0/1; order 0 = workgroups of one tile block
+ *  on one XCD, 1 = workgroups of one channel block on one XCD.  B*h*w*c_in < 2^32; pointers 16-B aligned. */
+int opa_conv3x3_winograd_f32(const float* x_dev, const float* u_dev, const float* bias_dev, float* out_dev, int32_t batch,
+                             int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t relu, int32_t variant,
+                             int32_t order, void* stream);
+
 /* Depthwise k x k convolution (k = 3 or 5, stride 1 or 2, padding k/2) of a channels-last activation, with the
  * folded batch-norm bias and optionally ReLU fused (the ShuffleNetV2K unit of the reference,
  * network/basenetworks.py:186-268; MIOpen runs it as a grouped MFMA convolution, ~100x slower).

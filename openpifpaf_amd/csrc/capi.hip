@@ -918,6 +918,24 @@ int opa_gemm_bias_act_f32(const float* a_dev, const float* a_bias_dev, const flo
     return OPA_OK;
 }
 
+int opa_conv3x3_winograd_f32(const float* x_dev, const float* u_dev, const float* bias_dev, float* out_dev, int32_t batch,
+                             int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t relu, int32_t variant,
+                             int32_t order, void* stream) {
+    if (!x_dev || !u_dev || !out_dev || batch <= 0 || h <= 0 || w <= 0 || c_in <= 0 || c_out <= 0 || (variant != 0 && variant != 1))
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_conv3x3_winograd_f32: bad arguments");
+    if (variant == 0 ? (c_in % 16 != 0 || c_out % 64 != 0) : (c_in % 8 != 0 || c_out % 32 != 0))
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_conv3x3_winograd_f32: channel counts do not fit the variant's tiles");
+    if ((double)batch * h * w * c_in >= 4294967296.0 || (double)batch * ((h + 1) / 2) * ((w + 1) / 2) >= 2147483647.0)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_conv3x3_winograd_f32: the activation needs 32-bit element offsets");
+    if (((uintptr_t)x_dev | (uintptr_t)u_dev | (uintptr_t)out_dev | (uintptr_t)bias_dev) & 15)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_conv3x3_winograd_f32: pointers must be 16-B aligned");
+    hipError_t e = launch_winograd_f23(x_dev, u_dev, out_dev, bias_dev, batch, h, w, c_in, c_out, relu, variant, order,
+                                       (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "winograd_f23");
+    prof_mark((hipStream_t)stream, "winograd_f23_kernel");
+    return OPA_OK;
+}
+
 int opa_dwconv_bias_act(const void* x_dev, int64_t x_pixel_stride, const void* w_dev, const void* bias_dev,
                         void* out_dev, int64_t out_pixel_stride, int32_t batch, int32_t h, int32_t w,
                         int32_t channels, int32_t k, int32_t stride, int32_t dtype, int32_t relu, void* stream) {

@@ -257,6 +257,8 @@ hipError_t launch_gemm_bias_act(const void* A, const void* W, const void* bias, 
 
 hipError_t launch_gemm_f32_bias_act(const float* A, const float* W, const float* bias, const float* res, float* out,
                                     int M, int N, int K, int relu, hipStream_t st, const float* a_bias = nullptr);
+hipError_t launch_winograd_f23(const float* x, const float* U, float* y, const float* bias, int N, int H, int W, int Cin,
+                               int Cout, int relu, int variant, int nb_major, hipStream_t st);
 
 hipError_t launch_dwconv(const void* x, long long xs, const void* w, const void* bias, void* out, long long os,
                          int B, int H, int W, int C, int K, int S, int dtype, int relu, hipStream_t st);

@@ -1,0 +1,269 @@
+// 3x3 stride-1 convolution of the float32 network as Winograd F(2x2, 3x3), ONE kernel: input transform -> sixteen
+// MFMA GEMMs -> output transform, nothing of the transformed domain ever leaves the compute unit.
+//     y[n, h, w, :] = sum_{r,s} x[n, h + r - 1, w + s - 1, :] * g[:, :, r, s]^T        (NHWC float32, zero padding 1)
+// The ResNet-50 trunk at 641 px / batch 32 spends 39 of its 75 ms in thirteen such convolutions (250 GFLOP each as a direct
+// convolution, CK's implicit GEMM at 112 TFLOP/s = 0.71 of the dense float32 MFMA peak: there is no TF32 on gfx950, the
+// float32 MFMA runs at the vector rate).  F(2x2, 3x3) needs 16 multiplications per 2x2 outputs instead of 36: 2.25x fewer
+// MFMA flops, in float32 arithmetic throughout (the transforms are additions; G g G^T is computed once on the host in
+// float64).  Separate transform kernels would write and re-read the 4x larger transformed tensors (15 GB per layer-1
+// convolution) -- so one workgroup does all of it for 64 tiles x BN output channels:
+//   * 256 threads, four waves, wave w owns the four transform positions (xi = w, nu = 0..3) as 64 x BN accumulators each:
+//     v_mfma_f32_32x32x2f32, 4 x 2 x NB accumulator blocks of 16 registers (NB = 2: 256 accumulator registers, one wave per
+//     SIMD -- the float32 MFMA issues once per 64 cycles, one wave's other instructions fit into its shadow);
+//   * per K-chunk of KC input channels: thread (tile, channel group) loads its tile's 4x4 pixels (KC/4 channels each) from
+//     global memory one chunk AHEAD, transforms them in registers (B^T d B: 32 additions per channel) and stores the sixteen
+//     positions into the other LDS buffer as V[position][k][tile] (pitch 66 / 68: conflict-free for the thread map of the
+//     stores AND the MFMA operand reads); one barrier per chunk;
+//   * the filter operand U[position][k][cout] is used by exactly one wave (the owner of the position), so it does not go
+//     through LDS at all: the host lays it out so that a lane's values of a chunk are float4-contiguous, and every register
+//     group is reloaded for the next chunk right after its last MFMA of this one;
+//   * output transform: A^T m A splits into the nu-sum (inside the owning wave, registers) and the xi-sum across the four
+//     waves through LDS (the staging buffers, reused), then bias / ReLU if asked and 256-B contiguous stores.
+#include "common.hpp"
+
+namespace opa {
+
+typedef __attribute__((ext_vector_type(16))) float wf32x16_t;
+typedef __attribute__((ext_vector_type(4))) float wf32x4_t;
+
+template <int KC, int NB>
+struct WinoCfg {
+    static constexpr int VW = KC / 4;                  // channels per thread and pixel (float2 / float4 loads)
+    static constexpr int P = VW == 4 ? 66 : 68;        // floats between two k rows of the LDS operand (64 tiles + pad)
+    static constexpr int ROWS = 16 * KC;
+    static constexpr int VBUF = ROWS * P;              // floats per stage
+    static constexpr int BN = 32 * NB;                 // output channels per workgroup
+    static constexpr int KQ = KC / 8;                  // float4 groups of k pairs per chunk
+    static constexpr int STAGE_BYTES = 2 * VBUF * 4;
+    static constexpr int EPI_BYTES = 4 * 2 * 64 * BN * 4;
+    static constexpr int LDS_BYTES = STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES;
+};
+
+template <int KC, int NB, int WGS>
+__global__ __launch_bounds__(256, WGS) void winograd_f23_kernel(
+        const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ y, const float* __restrict__ bias,
+        int H, int W, int Cin, int Cout, int TH, int TW, int T, int relu, int nb_major) {
+    using C = WinoCfg<KC, NB>;
+    constexpr int VW = C::VW, P = C::P, BN = C::BN, KQ = C::KQ;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wino_smem[];
+    float* const lds = reinterpret_cast<float*>(wino_smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_nb = Cout / BN;
+    // XCD-aware order (gemm_f32.hip): consecutive logical workgroups run on ONE XCD and share its L2
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3;
+    const unsigned q8 = nwg >> 3, r8 = nwg & 7u;
+    const unsigned logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + in_xcd;
+    const unsigned n_tb = nwg / (unsigned)n_nb;
+    const int tb = nb_major ? (int)(logical % n_tb) : (int)(logical / (unsigned)n_nb);
+    const int nb = nb_major ? (int)(logical / n_tb) : (int)(logical % (unsigned)n_nb);
+    const int nchunks = Cin / KC;
+
+    // ---- the staging thread's tile: pixel offsets (clamped into the image) and validity, once
+    const int tile_l = tid >> 2, cg = tid & 3;
+    int t = tb * 64 + tile_l;
+    if (t > T - 1) t = T - 1;
+    const int tx = t % TW, ty = (t / TW) % TH, n = t / (TW * TH);
+    unsigned rowoff[4], coloff[4];
+    bool rv[4], cv[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = 2 * ty - 1 + i, c = 2 * tx - 1 + i;
+        rv[i] = r >= 0 && r < H;
+        cv[i] = c >= 0 && c < W;
+        const int rc = r < 0 ? 0 : (r > H - 1 ? H - 1 : r), cc = c < 0 ? 0 : (c > W - 1 ? W - 1 : c);
+        rowoff[i] = (unsigned)((n * H + rc) * W) * (unsigned)Cin;
+        coloff[i] = (unsigned)cc * (unsigned)Cin + (unsigned)(cg * VW);
+    }
+    float d[16][VW];
+    auto fetch_x = [&](int chunk) {
+        const unsigned c0 = (unsigned)(chunk * KC);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float* p = x + (size_t)(rowoff[i] + coloff[j] + c0);
+                if (VW == 4) {
+                    const wf32x4_t v = *reinterpret_cast<const wf32x4_t*>(p);
+#pragma unroll
+                    for (int e = 0; e < VW; e++) d[i * 4 + j][e] = v[e];
+                } else {
+                    const float2 v = *reinterpret_cast<const float2*>(p);
+                    d[i * 4 + j][0] = v.x; d[i * 4 + j][VW - 1] = v.y;
+                }
+            }
+    };
+    // B^T d B in registers, then the sixteen positions of this thread's VW channels to stage `buf`
+    auto transform_store = [&](int buf) {
+        float* const vb = lds + buf * C::VBUF + (cg * VW) * P + tile_l;
+#pragma unroll
+        for (int e = 0; e < VW; e++) {
+            float z[16];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) z[i * 4 + j] = (rv[i] && cv[j]) ? d[i * 4 + j][e] : 0.0f;
+            float s[16];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                s[0 * 4 + j] = z[0 * 4 + j] - z[2 * 4 + j];
+                s[1 * 4 + j] = z[1 * 4 + j] + z[2 * 4 + j];
+                s[2 * 4 + j] = z[2 * 4 + j] - z[1 * 4 + j];
+                s[3 * 4 + j] = z[1 * 4 + j] - z[3 * 4 + j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                vb[((i * 4 + 0) * KC + e) * P] = s[i * 4 + 0] - s[i * 4 + 2];
+                vb[((i * 4 + 1) * KC + e) * P] = s[i * 4 + 1] + s[i * 4 + 2];
+                vb[((i * 4 + 2) * KC + e) * P] = s[i * 4 + 2] - s[i * 4 + 1];
+                vb[((i * 4 + 3) * KC + e) * P] = s[i * 4 + 1] - s[i * 4 + 3];
+            }
+        }
+    };
+
+    // ---- the filter operand of this wave: U laid out [nb][chunk][position][j][kq][lane] float4 (winograd.py)
+    wf32x4_t ub[4][KQ][NB];
+    const wf32x4_t* const ubase = reinterpret_cast<const wf32x4_t*>(U) + (size_t)nb * nchunks * (16 * NB * KQ * 64) + lane;
+    auto u_ptr = [&](int chunk, int pl, int kq, int j) {
+        return ubase + ((size_t)((chunk * 16 + wave * 4 + pl) * NB + j) * KQ + kq) * 64;
+    };
+
+    wf32x16_t acc[4][2][NB];
+#pragma unroll
+    for (int pl = 0; pl < 4; pl++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < NB; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[pl][i][j][r] = 0.0f;
+
+    fetch_x(0);
+#pragma unroll
+    for (int pl = 0; pl < 4; pl++)
+#pragma unroll
+        for (int kq = 0; kq < KQ; kq++)
+#pragma unroll
+            for (int j = 0; j < NB; j++) ub[pl][kq][j] = *u_ptr(0, pl, kq, j);
+    transform_store(0);
+    __syncthreads();
+
+    const int a_lane = (lane >> 5) * P + (lane & 31);
+    // the sixteen GEMM steps of one chunk for this wave's four positions; every filter register group is reloaded for chunk
+    // `nxt` right behind its last use (nxt < 0: the last chunk, nothing to reload)
+    auto mfma_phase = [&](int chunk, int nxt) {
+        const float* const vb = lds + (chunk & 1) * C::VBUF + a_lane;
+#pragma unroll
+        for (int pl = 0; pl < 4; pl++) {
+            const float* const vp = vb + ((wave * 4 + pl) * KC) * P;
+#pragma unroll
+            for (int kq = 0; kq < KQ; kq++) {
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const int kp = kq * 4 + m;
+                    const float a0 = vp[(2 * kp) * P], a1 = vp[(2 * kp) * P + 32];
+#pragma unroll
+                    for (int j = 0; j < NB; j++) {
+                        acc[pl][0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ub[pl][kq][j][m], acc[pl][0][j], 0, 0, 0);
+                        acc[pl][1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, ub[pl][kq][j][m], acc[pl][1][j], 0, 0, 0);
+                    }
+                }
+                if (nxt >= 0) {
+#pragma unroll
+                    for (int j = 0; j < NB; j++) ub[pl][kq][j] = *u_ptr(nxt, pl, kq, j);
+                }
+            }
+        }
+    };
+    // (the last chunk is peeled off: with `if (more)` around the transform the optimiser sinks the loads of fetch_x into that
+    // block, i.e. behind the MFMA phase, and the memory latency of every chunk is exposed)
+    for (int chunk = 0; chunk + 1 < nchunks; chunk++) {
+        fetch_x(chunk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_phase(chunk, chunk + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        transform_store((chunk + 1) & 1);
+        __syncthreads();
+    }
+    mfma_phase(nchunks - 1, -1);
+    __syncthreads();
+
+    // ---- output transform.  nu-sum in registers: P0 = m0 + m1 + m2, P1 = m1 - m2 - m3 (A^T = [1 1 1 0; 0 1 -1 -1])
+    float* const sw = lds + wave * (2 * 64 * BN);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < NB; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int tile = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = j * 32 + (lane & 31);
+                const float m0 = acc[0][i][j][r], m1 = acc[1][i][j][r], m2 = acc[2][i][j][r], m3 = acc[3][i][j][r];
+                sw[tile * BN + col] = (m0 + m1) + m2;
+                sw[64 * BN + tile * BN + col] = (m1 - m2) - m3;
+            }
+    __syncthreads();
+    // xi-sum across the waves: Y[0][.] = P(0) + P(1) + P(2), Y[1][.] = P(1) - P(2) - P(3); item = (tile, 4 channels)
+    constexpr int V4 = BN / 4;
+#pragma unroll
+    for (int it = 0; it < 64 * V4 / 256; it++) {
+        const int item = it * 256 + tid;
+        const int tile = item / V4, c4 = (item % V4) * 4;
+        const int tt = tb * 64 + tile;
+        if (tt >= T) continue;
+        const int ox = tt % TW, oy = (tt / TW) % TH, on = tt / (TW * TH);
+        wf32x4_t pq[4][2];
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++)
+                pq[w][jj] = *reinterpret_cast<const wf32x4_t*>(lds + (w * 2 + jj) * (64 * BN) + tile * BN + c4);
+        wf32x4_t bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias) bv = *reinterpret_cast<const wf32x4_t*>(bias + nb * BN + c4);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int oh = 2 * oy + i;
+            if (oh >= H) continue;
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const int ow = 2 * ox + jj;
+                if (ow >= W) continue;
+                wf32x4_t v = i == 0 ? (pq[0][jj] + pq[1][jj]) + pq[2][jj] : (pq[1][jj] - pq[2][jj]) - pq[3][jj];
+                v += bv;
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
+                }
+                *reinterpret_cast<wf32x4_t*>(y + ((size_t)(on * H + oh) * W + ow) * Cout + nb * BN + c4) = v;
+            }
+        }
+    }
+}
+
+template <int KC, int NB, int WGS>
+static hipError_t launch_wino(const float* x, const float* U, float* y, const float* bias, int N, int H, int W, int Cin,
+                              int Cout, int relu, int nb_major, hipStream_t st) {
+    using C = WinoCfg<KC, NB>;
+    const int TH = (H + 1) / 2, TW = (W + 1) / 2, T = N * TH * TW;
+    const long long blocks = (long long)((T + 63) / 64) * (Cout / C::BN);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_f23_kernel<KC, NB, WGS>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    winograd_f23_kernel<KC, NB, WGS><<<(unsigned)blocks, 256, C::LDS_BYTES, st>>>(x, U, y, bias, H, W, Cin, Cout, TH, TW, T,
+                                                                                  relu, nb_major);
+    return hipGetLastError();
+}
+
+// variant 0: 64 tiles x 64 channels, K-chunks of 16, one workgroup per compute unit (256 accumulator registers per lane);
+// variant 1: 64 tiles x 32 channels, K-chunks of 8, two workgroups per compute unit.  The filter layout depends on it.
+hipError_t launch_winograd_f23(const float* x, const float* U, float* y, const float* bias, int N, int H, int W, int Cin,
+                               int Cout, int relu, int variant, int nb_major, hipStream_t st) {
+    if (variant == 0) return launch_wino<16, 2, 1>(x, U, y, bias, N, H, W, Cin, Cout, relu, nb_major, st);
+    return launch_wino<8, 1, 2>(x, U, y, bias, N, H, W, Cin, Cout, relu, nb_major, st);
+}
+
+}  // namespace opa
