@@ -20,7 +20,7 @@ import math
 import torch
 from torch import nn
 
-from . import fused, headmeta
+from . import fused, headmeta, winograd
 
 
 def _take_biases(block, conv_names):
@@ -56,13 +56,17 @@ class _Bottleneck(nn.Module):
 
     def enable_fused_(self):
         _take_biases(self, ('conv1', 'conv2', 'conv3'))
+        if self.conv2.stride == (1, 1):     # the stride-1 3x3: G g G^T once, in the Winograd kernel's operand order
+            self.register_buffer('wino_u', winograd.transform_filter(self.conv2.weight, winograd.DEFAULT_VARIANT),
+                                 persistent=False)
         self.fused = True
 
     def forward(self, x):
         if self.fused:      # conv (no bias) -> ONE fused bias(+residual)+ReLU pass each
             identity = x if self.downsample is None else self.downsample[0](x)
             out = fused.conv_bias_act(self.conv1, x, self.fb1)            # 1x1: fused MFMA GEMM
-            out = self.conv2(out)                                         # 3x3: MIOpen, raw output ...
+            # 3x3, raw output: float32 stride 1 -> Winograd F(2x2, 3x3) in one HIP kernel; strided / bfloat16 -> MIOpen ...
+            out = winograd.conv_or_fallback(self.conv2, out, getattr(self, 'wino_u', None))
             # ... whose bias + ReLU is applied by the 1x1 GEMM below while it stages its operand
             return fused.conv_bias_act(self.conv3, out, self.fb3, identity, a_bias=self.fb2)
         identity = x if self.downsample is None else self.downsample(x)

@@ -6,6 +6,7 @@ with 16 instead of 36 multiplications per 2x2 outputs, in float32 throughout; th
 per weight, in float64, and stored in the order the kernel's lanes read it.
 """
 import ctypes
+import os
 
 import torch
 
@@ -13,7 +14,27 @@ from . import _lib
 
 # variant -> (K-chunk, 32-wide channel blocks per workgroup): must match launch_winograd_f23 (csrc/winograd.hip)
 VARIANTS = {0: (16, 2), 1: (8, 1)}
+DEFAULT_VARIANT = 0
+MIN_WORKGROUPS = 256        # below one workgroup per compute unit the launch does not fill the chip: MIOpen's convolution
 _G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+
+def workgroups(x_shape, c_out, variant=DEFAULT_VARIANT):
+    B, _, H, W = x_shape
+    return ((B * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64) * (c_out // (32 * VARIANTS[variant][1]))
+
+
+def conv_or_fallback(conv, x, u, variant=DEFAULT_VARIANT):
+    """``conv(x)`` for a bias-free 3x3 ``torch.nn.Conv2d``: the Winograd kernel when ``u`` (its transformed filter) is
+    there, the operands qualify and the launch fills the chip -- a rule on shapes, not a timing, so that every rank of a job
+    and every run take the same path (the two round differently); ``OPA_CONV3X3=conv|winograd`` forces one."""
+    forced = os.environ.get('OPA_CONV3X3', 'auto')
+    if (u is not None and forced != 'conv' and u.dtype == torch.float32 and conv.bias is None
+            and supported(x, conv.weight, variant, conv.stride, conv.padding, conv.groups, conv.dilation)
+            and (forced == 'winograd' or workgroups(x.shape, conv.out_channels, variant) >= MIN_WORKGROUPS)
+            and not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad))):
+        return conv3x3(x, u, conv.out_channels, variant=variant)
+    return conv(x)
 
 
 def supported(x, weight, variant=0, stride=(1, 1), padding=(1, 1), groups=1, dilation=(1, 1)):
