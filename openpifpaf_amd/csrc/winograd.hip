@@ -240,6 +240,240 @@ __global__ __launch_bounds__(256, WGS) void winograd_f23_kernel(
     }
 }
 
+// ---- variant 2: the same 64 tiles x 64 channels with EIGHT waves (512 threads), two per SIMD, in two shifts.
+// Variant 0's single wave per SIMD does its transform and its LDS round trips in front of the idle MFMA pipe (the compiler
+// schedules them behind the multiplications whatever the source says: 20 % + 20 % of a chunk).  Here wave w owns TWO positions
+// (xi = w / 2, nu = 2 * (w % 2) + {0, 1}: 128 accumulator registers), waves w and w + 4 share a SIMD, and the two halves of
+// the workgroup take the phases of a chunk in opposite order:
+//     waves 0-3:  fetch x(c + 1) | multiply chunk c                | transform x(c + 1) -> other stage | barrier
+//     waves 4-7:  transform x(c + 1) -> other stage | fetch x(c + 2) | multiply chunk c                 | barrier
+// so that one wave of every SIMD has MFMAs to issue while the other one adds, stores and waits for LDS.  Same filter layout
+// as variant 0.  Thread (tile = tid / 8, channel pair = tid % 8) stages float2's; LDS pitch 66 is conflict-free for that map.
+// Output transform in two halves of 32 tiles (8 waves x 2 x 32 x 64 floats = 128 KB per half).
+constexpr int kW8KC = 16, kW8P = 66, kW8VBUF = 16 * kW8KC * kW8P;
+constexpr int kW8LdsBytes = 2 * kW8VBUF * 4;            // 135 168 B (>= the 131 072 B of an output half)
+
+template <int DIAG>
+__global__ __launch_bounds__(512, 1) void winograd_f23_w8_kernel(
+        const float* __restrict__ x, const float* __restrict__ U, float* __restrict__ y, const float* __restrict__ bias,
+        int H, int W, int Cin, int Cout, int TH, int TW, int T, int relu, int nb_major) {
+    constexpr int KC = kW8KC, P = kW8P, NB = 2, BN = 64, KQ = 2, S = 2 * KQ;
+    extern __shared__ __attribute__((aligned(16))) unsigned char wino_smem[];
+    float* const lds = reinterpret_cast<float*>(wino_smem);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n_nb = Cout / BN;
+    const unsigned nwg = gridDim.x, xcd = blockIdx.x & 7u, in_xcd = blockIdx.x >> 3;
+    const unsigned q8 = nwg >> 3, r8 = nwg & 7u;
+    const unsigned logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + in_xcd;
+    const unsigned n_tb = nwg / (unsigned)n_nb;
+    const int tb = nb_major ? (int)(logical % n_tb) : (int)(logical / (unsigned)n_nb);
+    const int nb = nb_major ? (int)(logical / n_tb) : (int)(logical % (unsigned)n_nb);
+    const int nchunks = Cin / KC;
+
+    const int tile_l = tid >> 3, cg = tid & 7;
+    int t = tb * 64 + tile_l;
+    if (t > T - 1) t = T - 1;
+    const int tx = t % TW, ty = (t / TW) % TH, n = t / (TW * TH);
+    unsigned rowoff[4], coloff[4];
+    bool rv[4], cv[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int r = 2 * ty - 1 + i, c = 2 * tx - 1 + i;
+        rv[i] = r >= 0 && r < H;
+        cv[i] = c >= 0 && c < W;
+        const int rc = r < 0 ? 0 : (r > H - 1 ? H - 1 : r), cc = c < 0 ? 0 : (c > W - 1 ? W - 1 : c);
+        rowoff[i] = (unsigned)((n * H + rc) * W) * (unsigned)Cin;
+        coloff[i] = (unsigned)cc * (unsigned)Cin + (unsigned)(cg * 2);
+    }
+    float d[16][2];
+    auto fetch_x = [&](int chunk) {
+        const unsigned c0 = (unsigned)(chunk * KC);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float2 v = *reinterpret_cast<const float2*>(x + (size_t)(rowoff[i] + coloff[j] + c0));
+                d[i * 4 + j][0] = v.x; d[i * 4 + j][1] = v.y;
+            }
+    };
+    auto transform_store = [&](int buf) {
+        float* const vb = lds + buf * kW8VBUF + (cg * 2) * P + tile_l;
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            float z[16];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) z[i * 4 + j] = (rv[i] && cv[j]) ? d[i * 4 + j][e] : 0.0f;
+            float s[16];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                s[0 * 4 + j] = z[0 * 4 + j] - z[2 * 4 + j];
+                s[1 * 4 + j] = z[1 * 4 + j] + z[2 * 4 + j];
+                s[2 * 4 + j] = z[2 * 4 + j] - z[1 * 4 + j];
+                s[3 * 4 + j] = z[1 * 4 + j] - z[3 * 4 + j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                vb[((i * 4 + 0) * KC + e) * P] = s[i * 4 + 0] - s[i * 4 + 2];
+                vb[((i * 4 + 1) * KC + e) * P] = s[i * 4 + 1] + s[i * 4 + 2];
+                vb[((i * 4 + 2) * KC + e) * P] = s[i * 4 + 2] - s[i * 4 + 1];
+                vb[((i * 4 + 3) * KC + e) * P] = s[i * 4 + 1] - s[i * 4 + 3];
+            }
+        }
+    };
+
+    // filter operand: step st = (position 2 * wave + st / KQ, kq = st % KQ); all four steps of a chunk in registers, each
+    // reloaded for the next chunk behind its last MFMA
+    wf32x4_t ub[S][NB];
+    const wf32x4_t* const ubase = reinterpret_cast<const wf32x4_t*>(U) + (size_t)nb * nchunks * (16 * NB * KQ * 64) + lane;
+    auto u_ptr = [&](int chunk, int st, int j) {
+        return ubase + ((size_t)((chunk * 16 + wave * 2 + st / KQ) * NB + j) * KQ + st % KQ) * 64;
+    };
+    wf32x16_t acc[2][2][NB];
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < NB; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[pl][i][j][r] = 0.0f;
+
+    const int a_lane = (lane >> 5) * P + (lane & 31) + (wave * 2 * KC) * P;
+    auto mfma_phase = [&](int chunk, int nxt) {
+        const float* const vb = lds + (chunk & 1) * kW8VBUF + a_lane;
+#pragma unroll
+        for (int st = 0; st < S; st++) {
+            const int pl = st / KQ;
+            const float* const vp = vb + (pl * KC + (st % KQ) * 8) * P;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const float a0 = DIAG == 5 ? ub[st][0][m] : vp[(2 * m) * P], a1 = DIAG == 5 ? ub[st][1][m] : vp[(2 * m) * P + 32];
+#pragma unroll
+                for (int j = 0; j < NB; j++) {
+                    acc[pl][0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, ub[st][j][m], acc[pl][0][j], 0, 0, 0);
+                    acc[pl][1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, ub[st][j][m], acc[pl][1][j], 0, 0, 0);
+                }
+            }
+            if (DIAG != 1 && DIAG < 4) {
+#pragma unroll
+                for (int j = 0; j < NB; j++) ub[st][j] = *u_ptr(nxt, st, j);
+            }
+        }
+    };
+
+    // Prologue in the loops' own order of loads -- pixels first, filter behind them: the compiler's s_waitcnt at a loop head
+    // covers the entry edge as well, and with the filter loads issued first the second shift's `wait for the pixels` became
+    // vmcnt(0), i.e. every period began by waiting for the filter reloads issued at the end of the period before.
+    const int last = nchunks - 1;
+    fetch_x(0);
+    transform_store(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave >= 4) fetch_x(nchunks > 1 ? 1 : 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < S; st++)
+#pragma unroll
+        for (int j = 0; j < NB; j++) ub[st][j] = *u_ptr(0, st, j);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave < 4) {                                    // first shift: multiply, then transform
+        __syncthreads();
+        for (int chunk = 0; chunk < nchunks; chunk++) {
+            const int nxt = chunk < last ? chunk + 1 : last;
+            if (DIAG != 2 && DIAG < 4) fetch_x(nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_phase(chunk, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            if (DIAG != 3 && DIAG < 4) transform_store((chunk + 1) & 1);          // (the last chunk's goes to the stage nobody reads any more)
+            __syncthreads();
+        }
+    } else {                                           // second shift: transform, then multiply
+        __syncthreads();
+        for (int chunk = 0; chunk < nchunks; chunk++) {
+            const int nxt = chunk < last ? chunk + 1 : last;
+            if (DIAG != 3 && DIAG < 4) transform_store((chunk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (DIAG != 2 && DIAG < 4) fetch_x(chunk + 2 < nchunks ? chunk + 2 : last);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_phase(chunk, nxt);
+            __syncthreads();
+        }
+    }
+
+    // ---- output transform, 32 tiles (accumulator row block i) at a time.  This wave's part of the nu-sum:
+    //      nu in {0, 1}: P0 = m0 + m1, P1 = m1;   nu in {2, 3}: P0 = m2, P1 = -(m2 + m3)
+    const int h = wave & 1;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        float* const sw = lds + wave * (2 * 32 * BN);
+#pragma unroll
+        for (int j = 0; j < NB; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int tile = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = j * 32 + (lane & 31);
+                const float ma = acc[0][i][j][r], mb = acc[1][i][j][r];
+                sw[tile * BN + col] = h == 0 ? ma + mb : ma;
+                sw[32 * BN + tile * BN + col] = h == 0 ? mb : -(ma + mb);
+            }
+        __syncthreads();
+        // item = (tile of this half, 4 channels): 32 x 16 = 512 = one per thread.  xi-sum over the wave pairs:
+        //      Y[0][.] = P(0) + P(1) + P(2), Y[1][.] = P(1) - P(2) - P(3), P(xi) = the two waves 2 xi, 2 xi + 1
+        {
+            const int tile = tid >> 4, c4 = (tid & 15) * 4;
+            const int tt = tb * 64 + i * 32 + tile;
+            if (tt < T) {
+                const int ox = tt % TW, oy = (tt / TW) % TH, on = tt / (TW * TH);
+                wf32x4_t pq[4][2];
+#pragma unroll
+                for (int xi = 0; xi < 4; xi++)
+#pragma unroll
+                    for (int jj = 0; jj < 2; jj++)
+                        pq[xi][jj] = *reinterpret_cast<const wf32x4_t*>(lds + ((2 * xi) * 2 + jj) * (32 * BN) + tile * BN + c4) +
+                                     *reinterpret_cast<const wf32x4_t*>(lds + ((2 * xi + 1) * 2 + jj) * (32 * BN) + tile * BN + c4);
+                wf32x4_t bv = {0.f, 0.f, 0.f, 0.f};
+                if (bias) bv = *reinterpret_cast<const wf32x4_t*>(bias + nb * BN + c4);
+#pragma unroll
+                for (int a = 0; a < 2; a++) {
+                    const int oh = 2 * oy + a;
+                    if (oh >= H) continue;
+#pragma unroll
+                    for (int jj = 0; jj < 2; jj++) {
+                        const int ow = 2 * ox + jj;
+                        if (ow >= W) continue;
+                        wf32x4_t v = a == 0 ? (pq[0][jj] + pq[1][jj]) + pq[2][jj] : (pq[1][jj] - pq[2][jj]) - pq[3][jj];
+                        v += bv;
+                        if (relu) {
+#pragma unroll
+                            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.0f);
+                        }
+                        *reinterpret_cast<wf32x4_t*>(y + ((size_t)(on * H + oh) * W + ow) * Cout + nb * BN + c4) = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int DIAG>
+static hipError_t launch_wino_w8(const float* x, const float* U, float* y, const float* bias, int N, int H, int W, int Cin,
+                                 int Cout, int relu, int nb_major, hipStream_t st) {
+    const int TH = (H + 1) / 2, TW = (W + 1) / 2, T = N * TH * TW;
+    const long long blocks = (long long)((T + 63) / 64) * (Cout / 64);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&winograd_f23_w8_kernel<DIAG>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, kW8LdsBytes);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    winograd_f23_w8_kernel<DIAG><<<(unsigned)blocks, 512, kW8LdsBytes, st>>>(x, U, y, bias, H, W, Cin, Cout, TH, TW, T, relu, nb_major);
+    return hipGetLastError();
+}
+
 template <int KC, int NB, int WGS>
 static hipError_t launch_wino(const float* x, const float* U, float* y, const float* bias, int N, int H, int W, int Cin,
                               int Cout, int relu, int nb_major, hipStream_t st) {
@@ -259,10 +493,19 @@ static hipError_t launch_wino(const float* x, const float* U, float* y, const fl
 }
 
 // variant 0: 64 tiles x 64 channels, K-chunks of 16, one workgroup per compute unit (256 accumulator registers per lane);
-// variant 1: 64 tiles x 32 channels, K-chunks of 8, two workgroups per compute unit.  The filter layout depends on it.
+// variant 1: 64 tiles x 32 channels, K-chunks of 8, two workgroups per compute unit;
+// variant 2: variant 0's tile and filter layout, eight waves in two shifts.  The filter layout depends on the variant.
 hipError_t launch_winograd_f23(const float* x, const float* U, float* y, const float* bias, int N, int H, int W, int Cin,
                                int Cout, int relu, int variant, int nb_major, hipStream_t st) {
     if (variant == 0) return launch_wino<16, 2, 1>(x, U, y, bias, N, H, W, Cin, Cout, relu, nb_major, st);
+    if (variant == 2) return launch_wino_w8<0>(x, U, y, bias, N, H, W, Cin, Cout, relu, nb_major, st);
+#ifdef OPA_WINO_DIAG          // timing experiments (wrong results): without the filter reloads / pixel fetches / transforms
+    if (variant == 11) return launch_wino_w8<1>(x, U, y, bias, N, H, W, Cin, Cout, relu, nb_major, st);
+    if (variant == 12) return launch_wino_w8<2>(x, U, y, bias, N, H, W, Cin, Cout, relu, nb_major, st);
+    if (variant == 13) return launch_wino_w8<3>(x, U, y, bias, N, H, W, Cin, Cout, relu, nb_major, st);
+    if (variant == 14) return launch_wino_w8<4>(x, U, y, bias, N, H, W, Cin, Cout, relu, nb_major, st);
+    if (variant == 15) return launch_wino_w8<5>(x, U, y, bias, N, H, W, Cin, Cout, relu, nb_major, st);
+#endif
     return launch_wino<8, 1, 2>(x, U, y, bias, N, H, W, Cin, Cout, relu, nb_major, st);
 }
 

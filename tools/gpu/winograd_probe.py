@@ -50,11 +50,13 @@ def main():
     ap.add_argument('--quick', action='store_true')
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--reps', type=int, default=10)
-    ap.add_argument('--variants', default='0,1')
+    ap.add_argument('--variants', default='0,1,2')
+    ap.add_argument('--timing-only', action='store_true')
+    ap.add_argument('--orders', default='0,1')
     args = ap.parse_args()
     variants = [int(v) for v in args.variants.split(',')]
     ok = True
-    for variant in variants:
+    for variant in ([] if args.timing_only else variants):
         for (B, C, O, H, W) in ((1, 16, 64, 8, 8), (2, 32, 64, 7, 9), (3, 64, 128, 21, 21), (2, 64, 64, 41, 40), (1, 128, 128, 5, 3)):
             for order in (0, 1):
                 ok &= check(B, C, O, H, W, variant, order)
@@ -77,7 +79,7 @@ def main():
             yref = conv(x)
             for variant in variants:
                 u = winograd.transform_filter(w, variant)
-                for order in (0, 1):
+                for order in [int(o) for o in args.orders.split(',')]:
                     out = torch.empty_like(yref)
                     t = time_ms(lambda: winograd.conv3x3(x, u, C, variant=variant, order=order, out=out), args.reps)
                     err = (out - yref).abs().max().item() / yref.abs().max().item()
