@@ -1017,7 +1017,16 @@ __device__ __forceinline__ SpecOut spec_scan_batch(ImageCtx& c, bool active, int
 // seeds this pose is going to cover (defined behind the occupancy helpers).
 // task slots of the growers (states, see the kernel)
 constexpr int kTaskIdle = 0, kTaskAssigned = 1, kTaskDone = 2, kTaskAccepted = 3;
-struct __attribute__((aligned(16))) TaskSlot { int state, seed, cancel, epoch, npub, pk, f, pad0; double score; int t_emit, t_done, pad1, coll; };
+// 72 bytes = 18 banks between the slots: the coordinator's snapshot and publish_joint read one field of ALL slots with lane =
+// grower; at 64 bytes twelve lanes fell on two banks (6-way conflicts on every such read, -DOPA_TASK_SLOT_PAD=0 brings it back)
+#ifndef OPA_TASK_SLOT_PAD
+#define OPA_TASK_SLOT_PAD 2
+#endif
+struct __attribute__((aligned(8))) TaskSlot { int state, seed, cancel, epoch, npub, pk, f, pad0; double score; int t_emit, t_done, pad1, coll;
+#if OPA_TASK_SLOT_PAD
+    int pad_bank[OPA_TASK_SLOT_PAD];
+#endif
+};
 template <int WR> __device__ __forceinline__ void publish_joint(ImageCtx& c, const DevParams& p, int k, float x, float y, float s);
 template <int WR> __device__ __forceinline__ void pool_catch_up(ImageCtx& c, int e);
 template <int WR> __device__ __forceinline__ void spec_phase(ImageCtx& c, const DevParams& p, bool reverse_match_, double filter_sigmas);
@@ -2134,6 +2143,9 @@ __host__ __device__ inline size_t assoc_private_bytes(int K, int A, bool reg, in
     b = (b + 15) / 16 * 16;
     if (spec) b += assoc_spec_bytes(K, A, reg);
     if (help) b += assoc_help_bytes(K, A, reg);
+#ifdef OPA_ASSOC_PRIVATE_PAD     // experiment: other distances between the growers' blocks (LDS bank conflicts)
+    b += OPA_ASSOC_PRIVATE_PAD;
+#endif
     return b + sizeof(float) * tgt_floats;
 }
 template <bool REG>
