@@ -275,44 +275,56 @@ __global__ __launch_bounds__(512, 1) void winograd_f23_w8_kernel(
     int t = tb * 64 + tile_l;
     if (t > T - 1) t = T - 1;
     const int tx = t % TW, ty = (t / TW) % TH, n = t / (TW * TH);
-    unsigned rowoff[4], coloff[4];
-    bool rv[4], cv[4];
+    // byte offsets of the tile's sixteen pixels (clamped into the image), once: a fetch is then sixteen loads of the form
+    // uniform base (x + chunk * KC, scalar registers) + 32-bit lane offset -- no address arithmetic in the loop
+    unsigned off[16];
+    unsigned valid = 0u;                               // bit i * 4 + j: pixel (i, j) lies inside the image
+    {
+        unsigned rowoff[4], coloff[4];
+        bool rv[4], cv[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int r = 2 * ty - 1 + i, c = 2 * tx - 1 + i;
-        rv[i] = r >= 0 && r < H;
-        cv[i] = c >= 0 && c < W;
-        const int rc = r < 0 ? 0 : (r > H - 1 ? H - 1 : r), cc = c < 0 ? 0 : (c > W - 1 ? W - 1 : c);
-        rowoff[i] = (unsigned)((n * H + rc) * W) * (unsigned)Cin;
-        coloff[i] = (unsigned)cc * (unsigned)Cin + (unsigned)(cg * 2);
-    }
-    float d[16][2];
-    auto fetch_x = [&](int chunk) {
-        const unsigned c0 = (unsigned)(chunk * KC);
+        for (int i = 0; i < 4; i++) {
+            const int r = 2 * ty - 1 + i, c = 2 * tx - 1 + i;
+            rv[i] = r >= 0 && r < H;
+            cv[i] = c >= 0 && c < W;
+            const int rc = r < 0 ? 0 : (r > H - 1 ? H - 1 : r), cc = c < 0 ? 0 : (c > W - 1 ? W - 1 : c);
+            rowoff[i] = (unsigned)((n * H + rc) * W) * (unsigned)Cin;
+            coloff[i] = (unsigned)cc * (unsigned)Cin + (unsigned)(cg * 2);
+        }
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const float2 v = *reinterpret_cast<const float2*>(x + (size_t)(rowoff[i] + coloff[j] + c0));
-                d[i * 4 + j][0] = v.x; d[i * 4 + j][1] = v.y;
+                off[i * 4 + j] = (rowoff[i] + coloff[j]) * 4u;
+                if (rv[i] && cv[j]) valid |= 1u << (i * 4 + j);
             }
+    }
+    const bool wave_inside = __ballot(valid != 0xffffu) == 0ull;   // no lane of this wave has a pixel in the padding
+    float d[16][2];
+    auto fetch_x = [&](int chunk) {
+        const char* const base = reinterpret_cast<const char*>(x + chunk * KC);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float2 v = *reinterpret_cast<const float2*>(base + off[k]);
+            d[k][0] = v.x; d[k][1] = v.y;
+        }
     };
     auto transform_store = [&](int buf) {
         float* const vb = lds + buf * kW8VBUF + (cg * 2) * P + tile_l;
+        if (!wave_inside) {                            // zero padding: only the waves that hold a border tile pay for it
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (!((valid >> k) & 1u)) { d[k][0] = 0.0f; d[k][1] = 0.0f; }
+        }
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-            float z[16];
-#pragma unroll
-            for (int i = 0; i < 4; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) z[i * 4 + j] = (rv[i] && cv[j]) ? d[i * 4 + j][e] : 0.0f;
             float s[16];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                s[0 * 4 + j] = z[0 * 4 + j] - z[2 * 4 + j];
-                s[1 * 4 + j] = z[1 * 4 + j] + z[2 * 4 + j];
-                s[2 * 4 + j] = z[2 * 4 + j] - z[1 * 4 + j];
-                s[3 * 4 + j] = z[1 * 4 + j] - z[3 * 4 + j];
+                s[0 * 4 + j] = d[0 * 4 + j][e] - d[2 * 4 + j][e];
+                s[1 * 4 + j] = d[1 * 4 + j][e] + d[2 * 4 + j][e];
+                s[2 * 4 + j] = d[2 * 4 + j][e] - d[1 * 4 + j][e];
+                s[3 * 4 + j] = d[1 * 4 + j][e] - d[3 * 4 + j][e];
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) {
