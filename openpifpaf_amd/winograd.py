@@ -62,10 +62,28 @@ def transform_filter(weight, variant=0):
     return u.contiguous().float().reshape(-1)
 
 
+# direct-convolution flops of the launches that went through the kernel since the last reset: a measurement (bench.py) that
+# quotes a convolutional network's FLOP/s has to say how many of its multiplications F(2x2, 3x3) did not execute
+_direct_flops = 0.0
+
+
+def reset_flop_counter():
+    global _direct_flops
+    _direct_flops = 0.0
+
+
+def direct_flops():
+    """Flops (2 x MACs of the DIRECT form) of the convolutions run by the kernel since ``reset_flop_counter``; the kernel's
+    MFMAs execute 1 / 2.25 of them."""
+    return _direct_flops
+
+
 def conv3x3(x, u, c_out, bias=None, relu=False, variant=0, order=0, out=None):
     """``conv2d(x, weight, padding=1)`` (+ bias, ReLU) for the ``u = transform_filter(weight, variant)`` of a 3x3 weight.
     ``x``: ``[B, C_in, H, W]`` float32 channels_last on the GPU -> ``[B, c_out, H, W]`` channels_last."""
+    global _direct_flops
     B, cin, H, W = x.shape
+    _direct_flops += 18.0 * B * H * W * cin * c_out
     if out is None:
         out = torch.empty((B, c_out, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     _lib.check(_lib.lib().opa_conv3x3_winograd_f32(
