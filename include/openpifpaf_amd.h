@@ -394,8 +394,8 @@ int opa_gemm_bias_act_f32(const float* a_dev, const float* a_bias_dev, const flo
  * ResNet trunk (reference network/basenetworks.py:71-150 runs them through torch.nn.Conv2d), 2.25x fewer multiplications
  * than the direct form, float32 arithmetic throughout.
  *  x_dev [B, h, w, c_in], u_dev = the filter transformed and laid out by openpifpaf_amd.winograd.transform_filter for
- *  `variant` (0 and 2: 64 output channels per workgroup, c_in % 16 == 0, c_out % 64 == 0 -- 2 runs eight waves in two
- *  shifts on the same operand; 1: 32 channels, c_in % 8 == 0, c_out % 32 == 0), out_dev [B, h, w, c_out]; bias_dev [c_out] or NULL; relu 0/1; order 0 = workgroups of one tile block
+ *  `variant` (0, 2 and 3: 64 output channels per workgroup, c_in % 16 == 0, c_out % 64 == 0 -- 2 runs eight waves in two
+ *  shifts on the same operand (the default of the Python side), 3 the same as persistent workgroups; 1: 32 channels, c_in % 8 == 0, c_out % 32 == 0), out_dev [B, h, w, c_out]; bias_dev [c_out] or NULL; relu 0/1; order 0 = workgroups of one tile block
  *  on one XCD, 1 = workgroups of one channel block on one XCD.  B*h*w*c_in < 2^32; pointers 16-B aligned. */
 int opa_conv3x3_winograd_f32(const float* x_dev, const float* u_dev, const float* bias_dev, float* out_dev, int32_t batch,
                              int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t relu, int32_t variant,

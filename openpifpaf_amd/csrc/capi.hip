@@ -921,7 +921,7 @@ int opa_gemm_bias_act_f32(const float* a_dev, const float* a_bias_dev, const flo
 int opa_conv3x3_winograd_f32(const float* x_dev, const float* u_dev, const float* bias_dev, float* out_dev, int32_t batch,
                              int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t relu, int32_t variant,
                              int32_t order, void* stream) {
-    if (!x_dev || !u_dev || !out_dev || batch <= 0 || h <= 0 || w <= 0 || c_in <= 0 || c_out <= 0 || variant < 0 || (variant > 2 && (variant < 11 || variant > 15)))
+    if (!x_dev || !u_dev || !out_dev || batch <= 0 || h <= 0 || w <= 0 || c_in <= 0 || c_out <= 0 || variant < 0 || (variant > 3 && (variant < 11 || variant > 18)))
         return fail(OPA_ERR_INVALID_ARGUMENT, "opa_conv3x3_winograd_f32: bad arguments");
     if (variant != 1 ? (c_in % 16 != 0 || c_out % 64 != 0) : (c_in % 8 != 0 || c_out % 32 != 0))
         return fail(OPA_ERR_INVALID_ARGUMENT, "opa_conv3x3_winograd_f32: channel counts do not fit the variant's tiles");

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 
 # variant -> (K-chunk, 32-wide channel blocks per workgroup): must match launch_winograd_f23 (csrc/winograd.hip)
-VARIANTS = {0: (16, 2), 1: (8, 1), 2: (16, 2)}     # 2: variant 0's tile and filter layout, eight waves in two shifts
+VARIANTS = {0: (16, 2), 1: (8, 1), 2: (16, 2), 3: (16, 2)}     # 2: variant 0's tile and filter layout, eight waves in two shifts
 DEFAULT_VARIANT = 2         # eight waves in two shifts (csrc/winograd.hip): 5-8 % faster than variant 0 on every ResNet-50 shape
 MIN_WORKGROUPS = 256        # below one workgroup per compute unit the launch does not fill the chip: MIOpen's convolution
 _G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))

@@ -23,7 +23,7 @@ def _case(B, C, O, H, W, variant, order, bias=False, relu=False, seed=0):
     return (y.double() - ref).abs().max().item() / ref.abs().max().item()
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
 @pytest.mark.parametrize('shape', [(1, 16, 64, 8, 8), (2, 32, 64, 7, 9), (3, 64, 128, 21, 21), (2, 64, 64, 41, 40),
                                    (1, 128, 128, 5, 3), (1, 16, 64, 1, 1), (5, 48, 192, 16, 13)])
 def test_winograd_equals_the_convolution(variant, shape):
@@ -31,7 +31,7 @@ def test_winograd_equals_the_convolution(variant, shape):
         assert _case(*shape, variant, order) < 2e-5
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
 def test_bias_and_relu_in_the_output_transform(variant):
     assert _case(2, 32, 64, 11, 13, variant, 0, bias=True, relu=True) < 2e-5
     assert _case(2, 32, 64, 11, 13, variant, 1, bias=True, relu=False) < 2e-5

@@ -16,7 +16,7 @@ def test_reference_model_equals_the_direct_convolution(shape):
     assert (winograd.reference_f23(x, w) - ref).abs().max().item() < 1e-12
 
 
-@pytest.mark.parametrize('variant', [0, 1, 2])
+@pytest.mark.parametrize('variant', [0, 1, 2, 3])
 def test_filter_operand_layout_is_what_the_lanes_read(variant):
     """Lane l of the wave that owns position p reads float4 number ((((block * chunks + chunk) * 16 + p) * NB + j) * KQ + kq)
     * 64 + l and multiplies its e-th element as B[k = l // 32][c = l % 32] of MFMA e: that must be U[p][chunk * KC + 2 * (4 *

@@ -13,7 +13,7 @@ from openpifpaf_amd import winograd  # noqa: E402
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from winograd_probe import time_ms  # noqa: E402
 
-winograd.VARIANTS.update({v: (16, 2) for v in range(11, 16)})
+winograd.VARIANTS.update({v: (16, 2) for v in range(11, 19)})
 B = 32
 for (C, H) in ((64, 321), (128, 161), (256, 81), (512, 41)):
     x = torch.randn((B, C, H, H), device='cuda').contiguous(memory_format=torch.channels_last)
@@ -22,7 +22,8 @@ for (C, H) in ((64, 321), (128, 161), (256, 81), (512, 41)):
     out = torch.empty_like(x)
     line = 'C %3d %3dx%3d:' % (C, H, H)
     for variant, name in ((2, 'full'), (11, 'no filter reloads'), (12, 'no pixel fetches'), (13, 'no transforms'),
-                          (14, 'MFMA + operand reads only'), (15, 'MFMA only')):
+                          (14, 'MFMA + operand reads only'), (15, 'MFMA only'), (16, 'no output transform'),
+                          (17, 'output transform without its stores'), (18, 'nontemporal stores')):
         t = time_ms(lambda: winograd.conv3x3(x, u, C, variant=variant, out=out), 10)
         line += '  %s %.3f ms' % (name, t)
     ideal = 2.0 * B * H * H * C * C * 9 / 2.25 / 157.3e9
