@@ -24,15 +24,20 @@ def workgroups(x_shape, c_out, variant=DEFAULT_VARIANT):
     return ((B * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64) * (c_out // (32 * VARIANTS[variant][1]))
 
 
-def conv_or_fallback(conv, x, u, variant=DEFAULT_VARIANT):
-    """``conv(x)`` for a bias-free 3x3 ``torch.nn.Conv2d``: the Winograd kernel when ``u`` (its transformed filter) is
-    there, the operands qualify and the launch fills the chip -- a rule on shapes, not a timing, so that every rank of a job
+def takes(conv, x, u, variant=DEFAULT_VARIANT):
+    """True if the Winograd kernel runs ``conv(x)`` for this bias-free 3x3 ``torch.nn.Conv2d``: ``u`` (its transformed filter)
+    is there, the operands qualify and the launch fills the chip -- a rule on shapes, not a timing, so that every rank of a job
     and every run take the same path (the two round differently); ``OPA_CONV3X3=conv|winograd`` forces one."""
     forced = os.environ.get('OPA_CONV3X3', 'auto')
-    if (u is not None and forced != 'conv' and u.dtype == torch.float32 and conv.bias is None
+    return (u is not None and forced != 'conv' and u.dtype == torch.float32 and conv.bias is None
             and supported(x, conv.weight, variant, conv.stride, conv.padding, conv.groups, conv.dilation)
             and (forced == 'winograd' or workgroups(x.shape, conv.out_channels, variant) >= MIN_WORKGROUPS)
-            and not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad))):
+            and not (torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad)))
+
+
+def conv_or_fallback(conv, x, u, variant=DEFAULT_VARIANT):
+    """``conv(x)``: through the kernel where :func:`takes` says so, else the module itself (MIOpen)."""
+    if takes(conv, x, u, variant):
         return conv3x3(x, u, conv.out_channels, variant=variant)
     return conv(x)
 
