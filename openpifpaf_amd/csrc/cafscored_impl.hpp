@@ -2,6 +2,9 @@
 // (cafscored.hip: one group per workgroup) and the fused sort + cafscored launch of the decode (cifseeds.hip: two
 // groups per 1024-thread workgroup, beside the seed sort's workgroups).  See cafscored.hip for the description.
 #pragma once
+#ifndef OPA_SCORED_EAGER
+#define OPA_SCORED_EAGER 0
+#endif
 #include "common.hpp"
 
 namespace opa {
@@ -101,6 +104,13 @@ __device__ __forceinline__ void cafscored_plane(const ScoredArgs& s, int plane_i
             c = P[1 * HW + o];
             const float r2 = P[2 * HW + o], r3 = P[3 * HW + o], r4 = P[4 * HW + o], r5 = P[5 * HW + o],
                         r6 = P[6 * HW + o], r7 = P[7 * HW + o];
+#if OPA_SCORED_EAGER
+            // (the optimiser sinks the six loads above into the block below -- the ISA has the confidence load, vmcnt(0), the
+            // threshold branch, THEN the other six: two dependent round trips per step, and FETCH_SIZE sees 41 MB of the 112 MB
+            // the source asks for.  With the products computed out here the seven loads travel together.)
+            x1 = r2 * stride_f; y1 = r3 * stride_f; x2 = r4 * stride_f; y2 = r5 * stride_f; s1 = r6 * stride_f; s2 = r7 * stride_f;
+            asm volatile("" : "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2), "+v"(s1), "+v"(s2));
+#endif
             if (!((double)c < score_th)) {                               // caf_scored.cpp:44
                 x1 = r2 * stride_f; y1 = r3 * stride_f;                  // :46-54
                 x2 = r4 * stride_f; y2 = r5 * stride_f;
