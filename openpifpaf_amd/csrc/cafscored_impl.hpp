@@ -99,15 +99,17 @@ __device__ __forceinline__ void cafscored_plane(const ScoredArgs& s, int plane_i
         bool keep_f = false, keep_b = false;
         float c = 0.f, cf = 0.f, cb = 0.f, x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, s1 = 0.f, s2 = 0.f;
         if (o < HW && live) {
-            // all seven planes of the cell are requested at once (the stage's compulsory bytes): one memory
-            // round trip before the two CifHr gathers instead of two
+            // The source asks for all seven planes of the cell at once; the optimiser SINKS the six coordinate / scale loads
+            // into the threshold block below (ISA: confidence load, vmcnt(0), branch, then the six) -- a wave fetches them only
+            // where one of its cells passes: 41 MB per 32 images instead of 112 (that is the FETCH_SIZE the review of round 5
+            // could not explain), at the price of a second dependent round trip.  Forcing the seven loads to travel together
+            // (-DOPA_SCORED_EAGER=1) is slower: 49-50 against 48 us at 32 images, 277-280 against 250-253 at 256, wholebody
+            // 144 against 121 (profiles/r6/cafscored_eager_loads_ab.log) -- the compiler's choice stays.
             c = P[1 * HW + o];
             const float r2 = P[2 * HW + o], r3 = P[3 * HW + o], r4 = P[4 * HW + o], r5 = P[5 * HW + o],
                         r6 = P[6 * HW + o], r7 = P[7 * HW + o];
 #if OPA_SCORED_EAGER
-            // (the optimiser sinks the six loads above into the block below -- the ISA has the confidence load, vmcnt(0), the
-            // threshold branch, THEN the other six: two dependent round trips per step, and FETCH_SIZE sees 41 MB of the 112 MB
-            // the source asks for.  With the products computed out here the seven loads travel together.)
+            // (experiment: with the products computed out here the seven loads travel together)
             x1 = r2 * stride_f; y1 = r3 * stride_f; x2 = r4 * stride_f; y2 = r5 * stride_f; s1 = r6 * stride_f; s2 = r7 * stride_f;
             asm volatile("" : "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2), "+v"(s1), "+v"(s2));
 #endif
