@@ -5,6 +5,9 @@
 #ifndef OPA_SCORED_EAGER
 #define OPA_SCORED_EAGER 0
 #endif
+#ifndef OPA_SCORED_PREFETCH
+#define OPA_SCORED_PREFETCH 1      // [r6] 250 -> 234 us at 256 images, wholebody 121 -> 110 (profiles/r6/cafscored_confidence_prefetch_ab.log; 0: round 5's loop)
+#endif
 #include "common.hpp"
 
 namespace opa {
@@ -94,10 +97,19 @@ __device__ __forceinline__ void cafscored_plane(const ScoredArgs& s, int plane_i
     const float stride_f = (float)stride;
     int base_f = 0, base_b = 0, parity = 0;
 
+#if OPA_SCORED_PREFETCH
+    // the confidence of the NEXT step's cell travels while this step is compacted (one load per thread, index clamped: no load
+    // under a condition): the first of a step's three dependent round trips is off its critical path
+    float c_pre = P[1 * HW + (tid < HW ? tid : HW - 1)];
+#endif
     for (int c0 = 0; c0 < HW; c0 += kScoredThreads, parity ^= 1) {
         const int o = c0 + tid;
         bool keep_f = false, keep_b = false;
         float c = 0.f, cf = 0.f, cb = 0.f, x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, s1 = 0.f, s2 = 0.f;
+#if OPA_SCORED_PREFETCH
+        const float c_now = c_pre;
+        { const int on = o + kScoredThreads; c_pre = P[1 * HW + (on < HW ? on : HW - 1)]; }
+#endif
         if (o < HW && live) {
             // The source asks for all seven planes of the cell at once; the optimiser SINKS the six coordinate / scale loads
             // into the threshold block below (ISA: confidence load, vmcnt(0), branch, then the six) -- a wave fetches them only
@@ -105,7 +117,11 @@ __device__ __forceinline__ void cafscored_plane(const ScoredArgs& s, int plane_i
             // could not explain), at the price of a second dependent round trip.  Forcing the seven loads to travel together
             // (-DOPA_SCORED_EAGER=1) is slower: 49-50 against 48 us at 32 images, 277-280 against 250-253 at 256, wholebody
             // 144 against 121 (profiles/r6/cafscored_eager_loads_ab.log) -- the compiler's choice stays.
+#if OPA_SCORED_PREFETCH
+            c = c_now;
+#else
             c = P[1 * HW + o];
+#endif
             const float r2 = P[2 * HW + o], r3 = P[3 * HW + o], r4 = P[4 * HW + o], r5 = P[5 * HW + o],
                         r6 = P[6 * HW + o], r7 = P[7 * HW + o];
 #if OPA_SCORED_EAGER

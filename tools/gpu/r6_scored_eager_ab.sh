@@ -1,6 +1,8 @@
 #!/bin/bash
-# round 6, second session: CafScored::fill with its seven plane loads travelling together (-DOPA_SCORED_EAGER=1; the optimiser sinks six
-# of them behind the threshold test otherwise) against the default, 32 / 256 images and the force-complete pass, parity checked.
+# round 6, second session: A/B of a CafScored::fill variant built as lib/libopenpifpaf_amd_eager.so (build.build_diagnostic(<define>, 'eager',
+# source='cafscored.hip')) against the default library: -DOPA_SCORED_EAGER=1 (the seven plane loads travel together; the optimiser sinks
+# six of them behind the threshold test otherwise) and -DOPA_SCORED_PREFETCH=1 / 0 (the next step's confidence one step ahead);
+# 32 / 256 images, the force-complete pass, wholebody; parity checked.
 cd "${GRAFT_REPO_ROOT:-.}"
 OUT=gpurun_out/r6/scored_eager; mkdir -p $OUT
 export PYTHONPATH=. PYTHONUNBUFFERED=1
