@@ -99,7 +99,8 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
         for (int r = 0; r < kActiveCells; r++) {
             const int o = c0 + r * kActiveThreads + tid;
             const int oo = o < HW ? o : 0;
-            v_[r] = o < HW ? P[HW + oo] : -1.0f;
+            v_[r] = P[HW + oo];                       // (unconditional: every consumer tests o < HW itself; a load under a
+                                                      // condition makes the compiler's waits behind the join conservative)
             x_[r] = P[2 * HW + oo]; y_[r] = P[3 * HW + oo]; s_[r] = P[4 * HW + oo];
             h_[r] = DET ? P[5 * HW + oo] : 0.0f;
         }
@@ -108,7 +109,9 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
     for (int c0 = 0, step = 0; c0 < HW; c0 += kActiveThreads * kActiveCells, parity ^= 1, step++) {
         float vn[kActiveCells], xn[kActiveCells], yn[kActiveCells], sn[kActiveCells], hn[kActiveCells];
         const bool more = c0 + kActiveThreads * kActiveCells < HW;
-        if (more) request(c0 + kActiveThreads * kActiveCells, vn, xn, yn, sn, hn);
+        // (always: the last step requests its own cells again -- with the request under `if (more)` the step's first cell
+        // waited for part of the NEXT step's loads, vmcnt(12) with sixteen of them just issued)
+        request(more ? c0 + kActiveThreads * kActiveCells : c0, vn, xn, yn, sn, hn);
         if (WL && tid == 0) cand_start[(size_t)plane * cand_chunks + step] = cbase;
         bool on[kActiveCells], con[kActiveCells];
         float v16[kActiveCells], x[kActiveCells], y[kActiveCells], sigma[kActiveCells];
@@ -175,10 +178,8 @@ __global__ __launch_bounds__(kActiveThreads) void cif_active_kernel(
                 cout[coff] = make_float4(__int_as_float(c0 + r * kActiveThreads + tid), vin[r], xin[r], yin[r]);
             base += tot; cbase += ctot;
         }
-        if (more) {
 #pragma unroll
-            for (int r = 0; r < kActiveCells; r++) { vin[r] = vn[r]; xin[r] = xn[r]; yin[r] = yn[r]; sin_[r] = sn[r]; hin[r] = hn[r]; }
-        }
+        for (int r = 0; r < kActiveCells; r++) { vin[r] = vn[r]; xin[r] = xn[r]; yin[r] = yn[r]; sin_[r] = sn[r]; hin[r] = hn[r]; }
     }
     if (tid == 0) act_count[plane] = base;
     if (!WL) return;
