@@ -96,13 +96,21 @@ class _BasicBlock(nn.Module):
 
     def enable_fused_(self):
         _take_biases(self, ('conv1', 'conv2'))
+        for i, conv in ((1, self.conv1), (2, self.conv2)):   # stride-1 3x3: the Winograd kernel's operand (see _Bottleneck)
+            if conv.stride == (1, 1) and conv.in_channels % 16 == 0 and conv.out_channels % 64 == 0:
+                self.register_buffer('wino_u%d' % i, winograd.transform_filter(conv.weight, winograd.DEFAULT_VARIANT),
+                                     persistent=False)
         self.fused = True
 
     def forward(self, x):
         if self.fused:
             identity = x if self.downsample is None else self.downsample[0](x)
-            out = fused.bias_act_(self.conv1(x), self.fb1)
-            return fused.bias_act_(self.conv2(out), self.fb2, identity)
+            u1, u2 = getattr(self, 'wino_u1', None), getattr(self, 'wino_u2', None)
+            if winograd.takes(self.conv1, x, u1):             # bias + ReLU in the kernel's output transform
+                out = winograd.conv3x3(x, u1, self.conv1.out_channels, bias=self.fb1, relu=True, variant=winograd.DEFAULT_VARIANT)
+            else:
+                out = fused.bias_act_(self.conv1(x), self.fb1)
+            return fused.bias_act_(winograd.conv_or_fallback(self.conv2, out, u2), self.fb2, identity)
         identity = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))

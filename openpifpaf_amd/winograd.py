@@ -19,6 +19,25 @@ MIN_WORKGROUPS = 256        # below one workgroup per compute unit the launch do
 _G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
 
 
+_mode = os.environ.get('OPA_CONV3X3', 'auto')      # read ONCE, when the module is imported; set_mode() afterwards
+if _mode not in ('auto', 'conv', 'winograd'):
+    raise ValueError('OPA_CONV3X3 must be auto, conv or winograd, not %r' % _mode)
+
+
+def set_mode(mode):
+    """'auto' (the shape rule of :func:`takes`), 'conv' (always MIOpen's convolution) or 'winograd' (the kernel wherever the
+    operands qualify, however small the launch) -> the previous mode.  The two paths round differently: a job's ranks must agree."""
+    global _mode
+    if mode not in ('auto', 'conv', 'winograd'):
+        raise ValueError(mode)
+    previous, _mode = _mode, mode
+    return previous
+
+
+def get_mode():
+    return _mode
+
+
 def workgroups(x_shape, c_out, variant=DEFAULT_VARIANT):
     B, _, H, W = x_shape
     return ((B * ((H + 1) // 2) * ((W + 1) // 2) + 63) // 64) * (c_out // (32 * VARIANTS[variant][1]))
@@ -27,8 +46,8 @@ def workgroups(x_shape, c_out, variant=DEFAULT_VARIANT):
 def takes(conv, x, u, variant=DEFAULT_VARIANT):
     """True if the Winograd kernel runs ``conv(x)`` for this bias-free 3x3 ``torch.nn.Conv2d``: ``u`` (its transformed filter)
     is there, the operands qualify and the launch fills the chip -- a rule on shapes, not a timing, so that every rank of a job
-    and every run take the same path (the two round differently); ``OPA_CONV3X3=conv|winograd`` forces one."""
-    forced = os.environ.get('OPA_CONV3X3', 'auto')
+    and every run take the same path (the two round differently); :func:`set_mode` (default: ``OPA_CONV3X3`` at import) forces one."""
+    forced = _mode
     return (u is not None and forced != 'conv' and u.dtype == torch.float32 and conv.bias is None
             and supported(x, conv.weight, variant, conv.stride, conv.padding, conv.groups, conv.dilation)
             and (forced == 'winograd' or workgroups(x.shape, conv.out_channels, variant) >= MIN_WORKGROUPS)

@@ -1,8 +1,6 @@
 """csrc/winograd.hip on the GPU: F(2x2, 3x3) against a float64 convolution (tolerance: 2e-5 of the output's largest
 magnitude; torch's own float32 convolution is printed beside it by tools/gpu/winograd_probe.py), every variant / workgroup
 order, ragged sizes (odd H / W, a last tile block of one tile), bias + ReLU, and the ResNet trunk with and without it."""
-import os
-
 import pytest
 import torch
 
@@ -52,19 +50,35 @@ def test_resnet_fields_with_and_without_winograd():
     from openpifpaf_amd import network, winograd
     net = network.optimize_for_inference_(network.factory('resnet50')).cuda().to(memory_format=torch.channels_last)
     x = torch.randn((2, 3, 321, 321), generator=torch.Generator().manual_seed(1)).cuda().contiguous(memory_format=torch.channels_last)
-    old = os.environ.get('OPA_CONV3X3')
+    old = winograd.set_mode('winograd')
     try:
         with torch.no_grad():
-            os.environ['OPA_CONV3X3'] = 'winograd'
             a = net(x)
-            os.environ['OPA_CONV3X3'] = 'conv'
+            winograd.set_mode('conv')
             b = net(x)
     finally:
-        if old is None:
-            os.environ.pop('OPA_CONV3X3', None)
-        else:
-            os.environ['OPA_CONV3X3'] = old
+        winograd.set_mode(old)
     for fa, fb in zip(a, b):
         raw_a, raw_b = torch.nan_to_num(fa), torch.nan_to_num(fb)
         assert not torch.equal(raw_a, raw_b)                  # (it did take the other path)
+        assert (raw_a - raw_b).abs().max().item() <= 1e-4 * raw_b.abs().max().item()
+
+
+def test_basic_block_networks_take_the_kernel_too():
+    """resnet18 (BasicBlock: two 3x3 convolutions per block) at a batch that fills the chip: fields within 1e-4 of the MIOpen trunk."""
+    from openpifpaf_amd import network, winograd
+    net = network.optimize_for_inference_(network.factory('resnet18')).cuda().to(memory_format=torch.channels_last)
+    assert sum(1 for m in net.modules() if hasattr(m, 'wino_u1')) == 5 and sum(1 for m in net.modules() if hasattr(m, 'wino_u2')) == 8
+    x = torch.randn((16, 3, 321, 321), generator=torch.Generator().manual_seed(2)).cuda().contiguous(memory_format=torch.channels_last)
+    old = winograd.set_mode('winograd')
+    try:
+        with torch.no_grad():
+            a = net(x)
+            winograd.set_mode('conv')
+            b = net(x)
+    finally:
+        winograd.set_mode(old)
+    for fa, fb in zip(a, b):
+        raw_a, raw_b = torch.nan_to_num(fa), torch.nan_to_num(fb)
+        assert not torch.equal(raw_a, raw_b)
         assert (raw_a - raw_b).abs().max().item() <= 1e-4 * raw_b.abs().max().item()

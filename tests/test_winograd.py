@@ -61,3 +61,16 @@ def test_bottlenecks_carry_the_transformed_filter_of_their_stride_one_convolutio
     assert not any(k.endswith('wino_u') for k in net.state_dict())        # derived data: not part of a checkpoint
     net.to(torch.bfloat16)                                                 # a bfloat16 network keeps MIOpen's convolution
     assert with_u[0].wino_u.dtype == torch.bfloat16
+
+
+def test_mode_switch():
+    old = winograd.set_mode('conv')
+    try:
+        assert winograd.get_mode() == 'conv'
+        conv = torch.nn.Conv2d(16, 64, 3, 1, 1, bias=False)
+        assert not winograd.takes(conv, torch.randn(1, 16, 6, 6), winograd.transform_filter(conv.weight))
+        with pytest.raises(ValueError):
+            winograd.set_mode('fast')
+    finally:
+        winograd.set_mode(old)
+    assert winograd.get_mode() == old
