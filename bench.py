@@ -196,6 +196,8 @@ def compact_roofline(roof):
     path = roof.get('decode_path') or {}
     out['decode_path_frac'] = path.get('frac')
     out['decode_path_ms'] = path.get('ms_per_batch')
+    if path.get('tie_pass_ms') == 0.0 and str(path.get('seed_tie_order', '')).startswith('libstdcxx'):
+        out['kernel_includes'] = 'seed tie pass (r5: own launch, 0.078 ms)'
     return out
 
 
@@ -624,10 +626,12 @@ def decode_roofline(wl, variants, params, steps, force_complete=False):
                         'frac': round(alg['decode_path'] / (decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                         'seed_tie_order': native_tie_order(),
                         'tie_pass_ms': round(avg_ms.get('cifseeds_tie_kernel', 0.0), 4),
-                        'tie_pass_note': 'cifseeds_tie_kernel puts seeds of EQUAL score into the order the reference\'s '
-                                         'unstable std::sort leaves them in; it costs this much only for batches that hold '
-                                         'such seeds (the synthetic blobs are symmetric: about one image in eight has an '
-                                         'equal pair) and a few microseconds otherwise; OPA_SEED_TIES=index removes it'},
+                        'tie_pass_note': 'the pass that puts seeds of EQUAL score into the order the reference\'s unstable std::sort '
+                                         'leaves them in runs INSIDE the association kernel since round 6 (tie_pass_ms 0: no '
+                                         'launch of its own; rounds 3-5: cifseeds_tie_kernel, 0.078 ms per batch of 32) -- the '
+                                         'dominant kernel\'s time includes it for the images that hold such seeds (the synthetic '
+                                         'blobs are symmetric: about one image in eight); opa_cifcaf_set_tie_placement(dec, 0) '
+                                         'brings the launch back'},
         'field_batches_alternating': len(variants),
     }
     return roofline

@@ -6,7 +6,9 @@
 // float32 MFMA runs at the vector rate).  F(2x2, 3x3) needs 16 multiplications per 2x2 outputs instead of 36: 2.25x fewer
 // MFMA flops, in float32 arithmetic throughout (the transforms are additions; G g G^T is computed once on the host in
 // float64).  Separate transform kernels would write and re-read the 4x larger transformed tensors (15 GB per layer-1
-// convolution) -- so one workgroup does all of it for 64 tiles x BN output channels:
+// convolution) -- so one workgroup does all of it for 64 tiles x BN output channels.  Four kernels share that plan: the
+// four-wave one described here (variants 0 / 1, the first version), the eight-wave one in two shifts that the Python side uses
+// (variant 2, further down: what the four-wave kernel leaves idle and why) and its persistent form (variant 3: measured slower).
 //   * 256 threads, four waves, wave w owns the four transform positions (xi = w, nu = 0..3) as 64 x BN accumulators each:
 //     v_mfma_f32_32x32x2f32, 4 x 2 x NB accumulator blocks of 16 registers (NB = 2: 256 accumulator registers, one wave per
 //     SIMD -- the float32 MFMA issues once per 64 cycles, one wave's other instructions fit into its shadow);
@@ -789,7 +791,8 @@ static hipError_t launch_wino(const float* x, const float* U, float* y, const fl
 
 // variant 0: 64 tiles x 64 channels, K-chunks of 16, one workgroup per compute unit (256 accumulator registers per lane);
 // variant 1: 64 tiles x 32 channels, K-chunks of 8, two workgroups per compute unit;
-// variant 2: variant 0's tile and filter layout, eight waves in two shifts.  The filter layout depends on the variant.
+// variant 2: variant 0's tile and filter layout, eight waves in two shifts (openpifpaf_amd.winograd.DEFAULT_VARIANT);
+// variant 3: variant 2 as persistent workgroups.  The filter layout depends on the variant (0, 2, 3 share one).
 hipError_t launch_winograd_f23(const float* x, const float* U, float* y, const float* bias, int N, int H, int W, int Cin,
                                int Cout, int relu, int variant, int nb_major, hipStream_t st) {
     if (variant == 0) return launch_wino<16, 2, 1>(x, U, y, bias, N, H, W, Cin, Cout, relu, nb_major, st);
