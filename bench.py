@@ -139,12 +139,18 @@ def algorithmic_bytes(B, F, A, H, W, stride, max_ann, K=None):
     }
 
 
+# producer-side kernels (the network's convolutions and epilogues): not launched by a decode, so an edit there does not
+# invalidate a traffic file measured on the decode kernels
+PRODUCER_SOURCES = ('dwconv.hip', 'epilogue.hip', 'gemm_epilogue.hip', 'gemm_f32.hip', 'head.hip', 'winograd.hip')
+
+
 def kernel_source_hash():
-    """Identifies the kernels a PMC traffic file was measured on (profiles/r3/pmc_traffic.json)."""
+    """Identifies the DECODE kernels a PMC traffic file was measured on (profiles/r*/pmc_traffic.json; the same function
+    stamps it: tools/summarize_profiles.py)."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, 'openpifpaf_amd', 'csrc')
     for name in sorted(os.listdir(csrc)):
-        if name.endswith(('.hip', '.hpp')):
+        if name.endswith(('.hip', '.hpp')) and name not in PRODUCER_SOURCES:
             h.update(open(os.path.join(csrc, name), 'rb').read())
     return h.hexdigest()[:16]
 
