@@ -30,6 +30,9 @@ constexpr int kF32BM = 128, kF32BK = 32, kF32Pitch = kF32BK + 4;      // LDS row
 #ifndef OPA_F32_WGS
 #define OPA_F32_WGS 3
 #endif
+#ifndef OPA_GEMM_DIAG              // timing experiments (wrong results): 1 no global loads in the K loop, 2 no LDS stores either,
+#define OPA_GEMM_DIAG 0            // 3 = 2 without the epilogue's residual load and output store
+#endif
 constexpr int kF32Stages = OPA_F32_STAGES;       // LDS stages (2: the next K-step is stored while this one multiplies)
 
 template <int BN, bool RES, bool RELU, bool PRO>
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256, BN == 128 ? OPA_F32_WGS : 3) void gemm_f32_bia
     int buf = 0;
     for (int k0 = 0; k0 < K; k0 += kF32BK, buf ^= (kF32Stages - 1)) {
         const bool more = k0 + kF32BK < K;
-        if (more) fetch(k0 + kF32BK);          // the next K-step's operands travel while this one multiplies
+        if (more && OPA_GEMM_DIAG == 0) fetch(k0 + kF32BK);          // the next K-step's operands travel while this one multiplies
         const float* sA = stage0 + buf * (LDS_A + LDS_B);
         const float* sB = sA + LDS_A;
 #pragma unroll
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256, BN == 128 ? OPA_F32_WGS : 3) void gemm_f32_bia
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][m], fb[j][m], acc[i][j], 0, 0, 0);
         }
         if (kF32Stages == 1) __syncthreads(); // one stage: every wave is done reading it
-        if (more) store(buf ^ (kF32Stages - 1)); // (two stages: the other one, whose readers passed the previous step's barrier)
+        if (more && OPA_GEMM_DIAG < 2) store(buf ^ (kF32Stages - 1)); // (two stages: the other one, whose readers passed the previous step's barrier)
         __syncthreads();
     }
     // (the loop's last barrier: staging LDS is free, reuse it for the epilogue)
@@ -181,7 +184,7 @@ __global__ __launch_bounds__(256, BN == 128 ? OPA_F32_WGS : 3) void gemm_f32_bia
 #pragma unroll
                     for (int e = 0; e < 4; e++) f[e] = fmaxf(f[e], 0.0f);
                 }
-                *reinterpret_cast<f32x4_t*>(out + (size_t)m * N + n0 + wn * WN + c4) = f;
+                if (OPA_GEMM_DIAG < 3 || f[0] == 12345.678f) *reinterpret_cast<f32x4_t*>(out + (size_t)m * N + n0 + wn * WN + c4) = f;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
