@@ -6,7 +6,8 @@
 #define OPA_SCORED_EAGER 0
 #endif
 #ifndef OPA_SCORED_PREFETCH
-#define OPA_SCORED_PREFETCH 1      // [r6] 250 -> 234 us at 256 images, wholebody 121 -> 110 (profiles/r6/cafscored_confidence_prefetch_ab.log; 0: round 5's loop)
+#define OPA_SCORED_PREFETCH 2      // [r6] 1: the next confidence one step ahead, 250 -> 234 us at 256 images, wholebody 121 -> 110; 2: two steps deep (the
+                                   // next cell's six planes too), 233 -> 223 / 110 -> 106.5 / 46.5 -> 43.7 at 32 images (profiles/r6/cafscored_*prefetch_ab.log); 0: round 5's loop
 #endif
 #include "common.hpp"
 
@@ -102,11 +103,31 @@ __device__ __forceinline__ void cafscored_plane(const ScoredArgs& s, int plane_i
     // under a condition): the first of a step's three dependent round trips is off its critical path
     float c_pre = P[1 * HW + (tid < HW ? tid : HW - 1)];
 #endif
+#if OPA_SCORED_PREFETCH == 2
+    // two steps deep: the confidence two steps ahead, so that the other six planes of the NEXT step's cell can be
+    // requested -- where its confidence passes -- while this step waits for its map gathers: one exposed round trip per step
+    float c_pre2 = P[1 * HW + (tid + kScoredThreads < HW ? tid + kScoredThreads : HW - 1)];
+    float q2 = 0.f, q3 = 0.f, q4 = 0.f, q5 = 0.f, q6 = 0.f, q7 = 0.f;
+    if (tid < HW && live && !((double)c_pre < score_th)) {
+        q2 = P[2 * HW + tid]; q3 = P[3 * HW + tid]; q4 = P[4 * HW + tid]; q5 = P[5 * HW + tid]; q6 = P[6 * HW + tid]; q7 = P[7 * HW + tid];
+    }
+#endif
     for (int c0 = 0; c0 < HW; c0 += kScoredThreads, parity ^= 1) {
         const int o = c0 + tid;
         bool keep_f = false, keep_b = false;
         float c = 0.f, cf = 0.f, cb = 0.f, x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f, s1 = 0.f, s2 = 0.f;
-#if OPA_SCORED_PREFETCH
+#if OPA_SCORED_PREFETCH == 2
+        const float c_now = c_pre;
+        const float p2 = q2, p3 = q3, p4 = q4, p5 = q5, p6 = q6, p7 = q7;
+        c_pre = c_pre2;
+        { const int on2 = o + 2 * kScoredThreads; c_pre2 = P[1 * HW + (on2 < HW ? on2 : HW - 1)]; }
+        {
+            const int on = o + kScoredThreads;
+            if (on < HW && live && !((double)c_pre < score_th)) {
+                q2 = P[2 * HW + on]; q3 = P[3 * HW + on]; q4 = P[4 * HW + on]; q5 = P[5 * HW + on]; q6 = P[6 * HW + on]; q7 = P[7 * HW + on];
+            }
+        }
+#elif OPA_SCORED_PREFETCH
         const float c_now = c_pre;
         { const int on = o + kScoredThreads; c_pre = P[1 * HW + (on < HW ? on : HW - 1)]; }
 #endif
@@ -122,8 +143,12 @@ __device__ __forceinline__ void cafscored_plane(const ScoredArgs& s, int plane_i
 #else
             c = P[1 * HW + o];
 #endif
+#if OPA_SCORED_PREFETCH == 2
+            const float r2 = p2, r3 = p3, r4 = p4, r5 = p5, r6 = p6, r7 = p7;
+#else
             const float r2 = P[2 * HW + o], r3 = P[3 * HW + o], r4 = P[4 * HW + o], r5 = P[5 * HW + o],
                         r6 = P[6 * HW + o], r7 = P[7 * HW + o];
+#endif
 #if OPA_SCORED_EAGER
             // (experiment: with the products computed out here the seven loads travel together)
             x1 = r2 * stride_f; y1 = r3 * stride_f; x2 = r4 * stride_f; y2 = r5 * stride_f; s1 = r6 * stride_f; s2 = r7 * stride_f;
