@@ -96,12 +96,16 @@ rep.update({
     'R6M1': thousands(lanes[(256, 1)]), 'R6M2': thousands(lanes[(256, 2)]), 'R6M4GB': '%.0f' % (m4 * 6.2546e-3), 'R6M4F': '%.2f' % (m4 * 6.2546e-3 / 8000), 'R6M4': thousands(m4),
     'R6AAV': thousands(c['all_active']['decode_only_images_per_s']), 'R6AA': '%.1f' % c['all_active']['ms_per_batch_wall'],
 })
+probe = open(os.path.join(P, 'probe_all_workloads.log')).read()
+m = re.search(r'--batch 256 [^\n]*\n(?:config[^\n]*\n)?[^\n]*decode ([\d.]+) ms[^\n]*\nwall: ([\d.]+) ms', probe)
+if m:
+    rep['R6X_EV'], rep['R6X_WALL'] = m.group(1), m.group(2) + ' = %s images/s' % thousands(256 / float(m.group(2)) * 1e3)
 path = os.path.join(ROOT, 'DESIGN.md')
 text = open(path).read()
 missing = [key for key in rep if key not in text]
 for key in sorted(rep, key=len, reverse=True):          # longest first: R6_A256 before R6_A32 before R6_A...
     text = text.replace(key, rep[key])
-left = sorted(set(re.findall(r'R6_?[A-Z][A-Z0-9]*', text)))
+left = sorted(set(re.findall(r'R6X?_?[A-Z][A-Z0-9_]*', text)))
 print('filled %d placeholders; not found in the text: %s; still unfilled: %s' % (len(rep) - len(missing), missing, left))
 if '--check' not in sys.argv:
     open(path, 'w').write(text)
