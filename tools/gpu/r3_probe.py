@@ -31,6 +31,7 @@ ap.add_argument('--bench-batches', action='store_true', help='with --alternate: 
 ap.add_argument('--flush', action='store_true', help='overwrite 1 GB before every timed call: the fields come from HBM, not the 256 MB Infinity Cache')
 ap.add_argument('--param', action='append', default=[], metavar='NAME=VALUE',
                 help='decoder parameter override (sensitivity experiments), e.g. --param reverse_match=0 --param greedy=1')
+ap.add_argument('--debug', action='append', default=[], metavar='NAME=VALUE', help='opa_debug switch of the decoder, e.g. --debug scored_one_pass=0')
 args = ap.parse_args()
 
 if args.config == 'wholebody':
@@ -54,6 +55,8 @@ for s in (((0, 100000) if args.bench_batches else (0, 1000)) if args.alternate e
     cifs, cafs = synth.synth_batch(B, seed0=s, **kw)
     batches.append((cifs, cafs, torch.from_numpy(cifs).cuda(), torch.from_numpy(cafs).cuda()))
 dec = native.CifCaf(K, torch.from_numpy(skel0))
+if args.debug:
+    dec.set_debug(**{kv.split('=', 1)[0]: (float(kv.split('=', 1)[1]) if '.' in kv else int(kv.split('=', 1)[1])) for kv in args.debug})
 for i in range(3):
     _, _, cd, fd = batches[i % len(batches)]
     out, ids, counts = dec.call_batch(cd, 8, fd, 8, params=params)
