@@ -141,7 +141,23 @@ def algorithmic_bytes(B, F, A, H, W, stride, max_ann, K=None):
 
 # producer-side kernels (the network's convolutions and epilogues): not launched by a decode, so an edit there does not
 # invalidate a traffic file measured on the decode kernels
-PRODUCER_SOURCES = ('dwconv.hip', 'epilogue.hip', 'gemm_epilogue.hip', 'gemm_f32.hip', 'head.hip', 'winograd.hip')
+PRODUCER_SOURCES = ('dwconv.hip', 'epilogue.hip', 'gemm_epilogue.hip', 'gemm_f32.hip', 'gemm_f32x3.hip', 'head.hip', 'winograd.hip')
+
+
+def _conv1x1_text(primary):
+    """What the float32 1x1 convolutions ran on (openpifpaf_amd.fused: the choice table, after the legs have run)."""
+    if primary != 'fp32':
+        return 'bf16 MFMA GEMM, fused epilogue'
+    try:
+        from openpifpaf_amd import fused
+        ch = [v for k, v in fused.choices().items() if k[0] == 'torch.float32']
+        n3 = sum(1 for v in ch if v == 'gemm3')
+        if n3 and fused.X3_TERMS:
+            return ('f32 in/out; %d of %d shapes: operands split exactly into 3 bf16 pieces, %d of the 9 exact partial products on the '
+                    'bf16 MFMA, f32 accumulators (error vs f64 below the f32 MFMA kernel\'s); the rest: f32 MFMA' % (n3, len(ch), fused.X3_TERMS))
+    except Exception:          # noqa: BLE001
+        pass
+    return 'f32 MFMA GEMM, fused epilogue'
 
 
 def kernel_source_hash():
@@ -259,7 +275,7 @@ def compact_line(detail):
     line = _pick(detail, ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
                           'scaling', 'vs_baseline', 'dtype', 'data'))
     cfg = detail.get('config') or {}
-    line['config'] = _pick(cfg, ('workload', 'backbone', 'backbone_dtype', 'conv3x3', 'decode_dtype', 'global_batch', 'batch_per_gpu',
+    line['config'] = _pick(cfg, ('workload', 'backbone', 'backbone_dtype', 'conv3x3', 'conv1x1', 'decode_dtype', 'global_batch', 'batch_per_gpu',
                                  'parallelism', 'force_complete_pose'))
     line['roofline'] = compact_roofline(detail.get('roofline'))
     line['cpu_baseline'] = compact_cpu(detail.get('cpu_baseline'))
@@ -925,6 +941,7 @@ def main():
                 'backbone': 'none (decode only)' if decode_only else wl.backbone,
                 'backbone_dtype': primary, 'decode_dtype': 'f32 (+f64 where the reference uses double)',
                 'conv3x3': ('winograd F(2x2,3x3) f32 for the stride-1 ones' if wino.get(primary) else 'direct (MIOpen)'),
+                'conv1x1': _conv1x1_text(primary),
                 'global_batch': world * wl.B, 'batch_per_gpu': wl.B,
                 'fields': ('COCO-shaped synthetic fields injected after the heads (people per image cycle %s); %d different '
                            'field batches alternate step by step' % (list(wl.people), len(wl.variants)))

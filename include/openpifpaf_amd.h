@@ -389,6 +389,16 @@ int opa_gemm_bias_act_f32(const float* a_dev, const float* a_bias_dev, const flo
                           const float* residual_dev, float* out_dev, int64_t m, int32_t n, int32_t k,
                           int32_t relu, void* stream);
 
+/* The float32 GEMM above on the bfloat16 MFMA pipe with NOTHING of either operand dropped (csrc/gemm_f32x3.hip): a float32 is
+ * exactly the sum of three bfloat16 (its 24-bit significand cut into 8 + 8 + 8 bits), so a * b is the sum of nine bf16 x bf16
+ * products, each exact in the float32 accumulator.  w3_dev = the weight split on the host ([3][N][K] bfloat16:
+ * openpifpaf_amd.fused.split_weight), the activation is split while its tile is staged.  terms = 9: all nine products (the
+ * only rounding left is the accumulation's, as in any float32 GEMM); 6: without the three smallest (< 2^-23 of a product each).
+ * float32 in, float32 out; K % 64 == 0, N % 64 == 0, pointers 16-B aligned; a_bias_dev / residual_dev may be NULL. */
+int opa_gemm_bias_act_f32x3(const float* a_dev, const float* a_bias_dev, const void* w3_dev, const float* bias_dev,
+                            const float* residual_dev, float* out_dev, int64_t m, int32_t n, int32_t k,
+                            int32_t relu, int32_t terms, void* stream);
+
 /* 3x3 convolution, stride 1, padding 1, of an NHWC float32 activation as Winograd F(2x2, 3x3) in ONE kernel (input
  * transform -> sixteen float32 MFMA GEMMs -> output transform; csrc/winograd.hip): the bottleneck convolutions of the
  * ResNet trunk (reference network/basenetworks.py:71-150 runs them through torch.nn.Conv2d), 2.25x fewer multiplications

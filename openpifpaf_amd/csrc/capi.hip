@@ -918,6 +918,24 @@ int opa_gemm_bias_act_f32(const float* a_dev, const float* a_bias_dev, const flo
     return OPA_OK;
 }
 
+int opa_gemm_bias_act_f32x3(const float* a_dev, const float* a_bias_dev, const void* w3_dev, const float* bias_dev,
+                            const float* residual_dev, float* out_dev, int64_t m, int32_t n, int32_t k,
+                            int32_t relu, int32_t terms, void* stream) {
+    if (!a_dev || !w3_dev || !bias_dev || !out_dev || m < 0 || n <= 0 || k <= 0 || m > 0x7fffffffll || (terms != 6 && terms != 9))
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_gemm_bias_act_f32x3: bad arguments");
+    if (k % 64 != 0 || n % 64 != 0)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_gemm_bias_act_f32x3: K and N must be multiples of 64");
+    if (((uintptr_t)a_dev | (uintptr_t)a_bias_dev | (uintptr_t)w3_dev | (uintptr_t)out_dev | (uintptr_t)residual_dev |
+         (uintptr_t)bias_dev) & 15)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_gemm_bias_act_f32x3: pointers must be 16-B aligned");
+    if (m == 0) return OPA_OK;
+    hipError_t e = launch_gemm_f32x3_bias_act(a_dev, (const unsigned short*)w3_dev, bias_dev, residual_dev, out_dev, (int)m, n, k,
+                                              relu, terms, (hipStream_t)stream, a_bias_dev);
+    if (e != hipSuccess) return fail_hip(e, "gemm_f32x3_bias_act");
+    prof_mark((hipStream_t)stream, "gemm_f32x3_bias_act_kernel");
+    return OPA_OK;
+}
+
 int opa_conv3x3_winograd_f32(const float* x_dev, const float* u_dev, const float* bias_dev, float* out_dev, int32_t batch,
                              int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t relu, int32_t variant,
                              int32_t order, void* stream) {

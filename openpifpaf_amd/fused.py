@@ -100,7 +100,60 @@ def conv1x1_bias_act(x, weight2d, bias, residual=None, relu=True, a_bias=None):
     return out
 
 
-# (dtype, M, K, N, has_residual, has_a_bias) -> 'gemm' | 'pass+gemm' | 'conv'.  The three paths round
+def split_weight(weight2d):
+    """``[N, K]`` float32 -> ``[3, N, K]`` bfloat16: the three pieces of every weight (its 24-bit significand cut into 8 + 8 + 8
+    bits: ``w1`` = ``w`` with the low 16 bits cleared, ``r = w - w1``, ``w2`` = ``r`` with the low 16 bits cleared, ``w3 = r - w2``;
+    every step is exact and ``w1 + w2 + w3 == w`` bit for bit) -- the operand of ``opa_gemm_bias_act_f32x3`` (``csrc/gemm_f32x3.hip``)."""
+    w = weight2d.detach().to(torch.float32).contiguous()
+
+    def top(x):
+        return (x.view(torch.int32) & -65536).view(torch.float32)
+    w1 = top(w)
+    r1 = w - w1
+    w2 = top(r1)
+    w3 = r1 - w2
+    out = torch.stack((w1, w2, w3)).to(torch.bfloat16)          # (exact: each piece has at most 8 significant bits)
+    return out.contiguous()
+
+
+def conv1x1_bias_act_x3(x, w3, bias, residual=None, relu=True, a_bias=None, terms=9):
+    """``conv1x1_bias_act`` for float32 through the split-operand kernel: ``w3`` = ``split_weight(weight2d)``; ``terms`` 9 or 6."""
+    B, K, H, W = x.shape
+    N = w3.shape[1]
+    out = torch.empty((B, N, H, W), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().opa_gemm_bias_act_f32x3(
+        ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(a_bias.data_ptr()) if a_bias is not None else None,
+        ctypes.c_void_p(w3.data_ptr()), ctypes.c_void_p(bias.data_ptr()),
+        ctypes.c_void_p(residual.data_ptr()) if residual is not None else None,
+        ctypes.c_void_p(out.data_ptr()), B * H * W, N, K, int(bool(relu)), int(terms),
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'opa_gemm_bias_act_f32x3')
+    return out
+
+
+# float32 1x1 convolutions may take the split-operand kernel (choice 'gemm3'): float32 in and out, every product formed from
+# the operands' three bfloat16 pieces on the bf16 MFMA pipe (csrc/gemm_f32x3.hip).  X3_TERMS = 6 leaves out the three smallest of
+# the nine partial products (< 2^-23 of a product each); measured error against float64 BELOW the float32 MFMA kernel's and
+# torch's own float32 convolution on every ResNet-50 shape (tools/gpu/gemm_x3_probe.py, tests/test_gpu_gemm_x3.py).
+# OPA_GEMM3=0 (or fused.X3_TERMS = 0) takes the choice away.
+X3_TERMS = {'0': 0, '6': 6, '9': 9}.get(os.environ.get('OPA_GEMM3', '6'), 6)
+
+
+def _x3_supported(x, weight):
+    return X3_TERMS in (6, 9) and x.dtype == torch.float32 and weight.shape[1] % 64 == 0
+
+
+def _split_weight_of(conv, w2d):
+    """``split_weight(w2d)``, computed once per convolution and kept on the module (inference: the weight does not change; a weight
+    replaced or moved since is split again)."""
+    key = (w2d.data_ptr(), w2d._version, str(w2d.device))
+    cached = getattr(conv, '_opa_w3', None)
+    if cached is None or cached[0] != key:
+        cached = (key, split_weight(w2d))
+        conv._opa_w3 = cached
+    return cached[1]
+
+
+# (dtype, M, K, N, has_residual, has_a_bias) -> 'gemm' | 'gemm3' | 'pass+gemm' | 'conv'.  The three paths round
 # differently, so the choice is part of the result: it is made once per shape (the key holds no device index: a
 # table exported on rank 0 must match the lookups of every other rank), never by timing while a stream is being
 # captured (timing synchronises; the capture-time default is remembered, so a captured graph and a later eager
@@ -185,6 +238,9 @@ def conv_bias_act(conv, x, bias, residual=None, relu=True, a_bias=None):
                 choice = _CHOICE[key] = 'gemm'
         if choice is None:
             times = {'gemm': _time_ms(lambda: conv1x1_bias_act(x, w2d, bias, residual, relu, a_bias))}
+            if _x3_supported(x, w):
+                w3 = _split_weight_of(conv, w2d)
+                times['gemm3'] = _time_ms(lambda: conv1x1_bias_act_x3(x, w3, bias, residual, relu, a_bias, X3_TERMS))
             if a_bias is None:
                 times['conv'] = _time_ms(lambda: bias_act_(conv(x), bias, residual, relu))
             else:       # timing only: the separate epilogue pass runs on a scratch copy
@@ -193,6 +249,10 @@ def conv_bias_act(conv, x, bias, residual=None, relu=True, a_bias=None):
                     lambda: conv1x1_bias_act(bias_act_(scratch, a_bias), w2d, bias, residual, relu))
                 times['conv'] = _time_ms(lambda: bias_act_(conv(bias_act_(scratch, a_bias)), bias, residual, relu))
             choice = _CHOICE[key] = min(times, key=times.get)
+        if choice == 'gemm3' and not _x3_supported(x, w):
+            choice = 'gemm'                  # (switched off after the table was made: the float32 MFMA kernel)
+        if choice == 'gemm3':
+            return conv1x1_bias_act_x3(x, _split_weight_of(conv, w2d), bias, residual, relu, a_bias, X3_TERMS)
         if choice == 'gemm':
             return conv1x1_bias_act(x, w2d, bias, residual, relu, a_bias)
         if choice == 'pass+gemm':     # the prologue's VALU work is repeated per N-tile: cheaper as its own pass here

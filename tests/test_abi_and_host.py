@@ -401,3 +401,18 @@ def test_seed_tie_order_setting_and_workspace_view():
     # the stage-level entry point asks for its scratch: keys + the tie pass's arrays
     cells = 17 * 81 * 81
     assert L.opa_cifseeds_scratch_bytes(1, 17, 81, 81) >= 8 * cells + 16 * cells
+
+
+def test_split_weight_is_exact_on_the_cpu():
+    """``fused.split_weight``: every float32 weight is, bit for bit, the sum of its three bfloat16 pieces (the operand of the
+    split-operand GEMM, csrc/gemm_f32x3.hip) -- including denormal-free extremes, zeros and negative numbers."""
+    torch = pytest.importorskip('torch')
+    from openpifpaf_amd import fused
+    torch.manual_seed(0)
+    w = torch.randn(64, 128) * torch.logspace(-6, 6, 128)
+    w[0, :4] = torch.tensor([0.0, -0.0, 1.0, -1.0])
+    w[1, :3] = torch.tensor([3.4028234e38, -1.1754944e-38 * 70000, 1.0 + 2.0 ** -23])
+    w3 = fused.split_weight(w)
+    assert w3.dtype == torch.bfloat16 and tuple(w3.shape) == (3, 64, 128)
+    assert torch.equal((w3[0].float() + w3[1].float()) + w3[2].float(), w)
+    assert float(w3[1].float().abs().max() / w.abs().max()) < 2.0 ** -7 and float((w3[2].float().abs() / w.abs().clamp_min(1e-30)).max()) < 2.0 ** -15

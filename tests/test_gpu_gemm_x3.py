@@ -1,0 +1,102 @@
+"""The float32 1x1 convolution on the bf16 MFMA pipe with both operands split into three bfloat16 pieces
+(csrc/gemm_f32x3.hip, ``opa_gemm_bias_act_f32x3``): float32 in, float32 out, and -- the point of the test -- an error against a
+float64 product that is NOT above the float32 MFMA kernel's (csrc/gemm_f32.hip) nor torch's own float32 convolution."""
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+def _case(cin, cout, hw, with_res, pro, seed=3):
+    torch.manual_seed(seed)
+    B = 3                                   # M = 3*hw*hw is not a multiple of the 128-row tile
+    x = torch.randn(B, cin, hw, hw, device='cuda').contiguous(memory_format=torch.channels_last)
+    if not pro:
+        x = x.clamp_(min=0)                 # what the kernel sees in the network: post-ReLU activations
+    w = torch.randn(cout, cin, device='cuda') * (2.0 / cin) ** 0.5
+    bias = torch.randn(cout, device='cuda') * 0.1
+    res = torch.randn(B, cout, hw, hw, device='cuda').contiguous(memory_format=torch.channels_last) if with_res else None
+    a_bias = torch.randn(cin, device='cuda') * 0.3 if pro else None
+    xa = x.double()
+    if pro:
+        xa = (xa + a_bias.double().view(1, -1, 1, 1)).clamp_(min=0)
+    ref = torch.nn.functional.conv2d(xa, w.double().view(cout, cin, 1, 1), bias.double())
+    if with_res:
+        ref = ref + res.double()
+    return x, w, bias, res, a_bias, ref.clamp_(min=0)
+
+
+def _rms(out, ref):
+    d = out.double() - ref
+    return float((d * d).mean().sqrt()) / float(ref.abs().max())
+
+
+@pytest.mark.parametrize('cin,cout,hw,with_res,pro', [(1024, 256, 27, False, False), (256, 1024, 27, True, False),
+                                                      (2048, 512, 13, False, False), (512, 2048, 13, True, True),
+                                                      (64, 64, 23, False, False), (128, 512, 19, True, True)])
+@pytest.mark.parametrize('terms', [6, 9])
+def test_split_operand_gemm_is_at_least_as_exact_as_the_float32_mfma(cin, cout, hw, with_res, pro, terms):
+    from openpifpaf_amd import fused
+    x, w, bias, res, a_bias, ref = _case(cin, cout, hw, with_res, pro)
+    w3 = fused.split_weight(w)
+    assert w3.dtype == torch.bfloat16 and tuple(w3.shape) == (3, cout, cin)
+    assert torch.equal(w3.float().sum(0), w) and torch.equal((w3[0].float() + w3[1].float()) + w3[2].float(), w)
+    got = fused.conv1x1_bias_act_x3(x, w3, bias, res, True, a_bias, terms)
+    native = fused.conv1x1_bias_act(x, w, bias, res, True, a_bias)
+    assert got.dtype == torch.float32 and got.is_contiguous(memory_format=torch.channels_last)
+    e_got, e_native = _rms(got, ref), _rms(native, ref)
+    assert e_got <= 1.05 * e_native + 1e-9, (e_got, e_native)        # measured: 0.35-0.75 of the float32 MFMA's error
+    assert e_got < 2e-7, e_got
+    assert float((got.double() - ref).abs().max()) / float(ref.abs().max()) < 2e-6
+
+
+def test_split_operand_gemm_rejects_what_it_cannot_run():
+    import ctypes
+    from openpifpaf_amd import _lib, fused
+    x, w, bias, _, _, _ = _case(96, 64, 9, False, False)             # K = 96 is not a multiple of 64
+    w3 = fused.split_weight(w)
+    out = torch.empty((3, 64, 9, 9), device='cuda').contiguous(memory_format=torch.channels_last)
+    rc = _lib.lib().opa_gemm_bias_act_f32x3(ctypes.c_void_p(x.data_ptr()), None, ctypes.c_void_p(w3.data_ptr()),
+                                            ctypes.c_void_p(bias.data_ptr()), None, ctypes.c_void_p(out.data_ptr()), 243, 64, 96, 1, 6,
+                                            None)
+    assert rc != 0
+    x, w, bias, _, _, _ = _case(64, 64, 9, False, False)
+    rc = _lib.lib().opa_gemm_bias_act_f32x3(ctypes.c_void_p(x.data_ptr()), None, ctypes.c_void_p(fused.split_weight(w).data_ptr()),
+                                            ctypes.c_void_p(bias.data_ptr()), None, ctypes.c_void_p(out.data_ptr()), 243, 64, 64, 1, 7,
+                                            None)
+    assert rc != 0                                                  # terms is 6 or 9
+
+
+def test_resnet50_trunk_with_and_without_the_split_operand_kernel():
+    """The whole float32 trunk: the heads agree within 1e-4 of their largest magnitude whichever kernel the 1x1 convolutions take
+    (the bar the Winograd kernel was held to), and the 'gemm3' choice is really taken."""
+    from openpifpaf_amd import fused, network
+    torch.manual_seed(5)
+    net = network.factory('resnet50').cuda()
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.1)
+            m.running_var.uniform_(0.5, 1.5)
+    network.optimize_for_inference_(net)
+    net = net.to(memory_format=torch.channels_last)
+    x = torch.randn((2, 3, 193, 161), device='cuda').contiguous(memory_format=torch.channels_last)
+    saved, terms = fused.choices(), fused.X3_TERMS
+    try:
+        fused.X3_TERMS = 6
+        fused.set_choices({k: 'gemm' for k in saved}, replace=True)
+        with torch.no_grad():
+            fused.set_choices({}, replace=True)
+            import os
+            os.environ['OPA_CONV1X1'] = 'gemm'
+            a = net(x)
+            forced = {k: 'gemm3' for k, v in fused.choices().items() if k[0] == 'torch.float32' and k[2] % 64 == 0}
+            assert forced
+            fused.set_choices(forced)
+            b = net(x)
+        for u, v in zip(a, b):
+            assert float((u - v).abs().max()) <= 1e-4 * float(u.abs().max()), float((u - v).abs().max())
+        assert not all(torch.equal(u, v) for u, v in zip(a, b))      # (another kernel did run)
+    finally:
+        os.environ.pop('OPA_CONV1X1', None)
+        fused.X3_TERMS = terms
+        fused.set_choices(saved, replace=True)
