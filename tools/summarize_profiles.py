@@ -137,7 +137,7 @@ for key, title, cfg, B, fc in WORKLOADS:
     stats[key] = kernel_stats(os.path.join(key, 'stats'), '%s -- %s' % (key, title))
 
 # (the hash of the DECODE kernels' sources, as bench.kernel_source_hash computes it: producer-side files do not count)
-PRODUCER_SOURCES = ('dwconv.hip', 'epilogue.hip', 'gemm_epilogue.hip', 'gemm_f32.hip', 'head.hip', 'winograd.hip')
+PRODUCER_SOURCES = ('dwconv.hip', 'epilogue.hip', 'gemm_epilogue.hip', 'gemm_f32.hip', 'gemm_f32x3.hip', 'head.hip', 'winograd.hip')
 h = hashlib.sha256()
 csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'openpifpaf_amd', 'csrc')
 for n in sorted(os.listdir(csrc)):
