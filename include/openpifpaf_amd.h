@@ -399,6 +399,17 @@ int opa_gemm_bias_act_f32x3(const float* a_dev, const float* a_bias_dev, const v
                             const float* residual_dev, float* out_dev, int64_t m, int32_t n, int32_t k,
                             int32_t relu, int32_t terms, void* stream);
 
+/* Two 1x1 convolutions that are added -- the last convolution of a ResNet block and the block's downsampling convolution
+ * (reference network/basenetworks.py:71-150: torchvision's Bottleneck, out = relu(bn3(conv3(h)) + downsample(x))) -- as ONE product
+ * of the same kernel:  out[B, ho, wo, N] = act([a1 | a2 at stride] * w3cat^T + bias),  a1 [B*ho*wo, k1] (the block's inner
+ * activation), a2 [B, h_in, w_in, k2] channels-last (the block's input; output pixel (y, x) reads input pixel (stride*y,
+ * stride*x), ho = (h_in - 1) / stride + 1), w3cat = split_weight of the two weights concatenated along K ([3][N][k1 + k2]),
+ * a_bias_dev [k1 + k2] or NULL (relu(. + a_bias) on the operand: zeros behind k1 leave the non-negative a2 as it is).  The
+ * identity tensor is neither written nor read back.  k1 % 32 == 0, (k1 + k2) % 64 == 0, k2 % 4 == 0, N % 64 == 0. */
+int opa_gemm2_bias_act_f32x3(const float* a1_dev, int32_t k1, const float* a2_dev, int32_t k2, int32_t batch, int32_t h_in,
+                             int32_t w_in, int32_t stride, const float* a_bias_dev, const void* w3cat_dev, const float* bias_dev,
+                             float* out_dev, int32_t n, int32_t relu, int32_t terms, void* stream);
+
 /* 3x3 convolution, stride 1, padding 1, of an NHWC float32 activation as Winograd F(2x2, 3x3) in ONE kernel (input
  * transform -> sixteen float32 MFMA GEMMs -> output transform; csrc/winograd.hip): the bottleneck convolutions of the
  * ResNet trunk (reference network/basenetworks.py:71-150 runs them through torch.nn.Conv2d), 2.25x fewer multiplications

@@ -936,6 +936,26 @@ int opa_gemm_bias_act_f32x3(const float* a_dev, const float* a_bias_dev, const v
     return OPA_OK;
 }
 
+int opa_gemm2_bias_act_f32x3(const float* a1_dev, int32_t k1, const float* a2_dev, int32_t k2, int32_t batch, int32_t h_in,
+                             int32_t w_in, int32_t stride, const float* a_bias_dev, const void* w3cat_dev, const float* bias_dev,
+                             float* out_dev, int32_t n, int32_t relu, int32_t terms, void* stream) {
+    if (!a1_dev || !a2_dev || !w3cat_dev || !bias_dev || !out_dev || batch <= 0 || h_in <= 0 || w_in <= 0 || stride < 1 || n <= 0 ||
+        k1 <= 0 || k2 <= 0 || (terms != 6 && terms != 9))
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_gemm2_bias_act_f32x3: bad arguments");
+    if (k1 % 32 != 0 || (k1 + k2) % 64 != 0 || k2 % 4 != 0 || n % 64 != 0)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_gemm2_bias_act_f32x3: k1 % 32, (k1 + k2) % 64, k2 % 4, N % 64 must be 0");
+    if (((uintptr_t)a1_dev | (uintptr_t)a2_dev | (uintptr_t)a_bias_dev | (uintptr_t)w3cat_dev | (uintptr_t)out_dev | (uintptr_t)bias_dev) & 15)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_gemm2_bias_act_f32x3: pointers must be 16-B aligned");
+    const long long ho = (h_in - 1) / stride + 1, wo = (w_in - 1) / stride + 1;
+    if ((long long)batch * ho * wo > 0x7fffffffll || (long long)batch * h_in * w_in > 0x7fffffffll)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_gemm2_bias_act_f32x3: too many pixels");
+    hipError_t e = launch_gemm2_f32x3_bias_act(a1_dev, k1, a2_dev, k2, batch, h_in, w_in, stride, (const unsigned short*)w3cat_dev,
+                                               bias_dev, out_dev, n, relu, terms, (hipStream_t)stream, a_bias_dev);
+    if (e != hipSuccess) return fail_hip(e, "gemm2_f32x3_bias_act");
+    prof_mark((hipStream_t)stream, "gemm2_f32x3_bias_act_kernel");
+    return OPA_OK;
+}
+
 int opa_conv3x3_winograd_f32(const float* x_dev, const float* u_dev, const float* bias_dev, float* out_dev, int32_t batch,
                              int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t relu, int32_t variant,
                              int32_t order, void* stream) {

@@ -61,10 +61,21 @@ __device__ __forceinline__ void split4(const f32x4_t a, u32x2_t& p1, u32x2_t& p2
     p3[0] = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u); p3[1] = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
 }
 
-template <int BN, bool RES, bool RELU, bool PRO, int TERMS>
+// A SECOND activation behind the first along K (TWO): out = act([A | A2'] * W^T + bias) with A2'[m] = the pixel of A2 that
+// output pixel m reads through a 1x1 convolution of stride `stride` -- the last 1x1 convolution of a ResNet block and the
+// block's downsampling convolution as ONE product (the weights concatenated along K on the host), so that the identity tensor
+// is neither written nor read back.  Columns [0, K1) come from A (row length K1), [K1, K) from A2 (row length K - K1).
+struct X3Second {
+    const float* A2;           // [B, hi, wi, K - K1] channels-last, or null
+    int K1;                    // columns of the first activation (a multiple of the K-step)
+    int ho_wo, wo, hi_wi, wi, stride;
+};
+
+template <int BN, bool RES, bool RELU, bool PRO, int TERMS, bool TWO>
 __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
         const float* __restrict__ A, const unsigned short* __restrict__ W3, const float* __restrict__ bias,
-        const float* __restrict__ res, float* __restrict__ out, int M, int N, int K, const float* __restrict__ a_bias) {
+        const float* __restrict__ res, float* __restrict__ out, int M, int N, int K, const float* __restrict__ a_bias,
+        const X3Second sec) {
     constexpr int WN = BN / 2;                 // wave tile width
     constexpr int NT = WN / 32;                // 32-wide MFMA blocks per wave in N (2 or 1)
     constexpr int LDS_A = kX3BM * kX3Pitch, LDS_B = BN * kX3Pitch;        // bf16 elements of ONE plane
@@ -110,8 +121,26 @@ __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
     // destination, which made each K-step wait for all loads in flight before it could issue its own)
     // (buffer loads: a descriptor in scalar registers, ONE 32-bit byte offset per load, the K-step as the scalar offset)
     const int rows_here = M - m0 < kX3BM ? M - m0 : kX3BM;
-    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(A + (size_t)m0 * K), 0, (int)((size_t)rows_here * K * 4), 0x00020000);
+    const int KA = TWO ? sec.K1 : K;           // row length of the first activation
+    const float* a1_base = A + (size_t)m0 * KA;
+    const int a1_bytes = (int)((size_t)rows_here * KA * 4);
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a1_base), 0, a1_bytes, 0x00020000);
+    // the second activation: its rows are the input pixels the tile's output pixels read (monotonic in m: offsets from the first)
+    const int K2 = K - KA;
+    auto in_row = [&](int m) -> long long {
+        const int b = m / sec.ho_wo, r = m - b * sec.ho_wo, oy = r / sec.wo, ox = r - oy * sec.wo;
+        return (long long)b * sec.hi_wi + (long long)oy * sec.stride * sec.wi + (long long)ox * sec.stride;
+    };
+    long long row0_2 = 0;
+    const float* a2_base = nullptr;
+    int a2_bytes = 0;
+    unsigned pa2[NPA];
+    if constexpr (TWO) {
+        row0_2 = in_row(__builtin_amdgcn_readfirstlane(m0));
+        const int m_end = m0 + rows_here - 1;
+        a2_base = sec.A2 + (size_t)row0_2 * K2;
+        a2_bytes = (int)((size_t)(in_row(__builtin_amdgcn_readfirstlane(m_end)) - row0_2 + 1) * K2 * 4);
+    }
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short*>(W3 + (size_t)n0 * K), 0, (int)(((size_t)3 * N - n0) * K * 2), 0x00020000);
     unsigned pa[NPA], pb[WV];
@@ -120,7 +149,8 @@ __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
     for (int p = 0; p < NPA; p++) {            // rows past M read row M - 1 (valid memory; the epilogue never stores them)
         int m = m0 + p * RPP + s_row;
         if (m > M - 1) m = M - 1;
-        pa[p] = ((unsigned)(m - m0) * (unsigned)K + (unsigned)s_col) * 4u;
+        pa[p] = ((unsigned)(m - m0) * (unsigned)KA + (unsigned)s_col) * 4u;
+        if constexpr (TWO) pa2[p] = ((unsigned)(in_row(m) - row0_2) * (unsigned)K2 + (unsigned)s_col) * 4u;
     }
 #pragma unroll
     for (int t = 0; t < WV; t++) {
@@ -130,8 +160,18 @@ __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
         sb_off[t] = plane * LDS_B + row * kX3Pitch + c;
     }
     auto fetch_a = [&](f32x4_t (&ra)[NPA], int k0) {      // global -> registers for K-step k0 (with the operand prologue)
+        if constexpr (TWO) {                   // (uniform selects, no branch around the loads)
+            const bool second = k0 >= KA;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(second ? a2_base : a1_base), 0, second ? a2_bytes : a1_bytes, 0x00020000);
+            const int ks = (second ? k0 - KA : k0) * 4;
 #pragma unroll
-        for (int p = 0; p < NPA; p++) ra[p] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, pa[p], k0 * 4, 0));
+            for (int p = 0; p < NPA; p++)
+                ra[p] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, second ? pa2[p] : pa[p], ks, 0));
+        } else {
+#pragma unroll
+            for (int p = 0; p < NPA; p++) ra[p] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, pa[p], k0 * 4, 0));
+        }
         if (PRO) {                             // the preceding convolution's bias + ReLU, applied to the raw operand
             const f32x4_t ab = *reinterpret_cast<const f32x4_t*>(a_bias + k0 + s_col);
 #pragma unroll
@@ -277,33 +317,48 @@ __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
 
 template <int BN, bool PRO, int TERMS>
 static hipError_t launch_x3_bn(const float* a, const unsigned short* w, const float* b, const float* r, float* o,
-                               int M, int N, int K, int relu, const float* ab, hipStream_t st) {
+                               int M, int N, int K, int relu, const float* ab, hipStream_t st, const X3Second& sec) {
     const long long blocks = (long long)((M + kX3BM - 1) / kX3BM) * (N / BN);
-    if (r) {
-        if (relu) gemm_f32x3_bias_act_kernel<BN, true, true, PRO, TERMS><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab);
-        else gemm_f32x3_bias_act_kernel<BN, true, false, PRO, TERMS><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab);
+    if (sec.A2) {                              // (the pair has no residual: the second activation IS the identity branch)
+        if (relu) gemm_f32x3_bias_act_kernel<BN, false, true, PRO, TERMS, true><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, nullptr, o, M, N, K, ab, sec);
+        else gemm_f32x3_bias_act_kernel<BN, false, false, PRO, TERMS, true><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, nullptr, o, M, N, K, ab, sec);
+    } else if (r) {
+        if (relu) gemm_f32x3_bias_act_kernel<BN, true, true, PRO, TERMS, false><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab, sec);
+        else gemm_f32x3_bias_act_kernel<BN, true, false, PRO, TERMS, false><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab, sec);
     } else {
-        if (relu) gemm_f32x3_bias_act_kernel<BN, false, true, PRO, TERMS><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab);
-        else gemm_f32x3_bias_act_kernel<BN, false, false, PRO, TERMS><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab);
+        if (relu) gemm_f32x3_bias_act_kernel<BN, false, true, PRO, TERMS, false><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab, sec);
+        else gemm_f32x3_bias_act_kernel<BN, false, false, PRO, TERMS, false><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab, sec);
     }
     return hipGetLastError();
 }
 
 template <int TERMS>
 static hipError_t launch_x3_terms(const float* A, const unsigned short* W3, const float* bias, const float* res, float* out,
-                                  int M, int N, int K, int relu, hipStream_t st, const float* a_bias) {
+                                  int M, int N, int K, int relu, hipStream_t st, const float* a_bias, const X3Second& sec) {
     if (a_bias) {
-        if (N % 128 == 0) return launch_x3_bn<128, true, TERMS>(A, W3, bias, res, out, M, N, K, relu, a_bias, st);
-        return launch_x3_bn<64, true, TERMS>(A, W3, bias, res, out, M, N, K, relu, a_bias, st);
+        if (N % 128 == 0) return launch_x3_bn<128, true, TERMS>(A, W3, bias, res, out, M, N, K, relu, a_bias, st, sec);
+        return launch_x3_bn<64, true, TERMS>(A, W3, bias, res, out, M, N, K, relu, a_bias, st, sec);
     }
-    if (N % 128 == 0) return launch_x3_bn<128, false, TERMS>(A, W3, bias, res, out, M, N, K, relu, nullptr, st);
-    return launch_x3_bn<64, false, TERMS>(A, W3, bias, res, out, M, N, K, relu, nullptr, st);
+    if (N % 128 == 0) return launch_x3_bn<128, false, TERMS>(A, W3, bias, res, out, M, N, K, relu, nullptr, st, sec);
+    return launch_x3_bn<64, false, TERMS>(A, W3, bias, res, out, M, N, K, relu, nullptr, st, sec);
 }
 
 hipError_t launch_gemm_f32x3_bias_act(const float* A, const unsigned short* W3, const float* bias, const float* res, float* out,
                                       int M, int N, int K, int relu, int terms, hipStream_t st, const float* a_bias) {
-    if (terms == 6) return launch_x3_terms<6>(A, W3, bias, res, out, M, N, K, relu, st, a_bias);
-    return launch_x3_terms<9>(A, W3, bias, res, out, M, N, K, relu, st, a_bias);
+    X3Second none; none.A2 = nullptr; none.K1 = K; none.ho_wo = none.wo = none.hi_wi = none.wi = none.stride = 1;
+    if (terms == 6) return launch_x3_terms<6>(A, W3, bias, res, out, M, N, K, relu, st, a_bias, none);
+    return launch_x3_terms<9>(A, W3, bias, res, out, M, N, K, relu, st, a_bias, none);
+}
+
+// out[B, ho, wo, N] = act([A1 | pixels of A2 at stride s] * W3cat^T + bias): A1 [B*ho*wo, K1], A2 [B, hi, wi, K2], W3cat [3][N][K1 + K2]
+hipError_t launch_gemm2_f32x3_bias_act(const float* A1, int K1, const float* A2, int K2, int batch, int hi, int wi, int stride,
+                                       const unsigned short* W3, const float* bias, float* out, int N, int relu, int terms,
+                                       hipStream_t st, const float* a_bias) {
+    const int ho = (hi - 1) / stride + 1, wo = (wi - 1) / stride + 1;
+    X3Second sec; sec.A2 = A2; sec.K1 = K1; sec.ho_wo = ho * wo; sec.wo = wo; sec.hi_wi = hi * wi; sec.wi = wi; sec.stride = stride;
+    const int M = batch * ho * wo, K = K1 + K2;
+    if (terms == 6) return launch_x3_terms<6>(A1, W3, bias, nullptr, out, M, N, K, relu, st, a_bias, sec);
+    return launch_x3_terms<9>(A1, W3, bias, nullptr, out, M, N, K, relu, st, a_bias, sec);
 }
 
 }  // namespace opa

@@ -153,6 +153,57 @@ def _split_weight_of(conv, w2d):
     return cached[1]
 
 
+# ... and the block's LAST 1x1 convolution together with its downsampling convolution as one product (OPA_GEMM3_PAIR=0: off)
+X3_PAIR = os.environ.get('OPA_GEMM3_PAIR', '1') != '0'
+
+
+def pair_supported(conv, dconv, h, x, bias, a_bias=None):
+    """Can ``conv(h) + dconv(x)`` run as ONE split-operand product (``conv1x1_pair_bias_act_x3``)?  float32, channels_last,
+    both 1x1 without bias / groups / padding, ``conv`` of stride 1, ``dconv`` of any stride."""
+    k1, k2 = conv.in_channels, dconv.in_channels
+    ok = (X3_PAIR and X3_TERMS in (6, 9) and h.is_cuda and h.dtype == torch.float32 and x.dtype == torch.float32
+          and conv.kernel_size == (1, 1) and dconv.kernel_size == (1, 1) and conv.stride == (1, 1) and dconv.stride[0] == dconv.stride[1]
+          and conv.groups == 1 and dconv.groups == 1 and conv.padding == (0, 0) and dconv.padding == (0, 0)
+          and conv.bias is None and dconv.bias is None and conv.out_channels == dconv.out_channels
+          and k1 % 32 == 0 and (k1 + k2) % 64 == 0 and k2 % 4 == 0 and conv.out_channels % 64 == 0
+          and h.dim() == 4 and x.dim() == 4 and h.is_contiguous(memory_format=torch.channels_last)
+          and x.is_contiguous(memory_format=torch.channels_last) and h.shape[1] == k1 and x.shape[1] == k2
+          and h.shape[0] == x.shape[0] and h.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+          and bias.dtype == torch.float32 and bias.is_contiguous() and bias.data_ptr() % 16 == 0
+          and x.shape[0] * x.shape[2] * x.shape[3] < 2 ** 31)
+    if not ok:
+        return False
+    s = dconv.stride[0]
+    if (h.shape[2], h.shape[3]) != ((x.shape[2] - 1) // s + 1, (x.shape[3] - 1) // s + 1):
+        return False
+    return a_bias is None or (a_bias.dtype == torch.float32 and a_bias.numel() == k1 and a_bias.is_contiguous())
+
+
+def conv1x1_pair_bias_act_x3(conv, dconv, h, x, bias, relu=True, a_bias=None):
+    """``act(conv(h) + dconv(x) + bias)`` -- the last 1x1 convolution of a ResNet block and the block's downsampling convolution
+    (reference ``network/basenetworks.py:71-150``: torchvision's Bottleneck) -- as ONE product ``[h | x at stride] * [W ; Wd]^T`` of
+    the split-operand kernel (``opa_gemm2_bias_act_f32x3``): the identity tensor is neither written nor read back.  With
+    ``a_bias``, ``h`` is the raw output of the preceding convolution and ``relu(h + a_bias)`` is applied while it is staged (``x``
+    gets zeros: it is non-negative).  ``pair_supported`` says whether this can run."""
+    k1, k2, n = conv.in_channels, dconv.in_channels, conv.out_channels
+    w1, w2 = conv.weight.reshape(n, k1), dconv.weight.reshape(n, k2)
+    key = (w1.data_ptr(), w1._version, w2.data_ptr(), w2._version, str(w1.device), None if a_bias is None else (a_bias.data_ptr(), a_bias._version))
+    cached = getattr(conv, '_opa_w3_pair', None)
+    if cached is None or cached[0] != key:
+        ab = None if a_bias is None else torch.cat((a_bias.detach().float(), torch.zeros(k2, device=a_bias.device)))
+        cached = (key, split_weight(torch.cat((w1.detach(), w2.detach()), dim=1)), ab)
+        conv._opa_w3_pair = cached
+    _, w3, ab = cached
+    B, _, H, W = x.shape
+    out = torch.empty((B, n, h.shape[2], h.shape[3]), dtype=torch.float32, device=h.device, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().opa_gemm2_bias_act_f32x3(
+        ctypes.c_void_p(h.data_ptr()), k1, ctypes.c_void_p(x.data_ptr()), k2, B, H, W, dconv.stride[0],
+        ctypes.c_void_p(ab.data_ptr()) if ab is not None else None, ctypes.c_void_p(w3.data_ptr()), ctypes.c_void_p(bias.data_ptr()),
+        ctypes.c_void_p(out.data_ptr()), n, int(bool(relu)), int(X3_TERMS),
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'opa_gemm2_bias_act_f32x3')
+    return out
+
+
 # (dtype, M, K, N, has_residual, has_a_bias) -> 'gemm' | 'gemm3' | 'pass+gemm' | 'conv'.  The three paths round
 # differently, so the choice is part of the result: it is made once per shape (the key holds no device index: a
 # table exported on rank 0 must match the lookups of every other rank), never by timing while a stream is being

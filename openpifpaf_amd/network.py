@@ -63,15 +63,24 @@ class _Bottleneck(nn.Module):
 
     def forward(self, x):
         if self.fused:      # conv (no bias) -> ONE fused bias(+residual)+ReLU pass each
-            identity = x if self.downsample is None else self.downsample[0](x)
             out = fused.conv_bias_act(self.conv1, x, self.fb1)            # 1x1: fused MFMA GEMM
             # 3x3: float32 stride 1 -> Winograd F(2x2, 3x3) in one HIP kernel, whose output transform adds the bias and applies
             # the ReLU on the way out (nothing extra to read or write), so the expanding 1x1 is the plain GEMM ...
             u = getattr(self, 'wino_u', None)
-            if winograd.takes(self.conv2, out, u):
+            wino = winograd.takes(self.conv2, out, u)
+            if wino:
                 out = winograd.conv3x3(out, u, self.conv2.out_channels, bias=self.fb2, relu=True, variant=winograd.DEFAULT_VARIANT)
+            else:
+                out = self.conv2(out)                                     # ... strided / bfloat16: MIOpen, raw output ...
+            # a block WITH a downsampling convolution, float32: conv3(out) + downsample(x) as ONE product (the identity tensor
+            # is never written), conv2's bias + ReLU applied to the operand where conv2 left them out
+            if self.downsample is not None and fused.pair_supported(self.conv3, self.downsample[0], out, x, self.fb3,
+                                                                    None if wino else self.fb2):
+                return fused.conv1x1_pair_bias_act_x3(self.conv3, self.downsample[0], out, x, self.fb3, True,
+                                                      None if wino else self.fb2)
+            identity = x if self.downsample is None else self.downsample[0](x)
+            if wino:
                 return fused.conv_bias_act(self.conv3, out, self.fb3, identity)
-            out = self.conv2(out)                                         # ... strided / bfloat16: MIOpen, raw output ...
             # ... whose bias + ReLU is applied by the 1x1 GEMM below while it stages its operand
             return fused.conv_bias_act(self.conv3, out, self.fb3, identity, a_bias=self.fb2)
         identity = x if self.downsample is None else self.downsample(x)

@@ -67,6 +67,39 @@ def test_split_operand_gemm_rejects_what_it_cannot_run():
     assert rc != 0                                                  # terms is 6 or 9
 
 
+@pytest.mark.parametrize('k1,k2,n,hw_in,stride,pro', [(64, 64, 256, 37, 1, False), (128, 256, 512, 41, 2, True), (256, 512, 1024, 27, 2, True),
+                                                      (512, 1024, 2048, 14, 2, False), (64, 192, 128, 9, 3, True)])
+def test_block_tail_and_downsample_as_one_product(k1, k2, n, hw_in, stride, pro):
+    """``relu(conv3(h) + downsample(x) + bias)`` as ONE product of the split-operand kernel (``opa_gemm2_bias_act_f32x3``) against
+    float64, and against the two-launch form (downsampling convolution by torch, then the GEMM with a residual)."""
+    from openpifpaf_amd import fused
+    torch.manual_seed(11)
+    B = 3
+    ho = (hw_in - 1) // stride + 1
+    x = torch.randn(B, k2, hw_in, hw_in + 2, device='cuda').clamp_(min=0).contiguous(memory_format=torch.channels_last)
+    wo = (hw_in + 2 - 1) // stride + 1
+    h = torch.randn(B, k1, ho, wo, device='cuda').contiguous(memory_format=torch.channels_last)
+    if not pro:
+        h = h.clamp_(min=0)
+    conv = torch.nn.Conv2d(k1, n, 1, bias=False).cuda()
+    dconv = torch.nn.Conv2d(k2, n, 1, stride, bias=False).cuda()
+    bias = torch.randn(n, device='cuda') * 0.1
+    a_bias = torch.randn(k1, device='cuda') * 0.3 if pro else None
+    with torch.no_grad():
+        assert fused.pair_supported(conv, dconv, h, x, bias, a_bias)
+        got = fused.conv1x1_pair_bias_act_x3(conv, dconv, h, x, bias, True, a_bias)
+        hd = h.double()
+        if pro:
+            hd = (hd + a_bias.double().view(1, -1, 1, 1)).clamp_(min=0)
+        ref = (torch.nn.functional.conv2d(hd, conv.weight.double()) + torch.nn.functional.conv2d(x.double(), dconv.weight.double(), stride=stride)
+               + bias.double().view(1, -1, 1, 1)).clamp_(min=0)
+        two = fused.conv1x1_bias_act(h, conv.weight.reshape(n, k1), bias, dconv(x).contiguous(memory_format=torch.channels_last), True, a_bias)
+    assert tuple(got.shape) == (B, n, ho, wo) and got.is_contiguous(memory_format=torch.channels_last)
+    e_got, e_two = _rms(got, ref), _rms(two, ref)
+    assert e_got <= 1.05 * e_two + 1e-9 and e_got < 2e-7, (e_got, e_two)
+    assert float((got.double() - ref).abs().max()) / float(ref.abs().max()) < 2e-6
+
+
 def test_resnet50_trunk_with_and_without_the_split_operand_kernel():
     """The whole float32 trunk: the heads agree within 1e-4 of their largest magnitude whichever kernel the 1x1 convolutions take
     (the bar the Winograd kernel was held to), and the 'gemm3' choice is really taken."""
@@ -80,9 +113,10 @@ def test_resnet50_trunk_with_and_without_the_split_operand_kernel():
     network.optimize_for_inference_(net)
     net = net.to(memory_format=torch.channels_last)
     x = torch.randn((2, 3, 193, 161), device='cuda').contiguous(memory_format=torch.channels_last)
-    saved, terms = fused.choices(), fused.X3_TERMS
+    saved, terms, pair = fused.choices(), fused.X3_TERMS, fused.X3_PAIR
     try:
         fused.X3_TERMS = 6
+        fused.X3_PAIR = False
         fused.set_choices({k: 'gemm' for k in saved}, replace=True)
         with torch.no_grad():
             fused.set_choices({}, replace=True)
@@ -92,11 +126,12 @@ def test_resnet50_trunk_with_and_without_the_split_operand_kernel():
             forced = {k: 'gemm3' for k, v in fused.choices().items() if k[0] == 'torch.float32' and k[2] % 64 == 0}
             assert forced
             fused.set_choices(forced)
+            fused.X3_PAIR = True                                      # ... and the blocks' tails with their downsampling convolutions
             b = net(x)
         for u, v in zip(a, b):
             assert float((u - v).abs().max()) <= 1e-4 * float(u.abs().max()), float((u - v).abs().max())
         assert not all(torch.equal(u, v) for u, v in zip(a, b))      # (another kernel did run)
     finally:
         os.environ.pop('OPA_CONV1X1', None)
-        fused.X3_TERMS = terms
+        fused.X3_TERMS, fused.X3_PAIR = terms, pair
         fused.set_choices(saved, replace=True)
