@@ -160,6 +160,30 @@ def _conv1x1_text(primary):
     return 'f32 MFMA GEMM, fused epilogue'
 
 
+def f32_numerics_check():
+    """Outside every timed region: the float32 1x1 convolution of ResNet layer 3 (1024 -> 256 channels, 81x81, two images) by the
+    kernels the headline may use -- split bf16 operands (csrc/gemm_f32x3.hip) and the float32 MFMA (csrc/gemm_f32.hip) -- and by
+    torch's own float32 convolution, each against a float64 product: rms error relative to the output's largest magnitude.  The
+    headline's dtype is f32 because these numbers say so, not because the operands are."""
+    from openpifpaf_amd import fused
+    g = torch.Generator(device='cuda').manual_seed(7)
+    x = torch.randn((2, 1024, 81, 81), device='cuda', generator=g).clamp_(min=0).contiguous(memory_format=torch.channels_last)
+    w = torch.randn((256, 1024), device='cuda', generator=g) * (2.0 / 1024) ** 0.5
+    b = torch.randn(256, device='cuda', generator=g) * 0.1
+    ref = torch.nn.functional.conv2d(x.double(), w.double().view(256, 1024, 1, 1), b.double()).clamp_(min=0)
+    scale = float(ref.abs().max())
+
+    def rms(out):
+        d = out.double() - ref
+        return float('%.3g' % (float((d * d).mean().sqrt()) / scale))
+    out = {'shape': 'conv1x1 1024->256 @81x81 x2, relu', 'metric': 'rms error vs float64 / max|out|',
+           'f32_mfma': rms(fused.conv1x1_bias_act(x, w, b, None, True)),
+           'torch_f32_conv': rms(torch.relu(torch.nn.functional.conv2d(x, w.view(256, 1024, 1, 1), b)))}
+    if fused.X3_TERMS:
+        out['split_bf16_%dterms' % fused.X3_TERMS] = rms(fused.conv1x1_bias_act_x3(x, fused.split_weight(w), b, None, True, None, fused.X3_TERMS))
+    return out
+
+
 def kernel_source_hash():
     """Identifies the DECODE kernels a PMC traffic file was measured on (profiles/r*/pmc_traffic.json; the same function
     stamps it: tools/summarize_profiles.py)."""
@@ -282,6 +306,8 @@ def compact_line(detail):
     line['parity'] = compact_parity(detail.get('parity'))
     if 'per_rank_ms_per_step' in detail:
         line['per_rank_ms_per_step'] = detail['per_rank_ms_per_step']
+    if isinstance(detail.get('f32_check'), dict):
+        line['f32_check'] = {k: v for k, v in detail['f32_check'].items() if k not in ('metric',)}
     bf = detail.get('bf16_backbone')
     if bf:
         line['bf16_backbone'] = _pick(bf, ('value', 'ms_per_step'))
@@ -1011,6 +1037,12 @@ def main():
                        'taken off the network is taken off both flows.  15x needs a faster network than the reference\'s '
                        'float32 one: see bf16_backbone (reduced precision, reported beside the headline, not as it).'
                        % (primary, nn_ms, ref_ms - nn_ms, ref_ms, nn_ms, ref_ms / nn_ms)}
+
+        if primary == 'fp32' and not args.decode_only:
+            try:
+                line['f32_check'] = f32_numerics_check()
+            except Exception as e:            # noqa: BLE001  (a check, not the measurement)
+                line['f32_check'] = {'error': repr(e)[:80]}
 
     if rank == 0:
         _PARTIAL['line'] = line
