@@ -79,7 +79,10 @@ __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
     constexpr int WN = BN / 2;                 // wave tile width
     constexpr int NT = WN / 32;                // 32-wide MFMA blocks per wave in N (2 or 1)
     constexpr int LDS_A = kX3BM * kX3Pitch, LDS_B = BN * kX3Pitch;        // bf16 elements of ONE plane
-    constexpr int STAGE_BYTES = 3 * (LDS_A + LDS_B) * 2;
+#ifndef OPA_X3_PAD_LDS            // experiment: this many bytes of LDS more (fewer workgroups per compute unit)
+#define OPA_X3_PAD_LDS 0
+#endif
+    constexpr int STAGE_BYTES = 3 * (LDS_A + LDS_B) * 2 + OPA_X3_PAD_LDS;
     constexpr int EPI_BYTES = 4 * 32 * WN * 4; // per wave a 32 x WN f32 patch
     __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES > EPI_BYTES ? STAGE_BYTES : EPI_BYTES];
     unsigned short* sA = reinterpret_cast<unsigned short*>(smem);          // [3][128][pitch]
