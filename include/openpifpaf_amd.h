@@ -410,6 +410,15 @@ int opa_gemm2_bias_act_f32x3(const float* a1_dev, int32_t k1, const float* a2_de
                              int32_t w_in, int32_t stride, const float* a_bias_dev, const void* w3cat_dev, const float* bias_dev,
                              float* out_dev, int32_t n, int32_t relu, int32_t terms, void* stream);
 
+/* 3x3 convolution, padding 1, ANY stride, of an NHWC float32 activation as an implicit GEMM of the split-operand kernel: the
+ * strided convolution at the head of ResNet layers 2-4 (reference network/basenetworks.py:71-150: torch.nn.Conv2d -> MIOpen).
+ * Column block t = 3 ky + kx of K = 9 c_in holds the channels of input pixel (stride*y - 1 + ky, stride*x - 1 + kx); pixels in
+ * the padding are zeros.  x_dev [B, h_in, w_in, c_in] (< 2 GB), w3_dev = split_weight of the weight as [c_out, (ky, kx, c_in)]
+ * ([3][c_out][9 c_in] bfloat16: openpifpaf_amd.fused.split_weight_3x3), out_dev [B, ho, wo, c_out], ho = (h_in - 1) / stride + 1.
+ * c_in % 64 == 0, c_out % 64 == 0; terms 6 or 9 as above. */
+int opa_conv3x3_f32x3(const float* x_dev, const void* w3_dev, const float* bias_dev, float* out_dev, int32_t batch, int32_t h_in,
+                      int32_t w_in, int32_t c_in, int32_t c_out, int32_t stride, int32_t relu, int32_t terms, void* stream);
+
 /* 3x3 convolution, stride 1, padding 1, of an NHWC float32 activation as Winograd F(2x2, 3x3) in ONE kernel (input
  * transform -> sixteen float32 MFMA GEMMs -> output transform; csrc/winograd.hip): the bottleneck convolutions of the
  * ResNet trunk (reference network/basenetworks.py:71-150 runs them through torch.nn.Conv2d), 2.25x fewer multiplications

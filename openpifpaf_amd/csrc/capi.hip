@@ -956,6 +956,24 @@ int opa_gemm2_bias_act_f32x3(const float* a1_dev, int32_t k1, const float* a2_de
     return OPA_OK;
 }
 
+int opa_conv3x3_f32x3(const float* x_dev, const void* w3_dev, const float* bias_dev, float* out_dev, int32_t batch, int32_t h_in,
+                      int32_t w_in, int32_t c_in, int32_t c_out, int32_t stride, int32_t relu, int32_t terms, void* stream) {
+    if (!x_dev || !w3_dev || !bias_dev || !out_dev || batch <= 0 || h_in <= 0 || w_in <= 0 || stride < 1 || c_in <= 0 || c_out <= 0 ||
+        (terms != 6 && terms != 9))
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_conv3x3_f32x3: bad arguments");
+    if (c_in % 64 != 0 || c_out % 64 != 0)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_conv3x3_f32x3: c_in and c_out must be multiples of 64");
+    if (((uintptr_t)x_dev | (uintptr_t)w3_dev | (uintptr_t)out_dev | (uintptr_t)bias_dev) & 15)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_conv3x3_f32x3: pointers must be 16-B aligned");
+    if (((long long)batch * h_in * w_in + w_in + 1) * c_in * 4 > 0x7fffffffll)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_conv3x3_f32x3: the activation must be smaller than 2 GB");
+    hipError_t e = launch_conv3x3_f32x3(x_dev, batch, h_in, w_in, c_in, stride, (const unsigned short*)w3_dev, bias_dev, out_dev, c_out,
+                                        relu, terms, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "conv3x3_f32x3");
+    prof_mark((hipStream_t)stream, "conv3x3_f32x3_kernel");
+    return OPA_OK;
+}
+
 int opa_conv3x3_winograd_f32(const float* x_dev, const float* u_dev, const float* bias_dev, float* out_dev, int32_t batch,
                              int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t relu, int32_t variant,
                              int32_t order, void* stream) {

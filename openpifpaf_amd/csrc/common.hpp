@@ -260,6 +260,8 @@ hipError_t launch_gemm_f32x3_bias_act(const float* A, const unsigned short* W3, 
 hipError_t launch_gemm2_f32x3_bias_act(const float* A1, int K1, const float* A2, int K2, int batch, int hi, int wi, int stride,
                                        const unsigned short* W3, const float* bias, float* out, int N, int relu, int terms,
                                        hipStream_t st, const float* a_bias);
+hipError_t launch_conv3x3_f32x3(const float* x, int batch, int hi, int wi, int C, int stride, const unsigned short* W3,
+                                const float* bias, float* out, int N, int relu, int terms, hipStream_t st);
 hipError_t launch_gemm_f32_bias_act(const float* A, const float* W, const float* bias, const float* res, float* out,
                                     int M, int N, int K, int relu, hipStream_t st, const float* a_bias = nullptr);
 hipError_t launch_winograd_f23(const float* x, const float* U, float* y, const float* bias, int N, int H, int W, int Cin,

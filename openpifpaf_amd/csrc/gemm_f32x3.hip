@@ -65,13 +65,17 @@ __device__ __forceinline__ void split4(const f32x4_t a, u32x2_t& p1, u32x2_t& p2
 // output pixel m reads through a 1x1 convolution of stride `stride` -- the last 1x1 convolution of a ResNet block and the
 // block's downsampling convolution as ONE product (the weights concatenated along K on the host), so that the identity tensor
 // is neither written nor read back.  Columns [0, K1) come from A (row length K1), [K1, K) from A2 (row length K - K1).
+// NINE activations along K (SRC = 2): a 3x3 convolution with padding 1 and any stride as an implicit GEMM -- column block
+// t = 3 ky + kx of K holds the C channels of input pixel (stride * oy - 1 + ky, stride * ox - 1 + kx); a pixel in the padding is
+// requested beyond the end of the buffer, which a buffer load answers with zeros (one bit per row and tap decides).
 struct X3Second {
     const float* A2;           // [B, hi, wi, K - K1] channels-last, or null
     int K1;                    // columns of the first activation (a multiple of the K-step)
     int ho_wo, wo, hi_wi, wi, stride;
+    int hi, C, batch;          // (SRC = 2) input rows, channels per tap, images
 };
 
-template <int BN, bool RES, bool RELU, bool PRO, int TERMS, bool TWO>
+template <int BN, bool RES, bool RELU, bool PRO, int TERMS, int SRC>
 __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
         const float* __restrict__ A, const unsigned short* __restrict__ W3, const float* __restrict__ bias,
         const float* __restrict__ res, float* __restrict__ out, int M, int N, int K, const float* __restrict__ a_bias,
@@ -123,10 +127,13 @@ __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
     // themselves (with 64-bit per-thread pointers the compiler, short of registers, computed every address INTO the load's
     // destination, which made each K-step wait for all loads in flight before it could issue its own)
     // (buffer loads: a descriptor in scalar registers, ONE 32-bit byte offset per load, the K-step as the scalar offset)
+    constexpr bool TWO = SRC == 1, TAPS = SRC == 2;
     const int rows_here = M - m0 < kX3BM ? M - m0 : kX3BM;
-    const int KA = TWO ? sec.K1 : K;           // row length of the first activation
-    const float* a1_base = A + (size_t)m0 * KA;
-    const int a1_bytes = (int)((size_t)rows_here * KA * 4);
+    const int KA = TWO ? sec.K1 : TAPS ? sec.C : K;          // row length of the first activation
+    // (TAPS: the whole tensor, from wi + 1 pixels BEFORE its start -- the window of output pixel (oy, ox) begins at input pixel
+    //  (stride oy - 1, stride ox - 1); what lies before the tensor is only ever asked for by rows whose tap bit is clear)
+    const float* a1_base = TAPS ? A - (size_t)(sec.wi + 1) * KA : A + (size_t)m0 * KA;
+    const int a1_bytes = TAPS ? (int)(((size_t)sec.batch * sec.hi_wi + sec.wi + 1) * KA * 4) : (int)((size_t)rows_here * KA * 4);
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a1_base), 0, a1_bytes, 0x00020000);
     // the second activation: its rows are the input pixels the tile's output pixels read (monotonic in m: offsets from the first)
     const int K2 = K - KA;
@@ -147,12 +154,24 @@ __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned short*>(W3 + (size_t)n0 * K), 0, (int)(((size_t)3 * N - n0) * K * 2), 0x00020000);
     unsigned pa[NPA], pb[WV];
+    unsigned vmask[NPA];                       // (TAPS) bit t: tap t of this row lies inside the image
     int sb_off[WV];
 #pragma unroll
     for (int p = 0; p < NPA; p++) {            // rows past M read row M - 1 (valid memory; the epilogue never stores them)
         int m = m0 + p * RPP + s_row;
         if (m > M - 1) m = M - 1;
         pa[p] = ((unsigned)(m - m0) * (unsigned)KA + (unsigned)s_col) * 4u;
+        vmask[p] = 0u;
+        if constexpr (TAPS) {
+            const int b = m / sec.ho_wo, r = m - b * sec.ho_wo, oy = r / sec.wo, ox = r - oy * sec.wo;
+            pa[p] = (unsigned)((long long)b * sec.hi_wi + (long long)oy * sec.stride * sec.wi + (long long)ox * sec.stride) * (unsigned)KA * 4u
+                    + (unsigned)s_col * 4u;
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int iy = oy * sec.stride - 1 + t / 3, ix = ox * sec.stride - 1 + t % 3;
+                if (iy >= 0 && iy < sec.hi && ix >= 0 && ix < sec.wi) vmask[p] |= 1u << t;
+            }
+        }
         if constexpr (TWO) pa2[p] = ((unsigned)(in_row(m) - row0_2) * (unsigned)K2 + (unsigned)s_col) * 4u;
     }
 #pragma unroll
@@ -163,7 +182,13 @@ __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
         sb_off[t] = plane * LDS_B + row * kX3Pitch + c;
     }
     auto fetch_a = [&](f32x4_t (&ra)[NPA], int k0) {      // global -> registers for K-step k0 (with the operand prologue)
-        if constexpr (TWO) {                   // (uniform selects, no branch around the loads)
+        if constexpr (TAPS) {                  // tap t = k0 / C: a uniform shift of every row's window origin
+            const int t = k0 / KA, kc = k0 - t * KA;
+            const int soff = (((t / 3) * sec.wi + t % 3) * KA + kc) * 4;
+#pragma unroll
+            for (int p = 0; p < NPA; p++)
+                ra[p] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (vmask[p] >> t) & 1u ? pa[p] : 0xFFFFFFF0u, soff, 0));
+        } else if constexpr (TWO) {            // (uniform selects, no branch around the loads)
             const bool second = k0 >= KA;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(second ? a2_base : a1_base), 0, second ? a2_bytes : a1_bytes, 0x00020000);
@@ -322,15 +347,20 @@ template <int BN, bool PRO, int TERMS>
 static hipError_t launch_x3_bn(const float* a, const unsigned short* w, const float* b, const float* r, float* o,
                                int M, int N, int K, int relu, const float* ab, hipStream_t st, const X3Second& sec) {
     const long long blocks = (long long)((M + kX3BM - 1) / kX3BM) * (N / BN);
-    if (sec.A2) {                              // (the pair has no residual: the second activation IS the identity branch)
-        if (relu) gemm_f32x3_bias_act_kernel<BN, false, true, PRO, TERMS, true><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, nullptr, o, M, N, K, ab, sec);
-        else gemm_f32x3_bias_act_kernel<BN, false, false, PRO, TERMS, true><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, nullptr, o, M, N, K, ab, sec);
+    if (sec.C > 0) {                           // 3x3 implicit GEMM: no operand prologue, no residual
+        if constexpr (!PRO) {
+            if (relu) gemm_f32x3_bias_act_kernel<BN, false, true, false, TERMS, 2><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, nullptr, o, M, N, K, nullptr, sec);
+            else gemm_f32x3_bias_act_kernel<BN, false, false, false, TERMS, 2><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, nullptr, o, M, N, K, nullptr, sec);
+        }
+    } else if (sec.A2) {                       // (the pair has no residual: the second activation IS the identity branch)
+        if (relu) gemm_f32x3_bias_act_kernel<BN, false, true, PRO, TERMS, 1><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, nullptr, o, M, N, K, ab, sec);
+        else gemm_f32x3_bias_act_kernel<BN, false, false, PRO, TERMS, 1><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, nullptr, o, M, N, K, ab, sec);
     } else if (r) {
-        if (relu) gemm_f32x3_bias_act_kernel<BN, true, true, PRO, TERMS, false><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab, sec);
-        else gemm_f32x3_bias_act_kernel<BN, true, false, PRO, TERMS, false><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab, sec);
+        if (relu) gemm_f32x3_bias_act_kernel<BN, true, true, PRO, TERMS, 0><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab, sec);
+        else gemm_f32x3_bias_act_kernel<BN, true, false, PRO, TERMS, 0><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab, sec);
     } else {
-        if (relu) gemm_f32x3_bias_act_kernel<BN, false, true, PRO, TERMS, false><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab, sec);
-        else gemm_f32x3_bias_act_kernel<BN, false, false, PRO, TERMS, false><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab, sec);
+        if (relu) gemm_f32x3_bias_act_kernel<BN, false, true, PRO, TERMS, 0><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab, sec);
+        else gemm_f32x3_bias_act_kernel<BN, false, false, PRO, TERMS, 0><<<(unsigned)blocks, 256, 0, st>>>(a, w, b, r, o, M, N, K, ab, sec);
     }
     return hipGetLastError();
 }
@@ -348,7 +378,7 @@ static hipError_t launch_x3_terms(const float* A, const unsigned short* W3, cons
 
 hipError_t launch_gemm_f32x3_bias_act(const float* A, const unsigned short* W3, const float* bias, const float* res, float* out,
                                       int M, int N, int K, int relu, int terms, hipStream_t st, const float* a_bias) {
-    X3Second none; none.A2 = nullptr; none.K1 = K; none.ho_wo = none.wo = none.hi_wi = none.wi = none.stride = 1;
+    X3Second none; none.A2 = nullptr; none.K1 = K; none.ho_wo = none.wo = none.hi_wi = none.wi = none.stride = 1; none.hi = 1; none.C = 0; none.batch = 1;
     if (terms == 6) return launch_x3_terms<6>(A, W3, bias, res, out, M, N, K, relu, st, a_bias, none);
     return launch_x3_terms<9>(A, W3, bias, res, out, M, N, K, relu, st, a_bias, none);
 }
@@ -359,9 +389,22 @@ hipError_t launch_gemm2_f32x3_bias_act(const float* A1, int K1, const float* A2,
                                        hipStream_t st, const float* a_bias) {
     const int ho = (hi - 1) / stride + 1, wo = (wi - 1) / stride + 1;
     X3Second sec; sec.A2 = A2; sec.K1 = K1; sec.ho_wo = ho * wo; sec.wo = wo; sec.hi_wi = hi * wi; sec.wi = wi; sec.stride = stride;
+    sec.hi = hi; sec.C = 0; sec.batch = batch;
     const int M = batch * ho * wo, K = K1 + K2;
     if (terms == 6) return launch_x3_terms<6>(A1, W3, bias, nullptr, out, M, N, K, relu, st, a_bias, sec);
     return launch_x3_terms<9>(A1, W3, bias, nullptr, out, M, N, K, relu, st, a_bias, sec);
+}
+
+// 3x3 convolution, padding 1, stride s: out[B, ho, wo, N] = act(im2col(x) * W3^T + bias), x [B, hi, wi, C] channels-last,
+// W3 = split_weight of the weight as [N, (ky, kx, c)] ([3][N][9 C]); C % 32 == 0, 9 C % 64 == 0, tensor < 2 GB
+hipError_t launch_conv3x3_f32x3(const float* x, int batch, int hi, int wi, int C, int stride, const unsigned short* W3,
+                                const float* bias, float* out, int N, int relu, int terms, hipStream_t st) {
+    const int ho = (hi - 1) / stride + 1, wo = (wi - 1) / stride + 1;
+    X3Second sec; sec.A2 = nullptr; sec.K1 = C; sec.ho_wo = ho * wo; sec.wo = wo; sec.hi_wi = hi * wi; sec.wi = wi; sec.stride = stride;
+    sec.hi = hi; sec.C = C; sec.batch = batch;
+    const int M = batch * ho * wo, K = 9 * C;
+    if (terms == 6) return launch_x3_terms<6>(x, W3, bias, nullptr, out, M, N, K, relu, st, nullptr, sec);
+    return launch_x3_terms<9>(x, W3, bias, nullptr, out, M, N, K, relu, st, nullptr, sec);
 }
 
 }  // namespace opa

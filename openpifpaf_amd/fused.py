@@ -204,6 +204,45 @@ def conv1x1_pair_bias_act_x3(conv, dconv, h, x, bias, relu=True, a_bias=None):
     return out
 
 
+# ... and the STRIDED 3x3 convolutions (the head of ResNet layers 2-4) as an implicit GEMM of the same kernel (OPA_GEMM3_3X3=0: off)
+X3_CONV3 = os.environ.get('OPA_GEMM3_3X3', '1') != '0'
+
+
+def split_weight_3x3(weight):
+    """``[N, C, 3, 3]`` float32 -> ``split_weight`` of ``[N, (ky, kx, c)]``: the operand of ``opa_conv3x3_f32x3``."""
+    n, c = weight.shape[0], weight.shape[1]
+    return split_weight(weight.detach().permute(0, 2, 3, 1).reshape(n, 9 * c))
+
+
+def conv3x3_x3_supported(conv, x, bias):
+    return (X3_CONV3 and X3_TERMS in (6, 9) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+            and x.is_contiguous(memory_format=torch.channels_last) and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
+            and conv.stride[0] == conv.stride[1] and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+            and conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and x.shape[1] == conv.in_channels
+            and x.data_ptr() % 16 == 0 and bias.dtype == torch.float32 and bias.is_contiguous() and bias.data_ptr() % 16 == 0
+            and (x.shape[0] * x.shape[2] * x.shape[3] + x.shape[3] + 1) * x.shape[1] * 4 < 2 ** 31)
+
+
+def conv3x3_bias_act_x3(conv, x, bias, relu=True):
+    """``act(conv(x) + bias)`` for a 3x3 convolution with padding 1 and any stride (reference ``network/basenetworks.py:71-150``: the
+    strided convolution of a ResNet block) as an implicit GEMM of the split-operand kernel -- float32 in and out."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    cached = getattr(conv, '_opa_w3_3x3', None)
+    if cached is None or cached[0] != key:
+        cached = (key, split_weight_3x3(w))
+        conv._opa_w3_3x3 = cached
+    B, C, H, W = x.shape
+    s = conv.stride[0]
+    out = torch.empty((B, conv.out_channels, (H - 1) // s + 1, (W - 1) // s + 1), dtype=torch.float32, device=x.device,
+                      memory_format=torch.channels_last)
+    _lib.check(_lib.lib().opa_conv3x3_f32x3(
+        ctypes.c_void_p(x.data_ptr()), ctypes.c_void_p(cached[1].data_ptr()), ctypes.c_void_p(bias.data_ptr()),
+        ctypes.c_void_p(out.data_ptr()), B, H, W, C, conv.out_channels, s, int(bool(relu)), int(X3_TERMS),
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'opa_conv3x3_f32x3')
+    return out
+
+
 # (dtype, M, K, N, has_residual, has_a_bias) -> 'gemm' | 'gemm3' | 'pass+gemm' | 'conv'.  The three paths round
 # differently, so the choice is part of the result: it is made once per shape (the key holds no device index: a
 # table exported on rank 0 must match the lookups of every other rank), never by timing while a stream is being

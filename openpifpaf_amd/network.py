@@ -70,8 +70,11 @@ class _Bottleneck(nn.Module):
             wino = winograd.takes(self.conv2, out, u)
             if wino:
                 out = winograd.conv3x3(out, u, self.conv2.out_channels, bias=self.fb2, relu=True, variant=winograd.DEFAULT_VARIANT)
+            elif fused.conv3x3_x3_supported(self.conv2, out, self.fb2):  # ... float32 strided: implicit GEMM of the split-operand kernel
+                out = fused.conv3x3_bias_act_x3(self.conv2, out, self.fb2, True)
+                wino = True                                               # (bias + ReLU applied: nothing left for the next operand)
             else:
-                out = self.conv2(out)                                     # ... strided / bfloat16: MIOpen, raw output ...
+                out = self.conv2(out)                                     # ... bfloat16: MIOpen, raw output ...
             # a block WITH a downsampling convolution, float32: conv3(out) + downsample(x) as ONE product (the identity tensor
             # is never written), conv2's bias + ReLU applied to the operand where conv2 left them out
             if self.downsample is not None and fused.pair_supported(self.conv3, self.downsample[0], out, x, self.fb3,

@@ -113,10 +113,10 @@ def test_resnet50_trunk_with_and_without_the_split_operand_kernel():
     network.optimize_for_inference_(net)
     net = net.to(memory_format=torch.channels_last)
     x = torch.randn((2, 3, 193, 161), device='cuda').contiguous(memory_format=torch.channels_last)
-    saved, terms, pair = fused.choices(), fused.X3_TERMS, fused.X3_PAIR
+    saved, terms, pair, conv3 = fused.choices(), fused.X3_TERMS, fused.X3_PAIR, fused.X3_CONV3
     try:
         fused.X3_TERMS = 6
-        fused.X3_PAIR = False
+        fused.X3_PAIR = fused.X3_CONV3 = False
         fused.set_choices({k: 'gemm' for k in saved}, replace=True)
         with torch.no_grad():
             fused.set_choices({}, replace=True)
@@ -126,12 +126,33 @@ def test_resnet50_trunk_with_and_without_the_split_operand_kernel():
             forced = {k: 'gemm3' for k, v in fused.choices().items() if k[0] == 'torch.float32' and k[2] % 64 == 0}
             assert forced
             fused.set_choices(forced)
-            fused.X3_PAIR = True                                      # ... and the blocks' tails with their downsampling convolutions
+            fused.X3_PAIR = fused.X3_CONV3 = True                     # ... the blocks' tails with their downsampling convolutions, the strided 3x3
             b = net(x)
         for u, v in zip(a, b):
             assert float((u - v).abs().max()) <= 1e-4 * float(u.abs().max()), float((u - v).abs().max())
         assert not all(torch.equal(u, v) for u, v in zip(a, b))      # (another kernel did run)
     finally:
         os.environ.pop('OPA_CONV1X1', None)
-        fused.X3_TERMS, fused.X3_PAIR = terms, pair
+        fused.X3_TERMS, fused.X3_PAIR, fused.X3_CONV3 = terms, pair, conv3
         fused.set_choices(saved, replace=True)
+
+
+@pytest.mark.parametrize('c,n,h,w,stride', [(128, 128, 37, 41, 2), (256, 256, 20, 27, 2), (64, 128, 17, 9, 1), (512, 512, 11, 12, 2),
+                                            (64, 64, 9, 30, 3)])
+def test_strided_3x3_convolution_as_implicit_gemm(c, n, h, w, stride):
+    """``opa_conv3x3_f32x3``: padding 1, any stride, against a float64 convolution and against torch's float32 one."""
+    from openpifpaf_amd import fused
+    torch.manual_seed(13)
+    x = torch.randn(3, c, h, w, device='cuda').clamp_(min=0).contiguous(memory_format=torch.channels_last)
+    conv = torch.nn.Conv2d(c, n, 3, stride, 1, bias=False).cuda()
+    bias = torch.randn(n, device='cuda') * 0.1
+    with torch.no_grad():
+        assert fused.conv3x3_x3_supported(conv, x, bias)
+        got = fused.conv3x3_bias_act_x3(conv, x, bias, True)
+        ref = (torch.nn.functional.conv2d(x.double(), conv.weight.double(), stride=stride, padding=1) + bias.double().view(1, -1, 1, 1)).clamp_(min=0)
+        theirs = torch.relu(conv(x) + bias.view(1, -1, 1, 1))
+    assert tuple(got.shape) == tuple(ref.shape) and got.is_contiguous(memory_format=torch.channels_last)
+    e_got, e_theirs = _rms(got, ref), _rms(theirs, ref)
+    # (measured: 0.4-1.4 x the error of whatever algorithm MIOpen picks for the shape; float32-grade either way)
+    assert e_got <= 2.0 * e_theirs + 1e-9 and e_got < 1e-7, (e_got, e_theirs)
+    assert float((got.double() - ref).abs().max()) / float(ref.abs().max()) < 2e-6
