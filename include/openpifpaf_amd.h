@@ -419,6 +419,17 @@ int opa_gemm2_bias_act_f32x3(const float* a1_dev, int32_t k1, const float* a2_de
 int opa_conv3x3_f32x3(const float* x_dev, const void* w3_dev, const float* bias_dev, float* out_dev, int32_t batch, int32_t h_in,
                       int32_t w_in, int32_t c_in, int32_t c_out, int32_t stride, int32_t relu, int32_t terms, void* stream);
 
+/* A convolution whose window ROWS are the taps of the same implicit GEMM, on an input that is padded IN MEMORY: the 7x7 stride-2
+ * stem of a ResNet (reference network/basenetworks.py:71-150) on a 4-channel, zero-padded copy of the image.  x_dev [B, hp, wp, pix]
+ * (pix floats per pixel); output pixel (y, x) reads for tap t the tap_floats contiguous floats that begin at input pixel
+ * (stride*y + t, stride*x); w3_dev = split_weight of the weight laid out to match ([3][c_out][ntaps * tap_floats];
+ * openpifpaf_amd.fused.stem7x7_bias_act_x3 pads the image by 3 + 4 pixels and the weight to 8 rows x 8 columns x 4 channels);
+ * out_dev [B, ho, wo, c_out].  tap_floats % 32 == 0, ntaps * tap_floats % 64 == 0, ntaps <= 32, c_out % 64 == 0, x < 2 GB; the caller
+ * guarantees that every tap of every output pixel lies inside x. */
+int opa_conv_rows_f32x3(const float* x_dev, const void* w3_dev, const float* bias_dev, float* out_dev, int32_t batch, int32_t hp,
+                        int32_t wp, int32_t pix, int32_t ho, int32_t wo, int32_t stride, int32_t ntaps, int32_t tap_floats,
+                        int32_t c_out, int32_t relu, int32_t terms, void* stream);
+
 /* 3x3 convolution, stride 1, padding 1, of an NHWC float32 activation as Winograd F(2x2, 3x3) in ONE kernel (input
  * transform -> sixteen float32 MFMA GEMMs -> output transform; csrc/winograd.hip): the bottleneck convolutions of the
  * ResNet trunk (reference network/basenetworks.py:71-150 runs them through torch.nn.Conv2d), 2.25x fewer multiplications

@@ -136,6 +136,7 @@ SYMBOLS = {
     'opa_gemm_pro_bias_act_bf16': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     'opa_gemm_bias_act_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     'opa_gemm_bias_act_f32x3': (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    'opa_conv_rows_f32x3': (ctypes.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 12 + [_vp]),
     'opa_conv3x3_f32x3': (ctypes.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     'opa_gemm2_bias_act_f32x3': (ctypes.c_int, [_vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     'opa_conv3x3_winograd_f32': (ctypes.c_int, [_vp, _vp, _vp, _vp] + [_i32] * 8 + [_vp]),

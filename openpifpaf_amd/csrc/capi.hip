@@ -956,6 +956,27 @@ int opa_gemm2_bias_act_f32x3(const float* a1_dev, int32_t k1, const float* a2_de
     return OPA_OK;
 }
 
+int opa_conv_rows_f32x3(const float* x_dev, const void* w3_dev, const float* bias_dev, float* out_dev, int32_t batch, int32_t hp,
+                        int32_t wp, int32_t pix, int32_t ho, int32_t wo, int32_t stride, int32_t ntaps, int32_t tap_floats,
+                        int32_t c_out, int32_t relu, int32_t terms, void* stream) {
+    if (!x_dev || !w3_dev || !bias_dev || !out_dev || batch <= 0 || hp <= 0 || wp <= 0 || pix <= 0 || ho <= 0 || wo <= 0 || stride < 1 ||
+        ntaps < 1 || ntaps > 32 || tap_floats <= 0 || c_out <= 0 || (terms != 6 && terms != 9))
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_conv_rows_f32x3: bad arguments");
+    if (tap_floats % 32 != 0 || (ntaps * tap_floats) % 64 != 0 || c_out % 64 != 0 || pix % 4 != 0)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_conv_rows_f32x3: tap_floats % 32, ntaps * tap_floats % 64, c_out % 64, pix % 4 must be 0");
+    if (((uintptr_t)x_dev | (uintptr_t)w3_dev | (uintptr_t)out_dev | (uintptr_t)bias_dev) & 15)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_conv_rows_f32x3: pointers must be 16-B aligned");
+    // every tap of the last output pixel inside the tensor
+    if ((long long)(ho - 1) * stride + ntaps > hp || ((long long)(wo - 1) * stride) * pix + tap_floats > (long long)wp * pix ||
+        (long long)batch * hp * wp * pix * 4 > 0x7fffffffll || (long long)batch * ho * wo > 0x7fffffffll)
+        return fail(OPA_ERR_INVALID_ARGUMENT, "opa_conv_rows_f32x3: the taps leave the (padded) input, or it is 2 GB or more");
+    hipError_t e = launch_convrows_f32x3(x_dev, batch, hp, wp, pix, ho, wo, stride, ntaps, tap_floats, (const unsigned short*)w3_dev,
+                                         bias_dev, out_dev, c_out, relu, terms, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "conv_rows_f32x3");
+    prof_mark((hipStream_t)stream, "conv_rows_f32x3_kernel");
+    return OPA_OK;
+}
+
 int opa_conv3x3_f32x3(const float* x_dev, const void* w3_dev, const float* bias_dev, float* out_dev, int32_t batch, int32_t h_in,
                       int32_t w_in, int32_t c_in, int32_t c_out, int32_t stride, int32_t relu, int32_t terms, void* stream) {
     if (!x_dev || !w3_dev || !bias_dev || !out_dev || batch <= 0 || h_in <= 0 || w_in <= 0 || stride < 1 || c_in <= 0 || c_out <= 0 ||

@@ -260,6 +260,8 @@ hipError_t launch_gemm_f32x3_bias_act(const float* A, const unsigned short* W3, 
 hipError_t launch_gemm2_f32x3_bias_act(const float* A1, int K1, const float* A2, int K2, int batch, int hi, int wi, int stride,
                                        const unsigned short* W3, const float* bias, float* out, int N, int relu, int terms,
                                        hipStream_t st, const float* a_bias);
+hipError_t launch_convrows_f32x3(const float* x, int batch, int hp, int wp, int pix, int ho, int wo, int stride, int ntaps, int tap_floats,
+                                 const unsigned short* W3, const float* bias, float* out, int N, int relu, int terms, hipStream_t st);
 hipError_t launch_conv3x3_f32x3(const float* x, int batch, int hi, int wi, int C, int stride, const unsigned short* W3,
                                 const float* bias, float* out, int N, int relu, int terms, hipStream_t st);
 hipError_t launch_gemm_f32_bias_act(const float* A, const float* W, const float* bias, const float* res, float* out,

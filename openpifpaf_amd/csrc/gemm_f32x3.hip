@@ -72,7 +72,9 @@ struct X3Second {
     const float* A2;           // [B, hi, wi, K - K1] channels-last, or null
     int K1;                    // columns of the first activation (a multiple of the K-step)
     int ho_wo, wo, hi_wi, wi, stride;
-    int hi, C, batch;          // (SRC = 2) input rows, channels per tap, images
+    int hi, C, batch;          // (SRC = 2) input rows, floats per tap (a multiple of the K-step), images
+    int pix, taps_x, ntaps, padded;   // (SRC = 2) floats per input pixel; taps per window row; taps; 1: the input is padded in
+                               // memory (window origin = (stride oy, stride ox), every tap valid), 0: padding 1 by the tap mask
 };
 
 template <int BN, bool RES, bool RELU, bool PRO, int TERMS, int SRC>
@@ -132,8 +134,9 @@ __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
     const int KA = TWO ? sec.K1 : TAPS ? sec.C : K;          // row length of the first activation
     // (TAPS: the whole tensor, from wi + 1 pixels BEFORE its start -- the window of output pixel (oy, ox) begins at input pixel
     //  (stride oy - 1, stride ox - 1); what lies before the tensor is only ever asked for by rows whose tap bit is clear)
-    const float* a1_base = TAPS ? A - (size_t)(sec.wi + 1) * KA : A + (size_t)m0 * KA;
-    const int a1_bytes = TAPS ? (int)(((size_t)sec.batch * sec.hi_wi + sec.wi + 1) * KA * 4) : (int)((size_t)rows_here * KA * 4);
+    const int shift = TAPS && !sec.padded ? (sec.wi + 1) * sec.pix : 0;
+    const float* a1_base = TAPS ? A - (size_t)shift : A + (size_t)m0 * KA;
+    const int a1_bytes = TAPS ? (int)(((size_t)sec.batch * sec.hi_wi * sec.pix + shift) * 4) : (int)((size_t)rows_here * KA * 4);
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a1_base), 0, a1_bytes, 0x00020000);
     // the second activation: its rows are the input pixels the tile's output pixels read (monotonic in m: offsets from the first)
     const int K2 = K - KA;
@@ -164,13 +167,14 @@ __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
         vmask[p] = 0u;
         if constexpr (TAPS) {
             const int b = m / sec.ho_wo, r = m - b * sec.ho_wo, oy = r / sec.wo, ox = r - oy * sec.wo;
-            pa[p] = (unsigned)((long long)b * sec.hi_wi + (long long)oy * sec.stride * sec.wi + (long long)ox * sec.stride) * (unsigned)KA * 4u
+            pa[p] = (unsigned)((long long)b * sec.hi_wi + (long long)oy * sec.stride * sec.wi + (long long)ox * sec.stride) * (unsigned)sec.pix * 4u
                     + (unsigned)s_col * 4u;
-#pragma unroll
-            for (int t = 0; t < 9; t++) {
-                const int iy = oy * sec.stride - 1 + t / 3, ix = ox * sec.stride - 1 + t % 3;
-                if (iy >= 0 && iy < sec.hi && ix >= 0 && ix < sec.wi) vmask[p] |= 1u << t;
-            }
+            if (sec.padded) vmask[p] = 0xffffffffu;
+            else
+                for (int t = 0; t < sec.ntaps; t++) {
+                    const int iy = oy * sec.stride - 1 + t / sec.taps_x, ix = ox * sec.stride - 1 + t % sec.taps_x;
+                    if (iy >= 0 && iy < sec.hi && ix >= 0 && ix < sec.wi) vmask[p] |= 1u << t;
+                }
         }
         if constexpr (TWO) pa2[p] = ((unsigned)(in_row(m) - row0_2) * (unsigned)K2 + (unsigned)s_col) * 4u;
     }
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
     auto fetch_a = [&](f32x4_t (&ra)[NPA], int k0) {      // global -> registers for K-step k0 (with the operand prologue)
         if constexpr (TAPS) {                  // tap t = k0 / C: a uniform shift of every row's window origin
             const int t = k0 / KA, kc = k0 - t * KA;
-            const int soff = (((t / 3) * sec.wi + t % 3) * KA + kc) * 4;
+            const int soff = (((t / sec.taps_x) * sec.wi + t % sec.taps_x) * sec.pix + kc) * 4;
 #pragma unroll
             for (int p = 0; p < NPA; p++)
                 ra[p] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (vmask[p] >> t) & 1u ? pa[p] : 0xFFFFFFF0u, soff, 0));
@@ -379,6 +383,7 @@ static hipError_t launch_x3_terms(const float* A, const unsigned short* W3, cons
 hipError_t launch_gemm_f32x3_bias_act(const float* A, const unsigned short* W3, const float* bias, const float* res, float* out,
                                       int M, int N, int K, int relu, int terms, hipStream_t st, const float* a_bias) {
     X3Second none; none.A2 = nullptr; none.K1 = K; none.ho_wo = none.wo = none.hi_wi = none.wi = none.stride = 1; none.hi = 1; none.C = 0; none.batch = 1;
+    none.pix = 1; none.taps_x = 1; none.ntaps = 1; none.padded = 0;
     if (terms == 6) return launch_x3_terms<6>(A, W3, bias, res, out, M, N, K, relu, st, a_bias, none);
     return launch_x3_terms<9>(A, W3, bias, res, out, M, N, K, relu, st, a_bias, none);
 }
@@ -389,7 +394,7 @@ hipError_t launch_gemm2_f32x3_bias_act(const float* A1, int K1, const float* A2,
                                        hipStream_t st, const float* a_bias) {
     const int ho = (hi - 1) / stride + 1, wo = (wi - 1) / stride + 1;
     X3Second sec; sec.A2 = A2; sec.K1 = K1; sec.ho_wo = ho * wo; sec.wo = wo; sec.hi_wi = hi * wi; sec.wi = wi; sec.stride = stride;
-    sec.hi = hi; sec.C = 0; sec.batch = batch;
+    sec.hi = hi; sec.C = 0; sec.batch = batch; sec.pix = 1; sec.taps_x = 1; sec.ntaps = 1; sec.padded = 0;
     const int M = batch * ho * wo, K = K1 + K2;
     if (terms == 6) return launch_x3_terms<6>(A1, W3, bias, nullptr, out, M, N, K, relu, st, a_bias, sec);
     return launch_x3_terms<9>(A1, W3, bias, nullptr, out, M, N, K, relu, st, a_bias, sec);
@@ -401,8 +406,21 @@ hipError_t launch_conv3x3_f32x3(const float* x, int batch, int hi, int wi, int C
                                 const float* bias, float* out, int N, int relu, int terms, hipStream_t st) {
     const int ho = (hi - 1) / stride + 1, wo = (wi - 1) / stride + 1;
     X3Second sec; sec.A2 = nullptr; sec.K1 = C; sec.ho_wo = ho * wo; sec.wo = wo; sec.hi_wi = hi * wi; sec.wi = wi; sec.stride = stride;
-    sec.hi = hi; sec.C = C; sec.batch = batch;
+    sec.hi = hi; sec.C = C; sec.batch = batch; sec.pix = C; sec.taps_x = 3; sec.ntaps = 9; sec.padded = 0;
     const int M = batch * ho * wo, K = 9 * C;
+    if (terms == 6) return launch_x3_terms<6>(x, W3, bias, nullptr, out, M, N, K, relu, st, nullptr, sec);
+    return launch_x3_terms<9>(x, W3, bias, nullptr, out, M, N, K, relu, st, nullptr, sec);
+}
+
+// A convolution whose window ROWS are the taps: x [B, hp, wp, pix] is padded in memory (pix floats per pixel), output pixel
+// (oy, ox) reads, for tap t, the `tap_floats` contiguous floats that begin at input pixel (stride oy + t, stride ox) -- the 7x7
+// stride-2 stem of a ResNet on a 4-channel copy of the image: 8 taps of 8 pixels x 4 channels (the eighth row and column and the
+// fourth channel meet zero weights).  W3 [3][N][ntaps * tap_floats].  out [B, ho, wo, N].
+hipError_t launch_convrows_f32x3(const float* x, int batch, int hp, int wp, int pix, int ho, int wo, int stride, int ntaps, int tap_floats,
+                                 const unsigned short* W3, const float* bias, float* out, int N, int relu, int terms, hipStream_t st) {
+    X3Second sec; sec.A2 = nullptr; sec.K1 = tap_floats; sec.ho_wo = ho * wo; sec.wo = wo; sec.hi_wi = hp * wp; sec.wi = wp; sec.stride = stride;
+    sec.hi = hp; sec.C = tap_floats; sec.batch = batch; sec.pix = pix; sec.taps_x = 1; sec.ntaps = ntaps; sec.padded = 1;
+    const int M = batch * ho * wo, K = ntaps * tap_floats;
     if (terms == 6) return launch_x3_terms<6>(x, W3, bias, nullptr, out, M, N, K, relu, st, nullptr, sec);
     return launch_x3_terms<9>(x, W3, bias, nullptr, out, M, N, K, relu, st, nullptr, sec);
 }

@@ -243,6 +243,43 @@ def conv3x3_bias_act_x3(conv, x, bias, relu=True):
     return out
 
 
+# ... and the 7x7 stride-2 stem (OPA_GEMM3_STEM=0: off)
+X3_STEM = os.environ.get('OPA_GEMM3_STEM', '1') != '0'
+
+
+def stem_x3_supported(conv, x, bias):
+    return (X3_STEM and X3_TERMS in (6, 9) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and conv.kernel_size == (7, 7)
+            and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None
+            and conv.in_channels == 3 and x.shape[1] == 3 and conv.out_channels % 64 == 0
+            and bias.dtype == torch.float32 and bias.is_contiguous() and bias.data_ptr() % 16 == 0
+            and x.shape[0] * (x.shape[2] + 7) * (x.shape[3] + 7) * 16 < 2 ** 31)
+
+
+def stem7x7_bias_act_x3(conv, x, bias, relu=True):
+    """``act(conv(x) + bias)`` for the 7x7 stride-2 padding-3 stem of a ResNet on RGB input (reference ``network/basenetworks.py:71-150``)
+    as an implicit GEMM of the split-operand kernel: the image is copied once into a zero-padded 4-channel NHWC tensor (3 pixels
+    before, 4 behind; ~1 % of the step), a window ROW -- 8 pixels x 4 channels = 32 contiguous floats -- is one K-step, the
+    eighth row and column and the fourth channel meet zero weights.  K = 8 x 32 = 256."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    cached = getattr(conv, '_opa_w3_stem', None)
+    if cached is None or cached[0] != key:
+        n = w.shape[0]
+        wp = torch.zeros((n, 8, 8, 4), dtype=torch.float32, device=w.device)
+        wp[:, :7, :7, :3] = w.detach().permute(0, 2, 3, 1)
+        cached = (key, split_weight(wp.reshape(n, 256)))
+        conv._opa_w3_stem = cached
+    B, _, H, W = x.shape
+    xp = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, 1, 3, 4, 3, 4)).contiguous()        # [B, H + 7, W + 7, 4]
+    ho, wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((B, conv.out_channels, ho, wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.check(_lib.lib().opa_conv_rows_f32x3(
+        ctypes.c_void_p(xp.data_ptr()), ctypes.c_void_p(cached[1].data_ptr()), ctypes.c_void_p(bias.data_ptr()),
+        ctypes.c_void_p(out.data_ptr()), B, H + 7, W + 7, 4, ho, wo, 2, 8, 32, conv.out_channels, int(bool(relu)), int(X3_TERMS),
+        ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'opa_conv_rows_f32x3')
+    return out
+
+
 # (dtype, M, K, N, has_residual, has_a_bias) -> 'gemm' | 'gemm3' | 'pass+gemm' | 'conv'.  The three paths round
 # differently, so the choice is part of the result: it is made once per shape (the key holds no device index: a
 # table exported on rank 0 must match the lookups of every other rank), never by timing while a stream is being

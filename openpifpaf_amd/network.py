@@ -179,7 +179,10 @@ class Resnet(BaseNetwork):
 
     def forward(self, x):
         if getattr(self, 'fused', False):
-            x = fused.bias_act_(self.input_block[0](x), self.fb0)
+            if fused.stem_x3_supported(self.input_block[0], x, self.fb0):     # float32: the stem as an implicit GEMM, bias + ReLU inside
+                x = fused.stem7x7_bias_act_x3(self.input_block[0], x, self.fb0)
+            else:
+                x = fused.bias_act_(self.input_block[0](x), self.fb0)
         else:
             x = self.input_block(x)
         return self.block5(self.block4(self.block3(self.block2(x))))

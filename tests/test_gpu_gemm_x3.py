@@ -113,10 +113,10 @@ def test_resnet50_trunk_with_and_without_the_split_operand_kernel():
     network.optimize_for_inference_(net)
     net = net.to(memory_format=torch.channels_last)
     x = torch.randn((2, 3, 193, 161), device='cuda').contiguous(memory_format=torch.channels_last)
-    saved, terms, pair, conv3 = fused.choices(), fused.X3_TERMS, fused.X3_PAIR, fused.X3_CONV3
+    saved, terms, pair, conv3, stem = fused.choices(), fused.X3_TERMS, fused.X3_PAIR, fused.X3_CONV3, fused.X3_STEM
     try:
         fused.X3_TERMS = 6
-        fused.X3_PAIR = fused.X3_CONV3 = False
+        fused.X3_PAIR = fused.X3_CONV3 = fused.X3_STEM = False
         fused.set_choices({k: 'gemm' for k in saved}, replace=True)
         with torch.no_grad():
             fused.set_choices({}, replace=True)
@@ -126,14 +126,14 @@ def test_resnet50_trunk_with_and_without_the_split_operand_kernel():
             forced = {k: 'gemm3' for k, v in fused.choices().items() if k[0] == 'torch.float32' and k[2] % 64 == 0}
             assert forced
             fused.set_choices(forced)
-            fused.X3_PAIR = fused.X3_CONV3 = True                     # ... the blocks' tails with their downsampling convolutions, the strided 3x3
+            fused.X3_PAIR = fused.X3_CONV3 = fused.X3_STEM = True                     # ... the blocks' tails with their downsampling convolutions, the strided 3x3
             b = net(x)
         for u, v in zip(a, b):
             assert float((u - v).abs().max()) <= 1e-4 * float(u.abs().max()), float((u - v).abs().max())
         assert not all(torch.equal(u, v) for u, v in zip(a, b))      # (another kernel did run)
     finally:
         os.environ.pop('OPA_CONV1X1', None)
-        fused.X3_TERMS, fused.X3_PAIR, fused.X3_CONV3 = terms, pair, conv3
+        fused.X3_TERMS, fused.X3_PAIR, fused.X3_CONV3, fused.X3_STEM = terms, pair, conv3, stem
         fused.set_choices(saved, replace=True)
 
 
@@ -156,3 +156,23 @@ def test_strided_3x3_convolution_as_implicit_gemm(c, n, h, w, stride):
     # (measured: 0.4-1.4 x the error of whatever algorithm MIOpen picks for the shape; float32-grade either way)
     assert e_got <= 2.0 * e_theirs + 1e-9 and e_got < 1e-7, (e_got, e_theirs)
     assert float((got.double() - ref).abs().max()) / float(ref.abs().max()) < 2e-6
+
+
+@pytest.mark.parametrize('h,w,n', [(641, 641, 64), (321, 193, 64), (37, 52, 128)])
+def test_resnet_stem_as_implicit_gemm(h, w, n):
+    """``opa_conv_rows_f32x3`` through ``fused.stem7x7_bias_act_x3``: the 7x7 stride-2 padding-3 convolution on RGB input."""
+    from openpifpaf_amd import fused
+    torch.manual_seed(17)
+    x = torch.randn(2, 3, h, w, device='cuda')
+    conv = torch.nn.Conv2d(3, n, 7, 2, 3, bias=False).cuda()
+    bias = torch.randn(n, device='cuda') * 0.1
+    with torch.no_grad():
+        for xin in (x, x.contiguous(memory_format=torch.channels_last)):
+            assert fused.stem_x3_supported(conv, xin, bias)
+            got = fused.stem7x7_bias_act_x3(conv, xin, bias, True)
+            ref = (torch.nn.functional.conv2d(x.double(), conv.weight.double(), stride=2, padding=3) + bias.double().view(1, -1, 1, 1)).clamp_(min=0)
+            theirs = torch.relu(conv(xin) + bias.view(1, -1, 1, 1))
+            assert tuple(got.shape) == tuple(ref.shape) and got.is_contiguous(memory_format=torch.channels_last)
+            e_got, e_theirs = _rms(got, ref), _rms(theirs, ref)
+            assert e_got <= 2.0 * e_theirs + 1e-9 and e_got < 1e-7, (e_got, e_theirs)
+            assert float((got.double() - ref).abs().max()) / float(ref.abs().max()) < 2e-6
