@@ -15,7 +15,13 @@
 // (six: 0.375).  The split costs ~5.5 VALU instructions per operand element, once per element and tile: the weight is
 // split on the host, once ([3][N][K] bf16, openpifpaf_amd.fused.split_weight), the activation while its tile is staged.
 // Error against a float64 product: tests/test_gpu_gemm_x3.py, tools/gpu/gemm_x3_probe.py (both variants next to
-// gemm_f32.hip's float32 MFMA and torch's float32 convolution).
+// gemm_f32.hip's float32 MFMA and torch's float32 convolution): six terms 2.4-2.8x BELOW the float32 MFMA's.
+// Measured (profiles/r6/gemm_x3_probe.log, gemm_x3_pmc.log): 0.62 ms against 0.93 on the layer-3 reduce shape; the kernel is
+// POWER-limited -- the clock falls to 1.8 GHz and the bf16 MFMA sustains 1.0e9 busy cycles per second per SIMD with six and with
+// nine terms alike, so MFMA time adds to the launch however well the rest overlaps.
+// The same kernel takes a SECOND activation along K (SRC = 1: a block's last 1x1 convolution + its downsampling convolution as
+// one product) or NINE / EIGHT shifted views of one activation (SRC = 2: strided 3x3 convolutions and the 7x7 stem as implicit
+// GEMMs; padding through out-of-range buffer offsets).
 //
 // Tile 128 x BN (BN = 128 | 64) per 256-thread workgroup, BK = 32; 4 waves as 2(M) x 2(N), a wave 64 x BN/2 of 32x32
 // blocks; operands K-major in LDS, three bf16 planes each, row pitch 40 bf16 = 80 B (ds_read_b128 fragments of 16
