@@ -153,6 +153,28 @@ def _split_weight_of(conv, w2d):
     return cached[1]
 
 
+FORCE_PICK = os.environ.get('OPA_GEMM3_PICK') or None        # 'x3' | 'conv': every pick() takes that side (tests, A/B)
+
+
+def pick(kind, m, k, n, flag_a, flag_b, run_x3, run_other):
+    """One of two ways to compute the same tensor -- a split-operand kernel (``run_x3``) or what the trunk did before
+    (``run_other``: MIOpen's convolution + the fused passes) -- chosen ONCE per shape like ``conv_bias_act`` chooses its GEMM: from
+    the shipped table (``conv1x1_pinned.json``, key dtype ``'torch.float32/<kind>'``), else by timing both on the first call; while
+    a stream is being captured or in a job of several ranks, where timing is not an option, by size (the split-operand kernels win
+    from ~16 000 output pixels: a batch of one 641-px image keeps MIOpen in layers 3-4).  Returns the chosen function's result."""
+    if FORCE_PICK in ('x3', 'conv'):
+        return run_x3() if FORCE_PICK == 'x3' else run_other()
+    key = ('torch.float32/' + kind, int(m), int(k), int(n), bool(flag_a), bool(flag_b))
+    choice = _CHOICE.get(key)
+    if choice is None:
+        if torch.cuda.is_current_stream_capturing() or _in_multi_rank_job():
+            choice = 'x3' if m >= 16384 else 'conv'
+        else:
+            choice = 'x3' if _time_ms(run_x3) <= _time_ms(run_other) else 'conv'
+        _CHOICE[key] = choice
+    return run_x3() if choice == 'x3' else run_other()
+
+
 # ... and the block's LAST 1x1 convolution together with its downsampling convolution as one product (OPA_GEMM3_PAIR=0: off)
 X3_PAIR = os.environ.get('OPA_GEMM3_PAIR', '1') != '0'
 

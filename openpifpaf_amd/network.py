@@ -71,21 +71,29 @@ class _Bottleneck(nn.Module):
             if wino:
                 out = winograd.conv3x3(out, u, self.conv2.out_channels, bias=self.fb2, relu=True, variant=winograd.DEFAULT_VARIANT)
             elif fused.conv3x3_x3_supported(self.conv2, out, self.fb2):  # ... float32 strided: implicit GEMM of the split-operand kernel
-                out = fused.conv3x3_bias_act_x3(self.conv2, out, self.fb2, True)
+                h = out                                                   # (or MIOpen + the epilogue pass, whichever is faster for the shape)
+                s = self.conv2.stride[0]
+                out = fused.pick('conv3', h.shape[0] * ((h.shape[2] - 1) // s + 1) * ((h.shape[3] - 1) // s + 1), 9 * h.shape[1],
+                                 self.conv2.out_channels, s > 1, False,
+                                 lambda: fused.conv3x3_bias_act_x3(self.conv2, h, self.fb2, True),
+                                 lambda: fused.bias_act_(self.conv2(h), self.fb2))
                 wino = True                                               # (bias + ReLU applied: nothing left for the next operand)
             else:
                 out = self.conv2(out)                                     # ... bfloat16: MIOpen, raw output ...
+            a_bias = None if wino else self.fb2
+
+            def two_launches():
+                identity = x if self.downsample is None else self.downsample[0](x)
+                # (a_bias: conv2's bias + ReLU applied by the 1x1 GEMM while it stages its operand)
+                return fused.conv_bias_act(self.conv3, out, self.fb3, identity, a_bias=a_bias)
             # a block WITH a downsampling convolution, float32: conv3(out) + downsample(x) as ONE product (the identity tensor
-            # is never written), conv2's bias + ReLU applied to the operand where conv2 left them out
-            if self.downsample is not None and fused.pair_supported(self.conv3, self.downsample[0], out, x, self.fb3,
-                                                                    None if wino else self.fb2):
-                return fused.conv1x1_pair_bias_act_x3(self.conv3, self.downsample[0], out, x, self.fb3, True,
-                                                      None if wino else self.fb2)
-            identity = x if self.downsample is None else self.downsample[0](x)
-            if wino:
-                return fused.conv_bias_act(self.conv3, out, self.fb3, identity)
-            # ... whose bias + ReLU is applied by the 1x1 GEMM below while it stages its operand
-            return fused.conv_bias_act(self.conv3, out, self.fb3, identity, a_bias=self.fb2)
+            # is never written), conv2's bias + ReLU applied to the operand where conv2 left them out -- where that is faster
+            if self.downsample is not None and fused.pair_supported(self.conv3, self.downsample[0], out, x, self.fb3, a_bias):
+                return fused.pick('pair', out.shape[0] * out.shape[2] * out.shape[3], self.conv3.in_channels + self.downsample[0].in_channels,
+                                  self.conv3.out_channels, self.downsample[0].stride[0] > 1, a_bias is not None,
+                                  lambda: fused.conv1x1_pair_bias_act_x3(self.conv3, self.downsample[0], out, x, self.fb3, True, a_bias),
+                                  two_launches)
+            return two_launches()
         identity = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
@@ -180,7 +188,10 @@ class Resnet(BaseNetwork):
     def forward(self, x):
         if getattr(self, 'fused', False):
             if fused.stem_x3_supported(self.input_block[0], x, self.fb0):     # float32: the stem as an implicit GEMM, bias + ReLU inside
-                x = fused.stem7x7_bias_act_x3(self.input_block[0], x, self.fb0)
+                conv, x0 = self.input_block[0], x
+                x = fused.pick('stem', x0.shape[0] * ((x0.shape[2] - 1) // 2 + 1) * ((x0.shape[3] - 1) // 2 + 1), 256, conv.out_channels,
+                               True, False, lambda: fused.stem7x7_bias_act_x3(conv, x0, self.fb0),
+                               lambda: fused.bias_act_(conv(x0), self.fb0))
             else:
                 x = fused.bias_act_(self.input_block[0](x), self.fb0)
         else:

@@ -113,7 +113,7 @@ def test_resnet50_trunk_with_and_without_the_split_operand_kernel():
     network.optimize_for_inference_(net)
     net = net.to(memory_format=torch.channels_last)
     x = torch.randn((2, 3, 193, 161), device='cuda').contiguous(memory_format=torch.channels_last)
-    saved, terms, pair, conv3, stem = fused.choices(), fused.X3_TERMS, fused.X3_PAIR, fused.X3_CONV3, fused.X3_STEM
+    saved, terms, pair, conv3, stem, force = fused.choices(), fused.X3_TERMS, fused.X3_PAIR, fused.X3_CONV3, fused.X3_STEM, fused.FORCE_PICK
     try:
         fused.X3_TERMS = 6
         fused.X3_PAIR = fused.X3_CONV3 = fused.X3_STEM = False
@@ -126,6 +126,7 @@ def test_resnet50_trunk_with_and_without_the_split_operand_kernel():
             forced = {k: 'gemm3' for k, v in fused.choices().items() if k[0] == 'torch.float32' and k[2] % 64 == 0}
             assert forced
             fused.set_choices(forced)
+            fused.FORCE_PICK = 'x3'
             fused.X3_PAIR = fused.X3_CONV3 = fused.X3_STEM = True                     # ... the blocks' tails with their downsampling convolutions, the strided 3x3
             b = net(x)
         for u, v in zip(a, b):
@@ -133,7 +134,7 @@ def test_resnet50_trunk_with_and_without_the_split_operand_kernel():
         assert not all(torch.equal(u, v) for u, v in zip(a, b))      # (another kernel did run)
     finally:
         os.environ.pop('OPA_CONV1X1', None)
-        fused.X3_TERMS, fused.X3_PAIR, fused.X3_CONV3, fused.X3_STEM = terms, pair, conv3, stem
+        fused.X3_TERMS, fused.X3_PAIR, fused.X3_CONV3, fused.X3_STEM, fused.FORCE_PICK = terms, pair, conv3, stem, force
         fused.set_choices(saved, replace=True)
 
 
