@@ -416,3 +416,31 @@ def test_split_weight_is_exact_on_the_cpu():
     assert w3.dtype == torch.bfloat16 and tuple(w3.shape) == (3, 64, 128)
     assert torch.equal((w3[0].float() + w3[1].float()) + w3[2].float(), w)
     assert float(w3[1].float().abs().max() / w.abs().max()) < 2.0 ** -7 and float((w3[2].float().abs() / w.abs().clamp_min(1e-30)).max()) < 2.0 ** -15
+
+
+def test_pick_takes_the_pinned_choice_without_timing(monkeypatch):
+    """``fused.pick`` (the pair / strided-3x3 / stem paths of the float32 trunk): the shipped table decides without a measurement,
+    an unknown shape is decided by size where timing is not possible (several ranks), and ``FORCE_PICK`` overrides both."""
+    pytest.importorskip('torch')
+    from openpifpaf_amd import fused
+    table = fused.choices()
+    kinds = {k[0] for k in table if k[0].startswith('torch.float32/')}
+    assert kinds == {'torch.float32/pair', 'torch.float32/conv3', 'torch.float32/stem'}, kinds
+    assert table[('torch.float32/stem', 3297312, 256, 64, True, False)] == 'x3'            # the bench's batch of 32 at 641 px
+    assert table[('torch.float32/conv3', 1681, 4608, 512, True, False)] == 'conv'          # one image, layer 4: MIOpen
+
+    def no_timing(fn, reps=3):
+        raise AssertionError('timed')
+    monkeypatch.setattr(fused, '_time_ms', no_timing)
+    monkeypatch.setattr(fused.torch.cuda, 'is_current_stream_capturing', lambda: False)
+    assert fused.pick('stem', 3297312, 256, 64, True, False, lambda: 'x3', lambda: 'other') == 'x3'
+    assert fused.pick('conv3', 1681, 4608, 512, True, False, lambda: 'x3', lambda: 'other') == 'other'
+    monkeypatch.setattr(fused, '_in_multi_rank_job', lambda: True)
+    saved = fused.choices()
+    try:
+        assert fused.pick('pair', 999999, 192, 256, False, False, lambda: 'x3', lambda: 'other') == 'x3'       # by size
+        assert fused.pick('pair', 999, 192, 256, False, False, lambda: 'x3', lambda: 'other') == 'other'
+        monkeypatch.setattr(fused, 'FORCE_PICK', 'conv')
+        assert fused.pick('stem', 3297312, 256, 64, True, False, lambda: 'x3', lambda: 'other') == 'other'
+    finally:
+        fused.set_choices(saved, replace=True)
