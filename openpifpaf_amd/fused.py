@@ -265,6 +265,38 @@ def conv3x3_bias_act_x3(conv, x, bias, relu=True):
     return out
 
 
+# ... and the heads' 1x1 convolutions, whose output channels are no multiple of the kernel's 64-wide tile (OPA_GEMM3_HEAD=0: off)
+X3_HEAD = os.environ.get('OPA_GEMM3_HEAD', '1') != '0'
+
+
+def head_conv_x3_supported(conv, x):
+    return (X3_HEAD and X3_TERMS in (6, 9) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not x.requires_grad
+            and x.is_contiguous(memory_format=torch.channels_last) and conv.kernel_size == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.groups == 1 and conv.in_channels % 64 == 0 and x.shape[1] == conv.in_channels
+            and conv.weight.dtype == torch.float32 and x.data_ptr() % 16 == 0)
+
+
+def head_conv_x3(conv, x):
+    """``conv(x)`` for a head's biased 1x1 convolution (reference ``network/heads.py:272-378``: ``CompositeField4.conv``) through the
+    split-operand GEMM: the output channels are padded to the next multiple of 64 with zero weights, the product is written with
+    that pitch and the real channels are copied out (0.2 GB for both COCO heads at batch 32)."""
+    w = conv.weight
+    n, k = w.shape[0], w.shape[1]
+    npad = (n + 63) // 64 * 64
+    key = (w.data_ptr(), w._version, str(w.device), None if conv.bias is None else conv.bias._version)
+    cached = getattr(conv, '_opa_w3_head', None)
+    if cached is None or cached[0] != key:
+        wp = torch.zeros((npad, k), dtype=torch.float32, device=w.device)
+        wp[:n] = w.detach().reshape(n, k)
+        bp = torch.zeros(npad, dtype=torch.float32, device=w.device)
+        if conv.bias is not None:
+            bp[:n] = conv.bias.detach()
+        cached = (key, split_weight(wp), bp)
+        conv._opa_w3_head = cached
+    out = conv1x1_bias_act_x3(x, cached[1], cached[2], None, False, None, X3_TERMS)
+    return out[:, :n].contiguous(memory_format=torch.channels_last) if npad != n else out
+
+
 # ... and the 7x7 stride-2 stem (OPA_GEMM3_STEM=0: off)
 X3_STEM = os.environ.get('OPA_GEMM3_STEM', '1') != '0'
 

@@ -309,7 +309,12 @@ class CompositeField4(nn.Module):
     fused_epilogue = True      # one HIP kernel for everything behind the convolution (inference, channels_last)
 
     def forward(self, x):
-        x = self.conv(x)
+        if not self.training and fused.head_conv_x3_supported(self.conv, x):     # float32 inference: the head's 1x1 convolution through
+            conv, x0 = self.conv, x                                                # the split-operand GEMM where that is faster
+            x = fused.pick('head', x0.shape[0] * x0.shape[2] * x0.shape[3], conv.in_channels, conv.out_channels, False, False,
+                           lambda: fused.head_conv_x3(conv, x0), lambda: conv(x0))
+        else:
+            x = self.conv(x)
         if self.fused_epilogue and fused.head_epilogue_supported(x, self.meta, self.training):
             return fused.head_epilogue(x, self.meta)
         if self.upsample_op is not None:

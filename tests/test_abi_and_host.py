@@ -425,7 +425,7 @@ def test_pick_takes_the_pinned_choice_without_timing(monkeypatch):
     from openpifpaf_amd import fused
     table = fused.choices()
     kinds = {k[0] for k in table if k[0].startswith('torch.float32/')}
-    assert kinds == {'torch.float32/pair', 'torch.float32/conv3', 'torch.float32/stem'}, kinds
+    assert kinds >= {'torch.float32/pair', 'torch.float32/conv3', 'torch.float32/stem'}, kinds
     assert table[('torch.float32/stem', 3297312, 256, 64, True, False)] == 'x3'            # the bench's batch of 32 at 641 px
     assert table[('torch.float32/conv3', 1681, 4608, 512, True, False)] == 'conv'          # one image, layer 4: MIOpen
 

@@ -177,3 +177,18 @@ def test_resnet_stem_as_implicit_gemm(h, w, n):
             e_got, e_theirs = _rms(got, ref), _rms(theirs, ref)
             assert e_got <= 2.0 * e_theirs + 1e-9 and e_got < 1e-7, (e_got, e_theirs)
             assert float((got.double() - ref).abs().max()) / float(ref.abs().max()) < 2e-6
+
+
+def test_head_convolution_with_padded_output_channels():
+    """``fused.head_conv_x3``: a biased 1x1 convolution whose output channels (340 = 17 x 5 x 4) are no multiple of 64."""
+    from openpifpaf_amd import fused
+    torch.manual_seed(19)
+    x = torch.randn(2, 2048, 21, 23, device='cuda').clamp_(min=0).contiguous(memory_format=torch.channels_last)
+    conv = torch.nn.Conv2d(2048, 340, 1).cuda()
+    with torch.no_grad():
+        assert fused.head_conv_x3_supported(conv, x)
+        got = fused.head_conv_x3(conv, x)
+        ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double())
+        theirs = conv(x)
+    assert tuple(got.shape) == (2, 340, 21, 23) and got.is_contiguous(memory_format=torch.channels_last)
+    assert _rms(got, ref) <= 1.05 * _rms(theirs, ref) + 1e-9 and _rms(got, ref) < 1e-7
