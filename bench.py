@@ -153,8 +153,8 @@ def _conv1x1_text(primary):
         ch = [v for k, v in fused.choices().items() if k[0] == 'torch.float32']
         n3 = sum(1 for v in ch if v == 'gemm3')
         if n3 and fused.X3_TERMS:
-            return ('f32 in/out; %d of %d shapes: operands split exactly into 3 bf16 pieces, %d of the 9 exact partial products on the '
-                    'bf16 MFMA, f32 accumulators (error vs f64 below the f32 MFMA kernel\'s); the rest: f32 MFMA' % (n3, len(ch), fused.X3_TERMS))
+            return ('f32 in/out; %d/%d shapes as 3 exact bf16 pieces x %d of 9 products on the bf16 MFMA, f32 accumulate '
+                    '(error vs f64 < f32 MFMA\'s: f32_check); rest f32 MFMA' % (n3, len(ch), fused.X3_TERMS))
     except Exception:          # noqa: BLE001
         pass
     return 'f32 MFMA GEMM, fused epilogue'
