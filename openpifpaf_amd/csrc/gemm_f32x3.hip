@@ -24,8 +24,10 @@
 // GEMMs; padding through out-of-range buffer offsets).
 //
 // Tile 128 x BN (BN = 128 | 64) per 256-thread workgroup, BK = 32; 4 waves as 2(M) x 2(N), a wave 64 x BN/2 of 32x32
-// blocks; operands K-major in LDS, three bf16 planes each, row pitch 40 bf16 = 80 B (ds_read_b128 fragments of 16
-// consecutive rows fall on 16 different 16-byte bank groups); XCD-aware tile order and epilogue as in gemm_f32.hip.
+// blocks; operands K-major in LDS, three bf16 planes each, rows of 64 B whose 16-byte chunks are XOR-swizzled by (row / 4) % 4
+// (ds_read_b128 fragments of 16 consecutive rows fall on 16 different bank groups AND the 8-byte plane stores of the split do
+// not collide: with rows padded to 80 B a third of the LDS cycles were store conflicts; profiles/r6/gemm_x3_swizzle_ab.log:
+// 2-7 % on the reduce shapes); XCD-aware tile order and epilogue as in gemm_f32.hip.
 #include "common.hpp"
 
 namespace opa {
@@ -48,7 +50,15 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 #ifndef OPA_X3_ONE_ACC             // 1: the corrections go to the leading products' accumulators (64 registers less)
 #define OPA_X3_ONE_ACC 0
 #endif
-constexpr int kX3BM = 128, kX3BK = OPA_X3_BK, kX3Pitch = kX3BK + 8;      // LDS row pitch in bf16
+#ifndef OPA_X3_SWIZZLE             // 1: LDS rows without padding, the 16-byte chunks of a row XOR-swizzled by (row / 4) % 4: fragment
+#define OPA_X3_SWIZZLE 1           //    reads of 16 consecutive rows AND the 8-byte plane stores of the split fall on distinct banks
+#endif                             //    (0: rows 80 bytes apart -- the stores collide two-way, a third of the LDS cycles, profiles/r6/gemm_x3_pmc.log)
+constexpr int kX3BM = 128, kX3BK = OPA_X3_BK, kX3Pitch = OPA_X3_SWIZZLE ? kX3BK : kX3BK + 8;      // LDS row pitch in bf16
+// bf16 offset of element k (a multiple of 4) of row `row` in a plane
+__device__ __forceinline__ int x3_lds(int row, int k) {
+    if (OPA_X3_SWIZZLE && kX3BK == 32) return row * kX3Pitch + ((((k >> 3) ^ (row >> 2)) & 3) << 3) + (k & 7);
+    return row * kX3Pitch + k;
+}
 
 // four float32 -> their three bf16 pieces, packed pairwise (element e in the low half of word e / 2 ... K-major order)
 __device__ __forceinline__ void split4(const f32x4_t a, u32x2_t& p1, u32x2_t& p2, u32x2_t& p3) {
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
         const int v = t * 256 + tid < WTOT ? t * 256 + tid : WTOT - 1;     // (a thread without a vector of its own repeats the last one)
         const int plane = v / (BN * WQ), rem = v - plane * (BN * WQ), row = rem / WQ, c = (rem % WQ) * 8;
         pb[t] = (((unsigned)plane * (unsigned)N + (unsigned)row) * (unsigned)K + (unsigned)c) * 2u;
-        sb_off[t] = plane * LDS_B + row * kX3Pitch + c;
+        sb_off[t] = plane * LDS_B + x3_lds(row, c);
     }
     auto fetch_a = [&](f32x4_t (&ra)[NPA], int k0) {      // global -> registers for K-step k0 (with the operand prologue)
         if constexpr (TAPS) {                  // tap t = k0 / C: a uniform shift of every row's window origin
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
             u32x2_t p1, p2, p3;
             if (OPA_X3_DIAG == 1) { p1[0] = __float_as_uint(ra[p][0]); p1[1] = __float_as_uint(ra[p][2]); p2 = p1; p3 = p1; }
             else split4(ra[p], p1, p2, p3);
-            unsigned short* d = sA + (p * RPP + s_row) * kX3Pitch + s_col;
+            unsigned short* d = sA + x3_lds(p * RPP + s_row, s_col);
             *reinterpret_cast<u32x2_t*>(d) = p1;
             *reinterpret_cast<u32x2_t*>(d + LDS_A) = p2;
             *reinterpret_cast<u32x2_t*>(d + 2 * LDS_A) = p3;
@@ -256,10 +266,10 @@ __global__ __launch_bounds__(256, OPA_X3_WGS) void gemm_f32x3_bias_act_kernel(
             for (int pl = 0; pl < 3; pl++) {
 #pragma unroll
                 for (int i = 0; i < 2; i++)
-                    fa[pl][i] = *reinterpret_cast<const bf16x8_t*>(sA + pl * LDS_A + (wm * 64 + i * 32 + (lane & 31)) * kX3Pitch + kof);
+                    fa[pl][i] = *reinterpret_cast<const bf16x8_t*>(sA + pl * LDS_A + x3_lds(wm * 64 + i * 32 + (lane & 31), kof));
 #pragma unroll
                 for (int j = 0; j < NT; j++)
-                    fb[pl][j] = *reinterpret_cast<const bf16x8_t*>(sB + pl * LDS_B + (wn * WN + j * 32 + (lane & 31)) * kX3Pitch + kof);
+                    fb[pl][j] = *reinterpret_cast<const bf16x8_t*>(sB + pl * LDS_B + x3_lds(wn * WN + j * 32 + (lane & 31), kof));
             }
             // consecutive MFMAs go to different accumulators (a dependent MFMA waits for its predecessor's passes)
 #pragma unroll
